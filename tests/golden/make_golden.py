@@ -1,0 +1,221 @@
+"""Generates tests/golden/*.pt by running the REAL reference (/root/reference, imported under
+oracle/ref_shims.py) on CPU in fp32.  Build-container only (the reference cannot travel); the
+resulting fixtures are committed.  Re-run:  python tests/golden/make_golden.py
+
+Each fixture: dict(case=<ctor kwargs / options>, shapes={state_dict key: shape}, seed, inputs,
+outputs(loss / logits / grad digests)).  Parameter VALUES are re-synthesised from (shapes, seed)
+by tests/golden/common.py on both sides.
+
+Cases with num_residual_streams > 1 execute the reference's own code around the RESTATED
+hyper-connections module (third-party, not vendored) -> labelled restated=True.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+from common import synth_state_dict, grad_digest  # noqa: E402
+
+warnings.filterwarnings('ignore')
+A, S, AT = ref_shims.load_reference()
+
+
+class _Codec:   # the wrappers dereference codec.rq_groups / num_quantizers unconditionally (audiolm_pytorch.py:1598, 1877-1881)
+    rq_groups = 1
+
+    def __init__(self, num_quantizers=8):
+        self.num_quantizers = num_quantizers
+
+
+def _shapes(sd):
+    return {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def _forgetful(shape, prob, seed):
+    g = torch.Generator().manual_seed(seed)
+    seq = shape[-1]
+    rand = torch.randn(shape, generator=g)
+    rand[:, 0] = -torch.finfo(rand.dtype).max
+    num_mask = min(int(seq * prob), seq - 1)
+    idx = rand.topk(num_mask, dim=-1).indices
+    return ~torch.zeros(shape).scatter(1, idx, 1.).bool()
+
+
+def _run(model, wrapper, wrapper_kwargs, training, mask):
+    """forward(return_loss=True) + backward on the real reference.  `mask` replaces the RNG draw."""
+    wrapper.train(training)
+    model.zero_grad(set_to_none=True)
+    orig = A.generate_mask_with_prob
+    seen = {}
+
+    def fake(shape, prob, device):
+        seen['shape'] = tuple(shape)
+        assert mask is not None and tuple(mask.shape) == tuple(shape), (mask is None, shape)
+        return mask.clone()
+
+    A.generate_mask_with_prob = fake
+    hook = model.register_forward_hook(lambda m, a, out: seen.__setitem__('logits', out))
+    try:
+        loss = wrapper(**wrapper_kwargs, return_loss=True)
+    finally:
+        A.generate_mask_with_prob = orig
+        hook.remove()
+    logits = seen['logits']
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    return loss.detach(), logits, grads
+
+
+def semantic_case(name, *, ctor, ids, training=True, unique_consecutive=True, mask_prob=0., seed=1, full=True):
+    torch.manual_seed(0)
+    model = A.SemanticTransformer(**ctor)
+    shapes = _shapes(model.state_dict())
+    model.load_state_dict(synth_state_dict(shapes, seed))
+    wrapper = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=unique_consecutive, mask_prob=mask_prob)
+    mask = None
+    if mask_prob > 0 and training:
+        import audiolm_oracle as O
+        inp, _ = O.semantic_wrapper_bookkeeping(ids, model.eos_id, training=training, unique_consecutive=unique_consecutive)
+        mask = _forgetful(tuple(inp.shape), mask_prob, seed + 100)
+    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=ids), training, mask)
+    return dict(name=name, kind='semantic', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
+                options=dict(training=training, unique_consecutive=unique_consecutive, mask_prob=mask_prob),
+                inputs=dict(ids=ids, forgetful_mask=mask),
+                outputs=dict(loss=loss, logits=logits.detach() if full else logits.detach()[:, ::16].clone(),
+                             grads=grad_digest(grads, full)))
+
+
+def coarse_case(name, *, ctor, sem, coarse, training=True, unique_consecutive=True, mask_prob=0., seed=2, full=True):
+    torch.manual_seed(0)
+    model = A.CoarseTransformer(**ctor)
+    shapes = _shapes(model.state_dict())
+    model.load_state_dict(synth_state_dict(shapes, seed))
+    wrapper = A.CoarseTransformerWrapper(transformer=model, codec=_Codec(), unique_consecutive=unique_consecutive, mask_prob=mask_prob)
+    mask = None
+    if mask_prob > 0 and training:
+        import audiolm_oracle as O
+        *_, km = O.coarse_wrapper_bookkeeping(sem, coarse, model.semantic_eos_id, model.coarse_eos_id, training=training,
+                                              unique_consecutive=unique_consecutive)
+        mask = _forgetful(tuple(km.shape), mask_prob, seed + 100)
+    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=sem, coarse_token_ids=coarse), training, mask)
+    sl, cl = logits
+    return dict(name=name, kind='coarse', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
+                options=dict(training=training, unique_consecutive=unique_consecutive, mask_prob=mask_prob),
+                inputs=dict(semantic_token_ids=sem, coarse_token_ids=coarse, forgetful_mask=mask),
+                outputs=dict(loss=loss, semantic_logits=sl.detach(), coarse_logits=cl.detach(), grads=grad_digest(grads, full)))
+
+
+def fine_case(name, *, ctor, coarse, fine, training=True, mask_prob=0., seed=3, full=True):
+    torch.manual_seed(0)
+    model = A.FineTransformer(**ctor)
+    shapes = _shapes(model.state_dict())
+    model.load_state_dict(synth_state_dict(shapes, seed))
+    nq = ctor['num_coarse_quantizers'] + ctor['num_fine_quantizers']
+    wrapper = A.FineTransformerWrapper(transformer=model, codec=_Codec(nq), mask_prob=mask_prob)
+    mask = None
+    if mask_prob > 0 and training:
+        b = coarse.shape[0]
+        mask = _forgetful((b, coarse.reshape(b, -1).shape[1] + fine.reshape(b, -1).shape[1] - 1 + 2), mask_prob, seed + 100)
+    loss, logits, grads = _run(model, wrapper, dict(coarse_token_ids=coarse, fine_token_ids=fine), training, mask)
+    cl, fl = logits
+    return dict(name=name, kind='fine', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
+                options=dict(training=training, mask_prob=mask_prob),
+                inputs=dict(coarse_token_ids=coarse, fine_token_ids=fine, forgetful_mask=mask),
+                outputs=dict(loss=loss, coarse_logits=cl.detach(), fine_logits=fl.detach(), grads=grad_digest(grads, full)))
+
+
+def attend_case():
+    g = torch.Generator().manual_seed(7)
+    b, h, n, d = 2, 4, 37, 16
+    q = torch.randn(b, h, n, d, generator=g)
+    k = torch.randn(b, n, d, generator=g)
+    v = torch.randn(b, n, d, generator=g)
+    mask = torch.rand(b, n, generator=g) > 0.2
+    mask[:, 0] = True
+    bias = torch.randn(h, n, n, generator=g)
+    math_attn = AT.Attend(causal=True, flash=False)
+    flash_attn = AT.Attend(causal=True, flash=True)
+    out = dict(
+        math_plain=math_attn(q, k, v),
+        math_mask=math_attn(q, k, v, mask=mask),
+        math_mask_bias=math_attn(q, k, v, mask=mask, attn_bias=bias),
+        flash_mask=flash_attn(q, k, v, mask=mask),
+        flash_plain=flash_attn(q, k, v),
+    )
+    return dict(name='attend', kind='attend', inputs=dict(q=q, k=k, v=v, mask=mask, bias=bias), outputs=out)
+
+
+def soundstream_case():
+    torch.manual_seed(0)
+    ctor = dict(codebook_size=32, rq_num_quantizers=4, channels=4, codebook_dim=16, use_local_attn=False,
+                strides=(2, 4, 5, 8), target_sample_hz=16000)
+    ss = S.SoundStream(**ctor)
+    full_sd = ss.state_dict()
+    keep = {k: v for k, v in full_sd.items() if k.startswith('encoder.') or k.startswith('rq.')}
+    shapes = _shapes(keep)
+    new = synth_state_dict(shapes, 5)
+    full_sd.update(new)
+    ss.load_state_dict(full_sd)
+    ss.eval()
+    g = torch.Generator().manual_seed(11)
+    wave = torch.randn(2, 320 * 12 + 77, generator=g) * 0.3
+    with torch.no_grad():
+        emb, indices, _ = ss(wave, return_encoded=True)
+        codes = ss.tokenize(wave)
+        x, _ = ss.process_input(wave)
+        enc = ss.encoder(x)
+    return dict(name='soundstream_small', kind='soundstream', ctor=ctor, shapes=shapes, seed=5, restated=True,
+                inputs=dict(wave=wave),
+                outputs=dict(indices=indices, tokenize=codes, encoder_out=enc, quantized=emb))
+
+
+def main():
+    R = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
+    cases = []
+
+    # BASELINE.json configs[0]: SemanticTransformer dim=256 depth=2 seq=256 on CPU
+    cases.append(semantic_case('semantic_cfg0', ctor=dict(dim=256, depth=2, num_semantic_tokens=500),
+                               ids=R(500, (8, 255), 0), unique_consecutive=False, mask_prob=0., full=False))
+    ids = R(6, (4, 24), 1)     # tiny vocab -> consecutive repeats -> ragged after unique_consecutive
+    cases.append(semantic_case('semantic_s1_uc_mask', ctor=dict(dim=64, depth=2, num_semantic_tokens=6, num_residual_streams=1),
+                               ids=ids, unique_consecutive=True, mask_prob=0.15))
+    cases.append(semantic_case('semantic_s4_flash', ctor=dict(dim=64, depth=2, num_semantic_tokens=20, flash_attn=True),
+                               ids=R(20, (3, 17), 2), unique_consecutive=False, mask_prob=0.15))
+
+    cc = dict(dim=64, depth=2, num_semantic_tokens=6, codebook_size=16, num_coarse_quantizers=3)
+    cases.append(coarse_case('coarse_s1_flash_uc_mask', ctor=dict(cc, num_residual_streams=1, flash_attn=True),
+                             sem=R(6, (3, 12), 3), coarse=R(16, (3, 7, 3), 4), unique_consecutive=True, mask_prob=0.15))
+    cases.append(coarse_case('coarse_s4_bias', ctor=dict(cc), sem=R(6, (3, 12), 5), coarse=R(16, (3, 7, 3), 6),
+                             unique_consecutive=False, mask_prob=0.))
+    cases.append(coarse_case('coarse_s4_flash_mask', ctor=dict(cc, flash_attn=True), sem=R(6, (2, 9), 7), coarse=R(16, (2, 5, 3), 8),
+                             unique_consecutive=False, mask_prob=0.15))
+    cases.append(coarse_case('coarse_s1_bias_eval', ctor=dict(cc, num_residual_streams=1), sem=R(6, (2, 9), 9),
+                             coarse=R(16, (2, 5, 3), 10), training=False, unique_consecutive=False))
+
+    fc = dict(dim=64, depth=2, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5)
+    coarse = R(16, (3, 6, 3), 11)
+    coarse[0, -1, -1] = -1      # pad -> excluded from attention keys and from the CE
+    cases.append(fine_case('fine_s1_bias_mask', ctor=dict(fc, num_residual_streams=1), coarse=coarse, fine=R(16, (3, 6, 5), 12),
+                           mask_prob=0.15))
+    cases.append(fine_case('fine_s4_flash', ctor=dict(fc, flash_attn=True), coarse=R(16, (2, 4, 3), 13), fine=R(16, (2, 4, 5), 14)))
+
+    cases.append(attend_case())
+    cases.append(soundstream_case())
+
+    for c in cases:
+        path = os.path.join(HERE, c['name'] + '.pt')
+        torch.save(c, path)
+        print(f'{c["name"]:28s} {os.path.getsize(path) / 1024:8.1f} KiB', 'loss=%s' % (float(c['outputs']['loss']) if 'loss' in c['outputs'] else '-'))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,136 @@
+"""Pins oracle/audiolm_oracle.py (the CPU fp32 restatement) against golden vectors produced by the REAL
+reference (tests/golden/make_golden.py, run in the build container).  CPU only.
+
+Tolerances: fp32 vs fp32 on CPU, same op order up to reassociation -> loss 1e-5 rel, logits 2e-4 abs,
+gradients 1e-4 of the gradient's max-abs.
+"""
+import glob
+import os
+
+import pytest
+import torch
+
+import audiolm_oracle as O
+from common import GOLDEN_DIR, synth_state_dict
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name + '.pt'), weights_only=False)
+
+
+def _cfg(fx):
+    c = fx['ctor']
+    return O.Cfg(dim=c['dim'], depth=c['depth'], heads=c.get('heads', 8), streams=c.get('num_residual_streams', 4),
+                 num_semantic_tokens=c.get('num_semantic_tokens', 0), codebook_size=c.get('codebook_size', 0),
+                 num_coarse_quantizers=c.get('num_coarse_quantizers', 0), num_fine_quantizers=c.get('num_fine_quantizers', 0))
+
+
+def oracle_run(fx):
+    """Runs the oracle on a fixture -> (loss, logits tuple, grads dict)."""
+    sd = synth_state_dict(fx['shapes'], fx['seed'])
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith('.beta')}
+    full = dict(sd)
+    full.update(params)
+    cfg, inp, opt = _cfg(fx), fx['inputs'], fx['options']
+    captured = {}
+    if fx['kind'] == 'semantic':
+        orig = O.semantic_forward
+        O.semantic_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
+        try:
+            loss = O.semantic_wrapper_loss(full, cfg, inp['ids'], training=opt['training'],
+                                           unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'])
+        finally:
+            O.semantic_forward = orig
+        logits = (captured['l'],)
+    elif fx['kind'] == 'coarse':
+        orig = O.coarse_forward
+        O.coarse_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
+        try:
+            loss = O.coarse_wrapper_loss(full, cfg, inp['semantic_token_ids'], inp['coarse_token_ids'], training=opt['training'],
+                                         unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'])
+        finally:
+            O.coarse_forward = orig
+        logits = captured['l']
+    else:
+        orig = O.fine_forward
+        O.fine_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
+        try:
+            loss = O.fine_wrapper_loss(full, cfg, inp['coarse_token_ids'], inp['fine_token_ids'], forgetful_mask=inp['forgetful_mask'])
+        finally:
+            O.fine_forward = orig
+        logits = captured['l']
+    loss.backward()
+    return loss.detach(), logits, {k: p.grad for k, p in params.items()}
+
+
+MODEL_FIXTURES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.pt'))
+                        if os.path.basename(p).split('_')[0] in ('semantic', 'coarse', 'fine'))
+
+
+def test_fixtures_present():
+    assert len(MODEL_FIXTURES) >= 9, MODEL_FIXTURES
+
+
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_oracle_matches_reference(name):
+    fx = _load(name)
+    loss, logits, grads = oracle_run(fx)
+    ref = fx['outputs']
+    assert abs(float(loss) - float(ref['loss'])) <= 1e-5 * max(1.0, abs(float(ref['loss']))), (float(loss), float(ref['loss']))
+    if fx['kind'] == 'semantic':
+        got = logits[0].detach()
+        want = ref['logits']
+        if want.shape != got.shape:             # cfg0 stores a strided subsample
+            got = got[:, ::16]
+        assert torch.allclose(got, want, atol=2e-4, rtol=1e-4), (got - want).abs().max()
+    else:
+        keys = ('semantic_logits', 'coarse_logits') if fx['kind'] == 'coarse' else ('coarse_logits', 'fine_logits')
+        for g, k in zip(logits, keys):
+            assert torch.allclose(g.detach(), ref[k], atol=2e-4, rtol=1e-4), (k, (g.detach() - ref[k]).abs().max())
+    for k, dg in ref['grads'].items():
+        if dg is None:                             # unused parameter in the reference (e.g. proj_text_embed)
+            assert grads.get(k) is None or float(grads[k].abs().max()) == 0.0, k
+            continue
+        g = grads[k]
+        assert g is not None, k
+        flat = g.reshape(-1)
+        scale = max(float(flat.abs().max()), 1e-6)
+        assert abs(float(flat.norm()) - dg['norm']) <= 1e-4 * max(dg['norm'], 1e-6) + 1e-7, (k, float(flat.norm()), dg['norm'])
+        assert float((flat[::dg['stride']] - dg['sample']).abs().max()) <= 1e-4 * scale + 1e-7, k
+        if dg['full'] is not None:
+            assert float((g - dg['full']).abs().max()) <= 1e-4 * scale + 1e-7, k
+
+
+def test_attend_matches_reference():
+    fx = _load('attend')
+    i, o = fx['inputs'], fx['outputs']
+    q, k, v, mask, bias = i['q'], i['k'], i['v'], i['mask'], i['bias']
+    assert torch.allclose(O.attend(q, k, v), o['math_plain'], atol=1e-6)
+    assert torch.allclose(O.attend(q, k, v, mask=mask), o['math_mask'], atol=1e-6)
+    assert torch.allclose(O.attend(q, k, v, mask=mask, attn_bias=bias), o['math_mask_bias'], atol=1e-6)
+    # the reference's flash (SDPA) path computes the same function (attend.py:69-96)
+    assert torch.allclose(O.attend(q, k, v, mask=mask), o['flash_mask'], atol=2e-6)
+    assert torch.allclose(O.attend(q, k, v), o['flash_plain'], atol=2e-6)
+
+
+def test_soundstream_encode_matches_reference():
+    fx = _load('soundstream_small')
+    sd = synth_state_dict(fx['shapes'], fx['seed'])
+    wave = fx['inputs']['wave']
+    c = fx['ctor']
+    n = (wave.shape[-1] // 320) * 320
+    enc = O.soundstream_encoder(sd, wave[:, None, :n], strides=c['strides'])
+    assert torch.allclose(enc, fx['outputs']['encoder_out'], atol=1e-5, rtol=1e-5)
+    idx = O.soundstream_tokenize(sd, wave, strides=c['strides'], num_quantizers=c['rq_num_quantizers'])
+    assert idx.dtype == torch.int64
+    assert torch.equal(idx, fx['outputs']['indices'])                       # (b n (g q))
+    assert torch.equal(idx[None], fx['outputs']['tokenize'])                # tokenize() -> (g b n q), soundstream.py:847-848
+
+
+def test_bookkeeping_helpers_bit_exact():
+    ids = torch.tensor([[1, 1, 2, 2, 2, 3], [4, 4, 4, 4, 4, 4]])
+    uc = O.batch_unique_consecutive(ids, pad_value=-1)
+    assert torch.equal(uc, torch.tensor([[1, 2, 3], [4, -1, -1]]))
+    assert torch.equal(O.append_eos_id(ids, 9)[:, -1], torch.tensor([9, 9]))
+    m = O.generate_mask_with_prob((4, 20), 0.15, 'cpu')
+    assert m.dtype == torch.bool and bool(m[:, 0].all()) and int((~m).sum()) == 4 * 3
