@@ -1,0 +1,96 @@
+"""ctypes binding of libaudiolm_hip.so (C ABI declared in include/audiolm_hip.h).
+
+This is the reference-side binding a maintainer would add.  There is NO fallback: if the shared
+library is missing / cannot be built the import fails loudly, and every op refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libaudiolm_hip.so')
+
+_P, _I, _L, _F = c_void_p, c_int, c_longlong, c_float
+
+# name -> argtypes (all return int).  Kept in sync with include/audiolm_hip.h (tests/test_cabi.py checks both directions).
+SIGNATURES = {
+    'alm_gemm_bf16_nt': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _P],
+    'alm_transpose_bf16': [_P, _P, _I, _I, _L, _L, _I, _P],
+    'alm_pack_weight': [_P, _I, _I, _L, _P, _L, _I, _I, _P, _L, _P],
+    'alm_ln_partial_blocks': [_I],
+    'alm_layernorm_fwd': [_P, _I, _L, _P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
+    'alm_layernorm_bwd': [_P, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
+    'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P],
+    'alm_geglu_partial_blocks': [_I],
+    'alm_geglu_ln_fwd': [_P, _L, _I, _P, _P, _L, _P, _P, _I, _I, _I, _P],
+    'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
+    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
+    'alm_value_residual_mix': [_P, _L, _P, _L, _P, _L, _L, _I, _P],
+    'alm_kv_grad_pack': [_P, _P, _L, _P, _P, _L, _L, _I, _I, _P],
+    'alm_hc_coef_width': [_I],
+    'alm_hc_partial_width': [_I, _I],
+    'alm_hc_partial_blocks': [_L],
+    'alm_hc_width_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
+    'alm_hc_depth_fwd': [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P],
+    'alm_hc_depth_bwd': [_P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _P],
+    'alm_hc_width_bwd': [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
+    'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
+    'alm_residual_add': [_P, _P, _L, _P, _L, _I, _P],
+    'alm_f32_to_bf16': [_P, _P, _P, _L, _L, _I, _P],
+    'alm_add_f32': [_P, _P, _P, _L, _P],
+    'alm_embed_assemble': [_P, _I, _P, _P, _P, _L, _I, _P],
+    'alm_embed_scatter_add': [_P, _I, _P, _P, _P, _F, _L, _I, _P],
+    'alm_gather_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],
+    'alm_scatter_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],
+    'alm_cross_entropy_fwd': [_P, _L, _P, _P, _P, _L, _I, _I, _P],
+    'alm_cross_entropy_bwd': [_P, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
+    'alm_reduce_sum': [_P, _L, _P, _F, _P],
+}
+
+_lib = None
+
+
+class AlmError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True):
+    """Loads (building in-tree with hipcc if necessary) the shared library.  Raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        from . import build as _build
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # no hipcc on the box: fine as long as the prebuilt .so travelled with the tree
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(f'libaudiolm_hip.so is missing and could not be built: {e}') from e
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"`')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise AlmError(f'{name} failed with code {rc}' + (' (ALM_ERR_BAD_ARG)' if rc == 10001 else ' (ALM_ERR_UNSUPPORTED)' if rc == 10002 else ' (hipError_t)'))
+    return rc
+
+
+def query(name: str, *args) -> int:
+    """For the int-returning size queries (alm_*_blocks / alm_*_width)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,835 @@
+"""Host-side mirror of the reference's `audiolm_pytorch/audiolm_pytorch.py` for the training hot path.
+
+Same class names, constructor / forward signatures, attribute names and `state_dict` key names & shapes as the reference
+(SURVEY.md §8(b)), so that these classes drop in under the reference's trainer.py.  The modules are
+parameter containers + integer bookkeeping; every floating-point op of the path runs in libaudiolm_hip.so on the MI355X:
+
+  Transformer.forward                       -> core.TransformerStackFn   (one autograd node, explicit HIP launch sequences)
+  *Transformer.forward embeddings           -> EmbedAssembleFn           (gather + quantizer-position add + start tokens + concat)
+  logit heads + F.cross_entropy             -> heads.HeadsLossFn         (regrouped batched MFMA GEMM + online-softmax CE)
+
+Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning, kv-cache /
+generate(), and the dense relative-position attention bias of `flash_attn=False` models.
+There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
+"""
+from __future__ import annotations
+
+from functools import partial
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.utils.rnn import pad_sequence
+
+from . import core, heads, ops
+from .attend import Attend
+from .version import __version__
+
+DEFAULT_T5_NAME = 'google/t5-v1_1-base'
+_T5_DIMS = {'google/t5-v1_1-small': 512, 'google/t5-v1_1-base': 768, 'google/t5-v1_1-large': 1024,
+            'google/t5-v1_1-xl': 2048, 'google/t5-v1_1-xxl': 4096, 't5-small': 512, 't5-base': 768, 't5-large': 1024}
+
+
+def get_encoded_dim(name):
+    """reference t5.py:get_encoded_dim needs the HF hub; text conditioning is out of scope, only the width is needed so that
+    `proj_text_embed` keeps the reference's shape in the state_dict (audiolm_pytorch.py:604-605)."""
+    return _T5_DIMS.get(name, 768)
+
+
+# ---------------------------------------------------------------------------------------------- helpers (audiolm_pytorch.py:40-186)
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if exists(val) else d
+
+
+def ceil_div(numer, denom):
+    return (numer + denom - 1) // denom
+
+
+def round_down_nearest_multiple(val, mult):
+    return (val // mult) * mult
+
+
+def generate_mask_with_prob(shape, mask_prob, device):        # audiolm_pytorch.py:82-89
+    seq = shape[-1]
+    rand = torch.randn(shape, device=device)
+    rand[:, 0] = -torch.finfo(rand.dtype).max
+    num_mask = min(int(seq * mask_prob), seq - 1)
+    indices = rand.topk(num_mask, dim=-1).indices
+    mask = ~torch.zeros(shape, device=device).scatter(1, indices, 1.).bool()
+    return mask
+
+
+def grad_shrink(t, alpha=0.1):
+    return t * alpha + t.detach() * (1 - alpha)
+
+
+def append_eos_id(ids, eos_id):                               # audiolm_pytorch.py:155-160
+    b, device = ids.shape[0], ids.device
+    eos_ids = torch.full((b, 1), eos_id, dtype=torch.long, device=device)
+    return torch.cat((ids, eos_ids), dim=-1)
+
+
+def batch_unique_consecutive(t, pad_value=0.):                # audiolm_pytorch.py:162-164
+    unique_arr = [torch.unique_consecutive(el) for el in t.unbind(dim=0)]
+    return pad_sequence(unique_arr, batch_first=True, padding_value=pad_value)
+
+
+def get_embeds(embeddings: nn.Embedding, codes: torch.Tensor, pad_id=-1, return_mask=False, mask_pad_pos_to=0):
+    """audiolm_pytorch.py:168-186 (kept for API compatibility; the transformers use EmbedAssembleFn)."""
+    pad_mask = codes == pad_id
+    codes_without_pad = codes.masked_fill(pad_mask, 0)
+    embeds = embeddings(codes_without_pad)
+    if exists(mask_pad_pos_to):
+        embeds = embeds.masked_fill(pad_mask.unsqueeze(-1), mask_pad_pos_to)
+    if return_mask:
+        return embeds, ~pad_mask
+    return embeds
+
+
+def _flatten_ids(t):
+    return t.reshape(t.shape[0], -1)
+
+
+# ---------------------------------------------------------------------------------------------- parameter containers
+
+class LayerNorm(nn.Module):                                   # audiolm_pytorch.py:191-198
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+        self.register_buffer('beta', torch.zeros(dim))
+
+    def forward(self, x):
+        shape = x.shape
+        y, _, _, _ = LayerNormFn.apply(x.reshape(-1, shape[-1]), self.gamma)
+        return y.reshape(shape)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma):
+        xc = x.detach().contiguous()
+        if xc.dtype not in (torch.float32, torch.bfloat16):
+            xc = xc.float()
+        y, _, mean, rstd = ops.layernorm_fwd(xc, gamma.detach())
+        ctx.save_for_backward(xc, mean, rstd, gamma)
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, None, mean, rstd
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dx, dg = ops.layernorm_bwd(dy.contiguous().to(torch.bfloat16), x, mean, rstd, gamma.detach(), dx_dtype=torch.float32)
+        return dx.to(x.dtype), dg
+
+
+class RelativePositionBias(nn.Module):                        # audiolm_pytorch.py:202-242 (parameters only this round)
+    def __init__(self, *, dim, heads, layers=3):
+        super().__init__()
+        self.net = nn.ModuleList([])
+        self.net.append(nn.Sequential(nn.Linear(1, dim), nn.SiLU()))
+        for _ in range(layers - 1):
+            self.net.append(nn.Sequential(nn.Linear(dim, dim), nn.SiLU()))
+        self.net.append(nn.Linear(dim, heads))
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, i, j):
+        raise NotImplementedError('dense relative-position attention bias (flash_attn=False) is SURVEY.md §8(f) item 1; '
+                                  'construct the transformer with flash_attn=True (the README / benchmark configuration)')
+
+
+class GEGLU(nn.Module):                                       # audiolm_pytorch.py:246-249 (fused into alm_geglu_ln_*)
+    def forward(self, x):
+        raise NotImplementedError('GEGLU runs fused inside the transformer stack (alm_geglu_ln_fwd)')
+
+
+def FeedForward(dim, mult=4, dropout=0.1):                    # audiolm_pytorch.py:251-260
+    inner_dim = int(dim * 2 * mult / 3)
+    return nn.Sequential(
+        LayerNorm(dim),
+        nn.Linear(dim, inner_dim * 2, bias=False),
+        GEGLU(),
+        LayerNorm(inner_dim),
+        nn.Dropout(dropout),
+        nn.Linear(inner_dim, dim, bias=False)
+    )
+
+
+class Attention(nn.Module):                                   # audiolm_pytorch.py:264-305 (parameters; compute fused in the stack)
+    def __init__(self, dim, causal=False, dim_head=64, dim_context=None, heads=8, norm_context=False, num_null_kv=0,
+                 dropout=0.1, scale=8, flash=False):
+        super().__init__()
+        self.heads = heads
+        self.dim_head = dim_head
+        self.causal = causal
+        inner_dim = dim_head * heads
+        dim_context = default(dim_context, dim)
+        self.norm = LayerNorm(dim)
+        self.context_norm = LayerNorm(dim_context) if norm_context else nn.Identity()
+        self.attn_dropout = nn.Dropout(dropout)
+        self.num_null_kv = num_null_kv
+        self.null_kv = nn.Parameter(torch.randn(2, num_null_kv, dim_head)) if num_null_kv > 0 else None
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim_context, dim_head * 2, bias=False)
+        self.attend = Attend(flash=flash, dropout=dropout, causal=causal)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), nn.Dropout(dropout))
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('Attention runs fused inside Transformer.forward (core.TransformerStackFn); '
+                                  'standalone use / kv-cache / cross-attention are out of scope this round')
+
+
+class RMSNorm(nn.Module):                                     # hyper-connections stream norm (gamma init 0)
+    def __init__(self, dim):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.zeros(dim))
+
+
+class HyperConnections(nn.Module):
+    """Parameter container with the third-party module's state_dict names."""
+
+    def __init__(self, num_residual_streams, *, dim, branch=None, layer_index=None):
+        super().__init__()
+        from random import randrange
+        self.branch = branch
+        self.norm = RMSNorm(dim)
+        self.num_residual_streams = s = num_residual_streams
+        init_residual_index = default(layer_index, randrange(s)) % s
+        self.static_beta = nn.Parameter(torch.ones(s))
+        init_alpha0 = torch.zeros((s, 1))
+        init_alpha0[init_residual_index, 0] = 1.
+        self.static_alpha = nn.Parameter(torch.cat([init_alpha0, torch.eye(s)], dim=1))
+        self.dynamic_alpha_fn = nn.Parameter(torch.zeros(dim, s + 1))
+        self.dynamic_alpha_scale = nn.Parameter(torch.ones(()) * 1e-2)
+        self.dynamic_beta_fn = nn.Parameter(torch.zeros(dim))
+        self.dynamic_beta_scale = nn.Parameter(torch.ones(()) * 1e-2)
+
+    def hc_params(self):   # order == core.HC_KEYS
+        return [self.static_beta, self.static_alpha, self.dynamic_alpha_fn, self.dynamic_alpha_scale, self.dynamic_beta_fn,
+                self.dynamic_beta_scale, self.norm.gamma]
+
+
+class Residual(nn.Module):                                    # num_residual_streams == 1 wrapper (same `.branch.` prefix)
+    def __init__(self, *args, branch=None, **kwargs):
+        super().__init__()
+        self.branch = branch
+
+    def hc_params(self):
+        return []
+
+
+# ---------------------------------------------------------------------------------------------- Transformer (audiolm_pytorch.py:410-560)
+
+class Transformer(nn.Module):
+    def __init__(self, *, dim, depth, heads, dim_context=None, cross_attend=False, attn_dropout=0., ff_dropout=0.,
+                 grad_shrink_alpha=0.1, cond_as_self_attn_prefix=False, rel_pos_bias=True, flash_attn=False,
+                 add_value_residual=True, num_residual_streams=4, **kwargs):
+        super().__init__()
+        rel_pos_bias = rel_pos_bias and not flash_attn
+        assert not (cross_attend and cond_as_self_attn_prefix)
+        if cross_attend or cond_as_self_attn_prefix:
+            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        if attn_dropout != 0. or ff_dropout != 0.:
+            raise NotImplementedError('dropout > 0 is not implemented in the fused stack (reference default is 0.)')
+        self.dim = dim
+        self.depth = depth
+        self.heads = heads
+        self.dim_context = default(dim_context, dim)
+        self.cond_as_self_attn_prefix = cond_as_self_attn_prefix
+        self.grad_shrink_alpha = grad_shrink_alpha
+        self.grad_shrink = partial(grad_shrink, alpha=grad_shrink_alpha)
+        self.num_residual_streams = num_residual_streams
+        self.layers = nn.ModuleList([])
+        self.rel_pos_bias = RelativePositionBias(dim=dim // 2, heads=heads) if rel_pos_bias else None
+        hc = partial(HyperConnections, num_residual_streams) if num_residual_streams > 1 else partial(Residual, num_residual_streams)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                hc(dim=dim, branch=Attention(dim=dim, heads=heads, dropout=attn_dropout, flash=flash_attn, causal=True, **kwargs)),
+                None,
+                hc(dim=dim, branch=FeedForward(dim=dim, dropout=ff_dropout))
+            ]))
+        self.norm = LayerNorm(dim)
+        self.add_value_residual = add_value_residual
+        attn0 = self.layers[0][0].branch
+        self.cfg = core.StackCfg(dim=dim, depth=depth, heads=heads, dim_head=attn0.dim_head, streams=num_residual_streams,
+                                 inner=int(dim * 2 * 4 / 3), add_value_residual=add_value_residual,
+                                 grad_shrink_alpha=grad_shrink_alpha)
+        self._cache = core.WeightCache()
+        self._layer_grad_hook = None          # set by parallel.DataParallelEngine: called as each layer's grads become final
+
+    def flat_params(self):
+        """Parameter order consumed by core.stack_forward / stack_backward."""
+        out = []
+        for attn, _, ff in self.layers:
+            a, f = attn.branch, ff.branch
+            out += attn.hc_params() + [a.norm.gamma, a.to_q.weight, a.to_kv.weight, a.to_out[0].weight]
+            out += ff.hc_params() + [f[0].gamma, f[1].weight, f[3].gamma, f[5].weight]
+        out.append(self.norm.gamma)
+        return out
+
+    def forward(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, return_kv_cache=False, kv_cache=None,
+                return_flat_hidden=False):
+        if exists(context) or exists(kv_cache):
+            raise NotImplementedError('conditioning / kv-cache inference are out of scope this round (SURVEY.md §8(f))')
+        if exists(attn_bias) or exists(self.rel_pos_bias):
+            raise NotImplementedError('dense attention bias (flash_attn=False models) is SURVEY.md §8(f) item 1; use flash_attn=True')
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
+        b, n, d = x.shape
+        mask_u8 = None
+        if exists(self_attn_mask):
+            mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
+        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, self._layer_grad_hook, *self.flat_params())
+        if return_flat_hidden:
+            return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
+        out = hn.view(b, n, d)
+        if not return_kv_cache:
+            return out
+        return out, None
+
+
+# ---------------------------------------------------------------------------------------------- embedding assembly
+
+class EmbedAssembleFn(torch.autograd.Function):
+    """tokens[r] = table_a[row_a] (+ table_b[row_b]); src codes are (table_id << 24 | row), -1 = zero vector."""
+
+    @staticmethod
+    def forward(ctx, src_a, src_b, rows, dim, *tables):
+        flat = [t.detach().reshape(-1, dim) for t in tables]
+        out = ops.embed_assemble(flat, src_a, src_b, rows, dim)
+        ctx.src, ctx.tables, ctx.dim, ctx.rows = (src_a, src_b), tables, dim, rows
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous().to(torch.float32)
+        grads = [torch.zeros_like(t, dtype=torch.float32) for t in ctx.tables]
+        ops.embed_scatter_add([g.view(-1, ctx.dim) for g in grads], ctx.src[0], ctx.src[1], dout.view(-1, ctx.dim), 1.0, ctx.rows, ctx.dim)
+        return (None, None, None, None, *grads)
+
+
+def _code(table_id, rows):
+    return (rows.to(torch.int32) + (table_id << 24)).to(torch.int32)
+
+
+def _const_code(table_id, b, device):
+    return torch.full((b, 1), table_id << 24, dtype=torch.int32, device=device)
+
+
+def _neg(b, n, device):
+    return torch.full((b, n), -1, dtype=torch.int32, device=device)
+
+
+def _quantizer_rows(n, Q, device):
+    return (torch.arange(n, device=device) % Q).to(torch.int32)
+
+
+def _group_index(B, N, start, n, Q, device):
+    """Rows of the flat hidden states [B*N, D] regrouped per quantizer: position i of the range uses head i mod Q
+    -> (idx int32 [Q, B*J] (-1 = pad), i_grid [Q, J], valid [Q, J])."""
+    J = ceil_div(n, Q)
+    i_grid = torch.arange(J, device=device)[None, :] * Q + torch.arange(Q, device=device)[:, None]     # [Q, J]
+    valid = i_grid < n
+    rows = torch.arange(B, device=device)[None, :, None] * N + start + i_grid[:, None, :]              # [Q, B, J]
+    idx = torch.where(valid[:, None, :], rows, torch.full_like(rows, -1)).reshape(Q, B * J).to(torch.int32)
+    return idx.contiguous(), i_grid, valid
+
+
+def _group_labels(labels, i_grid, valid, n):
+    """labels [B, n] int64 -> [Q, B*J] (-1 where the slot does not exist)."""
+    B = labels.shape[0]
+    Q, J = i_grid.shape
+    g = labels[:, i_grid.clamp(max=n - 1).reshape(-1)].reshape(B, Q, J).permute(1, 0, 2)              # [Q, B, J]
+    g = torch.where(valid[:, None, :], g, torch.full_like(g, -1))
+    return g.reshape(Q, B * J).contiguous()
+
+
+def _ungroup_logits(logits_g, B, n, Q, C):
+    """logits_g fp32 [Q*B*J, Cpad] -> reference layout [B, n, C]."""
+    J = ceil_div(n, Q)
+    lg = logits_g.view(Q, B, J, -1)[..., :C].permute(1, 2, 0, 3).reshape(B, J * Q, C)                # b (j q) c
+    return lg[:, :n].contiguous()
+
+
+class _TransformerBase(nn.Module):
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def load(self, path):                                     # audiolm_pytorch.py:627-638 / :805-816 / :1084-1095
+        from packaging import version
+        device = self.device
+        path = Path(path)
+        assert path.exists()
+        pkg = torch.load(str(path), map_location=device)
+        if 'version' in pkg and version.parse(pkg['version']) < version.parse(__version__):
+            print(f'model was trained on older version {pkg["version"]} of audiolm-pytorch')
+        self.load_state_dict(pkg['model'])
+        return pkg
+
+    def _reject_conditioning(self, text, text_embeds):
+        if exists(text) or exists(text_embeds) or self.has_condition:
+            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+
+    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
+        raise NotImplementedError('classifier-free-guidance sampling (inference) is SURVEY.md §8(f) item 2')
+
+    def _init_common(self, *, t5_name, has_condition, cond_dim, audio_text_condition, cond_drop_prob, dim):
+        if audio_text_condition:
+            has_condition = True
+            cond_dim = default(cond_dim, dim)
+        self.has_condition = has_condition
+        self.cond_drop_prob = cond_drop_prob
+        text_dim = default(cond_dim, get_encoded_dim(t5_name))
+        self.proj_text_embed = nn.Linear(text_dim, dim, bias=False) if text_dim != dim else nn.Identity()
+
+    def embed_text(self, *a, **k):
+        raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+
+    def _heads_cache(self):
+        return self.transformer._cache
+
+
+# ---------------------------------------------------------------------------------------------- SemanticTransformer (:564-724)
+
+class SemanticTransformer(_TransformerBase):
+    def __init__(self, *, dim, depth, num_semantic_tokens, heads=8, attn_dropout=0., ff_dropout=0., t5_name=DEFAULT_T5_NAME,
+                 cond_dim=None, has_condition=False, audio_text_condition=False, cond_as_self_attn_prefix=False, cond_drop_prob=0.5,
+                 grad_shrink_alpha=0.1, rel_pos_bias=True, flash_attn=False, **kwargs):
+        super().__init__()
+        rel_pos_bias = rel_pos_bias and not flash_attn
+        self.num_semantic_tokens = num_semantic_tokens
+        self._init_common(t5_name=t5_name, has_condition=has_condition, cond_dim=cond_dim, audio_text_condition=audio_text_condition,
+                          cond_drop_prob=cond_drop_prob, dim=dim)
+        self.start_token = nn.Parameter(torch.randn(dim))
+        self.semantic_embedding = nn.Embedding(num_semantic_tokens + 1, dim)
+        self.eos_id = num_semantic_tokens
+        self.transformer = Transformer(dim=dim, depth=depth, heads=heads, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+                                       cross_attend=self.has_condition and not cond_as_self_attn_prefix,
+                                       cond_as_self_attn_prefix=cond_as_self_attn_prefix, grad_shrink_alpha=grad_shrink_alpha,
+                                       rel_pos_bias=rel_pos_bias, flash_attn=flash_attn, **kwargs)
+        self.to_logits = nn.Linear(dim, num_semantic_tokens + 1)
+        self.dim = dim
+
+    def _hidden(self, ids, self_attn_mask):
+        b, n = ids.shape
+        dev = ids.device
+        sem = ids.to(torch.int32)                                                              # table 0; pad (-1) -> zero vector (:176-181)
+        src_a = torch.cat((_const_code(1, b, dev), sem), dim=1).contiguous()
+        src_b = _neg(b, n + 1, dev)
+        tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * (n + 1), self.dim,
+                                       self.semantic_embedding.weight, self.start_token).view(b, n + 1, self.dim)
+        if exists(self_attn_mask):
+            self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)                       # :716
+        return self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True), b, n + 1
+
+    def forward(self, *, ids=None, return_loss=False, text=None, text_embeds=None, self_attn_mask=None, cond_drop_prob=None,
+                unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
+        self._reject_conditioning(text, text_embeds)
+        if exists(kv_cache):
+            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+        if return_loss:
+            ids = ids[:, :-1]                                                                # :706-707 (the reference drops the labels)
+        hn, b, N = self._hidden(ids, self_attn_mask)
+        idx, i_grid, valid = _group_index(b, N, 0, N, 1, ids.device)
+        if exists(labels):                                                                   # fused loss path (wrapper)
+            grp = heads.HeadGroup('semantic', self.to_logits.weight, self.to_logits.bias, idx, _group_labels(labels, i_grid, valid, N))
+            (loss_sum,) = heads.HeadsLossFn.apply(hn, [grp], self._heads_cache(), self.to_logits.weight, self.to_logits.bias)
+            return loss_sum / (labels != -1).sum().clamp(min=1)
+        C = self.num_semantic_tokens + 1
+        _, lg = heads.head_logits(hn, self.to_logits.weight.detach().unsqueeze(0), self.to_logits.bias.detach(), idx,
+                                  self._heads_cache(), ('head', 'semantic'))
+        logits = _ungroup_logits(lg, b, N, 1, C)
+        if not return_kv_cache:
+            return logits
+        return logits, None
+
+
+# ---------------------------------------------------------------------------------------------- CoarseTransformer (:726-990)
+
+class CoarseTransformer(_TransformerBase):
+    def __init__(self, *, codebook_size, num_coarse_quantizers, dim, depth, num_semantic_tokens, heads=8, attn_dropout=0.,
+                 ff_dropout=0., t5_name=DEFAULT_T5_NAME, has_condition=False, cond_dim=None, audio_text_condition=False,
+                 cond_as_self_attn_prefix=False, cond_drop_prob=0.5, grad_shrink_alpha=0.1, project_semantic_logits=True,
+                 rel_pos_bias=True, flash_attn=False, **kwargs):
+        super().__init__()
+        rel_pos_bias = rel_pos_bias and not flash_attn
+        self.num_semantic_tokens = num_semantic_tokens
+        self._init_common(t5_name=t5_name, has_condition=has_condition, cond_dim=cond_dim, audio_text_condition=audio_text_condition,
+                          cond_drop_prob=cond_drop_prob, dim=dim)
+        self.semantic_start_token = nn.Parameter(torch.randn(dim))
+        self.coarse_start_token = nn.Parameter(torch.randn(dim))
+        self.semantic_eos_id = num_semantic_tokens
+        self.semantic_embedding = nn.Embedding(num_semantic_tokens + 1, dim)
+        self.coarse_eos_id = codebook_size
+        codebook_size_with_eos = codebook_size + 1
+        self.coarse_embedding = nn.Embedding(num_coarse_quantizers * codebook_size_with_eos, dim)
+        self.coarse_quantize_embedding = nn.Embedding(num_coarse_quantizers, dim)
+        self.cross_attn_bias = nn.Parameter(torch.zeros(heads, 1, 1)) if rel_pos_bias else None
+        self.transformer = Transformer(dim=dim, depth=depth, heads=heads, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+                                       cross_attend=self.has_condition and not cond_as_self_attn_prefix,
+                                       cond_as_self_attn_prefix=cond_as_self_attn_prefix, grad_shrink_alpha=grad_shrink_alpha,
+                                       rel_pos_bias=rel_pos_bias, flash_attn=flash_attn, **kwargs)
+        self.codebook_size = codebook_size
+        self.num_coarse_quantizers = num_coarse_quantizers
+        self.to_semantic_logits = nn.Linear(dim, num_semantic_tokens + 1) if project_semantic_logits else None
+        self.coarse_logit_weights = nn.Parameter(torch.randn(num_coarse_quantizers, codebook_size_with_eos, dim))
+        self.dim = dim
+
+    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask):
+        b, dev = semantic_token_ids.shape[0], semantic_token_ids.device
+        Q, C = self.num_coarse_quantizers, self.codebook_size
+        coarse, sem = _flatten_ids(coarse_token_ids), _flatten_ids(semantic_token_ids)           # :894
+        ns, nc = sem.shape[1], coarse.shape[1]
+        qrow = _quantizer_rows(nc, Q, dev)                                                       # i mod Q
+        coarse_rows = coarse.to(torch.int32) + C * qrow[None]                                    # :896-899 (stride C: eos aliasing kept)
+        sem32 = sem.to(torch.int32)
+        sem_code = torch.where(sem32 >= 0, sem32, torch.full_like(sem32, -1))                    # table 0; pad -> zero (:901)
+        src_a = torch.cat((_const_code(3, b, dev), sem_code, _const_code(4, b, dev), _code(1, coarse_rows)), dim=1).contiguous()
+        src_b = torch.cat((_neg(b, ns + 2, dev), _code(2, qrow)[None].expand(b, -1)), dim=1).contiguous()     # :904-906
+        N = ns + nc + 2
+        tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.semantic_embedding.weight,
+                                       self.coarse_embedding.weight, self.coarse_quantize_embedding.weight,
+                                       self.semantic_start_token, self.coarse_start_token).view(b, N, self.dim)   # :913-918
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True)
+        return hn, b, N, ns, nc
+
+    def _groups(self, b, N, ns, nc, dev, semantic_labels=None, coarse_labels=None, only_coarse=False):
+        Q = self.num_coarse_quantizers
+        groups, params = [], []
+        n_coarse = nc + 1                                                                         # tokens[:, ns+1:]  (:957)
+        if exists(self.to_semantic_logits) and not only_coarse:
+            idx, ig, va = _group_index(b, N, 0, ns, 1, dev)                                       # tokens[:, :ns]
+            lab = _group_labels(semantic_labels, ig, va, ns) if exists(semantic_labels) else None
+            groups.append(heads.HeadGroup('semantic', self.to_semantic_logits.weight, self.to_semantic_logits.bias, idx, lab))
+            params += [self.to_semantic_logits.weight, self.to_semantic_logits.bias]
+        idx, ig, va = _group_index(b, N, ns + 1, n_coarse, Q, dev)
+        lab = _group_labels(coarse_labels, ig, va, n_coarse) if exists(coarse_labels) else None
+        groups.append(heads.HeadGroup('coarse', self.coarse_logit_weights, None, idx, lab))
+        params.append(self.coarse_logit_weights)
+        return groups, params
+
+    def forward(self, *, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text=None, text_embeds=None, cond_drop_prob=None,
+                return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None):
+        self._reject_conditioning(text, text_embeds)
+        if exists(kv_cache) or exists(embed_cache):
+            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+        hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask)
+        dev = hn.device
+        if exists(labels):                                                                        # fused loss path: (sem_labels, coarse_labels)
+            sem_labels, coarse_labels = labels
+            groups, params = self._groups(b, N, ns, nc, dev, sem_labels, coarse_labels)
+            sums = heads.HeadsLossFn.apply(hn, groups, self._heads_cache(), *params)
+            out = []
+            for s, lab in zip(sums, ([sem_labels] if len(sums) == 2 else []) + [coarse_labels]):
+                out.append(s / (lab != -1).sum().clamp(min=1))
+            return (out[0] if len(out) == 2 else None), out[-1]
+        groups, _ = self._groups(b, N, ns, nc, dev, only_coarse=return_only_coarse_logits)
+        outs = []
+        for gi, g in enumerate(groups):
+            w3 = g.weight.detach() if g.weight.dim() == 3 else g.weight.detach().unsqueeze(0)
+            _, lg = heads.head_logits(hn, w3, None if g.bias is None else g.bias.detach(), g.idx, self._heads_cache(), ('head', g.name))
+            outs.append(lg)
+        coarse_logits = _ungroup_logits(outs[-1], b, nc + 1, self.num_coarse_quantizers, self.codebook_size + 1)
+        semantic_logits = _ungroup_logits(outs[0], b, ns, 1, self.num_semantic_tokens + 1) if len(outs) == 2 else None
+        logits = (semantic_logits, coarse_logits)
+        if not return_cache:
+            return logits
+        return logits, (None, None)
+
+
+# ---------------------------------------------------------------------------------------------- FineTransformer (:992-1368)
+
+class FineTransformer(_TransformerBase):
+    def __init__(self, *, num_coarse_quantizers, num_fine_quantizers, codebook_size, dim, depth, heads=8, attn_dropout=0.,
+                 ff_dropout=0., t5_name=DEFAULT_T5_NAME, has_condition=False, cond_dim=None, audio_text_condition=False,
+                 cond_as_self_attn_prefix=False, cond_drop_prob=0.5, grad_shrink_alpha=0.1, project_coarse_logits=True, pad_id=-1,
+                 rel_pos_bias=True, flash_attn=False, **kwargs):
+        super().__init__()
+        rel_pos_bias = rel_pos_bias and not flash_attn
+        self._init_common(t5_name=t5_name, has_condition=has_condition, cond_dim=cond_dim, audio_text_condition=audio_text_condition,
+                          cond_drop_prob=cond_drop_prob, dim=dim)
+        self.num_coarse_quantizers = num_coarse_quantizers
+        self.coarse_start_token = nn.Parameter(torch.randn(dim))
+        self.fine_start_token = nn.Parameter(torch.randn(dim))
+        self.coarse_embedding = nn.Embedding(num_coarse_quantizers * codebook_size, dim)
+        self.fine_embedding = nn.Embedding(num_fine_quantizers * codebook_size, dim)
+        self.coarse_quantize_embedding = nn.Embedding(num_coarse_quantizers, dim)
+        self.fine_quantize_embedding = nn.Embedding(num_fine_quantizers, dim)
+        self.pad_id = pad_id
+        self.eos_id = codebook_size
+        self.transformer = Transformer(dim=dim, depth=depth, heads=heads, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+                                       cross_attend=self.has_condition and not cond_as_self_attn_prefix,
+                                       cond_as_self_attn_prefix=cond_as_self_attn_prefix, rel_pos_bias=False,
+                                       grad_shrink_alpha=grad_shrink_alpha, flash_attn=flash_attn, **kwargs)
+        self.null_pos_bias = nn.Parameter(torch.randn(heads, 1, 1)) if rel_pos_bias else None
+        pos_bias_mlp_dim = dim // 2
+        self.pos_bias_mlp = nn.Sequential(
+            nn.Linear(2, pos_bias_mlp_dim), nn.SiLU(), nn.Linear(pos_bias_mlp_dim, pos_bias_mlp_dim), nn.SiLU(),
+            nn.Linear(pos_bias_mlp_dim, heads)) if rel_pos_bias else None
+        self.codebook_size = codebook_size
+        self.num_fine_quantizers = num_fine_quantizers
+        self.coarse_logit_weights = nn.Parameter(torch.randn(num_coarse_quantizers, codebook_size, dim)) if project_coarse_logits else None
+        self.fine_logit_weights = nn.Parameter(torch.randn(num_fine_quantizers, codebook_size, dim))
+        self.dim = dim
+
+    def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
+                kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
+        self._reject_conditioning(text, text_embeds)
+        if exists(kv_cache) or exists(embed_cache):
+            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+        if exists(self.pos_bias_mlp):
+            raise NotImplementedError('dense attention bias (flash_attn=False models) is SURVEY.md §8(f) item 1; use flash_attn=True')
+        b, dev = coarse_token_ids.shape[0], coarse_token_ids.device
+        Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
+        coarse, fine = _flatten_ids(coarse_token_ids), _flatten_ids(fine_token_ids)               # :1171
+        coarse_mask = (coarse != self.pad_id) & (coarse != self.eos_id)                           # :1175
+        coarse = coarse.masked_fill(~coarse_mask, 0)
+        n, nf = coarse.shape[1], fine.shape[1]
+        coarse_mask = F.pad(coarse_mask, (1, nf + 1), value=True)                                 # :1179
+        if exists(self_attn_mask):
+            self_attn_mask &= coarse_mask                                                         # in place, like the reference (:1182)
+        else:
+            self_attn_mask = coarse_mask
+        qc, qf = _quantizer_rows(n, Qc, dev), _quantizer_rows(nf, Qf, dev)
+        coarse_rows = coarse.to(torch.int32) + qc[None] * C                                       # :1195
+        fine_rows = fine.to(torch.int32) + qf[None] * C                                           # :1202
+        src_a = torch.cat((_const_code(4, b, dev), _code(0, coarse_rows), _const_code(5, b, dev), _code(1, fine_rows)), dim=1).contiguous()
+        src_b = torch.cat((_neg(b, 1, dev), _code(2, qc)[None].expand(b, -1), _neg(b, 1, dev), _code(3, qf)[None].expand(b, -1)), dim=1).contiguous()
+        N = n + nf + 2
+        tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.coarse_embedding.weight,
+                                       self.fine_embedding.weight, self.coarse_quantize_embedding.weight,
+                                       self.fine_quantize_embedding.weight, self.coarse_start_token, self.fine_start_token).view(b, N, self.dim)
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True)
+
+        n_fine = nf + 1                                                                           # tokens[:, n+1:]  (:1319)
+        want_coarse = exists(self.coarse_logit_weights) and not return_only_fine_logits
+        groups, params = [], []
+        if want_coarse:
+            idx, ig, va = _group_index(b, N, 0, n, Qc, dev)                                       # tokens[:, :n] (zero-pad + slice == ragged tail)
+            lab = _group_labels(labels[0], ig, va, n) if exists(labels) else None
+            groups.append(heads.HeadGroup('coarse', self.coarse_logit_weights, None, idx, lab)); params.append(self.coarse_logit_weights)
+        idx, ig, va = _group_index(b, N, n + 1, n_fine, Qf, dev)
+        lab = _group_labels(labels[1], ig, va, n_fine) if exists(labels) else None
+        groups.append(heads.HeadGroup('fine', self.fine_logit_weights, None, idx, lab)); params.append(self.fine_logit_weights)
+
+        if exists(labels):
+            sums = heads.HeadsLossFn.apply(hn, groups, self._heads_cache(), *params)
+            labs = ([labels[0]] if want_coarse else []) + [labels[1]]
+            out = [s / (l != -1).sum().clamp(min=1) for s, l in zip(sums, labs)]
+            return (out[0] if want_coarse else None), out[-1]
+        outs = []
+        for gi, g in enumerate(groups):
+            _, lg = heads.head_logits(hn, g.weight.detach(), None, g.idx, self._heads_cache(), ('head', g.name))
+            outs.append(lg)
+        fine_logits = _ungroup_logits(outs[-1], b, n_fine, Qf, C)
+        coarse_logits = _ungroup_logits(outs[0], b, n, Qc, C) if want_coarse else None
+        logits = (coarse_logits, fine_logits)
+        if not return_cache:
+            return logits
+        return logits, (None, None)
+
+
+# ---------------------------------------------------------------------------------------------- training wrappers
+
+class _WrapperBase(nn.Module):
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def generate(self, *a, **k):
+        raise NotImplementedError('autoregressive sampling is SURVEY.md §8(f) item 2 (out of scope this round)')
+
+    def embed_text(self, text):
+        raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+
+
+class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.py:1372-1567
+    def __init__(self, *, transformer: SemanticTransformer, wav2vec=None, audio_conditioner=None, pad_id=-1, unique_consecutive=True,
+                 mask_prob=0.15):
+        super().__init__()
+        self.wav2vec = wav2vec
+        self.transformer = transformer
+        self.to(transformer.device)
+        self.audio_conditioner = audio_conditioner
+        assert not (exists(audio_conditioner) and not transformer.has_condition)
+        assert not exists(self.wav2vec) or self.wav2vec.codebook_size == transformer.num_semantic_tokens
+        self.unique_consecutive = unique_consecutive
+        self.pad_id = pad_id
+        self.eos_id = transformer.eos_id
+        self.mask_prob = mask_prob
+
+    def forward(self, *, semantic_token_ids=None, raw_wave=None, text=None, text_embeds=None, return_loss=False, **kwargs):
+        assert exists(raw_wave) or exists(semantic_token_ids)
+        if exists(self.audio_conditioner):
+            raise NotImplementedError('audio conditioning is out of scope')
+        if not exists(semantic_token_ids):
+            assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
+            semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
+        semantic_token_ids = _flatten_ids(semantic_token_ids)
+        if self.training:
+            semantic_token_ids = append_eos_id(semantic_token_ids, self.transformer.eos_id)        # :1536-1537
+        if self.unique_consecutive:
+            semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
+        input_ids = semantic_token_ids
+        if return_loss:
+            input_ids = semantic_token_ids[:, :-1]
+        self_attn_mask = None
+        if self.mask_prob > 0. and self.training:
+            self_attn_mask = generate_mask_with_prob(input_ids.shape, self.mask_prob, input_ids.device)
+        if not return_loss:
+            return self.transformer(ids=input_ids, text=text, text_embeds=text_embeds, self_attn_mask=self_attn_mask, **kwargs)
+        # reference: logits = transformer(ids = input_ids); CE(logits 'b c n', semantic_token_ids, ignore_index = pad_id)  (:1550-1565)
+        return self.transformer(ids=input_ids, text=text, text_embeds=text_embeds, self_attn_mask=self_attn_mask,
+                                labels=semantic_token_ids, **kwargs)
+
+
+class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.py:1569-1854
+    def __init__(self, *, transformer: CoarseTransformer, codec=None, wav2vec=None, audio_conditioner=None, pad_id=-1,
+                 unique_consecutive=True, semantic_cross_entropy_loss_weight=1., mask_prob=0.15):
+        super().__init__()
+        self.codec = codec
+        self.wav2vec = wav2vec
+        self.transformer = transformer
+        self.to(transformer.device)
+        self.audio_conditioner = audio_conditioner
+        assert not (exists(audio_conditioner) and not transformer.has_condition)
+        self.unique_consecutive = unique_consecutive
+        self.pad_id = pad_id
+        self.semantic_cross_entropy_loss_weight = semantic_cross_entropy_loss_weight
+        self.num_coarse_quantizers = transformer.num_coarse_quantizers * codec.rq_groups        # :1598 (codec=None crashes, like the reference)
+        self.semantic_eos_id = transformer.semantic_eos_id
+        self.coarse_eos_id = transformer.coarse_eos_id
+        self.mask_prob = mask_prob
+
+    def forward(self, *, semantic_token_ids=None, raw_wave=None, raw_wave_for_codec=None, text=None, text_embeds=None,
+                coarse_token_ids=None, return_loss=False, **kwargs):
+        assert exists(raw_wave) or exists(semantic_token_ids)
+        raw_wave_for_codec = default(raw_wave_for_codec, raw_wave)
+        assert exists(raw_wave_for_codec) or exists(coarse_token_ids)
+        assert not all(map(exists, (raw_wave, raw_wave_for_codec, semantic_token_ids, coarse_token_ids)))
+        if exists(self.audio_conditioner):
+            raise NotImplementedError('audio conditioning is out of scope')
+        if not exists(semantic_token_ids):
+            assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
+            semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
+        if not exists(coarse_token_ids):
+            assert exists(self.codec), 'Codec must be provided if given raw wave for training'
+            with torch.inference_mode():                                                          # :1773-1783
+                self.codec.eval()
+                _, indices, _ = self.codec(raw_wave_for_codec, return_encoded=True)
+                batch, num_timesteps = raw_wave_for_codec.shape
+                num_frames = int(num_timesteps / self.codec.seq_len_multiple_of)
+                assert indices.shape[0] == batch and indices.shape[1] == num_frames
+                coarse_token_ids = indices[..., :self.num_coarse_quantizers]
+            coarse_token_ids = coarse_token_ids.clone()
+        semantic_token_ids = _flatten_ids(semantic_token_ids)
+        coarse_token_ids = _flatten_ids(coarse_token_ids)
+        if self.training:                                                                         # :1788-1790
+            semantic_token_ids = append_eos_id(semantic_token_ids, self.transformer.semantic_eos_id)
+            coarse_token_ids = append_eos_id(coarse_token_ids, self.transformer.coarse_eos_id)
+        if self.unique_consecutive:
+            semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
+        if return_loss:
+            semantic_labels, coarse_labels = semantic_token_ids, coarse_token_ids.clone()
+            coarse_token_ids = coarse_token_ids[:, :-1]
+        self_attn_mask = (semantic_token_ids != self.pad_id) & (semantic_token_ids != self.semantic_eos_id)   # :1801
+        semantic_token_ids = semantic_token_ids.masked_fill(~self_attn_mask, 0)
+        coarse_token_len = coarse_token_ids.shape[-1]
+        self_attn_mask = F.pad(self_attn_mask, (1, coarse_token_len + 1), value=True)             # :1805
+        if self.mask_prob > 0 and self.training:                                                  # forgetful causal mask, :1809-1810
+            self_attn_mask &= generate_mask_with_prob(self_attn_mask.shape, self.mask_prob, device=self_attn_mask.device)
+        if not return_loss:
+            return self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids,
+                                    self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds, **kwargs)
+        use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(self.transformer.to_semantic_logits)
+        semantic_loss, coarse_loss = self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids,
+                                                      self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds,
+                                                      labels=(semantic_labels, coarse_labels), **kwargs)
+        if self.unique_consecutive:                                                               # :1828-1831
+            num_coarse_logits, _num_semantic_logits = coarse_labels.numel(), (semantic_labels != self.pad_id).sum()
+        else:
+            num_coarse_logits, _num_semantic_logits = coarse_labels.shape[-1], semantic_labels.shape[-1]
+        num_semantic_logits = 0
+        if not (use_sem and exists(semantic_loss)):
+            semantic_loss = 0.
+        else:
+            num_semantic_logits = _num_semantic_logits
+        return (semantic_loss * num_semantic_logits * self.semantic_cross_entropy_loss_weight +
+                coarse_loss * num_coarse_logits) / (num_semantic_logits + num_coarse_logits)        # :1851-1854
+
+
+class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.py:1856-2137
+    def __init__(self, *, transformer: FineTransformer, codec=None, audio_conditioner=None, coarse_cross_entropy_loss_weight=1.,
+                 pad_id=-1, mask_prob=0.15):
+        super().__init__()
+        self.codec = codec
+        self.transformer = transformer
+        self.to(transformer.device)
+        self.audio_conditioner = audio_conditioner
+        assert not (exists(audio_conditioner) and not transformer.has_condition)
+        self.num_fine_quantizers = transformer.num_fine_quantizers * codec.rq_groups
+        self.num_coarse_quantizers = transformer.num_coarse_quantizers * codec.rq_groups
+        if exists(codec):
+            assert (self.num_fine_quantizers + self.num_coarse_quantizers) == (codec.num_quantizers * codec.rq_groups)
+        self.eos_id = transformer.eos_id
+        assert self.num_coarse_quantizers > 0
+        self.pad_id = pad_id
+        self.coarse_cross_entropy_loss_weight = coarse_cross_entropy_loss_weight
+        self.mask_prob = mask_prob
+
+    def forward(self, *, raw_wave=None, text=None, text_embeds=None, token_ids=None, coarse_token_ids=None, fine_token_ids=None,
+                return_loss=False, **kwargs):
+        assert exists(raw_wave) ^ (exists(token_ids) ^ (exists(coarse_token_ids) and exists(fine_token_ids)))
+        if exists(self.audio_conditioner):
+            raise NotImplementedError('audio conditioning is out of scope')
+        if exists(raw_wave):
+            assert exists(self.codec), 'Codec must be provided if given raw wave for training'
+            with torch.inference_mode():                                                          # :2063-2071
+                self.codec.eval()
+                _, token_ids, _ = self.codec(raw_wave, return_encoded=True)
+                batch, num_timesteps = raw_wave.shape
+                num_frames = int(num_timesteps / self.codec.seq_len_multiple_of)
+                assert token_ids.shape == torch.Size((batch, num_frames, self.num_coarse_quantizers + self.num_fine_quantizers))
+            token_ids = token_ids.clone()
+        if exists(token_ids):
+            coarse_token_ids, fine_token_ids = token_ids[..., :self.num_coarse_quantizers], token_ids[..., self.num_coarse_quantizers:]
+        coarse_token_ids = _flatten_ids(coarse_token_ids)
+        fine_token_ids = _flatten_ids(fine_token_ids)
+        if return_loss:
+            coarse_labels, fine_labels = coarse_token_ids, fine_token_ids
+            fine_token_ids = fine_token_ids[:, :-1]
+        self_attn_mask = None
+        if self.mask_prob > 0 and self.training:
+            mask_shape = (coarse_token_ids.shape[0], coarse_token_ids.shape[-1] + fine_token_ids.shape[-1] + 2)
+            self_attn_mask = generate_mask_with_prob(mask_shape, self.mask_prob, device=self.device)
+        if not return_loss:
+            return self.transformer(coarse_token_ids=coarse_token_ids, fine_token_ids=fine_token_ids, self_attn_mask=self_attn_mask,
+                                    text=text, text_embeds=text_embeds, **kwargs)
+        use_coarse = self.coarse_cross_entropy_loss_weight > 0 and exists(self.transformer.coarse_logit_weights)
+        coarse_loss, fine_loss = self.transformer(coarse_token_ids=coarse_token_ids, fine_token_ids=fine_token_ids,
+                                                  self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds,
+                                                  labels=(coarse_labels, fine_labels), return_only_fine_logits=not use_coarse, **kwargs)
+        num_fine_logits = fine_labels.shape[-1]                                                   # :2114
+        num_coarse_logits = 0
+        if use_coarse and exists(coarse_loss):
+            num_coarse_logits = coarse_labels.shape[-1]
+        else:
+            coarse_loss = 0.
+        return (coarse_loss * num_coarse_logits * self.coarse_cross_entropy_loss_weight +
+                fine_loss * num_fine_logits) / (num_coarse_logits + num_fine_logits)               # :2134-2137
+
+
+class AudioLM(nn.Module):                                     # audiolm_pytorch.py:2141-2254
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError('AudioLM (hierarchical sampling) is inference: SURVEY.md §8(f) item 2, out of scope this round')

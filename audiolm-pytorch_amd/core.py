@@ -1,0 +1,307 @@
+"""Host-side driver of the transformer stack: the depth loop of reference audiolm_pytorch.py:461-560 (training path) written
+as ONE autograd node whose forward and backward are explicit sequences of HIP launches (ops.py -> C ABI).  There is no
+per-op autograd graph, no (b, h, n, n) tensors, no kv-cache stacking (audiolm_pytorch.py:532, :560 are semantics-free in
+training -- SURVEY.md Appendix A.7).
+
+Data layout in HBM (B sequences, N tokens, M = B*N rows, D model width, S residual streams):
+  residual streams  R    fp32 [B][S][N][D]            (reference '(b s) n d'); one tensor per branch boundary is kept for backward
+  branch input      X/XN bf16 [M][D]                  (XN = pre-LayerNorm output, X = un-normalised input feeding to_kv -- quirk A3)
+  q / kv / attn out      bf16 [M][H*64] / [M][128] / [M][H*64]
+  FFN               U    bf16 [M][2*Ipad] (x | gate halves, Ipad = inner rounded up to 8), HN bf16 [M][Ipad]
+  weights                fp32 masters (nn.Parameter) + bf16 packed copies W and W^T refreshed when the master's version changes
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class StackCfg:
+    dim: int
+    depth: int
+    heads: int
+    dim_head: int
+    streams: int
+    inner: int                    # FFN inner width int(dim * 8 / 3)
+    add_value_residual: bool
+    grad_shrink_alpha: float
+
+    @property
+    def inner_pad(self):
+        return (self.inner + 7) // 8 * 8
+
+
+HC_KEYS = ('Bb', 'Aa', 'Wa', 'sa', 'wb', 'sb', 'gamma')   # static_beta, static_alpha, dynamic_alpha_fn, dynamic_alpha_scale, dynamic_beta_fn, dynamic_beta_scale, norm.gamma
+
+
+def params_per_layer(S):
+    hc = len(HC_KEYS) if S > 1 else 0
+    return (hc + 4) + (hc + 4)
+
+
+def _split_layer(flat, S):
+    """flat per-layer parameter list -> (attn dict, ff dict) (see Transformer.flat_params for the order)."""
+    i = 0
+    a, f = {}, {}
+    if S > 1:
+        a['hc'] = dict(zip(HC_KEYS, flat[i:i + 7])); i += 7
+    a['ln'], a['wq'], a['wkv'], a['wo'] = flat[i:i + 4]; i += 4
+    if S > 1:
+        f['hc'] = dict(zip(HC_KEYS, flat[i:i + 7])); i += 7
+    f['ln'], f['w1'], f['ln3'], f['w2'] = flat[i:i + 4]
+    return a, f
+
+
+class WeightCache:
+    """bf16 packed copies (W and W^T, zero padded) of the fp32 master weights; refreshed when a master's version changes
+    (i.e. once per optimiser step) -- this is what `accelerator.autocast()` (trainer.py:1241) does per call, amortised."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, w, builder):
+        ver = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            packed = builder(w.detach())
+        self.store[key] = (ver, packed)
+        return packed
+
+
+def _pack_plain(w):
+    rows, cols = w.shape
+    rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+    W = torch.empty((rp, cp), dtype=BF16, device=w.device)
+    WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
+    ops.pack_weight(w, W, WT, rows_pad=rp, cols_pad=cp)
+    return W[:rows], WT[:cols]
+
+
+def _pack_w1(w, I, Ip):
+    D = w.shape[1]
+    W = torch.empty((2 * Ip, D), dtype=BF16, device=w.device)
+    WT = torch.empty((D, 2 * Ip), dtype=BF16, device=w.device)
+    ops.pack_weight(w[:I], W[:Ip], WT[:, :Ip], rows_pad=Ip, cols_pad=D)
+    ops.pack_weight(w[I:], W[Ip:], WT[:, Ip:], rows_pad=Ip, cols_pad=D)
+    return W, WT
+
+
+def _pack_w2(w, I, Ip):
+    D = w.shape[0]
+    W = torch.empty((D, Ip), dtype=BF16, device=w.device)
+    WT = torch.empty((Ip, D), dtype=BF16, device=w.device)
+    ops.pack_weight(w, W, WT, rows_pad=D, cols_pad=Ip)
+    return W, WT
+
+
+def _empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool):
+    """x fp32 [B, N, D] -> (hn bf16 [B*N, D], saved-for-backward | None)."""
+    B, N, D = x.shape
+    M, S, H, dh = B * N, cfg.streams, cfg.heads, cfg.dim_head
+    I, Ip = cfg.inner, cfg.inner_pad
+    dev = x.device
+    ppl = params_per_layer(S)
+    saved = dict(layers=[], B=B, N=N) if need_grad else None
+
+    R = ops.streams_expand(x, B, S) if S > 1 else x.reshape(M, D)
+    kv0 = None
+    for l in range(cfg.depth):
+        pa, pf = _split_layer(flat[l * ppl:(l + 1) * ppl], S)
+        Wq, WqT = cache.get((l, 'wq'), pa['wq'], _pack_plain)
+        Wkv, WkvT = cache.get((l, 'wkv'), pa['wkv'], _pack_plain)
+        Wo, WoT = cache.get((l, 'wo'), pa['wo'], _pack_plain)
+        W1, W1T = cache.get((l, 'w1'), pf['w1'], lambda w: _pack_w1(w, I, Ip))
+        W2, W2T = cache.get((l, 'w2'), pf['w2'], lambda w: _pack_w2(w, I, Ip))
+
+        # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
+        if S > 1:
+            X, XN, mean, rstd, coef = ops.hc_width_fwd(R, pa['hc'], pa['ln'], B, S, N, D, want_x=True)
+        else:
+            XN, X, mean, rstd = ops.layernorm_fwd(R, pa['ln'], want_copy=True)
+            coef = None
+        Q = _empty((M, H * dh), BF16, dev)
+        ops.gemm_nt(XN, Wq, Q)
+        KV = _empty((M, 2 * dh), BF16, dev)
+        ops.gemm_nt(X, Wkv, KV)                          # k / v from the UN-normalised branch input (:325 vs :347)
+        K, Vown = KV[:, :dh], KV[:, dh:]
+        if cfg.add_value_residual and kv0 is not None:
+            V = ops.value_residual_mix(Vown, kv0[:, dh:])  # :357-358
+        else:
+            V = Vown
+        if kv0 is None:
+            kv0 = KV                                      # :534-535 (layer-0 values, pre-mix)
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh)
+        Y = _empty((M, D), BF16, dev)
+        ops.gemm_nt(AO, Wo, Y)
+        R1 = ops.hc_depth_fwd(R, Y, coef, B, S, N, D) if S > 1 else ops.residual_add(R, Y)
+
+        # ---------------- feed-forward branch (audiolm_pytorch.py:246-260) ----------------
+        if S > 1:
+            X2, XN2, mean2, rstd2, coef2 = ops.hc_width_fwd(R1, pf['hc'], pf['ln'], B, S, N, D, want_x=True)
+        else:
+            XN2, X2, mean2, rstd2 = ops.layernorm_fwd(R1, pf['ln'], want_copy=False)
+            coef2 = None
+        U = _empty((M, 2 * Ip), BF16, dev)
+        ops.gemm_nt(XN2, W1, U)
+        HN, mean3, rstd3 = ops.geglu_ln_fwd(U, pf['ln3'], I, Ip)
+        Y2 = _empty((M, D), BF16, dev)
+        ops.gemm_nt(HN, W2, Y2)
+        R2 = ops.hc_depth_fwd(R1, Y2, coef2, B, S, N, D) if S > 1 else ops.residual_add(R1, Y2)
+
+        if need_grad:
+            saved['layers'].append(dict(R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Q=Q, KV=KV, V=V, AO=AO, LSE=LSE, Y=Y,
+                                        R1=R1, X2=X2, XN2=XN2, mean2=mean2, rstd2=rstd2, coef2=coef2, U=U, HN=HN, mean3=mean3,
+                                        rstd3=rstd3, Y2=Y2, mixed=V is not Vown))
+        R = R2
+
+    xs = ops.streams_reduce(R, B, S).reshape(M, D) if S > 1 else R        # :551
+    hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])                  # :555
+    if need_grad:
+        saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
+    return hn, saved
+
+
+def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None):
+    """dhn bf16 [M, D] -> (dx fp32 [B, N, D] (already scaled by grad_shrink alpha), list of parameter grads aligned with `flat`)."""
+    B, N = saved['B'], saved['N']
+    D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
+    M = B * N
+    I, Ip = cfg.inner, cfg.inner_pad
+    dev = dhn.device
+    ppl = params_per_layer(S)
+    grads = [None] * len(flat)
+
+    dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
+    grads[-1] = dgam
+    dR = ops.streams_expand(dxs.view(B, N, D), B, S) if S > 1 else dxs
+    acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if cfg.add_value_residual and cfg.depth > 1 else None
+
+    for l in reversed(range(cfg.depth)):
+        sv = saved['layers'][l]
+        base = l * ppl
+        pa, pf = _split_layer(flat[base:base + ppl], S)
+        Wq, WqT = cache.get((l, 'wq'), pa['wq'], _pack_plain)
+        Wkv, WkvT = cache.get((l, 'wkv'), pa['wkv'], _pack_plain)
+        Wo, WoT = cache.get((l, 'wo'), pa['wo'], _pack_plain)
+        W1, W1T = cache.get((l, 'w1'), pf['w1'], lambda w: _pack_w1(w, I, Ip))
+        W2, W2T = cache.get((l, 'w2'), pf['w2'], lambda w: _pack_w2(w, I, Ip))
+        hc_n = 7 if S > 1 else 0
+        ia = base + hc_n                      # index of attn ln gamma
+        iff = base + hc_n + 4 + hc_n          # index of ff ln gamma
+
+        # ================= feed-forward branch =================
+        if S > 1:
+            dY2, dbeta2 = ops.hc_depth_bwd(dR, sv['Y2'], sv['coef2'], B, S, N, D)
+        else:
+            dY2 = ops.f32_to_bf16(dR)
+        dHN = _empty((M, Ip), BF16, dev)
+        ops.gemm_nt(dY2, W2T, dHN)                                            # dHN = dY2 @ W2
+        dY2T = ops.transpose(dY2)
+        HNT = ops.transpose(sv['HN'])
+        dW2 = _empty((D, I), F32, dev)
+        ops.gemm_nt(dY2T, HNT[:I], dW2)                                       # dW2 = dY2^T @ HN
+        dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], pf['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
+        dXN2 = _empty((M, D), BF16, dev)
+        ops.gemm_nt(dU, W1T, dXN2)                                            # dXN2 = dU @ W1
+        dUT = ops.transpose(dU)
+        XN2T = ops.transpose(sv['XN2'])
+        dW1 = _empty((2 * I, D), F32, dev)
+        ops.gemm_nt(dUT[:I], XN2T, dW1[:I])
+        ops.gemm_nt(dUT[Ip:Ip + I], XN2T, dW1[I:])
+        xsrc = sv['X2'] if S > 1 else sv['R1']
+        dX2, dgl = ops.layernorm_bwd(dXN2, xsrc, sv['mean2'], sv['rstd2'], pf['ln'])
+        if S > 1:
+            dR1, hg = ops.hc_width_bwd(dR, dX2, sv['R1'], sv['coef2'], dbeta2, pf['hc'], B, S, N, D)
+            for j, k in enumerate(HC_KEYS):
+                grads[base + hc_n + 4 + j] = hg[k]
+        else:
+            dR1 = ops.add_f32(dR, dX2)
+        grads[iff], grads[iff + 1], grads[iff + 2], grads[iff + 3] = dgl, dW1, dg3, dW2
+
+        # ================= attention branch =================
+        if S > 1:
+            dY, dbeta = ops.hc_depth_bwd(dR1, sv['Y'], sv['coef'], B, S, N, D)
+        else:
+            dY = ops.f32_to_bf16(dR1)
+        dAO = _empty((M, H * dh), BF16, dev)
+        ops.gemm_nt(dY, WoT, dAO)
+        dYT = ops.transpose(dY)
+        AOT = ops.transpose(sv['AO'])
+        dWo = _empty((D, H * dh), F32, dev)
+        ops.gemm_nt(dYT, AOT, dWo)
+        KV = sv['KV']
+        dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh)
+        if acc_v0 is None:
+            mode = 0
+        elif sv['mixed']:
+            mode = 1
+        else:
+            mode = 2                                                          # layer 0: receives every later layer's 0.5 * dV
+        dKV = ops.kv_grad_pack(dkv32, acc_v0, mode, dh)
+        dXN = _empty((M, D), BF16, dev)
+        ops.gemm_nt(dQ, WqT, dXN)
+        dQT = ops.transpose(dQ)
+        XNT = ops.transpose(sv['XN'])
+        dWq = _empty((H * dh, D), F32, dev)
+        ops.gemm_nt(dQT, XNT, dWq)
+        dXkv = _empty((M, D), BF16, dev)
+        ops.gemm_nt(dKV, WkvT, dXkv)
+        dKVT = ops.transpose(dKV)
+        XT = ops.transpose(sv['X'])
+        dWkv = _empty((2 * dh, D), F32, dev)
+        ops.gemm_nt(dKVT, XT, dWkv)
+        xsrc = sv['X'] if S > 1 else sv['R']
+        dX, dgla = ops.layernorm_bwd(dXN, xsrc, sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
+        if S > 1:
+            dR, hg = ops.hc_width_bwd(dR1, dX, sv['R'], sv['coef'], dbeta, pa['hc'], B, S, N, D)
+            for j, k in enumerate(HC_KEYS):
+                grads[base + j] = hg[k]
+        else:
+            dR = ops.add_f32(dR1, dX)
+        grads[ia], grads[ia + 1], grads[ia + 2], grads[ia + 3] = dgla, dWq, dWkv, dWo
+        sv.clear()
+        if on_layer_grads is not None:
+            on_layer_grads(l, grads[base:base + ppl])
+
+    dx = ops.streams_reduce(dR, B, S) if S > 1 else dR.view(B, N, D)
+    return dx, grads
+
+
+class TransformerStackFn(torch.autograd.Function):
+    """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states bf16 [B*N, D]."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, cfg, cache, hooks, *flat):
+        need = any(t.requires_grad for t in flat) or x.requires_grad
+        xin = x.detach().contiguous().to(F32)
+        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need)
+        ctx.saved, ctx.cfg, ctx.cache, ctx.mask, ctx.hooks = saved, cfg, cache, mask_u8, hooks
+        ctx.flat = flat
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        cfg = ctx.cfg
+        flat = [t.detach() for t in ctx.flat]
+        dhn = dhn.contiguous()
+        if dhn.dtype != BF16:
+            dhn = dhn.to(BF16)
+        dx, grads = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks)
+        ctx.saved = None
+        dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478
+        out = []
+        for p, g in zip(ctx.flat, grads):
+            out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
+        return (dx, None, None, None, None, *out)

@@ -1,0 +1,265 @@
+// Token-id side of the hot path (gfx950, HBM-bound byte/index work -- deliberately NOT reshaped into GEMMs):
+//   * embedding assembly: per-quantizer offset embedding + quantizer-position embedding + start tokens + concat
+//     (reference audiolm_pytorch.py:709-713, :894-918, :1186-1223) and its scatter-add backward (x grad_shrink alpha, :93-94, :478)
+//   * row gather / scatter used to regroup the final hidden states per logit head ('b (n q) d -> q (b n) d', :965-983, :1325-1361)
+//   * cross-entropy forward (online log-sum-exp, fp32) and backward (softmax - onehot, bf16 for the dgrad/wgrad GEMMs)
+//     (reference F.cross_entropy(ignore_index = -1), audiolm_pytorch.py:1561-1565, :1839-1849, :2122-2132)
+//   * value-residual mixing v <- (v + v_layer0) / 2 (:357-358) and the matching gradient fan-in.
+#include "common.hpp"
+#include "../../include/audiolm_hip.h"
+
+namespace {
+
+constexpr int MAX_TABLES = 8;
+struct Tables { const float* p[MAX_TABLES]; };
+struct GradTables { float* p[MAX_TABLES]; };
+
+// source code: (table_id << 24) | row ; -1 = none (zero vector: padded position, get_embeds :176-181)
+__device__ __forceinline__ const float* src_row(const Tables& t, int code, int D) {
+    return t.p[code >> 24] + (long long)(code & 0xffffff) * D;
+}
+
+__global__ __launch_bounds__(256) void embed_assemble_kernel(Tables tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
+                                                             float* __restrict__ out, long long rows, int D) {
+    const int d4 = D / 4;
+    const long long total = rows * d4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d4;
+        const int e = (int)(i % d4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int a = src_a[r], b = src_b[r];
+        if (a >= 0) v = *reinterpret_cast<const float4*>(src_row(tabs, a, D) + e);
+        if (b >= 0) {
+            const float4 w = *reinterpret_cast<const float4*>(src_row(tabs, b, D) + e);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<float4*>(out + r * D + e) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_scatter_kernel(GradTables tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
+                                                            const float* __restrict__ dout, float alpha, long long rows, int D) {
+    const long long total = rows * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / D;
+        const int e = (int)(i % D);
+        const float g = dout[i] * alpha;
+        const int a = src_a[r], b = src_b[r];
+        if (a >= 0) atomicAdd(tabs.p[a >> 24] + (long long)(a & 0xffffff) * D + e, g);
+        if (b >= 0) atomicAdd(tabs.p[b >> 24] + (long long)(b & 0xffffff) * D + e, g);
+    }
+}
+
+// out[r] = in[idx[r]] (idx < 0 -> zero row)           bf16 rows, D % 8 == 0
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ in, long long ld_in, const int* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, long long ld_out, long long rows, int D) {
+    const int d8 = D / 8;
+    const long long total = rows * d8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d8;
+        const int e = (int)(i % d8) * 8;
+        const int s = idx[r];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (s >= 0) v = *reinterpret_cast<const uint4*>(in + (long long)s * ld_in + e);
+        *reinterpret_cast<uint4*>(out + r * ld_out + e) = v;
+    }
+}
+// out[idx[r]] = in[r] (idx < 0 skipped; idx must be injective; untouched rows keep their previous contents)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ in, long long ld_in, const int* __restrict__ idx,
+                                                           bf16_t* __restrict__ out, long long ld_out, long long rows, int D) {
+    const int d8 = D / 8;
+    const long long total = rows * d8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d8;
+        const int e = (int)(i % d8) * 8;
+        const int s = idx[r];
+        if (s >= 0) *reinterpret_cast<uint4*>(out + (long long)s * ld_out + e) = *reinterpret_cast<const uint4*>(in + r * ld_in + e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// cross entropy: one wave per row
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long long ld, const long long* __restrict__ labels,
+                                                     float* __restrict__ loss, float* __restrict__ lse_out, long long rows, int C, int ignore) {
+    const int lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        const float* lp = logits + r * ld;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lp[c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += __expf(lp[c] - mx);
+        s = wave_sum(s);
+        const float lse = mx + logf(s);
+        if (lane == 0) {
+            const long long lab = labels[r];
+            lse_out[r] = lse;
+            loss[r] = (lab == ignore || lab < 0 || lab >= C) ? 0.f : (lse - lp[lab]);
+        }
+    }
+}
+
+// dlogits[r][c] = (exp(logit - lse) - [c == label]) * gscale[0]   (ignored rows -> 0; pad columns [C, Cpad) -> 0)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long long ld, const long long* __restrict__ labels,
+                                                     const float* __restrict__ lse_in, const float* __restrict__ gscale,
+                                                     bf16_t* __restrict__ dlogits, long long ldd, long long rows, int C, int Cpad, int ignore) {
+    const int lane = threadIdx.x & 63;
+    const float gs = *gscale;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        const long long lab = labels[r];
+        const bool ign = (lab == ignore || lab < 0 || lab >= C);
+        const float lse = lse_in[r];
+        const float* lp = logits + r * ld;
+        bf16_t* dp = dlogits + r * ldd;
+        for (int c = lane; c < Cpad; c += 64) {
+            float v = 0.f;
+            if (!ign && c < C) v = (__expf(lp[c] - lse) - (c == lab ? 1.f : 0.f)) * gs;
+            dp[c] = f2bf(v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ in, long long n, float* __restrict__ out, float scale) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += in[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = t * scale;
+    }
+}
+
+// vmix[m][0:64] = 0.5 * (v[m] + v0[m])     (bf16, 8 lanes per row)
+__global__ __launch_bounds__(256) void vmix_kernel(const bf16_t* __restrict__ v, long long ldv, const bf16_t* __restrict__ v0, long long ldv0,
+                                                   bf16_t* __restrict__ out, long long ldo, long long rows, int dh) {
+    const int c8 = dh / 8;
+    const long long total = rows * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c8;
+        const int e = (int)(i % c8) * 8;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(v + r * ldv + e);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(v0 + r * ldv0 + e);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(0.5f * (bf2f((bf16_t)a[j]) + bf2f((bf16_t)b[j])));
+        *reinterpret_cast<bf16x8*>(out + r * ldo + e) = o;
+    }
+}
+
+// gradient fan-in of the value residual.  dk, dv: fp32 [rows][ld] from the attention backward (dv is the grad wrt the MIXED v).
+//   mode 0 (no value residual) : dkv = (dk, dv)
+//   mode 1 (layer >= 1)        : dkv = (dk, 0.5 dv)          ; acc_v0 += 0.5 dv
+//   mode 2 (layer 0)           : dkv = (dk, dv + acc_v0)
+__global__ __launch_bounds__(256) void kv_grad_pack_kernel(const float* __restrict__ dk, const float* __restrict__ dv, long long ld,
+                                                           float* __restrict__ acc_v0, bf16_t* __restrict__ dkv, long long ldo, long long rows,
+                                                           int dh, int mode) {
+    const long long total = rows * dh;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / dh;
+        const int e = (int)(i % dh);
+        const float gk = dk[r * ld + e];
+        float gv = dv[r * ld + e];
+        if (mode == 1) {
+            gv *= 0.5f;
+            acc_v0[i] += gv;
+        } else if (mode == 2) {
+            gv += acc_v0[i];
+        }
+        dkv[r * ldo + e] = f2bf(gk);
+        dkv[r * ldo + dh + e] = f2bf(gv);
+    }
+}
+
+int grid_for(long long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
+
+}  // namespace
+
+extern "C" int alm_embed_assemble(const float* const* tables, int ntables, const int* src_a, const int* src_b, float* out, long long rows,
+                                  int D, void* stream) {
+    if (ntables > MAX_TABLES || (D & 3)) return ALM_ERR_BAD_ARG;
+    Tables t{};
+    for (int i = 0; i < ntables; ++i) t.p[i] = tables[i];
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3(grid_for(rows * (D / 4))), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, out, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// grad tables must be zero-initialised (or hold a running gradient); dout fp32 [rows][D]; alpha = grad_shrink factor
+extern "C" int alm_embed_scatter_add(float* const* grad_tables, int ntables, const int* src_a, const int* src_b, const float* dout, float alpha,
+                                     long long rows, int D, void* stream) {
+    if (ntables > MAX_TABLES) return ALM_ERR_BAD_ARG;
+    GradTables t{};
+    for (int i = 0; i < ntables; ++i) t.p[i] = grad_tables[i];
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, dout, alpha, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_gather_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D,
+                                    void* stream) {
+    if ((D & 7) || (ld_in & 7) || (ld_out & 7)) return ALM_ERR_BAD_ARG;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, idx,
+                       (bf16_t*)out, ld_out, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_scatter_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D,
+                                     void* stream) {
+    if ((D & 7) || (ld_in & 7) || (ld_out & 7)) return ALM_ERR_BAD_ARG;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(rows * (D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, idx,
+                       (bf16_t*)out, ld_out, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_cross_entropy_fwd(const float* logits, long long ld, const long long* labels, float* loss_rows, float* lse, long long rows,
+                                     int C, int ignore_index, void* stream) {
+    if (rows <= 0) return 0;
+    const int grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss_rows, lse, rows, C, ignore_index);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_cross_entropy_bwd(const float* logits, long long ld, const long long* labels, const float* lse, const float* gscale,
+                                     void* dlogits, long long ldd, long long rows, int C, int Cpad, int ignore_index, void* stream) {
+    if (rows <= 0) return 0;
+    if (Cpad < C || ldd < Cpad) return ALM_ERR_BAD_ARG;
+    const int grid = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, gscale, (bf16_t*)dlogits, ldd, rows,
+                       C, Cpad, ignore_index);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_reduce_sum(const float* in, long long n, float* out, float scale, void* stream) {
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out, scale);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long long ldv0, void* out, long long ldo, long long rows,
+                                      int dim_head, void* stream) {
+    if ((dim_head & 7) || (ldv & 7) || (ldv0 & 7) || (ldo & 7)) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(vmix_kernel, dim3(grid_for(rows * (dim_head / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v, ldv,
+                       (const bf16_t*)v0, ldv0, (bf16_t*)out, ldo, rows, dim_head);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, float* acc_v0, void* dkv, long long ldo, long long rows,
+                                int dim_head, int mode, void* stream) {
+    if (mode < 0 || mode > 2 || (mode && !acc_v0)) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(kv_grad_pack_kernel, dim3(grid_for(rows * dim_head)), dim3(256), 0, (hipStream_t)stream, dk, dv, ld, acc_v0, (bf16_t*)dkv,
+                       ldo, rows, dim_head, mode);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}

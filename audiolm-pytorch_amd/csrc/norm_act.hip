@@ -1,0 +1,357 @@
+// HBM-bound row kernels of the transformer block (gfx950):
+//   * bias-less LayerNorm fwd/bwd            -- reference audiolm_pytorch.py:191-198  (F.layer_norm, gamma only, eps 1e-5)
+//   * fused GEGLU + inner LayerNorm fwd/bwd  -- reference audiolm_pytorch.py:246-260  (gelu(gate) * x, gate = 2nd half; LN(inner))
+//   * column sums (two-stage parameter-gradient reductions, bias grads)
+// Statistics are fp32; activations are bf16 (the dtype the reference's autocast feeds its GEMMs), residual input fp32.
+// One wave (64 lanes) owns one LayerNorm row of <= 1024 features: 16-B coalesced loads, the row stays in registers,
+// reductions are wave-64 shuffles (no LDS, no block barrier).  The 2730-wide GEGLU row is owned by a 256-thread block.
+#include "common.hpp"
+#include "../../include/audiolm_hip.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma.  NI = ceil(D / 256) chunks of 4 features per lane.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TIN, int NI>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                                     bf16_t* __restrict__ y, long long ldy, bf16_t* __restrict__ xcopy, long long ldc,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += gridDim.x * wpb) {
+        float4 v[NI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            v[i] = (e < D) ? load4(x + (long long)row * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            if (e < D) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                q += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + LN_EPS);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            if (e < D) {
+                const float4 g = load4(gamma + e);
+                store4(y + (long long)row * ldy + e,
+                       make_float4((v[i].x - mean) * rstd * g.x, (v[i].y - mean) * rstd * g.y, (v[i].z - mean) * rstd * g.z,
+                                   (v[i].w - mean) * rstd * g.w));
+                if (xcopy) store4(xcopy + (long long)row * ldc + e, v[i]);
+            }
+        }
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: g = dy * gamma ; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ extra) ;
+// dgamma partial sums per block -> dgamma_part[gridDim.x][D] (reduced by colsum).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TX, typename TDX, int NI>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, const TX* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const bf16_t* __restrict__ extra, long long lde,
+                                                     TDX* __restrict__ dx, long long lddx, float* __restrict__ dgamma_part, int rows, int D) {
+    __shared__ float red[4][NI * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 dg[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 xh[NI], g[NI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            if (e < D) {
+                const float4 xv = load4(x + (long long)row * ldx + e);
+                const float4 d = load4(dy + (long long)row * lddy + e);
+                const float4 gm = load4(gamma + e);
+                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+            } else {
+                xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = (i * 64 + lane) * 4;
+            if (e < D) {
+                float4 o = make_float4(rstd * (g[i].x - c1 - xh[i].x * c2), rstd * (g[i].y - c1 - xh[i].y * c2),
+                                       rstd * (g[i].z - c1 - xh[i].z * c2), rstd * (g[i].w - c1 - xh[i].w * c2));
+                if (extra) {
+                    const float4 ex = load4(extra + (long long)row * lde + e);
+                    o.x += ex.x; o.y += ex.y; o.z += ex.z; o.w += ex.w;
+                }
+                store4(dx + (long long)row * lddx + e, o);
+            }
+        }
+    }
+    if (!dgamma_part) return;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(&red[wave][(i * 64 + lane) * 4]) = dg[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < D; e += 256)
+        dgamma_part[(long long)blockIdx.x * D + e] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// column sum: out[c] (+)= scale * sum_r in[r][c]   (fp32 or bf16 input)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, long long ld, int rows, int cols, float* __restrict__ out,
+                                                     float scale, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = wave; r < rows; r += 4) {
+            if constexpr (sizeof(T) == 2) s += bf2f(in[(long long)r * ld + c]);
+            else s += in[(long long)r * ld + c];
+        }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        const float v = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale;
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused GEGLU + LayerNorm(inner) forward.  u: [rows][ldu] bf16, x half at cols [0, I), gate half at [goff, goff + I).
+// h = gelu(gate) * x ; out = LN(h) * gamma (bf16, cols [I, Ipad) zero-filled).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GE_MAX = 12;   // supports inner widths up to 12 * 256 = 3072
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restrict__ u, long long ldu, int goff, const float* __restrict__ gamma,
+                                                           bf16_t* __restrict__ out, long long ldo, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, int rows, int I, int Ipad) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        float h[GE_MAX];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = t + 256 * j;
+            h[j] = 0.f;
+            if (e < I) {
+                const float xv = bf2f(u[(long long)row * ldu + e]);
+                const float gv = bf2f(u[(long long)row * ldu + goff + e]);
+                h[j] = gelu_f(gv) * xv;
+                s += h[j];
+            }
+        }
+        const float mean = block_sum256(s, red) / (float)I;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = t + 256 * j;
+            if (e < I) q += (h[j] - mean) * (h[j] - mean);
+        }
+        const float rstd = rsqrtf(block_sum256(q, red) / (float)I + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = t + 256 * j;
+            if (e < I) out[(long long)row * ldo + e] = f2bf((h[j] - mean) * rstd * gamma[e]);
+            else if (e < Ipad) out[(long long)row * ldo + e] = 0;
+        }
+        if (t == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// backward: dhn = grad wrt LN output (bf16 [rows][lddh]); writes du (bf16 [rows][ldu], both halves, pads zeroed) and
+// per-block dgamma partial sums dgamma_part[gridDim.x][I].
+__global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restrict__ dhn, long long lddh, const bf16_t* __restrict__ u,
+                                                           long long ldu, int goff, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           bf16_t* __restrict__ du, float* __restrict__ dgamma_part, int rows, int I, int Ipad) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    float dgam[GE_MAX];
+#pragma unroll
+    for (int j = 0; j < GE_MAX; ++j) dgam[j] = 0.f;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xv[GE_MAX], gv[GE_MAX], xh[GE_MAX], g[GE_MAX];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = t + 256 * j;
+            xv[j] = gv[j] = xh[j] = g[j] = 0.f;
+            if (e < I) {
+                xv[j] = bf2f(u[(long long)row * ldu + e]);
+                gv[j] = bf2f(u[(long long)row * ldu + goff + e]);
+                const float h = gelu_f(gv[j]) * xv[j];
+                const float d = bf2f(dhn[(long long)row * lddh + e]);
+                xh[j] = (h - mean) * rstd;
+                g[j] = d * gamma[e];
+                dgam[j] += d * xh[j];
+                s1 += g[j];
+                s2 += g[j] * xh[j];
+            }
+        }
+        const float c1 = block_sum256(s1, red) / (float)I;
+        const float c2 = block_sum256(s2, red) / (float)I;
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = t + 256 * j;
+            if (e < I) {
+                const float dh = rstd * (g[j] - c1 - xh[j] * c2);
+                du[(long long)row * ldu + e] = f2bf(dh * gelu_f(gv[j]));
+                du[(long long)row * ldu + goff + e] = f2bf(dh * xv[j] * gelu_grad_f(gv[j]));
+            } else if (e < Ipad) {
+                du[(long long)row * ldu + e] = 0;
+                du[(long long)row * ldu + goff + e] = 0;
+            }
+        }
+    }
+    if (!dgamma_part) return;
+#pragma unroll
+    for (int j = 0; j < GE_MAX; ++j) {
+        const int e = t + 256 * j;
+        if (e < I) dgamma_part[(long long)blockIdx.x * I + e] = dgam[j];
+    }
+}
+
+template <typename TIN>
+int launch_ln_fwd(const TIN* x, long long ldx, const float* gamma, bf16_t* y, long long ldy, bf16_t* xc, long long ldc, float* mean,
+                  float* rstd, int rows, int D, hipStream_t st) {
+    const int grid = min((rows + 3) / 4, 4096);
+    if (D <= 256) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 1>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 2>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 4>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 2048) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 8>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else return ALM_ERR_UNSUPPORTED;
+    return 0;
+}
+
+template <typename TX, typename TDX>
+int launch_ln_bwd(const bf16_t* dy, long long lddy, const TX* x, long long ldx, const float* mean, const float* rstd, const float* gamma,
+                  const bf16_t* extra, long long lde, TDX* dx, long long lddx, float* part, int grid, int rows, int D, hipStream_t st) {
+#define ALM_LNB(NI) hipLaunchKernelGGL((ln_bwd_kernel<TX, TDX, NI>), dim3(grid), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, extra, lde, dx, lddx, part, rows, D)
+    if (D <= 256) ALM_LNB(1);
+    else if (D <= 512) ALM_LNB(2);
+    else if (D <= 1024) ALM_LNB(4);
+    else if (D <= 2048) ALM_LNB(8);
+    else return ALM_ERR_UNSUPPORTED;
+#undef ALM_LNB
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int alm_ln_partial_blocks(int rows) { return min((rows + 3) / 4, 512); }
+
+extern "C" int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y, long long ldy, void* xcopy,
+                                 long long ldc, float* mean, float* rstd, int rows, int D, void* stream) {
+    if (rows <= 0) return 0;
+    if ((D & 3) || (ldx & 3) || (ldy & 3) || (xcopy && (ldc & 3))) return ALM_ERR_BAD_ARG;
+    int rc = x_is_bf16 ? launch_ln_fwd((const bf16_t*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, (hipStream_t)stream)
+                       : launch_ln_fwd((const float*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgamma_part must hold alm_ln_partial_blocks(rows) * D floats (or be NULL); reduce it with alm_colsum_f32.
+extern "C" int alm_layernorm_bwd(const void* dy, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
+                                 const float* rstd, const float* gamma, const void* extra, long long lde, void* dx, int dx_is_bf16,
+                                 long long lddx, float* dgamma_part, int rows, int D, void* stream) {
+    if (rows <= 0) return 0;
+    if ((D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (extra && (lde & 3))) return ALM_ERR_BAD_ARG;
+    const int grid = alm_ln_partial_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (x_is_bf16 && dx_is_bf16)
+        rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (bf16_t*)dx, lddx, dgamma_part, grid, rows, D, st);
+    else if (x_is_bf16)
+        rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (float*)dx, lddx, dgamma_part, grid, rows, D, st);
+    else if (dx_is_bf16)
+        rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const float*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (bf16_t*)dx, lddx, dgamma_part, grid, rows, D, st);
+    else
+        rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const float*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (float*)dx, lddx, dgamma_part, grid, rows, D, st);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate,
+                          void* stream) {
+    if (cols <= 0) return 0;
+    dim3 grid((cols + 63) / 64);
+    if (in_is_bf16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld, rows, cols, out, scale, accumulate);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld, rows, cols, out, scale, accumulate);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_geglu_partial_blocks(int rows) { return min(rows, 1024); }
+
+extern "C" int alm_geglu_ln_fwd(const void* u, long long ldu, int gate_offset, const float* gamma, void* out, long long ldo, float* mean,
+                                float* rstd, int rows, int inner, int inner_pad, void* stream) {
+    if (rows <= 0) return 0;
+    if (inner <= 0 || inner > GE_MAX * 256 || inner_pad < inner || inner_pad > GE_MAX * 256) return ALM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(geglu_ln_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, ldu, gate_offset, gamma,
+                       (bf16_t*)out, ldo, mean, rstd, rows, inner, inner_pad);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgamma_part: alm_geglu_partial_blocks(rows) * inner floats (or NULL).
+extern "C" int alm_geglu_ln_bwd(const void* dhn, long long lddh, const void* u, long long ldu, int gate_offset, const float* gamma,
+                                const float* mean, const float* rstd, void* du, float* dgamma_part, int rows, int inner, int inner_pad,
+                                void* stream) {
+    if (rows <= 0) return 0;
+    if (inner <= 0 || inner > GE_MAX * 256 || inner_pad < inner || inner_pad > GE_MAX * 256) return ALM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(geglu_ln_bwd_kernel, dim3(alm_geglu_partial_blocks(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dhn, lddh,
+                       (const bf16_t*)u, ldu, gate_offset, gamma, mean, rstd, (bf16_t*)du, dgamma_part, rows, inner, inner_pad);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}

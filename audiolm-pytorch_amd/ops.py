@@ -1,0 +1,325 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per `alm_*` entry).  PyTorch only supplies device
+memory and the stream; all arithmetic happens in libaudiolm_hip.so.  No CPU / eager fallback exists on purpose.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=None):
+    if not t.is_cuda:
+        raise _lib.AlmError('audiolm_pytorch_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback')
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.AlmError(f'expected {dtype}, got {t.dtype}')
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rows_ld(t):
+    """2-D row-major view -> (rows, cols, ld)."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ dense contractions
+
+def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
+    """C[..., M, N] (+)= alpha * A[..., M, K] @ B[..., N, K]^T (+ bias).  Up to two leading batch dims (broadcast via stride 0)."""
+    _chk(A, BF16), _chk(B, BF16), _chk(C)
+    assert A.stride(-1) == 1 and B.stride(-1) == 1 and C.stride(-1) == 1
+    nb = A.dim() - 2
+    assert nb in (0, 1, 2) and B.dim() == A.dim() and C.dim() == A.dim()
+    M, K = A.shape[-2:]
+    N = B.shape[-2]
+    assert B.shape[-1] == K and C.shape[-2] == M and C.shape[-1] == N, (A.shape, B.shape, C.shape)
+    bs = [1, 1]
+    sa, sb, sc = [0, 0], [0, 0], [0, 0]
+    for i in range(nb):
+        j = 2 - nb + i
+        bs[j] = A.shape[i]
+        sa[j], sb[j], sc[j] = A.stride(i), B.stride(i) if B.shape[i] != 1 else 0, C.stride(i)
+    _lib.call('alm_gemm_bf16_nt', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2),
+              bs[0], bs[1], sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), int(C.dtype == F32), int(accumulate), _st())
+    return C
+
+
+def transpose(src, rows_pad=None):
+    """bf16 [rows, cols] -> new bf16 [cols, rows_pad] with zero-filled pad columns (rows_pad = rows rounded up to 8)."""
+    _chk(src, BF16)
+    rows, cols, ld = _rows_ld(src)
+    rp = rows_pad or ((rows + 7) // 8 * 8)
+    dst = torch.empty((cols, rp), dtype=BF16, device=src.device)
+    _lib.call('alm_transpose_bf16', src.data_ptr(), dst.data_ptr(), rows, cols, ld, rp, rp, _st())
+    return dst
+
+
+def pack_weight(w, dst=None, dstT=None, rows_pad=None, cols_pad=None):
+    """fp32 [rows, cols] -> bf16 dst[rows_pad, >= cols_pad] and / or bf16 dstT[cols_pad, >= rows_pad], zero padded."""
+    _chk(w, F32)
+    rows, cols, ld = _rows_ld(w)
+    rp, cp = rows_pad or rows, cols_pad or cols
+    _lib.call('alm_pack_weight', w.data_ptr(), rows, cols, ld, _p(dst), dst.stride(0) if dst is not None else 0, rp, cp,
+              _p(dstT), dstT.stride(0) if dstT is not None else 0, _st())
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
+
+def layernorm_fwd(x, gamma, *, want_copy=False):
+    """x [rows, D] fp32|bf16 -> (y bf16, xcopy bf16|None, mean, rstd)."""
+    _chk(x)
+    rows, D, ld = _rows_ld(x)
+    y = torch.empty((rows, D), dtype=BF16, device=x.device)
+    xc = torch.empty((rows, D), dtype=BF16, device=x.device) if want_copy else None
+    mean = torch.empty(rows, dtype=F32, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    _lib.call('alm_layernorm_fwd', x.data_ptr(), int(x.dtype == BF16), ld, gamma.data_ptr(), y.data_ptr(), D, _p(xc), D, mean.data_ptr(),
+              rstd.data_ptr(), rows, D, _st())
+    return y, xc, mean, rstd
+
+
+def colsum(inp, out=None, scale=1.0, accumulate=False):
+    _chk(inp)
+    rows, cols, ld = _rows_ld(inp)
+    if out is None:
+        out = torch.empty(cols, dtype=F32, device=inp.device)
+    _lib.call('alm_colsum', inp.data_ptr(), int(inp.dtype == BF16), ld, rows, cols, out.data_ptr(), float(scale), int(accumulate), _st())
+    return out
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, extra=None, dx_dtype=F32, want_dgamma=True):
+    """-> (dx [rows, D] dx_dtype, dgamma [D] fp32 | None)."""
+    _chk(dy, BF16), _chk(x)
+    rows, D, lddy = _rows_ld(dy)
+    dx = torch.empty((rows, D), dtype=dx_dtype, device=dy.device)
+    part = None
+    if want_dgamma:
+        nblk = _lib.query('alm_ln_partial_blocks', rows)
+        part = torch.empty((nblk, D), dtype=F32, device=dy.device)
+    _lib.call('alm_layernorm_bwd', dy.data_ptr(), lddy, x.data_ptr(), int(x.dtype == BF16), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
+              gamma.data_ptr(), _p(extra), extra.stride(0) if extra is not None else 0, dx.data_ptr(), int(dx_dtype == BF16), D, _p(part),
+              rows, D, _st())
+    return dx, (colsum(part) if want_dgamma else None)
+
+
+def geglu_ln_fwd(u, gamma, inner, inner_pad):
+    """u bf16 [rows, 2 * inner_pad] (x | gate halves) -> (hn bf16 [rows, inner_pad], mean, rstd)."""
+    _chk(u, BF16)
+    rows, _, ldu = _rows_ld(u)
+    out = torch.empty((rows, inner_pad), dtype=BF16, device=u.device)
+    mean = torch.empty(rows, dtype=F32, device=u.device)
+    rstd = torch.empty(rows, dtype=F32, device=u.device)
+    _lib.call('alm_geglu_ln_fwd', u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), out.data_ptr(), inner_pad, mean.data_ptr(), rstd.data_ptr(),
+              rows, inner, inner_pad, _st())
+    return out, mean, rstd
+
+
+def geglu_ln_bwd(dhn, u, gamma, mean, rstd, inner, inner_pad):
+    """-> (du bf16 [rows, 2 * inner_pad], dgamma [inner])."""
+    rows, _, ldu = _rows_ld(u)
+    du = torch.empty_like(u)
+    nblk = _lib.query('alm_geglu_partial_blocks', rows)
+    part = torch.empty((nblk, inner), dtype=F32, device=u.device)
+    _lib.call('alm_geglu_ln_bwd', dhn.data_ptr(), dhn.stride(0), u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              du.data_ptr(), part.data_ptr(), rows, inner, inner_pad, _st())
+    return du, colsum(part)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64):
+    """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse)."""
+    _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
+    o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, N), dtype=F32, device=q.device)
+    _lib.call('alm_mqa_attn_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
+              o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
+    return o, lse
+
+
+def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64):
+    """-> (dq bf16 [B*N, H*dh], dkv fp32 [B*N, 2*dh] = (dk | dv))."""
+    _chk(dout, BF16)
+    dq = torch.empty_like(q)
+    dkv = torch.empty((B * N, 2 * dim_head), dtype=F32, device=q.device)
+    delta = torch.empty((B, H, N), dtype=F32, device=q.device)
+    _lib.call('alm_mqa_attn_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
+              o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
+              dkv.data_ptr() + 4 * dim_head, dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
+    return dq, dkv
+
+
+def value_residual_mix(v, v0):
+    rows, dh, _ = _rows_ld(v)
+    out = torch.empty((rows, dh), dtype=BF16, device=v.device)
+    _lib.call('alm_value_residual_mix', v.data_ptr(), v.stride(0), v0.data_ptr(), v0.stride(0), out.data_ptr(), dh, rows, dh, _st())
+    return out
+
+
+def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
+    rows = dkv_f32.shape[0]
+    out = torch.empty((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
+    _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(0), _p(acc_v0), out.data_ptr(),
+              out.stride(0), rows, dim_head, mode, _st())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ hyper-connections
+
+def hc_width_fwd(R, hc, ln_gamma, B, S, N, D, want_x=True):
+    """R fp32 [B, S, N, D]; hc = dict of the 7 hyper-connection parameters -> (x bf16|None, xn bf16, mean, rstd, coef)."""
+    _chk(R, F32)
+    M = B * N
+    dev = R.device
+    x = torch.empty((M, D), dtype=BF16, device=dev) if want_x else None
+    xn = torch.empty((M, D), dtype=BF16, device=dev)
+    mean = torch.empty(M, dtype=F32, device=dev)
+    rstd = torch.empty(M, dtype=F32, device=dev)
+    coef = torch.empty((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
+    _lib.call('alm_hc_width_fwd', R.data_ptr(), hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['sa'].data_ptr(), hc['Aa'].data_ptr(),
+              hc['wb'].data_ptr(), hc['sb'].data_ptr(), hc['Bb'].data_ptr(), ln_gamma.data_ptr(), _p(x), D, xn.data_ptr(), D,
+              mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), B, S, N, D, _st())
+    return x, xn, mean, rstd, coef
+
+
+def hc_depth_fwd(R, y, coef, B, S, N, D):
+    Rn = torch.empty_like(R)
+    _lib.call('alm_hc_depth_fwd', R.data_ptr(), y.data_ptr(), y.stride(0), coef.data_ptr(), Rn.data_ptr(), B, S, N, D, _st())
+    return Rn
+
+
+def hc_depth_bwd(dRn, y, coef, B, S, N, D):
+    M = B * N
+    dy = torch.empty((M, D), dtype=BF16, device=dRn.device)
+    dbeta = torch.empty((M, S), dtype=F32, device=dRn.device)
+    _lib.call('alm_hc_depth_bwd', dRn.data_ptr(), y.data_ptr(), y.stride(0), coef.data_ptr(), dy.data_ptr(), D, dbeta.data_ptr(), B, S, N, D, _st())
+    return dy, dbeta
+
+
+def hc_width_bwd(dRn, dx, R, coef, dbeta, hc, B, S, N, D):
+    """-> (dR fp32 [B,S,N,D], grads dict for the 7 hyper-connection parameters)."""
+    M = B * N
+    dR = torch.empty_like(R)
+    nblk = _lib.query('alm_hc_partial_blocks', M)
+    P = _lib.query('alm_hc_partial_width', S, D)
+    part = torch.empty((nblk, P), dtype=F32, device=R.device)
+    _lib.call('alm_hc_width_bwd', dRn.data_ptr(), dx.data_ptr(), dx.stride(0), R.data_ptr(), coef.data_ptr(), dbeta.data_ptr(),
+              hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['sa'].data_ptr(), hc['wb'].data_ptr(), hc['sb'].data_ptr(), dR.data_ptr(),
+              part.data_ptr(), B, S, N, D, _st())
+    g = colsum(part)
+    o = 0
+    grads = {}
+    for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ())):
+        n = 1
+        for d in shape:
+            n *= d
+        grads[name] = g[o:o + n].view(shape)
+        o += n
+    return dR, grads
+
+
+def streams_expand(x, B, S):
+    _chk(x, F32)
+    nd = x.numel() // B
+    R = torch.empty((B, S) + tuple(x.shape[1:]), dtype=F32, device=x.device)
+    _lib.call('alm_streams_expand', x.data_ptr(), R.data_ptr(), B, S, nd, _st())
+    return R
+
+
+def streams_reduce(R, B, S):
+    nd = R.numel() // (B * S)
+    x = torch.empty((B,) + tuple(R.shape[2:]), dtype=F32, device=R.device)
+    _lib.call('alm_streams_reduce', R.data_ptr(), x.data_ptr(), B, S, nd, _st())
+    return x
+
+
+def residual_add(x, y):
+    """fp32 x [rows, D] + bf16 y [rows, D] -> new fp32."""
+    rows, D = y.shape
+    out = torch.empty((rows, D), dtype=F32, device=y.device)
+    _lib.call('alm_residual_add', x.data_ptr(), y.data_ptr(), y.stride(0), out.data_ptr(), rows, D, _st())
+    return out
+
+
+def f32_to_bf16(a, b=None):
+    rows, D = a.shape
+    out = torch.empty((rows, D), dtype=BF16, device=a.device)
+    _lib.call('alm_f32_to_bf16', a.data_ptr(), _p(b), out.data_ptr(), D, rows, D, _st())
+    return out
+
+
+def add_f32(a, b):
+    out = torch.empty_like(a)
+    _lib.call('alm_add_f32', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ token-id side
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def embed_assemble(tables, src_a, src_b, rows, D):
+    out = torch.empty((rows, D), dtype=F32, device=src_a.device)
+    arr = _ptr_array(tables)
+    _lib.call('alm_embed_assemble', ctypes.cast(arr, ctypes.c_void_p), len(tables), src_a.data_ptr(), src_b.data_ptr(), out.data_ptr(), rows, D, _st())
+    return out
+
+
+def embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D):
+    arr = _ptr_array(grad_tables)
+    _lib.call('alm_embed_scatter_add', ctypes.cast(arr, ctypes.c_void_p), len(grad_tables), src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(),
+              float(alpha), rows, D, _st())
+
+
+def gather_rows(inp, idx, out=None):
+    rows = idx.numel()
+    D = inp.shape[1]
+    if out is None:
+        out = torch.empty((rows, D), dtype=BF16, device=inp.device)
+    _lib.call('alm_gather_rows_bf16', inp.data_ptr(), inp.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), rows, D, _st())
+    return out
+
+
+def scatter_rows(inp, idx, out):
+    rows = idx.numel()
+    _lib.call('alm_scatter_rows_bf16', inp.data_ptr(), inp.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), rows, inp.shape[1], _st())
+    return out
+
+
+def cross_entropy_fwd(logits, labels, C, ignore_index=-1):
+    """logits fp32 [rows, >= C]; labels int64 [rows] -> (loss_rows fp32, lse fp32)."""
+    _chk(logits, F32), _chk(labels, torch.int64)
+    rows = labels.numel()
+    loss = torch.empty(rows, dtype=F32, device=logits.device)
+    lse = torch.empty(rows, dtype=F32, device=logits.device)
+    _lib.call('alm_cross_entropy_fwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), loss.data_ptr(), lse.data_ptr(), rows, C, ignore_index, _st())
+    return loss, lse
+
+
+def cross_entropy_bwd(logits, labels, lse, gscale, C, Cpad, ignore_index=-1):
+    rows = labels.numel()
+    d = torch.empty((rows, Cpad), dtype=BF16, device=logits.device)
+    _lib.call('alm_cross_entropy_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(), gscale.data_ptr(), d.data_ptr(), Cpad,
+              rows, C, Cpad, ignore_index, _st())
+    return d
+
+
+def reduce_sum(x, scale=1.0):
+    out = torch.empty((), dtype=F32, device=x.device)
+    _lib.call('alm_reduce_sum', x.data_ptr(), x.numel(), out.data_ptr(), float(scale), _st())
+    return out

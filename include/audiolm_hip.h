@@ -1,0 +1,108 @@
+/* libaudiolm_hip.so -- C ABI of the MI355X (gfx950) kernels behind the audiolm token-transformer training hot path.
+ *
+ * The reference (lucidrains/audiolm-pytorch) has no FFI of its own: its hot path is stock PyTorch ops.  This header is the
+ * drop-in boundary a maintainer binds instead of those ops (ctypes stub: INTEGRATION.md; the in-tree binding is
+ * audiolm-pytorch_amd/_lib.py).  Each entry cites the reference code it replaces (paths relative to
+ * /root/reference/audiolm_pytorch/).
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch allocator), incl. workspaces
+ *   - bf16 tensors are raw uint16 bit patterns (void*); fp32 statistics / master weights / gradients are float*
+ *   - `ld*` = leading dimension (row stride) in ELEMENTS; row-major everywhere
+ *   - kernels are stateless, re-entrant, asynchronous on `stream` (a hipStream_t passed as void*); callable from any thread
+ *   - return 0 on success, a hipError_t value (> 0) or ALM_ERR_* (>= 10001) otherwise; nothing is printed
+ */
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALM_ERR_BAD_ARG 10001
+#define ALM_ERR_UNSUPPORTED 10002
+
+/* ---- dense contractions (MFMA) -------------------------------------------------------------------------------------------
+ * C[z1][z2][M,N] (+)= alpha * A[z1][z2][M,K] . B[z1][z2][N,K]^T (+ bias[N]);  bf16 operands, fp32 accumulate, C bf16 or fp32.
+ * Replaces aten::mm / addmm / bmm behind nn.Linear and einsum at audiolm_pytorch.py:255-259 (FFN), :351 (to_q, to_kv),
+ * :395 (to_out), :719 / :961 (semantic logits, bias), :972 / :1335 / :1350 (per-quantizer logit heads, batched over z2 = q),
+ * and all their dgrad / wgrad forms (operands transposed with alm_transpose_bf16 / alm_pack_weight).
+ * K % 8 == 0, lda/ldb % 8 == 0, batch strides % 8 == 0. */
+int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
+                     long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
+                     long long sC2, float alpha, int out_f32, int accumulate, void* stream);
+/* dst[c][r] = src[r][c]; columns [rows, rows_pad) of dst are zero-filled (K-padding of a transposed GEMM operand). */
+int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, void* stream);
+/* fp32 master weight -> zero-padded bf16 copy (dst, may be NULL) and zero-padded bf16 transpose (dstT, may be NULL).
+ * This is the autocast weight cast of trainer.py:1241 (accelerator.autocast), done once per optimiser step. */
+int alm_pack_weight(const float* src, int rows, int cols, long long ld_src, void* dst, long long ld_dst, int rows_pad, int cols_pad,
+                    void* dstT, long long ld_dstT, void* stream);
+
+/* ---- LayerNorm (gamma only, eps 1e-5): audiolm_pytorch.py:191-198 ---------------------------------------------------------- */
+int alm_ln_partial_blocks(int rows);
+int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y_bf16, long long ldy, void* xcopy_bf16,
+                      long long ldc, float* mean, float* rstd, int rows, int D, void* stream);
+int alm_layernorm_bwd(const void* dy_bf16, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
+                      const float* rstd, const float* gamma, const void* extra_bf16, long long lde, void* dx, int dx_is_bf16,
+                      long long lddx, float* dgamma_part, int rows, int D, void* stream);
+/* out[c] (+)= scale * sum_r in[r][c]  (second stage of every parameter-gradient reduction; bias gradients) */
+int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate, void* stream);
+
+/* ---- GEGLU + inner LayerNorm: audiolm_pytorch.py:246-260 (gate = second half, exact-erf GELU, LN over int(dim*8/3)) -------- */
+int alm_geglu_partial_blocks(int rows);
+int alm_geglu_ln_fwd(const void* u_bf16, long long ldu, int gate_offset, const float* gamma, void* out_bf16, long long ldo, float* mean,
+                     float* rstd, int rows, int inner, int inner_pad, void* stream);
+int alm_geglu_ln_bwd(const void* dhn_bf16, long long lddh, const void* u_bf16, long long ldu, int gate_offset, const float* gamma,
+                     const float* mean, const float* rstd, void* du_bf16, float* dgamma_part, int rows, int inner, int inner_pad,
+                     void* stream);
+
+/* ---- causal multi-query flash attention: attend.py:69-146 as called from audiolm_pytorch.py:381-394 ------------------------
+ * q (B,N,H*64) bf16, k/v (B,N,64) bf16 single shared head, mask (B,N) uint8 (1 = attend) or NULL, scale = 64^-0.5.
+ * lse fp32 [B][H][N].  Backward: dq bf16, dk/dv fp32 [B*N][lddk] (64 columns each), delta = fp32 workspace [B][H][N]. */
+int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
+                     void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, void* stream);
+int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
+                     const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq, float* dk,
+                     float* dv, long long lddk, float* delta, int B, int N, int H, int dim_head, float scale, void* stream);
+/* value residual, audiolm_pytorch.py:353-358 / :534-535 */
+int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long long ldv0, void* out, long long ldo, long long rows,
+                           int dim_head, void* stream);
+int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, float* acc_v0, void* dkv_bf16, long long ldo, long long rows,
+                     int dim_head, int mode, void* stream);
+
+/* ---- hyper-connection residual streams: third-party `hyper_connections` used at audiolm_pytorch.py:24, 446-454, 524, 551 ----
+ * R fp32 [B][S][N][D].  coef: per-token fp32 record of alm_hc_coef_width(S) floats (alpha | beta | pre-activations | 1/norm). */
+int alm_hc_coef_width(int S);
+int alm_hc_partial_width(int S, int D);
+int alm_hc_partial_blocks(long long tokens);
+int alm_hc_width_fwd(const float* R, const float* hc_gamma, const float* Wa, const float* sa, const float* Aa, const float* wb,
+                     const float* sb, const float* Bb, const float* ln_gamma, void* x_bf16, long long ldx, void* xn_bf16, long long ldxn,
+                     float* mean, float* rstd, float* coef, int B, int S, int N, int D, void* stream);
+int alm_hc_depth_fwd(const float* R, const void* y_bf16, long long ldy, const float* coef, float* Rn, int B, int S, int N, int D,
+                     void* stream);
+int alm_hc_depth_bwd(const float* dRn, const void* y_bf16, long long ldy, const float* coef, void* dy_bf16, long long lddy, float* dbeta,
+                     int B, int S, int N, int D, void* stream);
+int alm_hc_width_bwd(const float* dRn, const float* dx, long long lddx, const float* R, const float* coef, const float* dbeta,
+                     const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR, float* partial,
+                     int B, int S, int N, int D, void* stream);
+int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
+int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */
+int alm_residual_add(const float* x, const void* y_bf16, long long ldy, float* out, long long rows, int D, void* stream);
+int alm_f32_to_bf16(const float* a, const float* b_or_null, void* out_bf16, long long ldo, long long rows, int D, void* stream);
+int alm_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
+
+/* ---- token-id side: embedding assembly (:709-713, :894-918, :1186-1223), logit-head regrouping (:965-983, :1325-1361),
+ *      cross-entropy (:1561-1565, :1839-1849, :2122-2132) -------------------------------------------------------------------- */
+int alm_embed_assemble(const float* const* tables, int ntables, const int* src_a, const int* src_b, float* out, long long rows, int D,
+                       void* stream);
+int alm_embed_scatter_add(float* const* grad_tables, int ntables, const int* src_a, const int* src_b, const float* dout, float alpha,
+                          long long rows, int D, void* stream);
+int alm_gather_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
+int alm_scatter_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
+int alm_cross_entropy_fwd(const float* logits, long long ld, const long long* labels, float* loss_rows, float* lse, long long rows, int C,
+                          int ignore_index, void* stream);
+int alm_cross_entropy_bwd(const float* logits, long long ld, const long long* labels, const float* lse, const float* gscale, void* dlogits_bf16,
+                          long long ldd, long long rows, int C, int Cpad, int ignore_index, void* stream);
+int alm_reduce_sum(const float* in, long long n, float* out, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports exactly the symbols include/audiolm_hip.h declares
+(and the ctypes binding table covers every one of them).  No compute calls: there is no GPU here."""
+import os
+import re
+
+import audiolm_pytorch_amd  # noqa: F401
+from audiolm_pytorch_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'audiolm_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(alm_\w+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header():
+    names = set(_declared())
+    table = set(_lib.SIGNATURES)
+    assert names == table, (sorted(names - table), sorted(table - names))
+
+
+def test_header_argument_counts_match_binding():
+    src = open(os.path.join(ROOT, 'include', 'audiolm_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    for m in re.finditer(r'\bint\s+(alm_\w+)\s*\((.*?)\)\s*;', src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ('', 'void') else len(args.split(','))
+        assert n == len(_lib.SIGNATURES[name]), (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_size_queries_run_on_host():
+    assert _lib.query('alm_hc_coef_width', 4) == 52
+    assert _lib.query('alm_hc_partial_width', 4, 1024) == 1024 * 7 + 26
+    assert _lib.query('alm_ln_partial_blocks', 16384) == 512
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from audiolm_pytorch_amd import ops
+    with pytest.raises(_lib.AlmError):
+        ops.gemm_nt(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8))

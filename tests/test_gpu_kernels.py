@@ -1,0 +1,339 @@
+"""Per-kernel parity: every C-ABI entry (through audiolm_pytorch_amd.ops -> ctypes -> libaudiolm_hip.so) against a plain fp32
+PyTorch restatement of the same op / the oracle function, on a real MI355X.  Tolerances are written next to each check:
+  * fp32 outputs of bf16-input MFMA contractions: <= 2e-5 of the output's max-abs (products exact, fp32 accumulate)
+  * bf16 outputs: one bf16 rounding of an fp32 result -> <= 2^-8 relative to max-abs (4e-3)
+  * integer / index work: bit exact
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd import ops as o
+    return o
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=F32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+def relmax(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / transpose / pack
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 128), (300, 200, 72), (1000, 520, 1024), (130, 1025, 64), (257, 129, 2736)])
+@pytest.mark.parametrize('out_f32', [True, False])
+def test_gemm_nt(ops, M, N, K, out_f32):
+    A, B = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, dtype=BF16)
+    C = torch.full((M, N), float('nan'), dtype=F32 if out_f32 else BF16, device=dev())
+    ops.gemm_nt(A, B, C)
+    ref = A.double() @ B.double().t()
+    err = relmax(C, ref)
+    assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
+
+
+def test_gemm_bias_alpha_accumulate_strided(ops):
+    M, N, K = 200, 136, 192
+    Abig, Bbig = rnd(M, K + 64, seed=3, dtype=BF16), rnd(N, K + 8, seed=4, dtype=BF16)
+    A, B = Abig[:, :K], Bbig[:, :K]                       # lda != K
+    bias = rnd(N, seed=5)
+    Cbig = rnd(M, N + 24, seed=6)
+    C0 = Cbig.clone()
+    ops.gemm_nt(A, B, Cbig[:, :N], bias=bias, alpha=0.5, accumulate=True)
+    ref = C0[:, :N].double() + 0.5 * (A.double() @ B.double().t()) + bias.double()
+    assert relmax(Cbig[:, :N], ref) <= 2e-5
+    assert torch.equal(Cbig[:, N:], C0[:, N:]), 'GEMM wrote outside its N columns'
+
+
+def test_gemm_batched_two_level(ops):
+    G, Bn, R, C, D = 3, 2, 70, 33, 64
+    A = rnd(G, R, D, seed=7, dtype=BF16)
+    W = rnd(G, C, D, seed=8, dtype=BF16)
+    out = torch.zeros((G, R, 40), dtype=F32, device=dev())
+    ops.gemm_nt(A, W, out[:, :, :C])
+    ref = torch.einsum('grd,gcd->grc', A.double(), W.double())
+    assert relmax(out[:, :, :C], ref) <= 2e-5
+    assert float(out[:, :, C:].abs().max()) == 0.0
+    A4 = rnd(Bn, G, R, D, seed=9, dtype=BF16)
+    out4 = torch.zeros((Bn, G, R, C), dtype=BF16, device=dev())
+    ops.gemm_nt(A4, W.unsqueeze(0).expand(Bn, -1, -1, -1), out4)
+    ref4 = torch.einsum('bgrd,gcd->bgrc', A4.double(), W.double())
+    assert relmax(out4, ref4) <= 4e-3
+
+
+def test_transpose_and_pack(ops):
+    src = rnd(150, 70, seed=10, dtype=BF16)
+    t = ops.transpose(src)
+    assert t.shape == (70, 152)
+    assert torch.equal(t[:, :150], src.t()) and float(t[:, 150:].float().abs().max()) == 0.0
+    w = rnd(170, 64, seed=11)
+    W = torch.full((176, 64), 7.0, dtype=BF16, device=dev())
+    WT = torch.full((64, 176), 7.0, dtype=BF16, device=dev())
+    ops.pack_weight(w, W, WT, rows_pad=176, cols_pad=64)
+    assert torch.equal(W[:170], w.to(BF16)) and float(W[170:].float().abs().max()) == 0.0
+    assert torch.equal(WT[:, :170], w.to(BF16).t()) and float(WT[:, 170:].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
+
+@pytest.mark.parametrize('D', [64, 256, 1024, 2048])
+@pytest.mark.parametrize('xdt', [F32, BF16])
+def test_layernorm(ops, D, xdt):
+    rows = 37
+    x = rnd(rows, D, seed=12, scale=2.0).add_(0.3).to(xdt)
+    gamma = (1 + 0.1 * rnd(D, seed=13)).contiguous()
+    y, xc, mean, rstd = ops.layernorm_fwd(x, gamma, want_copy=True)
+    xr = x.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, torch.zeros_like(gr))
+    assert relmax(y, ref) <= 4e-3, relmax(y, ref)
+    assert torch.equal(xc, x.to(BF16))
+    assert torch.allclose(mean, x.float().mean(-1), atol=1e-5) and relmax(rstd, (x.float().var(-1, unbiased=False) + 1e-5).rsqrt()) <= 1e-5
+    dy = rnd(rows, D, seed=14, dtype=BF16)
+    extra = rnd(rows, D, seed=15, dtype=BF16)
+    ref.backward(dy.float())
+    dx, dg = ops.layernorm_bwd(dy, x, mean, rstd, gamma, extra=extra, dx_dtype=F32)
+    assert relmax(dx, xr.grad + extra.float()) <= 2e-5, relmax(dx, xr.grad + extra.float())
+    assert relmax(dg, gr.grad) <= 2e-5, relmax(dg, gr.grad)
+    dxb, _ = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx_dtype=BF16, want_dgamma=False)
+    assert relmax(dxb, xr.grad) <= 4e-3
+
+
+@pytest.mark.parametrize('I', [170, 682, 2730])
+def test_geglu_ln(ops, I):
+    rows, Ip = 19, (I + 7) // 8 * 8
+    u = torch.zeros((rows, 2 * Ip), dtype=BF16, device=dev())
+    xh, gh = rnd(rows, I, seed=16, dtype=BF16), rnd(rows, I, seed=17, dtype=BF16)
+    u[:, :I], u[:, Ip:Ip + I] = xh, gh
+    gamma = (1 + 0.1 * rnd(I, seed=18)).contiguous()
+    hn, mean, rstd = ops.geglu_ln_fwd(u, gamma, I, Ip)
+    xr, gr_, gam = xh.float().requires_grad_(True), gh.float().requires_grad_(True), gamma.clone().requires_grad_(True)
+    h = F.gelu(gr_) * xr
+    ref = F.layer_norm(h, (I,), gam, torch.zeros_like(gam))
+    assert relmax(hn[:, :I], ref) <= 4e-3, relmax(hn[:, :I], ref)
+    assert float(hn[:, I:].float().abs().max()) == 0.0
+    dhn = torch.zeros((rows, Ip), dtype=BF16, device=dev())
+    dhn[:, :I] = rnd(rows, I, seed=19, dtype=BF16)
+    ref.backward(dhn[:, :I].float())
+    du, dg = ops.geglu_ln_bwd(dhn, u, gamma, mean, rstd, I, Ip)
+    assert relmax(du[:, :I], xr.grad) <= 4e-3 and relmax(du[:, Ip:Ip + I], gr_.grad) <= 4e-3
+    assert float(du[:, I:Ip].float().abs().max()) == 0.0 and float(du[:, Ip + I:].float().abs().max()) == 0.0
+    assert relmax(dg, gam.grad) <= 2e-5, relmax(dg, gam.grad)
+
+
+def test_colsum_reduce(ops):
+    x = rnd(300, 130, seed=20)
+    assert relmax(ops.colsum(x), x.double().sum(0)) <= 1e-6
+    assert relmax(ops.colsum(x.to(BF16)), x.to(BF16).double().sum(0)) <= 1e-6
+    v = rnd(5000, seed=21)
+    assert abs(float(ops.reduce_sum(v, 0.5)) - 0.5 * float(v.double().sum())) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention
+
+def _attn_ref(q2, k2, v2, mask, B, N, H, d):
+    import audiolm_oracle as O
+    q = q2.float().view(B, N, H, d).permute(0, 2, 1, 3)
+    return O.attend(q, k2.float().view(B, N, d), v2.float().view(B, N, d), mask=mask, causal=True)
+
+
+@pytest.mark.parametrize('B,N,H', [(2, 37, 8), (1, 64, 8), (2, 200, 8), (1, 512, 8), (2, 96, 4), (1, 33, 2)])
+@pytest.mark.parametrize('use_mask', [False, True])
+def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
+    d = 64
+    q = rnd(B * N, H * d, seed=22, dtype=BF16)
+    kv = rnd(B * N, 2 * d, seed=23, dtype=BF16)                     # k | v interleaved buffer: row stride 128
+    k, v = kv[:, :d], kv[:, d:]
+    mask = None
+    if use_mask:
+        g = torch.Generator().manual_seed(24)
+        mask = (torch.rand(B, N, generator=g) > 0.25)
+        mask[:, 0] = True
+        mask = mask.to(dev())
+    mu8 = None if mask is None else mask.contiguous().view(torch.uint8)
+    o, lse = ops.mqa_attn_fwd(q, k, v, mu8, B, N, H, d)
+
+    qf = q.float().clone().requires_grad_(True)
+    kf = k.float().clone().requires_grad_(True)
+    vf = v.float().clone().requires_grad_(True)
+    ref = _attn_ref(qf, kf, vf, mask, B, N, H, d)                    # b h n d
+    ref2 = ref.permute(0, 2, 1, 3).reshape(B * N, H * d)
+    e = relmax(o, ref2)
+    assert e <= 1.2e-2, f'attention fwd rel-max err {e}'            # P and O rounded to bf16 once each (2 x 2^-8) + exp2 vs exp
+    do = rnd(B * N, H * d, seed=25, dtype=BF16)
+    ref2.backward(do.float())
+    dq, dkv = ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d)
+    for name, got, want in (('dq', dq, qf.grad), ('dk', dkv[:, :d], kf.grad), ('dv', dkv[:, d:], vf.grad)):
+        e = relmax(got, want)
+        assert e <= 2e-2, f'attention bwd {name} rel-max err {e}'
+    # log-sum-exp statistic (fp32): lse = logsumexp(scale * q k^T over allowed keys)
+    sim = torch.einsum('bhid,bjd->bhij', qf.detach().view(B, N, H, d).permute(0, 2, 1, 3), kf.detach().view(B, N, d)) * d ** -0.5
+    allow = torch.ones(N, N, dtype=torch.bool, device=dev()).tril()
+    if mask is not None:
+        allow = allow[None] & mask[:, None, :]
+        allow = allow[:, None]
+    sim = sim.masked_fill(~allow, float('-inf'))
+    assert torch.allclose(lse, torch.logsumexp(sim, dim=-1), atol=2e-3, rtol=1e-4)
+
+
+def test_value_residual_and_kv_grad(ops):
+    rows, d = 77, 64
+    kv, kv0 = rnd(rows, 2 * d, seed=26, dtype=BF16), rnd(rows, 2 * d, seed=27, dtype=BF16)
+    mix = ops.value_residual_mix(kv[:, d:], kv0[:, d:])
+    assert torch.equal(mix, (0.5 * (kv[:, d:].float() + kv0[:, d:].float())).to(BF16))
+    dkv = rnd(rows, 2 * d, seed=28)
+    acc = torch.zeros((rows, d), dtype=F32, device=dev())
+    p1 = ops.kv_grad_pack(dkv, acc, 1, d)
+    assert torch.equal(p1[:, :d], dkv[:, :d].to(BF16)) and torch.equal(p1[:, d:], (0.5 * dkv[:, d:]).to(BF16))
+    assert torch.equal(acc, 0.5 * dkv[:, d:])
+    p2 = ops.kv_grad_pack(dkv, acc, 2, d)
+    assert torch.equal(p2[:, d:], (dkv[:, d:] + acc).to(BF16))
+    p0 = ops.kv_grad_pack(dkv, None, 0, d)
+    assert torch.equal(p0, dkv.to(BF16))
+
+
+# ------------------------------------------------------------------------------------------------ hyper-connections
+
+def _hc_params(S, D, seed):
+    return dict(gamma=0.1 * rnd(D, seed=seed), Wa=0.05 * rnd(D, S + 1, seed=seed + 1), sa=(0.1 + 0.02 * rnd(1, seed=seed + 2)).reshape(()),
+                Aa=torch.cat([torch.zeros(S, 1, device=dev()), torch.eye(S, device=dev())], 1) + 0.1 * rnd(S, S + 1, seed=seed + 3),
+                wb=0.05 * rnd(D, seed=seed + 4), sb=(0.1 + 0.02 * rnd(1, seed=seed + 5)).reshape(()), Bb=1 + 0.1 * rnd(S, seed=seed + 6))
+
+
+def _hc_sd(hc):
+    return {'norm.gamma': hc['gamma'], 'dynamic_alpha_fn': hc['Wa'], 'dynamic_alpha_scale': hc['sa'], 'static_alpha': hc['Aa'],
+            'dynamic_beta_fn': hc['wb'], 'dynamic_beta_scale': hc['sb'], 'static_beta': hc['Bb']}
+
+
+@pytest.mark.parametrize('S,D', [(4, 64), (4, 1024), (2, 256), (4, 512)])
+def test_hyper_connections(ops, S, D):
+    import audiolm_oracle as O
+    B, N = 2, 9
+    R = rnd(B, S, N, D, seed=30)
+    hc = {k: v.contiguous() for k, v in _hc_params(S, D, 31).items()}
+    ln_gamma = (1 + 0.1 * rnd(D, seed=40)).contiguous()
+    x, xn, mean, rstd, coef = ops.hc_width_fwd(R, hc, ln_gamma, B, S, N, D)
+
+    Rr = R.clone().requires_grad_(True)
+    hcr = {k: v.clone().requires_grad_(True) for k, v in hc.items()}
+    gl = ln_gamma.clone().requires_grad_(True)
+    bi, Rp, beta = O.hc_width(_hc_sd(hcr), '', Rr.reshape(B * S, N, D), S)
+    xn_ref = O.layer_norm(bi, gl)
+    assert relmax(x, bi.reshape(B * N, D)) <= 4e-3
+    assert relmax(xn, xn_ref.reshape(B * N, D)) <= 4e-3
+    assert relmax(coef[:, S * (S + 1):S * (S + 1) + S], beta.reshape(B * N, S)) <= 1e-5
+
+    y = rnd(B * N, D, seed=41, dtype=BF16)
+    Rn = ops.hc_depth_fwd(R, y, coef, B, S, N, D)
+    yr = y.float().clone().requires_grad_(True)
+    Rn_ref = O.hc_depth(yr.view(B, N, D), Rp, beta).reshape(B, S, N, D)
+    assert relmax(Rn, Rn_ref) <= 1e-5, relmax(Rn, Rn_ref)
+
+    # backward: L = <Rn, G> + <xn, Gx>
+    G = rnd(B, S, N, D, seed=42)
+    Gx = rnd(B * N, D, seed=43, dtype=BF16)
+    ((Rn_ref * G).sum() + (xn_ref.reshape(B * N, D) * Gx.float()).sum()).backward()
+    dy, dbeta = ops.hc_depth_bwd(G, y, coef, B, S, N, D)
+    assert relmax(dy, yr.grad) <= 4e-3
+    dx, dgl = ops.layernorm_bwd(Gx, x, mean, rstd, ln_gamma)           # x is the bf16 copy written by the width kernel
+    dR, hg = ops.hc_width_bwd(G, dx, R, coef, dbeta, hc, B, S, N, D)
+    e = relmax(dR, Rr.grad)
+    assert e <= 6e-3, f'hc dR rel-max err {e}'                          # LN backward re-derives xhat from the bf16 copy of x
+    assert relmax(dgl, gl.grad) <= 6e-3
+    for k in ('Wa', 'wb', 'gamma', 'Aa', 'Bb', 'sa', 'sb'):
+        e = relmax(hg[k], hcr[k].grad)
+        assert e <= 1e-2, f'hc grad {k} rel-max err {e}'
+
+
+def test_streams_and_elementwise(ops):
+    B, S, N, D = 2, 4, 5, 64
+    x = rnd(B, N, D, seed=44)
+    R = ops.streams_expand(x, B, S)
+    assert torch.equal(R, x[:, None].expand(B, S, N, D))
+    R2 = rnd(B, S, N, D, seed=45)
+    assert torch.allclose(ops.streams_reduce(R2, B, S), R2.sum(1), atol=1e-6)
+    y = rnd(B * N, D, seed=46, dtype=BF16)
+    xf = x.reshape(B * N, D)
+    assert torch.equal(ops.residual_add(xf, y), xf + y.float())
+    a, b = rnd(B * N, D, seed=47), rnd(B * N, D, seed=48)
+    assert torch.equal(ops.f32_to_bf16(a, b), (a + b).to(BF16)) and torch.equal(ops.f32_to_bf16(a), a.to(BF16))
+    assert torch.equal(ops.add_f32(a, b), a + b)
+
+
+# ------------------------------------------------------------------------------------------------ token-id side
+
+def test_embed_assemble_and_scatter(ops):
+    D = 64
+    t0, t1, t2 = rnd(11, D, seed=50), rnd(7, D, seed=51), rnd(1, D, seed=52)
+    g = torch.Generator().manual_seed(53)
+    rows = 40
+    ia = torch.randint(-1, 11, (rows,), generator=g)
+    ib = torch.randint(-1, 7, (rows,), generator=g)
+    src_a = torch.where(ia >= 0, ia, torch.full_like(ia, -1)).to(torch.int32).to(dev())
+    src_b = torch.where(ib >= 0, ib + (1 << 24), torch.full_like(ib, -1)).to(torch.int32).to(dev())
+    src_a[0] = 2 << 24
+    out = ops.embed_assemble([t0, t1, t2], src_a, src_b, rows, D)
+    ref = torch.zeros(rows, D, device=dev())
+    for r in range(rows):
+        a, b = int(src_a[r]), int(src_b[r])
+        if a >= 0:
+            ref[r] += [t0, t1, t2][a >> 24][a & 0xffffff]
+        if b >= 0:
+            ref[r] += [t0, t1, t2][b >> 24][b & 0xffffff]
+    assert torch.equal(out, ref)
+    dout = rnd(rows, D, seed=54)
+    grads = [torch.zeros_like(t) for t in (t0, t1, t2)]
+    ops.embed_scatter_add(grads, src_a, src_b, dout, 0.1, rows, D)
+    refg = [torch.zeros_like(t) for t in (t0, t1, t2)]
+    for r in range(rows):
+        for c in (int(src_a[r]), int(src_b[r])):
+            if c >= 0:
+                refg[c >> 24][c & 0xffffff] += 0.1 * dout[r]
+    for a, b in zip(grads, refg):
+        assert torch.allclose(a, b, atol=1e-5)
+
+
+def test_gather_scatter_rows(ops):
+    x = rnd(50, 64, seed=55, dtype=BF16)
+    idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32, device=dev())
+    g = ops.gather_rows(x, idx)
+    assert torch.equal(g[0], x[3]) and float(g[1].float().abs().max()) == 0 and torch.equal(g[2], x[49])
+    out = torch.zeros_like(x)
+    ops.scatter_rows(g, idx, out)
+    assert torch.equal(out[3], x[3]) and torch.equal(out[49], x[49]) and float(out[1].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize('C', [21, 501, 1025])
+def test_cross_entropy(ops, C):
+    rows, Cp = 45, (C + 7) // 8 * 8
+    logits = torch.full((rows, Cp), 1e9, dtype=F32, device=dev())       # poison the pad columns: they must never be read
+    logits[:, :C] = rnd(rows, C, seed=56, scale=3.0)
+    g = torch.Generator().manual_seed(57)
+    labels = torch.randint(0, C, (rows,), generator=g).to(dev())
+    labels[::7] = -1
+    loss_rows, lse = ops.cross_entropy_fwd(logits, labels, C)
+    lr = logits[:, :C].clone().requires_grad_(True)
+    ref_rows = F.cross_entropy(lr, labels, ignore_index=-1, reduction='none')
+    assert torch.allclose(loss_rows, ref_rows, atol=1e-5, rtol=1e-5)
+    gs = torch.tensor(0.37, device=dev())
+    (ref_rows.sum() * 0.37).backward()
+    d = ops.cross_entropy_bwd(logits, labels, lse, gs, C, Cp)
+    assert relmax(d[:, :C], lr.grad) <= 4e-3 and float(d[:, C:].float().abs().max()) == 0.0
+    assert float(d[::7].float().abs().max()) == 0.0
