@@ -1,0 +1,114 @@
+"""Data-parallel gradient exchange for the token-transformer training path: one process per GPU, RCCL over xGMI.
+
+Re-creates what the reference gets implicitly from HF accelerate -> torch DDP -> NCCL (trainer.py:56-57, 75, 1132-1140, 1247;
+SURVEY.md §2 row 8 / §8(e)) for THIS path only: pure data parallelism, one gradient all-reduce (mean) per step, overlapped with
+backward.  It is not a general DDP replacement.
+
+  * the path shards over batch rows (independent sequences); the only exchange step is the gradient mean
+  * buckets follow the backward order of the fused stack: [logit heads] -> layer depth-1 ... layer 0 -> [embeddings / start tokens];
+    a layer's bucket is launched by core.stack_backward's per-layer callback the moment that layer's weight gradients exist
+    (38 MB fp32 per layer at dim 1024), so RCCL traffic on the xGMI links runs under the remaining layers' backward GEMMs
+  * parameters that never receive a gradient (proj_text_embed -- the reason the reference needs find_unused_parameters=True,
+    trainer.py:75) are simply never bucketed; DDP's per-forward buffer broadcast is skipped (only constant zero `beta` buffers exist)
+  * `finish()` must be called after backward(): it waits for the collectives and writes the averaged gradients back into p.grad
+
+Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
+"""
+from __future__ import annotations
+
+import torch
+
+
+class _Bucket:
+    __slots__ = ('params', 'grads', 'flat', 'work')
+
+    def __init__(self):
+        self.params, self.grads, self.flat, self.work = [], [], None, None
+
+
+class DataParallelEngine:
+    def __init__(self, model, dist, process_group=None, broadcast_parameters=True):
+        self.model, self.dist, self.pg = model, dist, process_group
+        self.world = dist.get_world_size(process_group)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if broadcast_parameters and self.world > 1:
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p.data, src=0, group=process_group)
+        self._flat_cache = {}
+        self._inflight = []
+        self._loose = _Bucket()               # parameters outside the fused stack (heads first, embeddings last)
+        self._stack_param_ids = set()
+        tr = getattr(model, 'transformer', None)
+        self._stack = tr if (tr is not None and hasattr(tr, '_layer_grad_hook')) else None
+        if self._stack is not None:
+            self._stack._layer_grad_hook = self._on_layer_grads
+            self._stack_flat = self._stack.flat_params()
+            self._stack_param_ids = {id(p) for p in self._stack_flat}
+            self._ppl = (len(self._stack_flat) - 1) // self._stack.depth
+        self._hooks = []
+        for p in self.params:
+            if id(p) not in self._stack_param_ids or (self._stack is not None and p is self._stack_flat[-1]):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_loose_grad))
+        self._n_loose_heads = None
+
+    # ---- bucket launch -------------------------------------------------------------------------------------------
+    def _launch(self, key, params, grads):
+        if self.world == 1 or not params:
+            return
+        n = sum(g.numel() for g in grads)
+        flat = self._flat_cache.get(key)
+        if flat is None or flat.numel() != n or flat.device != grads[0].device:
+            flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+            self._flat_cache[key] = flat
+        torch.cat([g.reshape(-1).to(torch.float32) for g in grads], out=flat)
+        op = self.dist.ReduceOp.AVG if grads[0].is_cuda else self.dist.ReduceOp.SUM
+        work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
+        b = _Bucket()
+        b.params, b.flat, b.work = list(params), flat, work
+        b.grads = [tuple(g.shape) for g in grads]
+        self._inflight.append((b, op))
+
+    def _on_layer_grads(self, layer, grads):
+        """core.stack_backward callback: `grads` are the fresh gradients of layer `layer` (order == Transformer.flat_params)."""
+        self._flush_loose(('loose', 'pre', layer))       # whatever accumulated so far (logit heads, final norm) goes first
+        params = self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl]
+        pg = [(p, g) for p, g in zip(params, grads) if g is not None and p.requires_grad]
+        self._launch(('layer', layer), [p for p, _ in pg], [g for _, g in pg])
+
+    def _on_loose_grad(self, p):
+        self._loose.params.append(p)
+
+    def _flush_loose(self, key):
+        if self._loose.params:
+            ps = self._loose.params
+            self._loose = _Bucket()
+            self._launch(key, ps, [p.grad for p in ps])
+
+    # ---- end of backward ------------------------------------------------------------------------------------------
+    def finish(self):
+        """Call after loss.backward(): waits for every in-flight all-reduce and stores the mean gradients in p.grad."""
+        self._flush_loose(('loose', 'post'))
+        for b, op in self._inflight:
+            b.work.wait()
+            if op == self.dist.ReduceOp.SUM:
+                b.flat.div_(self.world)
+            views, o = [], 0
+            for p, shape in zip(b.params, b.grads):
+                n = 1
+                for d in shape:
+                    n *= d
+                views.append(b.flat[o:o + n].view(shape))
+                o += n
+            for p, v in zip(b.params, views):
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    p.grad.copy_(v)
+        self._inflight = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        if self._stack is not None:
+            self._stack._layer_grad_hook = None

@@ -1,0 +1,226 @@
+"""Headline benchmark: audio-tokens/sec, forward + backward of CoarseTransformer (dim 1024, depth 6, 3 coarse quantizers, 4 residual
+streams, flash_attn=True) over synthetic SoundStream-RVQ token sequences with transformer length N = 2048 (BASELINE.json metric,
+configs[1]/[3]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; per-rank batch B = 8 (weak scaling); a "step" = CoarseTransformerWrapper.forward(return_loss=True) +
+backward (+ RCCL gradient all-reduce over xGMI for N > 1), inputs resident in HBM, the bf16 weight copies are re-packed from
+the fp32 masters every step (as after an optimiser step).  The optimiser itself is outside the metric ("fwd+bwd"); a second
+timed loop that includes torch's Adam step is reported as `with_optimizer` for reference.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = the bf16 MFMA GEMM (gemm_nt_kernel); achieved = algorithmic GEMM FLOPs per launch / average launch
+               duration, measured live with HIP events on the launch stream over one instrumented step; peak = 2500 TFLOP/s dense bf16.
+  cpu_baseline the oracle (CPU fp32 restatement of the reference, "port") timed on this box's host cores on a bounded sample
+               (B = 1, N = 2048, same architecture), rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MODEL = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True)
+B_PER_GPU, N_SEM, N_FRAMES = 8, 509, 512          # N = 1 + (509 + 1) + 1 + 512 * 3 = 2048
+SEQ = 1 + (N_SEM + 1) + 1 + N_FRAMES * 3
+PEAK_BF16_TFLOPS = 2500.0                          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+class Codec:
+    rq_groups = 1
+    num_quantizers = 8
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Times the CPU oracle (fp32) on a bounded sample of the same workload: B = 1, N = 2048, fwd + bwd."""
+    import audiolm_oracle as O
+    import audiolm_pytorch_amd as A
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = A.CoarseTransformer(**MODEL)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith('.beta')}
+    full = dict(sd)
+    full.update(params)
+    cfg = O.Cfg(dim=1024, depth=6, streams=4, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3)
+    g = torch.Generator().manual_seed(0)
+    sem = torch.randint(0, 500, (1, N_SEM), generator=g)
+    coarse = torch.randint(0, 1024, (1, N_FRAMES, 3), generator=g)
+    mask = O.generate_mask_with_prob((1, SEQ), 0.15, 'cpu', generator=g)
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        loss = O.coarse_wrapper_loss(full, cfg, sem, coarse, training=True, unique_consecutive=False, forgetful_mask=mask)
+        loss.backward()
+        times.append(time.time() - t0)
+        for p in params.values():
+            p.grad = None
+        if time.time() - t_start > max_seconds:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=round(SEQ / best, 1), unit='audio-tokens/s', cores=cores, kind='port',
+                sample=f'oracle (CPU fp32 restatement of the reference, 4 residual streams) fwd+bwd, B=1 x N={SEQ}, best of {max(1, len(times) - 1)} after 1 warm-up')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optimizer-leg', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)          # backend "nccl" IS RCCL on ROCm
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+
+    import audiolm_pytorch_amd as A
+    from audiolm_pytorch_amd import ops, parallel
+
+    torch.manual_seed(0)                                        # identical initial weights on every rank
+    model = A.CoarseTransformer(**MODEL).to(dev)
+    wrapper = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
+    wrapper.train()
+    engine = parallel.DataParallelEngine(model, dist) if world > 1 else None
+
+    g = torch.Generator().manual_seed(1000 + rank)              # a different synthetic shard per rank
+    sem = torch.randint(0, 500, (B_PER_GPU, N_SEM), generator=g).to(dev)
+    coarse = torch.randint(0, 1024, (B_PER_GPU, N_FRAMES, 3), generator=g).to(dev)
+    cache = model.transformer._cache
+
+    def step(opt=None):
+        cache.store.clear()                                     # weights "changed": re-pack bf16 copies like after an optimiser step
+        for p in model.parameters():
+            p.grad = None
+        loss = wrapper(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True)
+        loss.backward()
+        if engine is not None:
+            engine.finish()                                     # waits for the overlapped RCCL all-reduces, grads averaged in place
+        if opt is not None:
+            opt.step()
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(nsteps, opt=None):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(opt)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    for _ in range(args.warmup):
+        loss = step()
+    dt = timed(args.steps)
+    ms = dt / args.steps * 1e3
+    tokens_per_s = world * B_PER_GPU * SEQ / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel: one instrumented step, HIP events around every GEMM launch on the launch stream
+    gemm_ms = gemm_flops = 0.0
+    launches = 0
+    if rank == 0:
+        events = []
+        orig = ops.gemm_nt
+
+        def timed_gemm(Am, Bm, Cm, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(Am, Bm, Cm, **kw)
+            e1.record()
+            nb = 1
+            for d in Am.shape[:-2]:
+                nb *= d
+            events.append((e0, e1, 2.0 * nb * Am.shape[-2] * Bm.shape[-2] * Am.shape[-1]))
+            return out
+        ops.gemm_nt = timed_gemm
+        import audiolm_pytorch_amd.core as core_mod
+        import audiolm_pytorch_amd.heads as heads_mod
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_nt = orig
+        for e0, e1, fl in events:
+            gemm_ms += e0.elapsed_time(e1)
+            gemm_flops += fl
+        launches = len(events)
+    if dist is not None:
+        dist.barrier()
+
+    opt_leg = None
+    if not args.no_optimizer_leg:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.99))     # reference optimizer.py:get_optimizer (wd = 0 -> Adam)
+        step(opt)
+        dto = timed(max(3, args.steps // 2), opt)
+        nst = max(3, args.steps // 2)
+        opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * B_PER_GPU * SEQ / (dto / nst), 1), optimizer='torch.optim.Adam')
+
+    if rank == 0:
+        out = {
+            'metric': 'audio-tokens/sec fwd+bwd, CoarseTransformer d=1024 seq=2048',
+            'value': round(tokens_per_s, 1),
+            'unit': 'audio-tokens/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(ms, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'bf16',
+            'data': 'synthetic (uniform random semantic / coarse RVQ token ids, random-init weights)',
+            'config': {'workload': 'CoarseTransformer dim=1024 depth=6 heads=8 (MQA) num_coarse_quantizers=3 codebook=1024 semantic=500 '
+                                   'residual_streams=4 flash_attn=True; per-GPU B=8, N=2048 (509 semantic + 512x3 coarse ids + eos/start); mask_prob=0.15',
+                       'global_batch': world * B_PER_GPU, 'seq_len': SEQ, 'parallelism': f'dp{world}'},
+            'loss': round(float(loss), 4),
+        }
+        if launches:
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (bf16 MFMA 32x32x16, all fwd/dgrad/wgrad/logit GEMMs of one step)',
+                               'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                               'traffic': None, 'launches_per_step': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
+                               'gemm_share_of_step': round(gemm_ms / ms, 3),
+                               'model_flops_frac': round(tokens_per_s / world * 391e6 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        if opt_leg:
+            out['with_optimizer'] = opt_leg
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

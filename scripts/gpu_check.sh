@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box visit: kernel parity, model parity, smoke, bench (+ rocprofv3 kernel stats).  Logs -> gpurun_out/.
+# usage: scripts/gpu_check.sh [tests|bench|prof|all]
+what=${1:-all}
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+python - > gpurun_out/env.log 2>&1 <<'PY'
+import torch, os
+print('torch', torch.__version__, 'cuda', torch.cuda.is_available(), torch.cuda.get_device_name(0) if torch.cuda.is_available() else None)
+p = torch.cuda.get_device_properties(0)
+print('CUs', p.multi_processor_count, 'mem GB', p.total_memory / 2**30, 'host cores', os.cpu_count())
+PY
+cat gpurun_out/env.log
+if [[ $what == tests || $what == all ]]; then
+  timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/kernels.log 2>&1
+  echo "kernels rc=$?"; tail -n 60 gpurun_out/kernels.log
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -s --timeout 600 > gpurun_out/parity.log 2>&1
+  echo "parity rc=$?"; tail -n 80 gpurun_out/parity.log
+  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?"; tail -n 5 gpurun_out/smoke.log
+fi
+if [[ $what == bench || $what == all ]]; then
+  timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
+  echo "bench rc=$?"; tail -n 12 gpurun_out/bench.log
+fi
+if [[ $what == prof || $what == all ]]; then
+  export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r1 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg > gpurun_out/prof.log 2>&1
+  echo "prof rc=$?"; tail -n 5 gpurun_out/prof.log
+  find gpurun_out/prof -name "*stats*" | head
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [[ -n $f ]] && head -n 30 "$f"
+fi

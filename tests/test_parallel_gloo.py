@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient engine (audiolm_pytorch_amd.parallel) averages gradients exactly like a
+single process seeing both shards -- for loose parameters (hooks) and for the fused-stack per-layer callback path."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeStack(nn.Module):
+    """Stands in for Transformer: exposes depth / flat_params() / _layer_grad_hook and calls the hook layer by layer in backward order."""
+
+    def __init__(self, depth=3):
+        super().__init__()
+        self.depth = depth
+        self.ws = nn.ParameterList([nn.Parameter(torch.randn(4, 4)) for _ in range(depth * 2)])
+        self.norm = nn.Parameter(torch.ones(4))
+        self._layer_grad_hook = None
+
+    def flat_params(self):
+        return list(self.ws) + [self.norm]
+
+
+class Model(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Embedding(10, 4)
+        self.transformer = FakeStack()
+        self.head = nn.Linear(4, 3)
+        self.unused = nn.Parameter(torch.zeros(2))          # never receives a gradient (like proj_text_embed)
+
+
+def _loss(model, ids):
+    x = model.embed(ids)
+    for w in model.transformer.ws:
+        x = torch.tanh(x @ w)
+    x = x * model.transformer.norm
+    return model.head(x).square().mean()
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(1234 + rank)                          # deliberately different init: the engine must broadcast rank 0's weights
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    ids = ids_all[rank:rank + 1]
+    loss = _loss(model, ids)
+    loss.backward()
+    # emulate the fused stack's per-layer callbacks (reverse layer order), as core.stack_backward does
+    flat = model.transformer.flat_params()
+    for l in reversed(range(model.transformer.depth)):
+        eng._on_layer_grads(l, [p.grad.clone() for p in flat[l * 2:(l + 1) * 2]])
+    eng.finish()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd=sd, grads=grads, ids=ids_all), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_world2_matches_big_batch(tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    losses = [_loss(model, r['ids'][i:i + 1]) for i in range(2)]
+    (sum(losses) / 2).backward()
+    for k, p in model.named_parameters():
+        if k == 'unused':
+            assert r['grads'][k] is None
+            continue
+        assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
