@@ -46,7 +46,7 @@ def cpu_baseline(max_seconds=30.0):
     """Times the CPU oracle (fp32) on a bounded sample of the same workload: B = 1, N = 2048, fwd + bwd."""
     import audiolm_oracle as O
     import audiolm_pytorch_amd as A
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)          # one GPU's share of the host (256 cores / 8 GPUs); more threads oversubscribe torch's CPU ops
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = A.CoarseTransformer(**MODEL)
