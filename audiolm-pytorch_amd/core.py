@@ -211,15 +211,15 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dY2T = ops.transpose(dY2)
         HNT = ops.transpose(sv['HN'])
         dW2 = _empty((D, I), F32, dev)
-        ops.gemm_nt(dY2T, HNT[:I], dW2)                                       # dW2 = dY2^T @ HN
+        ops.gemm_nt_splitk(dY2T, HNT[:I], dW2)                                       # dW2 = dY2^T @ HN
         dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], pf['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
         dXN2 = _empty((M, D), BF16, dev)
         ops.gemm_nt(dU, W1T, dXN2)                                            # dXN2 = dU @ W1
         dUT = ops.transpose(dU)
         XN2T = ops.transpose(sv['XN2'])
         dW1 = _empty((2 * I, D), F32, dev)
-        ops.gemm_nt(dUT[:I], XN2T, dW1[:I])
-        ops.gemm_nt(dUT[Ip:Ip + I], XN2T, dW1[I:])
+        ops.gemm_nt_splitk(dUT[:I], XN2T, dW1[:I])
+        ops.gemm_nt_splitk(dUT[Ip:Ip + I], XN2T, dW1[I:])
         xsrc = sv['X2'] if S > 1 else sv['R1']
         dX2, dgl = ops.layernorm_bwd(dXN2, xsrc, sv['mean2'], sv['rstd2'], pf['ln'])
         if S > 1:
@@ -240,7 +240,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dYT = ops.transpose(dY)
         AOT = ops.transpose(sv['AO'])
         dWo = _empty((D, H * dh), F32, dev)
-        ops.gemm_nt(dYT, AOT, dWo)
+        ops.gemm_nt_splitk(dYT, AOT, dWo)
         KV = sv['KV']
         dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh)
         if acc_v0 is None:
@@ -255,13 +255,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dQT = ops.transpose(dQ)
         XNT = ops.transpose(sv['XN'])
         dWq = _empty((H * dh, D), F32, dev)
-        ops.gemm_nt(dQT, XNT, dWq)
+        ops.gemm_nt_splitk(dQT, XNT, dWq)
         dXkv = _empty((M, D), BF16, dev)
         ops.gemm_nt(dKV, WkvT, dXkv)
         dKVT = ops.transpose(dKV)
         XT = ops.transpose(sv['X'])
         dWkv = _empty((2 * dh, D), F32, dev)
-        ops.gemm_nt(dKVT, XT, dWkv)
+        ops.gemm_nt_splitk(dKVT, XT, dWkv)
         xsrc = sv['X'] if S > 1 else sv['R']
         dX, dgla = ops.layernorm_bwd(dXN, xsrc, sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
         if S > 1:

@@ -37,6 +37,8 @@ struct GemmParams {
     long long sA1, sA2, sB1, sB2, sC1, sC2;
     float alpha;
     int accumulate;
+    int ksplit;        // > 0: split-K mode -- blockIdx.y is the K-slice index, slice z covers k in [z*ksplit, min(K, (z+1)*ksplit)) and
+                       // writes its fp32 partial tile to C + z * sC2 (reduced afterwards by splitk_reduce_kernel)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * 64) + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -59,6 +61,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     const int z1 = blockIdx.y / p.nb2, z2 = blockIdx.y % p.nb2;
     const bf16_t* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
     const bf16_t* __restrict__ B = p.B + z1 * p.sB1 + z2 * p.sB2;
+    int Kend = p.K;
+    if (p.ksplit > 0) {                     // sA2 == sB2 == ksplit: the slice starts ksplit elements further along every row
+        Kend = min(p.K - z2 * p.ksplit, p.ksplit);
+    }
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     uint4 ra[4], rb[4];
     auto load_tile = [&](int k0) {
         const int kk = k0 + schunk * 8;
-        const bool kok = kk < p.K;
+        const bool kok = kk < Kend;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 32 * i;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (Kend + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -153,11 +159,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
         }
 }
 
+// ---- split-K second stage: C[m][n] (+)= sum_z ws[z][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, int N, float* __restrict__ C,
+                                                            long long ldc, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < mn; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += ws[(long long)z * mn + i];
+        const long long m = i / N, n = i % N;
+        float* c = C + m * ldc + n;
+        *c = accumulate ? *c + s : s;
+    }
+}
+
 // ---- 2-D transpose of a bf16 matrix: dst[c][r] = src[r][c]; dst has ld_dst >= rows (pad columns are zero-filled
 // up to rows_pad so the transposed matrix can be used as a K-contiguous GEMM operand with K % 8 == 0).
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols,
-                                                             long long ld_src, long long ld_dst, int rows_pad) {
+                                                             long long ld_src, long long ld_dst, int rows_pad, long long bs_src,
+                                                             long long bs_dst) {
     __shared__ bf16_t tile[64][66];
+    src += (long long)blockIdx.z * bs_src;
+    dst += (long long)blockIdx.z * bs_dst;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
@@ -201,7 +222,7 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
     if (((sA1 | sA2 | sB1 | sB2) & 7) != 0) return ALM_ERR_BAD_ARG;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate};
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0};
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     dim3 grid(tiles, nb1 * nb2);
     if (out_f32)
@@ -212,14 +233,52 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     return 0;
 }
 
+// Split-K variant for long-K / few-tile contractions (weight gradients: K = B*N tokens).  ws: fp32 workspace of
+// alm_gemm_splitk_slices(M, N, K) * M * N floats.  Deterministic (no atomics): slices are reduced in a fixed order.
+extern "C" int alm_gemm_splitk_slices(int M, int N, int K) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int s = (1024 + tiles - 1) / tiles;                 // aim at ~2 resident blocks on each of the 256 CUs, twice over
+    const int maxs = (K + 511) / 512;                   // keep >= 512 of K per slice
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
+                                       long long ldc, float alpha, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
+    const int splits = alm_gemm_splitk_slices(M, N, K);
+    int kc = (K + splits - 1) / splits;
+    kc = (kc + BK - 1) / BK * BK;
+    const int nsl = (K + kc - 1) / kc;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, (long long)N, nsl, 0, kc, 0, kc, 0, (long long)M * N, alpha, 0, kc};
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(tiles, nsl), dim3(256), 0, (hipStream_t)stream, p);
+    const long long mn = (long long)M * N;
+    const int grid = (int)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nsl, mn, N, C, ldc, accumulate);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad,
                                   void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
     if (rows_pad < rows || ld_dst < rows_pad) return ALM_ERR_BAD_ARG;
     dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64);
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src,
-                       ld_dst, rows_pad);
+                       ld_dst, rows_pad, 0LL, 0LL);
     ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// batched form used inside the attention launchers: dst[z][c][r] = src[z][r][c]
+int alm_transpose_bf16_batched_internal(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad,
+                                        int batch, long long bs_src, long long bs_dst, hipStream_t stream) {
+    dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64, batch);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, ld_dst, rows_pad,
+                       bs_src, bs_dst);
     return 0;
 }
 

@@ -133,19 +133,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, long long ld, int rows, int cols, float* __restrict__ out,
                                                      float scale, int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    // block = 16 columns x 16 row-lanes: many more blocks than a 64-column tiling for the short-and-wide partial buffers this is
+    // used on (parameter-gradient partials: <= 1024 rows x up to 7k columns)
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float s = 0.f;
     if (c < cols)
-        for (int r = wave; r < rows; r += 4) {
+        for (int r = ry; r < rows; r += 16) {
             if constexpr (sizeof(T) == 2) s += bf2f(in[(long long)r * ld + c]);
             else s += in[(long long)r * ld + c];
         }
-    red[wave][lane] = s;
+    red[ry][cx] = s;
     __syncthreads();
-    if (wave == 0 && c < cols) {
-        const float v = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale;
+    if (ry == 0 && c < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][cx];
+        v *= scale;
         out[c] = accumulate ? out[c] + v : v;
     }
 }
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, l
 // fused GEGLU + LayerNorm(inner) forward.  u: [rows][ldu] bf16, x half at cols [0, I), gate half at [goff, goff + I).
 // h = gelu(gate) * x ; out = LN(h) * gamma (bf16, cols [I, Ipad) zero-filled).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int GE_MAX = 12;   // supports inner widths up to 12 * 256 = 3072
+constexpr int GE_MAX = 3;    // 4-wide vectors per thread: supports padded inner widths up to 3 * 256 * 4 = 3072
 
 __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
@@ -164,38 +169,50 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// 8-byte (4 x bf16) accesses: u rows are 16-B aligned (ldu = 2 * Ipad, Ipad % 8 == 0) and the pad columns [I, Ipad) of both halves
+// hold zeros (the packed W1 has zero rows there), so whole vectors can be loaded up to Ipad; statistics only count e < I.
 __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restrict__ u, long long ldu, int goff, const float* __restrict__ gamma,
                                                            bf16_t* __restrict__ out, long long ldo, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out, int rows, int I, int Ipad) {
     __shared__ float red[4];
     const int t = threadIdx.x;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        float h[GE_MAX];
+        float4 h[GE_MAX];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
-            const int e = t + 256 * j;
-            h[j] = 0.f;
-            if (e < I) {
-                const float xv = bf2f(u[(long long)row * ldu + e]);
-                const float gv = bf2f(u[(long long)row * ldu + goff + e]);
-                h[j] = gelu_f(gv) * xv;
-                s += h[j];
+            const int e = (t + 256 * j) * 4;
+            h[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Ipad) {
+                const float4 xv = load4(u + (long long)row * ldu + e);
+                const float4 gv = load4(u + (long long)row * ldu + goff + e);
+                h[j] = make_float4(e < I ? gelu_f(gv.x) * xv.x : 0.f, e + 1 < I ? gelu_f(gv.y) * xv.y : 0.f,
+                                   e + 2 < I ? gelu_f(gv.z) * xv.z : 0.f, e + 3 < I ? gelu_f(gv.w) * xv.w : 0.f);
+                s += h[j].x + h[j].y + h[j].z + h[j].w;
             }
         }
         const float mean = block_sum256(s, red) / (float)I;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
-            const int e = t + 256 * j;
-            if (e < I) q += (h[j] - mean) * (h[j] - mean);
+            const int e = (t + 256 * j) * 4;
+            if (e < I) {
+                const float a = h[j].x - mean, b = h[j].y - mean, c = h[j].z - mean, d = h[j].w - mean;
+                q += a * a + (e + 1 < I ? b * b : 0.f) + (e + 2 < I ? c * c : 0.f) + (e + 3 < I ? d * d : 0.f);
+            }
         }
         const float rstd = rsqrtf(block_sum256(q, red) / (float)I + LN_EPS);
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
-            const int e = t + 256 * j;
-            if (e < I) out[(long long)row * ldo + e] = f2bf((h[j] - mean) * rstd * gamma[e]);
-            else if (e < Ipad) out[(long long)row * ldo + e] = 0;
+            const int e = (t + 256 * j) * 4;
+            if (e < Ipad) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < I) o.x = (h[j].x - mean) * rstd * gamma[e];
+                if (e + 1 < I) o.y = (h[j].y - mean) * rstd * gamma[e + 1];
+                if (e + 2 < I) o.z = (h[j].z - mean) * rstd * gamma[e + 2];
+                if (e + 3 < I) o.w = (h[j].w - mean) * rstd * gamma[e + 3];
+                store4(out + (long long)row * ldo + e, o);
+            }
         }
         if (t == 0) {
             mean_out[row] = mean;
@@ -212,49 +229,67 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
                                                            bf16_t* __restrict__ du, float* __restrict__ dgamma_part, int rows, int I, int Ipad) {
     __shared__ float red[4];
     const int t = threadIdx.x;
-    float dgam[GE_MAX];
+    float4 dgam[GE_MAX], gam[GE_MAX];
 #pragma unroll
-    for (int j = 0; j < GE_MAX; ++j) dgam[j] = 0.f;
+    for (int j = 0; j < GE_MAX; ++j) {
+        const int e = (t + 256 * j) * 4;
+        dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gam[j] = make_float4(e < I ? gamma[e] : 0.f, e + 1 < I ? gamma[e + 1] : 0.f, e + 2 < I ? gamma[e + 2] : 0.f, e + 3 < I ? gamma[e + 3] : 0.f);
+    }
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float xv[GE_MAX], gv[GE_MAX], xh[GE_MAX], g[GE_MAX];
+        float4 xv[GE_MAX], gv[GE_MAX], xh[GE_MAX], g[GE_MAX];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
-            const int e = t + 256 * j;
-            xv[j] = gv[j] = xh[j] = g[j] = 0.f;
-            if (e < I) {
-                xv[j] = bf2f(u[(long long)row * ldu + e]);
-                gv[j] = bf2f(u[(long long)row * ldu + goff + e]);
-                const float h = gelu_f(gv[j]) * xv[j];
-                const float d = bf2f(dhn[(long long)row * lddh + e]);
-                xh[j] = (h - mean) * rstd;
-                g[j] = d * gamma[e];
-                dgam[j] += d * xh[j];
-                s1 += g[j];
-                s2 += g[j] * xh[j];
+            const int e = (t + 256 * j) * 4;
+            xv[j] = gv[j] = xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Ipad) {
+                xv[j] = load4(u + (long long)row * ldu + e);
+                gv[j] = load4(u + (long long)row * ldu + goff + e);
+                const float4 d = load4(dhn + (long long)row * lddh + e);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (e + c < I) {
+                        const float h = gelu_f((&gv[j].x)[c]) * (&xv[j].x)[c];
+                        const float xhat = (h - mean) * rstd;
+                        const float gg = (&d.x)[c] * (&gam[j].x)[c];
+                        (&xh[j].x)[c] = xhat;
+                        (&g[j].x)[c] = gg;
+                        (&dgam[j].x)[c] += (&d.x)[c] * xhat;
+                        s1 += gg;
+                        s2 += gg * xhat;
+                    }
+                }
             }
         }
         const float c1 = block_sum256(s1, red) / (float)I;
         const float c2 = block_sum256(s2, red) / (float)I;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
-            const int e = t + 256 * j;
-            if (e < I) {
-                const float dh = rstd * (g[j] - c1 - xh[j] * c2);
-                du[(long long)row * ldu + e] = f2bf(dh * gelu_f(gv[j]));
-                du[(long long)row * ldu + goff + e] = f2bf(dh * xv[j] * gelu_grad_f(gv[j]));
-            } else if (e < Ipad) {
-                du[(long long)row * ldu + e] = 0;
-                du[(long long)row * ldu + goff + e] = 0;
+            const int e = (t + 256 * j) * 4;
+            if (e < Ipad) {
+                float4 dxh = make_float4(0.f, 0.f, 0.f, 0.f), dgh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (e + c < I) {
+                        const float dh = rstd * ((&g[j].x)[c] - c1 - (&xh[j].x)[c] * c2);
+                        (&dxh.x)[c] = dh * gelu_f((&gv[j].x)[c]);
+                        (&dgh.x)[c] = dh * (&xv[j].x)[c] * gelu_grad_f((&gv[j].x)[c]);
+                    }
+                }
+                store4(du + (long long)row * ldu + e, dxh);
+                store4(du + (long long)row * ldu + goff + e, dgh);
             }
         }
     }
     if (!dgamma_part) return;
 #pragma unroll
     for (int j = 0; j < GE_MAX; ++j) {
-        const int e = t + 256 * j;
-        if (e < I) dgamma_part[(long long)blockIdx.x * I + e] = dgam[j];
+        const int e = (t + 256 * j) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (e + c < I) dgamma_part[(long long)blockIdx.x * I + e + c] = (&dgam[j].x)[c];
     }
 }
 
@@ -323,7 +358,7 @@ extern "C" int alm_layernorm_bwd(const void* dy, long long lddy, const void* x, 
 extern "C" int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate,
                           void* stream) {
     if (cols <= 0) return 0;
-    dim3 grid((cols + 63) / 64);
+    dim3 grid((cols + 15) / 16);
     if (in_is_bf16)
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld, rows, cols, out, scale, accumulate);
     else
@@ -337,7 +372,7 @@ extern "C" int alm_geglu_partial_blocks(int rows) { return min(rows, 1024); }
 extern "C" int alm_geglu_ln_fwd(const void* u, long long ldu, int gate_offset, const float* gamma, void* out, long long ldo, float* mean,
                                 float* rstd, int rows, int inner, int inner_pad, void* stream) {
     if (rows <= 0) return 0;
-    if (inner <= 0 || inner > GE_MAX * 256 || inner_pad < inner || inner_pad > GE_MAX * 256) return ALM_ERR_UNSUPPORTED;
+    if (inner <= 0 || inner_pad < inner || inner_pad > GE_MAX * 1024 || (inner_pad & 7) || (ldu & 7) || (gate_offset & 7)) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(geglu_ln_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, ldu, gate_offset, gamma,
                        (bf16_t*)out, ldo, mean, rstd, rows, inner, inner_pad);
     ALM_LAUNCH_CHECK();
@@ -349,7 +384,7 @@ extern "C" int alm_geglu_ln_bwd(const void* dhn, long long lddh, const void* u, 
                                 const float* mean, const float* rstd, void* du, float* dgamma_part, int rows, int inner, int inner_pad,
                                 void* stream) {
     if (rows <= 0) return 0;
-    if (inner <= 0 || inner > GE_MAX * 256 || inner_pad < inner || inner_pad > GE_MAX * 256) return ALM_ERR_UNSUPPORTED;
+    if (inner <= 0 || inner_pad < inner || inner_pad > GE_MAX * 1024 || (inner_pad & 7) || (ldu & 7) || (gate_offset & 7)) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(geglu_ln_bwd_kernel, dim3(alm_geglu_partial_blocks(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dhn, lddh,
                        (const bf16_t*)u, ldu, gate_offset, gamma, mean, rstd, (bf16_t*)du, dgamma_part, rows, inner, inner_pad);
     ALM_LAUNCH_CHECK();

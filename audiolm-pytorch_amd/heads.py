@@ -96,7 +96,7 @@ class HeadsLossFn(torch.autograd.Function):
             for q in range(G):                                                    # wgrad: dlogits_q^T @ hidden_q
                 dlT = ops.transpose(dl[q * Rg:(q + 1) * Rg])                      # [Cp, Rgpad]
                 hgT = ops.transpose(hg[q * Rg:(q + 1) * Rg])                      # [D, Rgpad]
-                ops.gemm_nt(dlT[:C], hgT, dW[q])
+                ops.gemm_nt_splitk(dlT[:C], hgT, dW[q])
             grads.append(dW.reshape(ctx.params[len(grads)].shape))
             if has_bias:
                 grads.append(ops.colsum(dl[:, :C]))

@@ -56,6 +56,21 @@ def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
     return C
 
 
+def gemm_nt_splitk(A, B, C, *, alpha=1.0, accumulate=False):
+    """fp32 C[M, N] (+)= alpha * A[M, K] @ B[N, K]^T with K split over workgroups (weight gradients: K = tokens)."""
+    _chk(A, BF16), _chk(B, BF16), _chk(C, F32)
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K and C.shape == (M, N) and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
+    slices = _lib.query('alm_gemm_splitk_slices', M, N, K)
+    if slices <= 1:
+        return gemm_nt(A, B, C, alpha=alpha, accumulate=accumulate)
+    ws = torch.empty((slices, M, N), dtype=F32, device=A.device)
+    _lib.call('alm_gemm_bf16_nt_splitk', A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), M, N, K, A.stride(0), B.stride(0), C.stride(0),
+              float(alpha), int(accumulate), _st())
+    return C
+
+
 def transpose(src, rows_pad=None):
     """bf16 [rows, cols] -> new bf16 [cols, rows_pad] with zero-filled pad columns (rows_pad = rows rounded up to 8)."""
     _chk(src, BF16)

@@ -29,6 +29,11 @@ extern "C" {
 int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                      long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
                      long long sC2, float alpha, int out_f32, int accumulate, void* stream);
+/* split-K variant for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * A . B^T, deterministic
+ * two-stage reduction through `ws` (alm_gemm_splitk_slices(M,N,K) * M * N floats). */
+int alm_gemm_splitk_slices(int M, int N, int K);
+int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
+                            long long ldc, float alpha, int accumulate, void* stream);
 /* dst[c][r] = src[r][c]; columns [rows, rows_pad) of dst are zero-filled (K-padding of a transposed GEMM operand). */
 int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, void* stream);
 /* fp32 master weight -> zero-padded bf16 copy (dst, may be NULL) and zero-padded bf16 transpose (dstT, may be NULL).
