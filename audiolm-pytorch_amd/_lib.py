@@ -17,8 +17,10 @@ _P, _I, _L, _F = c_void_p, c_int, c_longlong, c_float
 # name -> argtypes (all return int).  Kept in sync with include/audiolm_hip.h (tests/test_cabi.py checks both directions).
 SIGNATURES = {
     'alm_gemm_bf16_nt': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _P],
-    'alm_gemm_splitk_slices': [_I, _I, _I],
-    'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P],
+    'alm_gemm_splitk_slices': [_I, _I, _I, _I],
+    'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
+    'alm_gemm_bf16_tn_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
+    'alm_gemm_bf16_nt_tile': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _I, _I, _P],
     'alm_transpose_bf16': [_P, _P, _I, _I, _L, _L, _I, _P],
     'alm_pack_weight': [_P, _I, _I, _L, _P, _L, _I, _I, _P, _L, _P],
     'alm_ln_partial_blocks': [_I],

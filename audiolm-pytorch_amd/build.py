@@ -18,7 +18,7 @@ SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.h
 
 def _digest() -> str:
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(HERE, '..', 'include', 'audiolm_hip.h')]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.hpp', '.h'))] + [os.path.join(HERE, '..', 'include', 'audiolm_hip.h')]
     for f in files:
         with open(f, 'rb') as fh:
             h.update(f.encode() + b'\0' + fh.read())

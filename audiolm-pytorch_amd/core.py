@@ -208,18 +208,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             dY2 = ops.f32_to_bf16(dR)
         dHN = _empty((M, Ip), BF16, dev)
         ops.gemm_nt(dY2, W2T, dHN)                                            # dHN = dY2 @ W2
-        dY2T = ops.transpose(dY2)
-        HNT = ops.transpose(sv['HN'])
         dW2 = _empty((D, I), F32, dev)
-        ops.gemm_nt_splitk(dY2T, HNT[:I], dW2)                                       # dW2 = dY2^T @ HN
+        ops.gemm_tn_splitk(dY2, sv['HN'][:, :I], dW2)                         # dW2 = dY2^T @ HN
         dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], pf['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
         dXN2 = _empty((M, D), BF16, dev)
         ops.gemm_nt(dU, W1T, dXN2)                                            # dXN2 = dU @ W1
-        dUT = ops.transpose(dU)
-        XN2T = ops.transpose(sv['XN2'])
         dW1 = _empty((2 * I, D), F32, dev)
-        ops.gemm_nt_splitk(dUT[:I], XN2T, dW1[:I])
-        ops.gemm_nt_splitk(dUT[Ip:Ip + I], XN2T, dW1[I:])
+        ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], sv['XN2'], dW1.view(2, I, D))   # dW1 = dU^T @ XN2 (x | gate halves)
         xsrc = sv['X2'] if S > 1 else sv['R1']
         dX2, dgl = ops.layernorm_bwd(dXN2, xsrc, sv['mean2'], sv['rstd2'], pf['ln'])
         if S > 1:
@@ -237,10 +232,8 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             dY = ops.f32_to_bf16(dR1)
         dAO = _empty((M, H * dh), BF16, dev)
         ops.gemm_nt(dY, WoT, dAO)
-        dYT = ops.transpose(dY)
-        AOT = ops.transpose(sv['AO'])
         dWo = _empty((D, H * dh), F32, dev)
-        ops.gemm_nt_splitk(dYT, AOT, dWo)
+        ops.gemm_tn_splitk(dY, sv['AO'], dWo)
         KV = sv['KV']
         dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh)
         if acc_v0 is None:
@@ -252,16 +245,12 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dKV = ops.kv_grad_pack(dkv32, acc_v0, mode, dh)
         dXN = _empty((M, D), BF16, dev)
         ops.gemm_nt(dQ, WqT, dXN)
-        dQT = ops.transpose(dQ)
-        XNT = ops.transpose(sv['XN'])
         dWq = _empty((H * dh, D), F32, dev)
-        ops.gemm_nt_splitk(dQT, XNT, dWq)
+        ops.gemm_tn_splitk(dQ, sv['XN'], dWq)
         dXkv = _empty((M, D), BF16, dev)
         ops.gemm_nt(dKV, WkvT, dXkv)
-        dKVT = ops.transpose(dKV)
-        XT = ops.transpose(sv['X'])
         dWkv = _empty((2 * dh, D), F32, dev)
-        ops.gemm_nt_splitk(dKVT, XT, dWkv)
+        ops.gemm_tn_splitk(dKV, sv['X'], dWkv)
         xsrc = sv['X'] if S > 1 else sv['R']
         dX, dgla = ops.layernorm_bwd(dXN, xsrc, sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
         if S > 1:

@@ -1,30 +1,39 @@
-// bf16 MFMA GEMM for gfx950:  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T (+ bias[N])      ("NT": both operands K-contiguous)
+// bf16 MFMA GEMMs for gfx950 (MI355X): the dense-contraction workhorse of the token-transformer hot path.
 //
-// This is the dense-contraction workhorse of the token-transformer hot path: to_q / to_kv / to_out, the two FFN
-// projections, the logit heads, and -- with explicitly transposed operands -- every dgrad / wgrad of those.
-// Replaces aten::mm / addmm / bmm at reference audiolm_pytorch.py:255-259, :351, :395, :719, :961, :972.
+//   NT:  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T (+ bias[N])     both operands K-contiguous: forward and dgrad of every
+//        nn.Linear / einsum (to_q / to_kv / to_out, the two FFN projections, the logit heads).
+//        Replaces aten::mm / addmm / bmm at reference audiolm_pytorch.py:255-259, :351, :395, :719, :961, :972.
+//   TN:  C[M,N] (+)= alpha * At[K,M]^T . Bt[K,N]               both operands contraction-major (K = tokens): every weight
+//        gradient dW = dY^T X straight from the row-major activations -- no transposed copies of dY / X are ever made.
 //
-// Design (wave64 / CDNA4, not a warp-32 tiling):
-//   * 128x128x64 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 output tile
-//     = 2x2 MFMA 32x32x16 bf16 blocks -> 64 fp32 accumulator registers / lane.
-//   * operands are staged global -> registers -> LDS (16-B loads, 8 lanes cover one 128-B row segment), LDS is
-//     double buffered (2 x 32 KiB) so one __syncthreads per K-tile; the next tile's global loads are issued before
-//     the MFMA block of the current tile and written to the other buffer afterwards.
-//   * LDS rows are 128 B (64 bf16, no padding) with the 16-B chunk index XOR-swizzled by ((row >> 1) & 7): the
-//     ds_read_b128 of an MFMA fragment (32 rows x one chunk per half-wave) then touches 16 distinct 16-B slots per
-//     16-lane service group (conflict-free), and ds_write_b128 of one row (8 lanes) is conflict-free too.
-//   * XCD-aware block remap + grouped (GROUP_M = 8) rasterisation so that the ~64 blocks resident on one XCD share
-//     A / B panels in that XCD's 4 MiB L2.
-//   * two-level batch (blockIdx.y -> (z1, z2)) with element strides: used for the per-quantizer logit heads
+// Design (wave64 / CDNA4):
+//   * block tile 128x128 (4 waves, 2x2) or 256x256 (8 waves as 2(M) x 4(N), wave tile 128x64), K-step 64, MFMA 32x32x16 bf16.
+//     The accumulators hold C^T blocks (operands swapped in the MFMA) so that a lane owns ONE output row and 4 consecutive
+//     output columns per register quad: the epilogue stores 8-byte (bf16) / 16-byte (fp32) vectors.
+//   * operands go HBM/L2 -> LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write pass.  Out-of-range
+//     K chunks / rows are redirected to an out-of-bounds buffer offset, for which the DMA writes zeros.  Two LDS stages,
+//     ONE barrier per K-step: the next tile's DMA is issued before the MFMA block of the current tile.
+//   * NT LDS image: [row][64 k] (128-B rows); the DMA destination is lane-linear, so the conflict-avoiding XOR swizzle
+//     chunk ^= (row >> 1) & 7 is applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads.
+//   * TN LDS image: [k/4][i/16][4][16] sub-tiles of 128 B; a 16-lane group of `ds_read_b64_tr_b16` (LDS transpose read)
+//     turns one sub-tile into 4 k-consecutive values of 16 rows = half an MFMA A/B fragment.  Every half-wave reads 256
+//     contiguous bytes: bank-conflict free, and the DMA still fetches whole 128-B/256-B row segments from HBM.
+//   * XCD-aware block remap + grouped rasterisation: the blocks resident on one XCD share A / B panels in that XCD's L2.
+//   * split-K (weight gradients: K = B*N tokens, few output tiles): blockIdx.y = K-slice, fp32 partial tiles in a workspace,
+//     deterministic second-stage reduction (no atomics).
+//   * two-level batch (blockIdx.y -> (z1, z2)) with element strides for the per-quantizer logit heads
 //     (einsum 'q c d, b n q d -> b n q c').
-// Requirements: K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned (vector loads); M, N, ldc arbitrary.
+// Requirements: NT: K % 8 == 0, lda/ldb % 8 == 0;  TN: lda/ldb % 8 == 0;  A/B 16-byte aligned; every operand view < 2 GiB.
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
+constexpr unsigned OOB = 0x80000000u;         // buffer offset beyond every num_records: the DMA returns zeros
+
+typedef __attribute__((address_space(3))) void lds_void;
 
 struct GemmParams {
     const bf16_t* A;
@@ -37,15 +46,25 @@ struct GemmParams {
     long long sA1, sA2, sB1, sB2, sC1, sC2;
     float alpha;
     int accumulate;
-    int ksplit;        // > 0: split-K mode -- blockIdx.y is the K-slice index, slice z covers k in [z*ksplit, min(K, (z+1)*ksplit)) and
-                       // writes its fp32 partial tile to C + z * sC2 (reduced afterwards by splitk_reduce_kernel)
+    int ksplit;        // > 0: split-K -- blockIdx.z is the K-slice index, slice s covers k in [s*ksplit, min(K, (s+1)*ksplit)) and
+                       // writes its fp32 partial tile to C + s * sCk (reduced afterwards by splitk_reduce_kernel)
+    long long sCk;
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (row * 64) + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ bf16x4 ds_tr16_b64(unsigned addr) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
 
-template <bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BM * BK];   // [buffer][A|B][row*64 + swizzled chunk]
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int NW = WM * WN;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int TM = BM / WM / 32, TNB = BN / WN / 32;
+    constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;       // 1-KiB DMA pieces per wave per stage
+    static_assert(NIA >= 1 && NIB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile / wave shape");
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
@@ -59,112 +78,298 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z1 = blockIdx.y / p.nb2, z2 = blockIdx.y % p.nb2;
-    const bf16_t* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
-    const bf16_t* __restrict__ B = p.B + z1 * p.sB1 + z2 * p.sB2;
-    int Kend = p.K;
-    if (p.ksplit > 0) {                     // sA2 == sB2 == ksplit: the slice starts ksplit elements further along every row
-        Kend = min(p.K - z2 * p.ksplit, p.ksplit);
+    int kbeg = 0, Krem = p.K;
+    long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
+    if (p.ksplit > 0) {
+        kbeg = blockIdx.z * p.ksplit;
+        Krem = min(p.K - kbeg, p.ksplit);
     }
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // staging assignment: 4 x (row, chunk) per operand
-    const int srow = t >> 3, schunk = t & 7;
+    // ---- DMA source descriptors (block-local views) and per-lane source offsets --------------------------------------------
+    const bf16_t* Ab;
+    const bf16_t* Bb;
+    long long extA, extB;
+    if (!TNMODE) {
+        Ab = p.A + zoffA + (long long)m0 * p.lda + kbeg;
+        Bb = p.B + zoffB + (long long)n0 * p.ldb + kbeg;
+        extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + Krem) * 2;
+        extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + Krem) * 2;
+    } else {
+        Ab = p.A + zoffA + (long long)kbeg * p.lda + m0;
+        Bb = p.B + zoffB + (long long)kbeg * p.ldb + n0;
+        extA = ((long long)(Krem - 1) * p.lda + ((min(p.M - m0, BM) + 7) & ~7)) * 2;     // whole 16-B chunks (lda >= roundup8(M))
+        extB = ((long long)(Krem - 1) * p.ldb + ((min(p.N - n0, BN) + 7) & ~7)) * 2;
+    }
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)min(extA, 0x7fffffffLL), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)min(extB, 0x7fffffffLL), 0x00020000);
 
-    uint4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-        const int kk = k0 + schunk * 8;
-        const bool kok = kk < Kend;
+    unsigned offA[NIA], offB[NIB];
+    int kcA[NIA], kcB[NIB];      // K coordinate (within the stage) of the piece this lane fetches: for the K-tail predicate
+    if (!TNMODE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            const int gm = m0 + row, gn = n0 + row;
-            ra[i] = (kok && gm < p.M) ? *reinterpret_cast<const uint4*>(A + (long long)gm * p.lda + kk) : make_uint4(0, 0, 0, 0);
-            rb[i] = (kok && gn < p.N) ? *reinterpret_cast<const uint4*>(B + (long long)gn * p.ldb + kk) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < NIA; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offA[j] = (unsigned)(row * p.lda * 2 + c * 16);
+            kcA[j] = c * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offB[j] = (unsigned)(row * p.ldb * 2 + c * 16);
+            kcB[j] = c * 8;
+        }
+    } else {
+        const int st = lane >> 3, kin = (lane >> 1) & 3, half = lane & 1;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int q = j * NW + wave;                       // 1-KiB piece index within the stage
+            const int kg = q / (BM / 128), part = q % (BM / 128);
+            const int k = kg * 4 + kin, i = part * 128 + st * 16 + half * 8;
+            offA[j] = (unsigned)(k * p.lda * 2 + i * 2);
+            kcA[j] = k;
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const int q = j * NW + wave;
+            const int kg = q / (BN / 128), part = q % (BN / 128);
+            const int k = kg * 4 + kin, i = part * 128 + st * 16 + half * 8;
+            offB[j] = (unsigned)(k * p.ldb * 2 + i * 2);
+            kcB[j] = k;
+        }
+    }
+    const unsigned kstepA = TNMODE ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+    const unsigned kstepB = TNMODE ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * STAGE;
+        const int kleft = Krem - kt * BK;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            *reinterpret_cast<uint4*>(&lds[buf][0][swz(row, schunk)]) = ra[i];
-            *reinterpret_cast<uint4*>(&lds[buf][1][swz(row, schunk)]) = rb[i];
-        }
-    };
 
-    f32x16 acc[2][2];
+    // ---- fragment read addresses (bytes, within a stage) -------------------------------------------------------------------
+    unsigned fragA[TM], fragB[TNB];
+    if (!TNMODE) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((wr * (BM / WM) + i * 32 + lr) * 128);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TNB; ++j) fragB[j] = (unsigned)(A_BYTES + (wc * (BN / WN) + j * 32 + lr) * 128);
+    } else {
+        const int g = lane >> 4, s = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int it = (wr * (BM / WM) + i * 32) / 16 + (g & 1);
+            fragA[i] = (unsigned)((((g >> 1) * 2) * (BM / 16) + it) * 128 + s * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) {
+            const int it = (wc * (BN / WN) + j * 32) / 16 + (g & 1);
+            fragB[j] = (unsigned)(A_BYTES + (((g >> 1) * 2) * (BN / 16) + it) * 128 + s * 8);
+        }
+    }
+    const unsigned sw = (unsigned)((lr >> 1) & 7);          // NT read swizzle: (row >> 1) & 7 == (lr >> 1) & 7 (row bases are multiples of 32)
+
+    f32x16 acc[TM][TNB];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (Kend + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    const int nk = (Krem + BK - 1) / BK;
+    stage(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const bf16_t* As = lds[buf][0];
-        const bf16_t* Bs = lds[buf][1];
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const unsigned char* sb = smem + buf * STAGE;
+        const unsigned sbase = (unsigned)(uintptr_t)(lds_void*)sb;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[TM], b[TNB];
+            if (!TNMODE) {
+                const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(&As[swz(wr * 64 + i * 32 + lr, ks * 2 + lh)]);
-                b[i] = *reinterpret_cast<const bf16x8*>(&Bs[swz(wc * 64 + i * 32 + lr, ks * 2 + lh)]);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
+            } else {
+                // k-groups ks*4 + (g>>1)*2 + {0, 1}; consecutive k-groups are (Bx/16)*128 bytes apart
+                bf16x4 lo[TM + TNB], hi[TM + TNB];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned ad = sbase + fragA[i] + ks * 4 * (BM / 16) * 128;
+                    lo[i] = ds_tr16_b64(ad);
+                    hi[i] = ds_tr16_b64(ad + (BM / 16) * 128);
+                }
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) {
+                    const unsigned ad = sbase + fragB[j] + ks * 4 * (BN / 16) * 128;
+                    lo[TM + j] = ds_tr16_b64(ad);
+                    hi[TM + j] = ds_tr16_b64(ad + (BN / 16) * 128);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) b[j] = __builtin_shufflevector(lo[TM + j], hi[TM + j], 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TNB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const long long coff = z1 * p.sC1 + z2 * p.sC2;
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    // lane owns row gm of each 32-row block; register quad g holds columns n = 8*g + 4*lh + {0..3} of each 32-wide block.
+    // Fast path: every wave transposes its 32 x (32*TNB) block through a private, XOR-swizzled LDS slab (the stage buffers are free
+    // after the last barrier) and writes whole 128-B (bf16) / 256-B (fp32) row segments with 16-byte stores.
+    {
+        constexpr int ES = OUT_F32 ? 4 : 2;                 // output element size
+        constexpr int WCOLS = 32 * TNB;                     // columns of the wave tile
+        constexpr int ROWB = WCOLS * ES;                    // bytes per slab row
+        constexpr int NCH = ROWB / 16;                      // 16-B chunks per slab row
+        constexpr int SLAB = 32 * ROWB;
+        static_assert(NW * SLAB <= 2 * STAGE, "epilogue slab");
+        const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? blockIdx.z * p.sCk : 0);
+        unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + coff0 * ES;
+        const bool fast = !p.accumulate && ((p.ldc * ES) & 15) == 0 && ((uintptr_t)Cb & 15) == 0 && (p.N % (16 / ES)) == 0;
+        if (fast) {
+            unsigned char* slab = smem + wave * SLAB;
+            const int ncol0 = n0 + wc * (BN / WN);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int mrow0 = m0 + wr * (BM / WM) + i * 32;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gn = n0 + wc * 64 + j * 32 + lr;
-            if (gn >= p.N) continue;
-            const float bv = p.bias ? p.bias[gn] : 0.f;
+                for (int j = 0; j < TNB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (gm >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bv;
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = j * 32 + 8 * g + 4 * lh;
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            v[c] = acc[i][j][4 * g + c] * p.alpha;
+                            if (p.bias && ncol0 + c0 + c < p.N) v[c] += p.bias[ncol0 + c0 + c];
+                        }
+                        if (OUT_F32) {
+                            const int ch = c0 / 4;
+                            *reinterpret_cast<float4*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            const int ch = c0 / 8;
+                            *reinterpret_cast<uint2*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4) + lh * 8) =
+                                make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        }
+                    }
+                constexpr int LPR = NCH;                     // lanes per row
+                constexpr int RPI = 64 / LPR;                // rows per wave-instruction
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int row = it * RPI + lane / LPR, ch = lane % LPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * ROWB + ((ch ^ (row & (NCH - 1))) << 4));
+                    const int gm = mrow0 + row, gn = ncol0 + ch * (16 / ES);
+                    if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
+                }
+            }
+            return;
+        }
+    }
+    const long long coff = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? blockIdx.z * p.sCk : 0);
+    const bool vec_ok = OUT_F32 ? ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0)
+                                : ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + wr * (BM / WM) + i * 32 + lr;
+        if (gm >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gn = n0 + wc * (BN / WN) + j * 32 + 8 * g + 4 * lh;
+                if (gn >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = acc[i][j][4 * g + c] * p.alpha;
+                    if (p.bias && gn + c < p.N) v[c] += p.bias[gn + c];
+                }
                 const long long idx = coff + (long long)gm * p.ldc + gn;
                 if (OUT_F32) {
-                    float* C = reinterpret_cast<float*>(p.C);
-                    if (p.accumulate) v += C[idx];
-                    C[idx] = v;
+                    float* C = reinterpret_cast<float*>(p.C) + idx;
+                    if (vec_ok && gn + 3 < p.N) {
+                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.accumulate) { const float4 w = *reinterpret_cast<const float4*>(C); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+                        *reinterpret_cast<float4*>(C) = o;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (gn + c < p.N) C[c] = p.accumulate ? C[c] + v[c] : v[c];
+                    }
                 } else {
-                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-                    if (p.accumulate) v += bf2f(C[idx]);
-                    C[idx] = f2bf(v);
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + idx;
+                    if (vec_ok && gn + 3 < p.N) {
+                        if (p.accumulate) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(C);
+                            v[0] += __uint_as_float(w.x << 16); v[1] += __uint_as_float(w.x & 0xffff0000u);
+                            v[2] += __uint_as_float(w.y << 16); v[3] += __uint_as_float(w.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (gn + c < p.N) C[c] = f2bf(p.accumulate ? bf2f(C[c]) + v[c] : v[c]);
+                    }
                 }
             }
         }
+    }
 }
 
-// ---- split-K second stage: C[m][n] (+)= sum_z ws[z][m][n]
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, int N, float* __restrict__ C,
-                                                            long long ldc, int accumulate) {
+// ---- split-K second stage: C[b][m][n] (+)= sum_z ws[z][b][m][n]   (blockIdx.y = b)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, long long slice_stride, int N,
+                                                            float* __restrict__ C, long long ldc, long long sC, int accumulate) {
+    ws += (long long)blockIdx.y * mn;
+    C += (long long)blockIdx.y * sC;
+    const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (mn & 3) == 0 && (slice_stride & 3) == 0;
+    if (vec) {
+        const long long mn4 = mn >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (long long)gridDim.x * 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < splits; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(ws + (long long)z * slice_stride + i * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const long long e = i * 4, m = e / N, n = e % N;
+            float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
+            if (accumulate) { const float4 w = *c; s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w; }
+            *c = s;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < mn; i += (long long)gridDim.x * 256) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += ws[(long long)z * mn + i];
+        for (int z = 0; z < splits; ++z) s += ws[(long long)z * slice_stride + i];
         const long long m = i / N, n = i % N;
         float* c = C + m * ldc + n;
         *c = accumulate ? *c + s : s;
@@ -214,6 +419,65 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// ---- launch plumbing ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * BK * 2;
+    static bool attr_done = false;                 // idempotent; a benign race sets the same value twice
+    auto kfn = gemm_kernel<BM, BN, WM, WN, TNMODE, OUT_F32>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kfn, dim3(tiles, ny, nz), dim3(WM * WN * 64), smem, st, p);
+    return 0;
+}
+
+// tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU)
+int pick_tile(int M, int N, int ny, int tile) {
+    if (tile == 1 || tile == 2) return tile;
+    if (M < 256 || N < 256) return 1;
+    const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
+    return big >= 192 ? 2 : 1;                     // enough 256^2 tiles to occupy most of the 256 CUs
+}
+
+template <bool TNMODE>
+int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
+    const int tl = pick_tile(p.M, p.N, ny * nz, tile);
+    if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
+    return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);
+}
+
+bool view_too_big(long long rows, long long ld) { return rows * ld * 2 >= 0x7fffffffLL; }
+
+// Split-K plan for `nb` same-shape problems: choose (tile, slices) minimising a simple time model --
+//   block waves over the chip x K-steps per block x measured time per K-step  +  workspace round trip through HBM.
+struct SplitPlan { int tile, slices; };
+SplitPlan splitk_plan(int M, int N, int K, int nb) {
+    SplitPlan best{1, 1};
+    double best_t = 1e30;
+    for (int tile = 1; tile <= 2; ++tile) {
+        if (tile == 2 && (M < 256 || N < 256)) continue;
+        const int bm = tile == 2 ? 256 : 128;
+        const double tiles = (double)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * nb;
+        const double slots = tile == 2 ? 256.0 : 512.0;               // resident blocks on the chip
+        const double us_per_kstep = tile == 2 ? 2.0 : 1.25;          // one 64-deep K-step of one block (measured, whole chip busy)
+        for (int s = 1; s <= 64; ++s) {
+            if (s > 1 && (K + s - 1) / s < 256) break;
+            const int kc = ((K + s - 1) / s + BK - 1) / BK * BK;
+            const int nsl = (K + kc - 1) / kc;
+            if (nsl != s) continue;
+            const double waves = ceil(tiles * s / slots);
+            double t = waves * ((kc / BK) * us_per_kstep + 3.0);
+            if (s > 1) t += (double)s * M * N * nb * 8.0 / 4.0e6 + 3.0;   // fp32 partials: written + read back at ~4 TB/s, + the reduce launch
+            if (t < best_t) { best_t = t; best = SplitPlan{tile, s}; }
+        }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
@@ -222,42 +486,73 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
     if (((sA1 | sA2 | sB1 | sB2) & 7) != 0) return ALM_ERR_BAD_ARG;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0};
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    dim3 grid(tiles, nb1 * nb2);
-    if (out_f32)
-        hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (view_too_big(256, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0};
+    int rc = launch_gemm<false>(p, nb1 * nb2, 1, out_f32, 0, (hipStream_t)stream);
+    if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
-// Split-K variant for long-K / few-tile contractions (weight gradients: K = B*N tokens).  ws: fp32 workspace of
-// alm_gemm_splitk_slices(M, N, K) * M * N floats.  Deterministic (no atomics): slices are reduced in a fixed order.
-extern "C" int alm_gemm_splitk_slices(int M, int N, int K) {
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int s = (1024 + tiles - 1) / tiles;                 // aim at ~2 resident blocks on each of the 256 CUs, twice over
-    const int maxs = (K + 511) / 512;                   // keep >= 512 of K per slice
-    if (s > maxs) s = maxs;
-    if (s > 64) s = 64;
-    return s < 1 ? 1 : s;
+/* tile-selectable form of the above without batching (benchmarks / tuning): tile 0 = auto, 1 = 128x128, 2 = 256x256 */
+extern "C" int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
+                                     long long ldb, long long ldc, float alpha, int out_f32, int accumulate, int tile, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
+    if (view_too_big(256, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, 0, 0, 0, alpha, accumulate, 0, 0};
+    int rc = launch_gemm<false>(p, 1, 1, out_f32, tile, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Split-K for long-K / few-tile contractions (weight gradients: K = B*N tokens), `nb` same-shape problems per launch (element
+// strides sA / sB / sC between them).  ws: fp32 workspace of alm_gemm_splitk_slices(M, N, K, nb) * nb * M * N floats (unused when
+// that is 1).  Deterministic (no atomics): the slices are reduced in a fixed order by a second kernel.
+extern "C" int alm_gemm_splitk_slices(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).slices; }
+
+static int splitk_common(bool tn, const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
+                         long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, hipStream_t st) {
+    const SplitPlan pl = splitk_plan(M, N, K, nb);
+    if (pl.slices <= 1) {
+        GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, M, N, K, lda, ldb, ldc, nb, 0, sA, 0, sB, 0, sC, alpha, accumulate, 0, 0};
+        return tn ? launch_gemm<true>(p, nb, 1, 1, pl.tile, st) : launch_gemm<false>(p, nb, 1, 1, pl.tile, st);
+    }
+    if (!ws) return ALM_ERR_BAD_ARG;
+    int kc = (K + pl.slices - 1) / pl.slices;
+    kc = (kc + BK - 1) / BK * BK;
+    const int nsl = (K + kc - 1) / kc;
+    const long long mn = (long long)M * N;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, (long long)N, nb, 0, sA, 0, sB, 0, mn, alpha, 0, kc, mn * nb};
+    int rc = tn ? launch_gemm<true>(p, nb, nsl, 1, pl.tile, st) : launch_gemm<false>(p, nb, nsl, 1, pl.tile, st);
+    if (rc) return rc;
+    const int grid = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid, nb), dim3(256), 0, st, (const float*)ws, nsl, mn, mn * nb, N, C, ldc, sC, accumulate);
+    return 0;
 }
 
 extern "C" int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
-                                       long long ldc, float alpha, int accumulate, void* stream) {
-    if (M <= 0 || N <= 0) return 0;
-    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
-    const int splits = alm_gemm_splitk_slices(M, N, K);
-    int kc = (K + splits - 1) / splits;
-    kc = (kc + BK - 1) / BK * BK;
-    const int nsl = (K + kc - 1) / kc;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, (long long)N, nsl, 0, kc, 0, kc, 0, (long long)M * N, alpha, 0, kc};
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(tiles, nsl), dim3(256), 0, (hipStream_t)stream, p);
-    const long long mn = (long long)M * N;
-    const int grid = (int)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nsl, mn, N, C, ldc, accumulate);
+                                       long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate,
+                                       void* stream) {
+    if (M <= 0 || N <= 0 || nb <= 0) return 0;
+    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((sA | sB) & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
+    if (view_too_big(256, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
+    int rc = splitk_common(false, A, B, C, ws, M, N, K, lda, ldb, ldc, nb, sA, sB, sC, alpha, accumulate, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight-gradient form: C[M,N] fp32 (+)= alpha * sum_k At[k][m] * Bt[k][n]  (At: [K][lda], Bt: [K][ldb], row-major activations).
+extern "C" int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda,
+                                       long long ldb, long long ldc, int nb, long long sA, long long sB, long long sC, float alpha,
+                                       int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || nb <= 0) return 0;
+    if (K <= 0 || (lda & 7) || (ldb & 7) || ((sA | sB) & 7) || ((uintptr_t)At & 15) || ((uintptr_t)Bt & 15)) return ALM_ERR_BAD_ARG;
+    if (view_too_big(K, lda) || view_too_big(K, ldb)) return ALM_ERR_UNSUPPORTED;
+    int rc = splitk_common(true, At, Bt, C, ws, M, N, K, lda, ldb, ldc, nb, sA, sB, sC, alpha, accumulate, (hipStream_t)stream);
+    if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
@@ -270,15 +565,6 @@ extern "C" int alm_transpose_bf16(const void* src, void* dst, int rows, int cols
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src,
                        ld_dst, rows_pad, 0LL, 0LL);
     ALM_LAUNCH_CHECK();
-    return 0;
-}
-
-// batched form used inside the attention launchers: dst[z][c][r] = src[z][r][c]
-int alm_transpose_bf16_batched_internal(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad,
-                                        int batch, long long bs_src, long long bs_dst, hipStream_t stream) {
-    dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64, batch);
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, ld_dst, rows_pad,
-                       bs_src, bs_dst);
     return 0;
 }
 

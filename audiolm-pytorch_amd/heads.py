@@ -94,9 +94,7 @@ class HeadsLossFn(torch.autograd.Function):
             ops.scatter_rows(dhg.view(G * Rg, D), g.idx.reshape(-1), dhn)
             dW = torch.empty((G, C, D), dtype=F32, device=dev)
             for q in range(G):                                                    # wgrad: dlogits_q^T @ hidden_q
-                dlT = ops.transpose(dl[q * Rg:(q + 1) * Rg])                      # [Cp, Rgpad]
-                hgT = ops.transpose(hg[q * Rg:(q + 1) * Rg])                      # [D, Rgpad]
-                ops.gemm_nt_splitk(dlT[:C], hgT, dW[q])
+                ops.gemm_tn_splitk(dl[q * Rg:(q + 1) * Rg, :C], hg[q * Rg:(q + 1) * Rg], dW[q])
             grads.append(dW.reshape(ctx.params[len(grads)].shape))
             if has_bias:
                 grads.append(ops.colsum(dl[:, :C]))

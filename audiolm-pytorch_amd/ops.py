@@ -56,18 +56,45 @@ def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
     return C
 
 
+def _splitk(name, A, B, C, M, N, K, nb, sA, sB, sC, alpha, accumulate):
+    slices = _lib.query('alm_gemm_splitk_slices', M, N, K, nb)
+    ws = torch.empty((slices, nb, M, N), dtype=F32, device=A.device) if slices > 1 else None
+    _lib.call(name, A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(ws), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2), nb, sA, sB, sC,
+              float(alpha), int(accumulate), _st())
+    return C
+
+
 def gemm_nt_splitk(A, B, C, *, alpha=1.0, accumulate=False):
-    """fp32 C[M, N] (+)= alpha * A[M, K] @ B[N, K]^T with K split over workgroups (weight gradients: K = tokens)."""
+    """fp32 C[M, N] (+)= alpha * A[M, K] @ B[N, K]^T with K split over workgroups (long-K, few-tile contractions)."""
     _chk(A, BF16), _chk(B, BF16), _chk(C, F32)
     M, K = A.shape
     N = B.shape[0]
     assert B.shape[1] == K and C.shape == (M, N) and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
-    slices = _lib.query('alm_gemm_splitk_slices', M, N, K)
-    if slices <= 1:
-        return gemm_nt(A, B, C, alpha=alpha, accumulate=accumulate)
-    ws = torch.empty((slices, M, N), dtype=F32, device=A.device)
-    _lib.call('alm_gemm_bf16_nt_splitk', A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), M, N, K, A.stride(0), B.stride(0), C.stride(0),
-              float(alpha), int(accumulate), _st())
+    return _splitk('alm_gemm_bf16_nt_splitk', A, B, C, M, N, K, 1, 0, 0, 0, alpha, accumulate)
+
+
+def gemm_tn_splitk(At, Bt, C, *, alpha=1.0, accumulate=False):
+    """fp32 C[(nb,) M, N] (+)= alpha * At[K, (nb,) M]^T @ Bt[K, N]: the weight-gradient contraction over K = tokens, read straight from
+    the row-major activations (LDS transpose reads inside the kernel; no transposed copies).  A 3-D `At` of shape [nb, K, M] (a strided
+    view, e.g. the x / gate halves of dU) with a 3-D C [nb, M, N] runs the nb problems in one launch against the same Bt."""
+    _chk(At, BF16), _chk(Bt, BF16), _chk(C, F32)
+    nb, sA, sC = 1, 0, 0
+    if At.dim() == 3:
+        nb, sA, sC = At.shape[0], At.stride(0), C.stride(0)
+        assert C.dim() == 3 and C.shape[0] == nb
+    K, M = At.shape[-2:]
+    N = Bt.shape[1]
+    assert Bt.dim() == 2 and Bt.shape[0] == K and C.shape[-2:] == (M, N) and At.stride(-1) == 1 and Bt.stride(1) == 1 and C.stride(-1) == 1
+    return _splitk('alm_gemm_bf16_tn_splitk', At, Bt, C, M, N, K, nb, sA, 0, sC, alpha, accumulate)
+
+
+def gemm_nt_tile(A, B, C, tile, *, bias=None, alpha=1.0, accumulate=False):
+    """un-batched gemm_nt with an explicit tile configuration (0 auto, 1 = 128x128, 2 = 256x256): tuning / benchmarks."""
+    _chk(A, BF16), _chk(B, BF16), _chk(C)
+    M, K = A.shape
+    N = B.shape[0]
+    _lib.call('alm_gemm_bf16_nt_tile', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(0), B.stride(0), C.stride(0),
+              float(alpha), int(C.dtype == F32), int(accumulate), int(tile), _st())
     return C
 
 

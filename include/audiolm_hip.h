@@ -29,11 +29,22 @@ extern "C" {
 int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                      long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
                      long long sC2, float alpha, int out_f32, int accumulate, void* stream);
-/* split-K variant for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * A . B^T, deterministic
- * two-stage reduction through `ws` (alm_gemm_splitk_slices(M,N,K) * M * N floats). */
-int alm_gemm_splitk_slices(int M, int N, int K);
+/* tile-selectable, un-batched form of alm_gemm_bf16_nt (tuning / benchmarks): tile 0 = auto, 1 = 128x128x64 (4 waves),
+ * 2 = 256x256x64 (8 waves). */
+int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
+                          long long ldc, float alpha, int out_f32, int accumulate, int tile, void* stream);
+/* split-K forms for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * op(A) . op(B),
+ * deterministic two-stage reduction through `ws` (alm_gemm_splitk_slices(M,N,K,nb) * nb * M * N floats; may be NULL when that
+ * query returns 1).  `nb` same-shape problems per launch with element strides sA / sB / sC between them (sA, sB % 8 == 0).
+ *   _nt_: A[M][K], B[N][K] (K-contiguous operands)
+ *   _tn_: At[K][M], Bt[K][N] (contraction-major operands = the row-major activations themselves):
+ *         dW[out][in] = sum_tokens dY[token][out] * X[token][in], the wgrad of every nn.Linear on the path
+ *         (autograd of audiolm_pytorch.py:255-259, :351, :395, :961, :972) with no transposed copies; lda/ldb % 8 == 0. */
+int alm_gemm_splitk_slices(int M, int N, int K, int nb);
 int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
-                            long long ldc, float alpha, int accumulate, void* stream);
+                            long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
+int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
+                            long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 /* dst[c][r] = src[r][c]; columns [rows, rows_pad) of dst are zero-filled (K-padding of a transposed GEMM operand). */
 int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, void* stream);
 /* fp32 master weight -> zero-padded bf16 copy (dst, may be NULL) and zero-padded bf16 transpose (dstT, may be NULL).

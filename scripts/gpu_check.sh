@@ -19,6 +19,10 @@ if [[ $what == tests || $what == all ]]; then
   timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
   echo "smoke rc=$?"; tail -n 5 gpurun_out/smoke.log
 fi
+if [[ $what == kbench || $what == all ]]; then
+  timeout 600 python scripts/kbench.py > gpurun_out/kbench.log 2>&1
+  echo "kbench rc=$?"; cat gpurun_out/kbench.log
+fi
 if [[ $what == bench || $what == all ]]; then
   timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
   echo "bench rc=$?"; tail -n 12 gpurun_out/bench.log
@@ -27,6 +31,6 @@ if [[ $what == prof || $what == all ]]; then
   export TMPDIR=/tmp
   timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r1 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg > gpurun_out/prof.log 2>&1
   echo "prof rc=$?"; tail -n 5 gpurun_out/prof.log
-  find gpurun_out/prof -name "*stats*" | head
-  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [[ -n $f ]] && head -n 30 "$f"
+  db=$(find gpurun_out/prof -name "*.db" | head -1)
+  if [[ -n $db ]]; then python scripts/prof_summary.py "$db" gpurun_out/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg (8 steps incl. warm-up + 1 instrumented)"; rm -f "$db"; head -n 30 gpurun_out/kernel_stats.csv | cut -c1-180; fi
 fi

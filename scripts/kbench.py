@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on the MI355X for the hot-path shapes (B=8 x N=2048 tokens, D=1024): every GEMM variant vs the vendor
+BLAS yardstick (torch.matmul; NOT part of the product), attention fwd/bwd, hyper-connection kernels.  Prints one line per case:
+name, ms, TFLOP/s or GB/s.   usage: python scripts/kbench.py [gemm] [attn] [hc] [misc]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import audiolm_pytorch_amd as A  # noqa: E402,F401
+from audiolm_pytorch_amd import ops, _lib  # noqa: E402
+
+BF16, F32 = torch.bfloat16, torch.float32
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def rnd(*shape, dtype=BF16):
+    return (torch.rand(*shape, device=dev) * 2 - 1).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def bench_gemm():
+    T = 16384
+    shapes = [('W1 fwd', T, 5472, 1024), ('W2 fwd', T, 1024, 2736), ('dHN dgrad', T, 2736, 1024), ('dXN2 dgrad', T, 1024, 5472),
+              ('Wq fwd', T, 512, 1024), ('Wo fwd', T, 1024, 512), ('Wkv fwd', T, 128, 1024), ('square 4096', 4096, 4096, 4096),
+              ('square 8192', 8192, 8192, 8192)]
+    print('--- NT GEMMs  C[M,N] = A[M,K] B[N,K]^T (bf16 out)')
+    for name, M, N, K in shapes:
+        Am, Bm = rnd(M, K), rnd(N, K)
+        C = torch.empty((M, N), dtype=BF16, device=dev)
+        fl = 2.0 * M * N * K
+        ref = None
+        line = f'{name:14s} {M}x{N}x{K}:'
+        t = timeit(lambda: torch.matmul(Am, Bm.t(), out=C))
+        ref = C.clone()
+        line += f'  blas {t:.3f} ms {fl / t / 1e9:7.0f} TF |'
+        for tile in (1, 2):
+            if tile == 2 and (M < 256 or N < 256):
+                continue
+            C.zero_()
+            t = timeit(lambda: ops.gemm_nt_tile(Am, Bm, C, tile))
+            line += f'  tile{tile} {t:.3f} ms {fl / t / 1e9:7.0f} TF (err {relerr(C, ref):.1e}) |'
+        print(line, flush=True)
+    print('--- TN split-K wgrads  C[M,N] = At[K,M]^T Bt[K,N] (fp32 out)')
+    for name, M, N, K in [('dW1 half', 2730, 1024, T), ('dW2', 1024, 2730, T), ('dWq', 512, 1024, T), ('dWo', 1024, 512, T), ('dWkv', 128, 1024, T),
+                          ('dWhead', 1025, 1024, 4096)]:
+        At, Bt = rnd(K, (M + 7) // 8 * 8)[:, :M], rnd(K, (N + 7) // 8 * 8)[:, :N]
+        C = torch.empty((M, N), dtype=F32, device=dev)
+        fl = 2.0 * M * N * K
+        t0 = timeit(lambda: torch.matmul(At.t(), Bt))
+        ref = torch.matmul(At.t().float(), Bt.float())
+        t = timeit(lambda: ops.gemm_tn_splitk(At, Bt, C))
+        print(f'{name:14s} {M}x{N}x{K}:  blas {t0:.3f} ms {fl / t0 / 1e9:7.0f} TF |  tn-splitk {t:.3f} ms {fl / t / 1e9:7.0f} TF (err {relerr(C, ref):.1e}, '
+              f'slices {_lib.query("alm_gemm_splitk_slices", M, N, K, 1)})', flush=True)
+
+
+def bench_attn():
+    B, N, H, dh = 8, 2048, 8, 64
+    M = B * N
+    Q, KV = rnd(M, H * dh), rnd(M, 2 * dh)
+    K_, V_ = KV[:, :dh], KV[:, dh:]
+    mask = (torch.rand(B, N, device=dev) > 0.15).to(torch.uint8)
+    mask[:, 0] = 1
+    fl_f = 4.0 * B * H * dh * N * (N + 1) / 2
+    AO, LSE = ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh)
+    t = timeit(lambda: ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh))
+    print(f'attn fwd  B{B} N{N} H{H}: {t:.3f} ms  {fl_f / t / 1e9:.0f} TF (causal-exact flops)')
+    dAO = rnd(M, H * dh)
+    t = timeit(lambda: ops.mqa_attn_bwd(Q, K_, V_, mask, AO, LSE, dAO, B, N, H, dh))
+    print(f'attn bwd  B{B} N{N} H{H}: {t:.3f} ms  {2.5 * fl_f / t / 1e9:.0f} TF (2.5 x fwd flops)')
+
+
+def bench_hc():
+    from audiolm_pytorch_amd import core
+    B, S, N, D = 8, 4, 2048, 1024
+    M = B * N
+    R = torch.randn(B, S, N, D, device=dev)
+    hc = dict(Bb=torch.ones(S, device=dev), Aa=torch.randn(S, S + 1, device=dev), Wa=torch.randn(D, S + 1, device=dev) * 0.02,
+              sa=torch.tensor(0.01, device=dev), wb=torch.randn(D, device=dev) * 0.02, sb=torch.tensor(0.01, device=dev),
+              gamma=torch.zeros(D, device=dev))
+    lng = torch.ones(D, device=dev)
+    Rb = R.numel() * 4
+    X, XN, mean, rstd, coef = ops.hc_width_fwd(R, hc, lng, B, S, N, D, want_x=True)
+    t = timeit(lambda: ops.hc_width_fwd(R, hc, lng, B, S, N, D, want_x=True))
+    print(f'hc_width_fwd: {t:.3f} ms  {(Rb + 2 * M * D * 2) / t / 1e6:.0f} GB/s (alg bytes: read R, write X, XN)')
+    Y = rnd(M, D)
+    t = timeit(lambda: ops.hc_depth_fwd(R, Y, coef, B, S, N, D))
+    print(f'hc_depth_fwd: {t:.3f} ms  {(2 * Rb + M * D * 2) / t / 1e6:.0f} GB/s (read R, Y; write R)')
+    dR = torch.randn(B, S, N, D, device=dev)
+    t = timeit(lambda: ops.hc_depth_bwd(dR, Y, coef, B, S, N, D))
+    dY, dbeta = ops.hc_depth_bwd(dR, Y, coef, B, S, N, D)
+    print(f'hc_depth_bwd: {t:.3f} ms  {(Rb + 2 * M * D * 2) / t / 1e6:.0f} GB/s (read dR, Y; write dY)')
+    dX = torch.randn(M, D, device=dev)
+    t = timeit(lambda: ops.hc_width_bwd(dR, dX, R, coef, dbeta, hc, B, S, N, D))
+    print(f'hc_width_bwd: {t:.3f} ms  {(3 * Rb + M * D * 4) / t / 1e6:.0f} GB/s (read dR, R, dX; write dR)')
+
+
+def bench_misc():
+    M, D, I, Ip = 16384, 1024, 2730, 2736
+    U = rnd(M, 2 * Ip)
+    g3 = torch.ones(I, device=dev)
+    HN, mean3, rstd3 = ops.geglu_ln_fwd(U, g3, I, Ip)
+    t = timeit(lambda: ops.geglu_ln_fwd(U, g3, I, Ip))
+    print(f'geglu_ln_fwd: {t:.3f} ms  {(M * 3 * Ip * 2) / t / 1e6:.0f} GB/s')
+    dHN = rnd(M, Ip)
+    t = timeit(lambda: ops.geglu_ln_bwd(dHN, U, g3, mean3, rstd3, I, Ip))
+    print(f'geglu_ln_bwd: {t:.3f} ms  {(M * 5 * Ip * 2) / t / 1e6:.0f} GB/s')
+    x = rnd(M, D)
+    g = torch.ones(D, device=dev)
+    y, _, mean, rstd = ops.layernorm_fwd(x, g)
+    t = timeit(lambda: ops.layernorm_fwd(x, g))
+    print(f'layernorm_fwd bf16: {t:.3f} ms  {(M * D * 4) / t / 1e6:.0f} GB/s')
+    dy = rnd(M, D)
+    t = timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g))
+    print(f'layernorm_bwd: {t:.3f} ms  {(M * D * 8) / t / 1e6:.0f} GB/s')
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['gemm', 'attn', 'hc', 'misc']
+    print(torch.cuda.get_device_name(0), 'CUs', torch.cuda.get_device_properties(0).multi_processor_count)
+    for w in what:
+        globals()['bench_' + w]()

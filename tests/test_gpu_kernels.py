@@ -49,6 +49,49 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
+@pytest.mark.parametrize('tile', [1, 2])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736)])
+def test_gemm_nt_tile_configs(ops, M, N, K, tile):
+    """both block-tile configurations (128x128x64 / 4 waves, 256x256x64 / 8 waves) on full, ragged and K-tail shapes; an asymmetric
+    B catches operand / output transposes."""
+    A, B = rnd(M, K, seed=11, dtype=BF16), rnd(N, K, seed=12, dtype=BF16)
+    for dt, tol in ((F32, 2e-5), (BF16, 4e-3)):
+        C = torch.full((M + 3, N + 5), float('nan'), dtype=dt, device=dev())
+        ops.gemm_nt_tile(A, B, C[:M, :N], tile)
+        ref = A.double() @ B.double().t()
+        err = relmax(C[:M, :N], ref)
+        assert err <= tol, f'gemm tile={tile} {M}x{N}x{K} {dt}: rel-max err {err}'
+        assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'GEMM wrote outside its tile'
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (512, 1024, 4096), (130, 200, 100), (1025, 256, 333), (2730, 1024, 2048), (128, 1024, 16384),
+                                   (1024, 2730, 777)])
+def test_gemm_tn_splitk(ops, M, N, K):
+    """weight-gradient contraction over the ROW index of both operands (LDS transpose reads), incl. strided views, ragged M / N / K."""
+    Abig, Bbig = rnd(K, (M + 23) // 8 * 8, seed=13, dtype=BF16), rnd(K, (N + 15) // 8 * 8, seed=14, dtype=BF16)
+    At, Bt = Abig[:, 8:8 + M], Bbig[:, :N]
+    C = torch.full((M, N), float('nan'), dtype=F32, device=dev())
+    ops.gemm_tn_splitk(At, Bt, C)
+    ref = At.double().t() @ Bt.double()
+    err = relmax(C, ref)
+    assert err <= 3e-5, f'tn gemm {M}x{N}x{K}: rel-max err {err}'
+    C0 = rnd(M, N, seed=15)
+    C1 = C0.clone()
+    ops.gemm_tn_splitk(At, Bt, C1, alpha=0.25, accumulate=True)
+    assert relmax(C1, C0.double() + 0.25 * ref) <= 3e-5
+
+
+def test_gemm_tn_splitk_batched_halves(ops):
+    """the FFN W1 weight gradient: both (x | gate) halves of dU against the same XN2 in ONE launch (batch stride = Ipad columns)."""
+    T, I, Ip, D = 1000, 170, 176, 128
+    dU = rnd(T, 2 * Ip, seed=16, dtype=BF16)
+    XN = rnd(T, D, seed=17, dtype=BF16)
+    dW = torch.full((2 * I, D), float('nan'), dtype=F32, device=dev())
+    ops.gemm_tn_splitk(dU.view(T, 2, Ip).permute(1, 0, 2)[:, :, :I], XN, dW.view(2, I, D))
+    ref = torch.cat([dU[:, :I].double().t() @ XN.double(), dU[:, Ip:Ip + I].double().t() @ XN.double()])
+    assert relmax(dW, ref) <= 3e-5
+
+
 def test_gemm_bias_alpha_accumulate_strided(ops):
     M, N, K = 200, 136, 192
     Abig, Bbig = rnd(M, K + 64, seed=3, dtype=BF16), rnd(N, K + 8, seed=4, dtype=BF16)
