@@ -31,9 +31,10 @@ SIGNATURES = {
     'alm_geglu_ln_fwd': [_P, _L, _I, _P, _P, _L, _P, _P, _I, _I, _I, _P],
     'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
-    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
+    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _P],
     'alm_value_residual_mix': [_P, _L, _P, _L, _P, _L, _L, _I, _P],
-    'alm_kv_grad_pack': [_P, _P, _L, _P, _P, _L, _L, _I, _I, _P],
+    'alm_kv_grad_pack': [_P, _P, _L, _I, _L, _P, _P, _L, _L, _I, _I, _P],
+    'alm_mqa_head_groups': [_I],
     'alm_hc_coef_width': [_I],
     'alm_hc_partial_width': [_I, _I],
     'alm_hc_partial_blocks': [_L],

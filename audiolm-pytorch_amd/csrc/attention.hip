@@ -6,18 +6,23 @@
 // reference materialises never exist here: online softmax, fp32 statistics, bf16 MFMA operands.
 //
 // Mapping (wave64, MFMA 32x32x16 bf16):
-//   * forward / dQ: one workgroup = one 32-row query block of one batch element, one WAVE PER HEAD (8 waves for h = 8).
-//     The K / V tile (64 keys x 64) is loaded from HBM/L2 ONCE per workgroup and shared by all heads through LDS.
-//   * scores are computed transposed, S^T = K Q^T, so that one lane owns one query column: the softmax row statistics
-//     are lane-local (one cross-half shuffle), and the fp32 S^T accumulator registers ARE the B operand (P^T) of the
-//     second MFMA (O^T = V^T P^T) after an in-register bf16 pack: no LDS round trip, no permutes.  The k-index
-//     permutation this implies (a lane half holds keys {4h..4h+3} u {8+4h..8+4h+3} of each 16-key step) is applied
-//     consistently to the V^T fragment read.
-//   * K tile: LDS row-major [key][64], 16-B chunks XOR-swizzled by ((row>>1)&7)  -> conflict-free ds_read_b128.
-//     V tile: LDS transposed [d][64 keys (+4 pad)]                                -> conflict-free ds_read_b64.
-//   * dK/dV: one workgroup = 32 keys of one batch element, one wave per head, loops over the query blocks at/after the
-//     diagonal; the per-head dK^T / dV^T accumulators are summed over heads through LDS (MQA: k/v are shared).
-//   * heavy (long-causal-span) blocks are scheduled first.
+//   * forward / dQ: workgroup = 64 queries of one batch element x 4 heads, ONE WAVE PER HEAD, each wave owning a 64 x 64
+//     (queries x keys) score tile per step.  The 64-key K / V tile is fetched ONCE per workgroup by DMA
+//     (`buffer_load ... lds`, double buffered, one barrier per tile) and shared by the heads -- MQA makes K / V traffic ~free.
+//   * scores are computed transposed, S^T = K Q^T, so that one lane owns one query column: softmax statistics are lane-local
+//     (one cross-half exchange), and the fp32 S^T accumulator registers ARE the B operand (P^T) of the second MFMA
+//     (O^T = V^T P^T) after an in-register bf16 pack: no LDS round trip, no permutes.  The key-index permutation this implies
+//     (a lane half holds keys {4h..4h+3} u {8+4h..8+4h+3} of each 16-key step) is applied to the V^T fragment reads.
+//   * the key-padding mask costs nothing: the S^T accumulators are INITIALISED with a per-key bias (0 / -inf) instead of zero.
+//   * every LDS tile is a [64 rows][64 dims] image with 128-B rows whose 16-B chunks are XOR-swizzled by
+//     f(row) = bit1<<2 | bit3<<1 | bit2, chosen so that BOTH access patterns are bank-conflict free: row fragments
+//     (ds_read_b128, lane = row) and transposed fragments (ds_read_b64_tr_b16, lane = dim, 4 consecutive rows per read).
+//     One image therefore serves K (S^T) and K^T (dQ), V and V^T, Q and Q^T, dO and dO^T.
+//   * deferred rescaling: the running maximum is only raised (and O rescaled) when a tile's maximum exceeds it by 2^8.
+//   * dK/dV: workgroup = 64 keys x 4 heads (8 waves = 4 heads x 2 key halves), loops over the 64-query tiles at/after the
+//     diagonal (Q / dO tiles by DMA, double buffered); per-head dK^T / dV^T accumulators are summed over the 4 heads through
+//     LDS; the two head groups write separate fp32 partials that alm_kv_grad_pack adds (deterministic, no atomics).
+//   * heavy (long-causal-span) workgroups are scheduled first and paired with light ones on a CU.
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -25,28 +30,49 @@ namespace {
 
 constexpr int DH = 64;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int VT_LD = 68;    // transposed tile row stride (64 keys + 4 pad) in bf16
-constexpr int QT_LD = 36;    // transposed 32-wide tile row stride in bf16
+constexpr float RESCALE_THR = 8.0f;                 // log2 units
+constexpr unsigned OOB = 0x80000000u;
+constexpr int HPB = 4;                              // heads per workgroup
 
-__device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ bf16x8 ld_frag_rows(const bf16_t* base, int idx) { return *reinterpret_cast<const bf16x8*>(base + idx); }
+// chunk swizzle of the 128-B-row LDS images
+__device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 
-// two 8-byte reads -> one 8 x bf16 fragment (keys/queries {o..o+3} and {o+8..o+11})
-__device__ __forceinline__ bf16x8 ld_frag_t(const bf16_t* row_ptr, int o) {
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(row_ptr + o);
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(row_ptr + o + 8);
-    bf16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    return r;
+// row fragment: lane (row, lh) gets dims ks*16 + lh*8 .. +7 of `row`
+__device__ __forceinline__ bf16x8 nat_frag(const unsigned char* tile, int row, int frow, int ks, int lh) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((((ks << 1) | lh) ^ frow) << 4));
+}
+
+// transposed fragment for the 16-row step starting at row `k16`: lane (dim = db*32 + (lane & 31), half lh) gets rows
+// k16 + 4*lh + {0..3} and k16 + 8 + 4*lh + {0..3}  -- exactly the key set a lane half holds in the S^T accumulators.
+struct TrOff { unsigned o[2][2]; };                 // [db][r] byte offsets within a 16-row step
+__device__ __forceinline__ TrOff make_troff(int lane) {
+    TrOff t;
+    const int g = lane >> 4, s = lane & 15;
+    const int rr = 4 * (g >> 1) + (s >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = 8 * r + rr;
+            const int ch = db * 4 + (g & 1) * 2 + ((s & 3) >> 1);
+            t.o[db][r] = (unsigned)(row * 128 + ((ch ^ fsw(row)) << 4) + (s & 1) * 8);
+        }
+    return t;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int k16, const TrOff& t, int db) {
+    const unsigned char* base = tile + k16 * 128;
+    return __builtin_shufflevector(lds_tr16(base + t.o[db][0]), lds_tr16(base + t.o[db][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-    bf16x8 r;
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
+    f32x8 f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[8 * s + j]);
-    return r;
+    for (int j = 0; j < 8; ++j) f[j] = v[8 * s + j];
+    return __builtin_bit_cast(bf16x8, __builtin_convertvector(f, hbf16x8));      // 4 x v_cvt_pk_bf16_f32 (round-to-nearest-even)
 }
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -64,195 +90,236 @@ __device__ __forceinline__ bf16x8 gload8(const bf16_t* p, bool ok) {
 struct AttnParams {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const uint8_t* mask;
     bf16_t* o; float* lse;
-    const bf16_t* dout; const float* delta;
+    const bf16_t* dout; const float* ndelta; const float* nlse;
     bf16_t* dq; float* dk; float* dv;
-    long long ldq, ldk, ldv, ldo, lddo, lddq, lddk;
-    int B, N, H;
+    long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, part_stride;
+    int B, N, H, HG;
     float scale;
 };
 
-// key index (within a 32-key block) held by accumulator register r of a lane in half lh
+// log-sum-exp -> log2 domain; a fully masked query row (lse = -inf, the forward wrote zeros) gets +inf so that every P is 0
+__device__ __forceinline__ float lse_log2(float l) { return l == -INFINITY ? INFINITY : l * LOG2E; }
+
+// row (within a 32-row block) held by accumulator register r of a lane in half lh
 __device__ __forceinline__ int drow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-// ------------------------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[2][64 * VT_LD];
+// workgroup id -> (light/heavy-paired block index, head group, batch element)
+struct BlockId { int blk, hg, b; };
+__device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, bool heavy_is_high, bool pair_on_cu) {
+    BlockId r;
+    const int idx = L % nblk, rest = L / nblk;
+    r.hg = rest % HG;
+    r.b = rest / HG;
+    // two co-resident workgroups per CU: the second one (L + 256) gets the complementary weight; one workgroup per CU
+    // (round-based execution): plain heaviest-first order (longest-processing-time-first list scheduling)
+    const bool flip = pair_on_cu && ((L >> 8) & 1);
+    const int heavy_first = heavy_is_high ? nblk - 1 - idx : idx;
+    const int light_first = heavy_is_high ? idx : nblk - 1 - idx;
+    r.blk = flip ? light_first : heavy_first;
+    return r;
+}
 
-    const int nqb = (p.N + 31) / 32;
-    const int qb = nqb - 1 - blockIdx.x;          // heavy blocks first
-    const int b = blockIdx.y;
-    const int q0 = qb * 32;
-    const int t = threadIdx.x, nthreads = blockDim.x;
-    const int lane = t & 63, h = t >> 6;
-    const int lr = lane & 31, lh = lane >> 5;
-    const float sl2 = p.scale * LOG2E;
-
-    const bf16_t* kb_ptr = p.k + (long long)b * p.N * p.ldk;
-    const bf16_t* vb_ptr = p.v + (long long)b * p.N * p.ldv;
-    const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
-
-    // Q^T fragments (B operand): lane = query column, k = head-dim
-    const int qi = q0 + lr;
-    const bool qok = qi < p.N;
-    bf16x8 qf[4];
-    {
-        const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + h * DH;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = gload8(qp + ks * 16 + lh * 8, qok);
-    }
-
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
-
-    const int ntiles = min((q0 + 31) / 64 + 1, (p.N + 63) / 64);
-
-    // cooperative K / V tile staging: 512 16-byte chunks per operand per tile
-    uint4 rk, rv;
-    auto load_kv = [&](int tile) {
-        rk = rv = make_uint4(0, 0, 0, 0);
-        if (t < 512) {
-            const int key = tile * 64 + (t >> 3), c = t & 7;
-            if (key < p.N) {
-                rk = *reinterpret_cast<const uint4*>(kb_ptr + (long long)key * p.ldk + c * 8);
-                rv = *reinterpret_cast<const uint4*>(vb_ptr + (long long)key * p.ldv + c * 8);
-            }
-        }
-    };
-    auto store_kv = [&](int buf) {
-        if (t < 512) {
-            const int key = t >> 3, c = t & 7;
-            *reinterpret_cast<uint4*>(&Ks[buf][kswz(key, c)]) = rk;
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&rv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[buf][(c * 8 + j) * VT_LD + key] = e[j];
-        }
-    };
-    // with fewer than 8 heads (< 512 threads) every thread stages several chunks
-    auto stage_small = [&](int tile, int buf) {
-        for (int cidx = t; cidx < 512; cidx += nthreads) {
-            const int key = cidx >> 3, c = cidx & 7;
-            const int gk = tile * 64 + key;
-            uint4 a = make_uint4(0, 0, 0, 0), bq = make_uint4(0, 0, 0, 0);
-            if (gk < p.N) {
-                a = *reinterpret_cast<const uint4*>(kb_ptr + (long long)gk * p.ldk + c * 8);
-                bq = *reinterpret_cast<const uint4*>(vb_ptr + (long long)gk * p.ldv + c * 8);
-            }
-            *reinterpret_cast<uint4*>(&Ks[buf][kswz(key, c)]) = a;
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&bq);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[buf][(c * 8 + j) * VT_LD + key] = e[j];
-        }
-    };
-    const bool big = nthreads >= 512;
-
-    if (big) { load_kv(0); store_kv(0); } else stage_small(0, 0);
-    __syncthreads();
-
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        const int key0 = tile * 64;
-        if (big && tile + 1 < ntiles) load_kv(tile + 1);
-
-        // key-validity bits of this tile (bit i <-> key0 + i), wave-uniform
-        unsigned long long mbits;
-        {
-            const int kk = key0 + lane;
-            bool ok = kk < p.N;
-            if (ok && mrow) ok = mrow[kk] != 0;
-            mbits = __ballot(ok);
-        }
-
-        // S^T = K Q^T  (keys x queries), two 32-key blocks
-        f32x16 st[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = ld_frag_rows(Ks[buf], kswz(kb * 32 + lr, ks * 2 + lh));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-            }
-        }
-        // mask + online softmax (lane owns query qi; its partner lane^32 owns the other half of the keys)
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kb * 32 + drow(r, lh);
-                const bool ok = ((mbits >> kl) & 1ull) && (key0 + kl <= qi);
-                const float s = ok ? st[kb][r] * sl2 : -INFINITY;
-                st[kb][r] = s;
-                tmax = fmaxf(tmax, s);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);
-        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = exp2f(m - msafe);          // m == -inf -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(st[kb][r] - msafe);
-                st[kb][r] = pv;
-                psum += pv;
-            }
-        l = l * alpha + psum;
-        m = mnew;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-
-        // O^T += V^T P^T
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = pack8(st[kb], s);
-#pragma unroll
-                for (int di = 0; di < 2; ++di) {
-                    const bf16x8 vf = ld_frag_t(&Vt[buf][(di * 32 + lr) * VT_LD], kb * 32 + s * 16 + lh * 4);
-                    o[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[di], 0, 0, 0);
-                }
-            }
-
-        if (tile + 1 < ntiles) {
-            if (big) store_kv(buf ^ 1); else stage_small(tile + 1, buf ^ 1);
-        }
-        __syncthreads();
-    }
-
-    const float lt = l + __shfl_xor(l, 32, 64);
-    const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    if (qok) {
-        bf16_t* op = p.o + ((long long)b * p.N + qi) * p.ldo + h * DH;
-#pragma unroll
-        for (int di = 0; di < 2; ++di)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = di * 32 + 8 * g + 4 * lh;
-                *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(o[di][4 * g] * inv, o[di][4 * g + 1] * inv),
-                                                               pack_bf2(o[di][4 * g + 2] * inv, o[di][4 * g + 3] * inv));
-            }
-        if (lh == 0) p.lse[((long long)b * p.H + h) * p.N + qi] = (lt > 0.f) ? (m / LOG2E + logf(lt)) : -INFINITY;
+// DMA of one [64 rows][64 dims] tile (rows row0 .. row0 + 63 of a row-major matrix with `ld_bytes` row pitch, dims at byte
+// offset col_bytes) into a swizzled LDS image: 8 pieces of 8 rows; this wave issues pieces first, first + step, ...
+__device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsigned char* img, int first, int step, int lane, int row0, int nrows,
+                                         unsigned ld_bytes, unsigned col_bytes) {
+    for (int piece = first; piece < 8; piece += step) {
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ fsw(row);
+        const unsigned vo = (row0 + row < nrows) ? (unsigned)(row0 + row) * ld_bytes + col_bytes + (unsigned)c * 16u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + piece * 1024), 16, vo, 0, 0, 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// delta[b][h][q] = sum_d dO * O     (one wave per (b, q) row; 8 lanes per head)
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512];
+    float* kbias = reinterpret_cast<float*>(smem + 32768);          // [2][64]: 0 for attendable keys, -inf otherwise
+
+    const int nqb = (p.N + 63) / 64;
+    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, true, true);
+    const int qblk = id.blk, b = id.b;
+    const int q0 = qblk * 64;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int head = id.hg * HPB + wave;
+    const bool active = head < p.H;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float c2 = p.scale * LOG2E;
+
+    const bf16_t* kbase = p.k + (long long)b * p.N * p.ldk;
+    const bf16_t* vbase = p.v + (long long)b * p.N * p.ldv;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, (int)(((long long)(p.N - 1) * p.ldk + DH) * 2), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
+    const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
+
+    auto stage = [&](int tile, int buf) {
+        unsigned char* img = smem + buf * 16384;
+        dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
+        dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
+        if (t < 64) {
+            const int key = tile * 64 + t;
+            bool ok = key < p.N;
+            if (ok && mrow) ok = mrow[key] != 0;
+            kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
+        }
+    };
+
+    // Q^T fragments (B operand): lane = query column, k = head dim
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + lr;
+        const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + head * DH;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = gload8(qp + ks * 16 + lh * 8, active && qi < p.N);
+    }
+
+    f32x16 o[2][2];                    // [db][qb]: O^T blocks (rows = head dim, cols = queries)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][j][r] = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    const int frow = fsw(lr);
+    const TrOff troff = make_troff(lane);
+    const int ntiles = qblk + 1;
+
+    stage(0, 0);
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        if (active) {
+            const unsigned char* Kt = smem + buf * 16384;
+            const unsigned char* Vt = Kt + 8192;
+            const float* kbs = kbias + buf * 64;
+
+            // S^T = K Q^T (+ key bias): [kb][qb] 32x32 blocks
+            f32x16 st[2][2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        st[kb][qb][4 * g + 0] = bv.x; st[kb][qb][4 * g + 1] = bv.y;
+                        st[kb][qb][4 * g + 2] = bv.z; st[kb][qb][4 * g + 3] = bv.w;
+                    }
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 kf = nat_frag(Kt, kb * 32 + lr, frow, ks, lh);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
+                }
+            if (tile == qblk) {                                    // diagonal tile: causal mask (key index > query index)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kb * 32 + drow(r, lh) > qb * 32 + lr) st[kb][qb][r] = -INFINITY;
+            }
+            // online softmax, one lane = one query (its partner lane ^ 32 owns the other half of the keys)
+            float tm[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float a = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a = fmaxf(a, st[kb][qb][r]);
+                a = fmaxf(a, __shfl_xor(a, 32, 64));
+                tm[qb] = a * c2;
+            }
+            const bool need = (tm[0] > m[0] + RESCALE_THR) || (tm[1] > m[1] + RESCALE_THR);
+            if (__any(need)) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const float mn = fmaxf(m[qb], tm[qb]);
+                    const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qb] - mn);
+                    m[qb] = mn;
+                    l[qb] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float ms = (m[qb] == -INFINITY) ? 0.f : m[qb];
+                float ps = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][qb][r], c2, -ms));
+                        st[kb][qb][r] = pv;
+                        ps += pv;
+                    }
+                l[qb] += ps;
+            }
+            // O^T += V^T P^T
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 pf[2];
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) pf[qb] = pack8(st[kb][qb], s);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 vf = tr_frag(Vt, kb * 32 + s * 16, troff, db);
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + lr;
+        const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        if (qi < p.N) {
+            bf16_t* op = p.o + ((long long)b * p.N + qi) * p.ldo + head * DH;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * lh;
+                    *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv),
+                                                                   pack_bf2(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv));
+                }
+            if (lh == 0) p.lse[((long long)b * p.H + head) * p.N + qi] = (lt > 0.f) ? (m[qb] / LOG2E + logf(lt)) : -INFINITY;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward prologue (one wave per (b, q) row; 8 lanes per head):
+//   ndelta[b][h][q] = -sum_d dO * O          nlse[b][h][q] = -lse / scale   (-inf for a fully masked query row)
+// Both are accumulator INITIAL VALUES of the backward MFMAs: dP - delta and (S - lse / scale) come out of the matrix core.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, long long ldo, const bf16_t* __restrict__ dout,
-                                                         long long lddo, float* __restrict__ delta, int B, int N, int H) {
+                                                         long long lddo, const float* __restrict__ lse, float* __restrict__ ndelta,
+                                                         float* __restrict__ nlse, float inv_scale, int B, int N, int H) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)B * N) return;
@@ -266,156 +333,183 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
-        if ((lane & 7) == 0) delta[((long long)b * H + (c >> 3)) * N + qi] = s;
+        if ((lane & 7) == 0) {
+            const long long idx = ((long long)b * H + (c >> 3)) * N + qi;
+            ndelta[idx] = -s;
+            const float l = lse[idx];
+            nlse[idx] = (l == -INFINITY) ? -INFINITY : -l * inv_scale;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward dQ: same decomposition as forward.  dQ^T = scale * K^T dS^T,  dS^T = P^T o (dP^T - delta),  dP^T = V dO^T.
+// The two 32-query blocks of a wave are processed one after the other inside a tile (register budget).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];     // K natural  (A operand of K Q^T)
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];     // V natural  (A operand of V dO^T)
-    __shared__ __attribute__((aligned(16))) bf16_t Kt[64 * VT_LD];  // K transposed (A operand of K^T dS^T)
+__global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512];
+    float* kbias = reinterpret_cast<float*>(smem + 32768);
 
-    const int nqb = (p.N + 31) / 32;
-    const int qb = nqb - 1 - blockIdx.x;
-    const int b = blockIdx.y;
-    const int q0 = qb * 32;
-    const int t = threadIdx.x, nthreads = blockDim.x;
-    const int lane = t & 63, h = t >> 6;
+    const int nqb = (p.N + 63) / 64;
+    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, true, true);
+    const int qblk = id.blk, b = id.b;
+    const int q0 = qblk * 64;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int head = id.hg * HPB + wave;
+    const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
-    const float sl2 = p.scale * LOG2E;
+    const float c2 = p.scale * LOG2E;
 
-    const bf16_t* kb_ptr = p.k + (long long)b * p.N * p.ldk;
-    const bf16_t* vb_ptr = p.v + (long long)b * p.N * p.ldv;
+    const bf16_t* kbase = p.k + (long long)b * p.N * p.ldk;
+    const bf16_t* vbase = p.v + (long long)b * p.N * p.ldv;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, (int)(((long long)(p.N - 1) * p.ldk + DH) * 2), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
     const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
 
-    const int qi = q0 + lr;
-    const bool qok = qi < p.N;
-    bf16x8 qf[4], dof[4];
-    {
-        const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + h * DH;
-        const bf16_t* dp = p.dout + ((long long)b * p.N + qi) * p.lddo + h * DH;
+    auto stage = [&](int tile, int buf) {
+        unsigned char* img = smem + buf * 16384;
+        dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
+        dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
+        if (t < 64) {
+            const int key = tile * 64 + t;
+            bool ok = key < p.N;
+            if (ok && mrow) ok = mrow[key] != 0;
+            kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
+        }
+    };
+
+    bf16x8 qf[2][4], dof[2][4];
+    float lse2[2], dlt[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + lr;
+        const bool ok = active && qi < p.N;
+        const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + head * DH;
+        const bf16_t* dp = p.dout + ((long long)b * p.N + qi) * p.lddo + head * DH;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = gload8(qp + ks * 16 + lh * 8, qok);
-            dof[ks] = gload8(dp + ks * 16 + lh * 8, qok);
+            qf[qb][ks] = gload8(qp + ks * 16 + lh * 8, ok);
+            dof[qb][ks] = gload8(dp + ks * 16 + lh * 8, ok);
         }
+        lse2[qb] = ok ? lse_log2(p.lse[((long long)b * p.H + head) * p.N + qi]) : INFINITY;
+        dlt[qb] = ok ? p.ndelta[((long long)b * p.H + head) * p.N + qi] : 0.f;          // = -delta
     }
-    const float lse2 = qok ? p.lse[((long long)b * p.H + h) * p.N + qi] * LOG2E : INFINITY;
-    const float dlt = qok ? p.delta[((long long)b * p.H + h) * p.N + qi] : 0.f;
 
-    f32x16 dq[2];
+    f32x16 dq[2][2];                   // [db][qb]: dQ^T blocks
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[i][j][r] = 0.f;
 
-    const int ntiles = min((q0 + 31) / 64 + 1, (p.N + 63) / 64);
+    const int frow = fsw(lr);
+    const TrOff troff = make_troff(lane);
+    const int ntiles = qblk + 1;
+
+    stage(0, 0);
+    __syncthreads();
+
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int key0 = tile * 64;
-        __syncthreads();
-        for (int cidx = t; cidx < 512; cidx += nthreads) {
-            const int key = cidx >> 3, c = cidx & 7;
-            const int gk = key0 + key;
-            uint4 a = make_uint4(0, 0, 0, 0), bq = make_uint4(0, 0, 0, 0);
-            if (gk < p.N) {
-                a = *reinterpret_cast<const uint4*>(kb_ptr + (long long)gk * p.ldk + c * 8);
-                bq = *reinterpret_cast<const uint4*>(vb_ptr + (long long)gk * p.ldv + c * 8);
-            }
-            *reinterpret_cast<uint4*>(&Ks[kswz(key, c)]) = a;
-            *reinterpret_cast<uint4*>(&Vs[kswz(key, c)]) = bq;
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&a);
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        if (active) {
+            const unsigned char* Kt = smem + buf * 16384;
+            const unsigned char* Vt = Kt + 8192;
+            const float* kbs = kbias + buf * 64;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VT_LD + key] = e[j];
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 st[2], dpt[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                        st[kb][4 * g + 0] = bv.x; st[kb][4 * g + 1] = bv.y; st[kb][4 * g + 2] = bv.z; st[kb][4 * g + 3] = bv.w;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dpt[kb][4 * g + c] = 0.f;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const bf16x8 kf = nat_frag(Kt, kb * 32 + lr, frow, ks, lh);
+                        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], st[kb], 0, 0, 0);
+                        const bf16x8 vf = nat_frag(Vt, kb * 32 + lr, frow, ks, lh);
+                        dpt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[qb][ks], dpt[kb], 0, 0, 0);
+                    }
+                const bool diag = tile == qblk;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c2, -lse2[qb]));      // masked keys: exp2(-inf) = 0
+                        if (diag && kb * 32 + drow(r, lh) > qb * 32 + lr) pv = 0.f;
+                        st[kb][r] = pv * (dpt[kb][r] + dlt[qb]);                                           // dS^T (unscaled)
+                    }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 dsf = pack8(st[kb], s);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 ktf = tr_frag(Kt, kb * 32 + s * 16, troff, db);
+                            dq[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[db][qb], 0, 0, 0);
+                        }
+                    }
+            }
         }
         __syncthreads();
-
-        unsigned long long mbits;
-        {
-            const int kk = key0 + lane;
-            bool ok = kk < p.N;
-            if (ok && mrow) ok = mrow[kk] != 0;
-            mbits = __ballot(ok);
-        }
-
-        f32x16 st[2], dpt[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dpt[kb][r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = ld_frag_rows(Ks, kswz(kb * 32 + lr, ks * 2 + lh));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-                const bf16x8 vf = ld_frag_rows(Vs, kswz(kb * 32 + lr, ks * 2 + lh));
-                dpt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dpt[kb], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kb * 32 + drow(r, lh);
-                const bool ok = ((mbits >> kl) & 1ull) && (key0 + kl <= qi);
-                const float pv = ok ? exp2f(st[kb][r] * sl2 - lse2) : 0.f;
-                st[kb][r] = pv * (dpt[kb][r] - dlt);      // dS^T (unscaled)
-            }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 dsf = pack8(st[kb], s);
-#pragma unroll
-                for (int di = 0; di < 2; ++di) {
-                    const bf16x8 ktf = ld_frag_t(&Kt[(di * 32 + lr) * VT_LD], kb * 32 + s * 16 + lh * 4);
-                    dq[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[di], 0, 0, 0);
-                }
-            }
     }
 
-    if (qok) {
-        bf16_t* op = p.dq + ((long long)b * p.N + qi) * p.lddq + h * DH;
-        const float sc = p.scale;
+    if (!active) return;
+    const float sc = p.scale;
 #pragma unroll
-        for (int di = 0; di < 2; ++di)
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 32 + lr;
+        if (qi >= p.N) continue;
+        bf16_t* op = p.dq + ((long long)b * p.N + qi) * p.lddq + head * DH;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int d = di * 32 + 8 * g + 4 * lh;
-                *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(dq[di][4 * g] * sc, dq[di][4 * g + 1] * sc),
-                                                               pack_bf2(dq[di][4 * g + 2] * sc, dq[di][4 * g + 3] * sc));
+                const int d = db * 32 + 8 * g + 4 * lh;
+                *reinterpret_cast<uint2*>(op + d) = make_uint2(pack_bf2(dq[db][qb][4 * g] * sc, dq[db][qb][4 * g + 1] * sc),
+                                                               pack_bf2(dq[db][qb][4 * g + 2] * sc, dq[db][qb][4 * g + 3] * sc));
             }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward dK / dV: workgroup = 32 keys of one batch element; wave = head; loop over query blocks >= diagonal.
-//   S = Q K^T (q x keys),  P = exp2(S*sl2 - lse2[q]),  dP = dO V^T,  dS = P o (dP - delta[q])
-//   dV^T (d x keys) += dO^T P ;  dK^T (dh x keys) += scale * Q^T dS ;  then summed over heads through LDS.
+// backward dK / dV: workgroup = 64 keys x 4 heads of one batch element, 8 waves = (head, 32-key half); loop over the
+// 64-query tiles at/after the diagonal.
+//   S = Q K^T (q x keys),  P = exp2(S*c2 - lse2[q]),  dP = dO V^T,  dS = P o (dP - delta[q])
+//   dV^T (d x keys) += dO^T P ;  dK^T (d x keys) += Q^T dS  (x scale at the end); then summed over the heads through LDS.
+// LDS stage: per head Q tile [64 q][64 d] + dO tile (16 KB) -> 64 KB / stage, 2 stages.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int H = p.H;
-    // per wave: Qt[64][QT_LD], dOt[64][QT_LD] bf16 ; after the loop the region is reused as fp32 [H][64*32]
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+__global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB
 
-    const int kblk = blockIdx.x;
-    const int b = blockIdx.y;
-    const int key0 = kblk * 32;
+    const int nkb = (p.N + 63) / 64;
+    const BlockId id = decode_block(blockIdx.x, nkb, p.HG, false, false);      // low key blocks are the heavy ones
+    const int kblk = id.blk, b = id.b;
     const int t = threadIdx.x;
-    const int lane = t & 63, h = t >> 6;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hl = wave >> 1, kh = wave & 1;                                   // head within the group, key half
+    const int head = id.hg * HPB + hl;
+    const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
-    const float sl2 = p.scale * LOG2E;
+    const float c2 = p.scale * LOG2E;
+    const int key = kblk * 64 + kh * 32 + lr;
 
-    bf16_t* Qt = smem + (size_t)h * (2 * 64 * QT_LD);
-    bf16_t* dOt = Qt + 64 * QT_LD;
-
-    const int key = key0 + lr;
     bool kvalid = key < p.N;
     if (kvalid && p.mask) kvalid = p.mask[(long long)b * p.N + key] != 0;
 
-    // K^T / V^T fragments (B operands): lane = key column, k = head-dim
+    // K^T / V^T fragments (B operands): lane = key column, k = head dim
     bf16x8 kf[4], vf[4];
     {
         const bf16_t* kp = p.k + ((long long)b * p.N + key) * p.ldk;
@@ -427,93 +521,121 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnParams p) {
         }
     }
 
-    f32x16 dkt[2], dvt[2];
+    // DMA descriptors over this batch element's Q / dO rows
+    const bf16_t* qbase = p.q + (long long)b * p.N * p.ldq;
+    const bf16_t* dobase = p.dout + (long long)b * p.N * p.lddo;
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qbase), 0, (int)(((long long)(p.N - 1) * p.ldq + p.H * DH) * 2), 0x00020000);
+    const auto rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dobase), 0, (int)(((long long)(p.N - 1) * p.lddo + p.H * DH) * 2), 0x00020000);
+    auto stage = [&](int qt, int buf) {
+        // wave (hl, kh) fetches head hl's Q tile (kh == 0) or dO tile (kh == 1): 8 pieces each
+        if (!active) return;
+        unsigned char* img = smem + buf * 65536 + hl * 16384 + kh * 8192;
+        if (kh == 0) dma_tile(rsQ, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.ldq * 2), (unsigned)(head * DH * 2));
+        else dma_tile(rsD, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.lddo * 2), (unsigned)(head * DH * 2));
+    };
+
+    f32x16 dkt[2], dvt[2];             // [db]: (d x 32 keys) blocks
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
 
-    const int nqb = (p.N + 31) / 32;
-    for (int qb = kblk; qb < nqb; ++qb) {
-        const int q0 = qb * 32;
-        const int qi = q0 + lr;
-        const bool qok = qi < p.N;
-        // A operands: Q / dO rows (lane = query row, k = head-dim)
-        bf16x8 qa[4], da[4];
-        {
-            const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + h * DH;
-            const bf16_t* dp = p.dout + ((long long)b * p.N + qi) * p.lddo + h * DH;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                qa[ks] = gload8(qp + ks * 16 + lh * 8, qok);
-                da[ks] = gload8(dp + ks * 16 + lh * 8, qok);
-            }
-        }
-        __syncthreads();     // previous iteration's transposed tiles fully consumed
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = ks * 16 + lh * 8 + j;
-                Qt[d * QT_LD + lr] = (bf16_t)qa[ks][j];
-                dOt[d * QT_LD + lr] = (bf16_t)da[ks][j];
-            }
-        __syncthreads();
+    const int frow = fsw(lr);
+    const TrOff troff = make_troff(lane);
+    const int nqt = (p.N + 63) / 64;
+    const int hclamp = active ? head : 0;
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
+    const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
+    const int key_eff = kvalid ? key : 0x7fffffff;                       // a masked / out-of-range key "follows" every query
 
-        f32x16 s, dp;
+    stage(kblk, 0);
+    __syncthreads();
+
+    for (int qt = kblk; qt < nqt; ++qt) {
+        const int buf = (qt - kblk) & 1;
+        if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);
+        if (active) {
+            const unsigned char* Qt = smem + buf * 65536 + hl * 16384;
+            const unsigned char* Dt = Qt + 8192;
+            const int q0 = qt * 64;
+            // S' = Q K^T - lse / scale, dP' = dO V^T - delta : [qb] (32 queries x 32 keys) blocks; lane = key column, registers = query
+            // rows.  The row terms are the accumulators' initial values (bounds-checked loads: rows >= N read 0 -- harmless, their
+            // Q / dO rows are zero so P only ever meets zeros).
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            f32x16 s[2], dp[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], dp, 0, 0, 0);
+                for (int g = 0; g < 4; ++g) {
+                    const int qq0 = q0 + qb * 32 + 8 * g + 4 * lh;                      // 4 consecutive query rows
+                    const u32x4 lraw = __builtin_amdgcn_raw_buffer_load_b128(rsL, qq0 * 4, 0, 0);
+                    const u32x4 draw = __builtin_amdgcn_raw_buffer_load_b128(rsDl, qq0 * 4, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s[qb][4 * g + c] = __uint_as_float(lraw[c]);
+                        dp[qb][4 * g + c] = __uint_as_float(draw[c]);
+                    }
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const bf16x8 qa = nat_frag(Qt, qb * 32 + lr, frow, ks, lh);
+                    s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s[qb], 0, 0, 0);
+                    const bf16x8 da = nat_frag(Dt, qb * 32 + lr, frow, ks, lh);
+                    dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp[qb], 0, 0, 0);
+                }
+            const int nodiag = (qt == kblk) ? 0 : 0x40000000;               // off the diagonal every key precedes every query
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = q0 + qb * 32 + drow(r, lh);
+                    float pv = __builtin_amdgcn_exp2f(s[qb][r] * c2);
+                    if (key_eff > qq + nodiag) pv = 0.f;                            // masked key | causal (diagonal tile only)
+                    s[qb][r] = pv;
+                    dp[qb][r] *= pv;
+                }
+            // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 64 queries of the tile: 4 steps of 16)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16x8 pf = pack8(s[qb], st);
+                    const bf16x8 dsf = pack8(dp[qb], st);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 dotf = tr_frag(Dt, qb * 32 + st * 16, troff, db);
+                        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dvt[db], 0, 0, 0);
+                        const bf16x8 qtf = tr_frag(Qt, qb * 32 + st * 16, troff, db);
+                        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkt[db], 0, 0, 0);
+                    }
+                }
         }
-        // rows of S are queries q0 + drow(r, lh); column = this lane's key
-        const float* lsep = p.lse + ((long long)b * H + h) * p.N;
-        const float* dltp = p.delta + ((long long)b * H + h) * p.N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = q0 + drow(r, lh);
-            const bool ok = kvalid && qq < p.N && key <= qq;
-            float pv = 0.f, dsv = 0.f;
-            if (ok) {
-                pv = exp2f(s[r] * sl2 - lsep[qq] * LOG2E);
-                dsv = pv * (dp[r] - dltp[qq]);
-            }
-            s[r] = pv;
-            dp[r] = dsv;
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const bf16x8 pf = pack8(s, st);
-            const bf16x8 dsf = pack8(dp, st);
-#pragma unroll
-            for (int di = 0; di < 2; ++di) {
-                const bf16x8 dotf = ld_frag_t(&dOt[(di * 32 + lr) * QT_LD], st * 16 + lh * 4);
-                dvt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dvt[di], 0, 0, 0);
-                const bf16x8 qtf = ld_frag_t(&Qt[(di * 32 + lr) * QT_LD], st * 16 + lh * 4);
-                dkt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkt[di], 0, 0, 0);
-            }
-        }
+        __syncthreads();
     }
 
-    // reduce over heads through LDS: red[h][d][key] fp32 (64 x 32 per head)
-    float* red = reinterpret_cast<float*>(smem_raw);
+    // reduce over the 4 heads through LDS: red[wave][d][32 keys] fp32 (8 KiB per wave and pass)
+    float* red = reinterpret_cast<float*>(smem);
     for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
+        if (pass) __syncthreads();
         const f32x16* acc = pass == 0 ? dkt : dvt;
+        if (active) {
 #pragma unroll
-        for (int di = 0; di < 2; ++di)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(size_t)h * 2048 + (di * 32 + drow(r, lh)) * 32 + lr] = acc[di][r];
+                for (int r = 0; r < 16; ++r) red[wave * 2048 + (db * 32 + drow(r, lh)) * 32 + lr] = acc[db][r];
+        }
         __syncthreads();
-        float* outp = pass == 0 ? p.dk : p.dv;
+        float* outp = (pass == 0 ? p.dk : p.dv) + (long long)id.hg * p.part_stride;
         const float sc = pass == 0 ? p.scale : 1.f;
-        for (int e = t; e < 2048; e += blockDim.x) {
-            const int kk = e >> 6, d = e & 63;          // output element (key kk, dim d): coalesced along d
+        const int nh = min(HPB, p.H - id.hg * HPB);
+        for (int e = t; e < 64 * 64; e += 512) {
+            const int kk = e >> 6, d = e & 63;          // output element (key kk of the block, dim d): coalesced along d
+            const int half = kk >> 5, kl = kk & 31;
             float sum = 0.f;
-            for (int hh = 0; hh < H; ++hh) sum += red[(size_t)hh * 2048 + d * 32 + kk];
-            if (key0 + kk < p.N) outp[((long long)b * p.N + key0 + kk) * p.lddk + d] = sum * sc;
+            for (int hh = 0; hh < nh; ++hh) sum += red[(hh * 2 + half) * 2048 + d * 32 + kl];
+            if (kblk * 64 + kk < p.N) outp[((long long)b * p.N + kblk * 64 + kk) * p.lddk + d] = sum * sc;
         }
     }
 }
@@ -521,10 +643,13 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnParams p) {
 }  // namespace
 
 static int check_attn(int B, int N, int H, long long ldq, long long ldk, long long ldv, long long ldo) {
-    if (B <= 0 || N <= 0 || H <= 0 || H > 8) return ALM_ERR_UNSUPPORTED;
+    if (B <= 0 || N <= 0 || H <= 0 || H > 64) return ALM_ERR_UNSUPPORTED;
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return ALM_ERR_BAD_ARG;
+    if ((long long)N * ldq * 2 >= 0x7fffffffLL || (long long)N * ldk * 2 >= 0x7fffffffLL || (long long)N * ldv * 2 >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
     return 0;
 }
+
+extern "C" int alm_mqa_head_groups(int H) { return (H + HPB - 1) / HPB; }
 
 extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
@@ -532,42 +657,46 @@ extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, lon
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) return ALM_ERR_BAD_ARG;
     AttnParams p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.mask = mask; p.o = (bf16_t*)o; p.lse = lse;
-    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.B = B; p.N = N; p.H = H; p.scale = scale;
-    hipLaunchKernelGGL(mqa_fwd_kernel, dim3((N + 31) / 32, B), dim3(64 * H), 0, (hipStream_t)stream, p);
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
+    const int nqb = (N + 63) / 64;
+    hipLaunchKernelGGL(mqa_fwd_kernel, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
-// dk / dv: fp32 [B*N][lddk] (64 valid columns each).  delta: fp32 workspace [B][H][N].
+// dk / dv: fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 valid columns each; partial g at + g * part_stride floats);
+// the caller (alm_kv_grad_pack) adds the partials.  delta: fp32 workspace [2][B][H][N].
 extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
-                                void* dq, long long lddq, float* dk, float* dv, long long lddk, float* delta, int B, int N, int H,
-                                int dim_head, float scale, void* stream) {
+                                void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
+                                int N, int H, int dim_head, float scale, void* stream) {
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
-    if ((lddo & 7) || (lddq & 3)) return ALM_ERR_BAD_ARG;
+    if ((lddo & 7) || (lddq & 3) || (long long)N * lddo * 2 >= 0x7fffffffLL) return ALM_ERR_BAD_ARG;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7)) return ALM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(((long long)B * N + 3) / 4), dim3(256), 0, st, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo,
-                       delta, B, N, H);
+    float* ndelta = delta;
+    float* nlse = delta + (long long)B * H * N;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(((long long)B * N + 3) / 4), dim3(256), 0, st, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse,
+                       ndelta, nlse, 1.0f / scale, B, N, H);
     AttnParams p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.mask = mask; p.lse = const_cast<float*>(lse);
-    p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = dk; p.dv = dv;
-    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk;
-    p.B = B; p.N = N; p.H = H; p.scale = scale;
-    hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3((N + 31) / 32, B), dim3(64 * H), 0, st, p);
-    const size_t per_wave = 2 * 64 * QT_LD * sizeof(bf16_t);
-    size_t smem = (size_t)H * per_wave;
-    const size_t red = (size_t)H * 2048 * sizeof(float);
-    if (red > smem) smem = red;
+    p.dout = (const bf16_t*)dout; p.ndelta = ndelta; p.nlse = nlse; p.dq = (bf16_t*)dq; p.dk = dk; p.dv = dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.part_stride = part_stride;
+    p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
+    const int nqb = (N + 63) / 64;
+    hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3((N + 31) / 32, B), dim3(64 * H), smem, st, p);
+    hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }

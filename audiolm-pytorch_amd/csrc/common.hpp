@@ -32,7 +32,20 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two fp32 -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, quiet NaN)
+typedef __attribute__((ext_vector_type(2))) __bf16 alm_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    alm_bf16x2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// LDS transpose read (ds_read_b64_tr_b16): within each 16-lane group, lane s supplies the address of 4 consecutive bf16 of
+// "row" s >> 2, column chunk s & 3 of a [4][16] block; lane c of the group receives column c of that block (4 values, rows 0..3).
+__device__ __forceinline__ bf16x4 lds_tr16(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds_ptr));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -151,19 +151,23 @@ __global__ __launch_bounds__(256) void vmix_kernel(const bf16_t* __restrict__ v,
     }
 }
 
-// gradient fan-in of the value residual.  dk, dv: fp32 [rows][ld] from the attention backward (dv is the grad wrt the MIXED v).
+// gradient fan-in of the value residual.  dk, dv: `nparts` fp32 partials [rows][ld] (part_stride floats apart; one per head group)
+// from the attention backward, summed here (dv is the grad wrt the MIXED v).
 //   mode 0 (no value residual) : dkv = (dk, dv)
 //   mode 1 (layer >= 1)        : dkv = (dk, 0.5 dv)          ; acc_v0 += 0.5 dv
 //   mode 2 (layer 0)           : dkv = (dk, dv + acc_v0)
-__global__ __launch_bounds__(256) void kv_grad_pack_kernel(const float* __restrict__ dk, const float* __restrict__ dv, long long ld,
-                                                           float* __restrict__ acc_v0, bf16_t* __restrict__ dkv, long long ldo, long long rows,
-                                                           int dh, int mode) {
+__global__ __launch_bounds__(256) void kv_grad_pack_kernel(const float* __restrict__ dk, const float* __restrict__ dv, long long ld, int nparts,
+                                                           long long part_stride, float* __restrict__ acc_v0, bf16_t* __restrict__ dkv,
+                                                           long long ldo, long long rows, int dh, int mode) {
     const long long total = rows * dh;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / dh;
         const int e = (int)(i % dh);
-        const float gk = dk[r * ld + e];
-        float gv = dv[r * ld + e];
+        float gk = 0.f, gv = 0.f;
+        for (int pt = 0; pt < nparts; ++pt) {
+            gk += dk[pt * part_stride + r * ld + e];
+            gv += dv[pt * part_stride + r * ld + e];
+        }
         if (mode == 1) {
             gv *= 0.5f;
             acc_v0[i] += gv;
@@ -255,11 +259,11 @@ extern "C" int alm_value_residual_mix(const void* v, long long ldv, const void* 
     return 0;
 }
 
-extern "C" int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, float* acc_v0, void* dkv, long long ldo, long long rows,
-                                int dim_head, int mode, void* stream) {
-    if (mode < 0 || mode > 2 || (mode && !acc_v0)) return ALM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(kv_grad_pack_kernel, dim3(grid_for(rows * dim_head)), dim3(256), 0, (hipStream_t)stream, dk, dv, ld, acc_v0, (bf16_t*)dkv,
-                       ldo, rows, dim_head, mode);
+extern "C" int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts, long long part_stride, float* acc_v0, void* dkv,
+                                long long ldo, long long rows, int dim_head, int mode, void* stream) {
+    if (mode < 0 || mode > 2 || (mode && !acc_v0) || nparts < 1) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(kv_grad_pack_kernel, dim3(grid_for(rows * dim_head)), dim3(256), 0, (hipStream_t)stream, dk, dv, ld, nparts, part_stride,
+                       acc_v0, (bf16_t*)dkv, ldo, rows, dim_head, mode);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -51,12 +51,6 @@ struct GemmParams {
     long long sCk;
 };
 
-__device__ __forceinline__ bf16x4 ds_tr16_b64(unsigned addr) {
-    bf16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-    return r;
-}
-
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -201,7 +195,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         const unsigned char* sb = smem + buf * STAGE;
-        const unsigned sbase = (unsigned)(uintptr_t)(lds_void*)sb;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a[TM], b[TNB];
@@ -213,25 +206,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
                 for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
             } else {
                 // k-groups ks*4 + (g>>1)*2 + {0, 1}; consecutive k-groups are (Bx/16)*128 bytes apart
-                bf16x4 lo[TM + TNB], hi[TM + TNB];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const unsigned ad = sbase + fragA[i] + ks * 4 * (BM / 16) * 128;
-                    lo[i] = ds_tr16_b64(ad);
-                    hi[i] = ds_tr16_b64(ad + (BM / 16) * 128);
+                    const unsigned char* ad = sb + fragA[i] + ks * 4 * (BM / 16) * 128;
+                    a[i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BM / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int j = 0; j < TNB; ++j) {
-                    const unsigned ad = sbase + fragB[j] + ks * 4 * (BN / 16) * 128;
-                    lo[TM + j] = ds_tr16_b64(ad);
-                    hi[TM + j] = ds_tr16_b64(ad + (BN / 16) * 128);
+                    const unsigned char* ad = sb + fragB[j] + ks * 4 * (BN / 16) * 128;
+                    b[j] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BN / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int j = 0; j < TNB; ++j) b[j] = __builtin_shufflevector(lo[TM + j], hi[TM + j], 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)

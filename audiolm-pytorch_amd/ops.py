@@ -192,14 +192,15 @@ def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64):
 
 
 def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64):
-    """-> (dq bf16 [B*N, H*dh], dkv fp32 [B*N, 2*dh] = (dk | dv))."""
+    """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them)."""
     _chk(dout, BF16)
     dq = torch.empty_like(q)
-    dkv = torch.empty((B * N, 2 * dim_head), dtype=F32, device=q.device)
-    delta = torch.empty((B, H, N), dtype=F32, device=q.device)
+    hg = _lib.query('alm_mqa_head_groups', H)
+    dkv = torch.empty((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
+    delta = torch.empty((2, B, H, N), dtype=F32, device=q.device)
     _lib.call('alm_mqa_attn_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
               o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
-              dkv.data_ptr() + 4 * dim_head, dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
+              dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
     return dq, dkv
 
 
@@ -211,10 +212,13 @@ def value_residual_mix(v, v0):
 
 
 def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
-    rows = dkv_f32.shape[0]
+    """dkv_f32: [rows, 2*dh] or per-head-group partials [HG, rows, 2*dh] (summed here) -> bf16 [rows, 2*dh]."""
+    if dkv_f32.dim() == 2:
+        dkv_f32 = dkv_f32.unsqueeze(0)
+    nparts, rows = dkv_f32.shape[0], dkv_f32.shape[1]
     out = torch.empty((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
-    _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(0), _p(acc_v0), out.data_ptr(),
-              out.stride(0), rows, dim_head, mode, _st())
+    _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(1), nparts, dkv_f32.stride(0),
+              _p(acc_v0), out.data_ptr(), out.stride(0), rows, dim_head, mode, _st())
     return out
 
 

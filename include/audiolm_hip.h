@@ -72,17 +72,21 @@ int alm_geglu_ln_bwd(const void* dhn_bf16, long long lddh, const void* u_bf16, l
 
 /* ---- causal multi-query flash attention: attend.py:69-146 as called from audiolm_pytorch.py:381-394 ------------------------
  * q (B,N,H*64) bf16, k/v (B,N,64) bf16 single shared head, mask (B,N) uint8 (1 = attend) or NULL, scale = 64^-0.5.
- * lse fp32 [B][H][N].  Backward: dq bf16, dk/dv fp32 [B*N][lddk] (64 columns each), delta = fp32 workspace [B][H][N]. */
+ * lse fp32 [B][H][N].  Backward: dq bf16; dk/dv fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 columns each, `part_stride`
+ * floats between partials; summed by alm_kv_grad_pack: deterministic, no atomics); delta = fp32 workspace [2][B][H][N]. */
 int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                      void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, void* stream);
 int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                      const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq, float* dk,
-                     float* dv, long long lddk, float* delta, int B, int N, int H, int dim_head, float scale, void* stream);
+                     float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head, float scale,
+                     void* stream);
+/* number of head groups (4 heads each) = number of dk / dv partials the backward writes */
+int alm_mqa_head_groups(int H);
 /* value residual, audiolm_pytorch.py:353-358 / :534-535 */
 int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long long ldv0, void* out, long long ldo, long long rows,
                            int dim_head, void* stream);
-int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, float* acc_v0, void* dkv_bf16, long long ldo, long long rows,
-                     int dim_head, int mode, void* stream);
+int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts, long long part_stride, float* acc_v0, void* dkv_bf16,
+                     long long ldo, long long rows, int dim_head, int mode, void* stream);
 
 /* ---- hyper-connection residual streams: third-party `hyper_connections` used at audiolm_pytorch.py:24, 446-454, 524, 551 ----
  * R fp32 [B][S][N][D].  coef: per-token fp32 record of alm_hc_coef_width(S) floats (alpha | beta | pre-activations | 1/norm). */

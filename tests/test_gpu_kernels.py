@@ -197,7 +197,7 @@ def _attn_ref(q2, k2, v2, mask, B, N, H, d):
     return O.attend(q, k2.float().view(B, N, d), v2.float().view(B, N, d), mask=mask, causal=True)
 
 
-@pytest.mark.parametrize('B,N,H', [(2, 37, 8), (1, 64, 8), (2, 200, 8), (1, 512, 8), (2, 96, 4), (1, 33, 2)])
+@pytest.mark.parametrize('B,N,H', [(2, 37, 8), (1, 64, 8), (2, 200, 8), (1, 512, 8), (2, 96, 4), (1, 33, 2), (3, 130, 6), (1, 1024, 8)])
 @pytest.mark.parametrize('use_mask', [False, True])
 def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
     d = 64
@@ -222,7 +222,9 @@ def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
     assert e <= 1.2e-2, f'attention fwd rel-max err {e}'            # P and O rounded to bf16 once each (2 x 2^-8) + exp2 vs exp
     do = rnd(B * N, H * d, seed=25, dtype=BF16)
     ref2.backward(do.float())
-    dq, dkv = ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d)
+    dq, dkv_parts = ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d)
+    dkv = dkv_parts.sum(0)                                           # per-head-group partials (alm_kv_grad_pack adds them in the product path)
+
     for name, got, want in (('dq', dq, qf.grad), ('dk', dkv[:, :d], kf.grad), ('dv', dkv[:, d:], vf.grad)):
         e = relmax(got, want)
         assert e <= 2e-2, f'attention bwd {name} rel-max err {e}'
