@@ -37,11 +37,11 @@ SIGNATURES = {
     'alm_mqa_head_groups': [_I],
     'alm_hc_coef_width': [_I],
     'alm_hc_partial_width': [_I, _I],
-    'alm_hc_partial_blocks': [_L],
-    'alm_hc_width_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
-    'alm_hc_depth_fwd': [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P],
-    'alm_hc_depth_bwd': [_P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _P],
-    'alm_hc_width_bwd': [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'alm_hc_grads_width': [_I, _I],
+    'alm_hc_partial_rows': [_L, _I],
+    'alm_hc_fwd': [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_bwd': [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_param_grads': [_P, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
     'alm_residual_add': [_P, _P, _L, _P, _L, _I, _P],

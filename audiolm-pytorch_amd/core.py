@@ -117,6 +117,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
     R = ops.streams_expand(x, B, S) if S > 1 else x.reshape(M, D)
     kv0 = None
+    pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
         pa, pf = _split_layer(flat[l * ppl:(l + 1) * ppl], S)
         Wq, WqT = cache.get((l, 'wq'), pa['wq'], _pack_plain)
@@ -127,7 +128,9 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
         # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
         if S > 1:
-            X, XN, mean, rstd, coef = ops.hc_width_fwd(R, pa['hc'], pa['ln'], B, S, N, D, want_x=True)
+            # depth connection of the previous branch fused with this branch's width connection + pre-LayerNorm (one pass over R)
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'])
+            R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
         else:
             XN, X, mean, rstd = ops.layernorm_fwd(R, pa['ln'], want_copy=True)
             coef = None
@@ -145,12 +148,13 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh)
         Y = _empty((M, D), BF16, dev)
         ops.gemm_nt(AO, Wo, Y)
-        R1 = ops.hc_depth_fwd(R, Y, coef, B, S, N, D) if S > 1 else ops.residual_add(R, Y)
 
         # ---------------- feed-forward branch (audiolm_pytorch.py:246-260) ----------------
         if S > 1:
-            X2, XN2, mean2, rstd2, coef2 = ops.hc_width_fwd(R1, pf['hc'], pf['ln'], B, S, N, D, want_x=True)
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'])
+            R1, X2, XN2, mean2, rstd2, coef2 = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
         else:
+            R1 = ops.residual_add(R, Y)
             XN2, X2, mean2, rstd2 = ops.layernorm_fwd(R1, pf['ln'], want_copy=False)
             coef2 = None
         U = _empty((M, 2 * Ip), BF16, dev)
@@ -158,16 +162,23 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         HN, mean3, rstd3 = ops.geglu_ln_fwd(U, pf['ln3'], I, Ip)
         Y2 = _empty((M, D), BF16, dev)
         ops.gemm_nt(HN, W2, Y2)
-        R2 = ops.hc_depth_fwd(R1, Y2, coef2, B, S, N, D) if S > 1 else ops.residual_add(R1, Y2)
 
         if need_grad:
             saved['layers'].append(dict(R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Q=Q, KV=KV, V=V, AO=AO, LSE=LSE, Y=Y,
                                         R1=R1, X2=X2, XN2=XN2, mean2=mean2, rstd2=rstd2, coef2=coef2, U=U, HN=HN, mean3=mean3,
                                         rstd3=rstd3, Y2=Y2, mixed=V is not Vown))
-        R = R2
+        if S > 1:
+            R, pend_y, pend_coef = R1, Y2, coef2
+        else:
+            R = ops.residual_add(R1, Y2)
 
-    xs = ops.streams_reduce(R, B, S).reshape(M, D) if S > 1 else R        # :551
-    hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])                  # :555
+    if S > 1:
+        # last depth connection + stream sum (:551) + final LayerNorm (:555) in one pass; the final residual streams are never stored
+        h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, ln_gamma=flat[-1], final=True)
+        xs, hn, fmean, frstd = h['xs'], h['xn'], h['mean'], h['rstd']
+    else:
+        xs = R
+        hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])              # :555
     if need_grad:
         saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
     return hn, saved
@@ -185,8 +196,15 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
 
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
     grads[-1] = dgam
-    dR = ops.streams_expand(dxs.view(B, N, D), B, S) if S > 1 else dxs
     acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if cfg.add_value_residual and cfg.depth > 1 else None
+    # S > 1: dR = gradient wrt the residual streams after the current branch; right after the final stream sum it is dxs for every
+    # stream (`bcast`).  dY2 / dbeta2 (depth-connection backward of the FF branch) are produced one step ahead by the fused kernels.
+    dR, bcast = dxs, S > 1
+    dY2 = dbeta2 = None
+    if S > 1:
+        last = saved['layers'][-1]
+        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=last['Y2'], coef_prev=last['coef2'])
+        dY2, dbeta2 = h['dy'], h['dbeta']
 
     for l in reversed(range(cfg.depth)):
         sv = saved['layers'][l]
@@ -202,9 +220,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         iff = base + hc_n + 4 + hc_n          # index of ff ln gamma
 
         # ================= feed-forward branch =================
-        if S > 1:
-            dY2, dbeta2 = ops.hc_depth_bwd(dR, sv['Y2'], sv['coef2'], B, S, N, D)
-        else:
+        if S == 1:
             dY2 = ops.f32_to_bf16(dR)
         dHN = _empty((M, Ip), BF16, dev)
         ops.gemm_nt(dY2, W2T, dHN)                                            # dHN = dY2 @ W2
@@ -218,18 +234,18 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         xsrc = sv['X2'] if S > 1 else sv['R1']
         dX2, dgl = ops.layernorm_bwd(dXN2, xsrc, sv['mean2'], sv['rstd2'], pf['ln'])
         if S > 1:
-            dR1, hg = ops.hc_width_bwd(dR, dX2, sv['R1'], sv['coef2'], dbeta2, pf['hc'], B, S, N, D)
+            # width-connection backward of the FF branch fused with the depth-connection backward of this layer's attention branch
+            h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dx=dX2, R=sv['R1'], coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'],
+                           y_prev=sv['Y'], coef_prev=sv['coef'])
+            dR1, dY, dbeta, bcast = h['dR'], h['dy'], h['dbeta'], False
             for j, k in enumerate(HC_KEYS):
-                grads[base + hc_n + 4 + j] = hg[k]
+                grads[base + hc_n + 4 + j] = h['grads'][k]
         else:
             dR1 = ops.add_f32(dR, dX2)
+            dY = ops.f32_to_bf16(dR1)
         grads[iff], grads[iff + 1], grads[iff + 2], grads[iff + 3] = dgl, dW1, dg3, dW2
 
         # ================= attention branch =================
-        if S > 1:
-            dY, dbeta = ops.hc_depth_bwd(dR1, sv['Y'], sv['coef'], B, S, N, D)
-        else:
-            dY = ops.f32_to_bf16(dR1)
         dAO = _empty((M, H * dh), BF16, dev)
         ops.gemm_nt(dY, WoT, dAO)
         dWo = _empty((D, H * dh), F32, dev)
@@ -254,9 +270,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         xsrc = sv['X'] if S > 1 else sv['R']
         dX, dgla = ops.layernorm_bwd(dXN, xsrc, sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
         if S > 1:
-            dR, hg = ops.hc_width_bwd(dR1, dX, sv['R'], sv['coef'], dbeta, pa['hc'], B, S, N, D)
+            # width-connection backward of the attention branch (+ depth-connection backward of the previous layer's FF branch)
+            prev = saved['layers'][l - 1] if l > 0 else None
+            h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'],
+                           y_prev=prev['Y2'] if prev else None, coef_prev=prev['coef2'] if prev else None)
+            dR, dY2, dbeta2 = h['dR'], h['dy'], h['dbeta']
             for j, k in enumerate(HC_KEYS):
-                grads[base + j] = hg[k]
+                grads[base + j] = h['grads'][k]
         else:
             dR = ops.add_f32(dR1, dX)
         grads[ia], grads[ia + 1], grads[ia + 2], grads[ia + 3] = dgla, dWq, dWkv, dWo

@@ -45,358 +45,416 @@ struct HcParams {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// width forward (+ fused branch pre-LayerNorm)
+// Work decomposition: ONE TOKEN = WPT waves (WPT * 256 >= D), thread -> 4 consecutive elements of every stream; a 256-thread
+// block works on 4 / WPT tokens at a time and grid-strides over the rest.  All token-wide reductions (S norms, S*(S+2) dot
+// products, S stream sums ...) are done TOGETHER: a multi-value butterfly leaves the wave total of slot (lane & 31) in every lane
+// with 31 shuffles instead of 6 per value, one LDS exchange combines the WPT waves, and lane l post-processes slot l
+// (one tanh per lane).  Per-element weights and parameter-gradient accumulators live in registers across the token loop.
 // ------------------------------------------------------------------------------------------------------------------
-template <int S, int NI>
-__global__ __launch_bounds__(256) void hc_width_fwd_kernel(const float* __restrict__ R, HcParams hp, const float* __restrict__ ln_gamma,
-                                                           bf16_t* __restrict__ x_out, long long ldx, bf16_t* __restrict__ xn_out,
-                                                           long long ldxn, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                           float* __restrict__ coef, int B, int N, int D) {
+template <int NV>
+__device__ __forceinline__ float bfly(float (&v)[NV], int lane) {
+    // NV (power of two <= 32) values per lane -> lane l returns the sum over the 64 lanes of slot l & (NV - 1)
+    int st = 0;
+#pragma unroll
+    for (int n = NV / 2; n >= 1; n >>= 1, ++st) {
+        const bool up = (lane >> st) & 1;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const float keep = up ? v[2 * i + 1] : v[2 * i];
+            const float send = up ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + __shfl_xor(send, 1 << st, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int m = NV; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
+    return r;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+
+// combine the per-wave totals of the WPT waves of a token through LDS (one block barrier); every lane gets slot (lane & (NV-1))
+template <int WPT, int NV>
+__device__ __forceinline__ float token_combine(float tot, float* red, int tok, int wv, int lane) {
+    if (WPT == 1) return tot;
+    if (lane < NV) red[(tok * WPT + wv) * NV + lane] = tot;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPT; ++w) r += red[(tok * WPT + w) * NV + (lane & (NV - 1))];
+    return r;
+}
+
+struct HcFwdArgs {
+    const float* R_in; const bf16_t* y; long long ldy; const float* coef_prev; float* R_out;
+    HcParams hp; const float* ln_gamma;
+    bf16_t* x_out; long long ldx; bf16_t* xn_out; long long ldxn; float* mean_out; float* rstd_out; float* coef; float* xs_out;
+    int B, N, D;
+};
+
+// forward: [depth connection of the previous branch] -> [width connection + pre-LayerNorm of the next branch | stream sum + final LN]
+//   DEPTH: r_t = sum_s alpha_p[s][t+1] R_in[s] + beta_p[t] y       (written to R_out unless FINAL)
+//   WIDTH: coefficients of the next branch from r, x = sum_s alpha[s][0] r_s, xn = LN(x) * ln_gamma
+//   FINAL: xs = sum_t r_t (reference audiolm_pytorch.py:551), xn = LN(xs) * ln_gamma (:555)
+template <int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
+__global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     using C = Coef<S>;
+    constexpr int TPB = 4 / WPT;
+    constexpr int NV = (S == 4) ? 32 : 16;                       // slots: ss[S] | dots[S][S+2] | sums[S]
+    constexpr int O_DOT = S, O_SUM = S + S * (S + 2);
+    static_assert(O_SUM + S <= NV, "slot budget");
+    __shared__ float red[TPB * WPT * NV];
+    __shared__ float red2[2][TPB * WPT];
     const int lane = threadIdx.x & 63;
-    const long long M = (long long)B * N;
-    const float cD = sqrtf((float)D);
-    const float sa = *hp.sa, sb = *hp.sb;
-    for (long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long long)gridDim.x * 4) {
-        const int b = (int)(m / N), n = (int)(m % N);
-        float4 r[S][NI];
-        float ss[S];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tok = wave / WPT, wv = wave % WPT;
+    const int e0 = (wv * 64 + lane) * 4;
+    const bool eok = e0 < a.D;
+    const long long M = (long long)a.B * a.N;
+    const float cD = sqrtf((float)a.D);
+
+    float w[S + 2][4];
+    float4 lng = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sa = 0.f, sb = 0.f;
+    if (WIDTH || FINAL) { if (eok) lng = ld4(a.ln_gamma + e0); }
+    if (WIDTH) {
+        sa = *a.hp.sa; sb = *a.hp.sb;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            ss[s] = 0.f;
-            const float* rp = R + (((long long)b * S + s) * N + n) * D;
+        for (int c = 0; c < 4; ++c) {
+            const int e = e0 + c;
+            const float g1 = eok ? a.hp.hc_gamma[e] + 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int e = (i * 64 + lane) * 4;
-                r[s][i] = (e < D) ? ld4(rp + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ss[s] += r[s][i].x * r[s][i].x + r[s][i].y * r[s][i].y + r[s][i].z * r[s][i].z + r[s][i].w * r[s][i].w;
+            for (int t = 0; t < S + 1; ++t) w[t][c] = eok ? a.hp.Wa[(long long)e * (S + 1) + t] * g1 : 0.f;
+            w[S + 1][c] = eok ? a.hp.wb[e] * g1 : 0.f;
+        }
+    }
+
+    const long long niter = (M + TPB - 1) / TPB;
+    for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+        const long long m = it * TPB + tok;
+        const bool valid = m < M;
+        const int b = valid ? (int)(m / a.N) : 0, n = valid ? (int)(m % a.N) : 0;
+        const bool ld_ok = valid && eok;
+        float4 r[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) r[s] = ld_ok ? ld4(a.R_in + (((long long)b * S + s) * a.N + n) * a.D + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DEPTH) {
+            const float* cp = a.coef_prev + (valid ? m : 0) * C::W;
+            const float4 yv = ld_ok ? ld4bf(a.y + m * a.ldy + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o[S];
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const float bt = cp[C::Bt + t];
+                o[t] = make_float4(bt * yv.x, bt * yv.y, bt * yv.z, bt * yv.w);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float al = cp[C::A + s * (S + 1) + t + 1];
+                    o[t].x += al * r[s].x; o[t].y += al * r[s].y; o[t].z += al * r[s].z; o[t].w += al * r[s].w;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                r[t] = o[t];
+                if (!FINAL && ld_ok) *reinterpret_cast<float4*>(a.R_out + (((long long)b * S + t) * a.N + n) * a.D + e0) = o[t];
             }
         }
-        float dots[S][S + 2];
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        float mean = 0.f;
+        if (WIDTH) {
+            float v[NV];
 #pragma unroll
-        for (int s = 0; s < S; ++s)
+            for (int i = 0; i < NV; ++i) v[i] = 0.f;
 #pragma unroll
-            for (int t = 0; t < S + 2; ++t) dots[s][t] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e0 = (i * 64 + lane) * 4;
-            if (e0 < D) {
+            for (int s = 0; s < S; ++s)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int e = e0 + c;
-                    const float g1 = hp.hc_gamma[e] + 1.f;
-                    float w[S + 2];
+                    const float rv = f4c(r[s], c);
+                    v[s] += rv * rv;
+                    v[O_SUM + s] += rv;
 #pragma unroll
-                    for (int t = 0; t < S + 1; ++t) w[t] = hp.Wa[(long long)e * (S + 1) + t] * g1;
-                    w[S + 1] = hp.wb[e] * g1;
+                    for (int t = 0; t < S + 2; ++t) v[O_DOT + s * (S + 2) + t] += rv * w[t][c];
+                }
+            float tot = bfly<NV>(v, lane);
+            tot = token_combine<WPT, NV>(tot, red, tok, wv, lane);
+            // lane l post-processes slot l
+            const int l = lane & (NV - 1);
+            float rn[S];
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float rv = f4c(r[s][i], c);
+            for (int s = 0; s < S; ++s) rn[s] = 1.f / fmaxf(sqrtf(lane_bcast(tot, s)), NORM_EPS);
+            const int di = l - O_DOT;
+            const bool is_dot = di >= 0 && di < S * (S + 2);
+            const int ds = is_dot ? di / (S + 2) : 0, dt = is_dot ? di % (S + 2) : 0;
+            float rn_l = rn[0];
 #pragma unroll
-                        for (int t = 0; t < S + 2; ++t) dots[s][t] += rv * w[t];
-                    }
+            for (int s = 1; s < S; ++s) rn_l = (ds == s) ? rn[s] : rn_l;
+            const float pre = tot * rn_l * cD;
+            const float th = tanhf(pre);
+            const bool is_beta = dt == S + 1;
+            const float stat = is_dot ? (is_beta ? a.hp.Bb[ds] : a.hp.Aa[ds * (S + 1) + dt]) : 0.f;
+            const float coefv = th * (is_beta ? sb : sa) + stat;             // alpha[ds][dt] or beta[ds]
+            if (valid && wv == 0 && lane < NV) {
+                float* cp = a.coef + m * C::W;
+                if (is_dot) {
+                    if (is_beta) { cp[C::Bt + ds] = coefv; cp[C::BP + ds] = pre; }
+                    else { cp[C::A + ds * (S + 1) + dt] = coefv; cp[C::AP + ds * (S + 1) + dt] = pre; }
+                } else if (l < S) {
+                    cp[C::RN + l] = 1.f / fmaxf(sqrtf(tot), NORM_EPS);
                 }
             }
-        }
-        float alpha[S][S + 1], beta[S], apre[S][S + 1], bpre[S], rn[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            rn[s] = 1.f / fmaxf(sqrtf(wave_sum(ss[s])), NORM_EPS);
-#pragma unroll
-            for (int t = 0; t < S + 1; ++t) {
-                apre[s][t] = wave_sum(dots[s][t]) * rn[s] * cD;
-                alpha[s][t] = tanhf(apre[s][t]) * sa + hp.Aa[s * (S + 1) + t];
-            }
-            bpre[s] = wave_sum(dots[s][S + 1]) * rn[s] * cD;
-            beta[s] = tanhf(bpre[s]) * sb + hp.Bb[s];
-        }
-        // branch input + LayerNorm
-        float4 x[NI];
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float msum = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                x[i].x += alpha[s][0] * r[s][i].x; x[i].y += alpha[s][0] * r[s][i].y;
-                x[i].z += alpha[s][0] * r[s][i].z; x[i].w += alpha[s][0] * r[s][i].w;
+                const float a0 = lane_bcast(coefv, O_DOT + s * (S + 2));
+                x.x += a0 * r[s].x; x.y += a0 * r[s].y; x.z += a0 * r[s].z; x.w += a0 * r[s].w;
+                msum += a0 * lane_bcast(tot, O_SUM + s);
             }
-            sum += x[i].x + x[i].y + x[i].z + x[i].w;
+            mean = msum / (float)a.D;
         }
-        const float mean = wave_sum(sum) / (float)D;
-        float q = 0.f;
+        if (FINAL) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = (i * 64 + lane) * 4;
-            if (e < D) {
-                const float a = x[i].x - mean, bq = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
-                q += a * a + bq * bq + c * c + d * d;
+            for (int s = 0; s < S; ++s) { x.x += r[s].x; x.y += r[s].y; x.z += r[s].z; x.w += r[s].w; }
+            float sm = wave_sum(x.x + x.y + x.z + x.w);
+            if (WPT > 1) {
+                if (lane == 0) red2[0][tok * WPT + wv] = sm;
+                __syncthreads();
+                sm = 0.f;
+#pragma unroll
+                for (int q = 0; q < WPT; ++q) sm += red2[0][tok * WPT + q];
             }
+            mean = sm / (float)a.D;
+            if (ld_ok) *reinterpret_cast<float4*>(a.xs_out + m * a.D + e0) = x;
         }
-        const float rstd = rsqrtf(wave_sum(q) / (float)D + LN_EPS);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = (i * 64 + lane) * 4;
-            if (e < D) {
-                const float4 g = ld4(ln_gamma + e);
-                st4bf(xn_out + m * ldxn + e, make_float4((x[i].x - mean) * rstd * g.x, (x[i].y - mean) * rstd * g.y,
-                                                         (x[i].z - mean) * rstd * g.z, (x[i].w - mean) * rstd * g.w));
-                if (x_out) st4bf(x_out + m * ldx + e, x[i]);
+        if (WIDTH || FINAL) {
+            float q = 0.f;
+            if (eok) {
+                const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+                q = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
-        }
-        if (lane == 0) {
-            mean_out[m] = mean;
-            rstd_out[m] = rstd;
-            float* cp = coef + m * C::W;
+            q = wave_sum(q);
+            if (WPT > 1) {
+                if (lane == 0) red2[1][tok * WPT + wv] = q;
+                __syncthreads();
+                q = 0.f;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-#pragma unroll
-                for (int t = 0; t < S + 1; ++t) {
-                    cp[C::A + s * (S + 1) + t] = alpha[s][t];
-                    cp[C::AP + s * (S + 1) + t] = apre[s][t];
-                }
-                cp[C::Bt + s] = beta[s];
-                cp[C::BP + s] = bpre[s];
-                cp[C::RN + s] = rn[s];
+                for (int j = 0; j < WPT; ++j) q += red2[1][tok * WPT + j];
             }
+            const float rstd = rsqrtf(q / (float)a.D + LN_EPS);
+            if (ld_ok) {
+                st4bf(a.xn_out + m * a.ldxn + e0, make_float4((x.x - mean) * rstd * lng.x, (x.y - mean) * rstd * lng.y,
+                                                             (x.z - mean) * rstd * lng.z, (x.w - mean) * rstd * lng.w));
+                if (WIDTH && a.x_out) st4bf(a.x_out + m * a.ldx + e0, x);
+            }
+            if (valid && wv == 0 && lane == 0) { a.mean_out[m] = mean; a.rstd_out[m] = rstd; }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// depth forward: Rn_t = sum_s alpha[s][t+1] R_s + beta[t] y
-// ------------------------------------------------------------------------------------------------------------------
-template <int S, int NI>
-__global__ __launch_bounds__(256) void hc_depth_fwd_kernel(const float* __restrict__ R, const bf16_t* __restrict__ y, long long ldy,
-                                                           const float* __restrict__ coef, float* __restrict__ Rn, int B, int N, int D) {
+struct HcBwdArgs {
+    const float* dRn; int bcast;                         // gradient wrt the width connection's residual output: [B][S][N][D], or (bcast) [M][D] shared by all streams
+    const float* dx; long long lddx;                     // gradient wrt the branch input x (fp32)
+    const float* R; const float* coef; const float* dbeta;
+    HcParams hp;
+    float* dR; float* partial;
+    const bf16_t* y; long long ldy; const float* coef_prev; bf16_t* dy; long long lddy; float* dbeta_out;
+    int B, N, D;
+};
+
+// backward: [width connection of branch k+1] -> [depth connection of branch k]
+//   WIDTH: dR_s = alpha[s][0] dx + sum_t alpha[s][t+1] dRn_t + (dynamic-coefficient / RMS-norm terms); parameter-gradient partial sums
+//   DEPTH: dy = sum_t beta_p[t] dR_t (bf16), dbeta_p[t] = <dR_t, y>      (on dRn itself when there is no width part)
+// partial row (floats): raw_a[S+1][D] | raw_b[D] | dAa[S][S+1] | dBb[S] | dsa | dsb   with raw_* = sum over tokens, streams of
+// nhat * (dap | dbp): dWa = (gamma+1) raw_a, dwb = (gamma+1) raw_b, dgamma = sum_t Wa raw_a + wb raw_b  (alm_hc_param_grads).
+template <int S, int WPT, bool WIDTH, bool DEPTH>
+__global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
+    constexpr int TPB = 4 / WPT;
+    constexpr int NV = (S == 4) ? 32 : 8;                        // width slots: dal[S][S+1]
+    constexpr int NB = S * (S + 1);
+    __shared__ float red[2][TPB * WPT * NV];                     // parity-double-buffered: possibly the only barrier of an iteration
+    __shared__ float redd[2][TPB * WPT * 4];
     const int lane = threadIdx.x & 63;
-    const long long M = (long long)B * N;
-    for (long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long long)gridDim.x * 4) {
-        const int b = (int)(m / N), n = (int)(m % N);
-        const float* cp = coef + m * C::W;
-        float alpha[S][S + 1], beta[S];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tok = wave / WPT, wv = wave % WPT;
+    const int e0 = (wv * 64 + lane) * 4;
+    const bool eok = e0 < a.D;
+    const long long M = (long long)a.B * a.N;
+    const float cD = sqrtf((float)a.D);
+
+    float wa[S + 1][4], wbv[4], g1[4];
+    float rawa[S + 1][4], rawb[4];
+    float sa = 0.f, sb = 0.f;
+    float accA = 0.f, accsa = 0.f, accB = 0.f, accsb = 0.f;      // lane l of the token's wave 0: slot-l scalar statistics
+    if (WIDTH) {
+        sa = *a.hp.sa; sb = *a.hp.sb;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int c = 0; c < 4; ++c) {
+            const int e = e0 + c;
+            g1[c] = eok ? a.hp.hc_gamma[e] + 1.f : 0.f;
+            wbv[c] = eok ? a.hp.wb[e] : 0.f;
+            rawb[c] = 0.f;
 #pragma unroll
-            for (int t = 0; t < S + 1; ++t) alpha[s][t] = cp[C::A + s * (S + 1) + t];
-            beta[s] = cp[C::Bt + s];
+            for (int t = 0; t < S + 1; ++t) { wa[t][c] = eok ? a.hp.Wa[(long long)e * (S + 1) + t] : 0.f; rawa[t][c] = 0.f; }
         }
+    }
+
+    const long long niter = (M + TPB - 1) / TPB;
+    int par = 0;
+    for (long long it = blockIdx.x; it < niter; it += gridDim.x, par ^= 1) {
+        const long long m = it * TPB + tok;
+        const bool valid = m < M;
+        const int b = valid ? (int)(m / a.N) : 0, n = valid ? (int)(m % a.N) : 0;
+        const bool ld_ok = valid && eok;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g[S];
+        if (a.bcast) {
+            const float4 gb = ld_ok ? ld4(a.dRn + m * a.D + e0) : z4;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = (i * 64 + lane) * 4;
-            if (e >= D) continue;
+            for (int t = 0; t < S; ++t) g[t] = gb;
+        } else {
+#pragma unroll
+            for (int t = 0; t < S; ++t) g[t] = ld_ok ? ld4(a.dRn + (((long long)b * S + t) * a.N + n) * a.D + e0) : z4;
+        }
+        float4 out[S];
+        if (WIDTH) {
             float4 r[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) r[s] = ld4(R + (((long long)b * S + s) * N + n) * D + e);
-            const float4 yv = ld4bf(y + m * ldy + e);
+            for (int s = 0; s < S; ++s) r[s] = ld_ok ? ld4(a.R + (((long long)b * S + s) * a.N + n) * a.D + e0) : z4;
+            const float4 dxv = ld_ok ? ld4(a.dx + m * a.lddx + e0) : z4;
+            float v[NV];
 #pragma unroll
-            for (int t = 0; t < S; ++t) {
-                float4 o = make_float4(beta[t] * yv.x, beta[t] * yv.y, beta[t] * yv.z, beta[t] * yv.w);
+            for (int i = 0; i < NV; ++i) v[i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    o.x += alpha[s][t + 1] * r[s].x; o.y += alpha[s][t + 1] * r[s].y;
-                    o.z += alpha[s][t + 1] * r[s].z; o.w += alpha[s][t + 1] * r[s].w;
+            for (int s = 0; s < S; ++s) {
+                v[s * (S + 1)] = dxv.x * r[s].x + dxv.y * r[s].y + dxv.z * r[s].z + dxv.w * r[s].w;
+#pragma unroll
+                for (int t = 0; t < S; ++t) v[s * (S + 1) + t + 1] = g[t].x * r[s].x + g[t].y * r[s].y + g[t].z * r[s].z + g[t].w * r[s].w;
+            }
+            float da = bfly<NV>(v, lane);
+            da = token_combine<WPT, NV>(da, red[par], tok, wv, lane);
+            // lane l < NB: slot (s, t) = (l / (S+1), l % (S+1)); lanes NB .. NB+S-1: the beta path of stream l - NB
+            const float* cp = a.coef + (valid ? m : 0) * C::W;
+            const int l = lane & (NV - 1);
+            const bool is_a = lane < NB, is_b = lane >= NB && lane < NB + S;
+            const int sl = is_a ? lane / (S + 1) : (is_b ? lane - NB : 0);
+            float pre = 0.f, up = 0.f;                                   // pre-activation and upstream gradient of this lane's coefficient
+            if (valid) {
+                if (is_a) { pre = cp[C::AP + lane]; up = da; }
+                else if (is_b) { pre = cp[C::BP + sl]; up = a.dbeta[m * S + sl]; }
+            }
+            (void)l;
+            const float th = tanhf(pre);
+            const float dpre = up * (is_a ? sa : sb) * (1.f - th * th);     // dap[s][t] (lanes < NB) | dbp[s] (lanes NB..)
+            if (wv == 0) {
+                if (is_a) { accA += up; accsa += up * th; }
+                if (is_b) { accB += up; accsb += up * th; }
+            }
+            float dap[S][S + 1], dbp[S], alpha[S][S + 1], rn[S], gdot[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                rn[s] = cp[C::RN + s];
+                dbp[s] = lane_bcast(dpre, NB + s);
+                float gd = dbp[s] * cp[C::BP + s];
+#pragma unroll
+                for (int t = 0; t < S + 1; ++t) {
+                    dap[s][t] = lane_bcast(dpre, s * (S + 1) + t);
+                    alpha[s][t] = cp[C::A + s * (S + 1) + t];
+                    gd += dap[s][t] * cp[C::AP + s * (S + 1) + t];
                 }
-                *reinterpret_cast<float4*>(Rn + (((long long)b * S + t) * N + n) * D + e) = o;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// depth backward: dy = sum_t beta[t] dRn_t (bf16) ; dbeta[t] = <dRn_t, y>
-// ------------------------------------------------------------------------------------------------------------------
-template <int S, int NI>
-__global__ __launch_bounds__(256) void hc_depth_bwd_kernel(const float* __restrict__ dRn, const bf16_t* __restrict__ y, long long ldy,
-                                                           const float* __restrict__ coef, bf16_t* __restrict__ dy, long long lddy,
-                                                           float* __restrict__ dbeta, int B, int N, int D) {
-    using C = Coef<S>;
-    const int lane = threadIdx.x & 63;
-    const long long M = (long long)B * N;
-    for (long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long long)gridDim.x * 4) {
-        const int b = (int)(m / N), n = (int)(m % N);
-        const float* cp = coef + m * C::W;
-        float beta[S], db[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) { beta[s] = cp[C::Bt + s]; db[s] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = (i * 64 + lane) * 4;
-            if (e >= D) continue;
-            const float4 yv = ld4bf(y + m * ldy + e);
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int t = 0; t < S; ++t) {
-                const float4 g = ld4(dRn + (((long long)b * S + t) * N + n) * D + e);
-                o.x += beta[t] * g.x; o.y += beta[t] * g.y; o.z += beta[t] * g.z; o.w += beta[t] * g.w;
-                db[t] += g.x * yv.x + g.y * yv.y + g.z * yv.z + g.w * yv.w;
-            }
-            st4bf(dy + m * lddy + e, o);
-        }
-#pragma unroll
-        for (int t = 0; t < S; ++t) {
-            const float v = wave_sum(db[t]);
-            if (lane == 0) dbeta[m * S + t] = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// width backward.  Inputs: dRn (= dR'), dx (grad wrt branch input x, fp32), R, coef, dbeta.  Output dR + parameter partials.
-// partial row layout (floats): dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb
-// ------------------------------------------------------------------------------------------------------------------
-template <int S, int NI>
-__global__ __launch_bounds__(256) void hc_width_bwd_kernel(const float* __restrict__ dRn, const float* __restrict__ dx, long long lddx,
-                                                           const float* __restrict__ R, const float* __restrict__ coef,
-                                                           const float* __restrict__ dbeta, HcParams hp, float* __restrict__ dR,
-                                                           float* __restrict__ partial, int B, int N, int D) {
-    using C = Coef<S>;
-    extern __shared__ float lds_red[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long M = (long long)B * N;
-    const float cD = sqrtf((float)D);
-    const float sa = *hp.sa, sb = *hp.sb;
-
-    float accWa[NI][4][S + 1], accwb[NI][4], accg[NI][4];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            accwb[i][c] = 0.f; accg[i][c] = 0.f;
-#pragma unroll
-            for (int t = 0; t < S + 1; ++t) accWa[i][c][t] = 0.f;
-        }
-    float accAa[S][S + 1], accBb[S], accsa = 0.f, accsb = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        accBb[s] = 0.f;
-#pragma unroll
-        for (int t = 0; t < S + 1; ++t) accAa[s][t] = 0.f;
-    }
-
-    for (long long m = (long long)blockIdx.x * 4 + wave; m < M; m += (long long)gridDim.x * 4) {
-        const int b = (int)(m / N), n = (int)(m % N);
-        const float* cp = coef + m * C::W;
-        float4 r[S][NI], g[S][NI], dxv[NI];
-        float dal[S][S + 1];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int t = 0; t < S + 1; ++t) dal[s][t] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e = (i * 64 + lane) * 4;
-            const bool ok = e < D;
-            dxv[i] = ok ? ld4(dx + m * lddx + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const long long off = (((long long)b * S + s) * N + n) * D + e;
-                r[s][i] = ok ? ld4(R + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                g[s][i] = ok ? ld4(dRn + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gdot[s] = gd / rn[s];      // <g_s, R_s> = sum_t dap * apre / rn  (n_s . W = apre => sum_e W[e] (gamma+1) c R_s[e] = apre / rn)
             }
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                dal[s][0] += dxv[i].x * r[s][i].x + dxv[i].y * r[s][i].y + dxv[i].z * r[s][i].z + dxv[i].w * r[s][i].w;
-#pragma unroll
-                for (int t = 0; t < S; ++t)
-                    dal[s][t + 1] += g[t][i].x * r[s][i].x + g[t][i].y * r[s][i].y + g[t][i].z * r[s][i].z + g[t][i].w * r[s][i].w;
-            }
-        }
-        float alpha[S][S + 1], dap[S][S + 1], dbp[S], rn[S], gdot[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            rn[s] = cp[C::RN + s];
-            const float bpre = cp[C::BP + s];
-            const float tb = tanhf(bpre);
-            const float dbt = dbeta[m * S + s];
-            dbp[s] = dbt * sb * (1.f - tb * tb);
-            accBb[s] += dbt;
-            accsb += dbt * tb;
-            gdot[s] = dbp[s] * bpre;
-#pragma unroll
-            for (int t = 0; t < S + 1; ++t) {
-                alpha[s][t] = cp[C::A + s * (S + 1) + t];
-                const float apre = cp[C::AP + s * (S + 1) + t];
-                const float ta = tanhf(apre);
-                const float da = wave_sum(dal[s][t]);
-                dap[s][t] = da * sa * (1.f - ta * ta);
-                accAa[s][t] += da;
-                accsa += da * ta;
-                gdot[s] += dap[s][t] * apre;
-            }
-            // <g_s, R_s> = sum_t dap * apre / rn  (n_s . W = apre  =>  sum_e W[e] (gamma+1) c R_s[e] = apre / rn)
-            gdot[s] = gdot[s] / rn[s];
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int e0 = (i * 64 + lane) * 4;
-            if (e0 >= D) continue;
-            float4 outv[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) outv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < S; ++s) out[s] = z4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int e = e0 + c;
-                const float g1 = hp.hc_gamma[e] + 1.f;
-                float w[S + 2];
-#pragma unroll
-                for (int t = 0; t < S + 1; ++t) w[t] = hp.Wa[(long long)e * (S + 1) + t];
-                w[S + 1] = hp.wb[e];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const float rv = f4c(r[s][i], c);
-                    float dn = dbp[s] * w[S + 1];
+                    const float rv = f4c(r[s], c);
+                    float dn = dbp[s] * wbv[c];
 #pragma unroll
-                    for (int t = 0; t < S + 1; ++t) dn += dap[s][t] * w[t];
-                    const float nhat = rv * rn[s] * cD;            // n_s / (gamma + 1)
-                    const float nv = nhat * g1;
+                    for (int t = 0; t < S + 1; ++t) dn += dap[s][t] * wa[t][c];
+                    const float nhat = rv * rn[s] * cD;                    // n_s / (gamma + 1)
 #pragma unroll
-                    for (int t = 0; t < S + 1; ++t) accWa[i][c][t] += nv * dap[s][t];
-                    accwb[i][c] += nv * dbp[s];
-                    accg[i][c] += dn * nhat;
-                    const float gs = dn * g1 * cD;
-                    float o = alpha[s][0] * f4c(dxv[i], c) + rn[s] * (gs - gdot[s] * rn[s] * rn[s] * rv);
+                    for (int t = 0; t < S + 1; ++t) rawa[t][c] += nhat * dap[s][t];
+                    rawb[c] += nhat * dbp[s];
+                    const float gs = dn * g1[c] * cD;
+                    float o = alpha[s][0] * f4c(dxv, c) + rn[s] * (gs - gdot[s] * rn[s] * rn[s] * rv);
 #pragma unroll
-                    for (int t = 0; t < S; ++t) o += alpha[s][t + 1] * f4c(g[t][i], c);
-                    f4(outv[s], c) = o;
+                    for (int t = 0; t < S; ++t) o += alpha[s][t + 1] * f4c(g[t], c);
+                    f4(out[s], c) = o;
                 }
             }
+            if (ld_ok) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) *reinterpret_cast<float4*>(dR + (((long long)b * S + s) * N + n) * D + e0) = outv[s];
+                for (int s = 0; s < S; ++s) *reinterpret_cast<float4*>(a.dR + (((long long)b * S + s) * a.N + n) * a.D + e0) = out[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) out[s] = g[s];
+        }
+        if (DEPTH) {
+            const float* cq = a.coef_prev + (valid ? m : 0) * C::W;
+            const float4 yv = ld_ok ? ld4bf(a.y + m * a.ldy + e0) : z4;
+            float4 o = z4;
+            float v4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v4[t] = 0.f;
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const float bt = cq[C::Bt + t];
+                o.x += bt * out[t].x; o.y += bt * out[t].y; o.z += bt * out[t].z; o.w += bt * out[t].w;
+                v4[t] = out[t].x * yv.x + out[t].y * yv.y + out[t].z * yv.z + out[t].w * yv.w;
+            }
+            if (ld_ok) st4bf(a.dy + m * a.lddy + e0, o);
+            float db = bfly<4>(v4, lane);
+            if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
+                float* rd = redd[par];
+                if (lane < 4) rd[(tok * WPT + wv) * 4 + lane] = db;
+                __syncthreads();
+                db = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WPT; ++w2) db += rd[(tok * WPT + w2) * 4 + (lane & 3)];
+            }
+            if (valid && wv == 0 && lane < S) a.dbeta_out[m * S + lane] = db;
         }
     }
 
-    // block reduction of the parameter partials over the 4 waves
-    const int P = D * (S + 3) + S * (S + 1) + S + 2;
-    float* red = lds_red;                      // [4][P]
-    float* mine = red + (size_t)wave * P;
+    if (!WIDTH) return;
+    // per-(block, token slot) partial rows; the token's WPT waves own disjoint element ranges
+    const int P = a.D * (S + 2) + NB + S + 2;
+    float* prow = a.partial + ((long long)blockIdx.x * TPB + tok) * P;
+    if (eok) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = (i * 64 + lane) * 4 + c;
-            if (e < D) {
-#pragma unroll
-                for (int t = 0; t < S + 1; ++t) mine[(long long)e * (S + 1) + t] = accWa[i][c][t];
-                mine[D * (S + 1) + e] = accwb[i][c];
-                mine[D * (S + 2) + e] = accg[i][c];
-            }
-        }
-    if (lane == 0) {
-        float* q = mine + D * (S + 3);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int t = 0; t < S + 1; ++t) q[s * (S + 1) + t] = accAa[s][t];
-            q[S * (S + 1) + s] = accBb[s];
-        }
-        q[S * (S + 1) + S] = accsa;
-        q[S * (S + 1) + S + 1] = accsb;
+        for (int t = 0; t < S + 1; ++t) *reinterpret_cast<float4*>(prow + (long long)t * a.D + e0) = make_float4(rawa[t][0], rawa[t][1], rawa[t][2], rawa[t][3]);
+        *reinterpret_cast<float4*>(prow + (long long)(S + 1) * a.D + e0) = make_float4(rawb[0], rawb[1], rawb[2], rawb[3]);
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < P; e += 256)
-        partial[(long long)blockIdx.x * P + e] = red[e] + red[P + e] + red[2 * P + e] + red[3 * P + e];
+    if (wv == 0) {
+        float* q = prow + (long long)a.D * (S + 2);
+        if (lane < NB) q[lane] = accA;
+        if (lane >= NB && lane < NB + S) q[lane] = accB;
+        const float tsa = wave_sum(accsa), tsb = wave_sum(accsb);
+        if (lane == 0) { q[NB + S] = tsa; q[NB + S + 1] = tsb; }
+    }
+}
+
+// second stage of the hyper-connection parameter gradients: column sums of the partial rows (alm_colsum) -> the 7 gradients,
+// out layout (floats): dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb
+template <int S>
+__global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __restrict__ sums, HcParams hp, float* __restrict__ out, int D) {
+    constexpr int NB = S * (S + 1);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < D) {
+        const float g1 = hp.hc_gamma[e] + 1.f;
+        float dg = hp.wb[e] * sums[(long long)(S + 1) * D + e];
+#pragma unroll
+        for (int t = 0; t < S + 1; ++t) {
+            const float ra = sums[(long long)t * D + e];
+            out[(long long)e * (S + 1) + t] = g1 * ra;
+            dg += hp.Wa[(long long)e * (S + 1) + t] * ra;
+        }
+        out[(long long)D * (S + 1) + e] = g1 * sums[(long long)(S + 1) * D + e];
+        out[(long long)D * (S + 2) + e] = dg;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums[(long long)D * (S + 2) + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -460,108 +518,114 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
     }
 }
 
-template <int S>
-int dispatch_width_fwd(int D, int grid, hipStream_t st, const float* R, HcParams hp, const float* lng, bf16_t* x, long long ldx, bf16_t* xn,
-                       long long ldxn, float* mean, float* rstd, float* coef, int B, int N) {
-#define ALM_W(NI) hipLaunchKernelGGL((hc_width_fwd_kernel<S, NI>), dim3(grid), dim3(256), 0, st, R, hp, lng, x, ldx, xn, ldxn, mean, rstd, coef, B, N, D)
-    if (D <= 256) ALM_W(1); else if (D <= 512) ALM_W(2); else if (D <= 1024) ALM_W(4); else return ALM_ERR_UNSUPPORTED;
-#undef ALM_W
+int hc_grid(long long M, int tpb, int blocks_per_cu) {
+    const long long niter = (M + tpb - 1) / tpb;
+    const long long cap = 256LL * blocks_per_cu;
+    return (int)(niter < cap ? niter : cap);
+}
+int hc_wpt(int D) { return D <= 256 ? 1 : (D <= 512 ? 2 : 4); }
+
+template <int S, bool DEPTH, bool WIDTH, bool FINAL>
+int launch_fwd(const HcFwdArgs& a, hipStream_t st) {
+    const int wpt = hc_wpt(a.D);
+    const int grid = hc_grid((long long)a.B * a.N, 4 / wpt, 5);
+    if (wpt == 1) hipLaunchKernelGGL((hc_fwd_kernel<S, 1, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
+    else if (wpt == 2) hipLaunchKernelGGL((hc_fwd_kernel<S, 2, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((hc_fwd_kernel<S, 4, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
 template <int S>
-int dispatch_depth_fwd(int D, int grid, hipStream_t st, const float* R, const bf16_t* y, long long ldy, const float* coef, float* Rn, int B, int N) {
-#define ALM_W(NI) hipLaunchKernelGGL((hc_depth_fwd_kernel<S, NI>), dim3(grid), dim3(256), 0, st, R, y, ldy, coef, Rn, B, N, D)
-    if (D <= 256) ALM_W(1); else if (D <= 512) ALM_W(2); else if (D <= 1024) ALM_W(4); else return ALM_ERR_UNSUPPORTED;
-#undef ALM_W
-    return 0;
-}
-template <int S>
-int dispatch_depth_bwd(int D, int grid, hipStream_t st, const float* dRn, const bf16_t* y, long long ldy, const float* coef, bf16_t* dy,
-                       long long lddy, float* dbeta, int B, int N) {
-#define ALM_W(NI) hipLaunchKernelGGL((hc_depth_bwd_kernel<S, NI>), dim3(grid), dim3(256), 0, st, dRn, y, ldy, coef, dy, lddy, dbeta, B, N, D)
-    if (D <= 256) ALM_W(1); else if (D <= 512) ALM_W(2); else if (D <= 1024) ALM_W(4); else return ALM_ERR_UNSUPPORTED;
-#undef ALM_W
-    return 0;
-}
-template <int S>
-int dispatch_width_bwd(int D, int grid, hipStream_t st, const float* dRn, const float* dx, long long lddx, const float* R, const float* coef,
-                       const float* dbeta, HcParams hp, float* dR, float* partial, int B, int N) {
-    const int P = D * (S + 3) + S * (S + 1) + S + 2;
-    const size_t smem = (size_t)4 * P * sizeof(float);
-#define ALM_W(NI)                                                                                                                        \
-    do {                                                                                                                                 \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(hc_width_bwd_kernel<S, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((hc_width_bwd_kernel<S, NI>), dim3(grid), dim3(256), smem, st, dRn, dx, lddx, R, coef, dbeta, hp, dR, partial, B, N, D); \
-    } while (0)
-    if (D <= 256) ALM_W(1); else if (D <= 512) ALM_W(2); else if (D <= 1024) ALM_W(4); else return ALM_ERR_UNSUPPORTED;
-#undef ALM_W
-    return 0;
+int dispatch_fwd(const HcFwdArgs& a, int mode, hipStream_t st) {
+    switch (mode) {
+        case 1: return launch_fwd<S, true, false, false>(a, st);
+        case 2: return launch_fwd<S, false, true, false>(a, st);
+        case 3: return launch_fwd<S, true, true, false>(a, st);
+        case 5: return launch_fwd<S, true, false, true>(a, st);
+        default: return ALM_ERR_BAD_ARG;
+    }
 }
 
-int grid_tokens(long long M, int cap) { return (int)((M + 3) / 4 < cap ? (M + 3) / 4 : cap); }
+int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 3); }
+
+template <int S, bool WIDTH, bool DEPTH>
+int launch_bwd(const HcBwdArgs& a, hipStream_t st) {
+    const int wpt = hc_wpt(a.D);
+    const int grid = hc_bwd_blocks((long long)a.B * a.N, a.D);
+    if (wpt == 1) hipLaunchKernelGGL((hc_bwd_kernel<S, 1, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
+    else if (wpt == 2) hipLaunchKernelGGL((hc_bwd_kernel<S, 2, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((hc_bwd_kernel<S, 4, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
+    return 0;
+}
+template <int S>
+int dispatch_bwd(const HcBwdArgs& a, int mode, hipStream_t st) {
+    switch (mode) {
+        case 1: return launch_bwd<S, false, true>(a, st);
+        case 2: return launch_bwd<S, true, false>(a, st);
+        case 3: return launch_bwd<S, true, true>(a, st);
+        default: return ALM_ERR_BAD_ARG;
+    }
+}
 
 }  // namespace
 
-#define ALM_S_DISPATCH(S, CALL2, CALL4)          \
-    do {                                         \
-        if ((S) == 2) rc = CALL2;                \
-        else if ((S) == 4) rc = CALL4;           \
-        else return ALM_ERR_UNSUPPORTED;         \
-    } while (0)
-
 extern "C" int alm_hc_coef_width(int S) { return 2 * S * (S + 1) + 3 * S; }
-extern "C" int alm_hc_partial_width(int S, int D) { return D * (S + 3) + S * (S + 1) + S + 2; }
-extern "C" int alm_hc_partial_blocks(long long M) { return grid_tokens(M, 512); }
+extern "C" int alm_hc_partial_width(int S, int D) { return D * (S + 2) + S * (S + 1) + S + 2; }
+extern "C" int alm_hc_grads_width(int S, int D) { return D * (S + 3) + S * (S + 1) + S + 2; }
+/* number of partial rows alm_hc_bwd writes (one per workgroup and token slot) */
+extern "C" int alm_hc_partial_rows(long long tokens, int D) { return hc_bwd_blocks(tokens, D) * (4 / hc_wpt(D)); }
 
-extern "C" int alm_hc_width_fwd(const float* R, const float* hc_gamma, const float* Wa, const float* sa, const float* Aa, const float* wb,
-                                const float* sb, const float* Bb, const float* ln_gamma, void* x_out, long long ldx, void* xn_out,
-                                long long ldxn, float* mean, float* rstd, float* coef, int B, int S, int N, int D, void* stream) {
-    if ((D & 3) || (ldx & 3) || (ldxn & 3)) return ALM_ERR_BAD_ARG;
-    HcParams hp{hc_gamma, Wa, sa, Aa, wb, sb, Bb};
-    const int grid = grid_tokens((long long)B * N, 8192);
+// mode: 1 = depth connection only (-> R_out), 2 = width connection only, 3 = depth (previous branch) + width (next branch) fused,
+//       5 = depth + stream sum + final LayerNorm (-> xs_out fp32, xn_out bf16, mean, rstd; R_out is not written)
+extern "C" int alm_hc_fwd(const float* R_in, const void* y_prev, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
+                          const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb,
+                          const float* ln_gamma, void* x_out, long long ldx, void* xn_out, long long ldxn, float* mean, float* rstd,
+                          float* coef, float* xs_out, int mode, int B, int S, int N, int D, void* stream) {
+    if ((D & 3) || D > 1024 || (ldx & 3) || (ldxn & 3) || (ldy & 3)) return ALM_ERR_BAD_ARG;
+    if ((mode & 1) && (!y_prev || !coef_prev || (!(mode & 4) && !R_out))) return ALM_ERR_BAD_ARG;
+    if ((mode & 2) && (!hc_gamma || !Wa || !sa || !Aa || !wb || !sb || !Bb || !ln_gamma || !xn_out || !mean || !rstd || !coef)) return ALM_ERR_BAD_ARG;
+    if ((mode & 4) && (!ln_gamma || !xn_out || !mean || !rstd || !xs_out)) return ALM_ERR_BAD_ARG;
+    HcFwdArgs a{R_in, (const bf16_t*)y_prev, ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
+                (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, B, N, D};
     int rc;
-    ALM_S_DISPATCH(S, (dispatch_width_fwd<2>(D, grid, (hipStream_t)stream, R, hp, ln_gamma, (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, B, N)),
-                   (dispatch_width_fwd<4>(D, grid, (hipStream_t)stream, R, hp, ln_gamma, (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, B, N)));
+    if (S == 2) rc = dispatch_fwd<2>(a, mode, (hipStream_t)stream);
+    else if (S == 4) rc = dispatch_fwd<4>(a, mode, (hipStream_t)stream);
+    else return ALM_ERR_UNSUPPORTED;
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int alm_hc_depth_fwd(const float* R, const void* y, long long ldy, const float* coef, float* Rn, int B, int S, int N, int D,
-                                void* stream) {
-    if ((D & 3) || (ldy & 3)) return ALM_ERR_BAD_ARG;
-    const int grid = grid_tokens((long long)B * N, 8192);
+// mode: 1 = depth-connection backward only (dy, dbeta_out from dRn), 2 = width-connection backward only (dR, partial),
+//       3 = width backward of branch k+1 followed by the depth backward of branch k on the freshly computed dR.
+// dRn_bcast != 0: dRn is [B*N][D] and stands for all S streams (the gradient of the final stream sum, audiolm_pytorch.py:551).
+// partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads.
+extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const float* R, const float* coef,
+                          const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb,
+                          float* dR, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
+                          float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
+    if ((D & 3) || D > 1024 || (lddx & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
+    if ((mode & 2) && (!dx || !R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !dR || !partial)) return ALM_ERR_BAD_ARG;
+    if ((mode & 1) && (!y_prev || !coef_prev || !dy || !dbeta_out)) return ALM_ERR_BAD_ARG;
+    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, R, coef, dbeta, HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, partial,
+                (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out, B, N, D};
     int rc;
-    ALM_S_DISPATCH(S, (dispatch_depth_fwd<2>(D, grid, (hipStream_t)stream, R, (const bf16_t*)y, ldy, coef, Rn, B, N)),
-                   (dispatch_depth_fwd<4>(D, grid, (hipStream_t)stream, R, (const bf16_t*)y, ldy, coef, Rn, B, N)));
+    if (S == 2) rc = dispatch_bwd<2>(a, mode, (hipStream_t)stream);
+    else if (S == 4) rc = dispatch_bwd<4>(a, mode, (hipStream_t)stream);
+    else return ALM_ERR_UNSUPPORTED;
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int alm_hc_depth_bwd(const float* dRn, const void* y, long long ldy, const float* coef, void* dy, long long lddy, float* dbeta,
-                                int B, int S, int N, int D, void* stream) {
-    if ((D & 3) || (ldy & 3) || (lddy & 3)) return ALM_ERR_BAD_ARG;
-    const int grid = grid_tokens((long long)B * N, 8192);
-    int rc;
-    ALM_S_DISPATCH(S, (dispatch_depth_bwd<2>(D, grid, (hipStream_t)stream, dRn, (const bf16_t*)y, ldy, coef, (bf16_t*)dy, lddy, dbeta, B, N)),
-                   (dispatch_depth_bwd<4>(D, grid, (hipStream_t)stream, dRn, (const bf16_t*)y, ldy, coef, (bf16_t*)dy, lddy, dbeta, B, N)));
-    if (rc) return rc;
-    ALM_LAUNCH_CHECK();
-    return 0;
-}
-
-// partial: [alm_hc_partial_blocks(B*N)][alm_hc_partial_width(S, D)] floats; reduce with alm_colsum.
-extern "C" int alm_hc_width_bwd(const float* dRn, const float* dx, long long lddx, const float* R, const float* coef, const float* dbeta,
-                                const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR,
-                                float* partial, int B, int S, int N, int D, void* stream) {
-    if ((D & 3) || (lddx & 3)) return ALM_ERR_BAD_ARG;
-    HcParams hp{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr};
-    const int grid = alm_hc_partial_blocks((long long)B * N);
-    int rc;
-    ALM_S_DISPATCH(S, (dispatch_width_bwd<2>(D, grid, (hipStream_t)stream, dRn, dx, lddx, R, coef, dbeta, hp, dR, partial, B, N)),
-                   (dispatch_width_bwd<4>(D, grid, (hipStream_t)stream, dRn, dx, lddx, R, coef, dbeta, hp, dR, partial, B, N)));
-    if (rc) return rc;
+// sums: column sums (alm_colsum) of the partial rows.  out: alm_hc_grads_width(S, D) floats:
+// dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb
+extern "C" int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D,
+                                  void* stream) {
+    HcParams hp{hc_gamma, Wa, nullptr, nullptr, wb, nullptr, nullptr};
+    const int grid = (D + 255) / 256;
+    if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
+    else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
+    else return ALM_ERR_UNSUPPORTED;
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -224,56 +224,92 @@ def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
 
 # ------------------------------------------------------------------------------------------------ hyper-connections
 
+_HC_KEYS7 = ('gamma', 'Wa', 'sa', 'Aa', 'wb', 'sb', 'Bb')
+
+
+def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True):
+    """Hyper-connection forward pass over the fp32 residual streams R_in [B, S, N, D] (C ABI: alm_hc_fwd).
+      y_prev / coef_prev given : depth connection of the previous branch (R = mix(R_in) + beta * y_prev)
+      hc given                 : width connection + pre-LayerNorm of the next branch on that R
+      final                    : depth connection + stream sum + final LayerNorm (ln_gamma)
+    -> dict(R=..., x, xn, mean, rstd, coef | xs, hn, mean, rstd)."""
+    _chk(R_in, F32)
+    dev, M = R_in.device, B * N
+    depth, width = y_prev is not None, hc is not None
+    mode = (1 if depth else 0) | (2 if width else 0) | (4 if final else 0)
+    out = {}
+    R_out = torch.empty_like(R_in) if (depth and not final) else None
+    x = xn = mean = rstd = coef = xs = None
+    if width or final:
+        xn = torch.empty((M, D), dtype=BF16, device=dev)
+        mean = torch.empty(M, dtype=F32, device=dev)
+        rstd = torch.empty(M, dtype=F32, device=dev)
+    if width:
+        x = torch.empty((M, D), dtype=BF16, device=dev) if want_x else None
+        coef = torch.empty((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
+    if final:
+        xs = torch.empty((M, D), dtype=F32, device=dev)
+    hp = [hc[k].data_ptr() for k in _HC_KEYS7] if width else [None] * 7
+    _lib.call('alm_hc_fwd', R_in.data_ptr(), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out), *hp, _p(ln_gamma),
+              _p(x), D, _p(xn), D, _p(mean), _p(rstd), _p(coef), _p(xs), mode, B, S, N, D, _st())
+    out.update(R=R_out if depth else R_in, x=x, xn=xn, mean=mean, rstd=rstd, coef=coef, xs=xs)
+    return out
+
+
+def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, R=None, coef=None, dbeta=None, hc=None, y_prev=None, coef_prev=None):
+    """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D], or with
+    bcast [B*N, D] shared by all streams.  dx / R / coef / dbeta / hc given: width-connection backward -> dR + the 7 parameter gradients.
+    y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
+    -> dict(dR, grads, dy, dbeta)."""
+    width, depth = hc is not None, y_prev is not None
+    mode = (2 if width else 0) | (1 if depth else 0)
+    dev, M = dRn.device, B * N
+    dR = part = dy = dbo = None
+    if width:
+        dR = torch.empty((B, S, N, D), dtype=F32, device=dev)
+        rows = _lib.query('alm_hc_partial_rows', M, D)
+        P = _lib.query('alm_hc_partial_width', S, D)
+        part = torch.empty((rows, P), dtype=F32, device=dev)
+    if depth:
+        dy = torch.empty((M, D), dtype=BF16, device=dev)
+        dbo = torch.empty((M, S), dtype=F32, device=dev)
+    hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
+    _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), _p(dx), dx.stride(0) if width else 0, _p(R), _p(coef), _p(dbeta), *hp, _p(dR), _p(part),
+              _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo), mode, B, S, N, D, _st())
+    grads = None
+    if width:
+        sums = colsum(part)
+        g = torch.empty(_lib.query('alm_hc_grads_width', S, D), dtype=F32, device=dev)
+        _lib.call('alm_hc_param_grads', sums.data_ptr(), hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['wb'].data_ptr(), g.data_ptr(), S, D, _st())
+        o = 0
+        grads = {}
+        for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ())):
+            n = 1
+            for d in shape:
+                n *= d
+            grads[name] = g[o:o + n].view(shape)
+            o += n
+    return dict(dR=dR, grads=grads, dy=dy, dbeta=dbo)
+
+
+# un-fused single-connection forms (kernel tests; the product path uses the fused modes)
 def hc_width_fwd(R, hc, ln_gamma, B, S, N, D, want_x=True):
-    """R fp32 [B, S, N, D]; hc = dict of the 7 hyper-connection parameters -> (x bf16|None, xn bf16, mean, rstd, coef)."""
-    _chk(R, F32)
-    M = B * N
-    dev = R.device
-    x = torch.empty((M, D), dtype=BF16, device=dev) if want_x else None
-    xn = torch.empty((M, D), dtype=BF16, device=dev)
-    mean = torch.empty(M, dtype=F32, device=dev)
-    rstd = torch.empty(M, dtype=F32, device=dev)
-    coef = torch.empty((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
-    _lib.call('alm_hc_width_fwd', R.data_ptr(), hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['sa'].data_ptr(), hc['Aa'].data_ptr(),
-              hc['wb'].data_ptr(), hc['sb'].data_ptr(), hc['Bb'].data_ptr(), ln_gamma.data_ptr(), _p(x), D, xn.data_ptr(), D,
-              mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), B, S, N, D, _st())
-    return x, xn, mean, rstd, coef
+    r = hc_fwd(R, B, S, N, D, hc=hc, ln_gamma=ln_gamma, want_x=want_x)
+    return r['x'], r['xn'], r['mean'], r['rstd'], r['coef']
 
 
 def hc_depth_fwd(R, y, coef, B, S, N, D):
-    Rn = torch.empty_like(R)
-    _lib.call('alm_hc_depth_fwd', R.data_ptr(), y.data_ptr(), y.stride(0), coef.data_ptr(), Rn.data_ptr(), B, S, N, D, _st())
-    return Rn
+    return hc_fwd(R, B, S, N, D, y_prev=y, coef_prev=coef)['R']
 
 
-def hc_depth_bwd(dRn, y, coef, B, S, N, D):
-    M = B * N
-    dy = torch.empty((M, D), dtype=BF16, device=dRn.device)
-    dbeta = torch.empty((M, S), dtype=F32, device=dRn.device)
-    _lib.call('alm_hc_depth_bwd', dRn.data_ptr(), y.data_ptr(), y.stride(0), coef.data_ptr(), dy.data_ptr(), D, dbeta.data_ptr(), B, S, N, D, _st())
-    return dy, dbeta
+def hc_depth_bwd(dRn, y, coef, B, S, N, D, bcast=False):
+    r = hc_bwd(dRn, B, S, N, D, bcast=bcast, y_prev=y, coef_prev=coef)
+    return r['dy'], r['dbeta']
 
 
 def hc_width_bwd(dRn, dx, R, coef, dbeta, hc, B, S, N, D):
-    """-> (dR fp32 [B,S,N,D], grads dict for the 7 hyper-connection parameters)."""
-    M = B * N
-    dR = torch.empty_like(R)
-    nblk = _lib.query('alm_hc_partial_blocks', M)
-    P = _lib.query('alm_hc_partial_width', S, D)
-    part = torch.empty((nblk, P), dtype=F32, device=R.device)
-    _lib.call('alm_hc_width_bwd', dRn.data_ptr(), dx.data_ptr(), dx.stride(0), R.data_ptr(), coef.data_ptr(), dbeta.data_ptr(),
-              hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['sa'].data_ptr(), hc['wb'].data_ptr(), hc['sb'].data_ptr(), dR.data_ptr(),
-              part.data_ptr(), B, S, N, D, _st())
-    g = colsum(part)
-    o = 0
-    grads = {}
-    for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ())):
-        n = 1
-        for d in shape:
-            n *= d
-        grads[name] = g[o:o + n].view(shape)
-        o += n
-    return dR, grads
+    r = hc_bwd(dRn, B, S, N, D, dx=dx, R=R, coef=coef, dbeta=dbeta, hc=hc)
+    return r['dR'], r['grads']
 
 
 def streams_expand(x, B, S):

@@ -92,17 +92,26 @@ int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts,
  * R fp32 [B][S][N][D].  coef: per-token fp32 record of alm_hc_coef_width(S) floats (alpha | beta | pre-activations | 1/norm). */
 int alm_hc_coef_width(int S);
 int alm_hc_partial_width(int S, int D);
-int alm_hc_partial_blocks(long long tokens);
-int alm_hc_width_fwd(const float* R, const float* hc_gamma, const float* Wa, const float* sa, const float* Aa, const float* wb,
-                     const float* sb, const float* Bb, const float* ln_gamma, void* x_bf16, long long ldx, void* xn_bf16, long long ldxn,
-                     float* mean, float* rstd, float* coef, int B, int S, int N, int D, void* stream);
-int alm_hc_depth_fwd(const float* R, const void* y_bf16, long long ldy, const float* coef, float* Rn, int B, int S, int N, int D,
-                     void* stream);
-int alm_hc_depth_bwd(const float* dRn, const void* y_bf16, long long ldy, const float* coef, void* dy_bf16, long long lddy, float* dbeta,
-                     int B, int S, int N, int D, void* stream);
-int alm_hc_width_bwd(const float* dRn, const float* dx, long long lddx, const float* R, const float* coef, const float* dbeta,
-                     const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR, float* partial,
-                     int B, int S, int N, int D, void* stream);
+int alm_hc_grads_width(int S, int D);
+int alm_hc_partial_rows(long long tokens, int D);
+/* forward.  mode 1: depth connection only, R_out[t] = sum_s alpha[s][t+1] R_in[s] + beta[t] y_prev (coef_prev = that branch's record);
+ * mode 2: width connection of a branch (its 7 parameters) + the branch's pre-LayerNorm: x, xn = LN(x) ln_gamma, mean, rstd, coef;
+ * mode 3: mode 1 of the previous branch fused with mode 2 of the next one on the freshly computed residual (one pass over R);
+ * mode 5: depth connection + stream sum (:551) + final LayerNorm (:555): xs_out fp32 [B*N][D], xn_out bf16, mean, rstd. */
+int alm_hc_fwd(const float* R_in, const void* y_prev_bf16, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
+               const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb, const float* ln_gamma,
+               void* x_out_bf16, long long ldx, void* xn_out_bf16, long long ldxn, float* mean, float* rstd, float* coef, float* xs_out,
+               int mode, int B, int S, int N, int D, void* stream);
+/* backward.  mode 2: width-connection backward (dR, parameter-gradient partial rows); mode 1: depth-connection backward
+ * (dy = sum_t beta[t] dRn[t], dbeta_out[t] = <dRn[t], y>); mode 3: mode 2 of branch k+1 fused with mode 1 of branch k on the
+ * freshly computed dR.  dRn_bcast: dRn is [B*N][D] and stands for all S streams (gradient of the final stream sum).
+ * partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose output is
+ * dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb  (alm_hc_grads_width(S, D) floats). */
+int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const float* R, const float* coef, const float* dbeta,
+               const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR, float* partial,
+               const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out, int mode,
+               int B, int S, int N, int D, void* stream);
+int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
 int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */
 int alm_residual_add(const float* x, const void* y_bf16, long long ldy, float* out, long long rows, int D, void* stream);

@@ -90,7 +90,7 @@ def bench_attn():
     print(f'attn bwd  B{B} N{N} H{H}: {t:.3f} ms  {2.5 * fl_f / t / 1e9:.0f} TF (2.5 x fwd flops)')
 
 
-def bench_hc():
+def bench_hc_old():
     from audiolm_pytorch_amd import core
     B, S, N, D = 8, 4, 2048, 1024
     M = B * N
@@ -113,6 +113,38 @@ def bench_hc():
     dX = torch.randn(M, D, device=dev)
     t = timeit(lambda: ops.hc_width_bwd(dR, dX, R, coef, dbeta, hc, B, S, N, D))
     print(f'hc_width_bwd: {t:.3f} ms  {(3 * Rb + M * D * 4) / t / 1e6:.0f} GB/s (read dR, R, dX; write dR)')
+
+
+def bench_hc():
+    B, S, N, D = 8, 4, 2048, 1024
+    M = B * N
+    R = torch.randn(B, S, N, D, device=dev)
+    hc = dict(Bb=torch.ones(S, device=dev), Aa=torch.randn(S, S + 1, device=dev), Wa=torch.randn(D, S + 1, device=dev) * 0.02,
+              sa=torch.tensor(0.01, device=dev), wb=torch.randn(D, device=dev) * 0.02, sb=torch.tensor(0.01, device=dev),
+              gamma=torch.zeros(D, device=dev))
+    lng = torch.ones(D, device=dev)
+    Rb, Ab = R.numel() * 4, M * D * 2
+    w = ops.hc_fwd(R, B, S, N, D, hc=hc, ln_gamma=lng)
+    coef = w['coef']
+    Y = rnd(M, D)
+    for name, fn, byt in [
+        ('hc fwd width only', lambda: ops.hc_fwd(R, B, S, N, D, hc=hc, ln_gamma=lng), Rb + 2 * Ab),
+        ('hc fwd depth only', lambda: ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef), 2 * Rb + Ab),
+        ('hc fwd depth+width fused', lambda: ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=hc, ln_gamma=lng), 2 * Rb + 3 * Ab),
+        ('hc fwd final (depth+sum+LN)', lambda: ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, ln_gamma=lng, final=True), Rb + 2 * Ab + M * D * 4),
+    ]:
+        t = timeit(fn)
+        print(f'{name:30s}: {t:.3f} ms  {byt / t / 1e6:.0f} GB/s algorithmic')
+    dR = torch.randn(B, S, N, D, device=dev)
+    dX = torch.randn(M, D, device=dev)
+    dbeta = ops.hc_bwd(dR, B, S, N, D, y_prev=Y, coef_prev=coef)['dbeta']
+    for name, fn, byt in [
+        ('hc bwd depth only', lambda: ops.hc_bwd(dR, B, S, N, D, y_prev=Y, coef_prev=coef), Rb + 2 * Ab),
+        ('hc bwd width only', lambda: ops.hc_bwd(dR, B, S, N, D, dx=dX, R=R, coef=coef, dbeta=dbeta, hc=hc), 3 * Rb + M * D * 4),
+        ('hc bwd width+depth fused', lambda: ops.hc_bwd(dR, B, S, N, D, dx=dX, R=R, coef=coef, dbeta=dbeta, hc=hc, y_prev=Y, coef_prev=coef), 3 * Rb + M * D * 4 + 2 * Ab),
+    ]:
+        t = timeit(fn)
+        print(f'{name:30s}: {t:.3f} ms  {byt / t / 1e6:.0f} GB/s algorithmic')
 
 
 def bench_misc():

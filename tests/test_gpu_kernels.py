@@ -307,6 +307,54 @@ def test_hyper_connections(ops, S, D):
         assert e <= 1e-2, f'hc grad {k} rel-max err {e}'
 
 
+@pytest.mark.parametrize('S,D,N', [(4, 1024, 19), (4, 256, 37), (2, 512, 10)])
+def test_hyper_connections_fused_modes(ops, S, D, N):
+    """the fused product-path modes (depth of branch k + width of branch k+1 in one pass; final depth + stream sum + LayerNorm; width
+    backward of branch k+1 + depth backward of branch k; stream-broadcast gradients) against the single-connection kernels that
+    test_hyper_connections pins to the oracle."""
+    B = 2
+    M = B * N
+    R = rnd(B, S, N, D, seed=50)
+    hc1 = {k: v.contiguous() for k, v in _hc_params(S, D, 51).items()}
+    hc2 = {k: v.contiguous() for k, v in _hc_params(S, D, 61).items()}
+    g1, g2 = (1 + 0.1 * rnd(D, seed=52)).contiguous(), (1 + 0.1 * rnd(D, seed=53)).contiguous()
+    _, _, _, _, coef1 = ops.hc_width_fwd(R, hc1, g1, B, S, N, D)
+    y = rnd(M, D, seed=54, dtype=BF16)
+    # forward: fused vs two-step
+    R1 = ops.hc_depth_fwd(R, y, coef1, B, S, N, D)
+    x2, xn2, mean2, rstd2, coef2 = ops.hc_width_fwd(R1, hc2, g2, B, S, N, D)
+    f = ops.hc_fwd(R, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2)
+    assert torch.equal(f['R'], R1)
+    assert relmax(f['coef'], coef2) <= 1e-6 and relmax(f['mean'], mean2) <= 1e-5 and relmax(f['rstd'], rstd2) <= 1e-5
+    assert relmax(f['x'], x2) <= 4e-3 and relmax(f['xn'], xn2) <= 8e-3
+    # final: depth + stream sum + LayerNorm
+    fin = ops.hc_fwd(R, B, S, N, D, y_prev=y, coef_prev=coef1, ln_gamma=g2, final=True)
+    xs_ref = ops.streams_reduce(R1, B, S).reshape(M, D)
+    hn_ref, _, fm, fr = ops.layernorm_fwd(xs_ref, g2)
+    assert relmax(fin['xs'], xs_ref) <= 1e-6 and relmax(fin['mean'], fm) <= 1e-5 and relmax(fin['rstd'], fr) <= 1e-5
+    assert relmax(fin['xn'], hn_ref) <= 8e-3
+    # backward: fused vs two-step
+    G = rnd(B, S, N, D, seed=55)
+    dx2 = rnd(M, D, seed=56)
+    y2 = rnd(M, D, seed=57, dtype=BF16)
+    _, dbeta2 = ops.hc_depth_bwd(G, y2, coef2, B, S, N, D)
+    dR1, hg = ops.hc_width_bwd(G, dx2, R1, coef2, dbeta2, hc2, B, S, N, D)
+    dy1, dbeta1 = ops.hc_depth_bwd(dR1, y, coef1, B, S, N, D)
+    fb = ops.hc_bwd(G, B, S, N, D, dx=dx2, R=R1, coef=coef2, dbeta=dbeta2, hc=hc2, y_prev=y, coef_prev=coef1)
+    assert relmax(fb['dR'], dR1) <= 1e-6 and relmax(fb['dbeta'], dbeta1) <= 1e-5 and relmax(fb['dy'], dy1) <= 8e-3
+    for k in hg:
+        assert relmax(fb['grads'][k], hg[k]) <= 1e-5, k
+    # stream-broadcast gradient (right after the final stream sum)
+    gb = rnd(M, D, seed=58)
+    Gb = ops.streams_expand(gb.view(B, N, D), B, S)
+    dyb, dbb = ops.hc_depth_bwd(gb, y2, coef2, B, S, N, D, bcast=True)
+    dye, dbe = ops.hc_depth_bwd(Gb, y2, coef2, B, S, N, D)
+    assert torch.equal(dyb, dye) and relmax(dbb, dbe) <= 1e-6
+    dRb = ops.hc_bwd(gb, B, S, N, D, bcast=True, dx=dx2, R=R1, coef=coef2, dbeta=dbb, hc=hc2)['dR']
+    dRe, _ = ops.hc_width_bwd(Gb, dx2, R1, coef2, dbe, hc2, B, S, N, D)
+    assert relmax(dRb, dRe) <= 1e-6
+
+
 def test_streams_and_elementwise(ops):
     B, S, N, D = 2, 4, 5, 64
     x = rnd(B, N, D, seed=44)
