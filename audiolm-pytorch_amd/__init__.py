@@ -14,6 +14,7 @@ from . import _lib  # noqa: F401  (fails loudly if libaudiolm_hip.so can neither
 from .attend import Attend
 from .audiolm_pytorch import (AudioLM, CoarseTransformer, CoarseTransformerWrapper, FineTransformer, FineTransformerWrapper,
                               SemanticTransformer, SemanticTransformerWrapper, Transformer, get_embeds)
+from .soundstream import SoundStream
 from .version import __version__
 
 

@@ -54,6 +54,13 @@ SIGNATURES = {
     'alm_cross_entropy_fwd': [_P, _L, _P, _P, _P, _L, _I, _I, _P],
     'alm_cross_entropy_bwd': [_P, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     'alm_reduce_sum': [_P, _L, _P, _F, _P],
+    'alm_conv1d_packed_floats': [_I, _I, _I],
+    'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
+    'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'alm_rvq_padded_codes': [_I],
+    'alm_rvq_pack': [_P, _P, _P, _I, _I, _I, _P],
+    'alm_rvq_encode': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    'alm_bct_to_btc': [_P, _P, _I, _I, _I, _P],
 }
 
 _lib = None

@@ -30,6 +30,7 @@ class AttendFn(torch.autograd.Function):
         b, h, n, d = ctx.shape
         do = dout.permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
         dq, dkv = ops.mqa_attn_bwd(q2, k2, v2, ctx.mask, o, lse, do, b, n, h, d)
+        dkv = dkv.sum(0)                                   # per-head-group partials (summed by alm_kv_grad_pack on the fused path)
         dq = dq.view(b, n, h, d).permute(0, 2, 1, 3).to(ctx.dtypes[0])
         dk = dkv[:, :d].reshape(b, n, d).to(ctx.dtypes[1])
         dv = dkv[:, d:].reshape(b, n, d).to(ctx.dtypes[2])

@@ -405,3 +405,60 @@ def reduce_sum(x, scale=1.0):
     out = torch.empty((), dtype=F32, device=x.device)
     _lib.call('alm_reduce_sum', x.data_ptr(), x.numel(), out.data_ptr(), float(scale), _st())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ SoundStream tokenize path
+
+def conv1d_pack(w):
+    """nn.Conv1d weight fp32 [Cout, Cin, k] -> packed [k][Cin_pad][Cout_pad] fp32 (once per weight update)."""
+    _chk(w, F32)
+    Cout, Cin, ks = w.shape
+    wp = torch.empty(_lib.query('alm_conv1d_packed_floats', Cout, Cin, ks), dtype=F32, device=w.device)
+    _lib.call('alm_conv1d_pack', w.contiguous().data_ptr(), wp.data_ptr(), Cout, Cin, ks, _st())
+    return wp
+
+
+def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, residual=None):
+    """x fp32 [B, Cin, T] -> fp32 [B, Cout, T // stride]: CausalConv1d (reflect left pad) + bias (+ ELU) (+ residual)."""
+    _chk(x, F32)
+    B, Cin, T = x.shape
+    assert x.is_contiguous()
+    Tout = (T - stride) // stride + 1
+    out = torch.empty((B, Cout, Tout), dtype=F32, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    _lib.call('alm_conv1d_causal', x.data_ptr(), wp.data_ptr(), bias.data_ptr(), _p(residual), out.data_ptr(), B, Cin, Cout, T, ksize, stride,
+              dilation, int(elu), _st())
+    return out
+
+
+def rvq_pack(E):
+    """codebooks fp32 [Q, C, d] -> (Et [Q, d, Cpad], e2 [Q, Cpad])."""
+    _chk(E, F32)
+    Q, C, d = E.shape
+    CP = _lib.query('alm_rvq_padded_codes', C)
+    Et = torch.empty((Q, d, CP), dtype=F32, device=E.device)
+    e2 = torch.empty((Q, CP), dtype=F32, device=E.device)
+    _lib.call('alm_rvq_pack', E.contiguous().data_ptr(), Et.data_ptr(), e2.data_ptr(), Q, C, d, _st())
+    return Et, e2
+
+
+def rvq_encode(x, E, Et, e2, idx_out=None, quant_out=None):
+    """x fp32 [T, d] (row stride arbitrary) against codebooks E [Q, C, d] -> int64 indices [T, Q] (written into idx_out view if given)."""
+    _chk(x, F32)
+    T, d = x.shape
+    Q, C, _ = E.shape
+    assert x.stride(1) == 1
+    if idx_out is None:
+        idx_out = torch.empty((T, Q), dtype=torch.int64, device=x.device)
+    assert idx_out.shape == (T, Q) and idx_out.stride(1) == 1
+    _lib.call('alm_rvq_encode', x.data_ptr(), x.stride(0), E.data_ptr(), Et.data_ptr(), e2.data_ptr(), idx_out.data_ptr(), idx_out.stride(0),
+              _p(quant_out), quant_out.stride(0) if quant_out is not None else 0, T, d, C, Q, _st())
+    return idx_out
+
+
+def bct_to_btc(x):
+    B, C, T = x.shape
+    out = torch.empty((B, T, C), dtype=F32, device=x.device)
+    _lib.call('alm_bct_to_btc', x.data_ptr(), out.data_ptr(), B, C, T, _st())
+    return out

@@ -1,0 +1,235 @@
+"""Mirror of the reference's `audiolm_pytorch/soundstream.py` for the TOKENIZE path only:
+`SoundStream.tokenize(audio)` and `SoundStream.forward(x, return_encoded=True | return_codes_only=True)` -- the causal-conv encoder
+(soundstream.py:332-380, 519-531) and the eval-mode forward of the grouped residual VQ (soundstream.py:592-607, :840) run on the
+MI355X kernels of csrc/codec.hip (exact-fp32 MFMA).  Everything else the reference class does (decoder, discriminators, losses,
+training of the codec, local attention, LFQ / FSQ quantizers) is out of scope and raises.
+
+The module tree keeps the reference's parameter / buffer NAMES for the parts it has, so `state_dict()` entries `encoder.*` and
+`rq.*` of a reference checkpoint load with `load_state_dict(..., strict=False)`:
+    encoder.0.conv.{weight,bias}                        CausalConv1d(input_channels -> channels, 7)
+    encoder.{b}.{r}.fn.{0,2}.conv.{weight,bias}         ResidualUnit r of EncoderBlock b (k7 dilated conv, ELU, k1 conv, ELU, + x)
+    encoder.{b}.3.conv.{weight,bias}                    strided down-sampling conv (k = 2 * stride)
+    encoder.{last}.conv.{weight,bias}                   CausalConv1d(-> codebook_dim, 3)
+    rq.rvqs.{g}.layers.{q}._codebook.{initted, cluster_size, embed_avg, embed (1, C, d)}
+"""
+from __future__ import annotations
+
+import functools
+from itertools import cycle
+
+import torch
+from torch import nn
+
+from . import ops
+
+F32 = torch.float32
+
+
+class CausalConv1d(nn.Module):                                   # soundstream.py:332-345
+    def __init__(self, chan_in, chan_out, kernel_size, pad_mode='reflect', **kwargs):
+        super().__init__()
+        if pad_mode != 'reflect':
+            raise NotImplementedError('only the reference default pad_mode="reflect" is implemented')
+        self.dilation = kwargs.get('dilation', 1)
+        self.stride = kwargs.get('stride', 1)
+        self.kernel_size = kernel_size
+        self.pad_mode = pad_mode
+        self.causal_padding = self.dilation * (kernel_size - 1) + (1 - self.stride)
+        self.conv = nn.Conv1d(chan_in, chan_out, kernel_size, **kwargs)
+        self._packed = None
+
+    def packed(self):
+        w = self.conv.weight
+        ver = (w.data_ptr(), w._version)
+        if self._packed is None or self._packed[0] != ver:
+            self._packed = (ver, ops.conv1d_pack(w.detach().to(F32)))
+        return self._packed[1]
+
+    def run(self, x, *, elu=False, residual=None):
+        return ops.conv1d_causal(x, self.packed(), self.conv.bias.detach(), self.conv.out_channels, self.kernel_size, stride=self.stride,
+                                 dilation=self.dilation, elu=elu, residual=residual)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class _ResidualFn(nn.Module):
+    """holder with the reference's `.fn` Sequential naming: fn.0 = dilated k7 conv, fn.2 = k1 conv (fn.1 / fn.3 are ELUs)."""
+
+    def __init__(self, chan, dilation, kernel_size, pad_mode):
+        super().__init__()
+        self.fn = nn.Sequential(CausalConv1d(chan, chan, kernel_size, dilation=dilation, pad_mode=pad_mode), nn.ELU(),
+                                CausalConv1d(chan, chan, 1, pad_mode=pad_mode), nn.ELU())
+
+    def forward(self, x):                                        # soundstream.py:362-369: ELU(conv1(ELU(conv7(x)))) + x
+        h = self.fn[0].run(x, elu=True)
+        return self.fn[2].run(h, elu=True, residual=x)
+
+
+def ResidualUnit(chan_in, chan_out, dilation, kernel_size=7, squeeze_excite=False, pad_mode='reflect'):
+    if squeeze_excite:
+        raise NotImplementedError('squeeze_excite is not on the tokenize hot path (reference default False)')
+    assert chan_in == chan_out
+    return _ResidualFn(chan_in, dilation, kernel_size, pad_mode)
+
+
+def EncoderBlock(chan_in, chan_out, stride, cycle_dilations=(1, 3, 9), squeeze_excite=False, pad_mode='reflect'):   # soundstream.py:371-380
+    it = cycle(cycle_dilations)
+    return nn.Sequential(ResidualUnit(chan_in, chan_in, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
+                         ResidualUnit(chan_in, chan_in, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
+                         ResidualUnit(chan_in, chan_in, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
+                         CausalConv1d(chan_in, chan_out, 2 * stride, stride=stride, pad_mode=pad_mode))
+
+
+class _EuclideanCodebook(nn.Module):
+    def __init__(self, dim, codebook_size):
+        super().__init__()
+        self.register_buffer('initted', torch.tensor([False]))
+        self.register_buffer('cluster_size', torch.ones(1, codebook_size))
+        self.register_buffer('embed_avg', torch.zeros(1, codebook_size, dim))
+        self.register_buffer('embed', torch.zeros(1, codebook_size, dim))
+
+
+class _VectorQuantize(nn.Module):
+    def __init__(self, dim, codebook_size):
+        super().__init__()
+        self._codebook = _EuclideanCodebook(dim, codebook_size)
+
+
+class _ResidualVQ(nn.Module):
+    def __init__(self, dim, num_quantizers, codebook_size):
+        super().__init__()
+        self.layers = nn.ModuleList([_VectorQuantize(dim, codebook_size) for _ in range(num_quantizers)])
+
+
+class GroupedResidualVQ(nn.Module):
+    """eval-mode forward of vector-quantize-pytorch's GroupedResidualVQ as the reference builds it (soundstream.py:592-607)."""
+
+    def __init__(self, *, dim, groups=1, num_quantizers, codebook_size, **unused):
+        super().__init__()
+        assert dim % groups == 0
+        self.dim, self.groups, self.num_quantizers, self.codebook_size = dim, groups, num_quantizers, codebook_size
+        self.rvqs = nn.ModuleList([_ResidualVQ(dim // groups, num_quantizers, codebook_size) for _ in range(groups)])
+        self._packed = None
+
+    def _pack(self):
+        embeds = [[l._codebook.embed for l in r.layers] for r in self.rvqs]
+        ver = tuple((e.data_ptr(), e._version) for row in embeds for e in row)
+        if self._packed is None or self._packed[0] != ver:
+            for r in self.rvqs:
+                for l in r.layers:
+                    if not bool(l._codebook.initted.item()):
+                        raise RuntimeError('codebooks are not initialised (`initted` is False): the k-means initialisation of the first training '
+                                           'batch (soundstream.py:600) is not part of the tokenize path -- load a trained codec or set them')
+            packs = []
+            for row in embeds:
+                E = torch.stack([e[0].detach().to(F32) for e in row]).contiguous()       # [Q, C, d]
+                packs.append((E,) + ops.rvq_pack(E))
+            self._packed = (ver, packs)
+        return self._packed[1]
+
+    def forward(self, x):
+        """x fp32 (b, n, dim) -> (quantized (b, n, dim), indices (g, b, n, q) int64, commit_loss zeros (g, q))."""
+        if self.training:
+            raise NotImplementedError('only the eval-mode forward (tokenize) is implemented')
+        b, n, dim = x.shape
+        x2 = x.reshape(b * n, dim).to(F32).contiguous()
+        dg = dim // self.groups
+        quant = torch.empty_like(x2)
+        idx = torch.empty((self.groups, b * n, self.num_quantizers), dtype=torch.int64, device=x.device)
+        for g, (E, Et, e2) in enumerate(self._pack()):
+            ops.rvq_encode(x2[:, g * dg:(g + 1) * dg], E, Et, e2, idx_out=idx[g], quant_out=quant[:, g * dg:(g + 1) * dg])
+        return quant.view(b, n, dim), idx.view(self.groups, b, n, self.num_quantizers), torch.zeros((self.groups, self.num_quantizers), device=x.device)
+
+
+def curtail_to_multiple(t, mult, from_left=False):               # soundstream.py:86-90
+    data_len = t.shape[-1]
+    rounded = (data_len // mult) * mult
+    return t[..., :rounded] if not from_left else t[..., -rounded:]
+
+
+class SoundStream(nn.Module):
+    """Constructor keywords and defaults follow the reference (soundstream.py:451-510); options outside the tokenize path raise."""
+
+    def __init__(self, *, channels=32, strides=(2, 4, 5, 8), channel_mults=(2, 4, 8, 16), codebook_dim=512, codebook_size=None,
+                 finite_scalar_quantizer_levels=None, rq_num_quantizers=8, rq_commitment_weight=1., rq_ema_decay=0.95,
+                 rq_quantize_dropout_multiple_of=1, rq_groups=1, rq_stochastic_sample_codes=False, rq_rotation_trick=True, rq_kwargs: dict = {},
+                 use_lookup_free_quantizer=False, use_finite_scalar_quantizer=False, input_channels=1, enc_cycle_dilations=(1, 3, 9),
+                 target_sample_hz=16000, use_local_attn=True, use_gate_loop_layers=False, squeeze_excite=False, pad_mode='reflect', **kwargs):
+        super().__init__()
+        if use_local_attn:
+            raise NotImplementedError('encoder local attention (soundstream.py:414-429) is SURVEY.md §8(f) item 3: construct with use_local_attn=False')
+        if use_lookup_free_quantizer or use_finite_scalar_quantizer or finite_scalar_quantizer_levels is not None:
+            raise NotImplementedError('LFQ / FSQ quantizers are out of scope (SURVEY.md §2)')
+        if use_gate_loop_layers or squeeze_excite or rq_stochastic_sample_codes:
+            raise NotImplementedError('gate-loop layers / squeeze-excite / stochastic code sampling are not on the tokenize hot path')
+        assert codebook_size is not None, '`codebook_size` must be set'
+        self.target_sample_hz = target_sample_hz
+        self.single_channel = input_channels == 1
+        self.strides = strides
+        layer_channels = (channels, *[m * channels for m in channel_mults])
+        pairs = tuple(zip(layer_channels[:-1], layer_channels[1:]))
+        blocks = [EncoderBlock(ci, co, s, enc_cycle_dilations, squeeze_excite, pad_mode) for (ci, co), s in zip(pairs, strides)]
+        self.encoder = nn.Sequential(CausalConv1d(input_channels, channels, 7, pad_mode=pad_mode), *blocks,
+                                     CausalConv1d(layer_channels[-1], codebook_dim, 3, pad_mode=pad_mode))
+        self.encoder_attn = None
+        self.num_quantizers = rq_num_quantizers
+        self.codebook_dim = codebook_dim
+        self.rq_groups = rq_groups
+        self.codebook_size = codebook_size
+        self.rq = GroupedResidualVQ(dim=codebook_dim, num_quantizers=rq_num_quantizers, codebook_size=codebook_size, groups=rq_groups)
+        self.eval()
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def seq_len_multiple_of(self):                               # soundstream.py:772-774
+        return functools.reduce(lambda x, y: x * y, self.strides)
+
+    @property
+    def downsample_factor(self):
+        return self.seq_len_multiple_of
+
+    def process_input(self, x, input_sample_hz=None, curtail_from_left=False):                   # soundstream.py:779-795
+        if input_sample_hz is not None and input_sample_hz != self.target_sample_hz:
+            raise NotImplementedError('on-the-fly resampling (torchaudio) is outside the hot path: resample before tokenizing')
+        lead = x.shape[:-1]
+        x = x.reshape(-1, x.shape[-1])                           # pack([x], '* n')
+        x = curtail_to_multiple(x, self.seq_len_multiple_of, from_left=curtail_from_left)
+        return x.unsqueeze(1), lead
+
+    def encode(self, x):
+        """(b, 1, n) fp32 -> (b, n / prod(strides), codebook_dim): the encoder stack + 'b c n -> b n c'."""
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd.SoundStream runs on the MI355X only (no CPU fallback)')
+        h = x.to(F32).contiguous()
+        for layer in self.encoder:
+            if isinstance(layer, CausalConv1d):
+                h = layer.run(h)
+            else:
+                for sub in layer:
+                    h = sub(h) if isinstance(sub, _ResidualFn) else sub.run(h)
+        return ops.bct_to_btc(h)
+
+    @torch.no_grad()
+    def tokenize(self, audio):                                   # soundstream.py:797-800
+        self.eval()
+        return self.forward(audio, return_codes_only=True)
+
+    @torch.no_grad()
+    def forward(self, x, target=None, is_denoising=None, return_encoded=False, return_codes_only=False, input_sample_hz=None,
+                curtail_from_left=False, **kwargs):
+        if target is not None or is_denoising is not None or not (return_encoded or return_codes_only) or any(kwargs.values()):
+            raise NotImplementedError('only forward(..., return_encoded=True) / return_codes_only=True (the tokenize path) is implemented')
+        x, _ = self.process_input(x, input_sample_hz=input_sample_hz, curtail_from_left=curtail_from_left)
+        feats = self.encode(x)
+        quantized, indices, commit_loss = self.rq(feats)
+        if return_codes_only:
+            return indices                                       # (g, b, n, q), soundstream.py:847-848
+        b, n = indices.shape[1], indices.shape[2]
+        return quantized, indices.permute(1, 2, 0, 3).reshape(b, n, -1), commit_loss          # 'g b n q -> b n (g q)', :851
+
+    def decode_from_codebook_indices(self, quantized_indices):
+        raise NotImplementedError('the decoder is out of scope (SURVEY.md §8(f) item 3)')

@@ -146,35 +146,63 @@ def main():
     ms = dt / args.steps * 1e3
     tokens_per_s = world * B_PER_GPU * SEQ / (dt / args.steps)
 
-    # ---- roofline of the dominant kernel: one instrumented step, HIP events around every GEMM launch on the launch stream
-    gemm_ms = gemm_flops = 0.0
-    launches = 0
+    # ---- roofline of the dominant kernel: one instrumented step, HIP events (torch.cuda.Event on the launch stream = torch's current
+    # stream, which is the stream every alm_* launch uses) around every MFMA GEMM launch.  The dominant kernel is the NT 256x256x64
+    # 8-wave tile (gemm_kernel<256,256,2,4,false,*>): its launches are singled out; all GEMM launches are reported alongside.
+    roof = None
     if rank == 0:
         events = []
-        orig = ops.gemm_nt
+        orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn_splitk
 
-        def timed_gemm(Am, Bm, Cm, **kw):
+        def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
+            return M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) * nb >= 192
+
+        def timed_nt(Am, Bm, Cm, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = orig(Am, Bm, Cm, **kw)
+            out = orig_nt(Am, Bm, Cm, **kw)
             e1.record()
             nb = 1
             for d in Am.shape[:-2]:
                 nb *= d
-            events.append((e0, e1, 2.0 * nb * Am.shape[-2] * Bm.shape[-2] * Am.shape[-1]))
+            Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
+            events.append((e0, e1, 2.0 * nb * Mm * Nn * Kk, 'nt256' if big_tile(Mm, Nn, nb) else 'nt128'))
             return out
-        ops.gemm_nt = timed_gemm
-        import audiolm_pytorch_amd.core as core_mod
-        import audiolm_pytorch_amd.heads as heads_mod
+
+        def timed_tn(At, Bt, Cm, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_tn(At, Bt, Cm, **kw)
+            e1.record()
+            nb = At.shape[0] if At.dim() == 3 else 1
+            events.append((e0, e1, 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2], 'tn'))
+            return out
+        ops.gemm_nt, ops.gemm_tn_splitk = timed_nt, timed_tn
         try:
             step()
             torch.cuda.synchronize()
         finally:
-            ops.gemm_nt = orig
-        for e0, e1, fl in events:
-            gemm_ms += e0.elapsed_time(e1)
-            gemm_flops += fl
-        launches = len(events)
+            ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
+        agg = {}
+        for e0, e1, fl, kind in events:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += fl
+            a[2] += 1
+        tot_ms = sum(a[0] for a in agg.values())
+        tot_fl = sum(a[1] for a in agg.values())
+        d_ms, d_fl, d_n = agg.get('nt256', [0.0, 0.0, 0])
+        if d_n:
+            ach = d_fl / (d_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<256,256,2,4,NT> (bf16 MFMA 32x32x16; FFN / projection forward + dgrad GEMMs)',
+                    'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                    'traffic': None, 'launches_per_step': d_n, 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
+                    'flop_per_launch_avg': round(d_fl / d_n, 0),
+                    'share_of_step': round(d_ms / ms, 3),
+                    'all_gemm_launches': {'launches_per_step': len(events), 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                          'share_of_step': round(tot_ms / ms, 3),
+                                          'by_kind_ms': {k: round(v[0], 3) for k, v in agg.items()}},
+                    'model_flops_frac': round(tokens_per_s / world * 391e6 / (PEAK_BF16_TFLOPS * 1e12), 4)}
     if dist is not None:
         dist.barrier()
 
@@ -205,13 +233,8 @@ def main():
                        'global_batch': world * B_PER_GPU, 'seq_len': SEQ, 'parallelism': f'dp{world}'},
             'loss': round(float(loss), 4),
         }
-        if launches:
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (bf16 MFMA 32x32x16, all fwd/dgrad/wgrad/logit GEMMs of one step)',
-                               'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                               'traffic': None, 'launches_per_step': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
-                               'gemm_share_of_step': round(gemm_ms / ms, 3),
-                               'model_flops_frac': round(tokens_per_s / world * 391e6 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        if roof:
+            out['roofline'] = roof
         if opt_leg:
             out['with_optimizer'] = opt_leg
         if world == 1 and not args.no_cpu_baseline:

@@ -132,6 +132,24 @@ int alm_cross_entropy_bwd(const float* logits, long long ld, const long long* la
                           long long ldd, long long rows, int C, int Cpad, int ignore_index, void* stream);
 int alm_reduce_sum(const float* in, long long n, float* out, float scale, void* stream);
 
+/* ---- SoundStream tokenize path (encode only): soundstream.py:332-345, 362-380, 519-531 (causal conv encoder), :592-607 / :840 ----
+ * (eval-mode GroupedResidualVQ of vector-quantize-pytorch, restated in oracle/rvq_restated.py).  All fp32: the code indices are an
+ * argmin over float distances, so both kernels run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), never bf16.
+ * conv: x [B][Cin][Tin] -> out [B][Cout][Tout], Tout = (Tin - stride) / stride + 1; left reflect pad dilation*(ksize-1) + 1 - stride;
+ *       out = act(conv + bias) (+ residual), act = ELU when `elu`.  wp = weights packed once by alm_conv1d_pack. */
+int alm_conv1d_packed_floats(int Cout, int Cin, int ksize);
+int alm_conv1d_pack(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream);
+int alm_conv1d_causal(const float* x, const float* wp, const float* bias, const float* residual, float* out, int B, int Cin, int Cout, int Tin,
+                      int ksize, int stride, int dilation, int elu, void* stream);
+/* rvq: frames x [T][ldx] (d columns of one group), codebooks E [Q][C][d]; Et [Q][d][CP] / e2 [Q][CP] packed once by alm_rvq_pack
+ * (CP = alm_rvq_padded_codes(C)); idx int64 [T][ldi] (Q columns): per quantizer argmin_e sqrt(clamp(|r|^2 + |e|^2 - 2 r.e, 0)) with
+ * first-index tie-breaking, r -= E[idx]; quant (optional) = sum of the selected code vectors. */
+int alm_rvq_padded_codes(int C);
+int alm_rvq_pack(const float* E, float* Et, float* e2, int Q, int C, int d, void* stream);
+int alm_rvq_encode(const float* x, long long ldx, const float* E, const float* Et, const float* e2, long long* idx, long long ldi, float* quant,
+                   long long ldq, int T, int d, int C, int Q, void* stream);
+int alm_bct_to_btc(const float* in, float* out, int B, int C, int T, void* stream);   /* 'b c n -> b n c', soundstream.py:823 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""SoundStream tokenize path on the MI355X (csrc/codec.hip through the C ABI) vs the CPU oracle and the golden fixture produced by the
+REAL reference encoder (first-party, pinned) around the restated residual VQ (third-party, parity unpinned -- SURVEY.md §8(c)).
+
+Tolerances: fp32 everywhere (exact-fp32 MFMA, a different summation order than the CPU convolution): activations rel-max 2e-5;
+code indices are integers -- bit-exact on the golden fixture; on large random problems an index may differ from the oracle only where
+the two candidates' distances are within float rounding of each other (checked explicitly, and < 0.1 % of the frames)."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import audiolm_oracle as O
+from common import GOLDEN_DIR, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from audiolm_pytorch_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize('B,Cin,Cout,T,k,stride,dil', [(2, 1, 32, 1000, 7, 1, 1), (1, 32, 32, 777, 7, 1, 9), (2, 32, 64, 640, 4, 2, 1),
+                                                       (1, 64, 128, 512, 8, 4, 1), (1, 128, 256, 400, 10, 5, 1), (1, 4, 8, 333, 7, 1, 3),
+                                                       (2, 48, 40, 300, 3, 1, 1), (1, 256, 512, 64, 16, 8, 1)])
+def test_causal_conv1d(ops, B, Cin, Cout, T, k, stride, dil):
+    x, w, b = rnd(B, Cin, T, seed=1), rnd(Cout, Cin, k, seed=2, scale=(Cin * k) ** -0.5), rnd(Cout, seed=3, scale=0.1)
+    ref = O.causal_conv1d(x, w, b, dilation=dil, stride=stride)
+    wp = ops.conv1d_pack(w.to(dev()))
+    out = ops.conv1d_causal(x.to(dev()), wp, b.to(dev()), Cout, k, stride=stride, dilation=dil)
+    assert out.shape == ref.shape
+    assert relmax(out, ref) <= 2e-5
+    if stride == 1 and Cin == Cout:                                 # the ResidualUnit epilogue: ELU + residual
+        out2 = ops.conv1d_causal(x.to(dev()), wp, b.to(dev()), Cout, k, stride=1, dilation=dil, elu=True, residual=x.to(dev()))
+        assert relmax(out2, F.elu(ref) + x) <= 2e-5
+
+
+def _check_indices(idx, x, cbs):
+    """idx (T, Q) vs the oracle on the same fp32 inputs: equal, or a float-rounding tie (replays the oracle's residual path)."""
+    ref = O.rvq_encode(x[None], cbs)[0]
+    bad = (idx != ref).any(dim=-1)
+    nbad = int(bad.sum())
+    if nbad == 0:
+        return 0
+    assert nbad <= max(1, int(1e-3 * idx.shape[0])), f'{nbad} of {idx.shape[0]} frames differ from the oracle'
+    for t in torch.nonzero(bad).flatten().tolist():
+        r = x[t].clone()
+        for q, E in enumerate(cbs):
+            d = ((r[None] - E) ** 2).sum(-1).sqrt()
+            a, b = int(idx[t, q]), int(ref[t, q])
+            if a != b:
+                assert abs(float(d[a]) - float(d[b])) <= 1e-4 * max(1.0, float(d[b])), (t, q, float(d[a]), float(d[b]))
+                break                                               # residual paths diverge after the first differing stage
+            r = r - E[a]
+    return nbad
+
+
+@pytest.mark.parametrize('T,d,C,Q', [(50, 16, 32, 4), (333, 64, 100, 3), (1000, 512, 1024, 8), (129, 24, 37, 2)])
+def test_rvq_encode(ops, T, d, C, Q):
+    x = rnd(T, d, seed=4)
+    E = rnd(Q, C, d, seed=5)
+    E[1:] *= 0.6 ** torch.arange(1, Q)[:, None, None]               # later stages quantize smaller residuals
+    Ed = E.to(dev())
+    Et, e2 = ops.rvq_pack(Ed)
+    quant = torch.empty((T, d), dtype=F32, device=dev())
+    idx = ops.rvq_encode(x.to(dev()), Ed, Et, e2, quant_out=quant).cpu()
+    assert int(idx.min()) >= 0 and int(idx.max()) < C
+    _check_indices(idx, x, list(E))
+    deq = sum(E[q][idx[:, q]] for q in range(Q))                    # quantized output == sum of the selected code vectors
+    assert relmax(quant, deq) <= 1e-5
+
+
+def test_rvq_exact_codes_and_idempotence(ops):
+    """known answers: a frame that IS a code vector selects that code with distance 0; re-encoding a dequantized frame reproduces it."""
+    d, C, Q = 64, 256, 1
+    E = rnd(Q, C, d, seed=6)
+    Ed = E.to(dev())
+    Et, e2 = ops.rvq_pack(Ed)
+    pick = torch.randint(0, C, (500,), generator=torch.Generator().manual_seed(7))
+    idx = ops.rvq_encode(E[0][pick].to(dev()).contiguous(), Ed, Et, e2).cpu()
+    assert torch.equal(idx[:, 0], pick)
+
+
+def _load_fixture():
+    return torch.load(os.path.join(GOLDEN_DIR, 'soundstream_small.pt'), weights_only=False)
+
+
+def test_soundstream_matches_reference_golden():
+    """tests/golden/soundstream_small.pt: the REAL reference SoundStream (encoder = reference code; RVQ = restated module) on seeded
+    weights / audio.  Our module loads the same state_dict by NAME and must reproduce the encoder output and every code index."""
+    import audiolm_pytorch_amd as A
+    fx = _load_fixture()
+    ss = A.SoundStream(**fx['ctor'])
+    missing, unexpected = ss.load_state_dict(synth_state_dict(fx['shapes'], fx['seed']), strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    ss.to(dev())
+    wave = fx['inputs']['wave'].to(dev())
+    x, _ = ss.process_input(wave)
+    enc = ss.encode(x)                                              # (b, n, c)
+    ref_enc = fx['outputs']['encoder_out'].transpose(1, 2)          # reference encoder output is (b, c, n)
+    assert relmax(enc, ref_enc) <= 2e-5
+    codes = ss.tokenize(wave)
+    assert codes.dtype == torch.int64 and torch.equal(codes.cpu(), fx['outputs']['tokenize'])            # (g, b, n, q)
+    emb, indices, _ = ss(wave, return_encoded=True)
+    assert torch.equal(indices.cpu(), fx['outputs']['indices'])                                         # (b, n, g*q)
+    assert relmax(emb, fx['outputs']['quantized']) <= 2e-5
+
+
+def test_soundstream_config5_shape_properties():
+    """BASELINE configs[4] codec shape (codebook 4096, 8 quantizers, strides 2*4*5*8 = 320, 512-d codes) on 1.5 s of 24 kHz audio:
+    size-independent properties -- index range, dequantization consistency, per-stage minimality of the selected code against sampled
+    alternatives (torch recomputation from the produced indices), and time-causality of the encoder (changing the LAST 320 samples changes only the last frame)."""
+    import audiolm_pytorch_amd as A
+    torch.manual_seed(0)
+    ss = A.SoundStream(codebook_size=4096, rq_num_quantizers=8, target_sample_hz=24000, strides=(2, 4, 5, 8), use_local_attn=False)
+    g = torch.Generator().manual_seed(3)
+    for r in ss.rq.rvqs:
+        for q, l in enumerate(r.layers):
+            l._codebook.embed.copy_(torch.randn(1, 4096, 512, generator=g) * (0.5 ** q))
+            l._codebook.initted.fill_(True)
+    ss.to(dev())
+    wave = (torch.randn(2, 36000, generator=g) * 0.1).to(dev())
+    emb, idx, _ = ss(wave, return_encoded=True)
+    assert idx.shape == (2, 36000 // 320, 8) and int(idx.min()) >= 0 and int(idx.max()) < 4096
+    E = torch.stack([l._codebook.embed[0] for l in ss.rq.rvqs[0].layers])
+    feats = ss.encode(ss.process_input(wave)[0])
+    res = feats.reshape(-1, 512).clone()
+    gen = torch.Generator().manual_seed(9)
+    for q in range(8):
+        chosen = (res - E[q][idx.reshape(-1, 8)[:, q]]).norm(dim=-1)
+        for _ in range(4):                                          # minimality: no sampled alternative code is closer
+            alt = torch.randint(0, 4096, (res.shape[0],), generator=gen).to(dev())
+            other = (res - E[q][alt]).norm(dim=-1)
+            assert bool((chosen <= other * (1 + 1e-5)).all()), f'stage {q}: a sampled code is closer than the selected one'
+        res = res - E[q][idx.reshape(-1, 8)[:, q]]
+    assert relmax(emb.reshape(-1, 512), feats.reshape(-1, 512) - res) <= 1e-4
+    wave2 = wave.clone()
+    wave2[:, -320:] += 0.05
+    idx2 = ss.tokenize(wave2)[0]
+    assert torch.equal(idx2[:, :-1], idx[:, :-1]), 'encoder is not causal'

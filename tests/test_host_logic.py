@@ -116,3 +116,22 @@ def test_product_refuses_cpu_and_out_of_scope_features():
         m(ids=torch.randint(0, 10, (2, 5)))
     with pytest.raises(NotImplementedError):
         A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, has_condition=True)
+
+
+def test_soundstream_module_tree_matches_reference_state_dict_names():
+    """The tokenize-path mirror keeps the reference's parameter / buffer names and shapes for `encoder.*` and `rq.*` (fixture shapes
+    come from the REAL reference module), so reference checkpoints load by name; options outside the hot path are refused."""
+    import os
+    import pytest
+    import torch
+    from common import GOLDEN_DIR
+    import audiolm_pytorch_amd as A
+    fx = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_small.pt'), weights_only=False)
+    ss = A.SoundStream(**fx['ctor'])
+    ours = {k: tuple(v.shape) for k, v in ss.state_dict().items()}
+    assert ours == {k: tuple(v) for k, v in fx['shapes'].items()}
+    assert ss.seq_len_multiple_of == 320 and ss.rq_groups == 1 and ss.num_quantizers == fx['ctor']['rq_num_quantizers']
+    with pytest.raises(NotImplementedError):
+        A.SoundStream(codebook_size=32)                              # reference default use_local_attn=True is SURVEY §8(f)-3
+    with pytest.raises(RuntimeError):
+        ss.tokenize(torch.zeros(1, 640))                              # CPU tensor: no CPU fallback
