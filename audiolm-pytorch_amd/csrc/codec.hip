@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
             pos[j] = pok[j] ? p : 0;
         }
         const float* wt = a.wp + (long long)tap * a.CinP * a.CoutP + co0 + lr;
-        for (int cc = 0; cc < a.CinP; cc += 2) {
+#pragma unroll 4
+        for (int cc = 0; cc < a.CinP; cc += 2) {                    // unrolled: 4 k-steps of loads in flight ahead of their MFMAs
             const int ci = cc + lh;
             float av[NA], bv[2];
 #pragma unroll
@@ -162,30 +163,42 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     }
     __syncthreads();
 
-    const int nblk = a.CP / 32;               // 32-code blocks; wave w scans blocks w, w + 4, ...
+    const int nblk = a.CP / 32;               // 32-code blocks; wave w scans block pairs 2w, 2w + 8, ...
     for (int q = 0; q < a.Q; ++q) {
         const float* Et = a.Et + (long long)q * a.d * a.CP;
         const float* e2 = a.e2 + (long long)q * a.CP;
         const float xn = x2[lr];
         float best = INFINITY;
         int besti = 0x7fffffff;
-        for (int cb = wave; cb < nblk; cb += 4) {
-            f32x16 acc;
+        // two 32-code blocks per pass share every residual (B) operand read; the k loop is unrolled so that several steps' loads are
+        // in flight ahead of the dependent MFMA chain
+        for (int cb = wave * 2; cb < nblk; cb += 8) {
+            const bool two = cb + 1 < nblk;
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             const float* ep = Et + cb * 32 + lr;
+            const int o1 = two ? 32 : 0;
+#pragma unroll 8
             for (int k = 0; k < a.d; k += 2) {
                 const int kk = k + lh;
-                const float av = kk < a.d ? ep[(long long)kk * a.CP] : 0.f;          // A[code][k]
-                const float bv = kk < a.d ? res[lr * ld + kk] : 0.f;                 // B[k][frame]
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                const bool kok = kk < a.d;
+                const float av0 = kok ? ep[(long long)kk * a.CP] : 0.f;             // A[code][k]
+                const float av1 = kok ? ep[(long long)kk * a.CP + o1] : 0.f;
+                const float bv = kok ? res[lr * ld + kk] : 0.f;                      // B[k][frame]
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc1, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {                                           // codes in increasing order per lane
-                const int code = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float d2 = (xn + e2[code]) + (-2.f * acc[r]);
-                const float dist = sqrtf(fmaxf(d2, 0.f));
-                if (dist < best) { best = dist; besti = code; }
+            for (int h2 = 0; h2 < 2; ++h2) {
+                if (h2 == 1 && !two) break;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                                       // codes in increasing order per lane
+                    const int code = (cb + h2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float d2 = (xn + e2[code]) + (-2.f * (h2 ? acc1[r] : acc0[r]));
+                    const float dist = sqrtf(fmaxf(d2, 0.f));
+                    if (dist < best) { best = dist; besti = code; }
+                }
             }
         }
         {   // merge the two lane halves (same frame, different codes), then the 4 waves: smallest distance, first index on ties

@@ -147,6 +147,29 @@ def bench_hc():
         print(f'{name:30s}: {t:.3f} ms  {byt / t / 1e6:.0f} GB/s algorithmic')
 
 
+def bench_codec():
+    """BASELINE configs[4] codec: SoundStream(codebook 4096, 8 quantizers, 24 kHz, strides 2*4*5*8) on 8 x 30 s of synthetic audio."""
+    torch.manual_seed(0)
+    ss = A.SoundStream(codebook_size=4096, rq_num_quantizers=8, target_sample_hz=24000, strides=(2, 4, 5, 8), use_local_attn=False)
+    for r in ss.rq.rvqs:
+        for q, l in enumerate(r.layers):
+            l._codebook.embed.copy_(torch.randn(1, 4096, 512) * (0.5 ** q))
+            l._codebook.initted.fill_(True)
+    ss.to(dev)
+    wave = torch.randn(8, 720000, device=dev) * 0.1
+    x, _ = ss.process_input(wave)
+    feats = ss.encode(x)
+    t_enc = timeit(lambda: ss.encode(x), iters=3, warm=1)
+    t_rvq = timeit(lambda: ss.rq(feats), iters=3, warm=1)
+    t_all = timeit(lambda: ss.tokenize(wave), iters=3, warm=1)
+    frames = feats.shape[0] * feats.shape[1]
+    macs_enc = 8 * 720000 * 190.6e3
+    macs_rvq = frames * 8 * 4096 * 512
+    print(f'codec encoder   8 x 30 s @ 24 kHz: {t_enc:.2f} ms  {2 * macs_enc / t_enc / 1e9:.1f} TF fp32')
+    print(f'codec rvq       {frames} frames x 8 x 4096 codes: {t_rvq:.2f} ms  {2 * macs_rvq / t_rvq / 1e9:.1f} TF fp32')
+    print(f'codec tokenize  total {t_all:.2f} ms -> {frames * 8 / t_all * 1e3:.0f} codes/s, {8 * 30 / t_all * 1e3:.0f} x real time')
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)
