@@ -18,10 +18,12 @@ _P, _I, _L, _F = c_void_p, c_int, c_longlong, c_float
 SIGNATURES = {
     'alm_gemm_bf16_nt': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _P],
     'alm_gemm_splitk_slices': [_I, _I, _I, _I],
+    'alm_debug_splitk': [_I, _I, _I],
     'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_nt_tile': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _I, _I, _P],
     'alm_transpose_bf16': [_P, _P, _I, _I, _L, _L, _I, _P],
+    'alm_pack_weights_multi': [_P, _I, _P],
     'alm_pack_weight': [_P, _I, _I, _L, _P, _L, _I, _I, _P, _L, _P],
     'alm_ln_partial_blocks': [_I],
     'alm_layernorm_fwd': [_P, _I, _L, _P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
@@ -38,9 +40,9 @@ SIGNATURES = {
     'alm_hc_coef_width': [_I],
     'alm_hc_partial_width': [_I, _I],
     'alm_hc_grads_width': [_I, _I],
-    'alm_hc_partial_rows': [_L, _I],
+    'alm_hc_partial_rows': [_I, _I, _I, _L, _I],
     'alm_hc_fwd': [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'alm_hc_bwd': [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_bwd': [_P, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     'alm_hc_param_grads': [_P, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
@@ -93,6 +95,12 @@ def load(build_if_missing: bool = True):
         fn.restype = c_int
     _lib = lib
     return lib
+
+
+class AlmPackJob(ctypes.Structure):
+    """mirror of AlmPackJob in include/audiolm_hip.h"""
+    _fields_ = [('src', c_void_p), ('rows', c_int), ('cols', c_int), ('ld_src', c_longlong), ('dst', c_void_p), ('ld_dst', c_longlong),
+                ('rows_pad', c_int), ('cols_pad', c_int), ('dstT', c_void_p), ('ld_dstT', c_longlong)]
 
 
 def call(name: str, *args):

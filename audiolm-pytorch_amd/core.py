@@ -12,6 +12,7 @@ Data layout in HBM (B sequences, N tokens, M = B*N rows, D model width, S residu
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -102,6 +103,41 @@ def _pack_w2(w, I, Ip):
     return W, WT
 
 
+def layer_weights(cache: WeightCache, l, pa, pf, I, Ip):
+    """bf16 packed (W, W^T) pairs of one layer's five dense weights; when any master changed, ALL are re-packed in one launch."""
+    ws = (('wq', pa['wq']), ('wkv', pa['wkv']), ('wo', pa['wo']), ('w1', pf['w1']), ('w2', pf['w2']))
+    vers = {k: (w.data_ptr(), w._version, tuple(w.shape)) for k, w in ws}
+    hits = {k: cache.store.get((l, k)) for k, _ in ws}
+    if all(h is not None and h[0] == vers[k] for k, h in hits.items()):
+        return tuple(hits[k][1] for k, _ in ws)
+    out, jobs = {}, []
+    with torch.no_grad():
+        for k, w in ws[:3]:
+            w = w.detach()
+            rows, cols = w.shape
+            rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+            W = torch.empty((rp, cp), dtype=BF16, device=w.device)
+            WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
+            jobs.append((w, W, WT, rp, cp))
+            out[k] = (W[:rows], WT[:cols])
+        w1 = pf['w1'].detach()
+        D = w1.shape[1]
+        W1 = torch.empty((2 * Ip, D), dtype=BF16, device=w1.device)
+        W1T = torch.empty((D, 2 * Ip), dtype=BF16, device=w1.device)
+        jobs.append((w1[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
+        jobs.append((w1[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
+        out['w1'] = (W1, W1T)
+        w2 = pf['w2'].detach()
+        W2 = torch.empty((D, Ip), dtype=BF16, device=w2.device)
+        W2T = torch.empty((Ip, D), dtype=BF16, device=w2.device)
+        jobs.append((w2, W2, W2T, D, Ip))
+        out['w2'] = (W2, W2T)
+        ops.pack_weights_multi(jobs)
+    for k, _ in ws:
+        cache.store[(l, k)] = (vers[k], out[k])
+    return tuple(out[k] for k, _ in ws)
+
+
 def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
@@ -120,11 +156,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
         pa, pf = _split_layer(flat[l * ppl:(l + 1) * ppl], S)
-        Wq, WqT = cache.get((l, 'wq'), pa['wq'], _pack_plain)
-        Wkv, WkvT = cache.get((l, 'wkv'), pa['wkv'], _pack_plain)
-        Wo, WoT = cache.get((l, 'wo'), pa['wo'], _pack_plain)
-        W1, W1T = cache.get((l, 'w1'), pf['w1'], lambda w: _pack_w1(w, I, Ip))
-        W2, W2T = cache.get((l, 'w2'), pf['w2'], lambda w: _pack_w2(w, I, Ip))
+        (Wq, WqT), (Wkv, WkvT), (Wo, WoT), (W1, W1T), (W2, W2T) = layer_weights(cache, l, pa, pf, I, Ip)
 
         # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
         if S > 1:
@@ -184,6 +216,45 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     return hn, saved
 
 
+class _SideStream:
+    """Weight-gradient GEMMs are off the critical path of the backward chain (nothing downstream reads dW before the optimiser / the
+    gradient all-reduce), so they are issued on a second HIP stream and fill CUs the critical-path kernels leave idle (tails of the
+    causal attention grids, HBM-bound hyper-connection / LayerNorm kernels, launch gaps).  Inputs are pinned with record_stream so the
+    caching allocator cannot recycle them while the side stream still reads them."""
+    _streams = {}
+
+    def __init__(self, dev, enabled=True):
+        self.enabled = enabled and dev.type == 'cuda'
+        if self.enabled:
+            key = (dev.type, dev.index)
+            if key not in _SideStream._streams:
+                _SideStream._streams[key] = torch.cuda.Stream(device=dev)
+            self.stream = _SideStream._streams[key]
+            self.main = torch.cuda.current_stream(dev)
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        for t in tensors:
+            t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            return fn()
+
+    def join(self):
+        """main stream waits for everything issued on the side stream so far"""
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.main.wait_event(ev)
+
+
+FUSE_LN_BWD = os.environ.get('ALM_FUSE_LN_BWD', '1') != '0'             # switch: pre-LayerNorm backward inside the hyper-connection kernel
+ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
+
+
 def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None):
     """dhn bf16 [M, D] -> (dx fp32 [B, N, D] (already scaled by grad_shrink alpha), list of parameter grads aligned with `flat`)."""
     B, N = saved['B'], saved['N']
@@ -193,6 +264,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     dev = dhn.device
     ppl = params_per_layer(S)
     grads = [None] * len(flat)
+    side = _SideStream(dev, ASYNC_WGRAD)
 
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
     grads[-1] = dgam
@@ -210,11 +282,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         sv = saved['layers'][l]
         base = l * ppl
         pa, pf = _split_layer(flat[base:base + ppl], S)
-        Wq, WqT = cache.get((l, 'wq'), pa['wq'], _pack_plain)
-        Wkv, WkvT = cache.get((l, 'wkv'), pa['wkv'], _pack_plain)
-        Wo, WoT = cache.get((l, 'wo'), pa['wo'], _pack_plain)
-        W1, W1T = cache.get((l, 'w1'), pf['w1'], lambda w: _pack_w1(w, I, Ip))
-        W2, W2T = cache.get((l, 'w2'), pf['w2'], lambda w: _pack_w2(w, I, Ip))
+        (Wq, WqT), (Wkv, WkvT), (Wo, WoT), (W1, W1T), (W2, W2T) = layer_weights(cache, l, pa, pf, I, Ip)
         hc_n = 7 if S > 1 else 0
         ia = base + hc_n                      # index of attn ln gamma
         iff = base + hc_n + 4 + hc_n          # index of ff ln gamma
@@ -225,22 +293,30 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dHN = _empty((M, Ip), BF16, dev)
         ops.gemm_nt(dY2, W2T, dHN)                                            # dHN = dY2 @ W2
         dW2 = _empty((D, I), F32, dev)
-        ops.gemm_tn_splitk(dY2, sv['HN'][:, :I], dW2)                         # dW2 = dY2^T @ HN
+        HNs = sv['HN']
+        side.run(lambda: ops.gemm_tn_splitk(dY2, HNs[:, :I], dW2), dY2, HNs, dW2)      # dW2 = dY2^T @ HN
         dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], pf['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
         dXN2 = _empty((M, D), BF16, dev)
         ops.gemm_nt(dU, W1T, dXN2)                                            # dXN2 = dU @ W1
         dW1 = _empty((2 * I, D), F32, dev)
-        ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], sv['XN2'], dW1.view(2, I, D))   # dW1 = dU^T @ XN2 (x | gate halves)
-        xsrc = sv['X2'] if S > 1 else sv['R1']
-        dX2, dgl = ops.layernorm_bwd(dXN2, xsrc, sv['mean2'], sv['rstd2'], pf['ln'])
+        XN2s = sv['XN2']
+        side.run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2s, dW1.view(2, I, D)), dU, XN2s, dW1)   # dW1 = dU^T @ XN2
         if S > 1:
-            # width-connection backward of the FF branch fused with the depth-connection backward of this layer's attention branch
-            h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dx=dX2, R=sv['R1'], coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'],
-                           y_prev=sv['Y'], coef_prev=sv['coef'])
+            # the FF branch's pre-LayerNorm backward + its width-connection backward + the depth-connection backward of this layer's
+            # attention branch: ONE pass over the residual streams
+            if FUSE_LN_BWD:
+                h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN2, mean=sv['mean2'], rstd=sv['rstd2'], ln_gamma=pf['ln'], R=sv['R1'],
+                               coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'], y_prev=sv['Y'], coef_prev=sv['coef'])
+                dgl = h['grads']['ln']
+            else:
+                dX2, dgl = ops.layernorm_bwd(dXN2, sv['X2'], sv['mean2'], sv['rstd2'], pf['ln'])
+                h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dx=dX2, R=sv['R1'], coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'],
+                               y_prev=sv['Y'], coef_prev=sv['coef'])
             dR1, dY, dbeta, bcast = h['dR'], h['dy'], h['dbeta'], False
             for j, k in enumerate(HC_KEYS):
                 grads[base + hc_n + 4 + j] = h['grads'][k]
         else:
+            dX2, dgl = ops.layernorm_bwd(dXN2, sv['R1'], sv['mean2'], sv['rstd2'], pf['ln'])
             dR1 = ops.add_f32(dR, dX2)
             dY = ops.f32_to_bf16(dR1)
         grads[iff], grads[iff + 1], grads[iff + 2], grads[iff + 3] = dgl, dW1, dg3, dW2
@@ -249,7 +325,8 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dAO = _empty((M, H * dh), BF16, dev)
         ops.gemm_nt(dY, WoT, dAO)
         dWo = _empty((D, H * dh), F32, dev)
-        ops.gemm_tn_splitk(dY, sv['AO'], dWo)
+        AOs = sv['AO']
+        side.run(lambda: ops.gemm_tn_splitk(dY, AOs, dWo), dY, AOs, dWo)
         KV = sv['KV']
         dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh)
         if acc_v0 is None:
@@ -262,29 +339,40 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         dXN = _empty((M, D), BF16, dev)
         ops.gemm_nt(dQ, WqT, dXN)
         dWq = _empty((H * dh, D), F32, dev)
-        ops.gemm_tn_splitk(dQ, sv['XN'], dWq)
+        XNs = sv['XN']
+        side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
         dXkv = _empty((M, D), BF16, dev)
         ops.gemm_nt(dKV, WkvT, dXkv)
         dWkv = _empty((2 * dh, D), F32, dev)
-        ops.gemm_tn_splitk(dKV, sv['X'], dWkv)
-        xsrc = sv['X'] if S > 1 else sv['R']
-        dX, dgla = ops.layernorm_bwd(dXN, xsrc, sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
+        Xs = sv['X']
+        side.run(lambda: ops.gemm_tn_splitk(dKV, Xs, dWkv), dKV, Xs, dWkv)
         if S > 1:
-            # width-connection backward of the attention branch (+ depth-connection backward of the previous layer's FF branch)
+            # pre-LayerNorm backward (+ the K/V-path gradient dXkv, which reaches the un-normalised branch input directly) + width-connection
+            # backward of the attention branch (+ depth-connection backward of the previous layer's FF branch)
             prev = saved['layers'][l - 1] if l > 0 else None
-            h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'],
-                           y_prev=prev['Y2'] if prev else None, coef_prev=prev['coef2'] if prev else None)
+            py, pc = (prev['Y2'], prev['coef2']) if prev else (None, None)
+            if FUSE_LN_BWD:
+                h = ops.hc_bwd(dR1, B, S, N, D, dxn=dXN, extra=dXkv, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=pa['ln'], R=sv['R'],
+                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc)
+                dgla = h['grads']['ln']
+            else:
+                dX, dgla = ops.layernorm_bwd(dXN, sv['X'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
+                h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc)
             dR, dY2, dbeta2 = h['dR'], h['dy'], h['dbeta']
             for j, k in enumerate(HC_KEYS):
                 grads[base + j] = h['grads'][k]
         else:
+            dX, dgla = ops.layernorm_bwd(dXN, sv['R'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
             dR = ops.add_f32(dR1, dX)
         grads[ia], grads[ia + 1], grads[ia + 2], grads[ia + 3] = dgla, dWq, dWkv, dWo
         sv.clear()
         if on_layer_grads is not None:
-            on_layer_grads(l, grads[base:base + ppl])
+            # the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the critical
+            # path never waits for them
+            side.run(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
     dx = ops.streams_reduce(dR, B, S) if S > 1 else dR.view(B, N, D)
+    side.join()                                    # autograd hands the gradients to consumers on the main stream
     return dx, grads
 
 

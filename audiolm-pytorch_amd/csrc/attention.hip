@@ -105,14 +105,29 @@ __device__ __forceinline__ int drow(int r, int lh) { return (r & 3) + 8 * (r >> 
 
 // workgroup id -> (light/heavy-paired block index, head group, batch element)
 struct BlockId { int blk, hg, b; };
-__device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, bool heavy_is_high, bool pair_on_cu) {
+__device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, int B, bool heavy_is_high, bool pair_on_cu) {
     BlockId r;
-    const int idx = L % nblk, rest = L / nblk;
-    r.hg = rest % HG;
-    r.b = rest / HG;
-    // two co-resident workgroups per CU: the second one (L + 256) gets the complementary weight; one workgroup per CU
-    // (round-based execution): plain heaviest-first order (longest-processing-time-first list scheduling)
-    const bool flip = pair_on_cu && ((L >> 8) & 1);
+    const int combos = HG * B;
+    int idx, combo;
+    bool flip;
+    if ((combos & 7) == 0) {
+        // XCD-aware: workgroup L runs on XCD L % 8 (observed dispatch order; a wrong guess only costs speed).  All key / query blocks of
+        // one (batch element, head group) go to ONE XCD so that the Q / dO (K / V) tiles they all stream are fetched from HBM once and
+        // then hit in that XCD's L2.  Each XCD serves combos / 8 groups one after the other.
+        const int xcd = L & 7, j = L >> 3;
+        const int cl = j / nblk;
+        idx = j % nblk;
+        combo = cl * 8 + xcd;
+        flip = pair_on_cu && (cl & 1);                // co-resident pairs on a CU (j, j + 32): complementary weights
+    } else {
+        idx = L % nblk;
+        combo = L / nblk;
+        flip = pair_on_cu && ((L >> 8) & 1);
+    }
+    r.hg = combo % HG;
+    r.b = combo / HG;
+    // pair_on_cu: two co-resident workgroups per CU, the second gets the complementary weight; otherwise (one workgroup per CU,
+    // round-based execution) plain heaviest-first order (longest-processing-time-first list scheduling)
     const int heavy_first = heavy_is_high ? nblk - 1 - idx : idx;
     const int light_first = heavy_is_high ? idx : nblk - 1 - idx;
     r.blk = flip ? light_first : heavy_first;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     float* kbias = reinterpret_cast<float*>(smem + 32768);          // [2][64]: 0 for attendable keys, -inf otherwise
 
     const int nqb = (p.N + 63) / 64;
-    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, true, true);
+    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
     const int qblk = id.blk, b = id.b;
     const int q0 = qblk * 64;
     const int t = threadIdx.x;
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     float* kbias = reinterpret_cast<float*>(smem + 32768);
 
     const int nqb = (p.N + 63) / 64;
-    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, true, true);
+    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
     const int qblk = id.blk, b = id.b;
     const int q0 = qblk * 64;
     const int t = threadIdx.x;
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB
 
     const int nkb = (p.N + 63) / 64;
-    const BlockId id = decode_block(blockIdx.x, nkb, p.HG, false, false);      // low key blocks are the heavy ones
+    const BlockId id = decode_block(blockIdx.x, nkb, p.HG, p.B, false, false);      // low key blocks are the heavy ones
     const int kblk = id.blk, b = id.b;
     const int t = threadIdx.x;
     const int lane = t & 63;

@@ -49,6 +49,8 @@ struct GemmParams {
     int ksplit;        // > 0: split-K -- blockIdx.z is the K-slice index, slice s covers k in [s*ksplit, min(K, (s+1)*ksplit)) and
                        // writes its fp32 partial tile to C + s * sCk (reduced afterwards by splitk_reduce_kernel)
     long long sCk;
+    int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel)
+    int nsl;           // number of K slices (raster 1)
 };
 
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
@@ -61,21 +63,45 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     static_assert(NIA >= 1 && NIB >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile / wave shape");
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    const int bid = xcd_remap(blockIdx.x, nwg);
-    const int per_group = GROUP_M * tiles_n;
-    const int group = bid / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (bid % per_group) % gsz;
-    const int tn = (bid % per_group) / gsz;
+    int tm, tn, zb, zs;
+    if (p.raster == 1) {
+        // split-K weight gradients: the operand with MANY tile panels (e.g. dU: 22 panels of 256 columns) is the big one.  Panel q
+        // (its K slices and the few tiles along the other dimension) is pinned to XCD q % 8 (workgroup L runs on XCD L % 8 -- observed
+        // dispatch order; a wrong guess only costs speed), so each of its K slices is fetched from HBM once and shared through that
+        // XCD's L2; only the small operand is fetched by every XCD.
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const bool m_major = tiles_m >= tiles_n;
+        const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
+        const int P = tmaj * p.nb2;
+        const int PL = (P + 7) / 8;
+        zs = j / (PL * Q);
+        const int rem = j % (PL * Q);
+        const int panel = (rem / Q) * 8 + xcd;
+        const int minor = rem % Q;
+        if (panel >= P || zs >= p.nsl) return;
+        zb = panel / tmaj;
+        const int tmajor = panel % tmaj;
+        tm = m_major ? tmajor : minor;
+        tn = m_major ? minor : tmajor;
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        tm = first_m + (bid % per_group) % gsz;
+        tn = (bid % per_group) / gsz;
+        zb = blockIdx.y;
+        zs = blockIdx.z;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int z1 = blockIdx.y / p.nb2, z2 = blockIdx.y % p.nb2;
+    const int z1 = zb / p.nb2, z2 = zb % p.nb2;
     int kbeg = 0, Krem = p.K;
     long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
     if (p.ksplit > 0) {
-        kbeg = blockIdx.z * p.ksplit;
+        kbeg = zs * p.ksplit;
         Krem = min(p.K - kbeg, p.ksplit);
     }
 
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         constexpr int NCH = ROWB / 16;                      // 16-B chunks per slab row
         constexpr int SLAB = 32 * ROWB;
         static_assert(NW * SLAB <= 2 * STAGE, "epilogue slab");
-        const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? blockIdx.z * p.sCk : 0);
+        const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
         unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + coff0 * ES;
         const bool fast = !p.accumulate && ((p.ldc * ES) & 15) == 0 && ((uintptr_t)Cb & 15) == 0 && (p.N % (16 / ES)) == 0;
         if (fast) {
@@ -279,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             return;
         }
     }
-    const long long coff = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? blockIdx.z * p.sCk : 0);
+    const long long coff = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
     const bool vec_ok = OUT_F32 ? ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0)
                                 : ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 7) == 0);
 #pragma unroll
@@ -403,6 +429,37 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// ---- several weights per launch (one transformer layer = 6 jobs): the per-step bf16 re-pack is launch-bound when done one weight at a time
+struct PackJobs {
+    AlmPackJob job[8];
+    int tile_end[8];          // exclusive prefix sums of the per-job 64x64 tile counts
+    int njobs;
+};
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs pj) {
+    __shared__ bf16_t tile[64][66];
+    int j = 0;
+    while (j + 1 < pj.njobs && (int)blockIdx.x >= pj.tile_end[j]) ++j;
+    const AlmPackJob& q = pj.job[j];
+    const int local = blockIdx.x - (j ? pj.tile_end[j - 1] : 0);
+    const int tcols = (q.cols_pad + 63) / 64;
+    const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(q.dst);
+    bf16_t* dstT = reinterpret_cast<bf16_t*>(q.dstT);
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        const bf16_t v = (r < q.rows && c < q.cols) ? f2bf(q.src[(long long)r * q.ld_src + c]) : (bf16_t)0;
+        tile[i][tx] = v;
+        if (dst && r < q.rows_pad && c < q.cols_pad) dst[(long long)r * q.ld_dst + c] = v;
+    }
+    if (!dstT) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < q.cols_pad && r < q.rows_pad) dstT[(long long)c * q.ld_dstT + r] = tile[tx][i];
+    }
+}
+
 // ---- launch plumbing ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
 int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
@@ -414,8 +471,14 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kfn, dim3(tiles, ny, nz), dim3(WM * WN * 64), smem, st, p);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    if (p.raster == 1) {
+        const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
+        const int PL = (tmaj * ny + 7) / 8;
+        hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(WM * WN * 64), smem, st, p);
+        return 0;
+    }
+    hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n, ny, nz), dim3(WM * WN * 64), smem, st, p);
     return 0;
 }
 
@@ -439,7 +502,21 @@ bool view_too_big(long long rows, long long ld) { return rows * ld * 2 >= 0x7fff
 // Split-K plan for `nb` same-shape problems: choose (tile, slices) minimising a simple time model --
 //   block waves over the chip x K-steps per block x measured time per K-step  +  workspace round trip through HBM.
 struct SplitPlan { int tile, slices; };
+int g_dbg_tile = 0, g_dbg_slices = 0, g_dbg_raster = 1;     // tuning hook (alm_debug_splitk): 0 = automatic
+
+// XCD-panel rasterisation pays only when the panels spread evenly over the 8 XCDs (measured: 22 panels +3 %, 11 panels -40 %)
+int pick_raster(int M, int N, int nb, int tile) {
+    if (!g_dbg_raster) return 0;
+    const int bm = tile == 2 ? 256 : 128;
+    const int tmm = (M + bm - 1) / bm, tnn = (N + bm - 1) / bm;
+    const int P = (tmm >= tnn ? tmm : tnn) * nb;
+    return (P % 8 == 0 || P >= 20) ? 1 : 0;
+}
 SplitPlan splitk_plan(int M, int N, int K, int nb) {
+    if (g_dbg_tile > 0 && g_dbg_slices > 0) {
+        const int kc = ((K + g_dbg_slices - 1) / g_dbg_slices + BK - 1) / BK * BK;
+        return SplitPlan{(g_dbg_tile == 2 && M >= 256 && N >= 256) ? 2 : 1, (K + kc - 1) / kc};
+    }
     SplitPlan best{1, 1};
     double best_t = 1e30;
     for (int tile = 1; tile <= 2; ++tile) {
@@ -471,7 +548,7 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
     if (((sA1 | sA2 | sB1 | sB2) & 7) != 0) return ALM_ERR_BAD_ARG;
     if (view_too_big(256, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0};
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0, 0, 1};
     int rc = launch_gemm<false>(p, nb1 * nb2, 1, out_f32, 0, (hipStream_t)stream);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
@@ -484,7 +561,7 @@ extern "C" int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, cons
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
     if (view_too_big(256, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, 0, 0, 0, alpha, accumulate, 0, 0};
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, 0, 0, 0, alpha, accumulate, 0, 0, 0, 1};
     int rc = launch_gemm<false>(p, 1, 1, out_f32, tile, (hipStream_t)stream);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
@@ -494,13 +571,22 @@ extern "C" int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, cons
 // Split-K for long-K / few-tile contractions (weight gradients: K = B*N tokens), `nb` same-shape problems per launch (element
 // strides sA / sB / sC between them).  ws: fp32 workspace of alm_gemm_splitk_slices(M, N, K, nb) * nb * M * N floats (unused when
 // that is 1).  Deterministic (no atomics): the slices are reduced in a fixed order by a second kernel.
+// tuning hook for benchmarks (process-global, not thread-safe; 0 = automatic): force the split-K tile (1 = 128x128, 2 = 256x256) and
+// slice count, and select the rasterisation of split-K launches (0 = plain grid, 1 = XCD-panel)
+extern "C" int alm_debug_splitk(int tile, int slices, int raster) {
+    g_dbg_tile = tile;
+    g_dbg_slices = slices;
+    g_dbg_raster = raster ? 1 : 0;
+    return 0;
+}
+
 extern "C" int alm_gemm_splitk_slices(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).slices; }
 
 static int splitk_common(bool tn, const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                          long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, hipStream_t st) {
     const SplitPlan pl = splitk_plan(M, N, K, nb);
     if (pl.slices <= 1) {
-        GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, M, N, K, lda, ldb, ldc, nb, 0, sA, 0, sB, 0, sC, alpha, accumulate, 0, 0};
+        GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, M, N, K, lda, ldb, ldc, nb, 0, sA, 0, sB, 0, sC, alpha, accumulate, 0, 0, pick_raster(M, N, nb, pl.tile), 1};
         return tn ? launch_gemm<true>(p, nb, 1, 1, pl.tile, st) : launch_gemm<false>(p, nb, 1, 1, pl.tile, st);
     }
     if (!ws) return ALM_ERR_BAD_ARG;
@@ -508,7 +594,7 @@ static int splitk_common(bool tn, const void* A, const void* B, float* C, float*
     kc = (kc + BK - 1) / BK * BK;
     const int nsl = (K + kc - 1) / kc;
     const long long mn = (long long)M * N;
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, (long long)N, nb, 0, sA, 0, sB, 0, mn, alpha, 0, kc, mn * nb};
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, (long long)N, nb, 0, sA, 0, sB, 0, mn, alpha, 0, kc, mn * nb, pick_raster(M, N, nb, pl.tile), nsl};
     int rc = tn ? launch_gemm<true>(p, nb, nsl, 1, pl.tile, st) : launch_gemm<false>(p, nb, nsl, 1, pl.tile, st);
     if (rc) return rc;
     const int grid = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
@@ -548,6 +634,25 @@ extern "C" int alm_transpose_bf16(const void* src, void* dst, int rows, int cols
     dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64);
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src,
                        ld_dst, rows_pad, 0LL, 0LL);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream) {
+    if (njobs <= 0) return 0;
+    if (njobs > 8 || !jobs) return ALM_ERR_BAD_ARG;
+    PackJobs pj{};
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const AlmPackJob& q = jobs[j];
+        if (q.rows <= 0 || q.cols <= 0 || q.rows_pad < q.rows || q.cols_pad < q.cols) return ALM_ERR_BAD_ARG;
+        if ((q.dst && q.ld_dst < q.cols_pad) || (q.dstT && q.ld_dstT < q.rows_pad)) return ALM_ERR_BAD_ARG;
+        pj.job[j] = q;
+        total += ((q.cols_pad + 63) / 64) * ((q.rows_pad + 63) / 64);
+        pj.tile_end[j] = total;
+    }
+    pj.njobs = njobs;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pj);
     ALM_LAUNCH_CHECK();
     return 0;
 }

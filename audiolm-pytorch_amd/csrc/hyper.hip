@@ -130,6 +130,18 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     }
 
     const long long niter = (M + TPB - 1) / TPB;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // software pipeline: the next token's streams are requested before the current token's reduction / barrier / tanh chain starts
+    float4 r_n[S], y_n = z4;
+    auto fetch = [&](long long it2) {
+        const long long m2 = it2 * TPB + tok;
+        const bool ok2 = it2 < niter && m2 < M && eok;
+        const int b2 = ok2 ? (int)(m2 / a.N) : 0, n2 = ok2 ? (int)(m2 % a.N) : 0;
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) r_n[s2] = ok2 ? ld4(a.R_in + (((long long)b2 * S + s2) * a.N + n2) * a.D + e0) : z4;
+        if (DEPTH) y_n = ok2 ? ld4bf(a.y + m2 * a.ldy + e0) : z4;
+    };
+    fetch(blockIdx.x);
     for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
         const long long m = it * TPB + tok;
         const bool valid = m < M;
@@ -137,10 +149,11 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
         const bool ld_ok = valid && eok;
         float4 r[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) r[s] = ld_ok ? ld4(a.R_in + (((long long)b * S + s) * a.N + n) * a.D + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < S; ++s) r[s] = r_n[s];
+        const float4 yv = y_n;
+        fetch(it + gridDim.x);
         if (DEPTH) {
             const float* cp = a.coef_prev + (valid ? m : 0) * C::W;
-            const float4 yv = ld_ok ? ld4bf(a.y + m * a.ldy + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o[S];
 #pragma unroll
             for (int t = 0; t < S; ++t) {
@@ -251,7 +264,10 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 
 struct HcBwdArgs {
     const float* dRn; int bcast;                         // gradient wrt the width connection's residual output: [B][S][N][D], or (bcast) [M][D] shared by all streams
-    const float* dx; long long lddx;                     // gradient wrt the branch input x (fp32)
+    const float* dx; long long lddx;                     // gradient wrt the branch input x (fp32)                      [LNF == false]
+    const bf16_t* dxn; long long lddxn;                  // gradient wrt the branch's pre-LayerNorm OUTPUT xn (bf16)     [LNF == true]
+    const bf16_t* extra; long long ldex;                 //   + gradient arriving at x directly (attention: the K/V path), or NULL
+    const float* mean; const float* rstd; const float* ln_gamma;        //   LayerNorm statistics saved by the forward, LN weight
     const float* R; const float* coef; const float* dbeta;
     HcParams hp;
     float* dR; float* partial;
@@ -262,14 +278,21 @@ struct HcBwdArgs {
 // backward: [width connection of branch k+1] -> [depth connection of branch k]
 //   WIDTH: dR_s = alpha[s][0] dx + sum_t alpha[s][t+1] dRn_t + (dynamic-coefficient / RMS-norm terms); parameter-gradient partial sums
 //   DEPTH: dy = sum_t beta_p[t] dR_t (bf16), dbeta_p[t] = <dR_t, y>      (on dRn itself when there is no width part)
-// partial row (floats): raw_a[S+1][D] | raw_b[D] | dAa[S][S+1] | dBb[S] | dsa | dsb   with raw_* = sum over tokens, streams of
+//   LNF  : the branch's pre-LayerNorm backward (audiolm_pytorch.py:191-198 autograd) is done HERE: x = sum_s alpha[s][0] R_s and
+//          xhat are recomputed in fp32 from the residual streams, dx = rstd (g - mean(g) - xhat mean(g xhat)) + extra with g = dxn * gamma,
+//          and <dx, R_s> is assembled from reduction slots (<rstd g + extra, R_s>, sum R_s, <xhat, R_s>, sum g, sum g xhat), so the
+//          whole thing still needs ONE token-wide reduction; the LN weight gradient joins the partial rows.  No fp32 dx tensor and no
+//          separate LayerNorm-backward launch exist on the 4-stream path.
+// partial row (floats): raw_a[S+1][D] | raw_b[D] | dln[D] | dAa[S][S+1] | dBb[S] | dsa | dsb   with raw_* = sum over tokens, streams of
 // nhat * (dap | dbp): dWa = (gamma+1) raw_a, dwb = (gamma+1) raw_b, dgamma = sum_t Wa raw_a + wb raw_b  (alm_hc_param_grads).
-template <int S, int WPT, bool WIDTH, bool DEPTH>
+template <int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
     constexpr int TPB = 4 / WPT;
-    constexpr int NV = (S == 4) ? 32 : 8;                        // width slots: dal[S][S+1]
+    constexpr int NV = (S == 4) ? 32 : 16;                       // width slots: dal[S][S+1] | (LNF) sum R_s [S] | <xhat, R_s> [S] | sum g | sum g xhat
     constexpr int NB = S * (S + 1);
+    constexpr int O_SR = NB, O_XR = NB + S, O_C1 = NB + 2 * S, O_C2 = NB + 2 * S + 1;
+    static_assert(O_C2 < NV, "slot budget");
     __shared__ float red[2][TPB * WPT * NV];                     // parity-double-buffered: possibly the only barrier of an iteration
     __shared__ float redd[2][TPB * WPT * 4];
     const int lane = threadIdx.x & 63;
@@ -281,11 +304,13 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     const float cD = sqrtf((float)a.D);
 
     float wa[S + 1][4], wbv[4], g1[4];
-    float rawa[S + 1][4], rawb[4];
+    float rawa[S + 1][4], rawb[4], dln[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 lng = make_float4(0.f, 0.f, 0.f, 0.f);
     float sa = 0.f, sb = 0.f;
     float accA = 0.f, accsa = 0.f, accB = 0.f, accsb = 0.f;      // lane l of the token's wave 0: slot-l scalar statistics
     if (WIDTH) {
         sa = *a.hp.sa; sb = *a.hp.sb;
+        if (LNF && eok) lng = ld4(a.ln_gamma + e0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int e = e0 + c;
@@ -298,31 +323,82 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     }
 
     const long long niter = (M + TPB - 1) / TPB;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // software pipeline: the next token's streams are requested before the current token's reduction / barrier / tanh chain starts,
+    // so every workgroup keeps two tokens' worth of loads in flight
+    float4 g_n[S], r_n[S], dx_n = z4, y_n = z4, ex_n = z4;
+    auto fetch = [&](long long it2) {
+        const long long m2 = it2 * TPB + tok;
+        const bool ok2 = it2 < niter && m2 < M && eok;
+        const int b2 = ok2 ? (int)(m2 / a.N) : 0, n2 = ok2 ? (int)(m2 % a.N) : 0;
+        if (a.bcast) {
+            const float4 gb = ok2 ? ld4(a.dRn + m2 * a.D + e0) : z4;
+#pragma unroll
+            for (int t = 0; t < S; ++t) g_n[t] = gb;
+        } else {
+#pragma unroll
+            for (int t = 0; t < S; ++t) g_n[t] = ok2 ? ld4(a.dRn + (((long long)b2 * S + t) * a.N + n2) * a.D + e0) : z4;
+        }
+        if (WIDTH) {
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) r_n[s2] = ok2 ? ld4(a.R + (((long long)b2 * S + s2) * a.N + n2) * a.D + e0) : z4;
+            if (LNF) {
+                dx_n = ok2 ? ld4bf(a.dxn + m2 * a.lddxn + e0) : z4;                   // dxn (bf16) travels in dx_n
+                ex_n = (ok2 && a.extra) ? ld4bf(a.extra + m2 * a.ldex + e0) : z4;
+            } else {
+                dx_n = ok2 ? ld4(a.dx + m2 * a.lddx + e0) : z4;
+            }
+        }
+        if (DEPTH) y_n = ok2 ? ld4bf(a.y + m2 * a.ldy + e0) : z4;
+    };
+    fetch(blockIdx.x);
     int par = 0;
     for (long long it = blockIdx.x; it < niter; it += gridDim.x, par ^= 1) {
         const long long m = it * TPB + tok;
         const bool valid = m < M;
         const int b = valid ? (int)(m / a.N) : 0, n = valid ? (int)(m % a.N) : 0;
         const bool ld_ok = valid && eok;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 g[S];
-        if (a.bcast) {
-            const float4 gb = ld_ok ? ld4(a.dRn + m * a.D + e0) : z4;
 #pragma unroll
-            for (int t = 0; t < S; ++t) g[t] = gb;
-        } else {
+        for (int t = 0; t < S; ++t) g[t] = g_n[t];
+        float4 r_c[S];
 #pragma unroll
-            for (int t = 0; t < S; ++t) g[t] = ld_ok ? ld4(a.dRn + (((long long)b * S + t) * a.N + n) * a.D + e0) : z4;
-        }
+        for (int s2 = 0; s2 < S; ++s2) r_c[s2] = r_n[s2];
+        const float4 dx_c = dx_n, yv = y_n, ex_c = ex_n;
+        fetch(it + gridDim.x);
         float4 out[S];
         if (WIDTH) {
             float4 r[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) r[s] = ld_ok ? ld4(a.R + (((long long)b * S + s) * a.N + n) * a.D + e0) : z4;
-            const float4 dxv = ld_ok ? ld4(a.dx + m * a.lddx + e0) : z4;
+            for (int s = 0; s < S; ++s) r[s] = r_c[s];
+            const float* cp = a.coef + (valid ? m : 0) * C::W;
+            float4 dxv = dx_c;
+            float4 xh = z4, gg = z4;                                        // LNF: xhat and g = dxn * gamma of this thread's 4 elements
+            float rs = 0.f;
             float v[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = 0.f;
+            if (LNF) {
+                const float mu = valid ? a.mean[m] : 0.f;
+                rs = valid ? a.rstd[m] : 0.f;
+                float4 x = z4;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float a0 = cp[C::A + s * (S + 1)];
+                    x.x += a0 * r[s].x; x.y += a0 * r[s].y; x.z += a0 * r[s].z; x.w += a0 * r[s].w;
+                }
+                xh = eok ? make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs) : z4;
+                gg = make_float4(dx_c.x * lng.x, dx_c.y * lng.y, dx_c.z * lng.z, dx_c.w * lng.w);
+                dln[0] += dx_c.x * xh.x; dln[1] += dx_c.y * xh.y; dln[2] += dx_c.z * xh.z; dln[3] += dx_c.w * xh.w;
+                dxv = make_float4(rs * gg.x + ex_c.x, rs * gg.y + ex_c.y, rs * gg.z + ex_c.z, rs * gg.w + ex_c.w);      // u = rstd g + extra
+                v[O_C1] = gg.x + gg.y + gg.z + gg.w;
+                v[O_C2] = gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    v[O_SR + s] = r[s].x + r[s].y + r[s].z + r[s].w;
+                    v[O_XR + s] = xh.x * r[s].x + xh.y * r[s].y + xh.z * r[s].z + xh.w * r[s].w;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 v[s * (S + 1)] = dxv.x * r[s].x + dxv.y * r[s].y + dxv.z * r[s].z + dxv.w * r[s].w;
@@ -331,9 +407,17 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             }
             float da = bfly<NV>(v, lane);
             da = token_combine<WPT, NV>(da, red[par], tok, wv, lane);
+            if (LNF) {
+                // <dx, R_s> = <u, R_s> - rstd mean(g) sum R_s - rstd mean(g xhat) <xhat, R_s>; then the per-element dx itself
+                const float invD = 1.f / (float)a.D;
+                const float c1 = lane_bcast(da, O_C1) * invD, c2 = lane_bcast(da, O_C2) * invD;
+                const int sl0 = (lane < NB) ? lane / (S + 1) : 0;
+                const float sr = __shfl(da, O_SR + sl0, 64), xr = __shfl(da, O_XR + sl0, 64);
+                if (lane < NB && lane % (S + 1) == 0) da -= rs * (c1 * sr + c2 * xr);
+                dxv = make_float4(rs * (gg.x - c1 - xh.x * c2) + ex_c.x, rs * (gg.y - c1 - xh.y * c2) + ex_c.y,
+                                  rs * (gg.z - c1 - xh.z * c2) + ex_c.z, rs * (gg.w - c1 - xh.w * c2) + ex_c.w);
+            }
             // lane l < NB: slot (s, t) = (l / (S+1), l % (S+1)); lanes NB .. NB+S-1: the beta path of stream l - NB
-            const float* cp = a.coef + (valid ? m : 0) * C::W;
-            const int l = lane & (NV - 1);
             const bool is_a = lane < NB, is_b = lane >= NB && lane < NB + S;
             const int sl = is_a ? lane / (S + 1) : (is_b ? lane - NB : 0);
             float pre = 0.f, up = 0.f;                                   // pre-activation and upstream gradient of this lane's coefficient
@@ -341,7 +425,6 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 if (is_a) { pre = cp[C::AP + lane]; up = da; }
                 else if (is_b) { pre = cp[C::BP + sl]; up = a.dbeta[m * S + sl]; }
             }
-            (void)l;
             const float th = tanhf(pre);
             const float dpre = up * (is_a ? sa : sb) * (1.f - th * th);     // dap[s][t] (lanes < NB) | dbp[s] (lanes NB..)
             if (wv == 0) {
@@ -393,7 +476,6 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         }
         if (DEPTH) {
             const float* cq = a.coef_prev + (valid ? m : 0) * C::W;
-            const float4 yv = ld_ok ? ld4bf(a.y + m * a.ldy + e0) : z4;
             float4 o = z4;
             float v4[4];
 #pragma unroll
@@ -420,15 +502,16 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
 
     if (!WIDTH) return;
     // per-(block, token slot) partial rows; the token's WPT waves own disjoint element ranges
-    const int P = a.D * (S + 2) + NB + S + 2;
+    const int P = a.D * (S + 3) + NB + S + 2;
     float* prow = a.partial + ((long long)blockIdx.x * TPB + tok) * P;
     if (eok) {
 #pragma unroll
         for (int t = 0; t < S + 1; ++t) *reinterpret_cast<float4*>(prow + (long long)t * a.D + e0) = make_float4(rawa[t][0], rawa[t][1], rawa[t][2], rawa[t][3]);
         *reinterpret_cast<float4*>(prow + (long long)(S + 1) * a.D + e0) = make_float4(rawb[0], rawb[1], rawb[2], rawb[3]);
+        *reinterpret_cast<float4*>(prow + (long long)(S + 2) * a.D + e0) = make_float4(dln[0], dln[1], dln[2], dln[3]);
     }
     if (wv == 0) {
-        float* q = prow + (long long)a.D * (S + 2);
+        float* q = prow + (long long)a.D * (S + 3);
         if (lane < NB) q[lane] = accA;
         if (lane >= NB && lane < NB + S) q[lane] = accB;
         const float tsa = wave_sum(accsa), tsb = wave_sum(accsb);
@@ -436,8 +519,8 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     }
 }
 
-// second stage of the hyper-connection parameter gradients: column sums of the partial rows (alm_colsum) -> the 7 gradients,
-// out layout (floats): dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb
+// second stage of the hyper-connection parameter gradients: column sums of the partial rows (alm_colsum) -> the gradients,
+// out layout (floats): dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D] (LayerNorm weight, fused-LN mode)
 template <int S>
 __global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __restrict__ sums, HcParams hp, float* __restrict__ out, int D) {
     constexpr int NB = S * (S + 1);
@@ -453,8 +536,9 @@ __global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __rest
         }
         out[(long long)D * (S + 1) + e] = g1 * sums[(long long)(S + 1) * D + e];
         out[(long long)D * (S + 2) + e] = dg;
+        out[(long long)D * (S + 3) + NB + S + 2 + e] = sums[(long long)(S + 2) * D + e];
     }
-    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums[(long long)D * (S + 2) + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums[(long long)D * (S + 3) + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -518,20 +602,38 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
     }
 }
 
-int hc_grid(long long M, int tpb, int blocks_per_cu) {
+// grid-stride kernels with ~10-30 tokens per workgroup: the grid must be EXACTLY the resident workgroup count (CUs x occupancy),
+// otherwise the surplus workgroups form a second, partly empty round (measured: 1.5 rounds at 768 blocks vs 512 resident)
+template <typename K>
+int resident_blocks(K kernel) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 2;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return occ * cus;
+}
+int hc_grid(long long M, int tpb, int resident) {
     const long long niter = (M + tpb - 1) / tpb;
-    const long long cap = 256LL * blocks_per_cu;
-    return (int)(niter < cap ? niter : cap);
+    return (int)(niter < resident ? niter : resident);
 }
 int hc_wpt(int D) { return D <= 256 ? 1 : (D <= 512 ? 2 : 4); }
 
+template <int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
+void launch_fwd_w(const HcFwdArgs& a, hipStream_t st) {
+    static int resident = 0;                                   // idempotent lazy query (same value from every thread)
+    auto k = hc_fwd_kernel<S, WPT, DEPTH, WIDTH, FINAL>;
+    if (!resident) resident = resident_blocks(k);
+    hipLaunchKernelGGL(k, dim3(hc_grid((long long)a.B * a.N, 4 / WPT, resident)), dim3(256), 0, st, a);
+}
 template <int S, bool DEPTH, bool WIDTH, bool FINAL>
 int launch_fwd(const HcFwdArgs& a, hipStream_t st) {
     const int wpt = hc_wpt(a.D);
-    const int grid = hc_grid((long long)a.B * a.N, 4 / wpt, 5);
-    if (wpt == 1) hipLaunchKernelGGL((hc_fwd_kernel<S, 1, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
-    else if (wpt == 2) hipLaunchKernelGGL((hc_fwd_kernel<S, 2, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((hc_fwd_kernel<S, 4, DEPTH, WIDTH, FINAL>), dim3(grid), dim3(256), 0, st, a);
+    if (wpt == 1) launch_fwd_w<S, 1, DEPTH, WIDTH, FINAL>(a, st);
+    else if (wpt == 2) launch_fwd_w<S, 2, DEPTH, WIDTH, FINAL>(a, st);
+    else launch_fwd_w<S, 4, DEPTH, WIDTH, FINAL>(a, st);
     return 0;
 }
 template <int S>
@@ -545,23 +647,46 @@ int dispatch_fwd(const HcFwdArgs& a, int mode, hipStream_t st) {
     }
 }
 
-int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 3); }
+// upper bound of the workgroup count of the backward kernel (sizes the partial-row buffer; the launch may use fewer)
+int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 256 * 4); }
 
-template <int S, bool WIDTH, bool DEPTH>
+template <int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
+int bwd_grid_w(long long M, int D) {
+    static int resident = 0;
+    if (!resident) resident = resident_blocks(hc_bwd_kernel<S, WPT, WIDTH, DEPTH, LNF>);
+    const int cap = hc_bwd_blocks(M, D);
+    const int grid = hc_grid(M, 4 / WPT, resident);
+    return grid > cap ? cap : grid;
+}
+template <int S, bool WIDTH, bool DEPTH, bool LNF>
+int bwd_grid(long long M, int D) {
+    const int wpt = hc_wpt(D);
+    if (wpt == 1) return bwd_grid_w<S, 1, WIDTH, DEPTH, LNF>(M, D);
+    if (wpt == 2) return bwd_grid_w<S, 2, WIDTH, DEPTH, LNF>(M, D);
+    return bwd_grid_w<S, 4, WIDTH, DEPTH, LNF>(M, D);
+}
+template <int S, bool WIDTH, bool DEPTH, bool LNF>
 int launch_bwd(const HcBwdArgs& a, hipStream_t st) {
     const int wpt = hc_wpt(a.D);
-    const int grid = hc_bwd_blocks((long long)a.B * a.N, a.D);
-    if (wpt == 1) hipLaunchKernelGGL((hc_bwd_kernel<S, 1, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
-    else if (wpt == 2) hipLaunchKernelGGL((hc_bwd_kernel<S, 2, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((hc_bwd_kernel<S, 4, WIDTH, DEPTH>), dim3(grid), dim3(256), 0, st, a);
+    const int grid = bwd_grid<S, WIDTH, DEPTH, LNF>((long long)a.B * a.N, a.D);
+    if (wpt == 1) hipLaunchKernelGGL((hc_bwd_kernel<S, 1, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
+    else if (wpt == 2) hipLaunchKernelGGL((hc_bwd_kernel<S, 2, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((hc_bwd_kernel<S, 4, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
     return 0;
 }
 template <int S>
-int dispatch_bwd(const HcBwdArgs& a, int mode, hipStream_t st) {
+int bwd_rows(int mode, bool lnf, long long M, int D) {
+    const int tpb = 4 / hc_wpt(D);
+    if (mode == 2) return tpb * (lnf ? bwd_grid<S, true, false, true>(M, D) : bwd_grid<S, true, false, false>(M, D));
+    if (mode == 3) return tpb * (lnf ? bwd_grid<S, true, true, true>(M, D) : bwd_grid<S, true, true, false>(M, D));
+    return 0;
+}
+template <int S>
+int dispatch_bwd(const HcBwdArgs& a, int mode, bool lnf, hipStream_t st) {
     switch (mode) {
-        case 1: return launch_bwd<S, false, true>(a, st);
-        case 2: return launch_bwd<S, true, false>(a, st);
-        case 3: return launch_bwd<S, true, true>(a, st);
+        case 1: return launch_bwd<S, false, true, false>(a, st);
+        case 2: return lnf ? launch_bwd<S, true, false, true>(a, st) : launch_bwd<S, true, false, false>(a, st);
+        case 3: return lnf ? launch_bwd<S, true, true, true>(a, st) : launch_bwd<S, true, true, false>(a, st);
         default: return ALM_ERR_BAD_ARG;
     }
 }
@@ -569,10 +694,14 @@ int dispatch_bwd(const HcBwdArgs& a, int mode, hipStream_t st) {
 }  // namespace
 
 extern "C" int alm_hc_coef_width(int S) { return 2 * S * (S + 1) + 3 * S; }
-extern "C" int alm_hc_partial_width(int S, int D) { return D * (S + 2) + S * (S + 1) + S + 2; }
-extern "C" int alm_hc_grads_width(int S, int D) { return D * (S + 3) + S * (S + 1) + S + 2; }
-/* number of partial rows alm_hc_bwd writes (one per workgroup and token slot) */
-extern "C" int alm_hc_partial_rows(long long tokens, int D) { return hc_bwd_blocks(tokens, D) * (4 / hc_wpt(D)); }
+extern "C" int alm_hc_partial_width(int S, int D) { return D * (S + 3) + S * (S + 1) + S + 2; }
+extern "C" int alm_hc_grads_width(int S, int D) { return D * (S + 4) + S * (S + 1) + S + 2; }
+/* number of partial rows alm_hc_bwd writes for (mode, fused-LayerNorm or not): one per RESIDENT workgroup and token slot */
+extern "C" int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D) {
+    if (S == 2) return bwd_rows<2>(mode, fused_ln != 0, tokens, D);
+    if (S == 4) return bwd_rows<4>(mode, fused_ln != 0, tokens, D);
+    return 0;
+}
 
 // mode: 1 = depth connection only (-> R_out), 2 = width connection only, 3 = depth (previous branch) + width (next branch) fused,
 //       5 = depth + stream sum + final LayerNorm (-> xs_out fp32, xn_out bf16, mean, rstd; R_out is not written)
@@ -599,18 +728,22 @@ extern "C" int alm_hc_fwd(const float* R_in, const void* y_prev, long long ldy, 
 //       3 = width backward of branch k+1 followed by the depth backward of branch k on the freshly computed dR.
 // dRn_bcast != 0: dRn is [B*N][D] and stands for all S streams (the gradient of the final stream sum, audiolm_pytorch.py:551).
 // partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads.
-extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const float* R, const float* coef,
+extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn, long long lddxn, const void* extra,
+                          long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, const float* coef,
                           const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb,
                           float* dR, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
                           float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
-    if ((D & 3) || D > 1024 || (lddx & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
-    if ((mode & 2) && (!dx || !R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !dR || !partial)) return ALM_ERR_BAD_ARG;
+    if ((D & 3) || D > 1024 || (lddx & 3) || (lddxn & 3) || (ldex & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
+    const bool lnf = dxn != nullptr;
+    if ((mode & 2) && (!R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !dR || !partial)) return ALM_ERR_BAD_ARG;
+    if ((mode & 2) && (lnf ? (!mean || !rstd || !ln_gamma || dx != nullptr) : !dx)) return ALM_ERR_BAD_ARG;
     if ((mode & 1) && (!y_prev || !coef_prev || !dy || !dbeta_out)) return ALM_ERR_BAD_ARG;
-    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, R, coef, dbeta, HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, partial,
-                (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out, B, N, D};
+    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, (const bf16_t*)dxn, lddxn, (const bf16_t*)extra, ldex, mean, rstd, ln_gamma, R, coef, dbeta,
+                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, partial, (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out,
+                B, N, D};
     int rc;
-    if (S == 2) rc = dispatch_bwd<2>(a, mode, (hipStream_t)stream);
-    else if (S == 4) rc = dispatch_bwd<4>(a, mode, (hipStream_t)stream);
+    if (S == 2) rc = dispatch_bwd<2>(a, mode, lnf, (hipStream_t)stream);
+    else if (S == 4) rc = dispatch_bwd<4>(a, mode, lnf, (hipStream_t)stream);
     else return ALM_ERR_UNSUPPORTED;
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
@@ -618,7 +751,7 @@ extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long
 }
 
 // sums: column sums (alm_colsum) of the partial rows.  out: alm_hc_grads_width(S, D) floats:
-// dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb
+// dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]
 extern "C" int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D,
                                   void* stream) {
     HcParams hp{hc_gamma, Wa, nullptr, nullptr, wb, nullptr, nullptr};

@@ -117,6 +117,17 @@ def pack_weight(w, dst=None, dstT=None, rows_pad=None, cols_pad=None):
               _p(dstT), dstT.stride(0) if dstT is not None else 0, _st())
 
 
+def pack_weights_multi(jobs):
+    """jobs: list of (w fp32 [rows, cols] view, dst | None, dstT | None, rows_pad, cols_pad): up to 8 weights in one launch."""
+    arr = (_lib.AlmPackJob * len(jobs))()
+    for i, (w, dst, dstT, rp, cp) in enumerate(jobs):
+        _chk(w, F32)
+        rows, cols, ld = _rows_ld(w)
+        arr[i] = _lib.AlmPackJob(w.data_ptr(), rows, cols, ld, _p(dst), dst.stride(0) if dst is not None else 0, rp, cp,
+                                 _p(dstT), dstT.stride(0) if dstT is not None else 0)
+    _lib.call('alm_pack_weights_multi', ctypes.cast(arr, ctypes.c_void_p), len(jobs), _st())
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
 
 def layernorm_fwd(x, gamma, *, want_copy=False):
@@ -256,9 +267,12 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
     return out
 
 
-def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, R=None, coef=None, dbeta=None, hc=None, y_prev=None, coef_prev=None):
+def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=None, rstd=None, ln_gamma=None, R=None, coef=None, dbeta=None,
+           hc=None, y_prev=None, coef_prev=None):
     """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D], or with
-    bcast [B*N, D] shared by all streams.  dx / R / coef / dbeta / hc given: width-connection backward -> dR + the 7 parameter gradients.
+    bcast [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
+    gradient wrt the branch input is either `dx` (fp32, LayerNorm backward already applied) or `dxn` (bf16, wrt the LayerNorm output) +
+    optional `extra` (bf16, added to dx) + mean / rstd / ln_gamma: then the LayerNorm backward is fused (grads['ln'] = its weight gradient).
     y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
     -> dict(dR, grads, dy, dbeta)."""
     width, depth = hc is not None, y_prev is not None
@@ -266,16 +280,19 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, R=None, coef=None, dbeta=No
     dev, M = dRn.device, B * N
     dR = part = dy = dbo = None
     if width:
+        assert (dx is None) != (dxn is None)
         dR = torch.empty((B, S, N, D), dtype=F32, device=dev)
-        rows = _lib.query('alm_hc_partial_rows', M, D)
+        rows = _lib.query('alm_hc_partial_rows', mode, int(dxn is not None), S, M, D)
         P = _lib.query('alm_hc_partial_width', S, D)
         part = torch.empty((rows, P), dtype=F32, device=dev)
     if depth:
         dy = torch.empty((M, D), dtype=BF16, device=dev)
         dbo = torch.empty((M, S), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
-    _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), _p(dx), dx.stride(0) if width else 0, _p(R), _p(coef), _p(dbeta), *hp, _p(dR), _p(part),
-              _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo), mode, B, S, N, D, _st())
+    _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
+              dxn.stride(0) if dxn is not None else 0, _p(extra), extra.stride(0) if extra is not None else 0, _p(mean), _p(rstd), _p(ln_gamma),
+              _p(R), _p(coef), _p(dbeta), *hp, _p(dR), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
+              mode, B, S, N, D, _st())
     grads = None
     if width:
         sums = colsum(part)
@@ -283,7 +300,7 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, R=None, coef=None, dbeta=No
         _lib.call('alm_hc_param_grads', sums.data_ptr(), hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['wb'].data_ptr(), g.data_ptr(), S, D, _st())
         o = 0
         grads = {}
-        for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ())):
+        for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ()), ('ln', (D,))):
             n = 1
             for d in shape:
                 n *= d

@@ -178,11 +178,14 @@ def main():
             events.append((e0, e1, 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2], 'tn'))
             return out
         ops.gemm_nt, ops.gemm_tn_splitk = timed_nt, timed_tn
+        import audiolm_pytorch_amd.core as core_mod
+        was_async, core_mod.ASYNC_WGRAD = core_mod.ASYNC_WGRAD, False      # per-kernel durations: no concurrent side-stream GEMMs in this step
         try:
             step()
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
+            core_mod.ASYNC_WGRAD = was_async
         agg = {}
         for e0, e1, fl, kind in events:
             a = agg.setdefault(kind, [0.0, 0.0, 0])

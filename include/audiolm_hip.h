@@ -41,6 +41,9 @@ int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bi
  *         dW[out][in] = sum_tokens dY[token][out] * X[token][in], the wgrad of every nn.Linear on the path
  *         (autograd of audiolm_pytorch.py:255-259, :351, :395, :961, :972) with no transposed copies; lda/ldb % 8 == 0. */
 int alm_gemm_splitk_slices(int M, int N, int K, int nb);
+/* tuning hook for benchmarks (process-global, not thread-safe; 0 = automatic): force the split-K tile (1 = 128x128, 2 = 256x256) and
+ * slice count; raster 0 = plain grid, 1 = XCD-panel rasterisation of split-K launches (default) */
+int alm_debug_splitk(int tile, int slices, int raster);
 int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
@@ -51,6 +54,14 @@ int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long
  * This is the autocast weight cast of trainer.py:1241 (accelerator.autocast), done once per optimiser step. */
 int alm_pack_weight(const float* src, int rows, int cols, long long ld_src, void* dst, long long ld_dst, int rows_pad, int cols_pad,
                     void* dstT, long long ld_dstT, void* stream);
+
+/* the same for up to 8 weights in ONE launch (a transformer layer's q / kv / out / W1 x-half / W1 gate-half / W2) */
+typedef struct {
+    const float* src; int rows, cols; long long ld_src;
+    void* dst; long long ld_dst; int rows_pad, cols_pad;
+    void* dstT; long long ld_dstT;
+} AlmPackJob;
+int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream);
 
 /* ---- LayerNorm (gamma only, eps 1e-5): audiolm_pytorch.py:191-198 ---------------------------------------------------------- */
 int alm_ln_partial_blocks(int rows);
@@ -93,7 +104,7 @@ int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts,
 int alm_hc_coef_width(int S);
 int alm_hc_partial_width(int S, int D);
 int alm_hc_grads_width(int S, int D);
-int alm_hc_partial_rows(long long tokens, int D);
+int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D);
 /* forward.  mode 1: depth connection only, R_out[t] = sum_s alpha[s][t+1] R_in[s] + beta[t] y_prev (coef_prev = that branch's record);
  * mode 2: width connection of a branch (its 7 parameters) + the branch's pre-LayerNorm: x, xn = LN(x) ln_gamma, mean, rstd, coef;
  * mode 3: mode 1 of the previous branch fused with mode 2 of the next one on the freshly computed residual (one pass over R);
@@ -105,12 +116,17 @@ int alm_hc_fwd(const float* R_in, const void* y_prev_bf16, long long ldy, const 
 /* backward.  mode 2: width-connection backward (dR, parameter-gradient partial rows); mode 1: depth-connection backward
  * (dy = sum_t beta[t] dRn[t], dbeta_out[t] = <dRn[t], y>); mode 3: mode 2 of branch k+1 fused with mode 1 of branch k on the
  * freshly computed dR.  dRn_bcast: dRn is [B*N][D] and stands for all S streams (gradient of the final stream sum).
- * partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose output is
- * dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb  (alm_hc_grads_width(S, D) floats). */
-int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const float* R, const float* coef, const float* dbeta,
-               const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR, float* partial,
-               const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out, int mode,
-               int B, int S, int N, int D, void* stream);
+ * The gradient wrt the branch input comes either as dx (fp32 [B*N][lddx], already through the branch's LayerNorm backward) or -- fused
+ * mode, dx == NULL -- as dxn (bf16, gradient wrt the LayerNorm OUTPUT) + optional extra (bf16, added to dx directly: the K/V path of
+ * the attention branch) + the LayerNorm statistics / weight: the LayerNorm backward (audiolm_pytorch.py:191-198 autograd) then happens
+ * inside this kernel and its weight gradient joins the outputs.
+ * partial: [alm_hc_partial_rows(mode, dx == NULL, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose output is
+ * dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]  (alm_hc_grads_width(S, D) floats). */
+int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn_bf16, long long lddxn, const void* extra_bf16,
+               long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, const float* coef,
+               const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR,
+               float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out,
+               int mode, int B, int S, int N, int D, void* stream);
 int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
 int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */

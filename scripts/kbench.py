@@ -74,6 +74,24 @@ def bench_gemm():
               f'slices {_lib.query("alm_gemm_splitk_slices", M, N, K, 1)})', flush=True)
 
 
+def bench_tn():
+    """split-K plan / rasterisation sweep for the two big weight-gradient shapes (tuning hook alm_debug_splitk)."""
+    T, I, Ip, D = 16384, 2730, 2736, 1024
+    dU, XN2 = rnd(T, 2 * Ip), rnd(T, D)
+    dW1 = torch.empty((2, I, D), dtype=F32, device=dev)
+    dY2, HN = rnd(T, D), rnd(T, Ip)
+    dW2 = torch.empty((D, I), dtype=F32, device=dev)
+    f1 = lambda: ops.gemm_tn_splitk(dU.view(T, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2, dW1)
+    f2 = lambda: ops.gemm_tn_splitk(dY2, HN[:, :I], dW2)
+    fl1, fl2 = 2.0 * 2 * I * D * T, 2.0 * D * I * T
+    for raster in (0, 1):
+        for tile, sl in [(0, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (2, 6), (2, 8), (1, 2), (1, 4), (1, 8)]:
+            _lib.call('alm_debug_splitk', tile, sl, raster)
+            t1, t2 = timeit(f1, iters=10), timeit(f2, iters=10)
+            print(f'raster {raster} tile {tile} slices {sl}:  dW1(batched x2) {t1:.3f} ms {fl1 / t1 / 1e9:5.0f} TF | dW2 {t2:.3f} ms {fl2 / t2 / 1e9:5.0f} TF', flush=True)
+    _lib.call('alm_debug_splitk', 0, 0, 1)
+
+
 def bench_attn():
     B, N, H, dh = 8, 2048, 8, 64
     M = B * N

@@ -40,8 +40,8 @@ def test_header_argument_counts_match_binding():
 
 def test_size_queries_run_on_host():
     assert _lib.query('alm_hc_coef_width', 4) == 52
-    assert _lib.query('alm_hc_partial_width', 4, 1024) == 1024 * 6 + 26
-    assert _lib.query('alm_hc_grads_width', 4, 1024) == 1024 * 7 + 26
+    assert _lib.query('alm_hc_partial_width', 4, 1024) == 1024 * 7 + 26
+    assert _lib.query('alm_hc_grads_width', 4, 1024) == 1024 * 8 + 26
     assert _lib.query('alm_ln_partial_blocks', 16384) == 512
 
 
