@@ -131,27 +131,33 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 
     const long long niter = (M + TPB - 1) / TPB;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // software pipeline: the next token's streams are requested before the current token's reduction / barrier / tanh chain starts
-    float4 r_n[S], y_n = z4;
-    auto fetch = [&](long long it2) {
-        const long long m2 = it2 * TPB + tok;
-        const bool ok2 = it2 < niter && m2 < M && eok;
-        const int b2 = ok2 ? (int)(m2 / a.N) : 0, n2 = ok2 ? (int)(m2 % a.N) : 0;
-#pragma unroll
-        for (int s2 = 0; s2 < S; ++s2) r_n[s2] = ok2 ? ld4(a.R_in + (((long long)b2 * S + s2) * a.N + n2) * a.D + e0) : z4;
-        if (DEPTH) y_n = ok2 ? ld4bf(a.y + m2 * a.ldy + e0) : z4;
-    };
-    fetch(blockIdx.x);
+    const long long sND = (long long)a.N * a.D;                              // stream stride of R
+    // token coordinates (b, n) advance incrementally: no 64-bit divisions in the loop; `valid` is wave-uniform, so the loads sit in ONE
+    // uniform branch instead of an exec-masked region each
+    unsigned bb, nn;
+    {
+        const unsigned m0 = (unsigned)(blockIdx.x * TPB + tok);
+        bb = m0 / (unsigned)a.N;
+        nn = m0 % (unsigned)a.N;
+    }
+    const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
     for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
         const long long m = it * TPB + tok;
         const bool valid = m < M;
-        const int b = valid ? (int)(m / a.N) : 0, n = valid ? (int)(m % a.N) : 0;
+        const int b = (int)bb, n = (int)nn;
+        bb += sbb; nn += snn;
+        if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
         const bool ld_ok = valid && eok;
         float4 r[S];
+        float4 yv = z4;
 #pragma unroll
-        for (int s = 0; s < S; ++s) r[s] = r_n[s];
-        const float4 yv = y_n;
-        fetch(it + gridDim.x);
+        for (int s = 0; s < S; ++s) r[s] = z4;
+        if (ld_ok) {
+            const float* Rt = a.R_in + ((long long)b * S * a.N + n) * a.D + e0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) r[s] = ld4(Rt + s * sND);
+            if (DEPTH) yv = ld4bf(a.y + m * a.ldy + e0);
+        }
         if (DEPTH) {
             const float* cp = a.coef_prev + (valid ? m : 0) * C::W;
             float4 o[S];
@@ -324,48 +330,48 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
 
     const long long niter = (M + TPB - 1) / TPB;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // software pipeline: the next token's streams are requested before the current token's reduction / barrier / tanh chain starts,
-    // so every workgroup keeps two tokens' worth of loads in flight
-    float4 g_n[S], r_n[S], dx_n = z4, y_n = z4, ex_n = z4;
-    auto fetch = [&](long long it2) {
-        const long long m2 = it2 * TPB + tok;
-        const bool ok2 = it2 < niter && m2 < M && eok;
-        const int b2 = ok2 ? (int)(m2 / a.N) : 0, n2 = ok2 ? (int)(m2 % a.N) : 0;
-        if (a.bcast) {
-            const float4 gb = ok2 ? ld4(a.dRn + m2 * a.D + e0) : z4;
-#pragma unroll
-            for (int t = 0; t < S; ++t) g_n[t] = gb;
-        } else {
-#pragma unroll
-            for (int t = 0; t < S; ++t) g_n[t] = ok2 ? ld4(a.dRn + (((long long)b2 * S + t) * a.N + n2) * a.D + e0) : z4;
-        }
-        if (WIDTH) {
-#pragma unroll
-            for (int s2 = 0; s2 < S; ++s2) r_n[s2] = ok2 ? ld4(a.R + (((long long)b2 * S + s2) * a.N + n2) * a.D + e0) : z4;
-            if (LNF) {
-                dx_n = ok2 ? ld4bf(a.dxn + m2 * a.lddxn + e0) : z4;                   // dxn (bf16) travels in dx_n
-                ex_n = (ok2 && a.extra) ? ld4bf(a.extra + m2 * a.ldex + e0) : z4;
-            } else {
-                dx_n = ok2 ? ld4(a.dx + m2 * a.lddx + e0) : z4;
-            }
-        }
-        if (DEPTH) y_n = ok2 ? ld4bf(a.y + m2 * a.ldy + e0) : z4;
-    };
-    fetch(blockIdx.x);
+    const long long sND = (long long)a.N * a.D;
+    unsigned bb, nn;                                                         // incremental token coordinates (see hc_fwd_kernel)
+    {
+        const unsigned m0 = (unsigned)(blockIdx.x * TPB + tok);
+        bb = m0 / (unsigned)a.N;
+        nn = m0 % (unsigned)a.N;
+    }
+    const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
     int par = 0;
     for (long long it = blockIdx.x; it < niter; it += gridDim.x, par ^= 1) {
         const long long m = it * TPB + tok;
         const bool valid = m < M;
-        const int b = valid ? (int)(m / a.N) : 0, n = valid ? (int)(m % a.N) : 0;
+        const int b = (int)bb, n = (int)nn;
+        bb += sbb; nn += snn;
+        if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
         const bool ld_ok = valid && eok;
-        float4 g[S];
+        float4 g[S], r_c[S];
+        float4 dx_c = z4, yv = z4, ex_c = z4;
 #pragma unroll
-        for (int t = 0; t < S; ++t) g[t] = g_n[t];
-        float4 r_c[S];
+        for (int t = 0; t < S; ++t) { g[t] = z4; r_c[t] = z4; }
+        if (ld_ok) {
+            const long long tofs = ((long long)b * S * a.N + n) * a.D + e0;
+            if (a.bcast) {
+                const float4 gb = ld4(a.dRn + m * a.D + e0);
 #pragma unroll
-        for (int s2 = 0; s2 < S; ++s2) r_c[s2] = r_n[s2];
-        const float4 dx_c = dx_n, yv = y_n, ex_c = ex_n;
-        fetch(it + gridDim.x);
+                for (int t = 0; t < S; ++t) g[t] = gb;
+            } else {
+#pragma unroll
+                for (int t = 0; t < S; ++t) g[t] = ld4(a.dRn + tofs + t * sND);
+            }
+            if (WIDTH) {
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld4(a.R + tofs + s2 * sND);
+                if (LNF) {
+                    dx_c = ld4bf(a.dxn + m * a.lddxn + e0);                      // dxn (bf16) travels in dx_c
+                    if (a.extra) ex_c = ld4bf(a.extra + m * a.ldex + e0);
+                } else {
+                    dx_c = ld4(a.dx + m * a.lddx + e0);
+                }
+            }
+            if (DEPTH) yv = ld4bf(a.y + m * a.ldy + e0);
+        }
         float4 out[S];
         if (WIDTH) {
             float4 r[S];
