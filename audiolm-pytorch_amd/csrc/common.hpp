@@ -66,6 +66,18 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Gaussian cdf / pdf pair for GELU with ONE exponential (Abramowitz & Stegun 7.1.26: |erf error| < 1.5e-7, far below the bf16 / fp32
+// statistics tolerances of the callers): cdf = 0.5 (1 + erf(v / sqrt 2)), pdf = exp(-v^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ void gauss_cdf_pdf(float v, float& cdf, float& pdf) {
+    const float ax = fabsf(v) * 0.70710678118654752f;
+    const float ex = __expf(-ax * ax);                                    // = exp(-v^2 / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, ex, 1.f);
+    cdf = 0.5f * (1.f + copysignf(erf_abs, v));
+    pdf = 0.3989422804014327f * ex;
+}
+
 // bijective XCD-aware block remap (block b runs on XCD b % 8): gives every XCD a contiguous chunk of the
 // logical grid so that neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -159,24 +159,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, l
 // fused GEGLU + LayerNorm(inner) forward.  u: [rows][ldu] bf16, x half at cols [0, I), gate half at [goff, goff + I).
 // h = gelu(gate) * x ; out = LN(h) * gamma (bf16, cols [I, Ipad) zero-filled).
 // ------------------------------------------------------------------------------------------------------------------
+// component c of a float4 (indexing through `&v.x` is undefined behaviour and was observed to drop the 4th component)
+__device__ __forceinline__ float& f4e(float4& v, int c) { return reinterpret_cast<float*>(&v)[c]; }
+__device__ __forceinline__ float f4e(const float4& v, int c) { return reinterpret_cast<const float*>(&v)[c]; }
+
 constexpr int GE_MAX = 3;    // 4-wide vectors per thread: supports padded inner widths up to 3 * 256 * 4 = 3072
 
+// block-wide sum of one or two values with ONE barrier: the scratch is parity-double-buffered by the caller, so the previous
+// reduction's readers never race with this one's writers
 __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
+__device__ __forceinline__ void block_sum256x2(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+}
 
 // 8-byte (4 x bf16) accesses: u rows are 16-B aligned (ldu = 2 * Ipad, Ipad % 8 == 0) and the pad columns [I, Ipad) of both halves
 // hold zeros (the packed W1 has zero rows there), so whole vectors can be loaded up to Ipad; statistics only count e < I.
+// GELU = v * Phi(v) with the exact-erf definition of F.gelu (reference audiolm_pytorch.py:246-249), Phi from gauss_cdf_pdf.
 __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restrict__ u, long long ldu, int goff, const float* __restrict__ gamma,
                                                            bf16_t* __restrict__ out, long long ldo, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out, int rows, int I, int Ipad) {
-    __shared__ float red[4];
+    __shared__ float red[4][4];                                  // 2 reductions per row x parity
     const int t = threadIdx.x;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    float4 gam[GE_MAX];
+#pragma unroll
+    for (int j = 0; j < GE_MAX; ++j) {
+        const int e = (t + 256 * j) * 4;
+        gam[j] = make_float4(e < I ? gamma[e] : 0.f, e + 1 < I ? gamma[e + 1] : 0.f, e + 2 < I ? gamma[e + 2] : 0.f, e + 3 < I ? gamma[e + 3] : 0.f);
+    }
+    int par = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 2) {
         float4 h[GE_MAX];
         float s = 0.f;
 #pragma unroll
@@ -186,12 +207,16 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
             if (e < Ipad) {
                 const float4 xv = load4(u + (long long)row * ldu + e);
                 const float4 gv = load4(u + (long long)row * ldu + goff + e);
-                h[j] = make_float4(e < I ? gelu_f(gv.x) * xv.x : 0.f, e + 1 < I ? gelu_f(gv.y) * xv.y : 0.f,
-                                   e + 2 < I ? gelu_f(gv.z) * xv.z : 0.f, e + 3 < I ? gelu_f(gv.w) * xv.w : 0.f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float cdf, pdf;
+                    gauss_cdf_pdf(f4e(gv, c), cdf, pdf);
+                    f4e(h[j], c) = (e + c < I) ? f4e(gv, c) * cdf * f4e(xv, c) : 0.f;
+                }
                 s += h[j].x + h[j].y + h[j].z + h[j].w;
             }
         }
-        const float mean = block_sum256(s, red) / (float)I;
+        const float mean = block_sum256(s, red[par]) / (float)I;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
@@ -201,16 +226,16 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
                 q += a * a + (e + 1 < I ? b * b : 0.f) + (e + 2 < I ? c * c : 0.f) + (e + 3 < I ? d * d : 0.f);
             }
         }
-        const float rstd = rsqrtf(block_sum256(q, red) / (float)I + LN_EPS);
+        const float rstd = rsqrtf(block_sum256(q, red[par + 1]) / (float)I + LN_EPS);
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
             const int e = (t + 256 * j) * 4;
             if (e < Ipad) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < I) o.x = (h[j].x - mean) * rstd * gamma[e];
-                if (e + 1 < I) o.y = (h[j].y - mean) * rstd * gamma[e + 1];
-                if (e + 2 < I) o.z = (h[j].z - mean) * rstd * gamma[e + 2];
-                if (e + 3 < I) o.w = (h[j].w - mean) * rstd * gamma[e + 3];
+                float4 o;
+                o.x = (e < I) ? (h[j].x - mean) * rstd * gam[j].x : 0.f;
+                o.y = (e + 1 < I) ? (h[j].y - mean) * rstd * gam[j].y : 0.f;
+                o.z = (e + 2 < I) ? (h[j].z - mean) * rstd * gam[j].z : 0.f;
+                o.w = (e + 3 < I) ? (h[j].w - mean) * rstd * gam[j].w : 0.f;
                 store4(out + (long long)row * ldo + e, o);
             }
         }
@@ -222,12 +247,13 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
 }
 
 // backward: dhn = grad wrt LN output (bf16 [rows][lddh]); writes du (bf16 [rows][ldu], both halves, pads zeroed) and
-// per-block dgamma partial sums dgamma_part[gridDim.x][I].
+// per-block dgamma partial sums dgamma_part[gridDim.x][I].  One block reduction (two sums, one barrier) per row; gelu and its
+// derivative come from one cdf / pdf evaluation per element and are kept in registers between the two passes.
 __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restrict__ dhn, long long lddh, const bf16_t* __restrict__ u,
                                                            long long ldu, int goff, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            bf16_t* __restrict__ du, float* __restrict__ dgamma_part, int rows, int I, int Ipad) {
-    __shared__ float red[4];
+    __shared__ float red[2][8];
     const int t = threadIdx.x;
     float4 dgam[GE_MAX], gam[GE_MAX];
 #pragma unroll
@@ -236,47 +262,51 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
         dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         gam[j] = make_float4(e < I ? gamma[e] : 0.f, e + 1 < I ? gamma[e + 1] : 0.f, e + 2 < I ? gamma[e + 2] : 0.f, e + 3 < I ? gamma[e + 3] : 0.f);
     }
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    int par = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float4 xv[GE_MAX], gv[GE_MAX], xh[GE_MAX], g[GE_MAX];
+        float4 ga[GE_MAX], gb[GE_MAX], xh[GE_MAX], g[GE_MAX];        // ga = d h / d x = gelu(gate); gb = d h / d gate = x * gelu'(gate)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
             const int e = (t + 256 * j) * 4;
-            xv[j] = gv[j] = xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ga[j] = gb[j] = xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < Ipad) {
-                xv[j] = load4(u + (long long)row * ldu + e);
-                gv[j] = load4(u + (long long)row * ldu + goff + e);
+                const float4 xv = load4(u + (long long)row * ldu + e);
+                const float4 gv = load4(u + (long long)row * ldu + goff + e);
                 const float4 d = load4(dhn + (long long)row * lddh + e);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (e + c < I) {
-                        const float h = gelu_f((&gv[j].x)[c]) * (&xv[j].x)[c];
-                        const float xhat = (h - mean) * rstd;
-                        const float gg = (&d.x)[c] * (&gam[j].x)[c];
-                        (&xh[j].x)[c] = xhat;
-                        (&g[j].x)[c] = gg;
-                        (&dgam[j].x)[c] += (&d.x)[c] * xhat;
+                        const float gt = f4e(gv, c), xx = f4e(xv, c);
+                        float cdf, pdf;
+                        gauss_cdf_pdf(gt, cdf, pdf);
+                        const float gl = gt * cdf;
+                        const float xhat = (gl * xx - mean) * rstd;
+                        const float gg = f4e(d, c) * f4e(gam[j], c);
+                        f4e(ga[j], c) = gl;
+                        f4e(gb[j], c) = xx * fmaf(gt, pdf, cdf);
+                        f4e(xh[j], c) = xhat;
+                        f4e(g[j], c) = gg;
+                        f4e(dgam[j], c) += f4e(d, c) * xhat;
                         s1 += gg;
                         s2 += gg * xhat;
                     }
                 }
             }
         }
-        const float c1 = block_sum256(s1, red) / (float)I;
-        const float c2 = block_sum256(s2, red) / (float)I;
+        block_sum256x2(s1, s2, red[par]);
+        const float c1 = s1 / (float)I, c2 = s2 / (float)I;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
             const int e = (t + 256 * j) * 4;
             if (e < Ipad) {
-                float4 dxh = make_float4(0.f, 0.f, 0.f, 0.f), dgh = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 dxh, dgh;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (e + c < I) {
-                        const float dh = rstd * ((&g[j].x)[c] - c1 - (&xh[j].x)[c] * c2);
-                        (&dxh.x)[c] = dh * gelu_f((&gv[j].x)[c]);
-                        (&dgh.x)[c] = dh * (&xv[j].x)[c] * gelu_grad_f((&gv[j].x)[c]);
-                    }
+                    const float dh = rstd * (f4e(g[j], c) - c1 - f4e(xh[j], c) * c2);
+                    f4e(dxh, c) = (e + c < I) ? dh * f4e(ga[j], c) : 0.f;
+                    f4e(dgh, c) = (e + c < I) ? dh * f4e(gb[j], c) : 0.f;
                 }
                 store4(du + (long long)row * ldu + e, dxh);
                 store4(du + (long long)row * ldu + goff + e, dgh);
@@ -289,7 +319,7 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
         const int e = (t + 256 * j) * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (e + c < I) dgamma_part[(long long)blockIdx.x * I + e + c] = (&dgam[j].x)[c];
+            if (e + c < I) dgamma_part[(long long)blockIdx.x * I + e + c] = f4e(dgam[j], c);
     }
 }
 

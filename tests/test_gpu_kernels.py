@@ -193,7 +193,7 @@ def test_geglu_ln(ops, I):
     xr, gr_, gam = xh.float().requires_grad_(True), gh.float().requires_grad_(True), gamma.clone().requires_grad_(True)
     h = F.gelu(gr_) * xr
     ref = F.layer_norm(h, (I,), gam, torch.zeros_like(gam))
-    assert relmax(hn[:, :I], ref) <= 4e-3, relmax(hn[:, :I], ref)
+    assert relmax(hn[:, :I], ref) <= 8e-3, relmax(hn[:, :I], ref)       # one bf16 ulp at the largest output
     assert float(hn[:, I:].float().abs().max()) == 0.0
     dhn = torch.zeros((rows, Ip), dtype=BF16, device=dev())
     dhn[:, :I] = rnd(rows, I, seed=19, dtype=BF16)
