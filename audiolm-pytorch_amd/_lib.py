@@ -41,8 +41,8 @@ SIGNATURES = {
     'alm_hc_partial_width': [_I, _I],
     'alm_hc_grads_width': [_I, _I],
     'alm_hc_partial_rows': [_I, _I, _I, _L, _I],
-    'alm_hc_fwd': [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'alm_hc_bwd': [_P, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_fwd': [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_bwd': [_P, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     'alm_hc_param_grads': [_P, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],

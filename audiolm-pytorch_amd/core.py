@@ -151,7 +151,8 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     ppl = params_per_layer(S)
     saved = dict(layers=[], B=B, N=N) if need_grad else None
 
-    R = ops.streams_expand(x, B, S) if S > 1 else x.reshape(M, D)
+    R = x.reshape(M, D)                  # S > 1: the stream expansion (:524) is never materialised -- the first branch reads x for every stream
+    rb = S > 1
     kv0 = None
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
@@ -161,8 +162,9 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
         if S > 1:
             # depth connection of the previous branch fused with this branch's width connection + pre-LayerNorm (one pass over R)
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'])
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'], rin_bcast=rb)
             R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
+            rb = rb and pend_y is None                 # still the un-expanded x after a width-only call
         else:
             XN, X, mean, rstd = ops.layernorm_fwd(R, pa['ln'], want_copy=True)
             coef = None
@@ -183,8 +185,9 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
         # ---------------- feed-forward branch (audiolm_pytorch.py:246-260) ----------------
         if S > 1:
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'])
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'], rin_bcast=rb)
             R1, X2, XN2, mean2, rstd2, coef2 = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
+            rb = False
         else:
             R1 = ops.residual_add(R, Y)
             XN2, X2, mean2, rstd2 = ops.layernorm_fwd(R1, pf['ln'], want_copy=False)
@@ -198,7 +201,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         if need_grad:
             saved['layers'].append(dict(R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Q=Q, KV=KV, V=V, AO=AO, LSE=LSE, Y=Y,
                                         R1=R1, X2=X2, XN2=XN2, mean2=mean2, rstd2=rstd2, coef2=coef2, U=U, HN=HN, mean3=mean3,
-                                        rstd3=rstd3, Y2=Y2, mixed=V is not Vown))
+                                        rstd3=rstd3, Y2=Y2, mixed=V is not Vown, r_bcast=(S > 1 and l == 0)))
         if S > 1:
             R, pend_y, pend_coef = R1, Y2, coef2
         else:
@@ -353,12 +356,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             py, pc = (prev['Y2'], prev['coef2']) if prev else (None, None)
             if FUSE_LN_BWD:
                 h = ops.hc_bwd(dR1, B, S, N, D, dxn=dXN, extra=dXkv, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=pa['ln'], R=sv['R'],
-                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc)
+                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=l == 0)
                 dgla = h['grads']['ln']
             else:
                 dX, dgla = ops.layernorm_bwd(dXN, sv['X'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
-                h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc)
-            dR, dY2, dbeta2 = h['dR'], h['dy'], h['dbeta']
+                h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc,
+                               r_bcast=sv['r_bcast'], sum_only=l == 0)
+            dR, dY2, dbeta2 = (h['dsum'] if l == 0 else h['dR']), h['dy'], h['dbeta']      # layer 0: already summed over the streams (:524)
             for j, k in enumerate(HC_KEYS):
                 grads[base + j] = h['grads'][k]
         else:
@@ -371,7 +375,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             # path never waits for them
             side.run(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
-    dx = ops.streams_reduce(dR, B, S) if S > 1 else dR.view(B, N, D)
+    dx = dR.view(B, N, D)
     side.join()                                    # autograd hands the gradients to consumers on the main stream
     return dx, grads
 

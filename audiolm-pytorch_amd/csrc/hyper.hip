@@ -86,7 +86,8 @@ __device__ __forceinline__ float token_combine(float tot, float* red, int tok, i
 }
 
 struct HcFwdArgs {
-    const float* R_in; const bf16_t* y; long long ldy; const float* coef_prev; float* R_out;
+    const float* R_in; int rin_bcast;                     // residual streams [B][S][N][D], or (rin_bcast) ONE [B*N][D] tensor every stream equals (:524)
+    const bf16_t* y; long long ldy; const float* coef_prev; float* R_out;
     HcParams hp; const float* ln_gamma;
     bf16_t* x_out; long long ldx; bf16_t* xn_out; long long ldxn; float* mean_out; float* rstd_out; float* coef; float* xs_out;
     int B, N, D;
@@ -153,9 +154,15 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 #pragma unroll
         for (int s = 0; s < S; ++s) r[s] = z4;
         if (ld_ok) {
-            const float* Rt = a.R_in + ((long long)b * S * a.N + n) * a.D + e0;
+            if (a.rin_bcast) {
+                const float4 rb = ld4(a.R_in + m * a.D + e0);
 #pragma unroll
-            for (int s = 0; s < S; ++s) r[s] = ld4(Rt + s * sND);
+                for (int s = 0; s < S; ++s) r[s] = rb;
+            } else {
+                const float* Rt = a.R_in + ((long long)b * S * a.N + n) * a.D + e0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) r[s] = ld4(Rt + s * sND);
+            }
             if (DEPTH) yv = ld4bf(a.y + m * a.ldy + e0);
         }
         if (DEPTH) {
@@ -274,9 +281,11 @@ struct HcBwdArgs {
     const bf16_t* dxn; long long lddxn;                  // gradient wrt the branch's pre-LayerNorm OUTPUT xn (bf16)     [LNF == true]
     const bf16_t* extra; long long ldex;                 //   + gradient arriving at x directly (attention: the K/V path), or NULL
     const float* mean; const float* rstd; const float* ln_gamma;        //   LayerNorm statistics saved by the forward, LN weight
-    const float* R; const float* coef; const float* dbeta;
+    const float* R; int r_bcast;                         // residual input of the width connection ([B][S][N][D], or one [B*N][D] tensor for all streams)
+    const float* coef; const float* dbeta;
     HcParams hp;
-    float* dR; float* partial;
+    float* dR; float* dsum;                              // dR [B][S][N][D] and / or dsum [B*N][D] = sum over streams of dR (gradient of the :524 expand)
+    float* partial;
     const bf16_t* y; long long ldy; const float* coef_prev; bf16_t* dy; long long lddy; float* dbeta_out;
     int B, N, D;
 };
@@ -361,8 +370,14 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 for (int t = 0; t < S; ++t) g[t] = ld4(a.dRn + tofs + t * sND);
             }
             if (WIDTH) {
+                if (a.r_bcast) {
+                    const float4 rb = ld4(a.R + m * a.D + e0);
 #pragma unroll
-                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld4(a.R + tofs + s2 * sND);
+                    for (int s2 = 0; s2 < S; ++s2) r_c[s2] = rb;
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld4(a.R + tofs + s2 * sND);
+                }
                 if (LNF) {
                     dx_c = ld4bf(a.dxn + m * a.lddxn + e0);                      // dxn (bf16) travels in dx_c
                     if (a.extra) ex_c = ld4bf(a.extra + m * a.ldex + e0);
@@ -473,8 +488,16 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 }
             }
             if (ld_ok) {
+                if (a.dR) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) *reinterpret_cast<float4*>(a.dR + (((long long)b * S + s) * a.N + n) * a.D + e0) = out[s];
+                    for (int s = 0; s < S; ++s) *reinterpret_cast<float4*>(a.dR + (((long long)b * S + s) * a.N + n) * a.D + e0) = out[s];
+                }
+                if (a.dsum) {
+                    float4 sm = out[0];
+#pragma unroll
+                    for (int s = 1; s < S; ++s) { sm.x += out[s].x; sm.y += out[s].y; sm.z += out[s].z; sm.w += out[s].w; }
+                    *reinterpret_cast<float4*>(a.dsum + m * a.D + e0) = sm;
+                }
             }
         } else {
 #pragma unroll
@@ -711,7 +734,7 @@ extern "C" int alm_hc_partial_rows(int mode, int fused_ln, int S, long long toke
 
 // mode: 1 = depth connection only (-> R_out), 2 = width connection only, 3 = depth (previous branch) + width (next branch) fused,
 //       5 = depth + stream sum + final LayerNorm (-> xs_out fp32, xn_out bf16, mean, rstd; R_out is not written)
-extern "C" int alm_hc_fwd(const float* R_in, const void* y_prev, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
+extern "C" int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
                           const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb,
                           const float* ln_gamma, void* x_out, long long ldx, void* xn_out, long long ldxn, float* mean, float* rstd,
                           float* coef, float* xs_out, int mode, int B, int S, int N, int D, void* stream) {
@@ -719,7 +742,7 @@ extern "C" int alm_hc_fwd(const float* R_in, const void* y_prev, long long ldy, 
     if ((mode & 1) && (!y_prev || !coef_prev || (!(mode & 4) && !R_out))) return ALM_ERR_BAD_ARG;
     if ((mode & 2) && (!hc_gamma || !Wa || !sa || !Aa || !wb || !sb || !Bb || !ln_gamma || !xn_out || !mean || !rstd || !coef)) return ALM_ERR_BAD_ARG;
     if ((mode & 4) && (!ln_gamma || !xn_out || !mean || !rstd || !xs_out)) return ALM_ERR_BAD_ARG;
-    HcFwdArgs a{R_in, (const bf16_t*)y_prev, ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
+    HcFwdArgs a{R_in, rin_bcast, (const bf16_t*)y_prev, ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
                 (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, B, N, D};
     int rc;
     if (S == 2) rc = dispatch_fwd<2>(a, mode, (hipStream_t)stream);
@@ -735,17 +758,18 @@ extern "C" int alm_hc_fwd(const float* R_in, const void* y_prev, long long ldy, 
 // dRn_bcast != 0: dRn is [B*N][D] and stands for all S streams (the gradient of the final stream sum, audiolm_pytorch.py:551).
 // partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads.
 extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn, long long lddxn, const void* extra,
-                          long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, const float* coef,
-                          const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb,
-                          float* dR, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
+                          long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, int r_bcast,
+                          const float* coef, const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb,
+                          const float* sb, float* dR, float* dsum, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
                           float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
     if ((D & 3) || D > 1024 || (lddx & 3) || (lddxn & 3) || (ldex & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
     const bool lnf = dxn != nullptr;
-    if ((mode & 2) && (!R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !dR || !partial)) return ALM_ERR_BAD_ARG;
+    if ((mode & 2) && (!R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !(dR || dsum) || !partial)) return ALM_ERR_BAD_ARG;
+    if ((mode & 1) && (mode & 2) && !dR) return ALM_ERR_BAD_ARG;
     if ((mode & 2) && (lnf ? (!mean || !rstd || !ln_gamma || dx != nullptr) : !dx)) return ALM_ERR_BAD_ARG;
     if ((mode & 1) && (!y_prev || !coef_prev || !dy || !dbeta_out)) return ALM_ERR_BAD_ARG;
-    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, (const bf16_t*)dxn, lddxn, (const bf16_t*)extra, ldex, mean, rstd, ln_gamma, R, coef, dbeta,
-                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, partial, (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out,
+    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, (const bf16_t*)dxn, lddxn, (const bf16_t*)extra, ldex, mean, rstd, ln_gamma, R, r_bcast, coef, dbeta,
+                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, partial, (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out,
                 B, N, D};
     int rc;
     if (S == 2) rc = dispatch_bwd<2>(a, mode, lnf, (hipStream_t)stream);

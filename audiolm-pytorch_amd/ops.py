@@ -238,18 +238,19 @@ def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
 _HC_KEYS7 = ('gamma', 'Wa', 'sa', 'Aa', 'wb', 'sb', 'Bb')
 
 
-def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True):
+def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True, rin_bcast=False):
     """Hyper-connection forward pass over the fp32 residual streams R_in [B, S, N, D] (C ABI: alm_hc_fwd).
       y_prev / coef_prev given : depth connection of the previous branch (R = mix(R_in) + beta * y_prev)
       hc given                 : width connection + pre-LayerNorm of the next branch on that R
       final                    : depth connection + stream sum + final LayerNorm (ln_gamma)
+      rin_bcast                : R_in is ONE [B*N, D] tensor every stream equals (right after the stream expansion)
     -> dict(R=..., x, xn, mean, rstd, coef | xs, hn, mean, rstd)."""
     _chk(R_in, F32)
     dev, M = R_in.device, B * N
     depth, width = y_prev is not None, hc is not None
     mode = (1 if depth else 0) | (2 if width else 0) | (4 if final else 0)
     out = {}
-    R_out = torch.empty_like(R_in) if (depth and not final) else None
+    R_out = torch.empty((B, S, N, D), dtype=F32, device=dev) if (depth and not final) else None
     x = xn = mean = rstd = coef = xs = None
     if width or final:
         xn = torch.empty((M, D), dtype=BF16, device=dev)
@@ -261,27 +262,31 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
     if final:
         xs = torch.empty((M, D), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in _HC_KEYS7] if width else [None] * 7
-    _lib.call('alm_hc_fwd', R_in.data_ptr(), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out), *hp, _p(ln_gamma),
+    _lib.call('alm_hc_fwd', R_in.data_ptr(), int(rin_bcast), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out), *hp, _p(ln_gamma),
               _p(x), D, _p(xn), D, _p(mean), _p(rstd), _p(coef), _p(xs), mode, B, S, N, D, _st())
     out.update(R=R_out if depth else R_in, x=x, xn=xn, mean=mean, rstd=rstd, coef=coef, xs=xs)
     return out
 
 
 def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=None, rstd=None, ln_gamma=None, R=None, coef=None, dbeta=None,
-           hc=None, y_prev=None, coef_prev=None):
+           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False):
     """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D], or with
     bcast [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
     gradient wrt the branch input is either `dx` (fp32, LayerNorm backward already applied) or `dxn` (bf16, wrt the LayerNorm output) +
     optional `extra` (bf16, added to dx) + mean / rstd / ln_gamma: then the LayerNorm backward is fused (grads['ln'] = its weight gradient).
     y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
-    -> dict(dR, grads, dy, dbeta)."""
+    r_bcast: R is one [B*N, D] tensor for all streams; sum_only: return dsum [B*N, D] = sum over streams of dR instead of dR.
+    -> dict(dR, dsum, grads, dy, dbeta)."""
     width, depth = hc is not None, y_prev is not None
     mode = (2 if width else 0) | (1 if depth else 0)
     dev, M = dRn.device, B * N
-    dR = part = dy = dbo = None
+    dR = dsum = part = dy = dbo = None
     if width:
         assert (dx is None) != (dxn is None)
-        dR = torch.empty((B, S, N, D), dtype=F32, device=dev)
+        if sum_only:
+            dsum = torch.empty((M, D), dtype=F32, device=dev)
+        else:
+            dR = torch.empty((B, S, N, D), dtype=F32, device=dev)
         rows = _lib.query('alm_hc_partial_rows', mode, int(dxn is not None), S, M, D)
         P = _lib.query('alm_hc_partial_width', S, D)
         part = torch.empty((rows, P), dtype=F32, device=dev)
@@ -291,7 +296,7 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
     hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
     _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
               dxn.stride(0) if dxn is not None else 0, _p(extra), extra.stride(0) if extra is not None else 0, _p(mean), _p(rstd), _p(ln_gamma),
-              _p(R), _p(coef), _p(dbeta), *hp, _p(dR), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
+              _p(R), int(r_bcast), _p(coef), _p(dbeta), *hp, _p(dR), _p(dsum), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
               mode, B, S, N, D, _st())
     grads = None
     if width:
@@ -306,7 +311,7 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
                 n *= d
             grads[name] = g[o:o + n].view(shape)
             o += n
-    return dict(dR=dR, grads=grads, dy=dy, dbeta=dbo)
+    return dict(dR=dR, dsum=dsum, grads=grads, dy=dy, dbeta=dbo)
 
 
 # un-fused single-connection forms (kernel tests; the product path uses the fused modes)

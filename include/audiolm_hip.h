@@ -108,14 +108,17 @@ int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D);
 /* forward.  mode 1: depth connection only, R_out[t] = sum_s alpha[s][t+1] R_in[s] + beta[t] y_prev (coef_prev = that branch's record);
  * mode 2: width connection of a branch (its 7 parameters) + the branch's pre-LayerNorm: x, xn = LN(x) ln_gamma, mean, rstd, coef;
  * mode 3: mode 1 of the previous branch fused with mode 2 of the next one on the freshly computed residual (one pass over R);
- * mode 5: depth connection + stream sum (:551) + final LayerNorm (:555): xs_out fp32 [B*N][D], xn_out bf16, mean, rstd. */
-int alm_hc_fwd(const float* R_in, const void* y_prev_bf16, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
+ * mode 5: depth connection + stream sum (:551) + final LayerNorm (:555): xs_out fp32 [B*N][D], xn_out bf16, mean, rstd.
+ * rin_bcast: R_in is ONE [B*N][D] tensor that every stream equals (the state right after the stream expansion, :524). */
+int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev_bf16, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
                const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb, const float* ln_gamma,
                void* x_out_bf16, long long ldx, void* xn_out_bf16, long long ldxn, float* mean, float* rstd, float* coef, float* xs_out,
                int mode, int B, int S, int N, int D, void* stream);
 /* backward.  mode 2: width-connection backward (dR, parameter-gradient partial rows); mode 1: depth-connection backward
  * (dy = sum_t beta[t] dRn[t], dbeta_out[t] = <dRn[t], y>); mode 3: mode 2 of branch k+1 fused with mode 1 of branch k on the
  * freshly computed dR.  dRn_bcast: dRn is [B*N][D] and stands for all S streams (gradient of the final stream sum).
+ * r_bcast: R is one [B*N][D] tensor for all streams (first branch); dsum (optional): [B*N][D] sum over streams of dR = the gradient of
+ * the stream expansion (:524); dR may then be NULL.
  * The gradient wrt the branch input comes either as dx (fp32 [B*N][lddx], already through the branch's LayerNorm backward) or -- fused
  * mode, dx == NULL -- as dxn (bf16, gradient wrt the LayerNorm OUTPUT) + optional extra (bf16, added to dx directly: the K/V path of
  * the attention branch) + the LayerNorm statistics / weight: the LayerNorm backward (audiolm_pytorch.py:191-198 autograd) then happens
@@ -123,9 +126,9 @@ int alm_hc_fwd(const float* R_in, const void* y_prev_bf16, long long ldy, const 
  * partial: [alm_hc_partial_rows(mode, dx == NULL, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose output is
  * dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]  (alm_hc_grads_width(S, D) floats). */
 int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn_bf16, long long lddxn, const void* extra_bf16,
-               long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, const float* coef,
+               long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, int r_bcast, const float* coef,
                const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR,
-               float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out,
+               float* dsum, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out,
                int mode, int B, int S, int N, int D, void* stream);
 int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */

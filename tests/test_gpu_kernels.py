@@ -381,6 +381,18 @@ def test_hyper_connections_fused_modes(ops, S, D, N):
         for k in hg:
             if k != 'ln':
                 assert relmax(fl['grads'][k], ref['grads'][k]) <= 1e-2, k
+    # un-expanded residual input (first branch): one [M, D] tensor for all streams; summed-over-streams gradient output
+    xb = rnd(M, D, seed=70)
+    Rb = ops.streams_expand(xb.view(B, N, D), B, S)
+    fe = ops.hc_fwd(Rb, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2)
+    fbc = ops.hc_fwd(xb, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2, rin_bcast=True)
+    assert torch.equal(fe['R'], fbc['R']) and torch.equal(fe['xn'], fbc['xn']) and torch.equal(fe['coef'], fbc['coef'])
+    _, _, _, _, coefb = ops.hc_width_fwd(Rb, hc2, g2, B, S, N, D)
+    be = ops.hc_bwd(G, B, S, N, D, dx=dx2, R=Rb, coef=coefb, dbeta=dbeta2, hc=hc2)
+    bb = ops.hc_bwd(G, B, S, N, D, dx=dx2, R=xb, coef=coefb, dbeta=dbeta2, hc=hc2, r_bcast=True, sum_only=True)
+    assert relmax(bb['dsum'], ops.streams_reduce(be['dR'], B, S).reshape(M, D)) <= 1e-6
+    for k in hg:
+        assert relmax(bb['grads'][k], be['grads'][k]) <= 1e-6, k
     # stream-broadcast gradient (right after the final stream sum)
     gb = rnd(M, D, seed=58)
     Gb = ops.streams_expand(gb.view(B, N, D), B, S)
