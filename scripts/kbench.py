@@ -188,6 +188,35 @@ def bench_codec():
     print(f'codec tokenize  total {t_all:.2f} ms -> {frames * 8 / t_all * 1e3:.0f} codes/s, {8 * 30 / t_all * 1e3:.0f} x real time')
 
 
+def bench_e2e():
+    """BASELINE configs[4]: SoundStream(codebook 4096, 8 quantizers, 24 kHz) tokenize + CoarseTransformer(codebook 4096) step on 8 x 30 s of
+    synthetic audio per GPU: N = 1 + 1501 + 1 + 6750 = 8253 tokens per sequence."""
+    torch.manual_seed(0)
+    ss = A.SoundStream(codebook_size=4096, rq_num_quantizers=8, target_sample_hz=24000, strides=(2, 4, 5, 8), use_local_attn=False)
+    for r in ss.rq.rvqs:
+        for q, l in enumerate(r.layers):
+            l._codebook.embed.copy_(torch.randn(1, 4096, 512) * (0.5 ** q))
+            l._codebook.initted.fill_(True)
+    ss.to(dev)
+    model = A.CoarseTransformer(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=4096, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=ss, unique_consecutive=False, mask_prob=0.15)
+    w.train()
+    wave = torch.randn(8, 720000, device=dev) * 0.1
+    sem = torch.randint(0, 500, (8, 1500), device=dev)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = w(semantic_token_ids=sem, raw_wave=wave, return_loss=True)
+        loss.backward()
+        return loss
+    t_tok = timeit(lambda: ss.tokenize(wave), iters=3, warm=1)
+    t_all = timeit(step, iters=3, warm=1)
+    ntok = 8 * 8253
+    print(f'config-5 end to end (B=8, 30 s @ 24 kHz, N=8253): tokenize {t_tok:.1f} ms + transformer fwd+bwd {t_all - t_tok:.1f} ms = {t_all:.1f} ms/step '
+          f'-> {ntok / t_all * 1e3:.0f} audio-tokens/s/GPU end to end, {ntok / (t_all - t_tok) * 1e3:.0f} transformer only')
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)

@@ -156,3 +156,35 @@ def test_soundstream_config5_shape_properties():
     wave2[:, -320:] += 0.05
     idx2 = ss.tokenize(wave2)[0]
     assert torch.equal(idx2[:, :-1], idx[:, :-1]), 'encoder is not causal'
+
+
+def test_end_to_end_raw_wave_to_coarse_loss_vs_oracle():
+    """BASELINE configs[4] at reduced size: raw audio -> SoundStream.tokenize (HIP conv encoder + RVQ) -> CoarseTransformerWrapper loss,
+    against the CPU oracle chain (oracle encoder + restated RVQ + oracle transformer) on the same weights.  The code indices are integers:
+    they must be identical, after which the loss comparison is the usual bf16-vs-fp32 one."""
+    import audiolm_pytorch_amd as A
+    fx = _load_fixture()
+    c = fx['ctor']
+    ss = A.SoundStream(**c)
+    sd_codec = synth_state_dict(fx['shapes'], fx['seed'])
+    ss.load_state_dict(sd_codec, strict=False)
+    ss.to(dev())
+    torch.manual_seed(3)
+    ctor = dict(dim=128, depth=2, num_semantic_tokens=50, codebook_size=c['codebook_size'], num_coarse_quantizers=3, flash_attn=True)
+    model = A.CoarseTransformer(**ctor)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev())
+    w = A.CoarseTransformerWrapper(transformer=model, codec=ss, unique_consecutive=False, mask_prob=0.)
+    w.train()
+    g = torch.Generator().manual_seed(21)
+    wave = torch.randn(2, 320 * 24, generator=g) * 0.3
+    sem = torch.randint(0, 50, (2, 30), generator=g)
+    loss = w(semantic_token_ids=sem.to(dev()), raw_wave=wave.to(dev()), return_loss=True)
+    loss.backward()
+    idx = O.soundstream_tokenize(sd_codec, wave, strides=c['strides'], num_quantizers=c['rq_num_quantizers'])     # (b, T, q)
+    ours_idx = ss(wave.to(dev()), return_encoded=True)[1].cpu()
+    assert torch.equal(ours_idx, idx)
+    cfg = O.Cfg(dim=128, depth=2, streams=4, num_semantic_tokens=50, codebook_size=c['codebook_size'], num_coarse_quantizers=3)
+    ref = O.coarse_wrapper_loss(sd, cfg, sem, idx[..., :3], training=True, unique_consecutive=False)
+    assert abs(float(loss) - float(ref)) <= 2e-3 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
