@@ -53,7 +53,18 @@ struct GemmParams {
     int nsl;           // number of K slices (raster 1)
 };
 
-template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {           // counted wait: at most N vector-memory operations (here: LDS DMA pieces) still in flight
+    static_assert(N == 0 || N == 6 || N == 8, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// STAGES = 2: one __syncthreads per K-step, the next step's DMA is in flight during the current step's MFMAs (prefetch distance 1).
+// STAGES = 3: prefetch distance 2 -- the DMA of step k+2 is issued at step k and stays in flight ACROSS the barrier of step k: the barrier
+//             is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(pieces of one stage), so only step k+1's data is waited for.
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int NW = WM * WN;
@@ -215,11 +226,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     const int nk = (Krem + BK - 1) / BK;
     stage(0, 0);
-    __syncthreads();
+    if (STAGES == 3) {
+        if (nk > 1) { stage(1, 1); wait_vmcnt<NIA + NIB>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
 
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (STAGES == 3) {
+            if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);       // (kt + 2) % 3: the buffer read during step kt - 1
+        } else {
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        }
         const unsigned char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -249,7 +269,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
                 for (int j = 0; j < TNB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
         }
-        __syncthreads();
+        if (STAGES == 3) {
+            // this wave's LDS reads of the step are complete (their results fed the MFMAs above); step kt+1's DMA must have landed,
+            // step kt+2's (just issued) may stay in flight
+            if (kt + 2 < nk) wait_vmcnt<NIA + NIB>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            buf = buf == 2 ? 0 : buf + 1;
+        } else {
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         constexpr int ROWB = WCOLS * ES;                    // bytes per slab row
         constexpr int NCH = ROWB / 16;                      // 16-B chunks per slab row
         constexpr int SLAB = 32 * ROWB;
-        static_assert(NW * SLAB <= 2 * STAGE, "epilogue slab");
+        static_assert(NW * SLAB <= STAGES * STAGE, "epilogue slab");
         const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
         unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + coff0 * ES;
         const bool fast = !p.accumulate && ((p.ldc * ES) & 15) == 0 && ((uintptr_t)Cb & 15) == 0 && (p.N % (16 / ES)) == 0;
@@ -461,11 +490,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs pj) {
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2>
 int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * BK * 2;
+    constexpr int smem = STAGES * (BM + BN) * BK * 2;
     static bool attr_done = false;                 // idempotent; a benign race sets the same value twice
-    auto kfn = gemm_kernel<BM, BN, WM, WN, TNMODE, OUT_F32>;
+    auto kfn = gemm_kernel<BM, BN, WM, WN, TNMODE, OUT_F32, STAGES>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -482,9 +511,9 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
     return 0;
 }
 
-// tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU)
+// tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU), 3 = 256x128 with a 3-stage DMA ring (8 waves)
 int pick_tile(int M, int N, int ny, int tile) {
-    if (tile == 1 || tile == 2) return tile;
+    if (tile == 1 || tile == 2 || tile == 3) return tile;
     if (M < 256 || N < 256) return 1;
     const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
     return big >= 192 ? 2 : 1;                     // enough 256^2 tiles to occupy most of the 256 CUs
@@ -493,6 +522,7 @@ int pick_tile(int M, int N, int ny, int tile) {
 template <bool TNMODE>
 int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
     const int tl = pick_tile(p.M, p.N, ny * nz, tile);
+    if (tl == 3) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true, 3>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false, 3>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);
 }
@@ -507,15 +537,15 @@ int g_dbg_tile = 0, g_dbg_slices = 0, g_dbg_raster = 1;     // tuning hook (alm_
 // XCD-panel rasterisation pays only when the panels spread evenly over the 8 XCDs (measured: 22 panels +3 %, 11 panels -40 %)
 int pick_raster(int M, int N, int nb, int tile) {
     if (!g_dbg_raster) return 0;
-    const int bm = tile == 2 ? 256 : 128;
-    const int tmm = (M + bm - 1) / bm, tnn = (N + bm - 1) / bm;
+    const int bm = tile >= 2 ? 256 : 128, bn = tile == 2 ? 256 : 128;
+    const int tmm = (M + bm - 1) / bm, tnn = (N + bn - 1) / bn;
     const int P = (tmm >= tnn ? tmm : tnn) * nb;
     return (P % 8 == 0 || P >= 20) ? 1 : 0;
 }
 SplitPlan splitk_plan(int M, int N, int K, int nb) {
     if (g_dbg_tile > 0 && g_dbg_slices > 0) {
         const int kc = ((K + g_dbg_slices - 1) / g_dbg_slices + BK - 1) / BK * BK;
-        return SplitPlan{(g_dbg_tile == 2 && M >= 256 && N >= 256) ? 2 : 1, (K + kc - 1) / kc};
+        return SplitPlan{(g_dbg_tile >= 2 && M >= 256 && N >= 256) ? g_dbg_tile : 1, (K + kc - 1) / kc};
     }
     SplitPlan best{1, 1};
     double best_t = 1e30;

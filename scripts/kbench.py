@@ -54,8 +54,8 @@ def bench_gemm():
         t = timeit(lambda: torch.matmul(Am, Bm.t(), out=C))
         ref = C.clone()
         line += f'  blas {t:.3f} ms {fl / t / 1e9:7.0f} TF |'
-        for tile in (1, 2):
-            if tile == 2 and (M < 256 or N < 256):
+        for tile in (1, 2, 3):
+            if tile >= 2 and (M < 256 or N < 256):
                 continue
             C.zero_()
             t = timeit(lambda: ops.gemm_nt_tile(Am, Bm, C, tile))
@@ -84,8 +84,8 @@ def bench_tn():
     f1 = lambda: ops.gemm_tn_splitk(dU.view(T, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2, dW1)
     f2 = lambda: ops.gemm_tn_splitk(dY2, HN[:, :I], dW2)
     fl1, fl2 = 2.0 * 2 * I * D * T, 2.0 * D * I * T
-    for raster in (0, 1):
-        for tile, sl in [(0, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (2, 6), (2, 8), (1, 2), (1, 4), (1, 8)]:
+    for raster in (0,):
+        for tile, sl in [(0, 0), (2, 2), (2, 5), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6)]:
             _lib.call('alm_debug_splitk', tile, sl, raster)
             t1, t2 = timeit(f1, iters=10), timeit(f2, iters=10)
             print(f'raster {raster} tile {tile} slices {sl}:  dW1(batched x2) {t1:.3f} ms {fl1 / t1 / 1e9:5.0f} TF | dW2 {t2:.3f} ms {fl2 / t2 / 1e9:5.0f} TF', flush=True)
@@ -215,6 +215,37 @@ def bench_e2e():
     ntok = 8 * 8253
     print(f'config-5 end to end (B=8, 30 s @ 24 kHz, N=8253): tokenize {t_tok:.1f} ms + transformer fwd+bwd {t_all - t_tok:.1f} ms = {t_all:.1f} ms/step '
           f'-> {ntok / t_all * 1e3:.0f} audio-tokens/s/GPU end to end, {ntok / (t_all - t_tok) * 1e3:.0f} transformer only')
+
+
+def bench_models():
+    """the other BASELINE configs on one GPU: configs[1] CoarseTransformer seq=1024, configs[2] FineTransformer seq=2049 (B=8, fwd+bwd)."""
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    torch.manual_seed(0)
+    cm = A.CoarseTransformer(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    cw = A.CoarseTransformerWrapper(transformer=cm, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
+    cw.train()
+    sem, coarse = torch.randint(0, 500, (8, 253), device=dev), torch.randint(0, 1024, (8, 256, 3), device=dev)
+
+    def cstep():
+        for p in cm.parameters():
+            p.grad = None
+        cw(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True).backward()
+    t = timeit(cstep, iters=10, warm=3)
+    print(f'configs[1] CoarseTransformer d=1024 depth=6 N=1024 B=8: {t:.2f} ms/step -> {8 * 1024 / t * 1e3:.0f} audio-tokens/s')
+    del cm, cw
+    fm = A.FineTransformer(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True).to(dev)
+    fw = A.FineTransformerWrapper(transformer=fm, codec=Codec(), mask_prob=0.15)
+    fw.train()
+    grid = torch.randint(0, 1024, (8, 256, 8), device=dev)
+
+    def fstep():
+        for p in fm.parameters():
+            p.grad = None
+        fw(coarse_token_ids=grid[..., :3], fine_token_ids=grid[..., 3:], return_loss=True).backward()
+    t = timeit(fstep, iters=10, warm=3)
+    print(f'configs[2] FineTransformer d=1024 depth=6 N=2049 B=8: {t:.2f} ms/step -> {8 * 2049 / t * 1e3:.0f} audio-tokens/s')
 
 
 def bench_misc():

@@ -263,3 +263,28 @@ def test_full_size_properties():
     la = w(semantic_token_ids=sem[:1], coarse_token_ids=coarse[:1], return_loss=True)
     lb = w(semantic_token_ids=sem[1:], coarse_token_ids=coarse[1:], return_loss=True)
     assert abs(float(l2) - 0.5 * (float(la) + float(lb))) <= 1e-4 * abs(float(l2)), (float(l2), float(la), float(lb))
+
+
+def test_fine_full_size_properties():
+    """BASELINE configs[2]: FineTransformer dim=1024 depth=6, 3 coarse + 5 fine quantizers, 256 frames -> N = 2049 (NOT a multiple of the
+    64-token attention / GEMM tiles): finite loss, every used parameter gets a finite gradient, deterministic forward, batch-row independence."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = A.FineTransformer(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True).to(dev)
+    w = A.FineTransformerWrapper(transformer=model, codec=Codec(8), mask_prob=0.)
+    w.train()
+    g = torch.Generator().manual_seed(6)
+    coarse = torch.randint(0, 1024, (2, 256, 3), generator=g).to(dev)
+    fine = torch.randint(0, 1024, (2, 256, 5), generator=g).to(dev)
+    l2 = w(coarse_token_ids=coarse, fine_token_ids=fine, return_loss=True)
+    l2.backward()
+    assert torch.isfinite(l2)
+    missing = [k for k, p in model.named_parameters() if p.grad is None and 'proj_text_embed' not in k and 'pos_bias' not in k and 'null_pos_bias' not in k]
+    assert not missing, missing
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    l2b = w(coarse_token_ids=coarse, fine_token_ids=fine, return_loss=True)
+    assert float(l2) == float(l2b), 'forward is not run-to-run deterministic'
+    la = w(coarse_token_ids=coarse[:1], fine_token_ids=fine[:1], return_loss=True)
+    lb = w(coarse_token_ids=coarse[1:], fine_token_ids=fine[1:], return_loss=True)
+    assert abs(float(l2) - 0.5 * (float(la) + float(lb))) <= 1e-4 * abs(float(l2)), (float(l2), float(la), float(lb))
