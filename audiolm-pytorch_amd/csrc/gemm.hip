@@ -53,6 +53,112 @@ struct GemmParams {
     int nsl;           // number of K slices (raster 1)
 };
 
+// ---- epilogue (shared by every GEMM kernel) --------------------------------------------------------------------------------------------
+// lane owns row gm of each 32-row block; register quad g holds columns n = 8*g + 4*lh + {0..3} of each 32-wide block.
+// Fast path: every wave transposes its 32 x (32*TNB) block through a private, XOR-swizzled LDS slab (`slabs`: NW slabs, free LDS) and
+// writes whole 128-B (bf16) / 256-B (fp32) row segments with 16-byte stores.  Returns after the stores were ISSUED (they drain
+// asynchronously).
+template <int BM, int BN, int WM, int WN, int TM, int TNB, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TNB], unsigned char* slabs, long long coff0, int m0, int n0,
+                                              int wave, int wr, int wc, int lane, int lr, int lh) {
+    {
+        constexpr int ES = OUT_F32 ? 4 : 2;                 // output element size
+        constexpr int WCOLS = 32 * TNB;                     // columns of the wave tile
+        constexpr int ROWB = WCOLS * ES;                    // bytes per slab row
+        constexpr int NCH = ROWB / 16;                      // 16-B chunks per slab row
+        constexpr int SLAB = 32 * ROWB;
+        unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + coff0 * ES;
+        const bool fast = !p.accumulate && ((p.ldc * ES) & 15) == 0 && ((uintptr_t)Cb & 15) == 0 && (p.N % (16 / ES)) == 0;
+        if (fast) {
+            unsigned char* slab = slabs + wave * SLAB;
+            const int ncol0 = n0 + wc * (BN / WN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mrow0 = m0 + wr * (BM / WM) + i * 32;
+#pragma unroll
+                for (int j = 0; j < TNB; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = j * 32 + 8 * g + 4 * lh;
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            v[c] = acc[i][j][4 * g + c] * p.alpha;
+                            if (p.bias && ncol0 + c0 + c < p.N) v[c] += p.bias[ncol0 + c0 + c];
+                        }
+                        if (OUT_F32) {
+                            const int ch = c0 / 4;
+                            *reinterpret_cast<float4*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            const int ch = c0 / 8;
+                            *reinterpret_cast<uint2*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4) + lh * 8) =
+                                make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        }
+                    }
+                constexpr int LPR = NCH;                     // lanes per row
+                constexpr int RPI = 64 / LPR;                // rows per wave-instruction
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int row = it * RPI + lane / LPR, ch = lane % LPR;
+                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * ROWB + ((ch ^ (row & (NCH - 1))) << 4));
+                    const int gm = mrow0 + row, gn = ncol0 + ch * (16 / ES);
+                    if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
+                }
+            }
+            return;
+        }
+    }
+    const long long coff = coff0;
+    const bool vec_ok = OUT_F32 ? ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0)
+                                : ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + wr * (BM / WM) + i * 32 + lr;
+        if (gm >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gn = n0 + wc * (BN / WN) + j * 32 + 8 * g + 4 * lh;
+                if (gn >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = acc[i][j][4 * g + c] * p.alpha;
+                    if (p.bias && gn + c < p.N) v[c] += p.bias[gn + c];
+                }
+                const long long idx = coff + (long long)gm * p.ldc + gn;
+                if (OUT_F32) {
+                    float* C = reinterpret_cast<float*>(p.C) + idx;
+                    if (vec_ok && gn + 3 < p.N) {
+                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.accumulate) { const float4 w = *reinterpret_cast<const float4*>(C); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+                        *reinterpret_cast<float4*>(C) = o;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (gn + c < p.N) C[c] = p.accumulate ? C[c] + v[c] : v[c];
+                    }
+                } else {
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + idx;
+                    if (vec_ok && gn + 3 < p.N) {
+                        if (p.accumulate) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(C);
+                            v[0] += __uint_as_float(w.x << 16); v[1] += __uint_as_float(w.x & 0xffff0000u);
+                            v[2] += __uint_as_float(w.y << 16); v[3] += __uint_as_float(w.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (gn + c < p.N) C[c] = f2bf(p.accumulate ? bf2f(C[c]) + v[c] : v[c]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {           // counted wait: at most N vector-memory operations (here: LDS DMA pieces) still in flight
     static_assert(N == 0 || N == 6 || N == 8, "add the literal");
@@ -281,107 +387,130 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         }
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
-    // lane owns row gm of each 32-row block; register quad g holds columns n = 8*g + 4*lh + {0..3} of each 32-wide block.
-    // Fast path: every wave transposes its 32 x (32*TNB) block through a private, XOR-swizzled LDS slab (the stage buffers are free
-    // after the last barrier) and writes whole 128-B (bf16) / 256-B (fp32) row segments with 16-byte stores.
+    // ---- epilogue: slabs reuse the (now idle) stage buffers ------------------------------------------------------------------------
     {
-        constexpr int ES = OUT_F32 ? 4 : 2;                 // output element size
-        constexpr int WCOLS = 32 * TNB;                     // columns of the wave tile
-        constexpr int ROWB = WCOLS * ES;                    // bytes per slab row
-        constexpr int NCH = ROWB / 16;                      // 16-B chunks per slab row
-        constexpr int SLAB = 32 * ROWB;
-        static_assert(NW * SLAB <= STAGES * STAGE, "epilogue slab");
+        constexpr int ES = OUT_F32 ? 4 : 2;
+        static_assert(NW * 32 * (32 * TNB * ES) <= STAGES * STAGE, "epilogue slab");
         const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
-        unsigned char* Cb = reinterpret_cast<unsigned char*>(p.C) + coff0 * ES;
-        const bool fast = !p.accumulate && ((p.ldc * ES) & 15) == 0 && ((uintptr_t)Cb & 15) == 0 && (p.N % (16 / ES)) == 0;
-        if (fast) {
-            unsigned char* slab = smem + wave * SLAB;
-            const int ncol0 = n0 + wc * (BN / WN);
+        gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+    }
+}
+
+// ---- persistent NT kernel (256x256x64, 8 waves): one workgroup per CU walks its share of the output tiles.  The DMA of the NEXT tile's
+// first K-step is issued before the epilogue of the current tile (into stage 0; the epilogue's transpose slabs live in stage 1), so the
+// cold-start latency of a tile and the drain of its output stores overlap -- this is what the K = 1024 shapes (W1 forward, dHN) lose
+// ~30 % of a tile to in the one-tile-per-workgroup kernel.  Same arithmetic, same rasterisation (tile v of workgroup b: v = b + i * grid).
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
+    constexpr int TM = 4, TNB = 2, NIA = 4, NIB = 4;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int zb = blockIdx.y;
+    const int z1 = zb / p.nb2, z2 = zb % p.nb2;
+    const long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
+    const long long coff0 = z1 * p.sC1 + z2 * p.sC2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    unsigned offA[NIA], offB[NIB];
+    int kc;                                                     // K coordinate (within a stage) of this lane's pieces
+    {
+        const int row0 = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row0 >> 1) & 7);           // (row >> 1) & 7 is the same for every piece of a lane (pieces are 64 rows apart)
+        kc = c * 8;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mrow0 = m0 + wr * (BM / WM) + i * 32;
-#pragma unroll
-                for (int j = 0; j < TNB; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c0 = j * 32 + 8 * g + 4 * lh;
-                        float v[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            v[c] = acc[i][j][4 * g + c] * p.alpha;
-                            if (p.bias && ncol0 + c0 + c < p.N) v[c] += p.bias[ncol0 + c0 + c];
-                        }
-                        if (OUT_F32) {
-                            const int ch = c0 / 4;
-                            *reinterpret_cast<float4*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-                            const int ch = c0 / 8;
-                            *reinterpret_cast<uint2*>(slab + lr * ROWB + ((ch ^ (lr & (NCH - 1))) << 4) + lh * 8) =
-                                make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                        }
-                    }
-                constexpr int LPR = NCH;                     // lanes per row
-                constexpr int RPI = 64 / LPR;                // rows per wave-instruction
-#pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
-                    const int row = it * RPI + lane / LPR, ch = lane % LPR;
-                    const uint4 val = *reinterpret_cast<const uint4*>(slab + row * ROWB + ((ch ^ (row & (NCH - 1))) << 4));
-                    const int gm = mrow0 + row, gn = ncol0 + ch * (16 / ES);
-                    if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
-                }
-            }
-            return;
+        for (int j = 0; j < NIA; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            offA[j] = (unsigned)(row * p.lda * 2 + c * 16);
+            offB[j] = (unsigned)(row * p.ldb * 2 + c * 16);
         }
     }
-    const long long coff = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
-    const bool vec_ok = OUT_F32 ? ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 15) == 0)
-                                : ((p.ldc & 3) == 0 && (coff & 3) == 0 && ((uintptr_t)p.C & 7) == 0);
+    unsigned fragA[TM], fragB[TNB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int gm = m0 + wr * (BM / WM) + i * 32 + lr;
-        if (gm >= p.M) continue;
+    for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((wr * 128 + i * 32 + lr) * 128);
 #pragma unroll
-        for (int j = 0; j < TNB; ++j) {
+    for (int j = 0; j < TNB; ++j) fragB[j] = (unsigned)(A_BYTES + (wc * 64 + j * 32 + lr) * 128);
+    const unsigned sw = (unsigned)((lr >> 1) & 7);
+
+    auto coords = [&](int v, int& m0, int& n0) {
+        const int bid = xcd_remap(v, nwg);
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM;
+        n0 = ((bid % per_group) / gsz) * BN;
+    };
+    auto stage = [&](int m0, int n0, int kt, int buf) {
+        const bf16_t* Ab = p.A + zoffA + (long long)m0 * p.lda;
+        const bf16_t* Bb = p.B + zoffB + (long long)n0 * p.ldb;
+        const long long extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2;
+        const long long extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + p.K) * 2;
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)min(extA, 0x7fffffffLL), 0x00020000);
+        const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)min(extB, 0x7fffffffLL), 0x00020000);
+        unsigned char* base = smem + buf * STAGE;
+        const bool kok = kc < p.K - kt * BK;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int gn = n0 + wc * (BN / WN) + j * 32 + 8 * g + 4 * lh;
-                if (gn >= p.N) continue;
-                float v[4];
+        for (int j = 0; j < NIA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, kok ? offA[j] : OOB, kt * (BK * 2), 0, 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    v[c] = acc[i][j][4 * g + c] * p.alpha;
-                    if (p.bias && gn + c < p.N) v[c] += p.bias[gn + c];
-                }
-                const long long idx = coff + (long long)gm * p.ldc + gn;
-                if (OUT_F32) {
-                    float* C = reinterpret_cast<float*>(p.C) + idx;
-                    if (vec_ok && gn + 3 < p.N) {
-                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                        if (p.accumulate) { const float4 w = *reinterpret_cast<const float4*>(C); o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
-                        *reinterpret_cast<float4*>(C) = o;
-                    } else {
+        for (int j = 0; j < NIB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, kok ? offB[j] : OOB, kt * (BK * 2), 0, 0);
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    int v = blockIdx.x;
+    if (v >= nwg) return;
+    int m0, n0;
+    coords(v, m0, n0);
+    stage(m0, n0, 0, 0);
+    for (;;) {
+        __syncthreads();            // this tile's first K-step has landed; everyone has left the previous tile's epilogue (slabs in stage 1)
+        f32x16 acc[TM][TNB];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (gn + c < p.N) C[c] = p.accumulate ? C[c] + v[c] : v[c];
-                    }
-                } else {
-                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + idx;
-                    if (vec_ok && gn + 3 < p.N) {
-                        if (p.accumulate) {
-                            const uint2 w = *reinterpret_cast<const uint2*>(C);
-                            v[0] += __uint_as_float(w.x << 16); v[1] += __uint_as_float(w.x & 0xffff0000u);
-                            v[2] += __uint_as_float(w.y << 16); v[3] += __uint_as_float(w.y & 0xffff0000u);
-                        }
-                        *reinterpret_cast<uint2*>(C) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                    } else {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (gn + c < p.N) C[c] = f2bf(p.accumulate ? bf2f(C[c]) + v[c] : v[c]);
-                    }
-                }
+            for (int j = 0; j < TNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(m0, n0, kt + 1, buf ^ 1);
+            const unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[TM], b[TNB];
+                const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
+            __syncthreads();
         }
+        // both stages are idle now: fetch the next tile's first K-step into stage 0 while this tile drains through stage 1
+        const int vn = v + (int)gridDim.x;
+        const int cm0 = m0, cn0 = n0;
+        const bool more = vn < nwg;
+        if (more) {
+            coords(vn, m0, n0);
+            stage(m0, n0, 0, 0);
+        }
+        gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem + STAGE, coff0, cm0, cn0, wave, wr, wc, lane, lr, lh);
+        if (!more) break;
+        v = vn;
     }
 }
 
@@ -513,15 +642,34 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU), 3 = 256x128 with a 3-stage DMA ring (8 waves)
 int pick_tile(int M, int N, int ny, int tile) {
-    if (tile == 1 || tile == 2 || tile == 3) return tile;
+    if (tile >= 1 && tile <= 4) return tile;
     if (M < 256 || N < 256) return 1;
     const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
     return big >= 192 ? 2 : 1;                     // enough 256^2 tiles to occupy most of the 256 CUs
 }
 
+template <bool OUT_F32>
+int launch_persist(const GemmParams& p, int ny, hipStream_t st) {
+    constexpr int smem = 2 * (256 + 256) * BK * 2;
+    static bool attr_done = false;
+    auto kfn = gemm_nt_persist_kernel<OUT_F32>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, ny), dim3(512), smem, st, p);
+    return 0;
+}
+
 template <bool TNMODE>
 int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
     const int tl = pick_tile(p.M, p.N, ny * nz, tile);
+    if (tl == 4) {
+        if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0) return ALM_ERR_UNSUPPORTED;
+        return out_f32 ? launch_persist<true>(p, ny, st) : launch_persist<false>(p, ny, st);
+    }
     if (tl == 3) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true, 3>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false, 3>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);

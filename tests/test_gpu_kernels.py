@@ -49,11 +49,12 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3])
-@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192)])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192), (1536, 5472, 128), (4096, 2736, 192)])
 def test_gemm_nt_tile_configs(ops, M, N, K, tile):
     """every block-tile configuration (128x128x64 / 4 waves, 256x256x64 / 8 waves, 256x128x64 with the 3-stage counted-vmcnt DMA ring: 1, 2, 3
-    and more K-steps exercise its prologue / steady state / drain) on full, ragged and K-tail shapes; an asymmetric
+    and more K-steps exercise its prologue / steady state / drain; 4 = persistent 256x256 kernel: shapes with more tiles than CUs make
+    every workgroup walk several tiles with the cross-tile prefetch) on full, ragged and K-tail shapes; an asymmetric
     B catches operand / output transposes."""
     A, B = rnd(M, K, seed=11, dtype=BF16), rnd(N, K, seed=12, dtype=BF16)
     for dt, tol in ((F32, 2e-5), (BF16, 4e-3)):
