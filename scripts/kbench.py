@@ -188,6 +188,38 @@ def bench_codec():
     print(f'codec tokenize  total {t_all:.2f} ms -> {frames * 8 / t_all * 1e3:.0f} codes/s, {8 * 30 / t_all * 1e3:.0f} x real time')
 
 
+def bench_convs():
+    """per-layer timing of the SoundStream encoder (8 x 30 s @ 24 kHz): every causal conv launch with its fp32 MFMA rate / HBM rate."""
+    torch.manual_seed(0)
+    ss = A.SoundStream(codebook_size=4096, rq_num_quantizers=8, target_sample_hz=24000, strides=(2, 4, 5, 8), use_local_attn=False).to(dev)
+    from audiolm_pytorch_amd import soundstream as SS
+    h = torch.randn(8, 1, 720000, device=dev) * 0.1
+    rows = []
+
+    def run(layer, x, **kw):
+        y = layer.run(x, **kw)
+        t = timeit(lambda: layer.run(x, **kw), iters=3, warm=1)
+        cin, cout, k = layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size
+        fl = 2.0 * y.numel() * cin * k
+        by = 4.0 * (x.numel() + y.numel() * (2 if kw.get('residual') is not None else 1))
+        rows.append((f'{cin}->{cout} k{k} s{layer.stride} d{layer.dilation} T={x.shape[-1]}', t, fl / t / 1e9, by / t / 1e6))
+        return y
+    for layer in ss.encoder:
+        if isinstance(layer, SS.CausalConv1d):
+            h = run(layer, h)
+        else:
+            for sub in layer:
+                if isinstance(sub, SS._ResidualFn):
+                    a1 = run(sub.fn[0], h, elu=True)
+                    h = run(sub.fn[2], a1, elu=True, residual=h)
+                else:
+                    h = run(sub, h)
+    tot = sum(r[1] for r in rows)
+    for name, t, tf, gb in rows:
+        print(f'{name:40s} {t:7.3f} ms  {tf:6.1f} TF fp32  {gb:7.0f} GB/s')
+    print(f'total {tot:.2f} ms')
+
+
 def bench_e2e():
     """BASELINE configs[4]: SoundStream(codebook 4096, 8 quantizers, 24 kHz) tokenize + CoarseTransformer(codebook 4096) step on 8 x 30 s of
     synthetic audio per GPU: N = 1 + 1501 + 1 + 6750 = 8253 tokens per sequence."""
