@@ -34,6 +34,18 @@ SIGNATURES = {
     'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
     'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _P],
+    'alm_mqa_attn_bias_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P],
+    'alm_mqa_attn_bias_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F,
+                              _P, _I, _P, _P, _P, _P, _P, _P],
+    'alm_attn_bias_part_rows': [_I, _I, _I],
+    'alm_attn_bias_grad_reduce': [_P, _P, _I, _I, _I, _I, _F, _P],
+    'alm_posmlp_in_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    'alm_posmlp_in_bwd_chunks': [_I],
+    'alm_posmlp_in_bwd': [_P, _P, _P, _I, _I, _I, _P],
+    'alm_silu_fwd': [_P, _P, _L, _P],
+    'alm_silu_bwd': [_P, _P, _P, _L, _P],
+    'alm_posmlp_out_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    'alm_posmlp_out_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'alm_value_residual_mix': [_P, _L, _P, _L, _P, _L, _L, _I, _P],
     'alm_kv_grad_pack': [_P, _P, _L, _I, _L, _P, _P, _L, _L, _I, _I, _P],
     'alm_mqa_head_groups': [_I],

@@ -8,8 +8,11 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
   *Transformer.forward embeddings           -> EmbedAssembleFn           (gather + quantizer-position add + start tokens + concat)
   logit heads + F.cross_entropy             -> heads.HeadsLossFn         (regrouped batched MFMA GEMM + online-softmax CE)
 
+  RelativePositionBias / pos_bias_mlp       -> relpos.PosTableFn         (`flash_attn=False` models: the bias stays a per-head table that
+                                                                          the attention kernels index in place; no (h, n, n) tensor)
+
 Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning, kv-cache /
-generate(), and the dense relative-position attention bias of `flash_attn=False` models.
+generate(), arbitrary dense `attn_bias` tensors.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
 from __future__ import annotations
@@ -22,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.utils.rnn import pad_sequence
 
-from . import core, heads, ops
+from . import core, heads, ops, relpos
 from .attend import Attend
 from .version import __version__
 
@@ -128,7 +131,7 @@ class LayerNormFn(torch.autograd.Function):
         return dx.to(x.dtype), dg
 
 
-class RelativePositionBias(nn.Module):                        # audiolm_pytorch.py:202-242 (parameters only this round)
+class RelativePositionBias(nn.Module):                        # audiolm_pytorch.py:202-242
     def __init__(self, *, dim, heads, layers=3):
         super().__init__()
         self.net = nn.ModuleList([])
@@ -141,9 +144,21 @@ class RelativePositionBias(nn.Module):                        # audiolm_pytorch.
     def device(self):
         return next(self.parameters()).device
 
-    def forward(self, i, j):
-        raise NotImplementedError('dense relative-position attention bias (flash_attn=False) is SURVEY.md §8(f) item 1; '
-                                  'construct the transformer with flash_attn=True (the README / benchmark configuration)')
+    def forward(self, i, j, special=None, num_leading=None):
+        """-> relpos.AttnBias: the (2j - 1)-row MLP table (:234-238) kept as a table + the index vectors that replace the gather
+        `x[rel_pos]` (:229-241); the (h, i, j) tensor is never built.  special / num_leading: the Coarse cross-attention override (:929-936)."""
+        if i != j:
+            raise NotImplementedError('kv-cache inference (i < j) is SURVEY.md §8(f) item 2')
+        dev = self.device
+        x = torch.arange(-j + 1, j, device=dev).float().unsqueeze(-1)                             # :234-235
+        ws = []
+        for layer in self.net:
+            lin = layer[0] if isinstance(layer, nn.Sequential) else layer
+            ws += [lin.weight, lin.bias]
+        heads_ = self.net[-1].weight.shape[0]
+        tbl = relpos.PosTableFn.apply(x, special, 64 ** 0.5, *ws)                                 # scores are scaled by dim_head^-0.5 = 1 / 8
+        assert tbl.shape[0] == heads_
+        return relpos.AttnBias(tbl, *relpos.toeplitz_index(j, dev, num_leading))
 
 
 class GEGLU(nn.Module):                                       # audiolm_pytorch.py:246-249 (fused into alm_geglu_ln_*)
@@ -280,15 +295,19 @@ class Transformer(nn.Module):
                 return_flat_hidden=False):
         if exists(context) or exists(kv_cache):
             raise NotImplementedError('conditioning / kv-cache inference are out of scope this round (SURVEY.md §8(f))')
-        if exists(attn_bias) or exists(self.rel_pos_bias):
-            raise NotImplementedError('dense attention bias (flash_attn=False models) is SURVEY.md §8(f) item 1; use flash_attn=True')
         if not x.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
         b, n, d = x.shape
+        if exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias):
+            raise NotImplementedError('a dense (h, n, n) attn_bias tensor is not supported: pass the structured relpos.AttnBias '
+                                      '(RelativePositionBias.forward / FineTransformer build it) -- the kernels index the bias table in place')
+        if not exists(attn_bias) and exists(self.rel_pos_bias):
+            attn_bias = self.rel_pos_bias(n, n)                                                   # :500-503
         mask_u8 = None
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
-        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, self._layer_grad_hook, *self.flat_params())
+        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, self._layer_grad_hook, attn_bias,
+                                           attn_bias.tbl if exists(attn_bias) else None, *self.flat_params())
         if return_flat_hidden:
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
         out = hn.view(b, n, d)
@@ -500,7 +519,12 @@ class CoarseTransformer(_TransformerBase):
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.semantic_embedding.weight,
                                        self.coarse_embedding.weight, self.coarse_quantize_embedding.weight,
                                        self.semantic_start_token, self.coarse_start_token).view(b, N, self.dim)   # :913-918
-        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True)
+        attn_bias = None
+        if exists(self.transformer.rel_pos_bias):
+            # :924-936 -- relative positions everywhere except across the semantic / coarse boundary, where every pair gets the learned
+            # per-head cross_attn_bias (is_semantic = arange(N) < ns + 1)
+            attn_bias = self.transformer.rel_pos_bias(N, N, special=self.cross_attn_bias, num_leading=ns + 1)
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, return_flat_hidden=True)
         return hn, b, N, ns, nc
 
     def _groups(self, b, N, ns, nc, dev, semantic_labels=None, coarse_labels=None, only_coarse=False):
@@ -587,8 +611,6 @@ class FineTransformer(_TransformerBase):
         self._reject_conditioning(text, text_embeds)
         if exists(kv_cache) or exists(embed_cache):
             raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
-        if exists(self.pos_bias_mlp):
-            raise NotImplementedError('dense attention bias (flash_attn=False models) is SURVEY.md §8(f) item 1; use flash_attn=True')
         b, dev = coarse_token_ids.shape[0], coarse_token_ids.device
         Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
         coarse, fine = _flatten_ids(coarse_token_ids), _flatten_ids(fine_token_ids)               # :1171
@@ -609,7 +631,15 @@ class FineTransformer(_TransformerBase):
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.coarse_embedding.weight,
                                        self.fine_embedding.weight, self.coarse_quantize_embedding.weight,
                                        self.fine_quantize_embedding.weight, self.coarse_start_token, self.fine_start_token).view(b, N, self.dim)
-        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True)
+        attn_bias = None
+        if exists(self.pos_bias_mlp):
+            # :1229-1298 -- the MLP over the (relative frame, relative quantizer) grid stays a table; start-token pairs read null_pos_bias
+            grid, index = relpos.fine_index(n, nf, Qc, Qf, dev)
+            mlp = self.pos_bias_mlp
+            tbl = relpos.PosTableFn.apply(grid, self.null_pos_bias, 64 ** 0.5, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+                                          mlp[4].weight, mlp[4].bias)
+            attn_bias = relpos.AttnBias(tbl, *index)
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, return_flat_hidden=True)
 
         n_fine = nf + 1                                                                           # tokens[:, n+1:]  (:1319)
         want_coarse = exists(self.coarse_logit_weights) and not return_only_fine_logits

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libaudiolm_hip.so')
 STAMP = os.path.join(HERE, '.libaudiolm_hip.stamp')
-SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.hip', 'codec.hip']
+SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.hip', 'codec.hip', 'relpos.hip']
 
 
 def _digest() -> str:
@@ -21,7 +21,7 @@ def _digest() -> str:
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.hpp', '.h'))] + [os.path.join(HERE, '..', 'include', 'audiolm_hip.h')]
     for f in files:
         with open(f, 'rb') as fh:
-            h.update(f.encode() + b'\0' + fh.read())
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())      # content only: the tree is copied to another path on the GPU box
     return h.hexdigest()
 
 

@@ -142,8 +142,9 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
-def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool):
-    """x fp32 [B, N, D] -> (hn bf16 [B*N, D], saved-for-backward | None)."""
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None):
+    """x fp32 [B, N, D] -> (hn bf16 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
+    audiolm_pytorch.py:500-506 / :532) or None."""
     B, N, D = x.shape
     M, S, H, dh = B * N, cfg.streams, cfg.heads, cfg.dim_head
     I, Ip = cfg.inner, cfg.inner_pad
@@ -179,7 +180,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
             V = Vown
         if kv0 is None:
             kv0 = KV                                      # :534-535 (layer-0 values, pre-mix)
-        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh)
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
         Y = _empty((M, D), BF16, dev)
         ops.gemm_nt(AO, Wo, Y)
 
@@ -258,8 +259,8 @@ FUSE_LN_BWD = os.environ.get('ALM_FUSE_LN_BWD', '1') != '0'             # switch
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
 
 
-def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None):
-    """dhn bf16 [M, D] -> (dx fp32 [B, N, D] (already scaled by grad_shrink alpha), list of parameter grads aligned with `flat`)."""
+def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None):
+    """dhn bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None)."""
     B, N = saved['B'], saved['N']
     D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
     M = B * N
@@ -274,6 +275,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if cfg.add_value_residual and cfg.depth > 1 else None
     # S > 1: dR = gradient wrt the residual streams after the current branch; right after the final stream sum it is dxs for every
     # stream (`bcast`).  dY2 / dbeta2 (depth-connection backward of the FF branch) are produced one step ahead by the fused kernels.
+    dtbl_part = ops.attn_bias_part(B, N, H, bias.tbl.shape[1], dev) if bias is not None else None
     dR, bcast = dxs, S > 1
     dY2 = dbeta2 = None
     if S > 1:
@@ -331,7 +333,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         AOs = sv['AO']
         side.run(lambda: ops.gemm_tn_splitk(dY, AOs, dWo), dY, AOs, dWo)
         KV = sv['KV']
-        dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh)
+        dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
         if acc_v0 is None:
             mode = 0
         elif sv['mixed']:
@@ -376,19 +378,22 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             side.run(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
     dx = dR.view(B, N, D)
+    dtbl = ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None
     side.join()                                    # autograd hands the gradients to consumers on the main stream
-    return dx, grads
+    return dx, grads, dtbl
 
 
 class TransformerStackFn(torch.autograd.Function):
     """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states bf16 [B*N, D]."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, cfg, cache, hooks, *flat):
-        need = any(t.requires_grad for t in flat) or x.requires_grad
+    def forward(ctx, x, mask_u8, cfg, cache, hooks, bias, tbl, *flat):
+        # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes its gradient
+        need = any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad)
         xin = x.detach().contiguous().to(F32)
-        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need)
-        ctx.saved, ctx.cfg, ctx.cache, ctx.mask, ctx.hooks = saved, cfg, cache, mask_u8, hooks
+        bias = bias.detached() if bias is not None else None
+        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need, bias)
+        ctx.saved, ctx.cfg, ctx.cache, ctx.mask, ctx.hooks, ctx.bias = saved, cfg, cache, mask_u8, hooks, bias
         ctx.flat = flat
         return hn
 
@@ -399,10 +404,10 @@ class TransformerStackFn(torch.autograd.Function):
         dhn = dhn.contiguous()
         if dhn.dtype != BF16:
             dhn = dhn.to(BF16)
-        dx, grads = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks)
+        dx, grads, dtbl = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
         ctx.saved = None
         dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478
         out = []
         for p, g in zip(ctx.flat, grads):
             out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
-        return (dx, None, None, None, None, *out)
+        return (dx, None, None, None, None, None, dtbl, *out)

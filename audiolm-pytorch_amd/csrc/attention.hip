@@ -23,6 +23,15 @@
 //     diagonal (Q / dO tiles by DMA, double buffered); per-head dK^T / dV^T accumulators are summed over the 4 heads through
 //     LDS; the two head groups write separate fp32 partials that alm_kv_grad_pack adds (deterministic, no atomics).
 //   * heavy (long-causal-span) workgroups are scheduled first and paired with light ones on a CU.
+//   * STRUCTURED ATTENTION BIAS (the `flash_attn=False` models: reference RelativePositionBias audiolm_pytorch.py:202-242, the Coarse
+//     cross-attention override :924-936 and the Fine (frame, quantizer) table :1227-1298).  The reference gathers a (h, n, n) fp32
+//     tensor from a small per-head table and adds it to the scores; here the table is indexed INSIDE the kernels:
+//         bias(h, i, j) = (qattr[i] & kattr[j]) ? tbl[h][0] : tbl[h][(qkey4[i] - kkey4[j]) / 4]
+//     (tbl in raw-score units, i.e. already divided by `scale`; slot 0 is the "special pair" value: cross_attn_bias / null_pos_bias).
+//     The gathered value is one more term of the S accumulators' INITIAL value.  The table gradient (dS summed over every pair that
+//     reads a slot) is accumulated by the dQ kernel: per wave, an LDS window covering the slots one (32 q x 64 key) pass can touch
+//     takes ds_add_f32 updates and is flushed into that workgroup's own partial table (plain read-modify-write: deterministic); a
+//     pass whose window would not fit falls back to global atomics on the same partial.  alm_attn_bias_grad_reduce sums the partials.
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -95,7 +104,17 @@ struct AttnParams {
     long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, part_stride;
     int B, N, H, HG;
     float scale;
+    // structured bias (null tbl = none)
+    const float* tbl; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part;
+    int LT;
 };
+
+constexpr int WCAP = 1024;                          // floats per wave in the dQ kernel's table-gradient window (slot 0 = special pairs)
+
+__device__ __forceinline__ float bias_at(const __amdgpu_buffer_rsrc_t& rsT, int kq4, int kk4, int aq, int ak) {
+    const int voff = (aq & ak) ? 0 : kq4 - kk4;                          // out-of-table offsets read 0 (buffer bounds check)
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsT, voff, 0, 0));
+}
 
 // log-sum-exp -> log2 domain; a fully masked query row (lse = -inf, the forward wrote zeros) gets +inf so that every P is 0
 __device__ __forceinline__ float lse_log2(float l) { return l == -INFINITY ? INFINITY : l * LOG2E; }
@@ -149,9 +168,12 @@ __device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsig
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
+template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 : 0)];
     float* kbias = reinterpret_cast<float*>(smem + 32768);          // [2][64]: 0 for attendable keys, -inf otherwise
+    int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] key-side attributes
+    int* kas = kk4s + 128;
 
     const int nqb = (p.N + 63) / 64;
     const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
@@ -180,6 +202,11 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
             bool ok = key < p.N;
             if (ok && mrow) ok = mrow[key] != 0;
             kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
+            if (BIAS) {
+                const int kc = min(key, p.N - 1);
+                kk4s[buf * 64 + t] = p.kkey4[kc];
+                kas[buf * 64 + t] = p.kattr[kc];
+            }
         }
     };
 
@@ -191,6 +218,18 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
         const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + head * DH;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = gload8(qp + ks * 16 + lh * 8, active && qi < p.N);
+    }
+
+    int kq4[2] = {0, 0}, aq[2] = {0, 0};
+    __amdgpu_buffer_rsrc_t rsT = rsK;
+    if (BIAS) {
+        rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tbl + (long long)(active ? head : 0) * p.LT), 0, p.LT * 4, 0x00020000);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qc = min(q0 + qb * 32 + lr, p.N - 1);
+            kq4[qb] = p.qkey4[qc];
+            aq[qb] = p.qattr[qc];
+        }
     }
 
     f32x16 o[2][2];                    // [db][qb]: O^T blocks (rows = head dim, cols = queries)
@@ -224,10 +263,20 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+                    if (BIAS) {
+                        const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                        const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                        const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) {
-                        st[kb][qb][4 * g + 0] = bv.x; st[kb][qb][4 * g + 1] = bv.y;
-                        st[kb][qb][4 * g + 2] = bv.z; st[kb][qb][4 * g + 3] = bv.w;
+                        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c] + bias_at(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
+                    } else {
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c];
                     }
                 }
 #pragma unroll
@@ -361,9 +410,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward dQ: same decomposition as forward.  dQ^T = scale * K^T dS^T,  dS^T = P^T o (dP^T - delta),  dP^T = V dO^T.
 // The two 32-query blocks of a wave are processed one after the other inside a tile (register budget).
 // ------------------------------------------------------------------------------------------------------------------
+template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 + 64 + HPB * WCAP * 4 : 0)];
     float* kbias = reinterpret_cast<float*>(smem + 32768);
+    int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] attributes,
+    int* kas = kk4s + 128;                                          //       [2][2] min / max offset of the staged key tile,
+    int* kmm = kas + 128;                                           //       [HPB][WCAP] per-wave table-gradient windows
+    float* wins = reinterpret_cast<float*>(smem + 32768 + 512 + 1024 + 64);
 
     const int nqb = (p.N + 63) / 64;
     const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
@@ -392,6 +446,19 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
             bool ok = key < p.N;
             if (ok && mrow) ok = mrow[key] != 0;
             kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
+            if (BIAS) {
+                const int kc = min(key, p.N - 1);
+                const int kv = p.kkey4[kc];
+                kk4s[buf * 64 + t] = kv;
+                kas[buf * 64 + t] = p.kattr[kc];
+                int mn = kv, mx = kv;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn = min(mn, __shfl_xor(mn, o, 64));
+                    mx = max(mx, __shfl_xor(mx, o, 64));
+                }
+                if (t == 0) { kmm[buf * 2] = mn; kmm[buf * 2 + 1] = mx; }
+            }
         }
     };
 
@@ -410,6 +477,30 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
         }
         lse2[qb] = ok ? lse_log2(p.lse[((long long)b * p.H + head) * p.N + qi]) : INFINITY;
         dlt[qb] = ok ? p.ndelta[((long long)b * p.H + head) * p.N + qi] : 0.f;          // = -delta
+    }
+
+    int kq4[2] = {0, 0}, aq[2] = {0, 0}, qmin4[2] = {0, 0}, qmax4[2] = {0, 0};
+    __amdgpu_buffer_rsrc_t rsT = rsK;
+    float* win = wins + wave * WCAP;
+    float* part = nullptr;
+    if (BIAS) {
+        rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tbl + (long long)(active ? head : 0) * p.LT), 0, p.LT * 4, 0x00020000);
+        part = p.dtbl_part + ((((long long)b * p.HG + id.hg) * nqb + qblk) * HPB + wave) * p.LT;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qc = min(q0 + qb * 32 + lr, p.N - 1);
+            kq4[qb] = p.qkey4[qc];
+            aq[qb] = p.qattr[qc];
+            int mn = kq4[qb], mx = kq4[qb];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                mn = min(mn, __shfl_xor(mn, o, 64));
+                mx = max(mx, __shfl_xor(mx, o, 64));
+            }
+            qmin4[qb] = __builtin_amdgcn_readfirstlane(mn);
+            qmax4[qb] = __builtin_amdgcn_readfirstlane(mx);
+        }
+        for (int e = lane; e < WCAP; e += 64) win[e] = 0.f;
     }
 
     f32x16 dq[2][2];                   // [db][qb]: dQ^T blocks
@@ -442,7 +533,17 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
-                        st[kb][4 * g + 0] = bv.x; st[kb][4 * g + 1] = bv.y; st[kb][4 * g + 2] = bv.z; st[kb][4 * g + 3] = bv.w;
+                        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+                        if (BIAS) {
+                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c] + bias_at(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c];
+                        }
 #pragma unroll
                         for (int c = 0; c < 4; ++c) dpt[kb][4 * g + c] = 0.f;
                     }
@@ -464,6 +565,45 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                         if (diag && kb * 32 + drow(r, lh) > qb * 32 + lr) pv = 0.f;
                         st[kb][r] = pv * (dpt[kb][r] + dlt[qb]);                                           // dS^T (unscaled)
                     }
+                if (BIAS) {
+                    // table gradient: every pair adds its dS to the slot it read.  wlo .. whi = byte offsets this pass can touch.
+                    const int wlo = qmin4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 2 + 1]), whi = qmax4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 2]);
+                    const bool windowed = (whi - wlo) <= (WCAP - 2) * 4;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float ds = st[kb][4 * g + c];
+                                const bool sp = (aq[qb] & kav[c]) != 0;
+                                const int voff = kq4[qb] - kkv[c];
+                                if (windowed) {
+                                    const int la = sp ? 0 : voff - wlo + 4;                                    // bytes into this wave's window
+                                    __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(win) + la), ds,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                } else if (ds != 0.f) {
+                                    const unsigned gi = sp ? 0u : (unsigned)voff >> 2;
+                                    if (gi < (unsigned)p.LT) unsafeAtomicAdd(part + gi, ds);
+                                }
+                            }
+                        }
+                    if (windowed) {
+                        const int n = ((whi - wlo) >> 2) + 1, g0 = wlo >> 2;
+                        for (int e = lane; e < n; e += 64) {
+                            const float v = win[1 + e];
+                            const int gi = g0 + e;
+                            if (v != 0.f) {
+                                win[1 + e] = 0.f;
+                                if (gi >= 1 && gi < p.LT) part[gi] += v;
+                            }
+                        }
+                        __builtin_amdgcn_s_waitcnt(0x0F70);                                                    // vmcnt(0): the partial is re-read next pass
+                    }
+                }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -481,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     }
 
     if (!active) return;
+    if (BIAS && lane == 0 && win[0] != 0.f) unsafeAtomicAdd(part, win[0]);                                     // special-pair slot
     const float sc = p.scale;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -505,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 //   dV^T (d x keys) += dO^T P ;  dK^T (d x keys) += Q^T dS  (x scale at the end); then summed over the heads through LDS.
 // LDS stage: per head Q tile [64 q][64 d] + dO tile (16 KB) -> 64 KB / stage, 2 stages.
 // ------------------------------------------------------------------------------------------------------------------
+template <bool BIAS>
 __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB
 
@@ -562,6 +704,15 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     const int key_eff = kvalid ? key : 0x7fffffff;                       // a masked / out-of-range key "follows" every query
+    int kk4l = 0, kal = 0;
+    __amdgpu_buffer_rsrc_t rsT = rsL, rsKQ = rsL, rsAQ = rsL;
+    if (BIAS) {
+        rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tbl + (long long)hclamp * p.LT), 0, p.LT * 4, 0x00020000);
+        rsKQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.qkey4), 0, p.N * 4, 0x00020000);
+        rsAQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.qattr), 0, p.N * 4, 0x00020000);
+        kk4l = p.kkey4[min(key, p.N - 1)];
+        kal = p.kattr[min(key, p.N - 1)];
+    }
 
     stage(kblk, 0);
     __syncthreads();
@@ -589,6 +740,12 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     for (int c = 0; c < 4; ++c) {
                         s[qb][4 * g + c] = __uint_as_float(lraw[c]);
                         dp[qb][4 * g + c] = __uint_as_float(draw[c]);
+                    }
+                    if (BIAS) {                                                         // rows >= N read offset 0 -> an out-of-table gather -> 0
+                        const u32x4 kq = __builtin_amdgcn_raw_buffer_load_b128(rsKQ, qq0 * 4, 0, 0);
+                        const u32x4 aqv = __builtin_amdgcn_raw_buffer_load_b128(rsAQ, qq0 * 4, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) s[qb][4 * g + c] += bias_at(rsT, (int)kq[c], kk4l, (int)aqv[c], kal);
                     }
                 }
 #pragma unroll
@@ -655,6 +812,26 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
+// dtbl[h][t] = sum over (batch element, query block) of the dQ kernel's per-workgroup partial tables
+__global__ __launch_bounds__(256) void bias_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtbl, int B, int HG, int nqb,
+                                                               int H, int LT, float scale) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (t >= LT) return;
+    const int hg = h / HPB, w = h % HPB;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* pp = part + ((((long long)b * HG + hg) * nqb) * HPB + w) * LT + t;
+        int qb = 0;
+        for (; qb + 1 < nqb; qb += 2) {
+            s0 += pp[(long long)qb * HPB * LT];
+            s1 += pp[(long long)(qb + 1) * HPB * LT];
+        }
+        if (qb < nqb) s0 += pp[(long long)qb * HPB * LT];
+    }
+    dtbl[(long long)h * LT + t] = (s0 + s1) * scale;               // the partials hold sums of dS; sim = scale * (q.k + tbl)
+}
+
 }  // namespace
 
 static int check_attn(int B, int N, int H, long long ldq, long long ldk, long long ldv, long long ldo) {
@@ -666,9 +843,18 @@ static int check_attn(int B, int N, int H, long long ldq, long long ldk, long lo
 
 extern "C" int alm_mqa_head_groups(int H) { return (H + HPB - 1) / HPB; }
 
-extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
-                                const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
-                                float scale, void* stream) {
+struct BiasArgs { const float* tbl; int LT; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part; };
+
+static int check_bias(const BiasArgs& ba, bool bwd) {
+    if (!ba.tbl) return 0;
+    if (ba.LT < 2 || ba.LT > (1 << 28) || !ba.qkey4 || !ba.kkey4 || !ba.qattr || !ba.kattr || (bwd && !ba.dtbl_part)) return ALM_ERR_BAD_ARG;
+    if (((uintptr_t)ba.qkey4 & 15) || ((uintptr_t)ba.qattr & 15)) return ALM_ERR_BAD_ARG;                // read 4 rows at a time (dK/dV kernel)
+    return 0;
+}
+
+static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                         const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
+                         float scale, const BiasArgs& ba, void* stream) {
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
@@ -676,22 +862,28 @@ extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, lon
     AttnParams p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.mask = mask; p.o = (bf16_t*)o; p.lse = lse;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
+    rc = check_bias(ba, false);
+    if (rc) return rc;
+    p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
     const int nqb = (N + 63) / 64;
-    hipLaunchKernelGGL(mqa_fwd_kernel, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_fwd_kernel<true>, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(mqa_fwd_kernel<false>, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
 // dk / dv: fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 valid columns each; partial g at + g * part_stride floats);
 // the caller (alm_kv_grad_pack) adds the partials.  delta: fp32 workspace [2][B][H][N].
-extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
-                                const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
-                                void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
-                                int N, int H, int dim_head, float scale, void* stream) {
+static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                         const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
+                         void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
+                         int N, int H, int dim_head, float scale, const BiasArgs& ba, void* stream) {
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
     if ((lddo & 7) || (lddq & 3) || (long long)N * lddo * 2 >= 0x7fffffffLL) return ALM_ERR_BAD_ARG;
+    rc = check_bias(ba, true);
+    if (rc) return rc;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7)) return ALM_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     float* ndelta = delta;
@@ -703,15 +895,67 @@ extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, lon
     p.dout = (const bf16_t*)dout; p.ndelta = ndelta; p.nlse = nlse; p.dq = (bf16_t*)dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.part_stride = part_stride;
     p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
+    p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr; p.dtbl_part = ba.dtbl_part;
     const int nqb = (N + 63) / 64;
-    hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
+    else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<false>, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                                const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
+                                float scale, void* stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{}, stream);
+}
+
+extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                                const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
+                                void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
+                                int N, int H, int dim_head, float scale, void* stream) {
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
+                         scale, BiasArgs{}, stream);
+}
+
+// Same contractions with the structured score bias described at the top of this file.  tbl: fp32 [H][LT] in raw-score units (bias /
+// scale), slot 0 = the value of "special" pairs; qkey4 / kkey4 / qattr / kattr: int32 [N] (16-B aligned), shared by the batch.
+extern "C" int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                                     const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
+                                     float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr,
+                                     const int* kattr, void* stream) {
+    if (!tbl) return ALM_ERR_BAD_ARG;
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, nullptr},
+                         stream);
+}
+
+// dtbl_part: fp32 [alm_attn_bias_part_rows(B, N, H)][LT] per-workgroup partial table gradients, ACCUMULATED into (zero it before the
+// first layer's backward, call alm_attn_bias_grad_reduce after the last: every layer of a stack shares one bias table).
+extern "C" int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                                     const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout,
+                                     long long lddo, void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride,
+                                     float* delta, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT, const int* qkey4,
+                                     const int* kkey4, const int* qattr, const int* kattr, float* dtbl_part, void* stream) {
+    if (!tbl) return ALM_ERR_BAD_ARG;
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
+                         scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, dtbl_part}, stream);
+}
+
+extern "C" int alm_attn_bias_part_rows(int B, int N, int H) { return B * alm_mqa_head_groups(H) * ((N + 63) / 64) * HPB; }
+
+// dtbl fp32 [H][LT] = scale * sum of the partial tables (= d loss / d tbl; the partials accumulate the un-scaled dS)
+extern "C" int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, int B, int N, int H, int LT, float scale, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0 || LT <= 0) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bias_grad_reduce_kernel, dim3((LT + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, dtbl_part, dtbl, B,
+                       alm_mqa_head_groups(H), (N + 63) / 64, H, LT, scale);
     ALM_LAUNCH_CHECK();
     return 0;
 }

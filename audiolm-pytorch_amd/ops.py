@@ -192,23 +192,58 @@ def geglu_ln_bwd(dhn, u, gamma, mean, rstd, inner, inner_pad):
 
 # ------------------------------------------------------------------------------------------------ attention
 
-def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64):
-    """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse)."""
+def _bias_args(bias, N, H):
+    """bias: object with tbl fp32 [H, LT] and int32 [N] qkey4 / kkey4 / qattr / kattr (relpos.AttnBias)."""
+    tbl = _chk(bias.tbl, F32)
+    assert tbl.dim() == 2 and tbl.shape[0] == H and tbl.is_contiguous(), tbl.shape
+    for t in (bias.qkey4, bias.kkey4, bias.qattr, bias.kattr):
+        _chk(t, torch.int32)
+        assert t.shape == (N,) and t.is_contiguous(), (t.shape, N)
+    return (tbl.data_ptr(), tbl.shape[1], bias.qkey4.data_ptr(), bias.kkey4.data_ptr(), bias.qattr.data_ptr(), bias.kattr.data_ptr())
+
+
+def attn_bias_part(B, N, H, LT, device):
+    """zeroed per-workgroup partial tables the biased attention backward accumulates the table gradient into"""
+    return torch.zeros((_lib.query('alm_attn_bias_part_rows', B, N, H), LT), dtype=F32, device=device)
+
+
+def attn_bias_grad_reduce(part, B, N, H, dim_head=64):
+    LT = part.shape[1]
+    dtbl = torch.empty((H, LT), dtype=F32, device=part.device)
+    _lib.call('alm_attn_bias_grad_reduce', part.data_ptr(), dtbl.data_ptr(), B, N, H, LT, float(dim_head) ** -0.5, _st())
+    return dtbl
+
+
+def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None):
+    """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse).
+    bias: structured score bias (see alm_mqa_attn_bias_fwd) or None."""
     _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
     o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, N), dtype=F32, device=q.device)
+    if bias is not None:
+        _lib.call('alm_mqa_attn_bias_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
+                  o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), _st())
+        return o, lse
     _lib.call('alm_mqa_attn_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
               o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
     return o, lse
 
 
-def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64):
-    """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them)."""
+def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None):
+    """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them).
+    With `bias`, the table gradient is accumulated into dtbl_part (attn_bias_part)."""
     _chk(dout, BF16)
     dq = torch.empty_like(q)
     hg = _lib.query('alm_mqa_head_groups', H)
     dkv = torch.empty((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
     delta = torch.empty((2, B, H, N), dtype=F32, device=q.device)
+    if bias is not None:
+        assert dtbl_part is not None and dtbl_part.shape[1] == bias.tbl.shape[1] and dtbl_part.is_contiguous()
+        _lib.call('alm_mqa_attn_bias_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask),
+                  o.data_ptr(), o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
+                  dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5,
+                  *_bias_args(bias, N, H), dtbl_part.data_ptr(), _st())
+        return dq, dkv
     _lib.call('alm_mqa_attn_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
               o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
               dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
@@ -231,6 +266,71 @@ def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
     _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(1), nparts, dkv_f32.stride(0),
               _p(acc_v0), out.data_ptr(), out.stride(0), rows, dim_head, mode, _st())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ position-bias table MLPs
+
+def posmlp_in_fwd(x, W, b):
+    """x fp32 [L, in]; W fp32 [C, in]; b [C] -> (pre fp32 [L, C], act bf16 [L, C] = silu(pre))."""
+    _chk(x, F32), _chk(W, F32), _chk(b, F32)
+    L, ind = x.shape
+    C = W.shape[0]
+    assert W.shape == (C, ind) and x.is_contiguous() and W.is_contiguous()
+    pre = torch.empty((L, C), dtype=F32, device=x.device)
+    act = torch.empty((L, C), dtype=BF16, device=x.device)
+    _lib.call('alm_posmlp_in_fwd', x.data_ptr(), W.data_ptr(), b.data_ptr(), pre.data_ptr(), act.data_ptr(), L, ind, C, _st())
+    return pre, act
+
+
+def posmlp_in_bwd(dpre, x):
+    """-> (dW fp32 [C, in], db [C])"""
+    _chk(dpre, BF16), _chk(x, F32)
+    L, C = dpre.shape
+    ind = x.shape[1]
+    chunks = _lib.query('alm_posmlp_in_bwd_chunks', L)
+    part = torch.empty((chunks, (1 + ind) * C), dtype=F32, device=x.device)
+    _lib.call('alm_posmlp_in_bwd', dpre.data_ptr(), x.data_ptr(), part.data_ptr(), L, ind, C, _st())
+    s = colsum(part)
+    return s[C:].view(ind, C).t().contiguous(), s[:C]
+
+
+def silu_fwd(pre):
+    _chk(pre, F32)
+    act = torch.empty(pre.shape, dtype=BF16, device=pre.device)
+    _lib.call('alm_silu_fwd', pre.data_ptr(), act.data_ptr(), pre.numel(), _st())
+    return act
+
+
+def silu_bwd(dact, pre):
+    _chk(dact, F32), _chk(pre, F32)
+    dpre = torch.empty(pre.shape, dtype=BF16, device=pre.device)
+    _lib.call('alm_silu_bwd', dact.data_ptr(), pre.data_ptr(), dpre.data_ptr(), pre.numel(), _st())
+    return dpre
+
+
+def posmlp_out_fwd(act, W, b, special, inv_scale):
+    """act bf16 [L, C]; W fp32 [H, C]; b [H]; special fp32 [H] | None -> tbl fp32 [H, L + 1] (x inv_scale, slot 0 = special)."""
+    _chk(act, BF16), _chk(W, F32), _chk(b, F32)
+    L, C = act.shape
+    H = W.shape[0]
+    tbl = torch.empty((H, L + 1), dtype=F32, device=act.device)
+    _lib.call('alm_posmlp_out_fwd', act.data_ptr(), W.data_ptr(), b.data_ptr(), _p(special), tbl.data_ptr(), L, C, H, float(inv_scale), _st())
+    return tbl
+
+
+def posmlp_out_bwd(dtbl, W, pre, inv_scale):
+    """-> (g bf16 [L, Hp] = d(loss)/d(last-layer output), dpre bf16 [L, C] for the layer below, dspecial fp32 [H])."""
+    _chk(dtbl, F32), _chk(W, F32), _chk(pre, F32)
+    H, LT = dtbl.shape
+    L, C = pre.shape
+    assert LT == L + 1 and dtbl.is_contiguous()
+    Hp = (H + 7) // 8 * 8
+    g = torch.empty((L, Hp), dtype=BF16, device=pre.device)
+    dpre = torch.empty((L, C), dtype=BF16, device=pre.device)
+    dsp = torch.empty(H, dtype=F32, device=pre.device)
+    _lib.call('alm_posmlp_out_bwd', dtbl.data_ptr(), W.data_ptr(), pre.data_ptr(), g.data_ptr(), dpre.data_ptr(), dsp.data_ptr(), L, C, H, Hp,
+              float(inv_scale), _st())
+    return g, dpre, dsp
 
 
 # ------------------------------------------------------------------------------------------------ hyper-connections

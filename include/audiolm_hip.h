@@ -93,6 +93,36 @@ int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk,
                      void* stream);
 /* number of head groups (4 heads each) = number of dk / dv partials the backward writes */
 int alm_mqa_head_groups(int H);
+/* The same attention with the STRUCTURED SCORE BIAS of the `flash_attn=False` models -- Attend.forward's `sim + attn_bias` (attend.py:118-
+ * 121) with the bias tensors of RelativePositionBias (audiolm_pytorch.py:202-242), the Coarse cross-attention override (:924-936) and the
+ * Fine (frame, quantizer) table (:1227-1298) -- without ever materialising the (h, n, n) tensor:
+ *     bias(h, i, j) = (qattr[i] & kattr[j]) ? tbl[h][0] : tbl[h][(qkey4[i] - kkey4[j]) / 4]
+ * tbl fp32 [H][LT] in raw-score units (bias / scale; slot 0 = cross_attn_bias / null_pos_bias); qkey4 / kkey4 / qattr / kattr int32 [N]
+ * (16-byte aligned, shared by the batch; qkey4 - kkey4 is a BYTE offset into a table row, offsets outside [0, 4 LT) read 0).
+ * Backward additionally accumulates d(loss)/d(tbl) into dtbl_part [alm_attn_bias_part_rows(B, N, H)][LT] (per-workgroup partial tables:
+ * zero before the first layer, alm_attn_bias_grad_reduce after the last -- all layers of a stack share one table). */
+int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
+                          void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT,
+                          const int* qkey4, const int* kkey4, const int* qattr, const int* kattr, void* stream);
+int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
+                          const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq,
+                          float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head,
+                          float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr, const int* kattr,
+                          float* dtbl_part, void* stream);
+int alm_attn_bias_part_rows(int B, int N, int H);
+int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, int B, int N, int H, int LT, float scale, void* stream);
+/* The small MLPs that produce `tbl` (RelativePositionBias.net audiolm_pytorch.py:214-221, FineTransformer.pos_bias_mlp :1065-1071): first
+ * layer (in_dim 1 or 2 -> C) + SiLU, SiLU forward / backward for the C x C layers (which run on alm_gemm_*), last layer (C -> H) written
+ * straight into the table layout [H][L + 1] (x inv_scale, slot 0 = special * inv_scale), and their backward passes. */
+int alm_posmlp_in_fwd(const float* x, const float* W, const float* b, float* pre, void* act_bf16, int L, int in_dim, int C, void* stream);
+int alm_posmlp_in_bwd_chunks(int L);
+int alm_posmlp_in_bwd(const void* dpre_bf16, const float* x, float* partial, int L, int in_dim, int C, void* stream);
+int alm_silu_fwd(const float* pre, void* act_bf16, long long n, void* stream);
+int alm_silu_bwd(const float* dact, const float* pre, void* dpre_bf16, long long n, void* stream);
+int alm_posmlp_out_fwd(const void* act_bf16, const float* W, const float* b, const float* special, float* tbl, int L, int C, int H,
+                       float inv_scale, void* stream);
+int alm_posmlp_out_bwd(const float* dtbl, const float* W, const float* pre, void* g_bf16, void* dpre_bf16, float* dspecial, int L, int C, int H,
+                       int Hp, float inv_scale, void* stream);
 /* value residual, audiolm_pytorch.py:353-358 / :534-535 */
 int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long long ldv0, void* out, long long ldo, long long rows,
                            int dim_head, void* stream);

@@ -1,4 +1,4 @@
-"""Measures the REAL reference's own bf16-autocast noise: for every flash golden fixture, runs the reference wrapper under
+"""Measures the REAL reference's own bf16-autocast noise: for every model-level golden fixture, runs the reference wrapper under
 torch.autocast('cpu', dtype=bfloat16) (what trainer.py:1241 `accelerator.autocast()` does) and records how far its loss / gradients
 move from its own fp32 run.  The GPU parity tests bound the HIP path's deviation by max(fixed tolerance, 2 x this noise).
 Build-container only.  Output: tests/golden/bf16_noise.pt
@@ -39,7 +39,8 @@ def run(fx, autocast):
 
 def main():
     out = {}
-    for name in ('semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_flash_mask', 'fine_s4_flash'):
+    for name in ('semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_flash_mask', 'fine_s4_flash',
+                 'coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask'):
         fx = torch.load(os.path.join(HERE, name + '.pt'), weights_only=False)
         l32, g32 = run(fx, False)
         l16, g16 = run(fx, True)

@@ -1,0 +1,206 @@
+"""Structured attention bias (`flash_attn=False` models) on a real MI355X, through the C ABI:
+  * alm_mqa_attn_bias_fwd / _bwd / alm_attn_bias_grad_reduce vs the fp32 oracle attention fed the DENSE (h, n, n) bias tensor the
+    reference would build (oracle/audiolm_oracle.py: attend, rel_pos_bias, coarse / fine bias), incl. the table gradient;
+  * the table MLP (alm_posmlp_* + GEMMs, relpos.PosTableFn) vs the same MLP in fp32 PyTorch autograd;
+  * index-vector builders vs the oracle's dense bias (exact slot agreement).
+Tolerances: attention outputs / dq / dk / dv as in test_gpu_kernels (bf16 operands: 1.2e-2 / 2e-2 rel-max); table gradient 1e-2 rel-max
+(fp32 sums of dS = P (dP - delta), P and dP from bf16 operands); MLP table 1e-2 rel-max, MLP parameter gradients 5e-2 rel-Frobenius
+(bf16 GEMM operands, the precision the reference's autocast gives these Linears; first-layer bias / weight gradients pass through three bf16
+roundings of the chain: 5e-2, cf. the reference's own bf16 noise of 3-9 % on these tensors in tests/golden/bf16_noise.pt).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import audiolm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+SCALE = 64 ** -0.5
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd import ops as o
+    return o
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=F32):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+def relmax(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def dense_bias(tbl, index):
+    """(h, n, n) score bias (already x scale, i.e. what the reference adds to sim) from a raw-score-unit table + index vectors."""
+    qkey4, kkey4, qattr, kattr = [t.long() for t in index]
+    LT = tbl.shape[1]
+    slot = (qkey4[:, None] - kkey4[None, :]) // 4
+    ok = (slot >= 0) & (slot < LT)
+    slot = torch.where((qattr[:, None] & kattr[None, :]) != 0, torch.zeros_like(slot), slot)
+    vals = tbl[:, slot.clamp(0, LT - 1)]
+    vals = torch.where(ok[None] | ((qattr[:, None] & kattr[None, :]) != 0)[None], vals, torch.zeros_like(vals))
+    return vals * SCALE
+
+
+def make_index(kind, N):
+    from audiolm_pytorch_amd import relpos
+    if kind == 'toeplitz':
+        return relpos.toeplitz_index(N, dev()), 2 * N
+    if kind == 'coarse':
+        return relpos.toeplitz_index(N, dev(), num_leading=N // 3 + 1), 2 * N
+    Qc, Qf = 3, 5
+    nf = (N - 2) * 5 // 8
+    n = N - 2 - nf
+    grid, index = relpos.fine_index(n, nf, Qc, Qf, dev())
+    return index, grid.shape[0] + 1
+
+
+@pytest.mark.parametrize('kind', ['toeplitz', 'coarse', 'fine'])
+@pytest.mark.parametrize('B,N,H,use_mask', [(2, 37, 8, False), (2, 200, 8, True), (1, 512, 8, False), (3, 130, 6, True), (1, 1030, 8, True), (2, 96, 3, False)])
+def test_biased_attention_fwd_bwd(ops, kind, B, N, H, use_mask):
+    from audiolm_pytorch_amd import relpos
+    d = 64
+    q = rnd(B * N, H * d, seed=32, dtype=BF16)
+    kv = rnd(B * N, 2 * d, seed=33, dtype=BF16)
+    k, v = kv[:, :d], kv[:, d:]
+    index, LT = make_index(kind, N)
+    tbl = rnd(H, LT, seed=34, scale=6.0)                              # raw-score units: bias = tbl / 8 ~ N(0, 0.75^2)
+    mask = None
+    if use_mask:
+        g = torch.Generator().manual_seed(35)
+        mask = (torch.rand(B, N, generator=g) > 0.25)
+        mask[:, 0] = True
+        mask = mask.to(dev())
+    mu8 = None if mask is None else mask.contiguous().view(torch.uint8)
+    bias = relpos.AttnBias(tbl, *index)
+    o, lse = ops.mqa_attn_fwd(q, k, v, mu8, B, N, H, d, bias=bias)
+
+    qf = q.float().clone().requires_grad_(True)
+    kf = k.float().clone().requires_grad_(True)
+    vf = v.float().clone().requires_grad_(True)
+    tf = tbl.clone().requires_grad_(True)
+    ref = O.attend(qf.view(B, N, H, d).permute(0, 2, 1, 3), kf.view(B, N, d), vf.view(B, N, d), mask=mask, attn_bias=dense_bias(tf, index), causal=True)
+    ref2 = ref.permute(0, 2, 1, 3).reshape(B * N, H * d)
+    e = relmax(o, ref2)
+    assert e <= 1.2e-2, f'{kind}: biased attention fwd rel-max err {e}'
+    do = rnd(B * N, H * d, seed=36, dtype=BF16)
+    ref2.backward(do.float())
+    part = ops.attn_bias_part(B, N, H, LT, dev())
+    dq, dkv_parts = ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d, bias=bias, dtbl_part=part)
+    dkv = dkv_parts.sum(0)
+    for name, got, want in (('dq', dq, qf.grad), ('dk', dkv[:, :d], kf.grad), ('dv', dkv[:, d:], vf.grad)):
+        e = relmax(got, want)
+        assert e <= 2e-2, f'{kind}: biased attention bwd {name} rel-max err {e}'
+    dtbl = ops.attn_bias_grad_reduce(part, B, N, H)
+    want = tf.grad
+    e = relmax(dtbl, want)
+    assert e <= 1e-2, f'{kind}: table gradient rel-max err {e}'
+    if kind != 'toeplitz':
+        e0 = float((dtbl[:, 0] - want[:, 0]).abs().max() / want[:, 0].abs().max().clamp(min=1e-30))
+        assert e0 <= 3e-2, f'{kind}: special-slot gradient rel err {e0}'          # one heavily cancelling sum over every special pair
+    # a second layer accumulates into the same partials: reduce(2 x) == 2 x reduce
+    ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d, bias=bias, dtbl_part=part)
+    assert relmax(ops.attn_bias_grad_reduce(part, B, N, H), 2 * dtbl) <= 1e-5
+    # the un-biased entry points are untouched by a zero table
+    zb = relpos.AttnBias(torch.zeros_like(tbl), *index)
+    o0, lse0 = ops.mqa_attn_fwd(q, k, v, mu8, B, N, H, d, bias=zb)
+    o1, lse1 = ops.mqa_attn_fwd(q, k, v, mu8, B, N, H, d)
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+
+
+def test_index_vectors_match_oracle_dense_bias():
+    """relpos.toeplitz_index / fine_index + a table == the dense tensors oracle.rel_pos_bias / coarse override / fine_attn_bias gather."""
+    from audiolm_pytorch_amd import relpos
+    g = torch.Generator().manual_seed(41)
+    H, n = 4, 23
+    # Semantic / Coarse: table rows = MLP output on -(n-1) .. n-1
+    T = torch.randn(2 * n - 1, H, generator=g)
+    tbl = torch.cat((torch.full((H, 1), 7.5), T.t() / SCALE), dim=1).to(dev())
+    i_pos = torch.arange(n)
+    rel = i_pos[:, None] - i_pos[None, :] + n - 1
+    want = T[rel].permute(2, 0, 1)
+    got = dense_bias(tbl, relpos.toeplitz_index(n, dev())).cpu()
+    causal = torch.ones(n, n, dtype=torch.bool).tril()
+    assert torch.allclose(got[:, causal], want[:, causal], atol=1e-5)
+    ns1 = 9
+    is_sem = torch.arange(n) < ns1
+    cross = is_sem[:, None] ^ is_sem[None, :]
+    want_c = torch.where(cross, torch.tensor(7.5 * SCALE), want)
+    got_c = dense_bias(tbl, relpos.toeplitz_index(n, dev(), num_leading=ns1)).cpu()
+    assert torch.allclose(got_c[:, causal], want_c[:, causal], atol=1e-5)
+    # Fine: oracle.fine_attn_bias with an identity-like "MLP" replaced by a random table -> compare slots through the oracle's own index maths
+    Qc, Qf = 3, 5
+    for (nc, nf) in ((12, 20), (11, 17), (3, 1), (30, 4)):
+        grid, index = relpos.fine_index(nc, nf, Qc, Qf, dev())
+        L = grid.shape[0]
+        Tf = torch.randn(L, H, generator=g)
+        sd = {'null_pos_bias': torch.full((H, 1, 1), -3.25)}
+        # restate oracle.fine_attn_bias' gather with the random table in place of the MLP output
+        cs, fs = -(-nc // Qc), -(-nf // Qf)
+        M, Qt = max(cs, fs), Qc + Qf
+        R = 2 * Qt - 1
+        c_pos = F.pad(torch.arange(cs).repeat_interleave(Qc)[:nc], (1, 0), value=-1)
+        f_pos = F.pad(torch.arange(fs).repeat_interleave(Qf)[:nf], (1, 0), value=-1)
+        c_off = F.pad(torch.arange(Qc).repeat(cs)[:nc], (1, 0), value=0)
+        f_off = F.pad(torch.arange(Qf).repeat(fs)[:nf] + Qc, (1, 0), value=0)
+        pos, off = torch.cat((c_pos, f_pos)), torch.cat((c_off, f_off))
+        pin = torch.stack((pos.clamp(min=0), off), dim=-1)
+        rd = pin[:, None, :] - pin[None, :, :]
+        idx = (rd[..., 0] + M - 1) * R + (rd[..., 1] + Qt - 1)
+        want_f = Tf[idx].permute(2, 0, 1)
+        st = pos == -1
+        want_f = torch.where(st[:, None] | st[None, :], sd['null_pos_bias'], want_f)
+        # the MLP input grid must enumerate (rel_seq, rel_off) in table-row order
+        assert torch.equal(grid.cpu()[:, 0].long() * R + grid.cpu()[:, 1].long(), torch.arange(L))
+        tblf = torch.cat((torch.full((H, 1), -3.25 / SCALE), Tf.t() / SCALE), dim=1).to(dev())
+        got_f = dense_bias(tblf, index).cpu()
+        N = nc + nf + 2
+        causal = torch.ones(N, N, dtype=torch.bool).tril()
+        assert torch.allclose(got_f[:, causal], want_f[:, causal], atol=1e-5), (nc, nf)
+
+
+@pytest.mark.parametrize('in_dim,nhid,L,C,H', [(1, 2, 399, 32, 8), (2, 1, 1005, 64, 8), (1, 2, 4095, 512, 8), (2, 1, 300, 32, 3)])
+def test_pos_table_mlp(ops, in_dim, nhid, L, C, H):
+    from audiolm_pytorch_amd import relpos
+    g = torch.Generator().manual_seed(50)
+    if in_dim == 1:
+        x = torch.arange(-(L // 2), L - L // 2).float().unsqueeze(-1)
+    else:
+        x = torch.stack((torch.arange(L) // 15, torch.arange(L) % 15), dim=-1).float()
+    dims = [in_dim] + [C] * (nhid + 1) + [H]
+    ws = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        bound = a ** -0.5
+        ws += [(torch.rand(b, a, generator=g) * 2 - 1) * bound, (torch.rand(b, generator=g) * 2 - 1) * bound]
+    special = torch.randn(H, 1, 1, generator=g)
+    ws_g = [w.to(dev()).requires_grad_(True) for w in ws]
+    sp_g = special.to(dev()).requires_grad_(True)
+    tbl = relpos.PosTableFn.apply(x.to(dev()), sp_g, 8.0, *ws_g)
+    # fp32 reference
+    ws_r = [w.clone().requires_grad_(True) for w in ws]
+    sp_r = special.clone().requires_grad_(True)
+    h = x
+    for li in range(nhid + 1):
+        h = F.silu(F.linear(h, ws_r[2 * li], ws_r[2 * li + 1]))
+    out = F.linear(h, ws_r[-2], ws_r[-1])
+    ref = torch.cat((sp_r.reshape(H, 1), out.t()), dim=1) * 8.0
+    e = relmax(tbl.cpu(), ref)
+    assert e <= 1e-2, f'table rel-max err {e}'
+    dt = torch.randn(H, L + 1, generator=g)
+    tbl.backward(dt.to(dev()))
+    ref.backward(dt)
+    for i, (a, b) in enumerate(zip(ws_g, ws_r)):
+        err = float((a.grad.cpu().double() - b.grad.double()).norm() / b.grad.double().norm().clamp(min=1e-30))
+        assert err <= 5e-2, f'MLP parameter {i} grad rel-frob {err}'
+    assert relmax(sp_g.grad.cpu(), sp_r.grad) <= 1e-5

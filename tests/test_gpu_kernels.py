@@ -67,7 +67,7 @@ def test_gemm_nt_tile_configs(ops, M, N, K, tile):
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (512, 1024, 4096), (130, 200, 100), (1025, 256, 333), (2730, 1024, 2048), (128, 1024, 16384),
-                                   (1024, 2730, 777)])
+                                   (1024, 2730, 777), (8, 512, 4095), (32, 32, 29)])
 def test_gemm_tn_splitk(ops, M, N, K):
     """weight-gradient contraction over the ROW index of both operands (LDS transpose reads), incl. strided views, ragged M / N / K."""
     Abig, Bbig = rnd(K, (M + 23) // 8 * 8, seed=13, dtype=BF16), rnd(K, (N + 15) // 8 * 8, seed=14, dtype=BF16)

@@ -127,9 +127,11 @@ def grad_report(items, report, gtol=3e-2):
 
 
 FLASH_FIXTURES = ['semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_flash_mask', 'fine_s4_flash']
+# `flash_attn=False` (reference default) models: attention bias from RelativePositionBias / cross_attn_bias / pos_bias_mlp + null_pos_bias
+BIAS_FIXTURES = ['coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask']
 
 
-@pytest.mark.parametrize('name', FLASH_FIXTURES)
+@pytest.mark.parametrize('name', FLASH_FIXTURES + BIAS_FIXTURES)
 def test_hip_path_matches_reference_golden(name):
     fx = _load(name)
     loss, logits, grads = ours_run(fx)
@@ -237,6 +239,36 @@ def test_semantic_cfg0_shape_on_gpu_vs_oracle():
     ids = torch.randint(0, 500, (8, 255), generator=g)
     res = _oracle_vs_ours('semantic', ctor, dict(ids=ids, forgetful_mask=None), dict(training=True, unique_consecutive=False, mask_prob=0.), seed=3)
     _check('semantic cfg0 shape', *res)
+
+
+def test_semantic_default_ctor_rel_pos_bias_vs_oracle():
+    """The reference's DEFAULT constructor (flash_attn=False, rel_pos_bias=True): several 64-wide attention tiles, forgetful mask."""
+    g = torch.Generator().manual_seed(4)
+    ctor = dict(dim=128, depth=2, num_semantic_tokens=500)
+    ids = torch.randint(0, 500, (2, 299), generator=g)
+    mask = O.generate_mask_with_prob((2, 301), 0.15, 'cpu', generator=g)          # start token + 299 ids + eos
+    res = _oracle_vs_ours('semantic', ctor, dict(ids=ids, forgetful_mask=mask), dict(training=True, unique_consecutive=False, mask_prob=0.15), seed=5)
+    _check('semantic default ctor (rel_pos_bias) N=301', *res)
+
+
+def test_coarse_default_ctor_cross_attn_bias_vs_oracle():
+    g = torch.Generator().manual_seed(6)
+    ctor = dict(dim=128, depth=2, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3)
+    sem = torch.randint(0, 500, (2, 90), generator=g)
+    coarse = torch.randint(0, 1024, (2, 50, 3), generator=g)
+    res = _oracle_vs_ours('coarse', ctor, dict(semantic_token_ids=sem, coarse_token_ids=coarse, forgetful_mask=None),
+                          dict(training=True, unique_consecutive=False, mask_prob=0.), seed=7)
+    _check('coarse default ctor (rel_pos_bias + cross_attn_bias)', *res)
+
+
+def test_fine_default_ctor_pos_bias_mlp_vs_oracle():
+    g = torch.Generator().manual_seed(8)
+    ctor = dict(dim=128, depth=2, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024)
+    coarse = torch.randint(0, 1024, (2, 30, 3), generator=g)
+    fine = torch.randint(0, 1024, (2, 30, 5), generator=g)
+    res = _oracle_vs_ours('fine', ctor, dict(coarse_token_ids=coarse, fine_token_ids=fine, forgetful_mask=None),
+                          dict(training=True, mask_prob=0.), seed=9)
+    _check('fine default ctor (pos_bias_mlp + null_pos_bias)', *res)
 
 
 def test_full_size_properties():
