@@ -32,6 +32,8 @@
 //     reads a slot) is accumulated by the dQ kernel: per wave, an LDS window covering the slots one (32 q x 64 key) pass can touch
 //     takes ds_add_f32 updates and is flushed into that workgroup's own partial table (plain read-modify-write: deterministic); a
 //     pass whose window would not fit falls back to global atomics on the same partial.  alm_attn_bias_grad_reduce sums the partials.
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -111,9 +113,18 @@ struct AttnParams {
 
 constexpr int WCAP = 1024;                          // floats per wave in the dQ kernel's table-gradient window (slot 0 = special pairs)
 
+// SP = false: the caller knows (wave-uniformly) that no pair of the tile is special, and skips the attribute test
+template <bool SP>
 __device__ __forceinline__ float bias_at(const __amdgpu_buffer_rsrc_t& rsT, int kq4, int kk4, int aq, int ak) {
-    const int voff = (aq & ak) ? 0 : kq4 - kk4;                          // out-of-table offsets read 0 (buffer bounds check)
+    int voff = kq4 - kk4;                                                // out-of-table offsets read 0 (buffer bounds check)
+    if (SP) voff = (aq & ak) ? 0 : voff;
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsT, voff, 0, 0));
+}
+
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // log-sum-exp -> log2 domain; a fully masked query row (lse = -inf, the forward wrote zeros) gets +inf so that every P is 0
@@ -170,10 +181,11 @@ __device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsig
 // ------------------------------------------------------------------------------------------------------------------
 template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 : 0)];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 + 64 : 0)];
     float* kbias = reinterpret_cast<float*>(smem + 32768);          // [2][64]: 0 for attendable keys, -inf otherwise
     int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] key-side attributes
     int* kas = kk4s + 128;
+    int* kor = kas + 128;                                           //       [2] OR of the staged tile's key attributes
 
     const int nqb = (p.N + 63) / 64;
     const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
@@ -205,7 +217,10 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
             if (BIAS) {
                 const int kc = min(key, p.N - 1);
                 kk4s[buf * 64 + t] = p.kkey4[kc];
-                kas[buf * 64 + t] = p.kattr[kc];
+                const int ka = p.kattr[kc];
+                kas[buf * 64 + t] = ka;
+                const int ko = wave_or(ka);
+                if (t == 0) kor[buf] = ko;
             }
         }
     };
@@ -231,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
             aq[qb] = p.qattr[qc];
         }
     }
+    const int aq_or = BIAS ? wave_or(aq[0] | aq[1]) : 0;
 
     f32x16 o[2][2];                    // [db][qb]: O^T blocks (rows = head dim, cols = queries)
 #pragma unroll
@@ -258,27 +274,33 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
 
             // S^T = K Q^T (+ key bias): [kb][qb] 32x32 blocks
             f32x16 st[2][2];
+            auto init_scores = [&](auto spc) {
+                constexpr bool SP = decltype(spc)::value;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
-                    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
-                    if (BIAS) {
-                        const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                        const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                        const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+                        if (BIAS) {
+                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            int4 ka = make_int4(0, 0, 0, 0);
+                            if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
-                        for (int qb = 0; qb < 2; ++qb)
+                            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c] + bias_at(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
-                    } else {
+                                for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c] + bias_at<SP>(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
+                        } else {
 #pragma unroll
-                        for (int qb = 0; qb < 2; ++qb)
+                            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c];
+                                for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c];
+                        }
                     }
-                }
+            };
+            if (BIAS && (aq_or & __builtin_amdgcn_readfirstlane(kor[buf])) != 0) init_scores(std::true_type{});
+            else init_scores(std::false_type{});
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     float* kbias = reinterpret_cast<float*>(smem + 32768);
     int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] attributes,
     int* kas = kk4s + 128;                                          //       [2][2] min / max offset of the staged key tile,
-    int* kmm = kas + 128;                                           //       [HPB][WCAP] per-wave table-gradient windows
+    int* kmm = kas + 128;                                           //       (+ OR of its attributes), [HPB][WCAP] per-wave table-gradient windows
     float* wins = reinterpret_cast<float*>(smem + 32768 + 512 + 1024 + 64);
 
     const int nqb = (p.N + 63) / 64;
@@ -450,14 +472,16 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                 const int kc = min(key, p.N - 1);
                 const int kv = p.kkey4[kc];
                 kk4s[buf * 64 + t] = kv;
-                kas[buf * 64 + t] = p.kattr[kc];
+                const int ka = p.kattr[kc];
+                kas[buf * 64 + t] = ka;
+                const int ko = wave_or(ka);
                 int mn = kv, mx = kv;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     mn = min(mn, __shfl_xor(mn, o, 64));
                     mx = max(mx, __shfl_xor(mx, o, 64));
                 }
-                if (t == 0) { kmm[buf * 2] = mn; kmm[buf * 2 + 1] = mx; }
+                if (t == 0) { kmm[buf * 4] = mn; kmm[buf * 4 + 1] = mx; kmm[buf * 4 + 2] = ko; }
             }
         }
     };
@@ -502,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
         }
         for (int e = lane; e < WCAP; e += 64) win[e] = 0.f;
     }
+    const int aq_or = BIAS ? wave_or(aq[0] | aq[1]) : 0;
 
     f32x16 dq[2][2];                   // [db][qb]: dQ^T blocks
 #pragma unroll
@@ -528,25 +553,32 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 f32x16 st[2], dpt[2];
+                const bool sp_tile = BIAS && (aq_or & __builtin_amdgcn_readfirstlane(kmm[buf * 4 + 2])) != 0;       // wave-uniform
+                auto init_scores = [&](auto spc) {
+                    constexpr bool SP = decltype(spc)::value;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
-                        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
-                        if (BIAS) {
-                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                            const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                            const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                            const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+                            if (BIAS) {
+                                const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                int4 ka = make_int4(0, 0, 0, 0);
+                                if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c] + bias_at(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
-                        } else {
+                                for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c] + bias_at<SP>(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
+                            } else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c];
+                                for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c];
+                            }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dpt[kb][4 * g + c] = 0.f;
                         }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) dpt[kb][4 * g + c] = 0.f;
-                    }
+                };
+                if (sp_tile) init_scores(std::true_type{});
+                else init_scores(std::false_type{});
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -567,31 +599,39 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                     }
                 if (BIAS) {
                     // table gradient: every pair adds its dS to the slot it read.  wlo .. whi = byte offsets this pass can touch.
-                    const int wlo = qmin4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 2 + 1]), whi = qmax4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 2]);
+                    const int wlo = qmin4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 4 + 1]), whi = qmax4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 4]);
                     const bool windowed = (whi - wlo) <= (WCAP - 2) * 4;
+                    const int kq4w = kq4[qb] - wlo + 4;                                                          // -> byte offset into this wave's window
+                    auto accumulate = [&](auto spc, auto wc) {
+                        constexpr bool SP = decltype(spc)::value, WIN = decltype(wc)::value;
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                            const int4 ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
-                            const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
+                            for (int g = 0; g < 4; ++g) {
+                                const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                int4 ka = make_int4(0, 0, 0, 0);
+                                if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const float ds = st[kb][4 * g + c];
-                                const bool sp = (aq[qb] & kav[c]) != 0;
-                                const int voff = kq4[qb] - kkv[c];
-                                if (windowed) {
-                                    const int la = sp ? 0 : voff - wlo + 4;                                    // bytes into this wave's window
-                                    __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(win) + la), ds,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                                } else if (ds != 0.f) {
-                                    const unsigned gi = sp ? 0u : (unsigned)voff >> 2;
-                                    if (gi < (unsigned)p.LT) unsafeAtomicAdd(part + gi, ds);
+                                for (int c = 0; c < 4; ++c) {
+                                    const float ds = st[kb][4 * g + c];
+                                    const bool sp = SP && (aq[qb] & kav[c]) != 0;
+                                    if (WIN) {
+                                        int la = kq4w - kkv[c];
+                                        if (SP) la = sp ? 0 : la;
+                                        __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(win) + la), ds, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                    } else if (ds != 0.f) {
+                                        const unsigned gi = sp ? 0u : (unsigned)(kq4[qb] - kkv[c]) >> 2;
+                                        if (gi < (unsigned)p.LT) unsafeAtomicAdd(part + gi, ds);
+                                    }
                                 }
                             }
-                        }
+                    };
                     if (windowed) {
+                        if (sp_tile) accumulate(std::true_type{}, std::true_type{});
+                        else accumulate(std::false_type{}, std::true_type{});
+                        // flush: plain read-modify-write of this workgroup's own partial (same-wave accesses to one address stay ordered)
                         const int n = ((whi - wlo) >> 2) + 1, g0 = wlo >> 2;
                         for (int e = lane; e < n; e += 64) {
                             const float v = win[1 + e];
@@ -601,7 +641,8 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                                 if (gi >= 1 && gi < p.LT) part[gi] += v;
                             }
                         }
-                        __builtin_amdgcn_s_waitcnt(0x0F70);                                                    // vmcnt(0): the partial is re-read next pass
+                    } else {
+                        accumulate(std::true_type{}, std::false_type{});
                     }
                 }
 #pragma unroll
@@ -649,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 template <bool BIAS>
 __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB
+    __shared__ int qor_s[BIAS ? 256 : 1];                                      // BIAS: OR of the query attributes of every 64-query tile
 
     const int nkb = (p.N + 63) / 64;
     const BlockId id = decode_block(blockIdx.x, nkb, p.HG, p.B, false, false);      // low key blocks are the heavy ones
@@ -712,7 +754,11 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         rsAQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.qattr), 0, p.N * 4, 0x00020000);
         kk4l = p.kkey4[min(key, p.N - 1)];
         kal = p.kattr[min(key, p.N - 1)];
+        for (int i = t; i < 256; i += 512) qor_s[i] = 0;
+        __syncthreads();
+        for (int i = t; i < p.N; i += 512) atomicOr(&qor_s[min(i >> 6, 255)], p.qattr[i]);
     }
+    const int kal_or = BIAS ? wave_or(kal) : 0;
 
     stage(kblk, 0);
     __syncthreads();
@@ -741,13 +787,25 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                         s[qb][4 * g + c] = __uint_as_float(lraw[c]);
                         dp[qb][4 * g + c] = __uint_as_float(draw[c]);
                     }
-                    if (BIAS) {                                                         // rows >= N read offset 0 -> an out-of-table gather -> 0
-                        const u32x4 kq = __builtin_amdgcn_raw_buffer_load_b128(rsKQ, qq0 * 4, 0, 0);
-                        const u32x4 aqv = __builtin_amdgcn_raw_buffer_load_b128(rsAQ, qq0 * 4, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) s[qb][4 * g + c] += bias_at(rsT, (int)kq[c], kk4l, (int)aqv[c], kal);
-                    }
                 }
+            if (BIAS) {                                                                 // rows >= N read offset 0 -> an out-of-table gather -> 0
+                auto add_bias = [&](auto spc) {
+                    constexpr bool SP = decltype(spc)::value;
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int qq0 = q0 + qb * 32 + 8 * g + 4 * lh;
+                            const u32x4 kq = __builtin_amdgcn_raw_buffer_load_b128(rsKQ, qq0 * 4, 0, 0);
+                            u32x4 aqv = {0u, 0u, 0u, 0u};
+                            if (SP) aqv = __builtin_amdgcn_raw_buffer_load_b128(rsAQ, qq0 * 4, 0, 0);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) s[qb][4 * g + c] += bias_at<SP>(rsT, (int)kq[c], kk4l, (int)aqv[c], kal);
+                        }
+                };
+                if ((__builtin_amdgcn_readfirstlane(qor_s[min(qt, 255)]) & kal_or) != 0) add_bias(std::true_type{});
+                else add_bias(std::false_type{});
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll

@@ -280,6 +280,57 @@ def bench_models():
     print(f'configs[2] FineTransformer d=1024 depth=6 N=2049 B=8: {t:.2f} ms/step -> {8 * 2049 / t * 1e3:.0f} audio-tokens/s')
 
 
+def bench_bias():
+    """`flash_attn=False` models: biased attention kernels vs the plain ones, the table MLP, and default-constructor model steps."""
+    from audiolm_pytorch_amd import relpos
+    B, N, H, dh = 8, 2048, 8, 64
+    M = B * N
+    Q, KV = rnd(M, H * dh), rnd(M, 2 * dh)
+    K_, V_ = KV[:, :dh], KV[:, dh:]
+    mask = (torch.rand(B, N, device=dev) > 0.15).to(torch.uint8)
+    mask[:, 0] = 1
+    dAO = rnd(M, H * dh)
+    AO, LSE = ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh)
+    t0f = timeit(lambda: ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh))
+    t0b = timeit(lambda: ops.mqa_attn_bwd(Q, K_, V_, mask, AO, LSE, dAO, B, N, H, dh))
+    print(f'plain attention  fwd {t0f:.3f} ms  bwd {t0b:.3f} ms')
+    grid, findex = relpos.fine_index(765, 1281, 3, 5, dev)
+    for name, index, LT in (('toeplitz', relpos.toeplitz_index(N, dev), 2 * N), ('coarse', relpos.toeplitz_index(N, dev, num_leading=1024), 2 * N),
+                            ('fine', findex, grid.shape[0] + 1)):
+        tbl = torch.randn(H, LT, device=dev)
+        bias = relpos.AttnBias(tbl, *index)
+        AOb, LSEb = ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh, bias=bias)
+        tf = timeit(lambda: ops.mqa_attn_fwd(Q, K_, V_, mask, B, N, H, dh, bias=bias))
+        part = ops.attn_bias_part(B, N, H, LT, dev)
+        tb = timeit(lambda: ops.mqa_attn_bwd(Q, K_, V_, mask, AOb, LSEb, dAO, B, N, H, dh, bias=bias, dtbl_part=part))
+        tr = timeit(lambda: ops.attn_bias_grad_reduce(part, B, N, H))
+        print(f'biased attention [{name}, LT={LT}]  fwd {tf:.3f} ms ({tf / t0f:.2f}x)  bwd {tb:.3f} ms ({tb / t0b:.2f}x)  table-grad reduce {tr:.3f} ms '
+              f'(partials {part.numel() * 4 / 2**20:.0f} MiB)')
+    rp = A.audiolm_pytorch.RelativePositionBias(dim=512, heads=8).to(dev)
+
+    def table():
+        for p in rp.parameters():
+            p.grad = None
+        b = rp(N, N)
+        b.tbl.backward(torch.ones_like(b.tbl))
+    t = timeit(table, iters=10, warm=3)
+    print(f'RelativePositionBias table MLP (4095 rows, d=512) fwd+bwd: {t:.3f} ms')
+    torch.manual_seed(0)
+    for flash in (True, False):
+        m = A.SemanticTransformer(dim=1024, depth=6, num_semantic_tokens=500, flash_attn=flash).to(dev)
+        w = A.SemanticTransformerWrapper(transformer=m, unique_consecutive=False, mask_prob=0.15)
+        w.train()
+        ids = torch.randint(0, 500, (8, 2047), device=dev)
+
+        def step():
+            for p in m.parameters():
+                p.grad = None
+            w(semantic_token_ids=ids, return_loss=True).backward()
+        t = timeit(step, iters=10, warm=3)
+        print(f'SemanticTransformer d=1024 depth=6 N=2048 B=8 flash_attn={flash}: {t:.2f} ms/step -> {8 * 2048 / t * 1e3:.0f} tokens/s')
+        del m, w
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)
