@@ -600,8 +600,23 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                 if (BIAS) {
                     // table gradient: every pair adds its dS to the slot it read.  wlo .. whi = byte offsets this pass can touch.
                     const int wlo = qmin4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 4 + 1]), whi = qmax4[qb] - __builtin_amdgcn_readfirstlane(kmm[buf * 4]);
-                    const bool windowed = (whi - wlo) <= (WCAP - 2) * 4;
+                    const bool windowed = (whi - wlo) <= (WCAP - 66) * 4;                                        // the last 64 entries are per-lane dump slots
                     const int kq4w = kq4[qb] - wlo + 4;                                                          // -> byte offset into this wave's window
+                    // The window accumulates BLOCK-SCALED INTEGERS: on gfx950 ds_add_f32 is serialised (~190 clk per wave instruction, ~3 clk per
+                    // lane: scripts/ubench/lds_atomics.hip) while ds_add_u32 runs at LDS rate (~6 clk).  Per pass: m = max |dS| over the wave,
+                    // values are scaled by the power of two that puts m just below 2^19 (<= 2048 addends per slot cannot overflow int32), rounded
+                    // to nearest, added as integers (associative: the sum does not depend on the order) and scaled back at the flush.
+                    float pmax = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, fabsf(st[kb][r]));
+                    pmax = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(pmax))));
+                    const int pex = (int)((__float_as_uint(pmax) >> 23) & 0xffu) - 127;                          // pmax < 2^(pex + 1)
+                    const int psh = min(100, max(-100, 18 - pex));
+                    const float pscale = __uint_as_float((unsigned)(127 + psh) << 23), pinv = __uint_as_float((unsigned)(127 - psh) << 23);
+                    int* iwin = reinterpret_cast<int*>(win);
+                    int spacc = 0;                                                                               // special pairs: summed in a register
                     auto accumulate = [&](auto spc, auto wc) {
                         constexpr bool SP = decltype(spc)::value, WIN = decltype(wc)::value;
 #pragma unroll
@@ -617,9 +632,14 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                                     const float ds = st[kb][4 * g + c];
                                     const bool sp = SP && (aq[qb] & kav[c]) != 0;
                                     if (WIN) {
+                                        // a special pair's lane adds into its private dump slot instead (64 lanes on slot 0 would serialise)
+                                        const int iv = __float2int_rn(ds * pscale);
                                         int la = kq4w - kkv[c];
-                                        if (SP) la = sp ? 0 : la;
-                                        __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(win) + la), ds, __ATOMIC_RELAXED,
+                                        if (SP) {
+                                            la = sp ? (WCAP - 64 + lane) * 4 : la;
+                                            spacc += sp ? iv : 0;
+                                        }
+                                        __hip_atomic_fetch_add(reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(iwin) + la), iv, __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_WAVEFRONT);
                                     } else if (ds != 0.f) {
                                         const unsigned gi = sp ? 0u : (unsigned)(kq4[qb] - kkv[c]) >> 2;
@@ -628,21 +648,29 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                                 }
                             }
                     };
-                    if (windowed) {
-                        if (sp_tile) accumulate(std::true_type{}, std::true_type{});
-                        else accumulate(std::false_type{}, std::true_type{});
-                        // flush: plain read-modify-write of this workgroup's own partial (same-wave accesses to one address stay ordered)
-                        const int n = ((whi - wlo) >> 2) + 1, g0 = wlo >> 2;
-                        for (int e = lane; e < n; e += 64) {
-                            const float v = win[1 + e];
-                            const int gi = g0 + e;
-                            if (v != 0.f) {
-                                win[1 + e] = 0.f;
-                                if (gi >= 1 && gi < p.LT) part[gi] += v;
+                    if (pmax > 0.f) {
+                        if (windowed) {
+                            if (sp_tile) accumulate(std::true_type{}, std::true_type{});
+                            else accumulate(std::false_type{}, std::true_type{});
+                            // flush into this workgroup's own partial table.  Every update of `part` is an L2 atomic issued by this one wave
+                            // (program order => deterministic), so the windowed and the fallback path can be mixed freely.
+                            const int n = ((whi - wlo) >> 2) + 2, g0 = (wlo >> 2) - 1;                           // window entry e >= 1 <-> table slot g0 + e
+                            for (int e = 1 + lane; e < n; e += 64) {
+                                const int iv = iwin[e];
+                                const int gi = g0 + e;
+                                if (iv != 0) {
+                                    iwin[e] = 0;
+                                    if (gi >= 1 && gi < p.LT) unsafeAtomicAdd(part + gi, (float)iv * pinv);
+                                }
                             }
+                            if (sp_tile) {
+#pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) spacc += __shfl_xor(spacc, o, 64);
+                                if (lane == 0 && spacc != 0) unsafeAtomicAdd(part, (float)spacc * pinv);
+                            }
+                        } else {
+                            accumulate(std::true_type{}, std::false_type{});
                         }
-                    } else {
-                        accumulate(std::true_type{}, std::false_type{});
                     }
                 }
 #pragma unroll
@@ -662,7 +690,6 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     }
 
     if (!active) return;
-    if (BIAS && lane == 0 && win[0] != 0.f) unsafeAtomicAdd(part, win[0]);                                     // special-pair slot
     const float sc = p.scale;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
