@@ -72,6 +72,7 @@ SIGNATURES = {
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
     'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'alm_rvq_padded_codes': [_I],
+    'alm_rvq_padded_dim': [_I],
     'alm_rvq_pack': [_P, _P, _P, _I, _I, _I, _P],
     'alm_rvq_encode': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     'alm_bct_to_btc': [_P, _P, _I, _I, _I, _P],

@@ -18,12 +18,29 @@
 //            transposed [d][C]), keeps a running (distance, index) minimum per frame with first-index tie-breaking, the waves'
 //            candidates are merged through LDS, the winning code vector is subtracted in place and the next quantizer starts --
 //            no intermediate tensor ever reaches HBM.
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
 namespace {
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+// ELU(alpha = 1): v > 0 ? v : exp(v) - 1, branch-free.  Near zero exp(v) - 1 cancels, so |v| < 0.35 uses the degree-8 Taylor polynomial
+// (truncation < 1e-9 relative); elsewhere exp2 (<= 2 ulp) minus one loses < 2 bits.  Agrees with expm1f to a few ulp.
+__device__ __forceinline__ float elu1(float v) {
+    const float em = __builtin_amdgcn_exp2f(v * 1.4426950408889634f) - 1.f;
+    float p = 2.48015873e-5f;                                                   // 1/8!
+    p = fmaf(p, v, 1.98412698e-4f);
+    p = fmaf(p, v, 1.38888889e-3f);
+    p = fmaf(p, v, 8.33333333e-3f);
+    p = fmaf(p, v, 4.16666667e-2f);
+    p = fmaf(p, v, 1.66666667e-1f);
+    p = fmaf(p, v, 0.5f);
+    p = fmaf(p, v, 1.f);
+    p *= v;
+    const float neg = v > -0.35f ? p : em;
+    return v > 0.f ? v : neg;
+}
 
 struct ConvArgs {
     const float* x; const float* wp; const float* bias; const float* residual; float* out;
@@ -53,50 +70,102 @@ __global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) tin[j] = (t0 + j * 32 + lr) * a.stride - a.pad;
 
-    for (int tap = 0; tap < a.ks; ++tap) {
-        int pos[2];
-        bool pok[2];
+    // The (tap, channel-pair) contraction steps are flattened into one sequence and software-pipelined by hand: two register groups of U
+    // steps, the loads of group g + 1 are issued before the MFMAs of group g.  All addressing is 32-bit buffer addressing: a per-lane byte
+    // offset that only changes with the tap (reflect-padded time index) plus a wave-uniform scalar offset per step -- no 64-bit VALU
+    // multiplies in the loop (they, not the loads, were what limited the first version).  Channels >= Cin meet zero-padded weights and
+    // read 0 past the end of this batch element's buffer; time steps >= Tout compute garbage that is never stored.
+    constexpr int U = 2;
+    const int nk = a.CinP >> 1;                                    // channel pairs per tap
+    const int nsteps = a.ks * nk, ng = (nsteps + U - 1) / U;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.Cin * a.Tin * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.ks * a.CinP * a.CoutP * 4, 0x00020000);
+    const int wvo = (lh * a.CoutP + co0 + lr) * 4;
+    int ltap = 0, lk = 0;                                          // next step to load (wave-uniform)
+    int xvo[2];
+    auto set_tap = [&](int tap) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int p = tin[j] + tap * a.dil;
             p = p < 0 ? -p : p;                                    // reflect (F.pad mode='reflect'): index -i -> i
-            pok[j] = p < a.Tin;
-            pos[j] = pok[j] ? p : 0;
+            xvo[j] = (lh * a.Tin + p) * 4;
         }
-        const float* wt = a.wp + (long long)tap * a.CinP * a.CoutP + co0 + lr;
-#pragma unroll 4
-        for (int cc = 0; cc < a.CinP; cc += 2) {                    // unrolled: 4 k-steps of loads in flight ahead of their MFMAs
-            const int ci = cc + lh;
-            float av[NA], bv[2];
+    };
+    set_tap(0);
+    float av[2][U][NA], bv[2][U][2];
+    auto load_group = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) av[i] = wt[(long long)ci * a.CoutP + i * 32];
-            const bool cok = ci < a.Cin;
+        for (int u = 0; u < U; ++u) {
+            if (ltap < a.ks) {
+                const int wso = ((ltap * a.CinP + 2 * lk) * a.CoutP) * 4, xso = (2 * lk * a.Tin) * 4;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = (cok && pok[j]) ? xb[(long long)ci * a.Tin + pos[j]] : 0.f;
+                for (int i = 0; i < NA; ++i) av[BUF][u][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, wvo + i * 128, wso, 0));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[BUF][u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, xvo[j], xso, 0));
+                if (++lk == nk) {
+                    lk = 0;
+                    ++ltap;
+                    set_tap(ltap);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) av[BUF][u][i] = 0.f;
+                bv[BUF][u][0] = bv[BUF][u][1] = 0.f;
+            }
+        }
+    };
+    auto mfma_group = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int i = 0; i < NA; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[BUF][u][i], bv[BUF][u][j], acc[i][j], 0, 0, 0);
+    };
+    load_group(std::integral_constant<int, 0>{});
+    for (int g = 0; g < ng; g += 2) {
+        if (g + 1 < ng) load_group(std::integral_constant<int, 1>{});
+        mfma_group(std::integral_constant<int, 0>{});
+        if (g + 2 < ng) load_group(std::integral_constant<int, 0>{});
+        if (g + 1 < ng) mfma_group(std::integral_constant<int, 1>{});
     }
-    // D layout: column = lane & 31 (time), row = (r & 3) + 8 * (r >> 2) + 4 * lh (output channel)
+    // D layout: column = lane & 31 (time), row = (r & 3) + 8 * (r >> 2) + 4 * lh (output channel).  Epilogue addressing is 32-bit buffer
+    // addressing too: per-lane byte offset (channel half, time) + a wave-uniform row offset; rows >= Cout fall outside the buffer and are
+    // dropped by the bounds check, lanes with t >= Tout get an out-of-range offset.
+    const long long ob = (long long)b * a.Cout * a.Tout;
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + ob, 0, a.Cout * a.Tout * 4, 0x00020000);
+    const auto rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual ? a.residual + ob : a.out + ob), 0, a.Cout * a.Tout * 4, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.Cout * 4, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+    for (int i = 0; i < NA; ++i) {
+        float bias[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rsB, (co0 + i * 32 + 8 * g + 4 * lh) * 4, 0, 0);      // channels >= Cout read 0
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bias[4 * g + c] = __uint_as_float(bq[c]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int t = t0 + j * 32 + lr;
-            if (t >= a.Tout) continue;
+            const int vb = t < a.Tout ? ((co0 + i * 32 + 4 * lh) * a.Tout + t) * 4 : (int)0x80000000;
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co >= a.Cout) continue;
-                float v = acc[i][j][r] + a.bias[co];
-                if (a.elu) v = elu1(v);
-                const long long o = ((long long)b * a.Cout + co) * a.Tout + t;
-                if (a.residual) v += a.residual[o];
-                a.out[o] = v;
+                v[r] = acc[i][j][r] + bias[r];
+                if (a.elu) v[r] = elu1(v[r]);
             }
+            if (a.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rsO, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0);
         }
+    }
 }
 
 // weight [Cout][Cin][ks] -> packed [ks][CinP][CoutP] (zero padded)
@@ -111,15 +180,18 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
     }
 }
 
-// codebook [C][d] -> transposed [d][CP] (zero padded) + squared norms [CP] (+inf for the pad codes: never selected)
+// codebook [C][d] -> MFMA-ordered image P[j][lh][code][4] = E[code][8 j + 4 lh + 0..3] (zero padded to dP = 8 ceil(d / 8) columns and CP codes):
+// lane (code, lh) of the distance GEMM reads ONE float4 per 4 MFMA steps, 512 contiguous bytes per half wave.  + squared norms [CP]
+// (+inf for the pad codes: never selected)
 __global__ __launch_bounds__(256) void rvq_pack_kernel(const float* __restrict__ E, float* __restrict__ Et, float* __restrict__ e2, int C, int d,
                                                        int CP) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= CP) return;
+    const int dP = (d + 7) & ~7;
     float s = 0.f;
-    for (int k = 0; k < d; ++k) {
-        const float v = c < C ? E[(long long)c * d + k] : 0.f;
-        Et[(long long)k * CP + c] = v;
+    for (int k = 0; k < dP; ++k) {
+        const float v = (c < C && k < d) ? E[(long long)c * d + k] : 0.f;
+        Et[(((long long)(k >> 3) * 2 + ((k >> 2) & 1)) * CP + c) * 4 + (k & 3)] = v;
         s += v * v;
     }
     e2[c] = c < C ? s : INFINITY;
@@ -128,7 +200,7 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float* __restrict__
 struct RvqArgs {
     const float* x; long long ldx;            // [T][ldx] frames (this group's d columns start at x)
     const float* E;                           // [Q][C][d]   original codebooks (residual update)
-    const float* Et;                          // [Q][d][CP]  packed transposed
+    const float* Et;                          // [Q][dP/8][2][CP][4]  MFMA-ordered image (rvq_pack_kernel)
     const float* e2;                          // [Q][CP]
     long long* idx; long long ldi;            // [T][ldi] output indices (this group's Q columns start at idx)
     float* quant; long long ldq;              // optional: sum of the selected code vectors [T][ldq] (the `quantized` output), or NULL
@@ -137,8 +209,9 @@ struct RvqArgs {
 
 __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     extern __shared__ float sm[];
-    const int ld = a.d + 1;
-    float* res = sm;                          // [32][d + 1]
+    const int dP = (a.d + 7) & ~7;
+    const int ld = dP + 4;                    // 16-B aligned rows (ds_read_b128), consecutive rows 4 banks apart
+    float* res = sm;                          // [32][dP + 4]
     float* x2 = res + 32 * ld;                // [32]
     float* candd = x2 + 32;                   // [4][32]
     int* candi = reinterpret_cast<int*>(candd + 128);   // [4][32]
@@ -148,13 +221,13 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int f0 = blockIdx.x * 32;
 
-    // residual tile <- x ; |x|^2 per frame (thread = (frame t / 8, column phase t % 8))
+    // residual tile <- x (pad columns zero) ; |x|^2 per frame (thread = (frame t / 8, column phase t % 8))
     const int fj = t >> 3, ph = t & 7;
     {
         float s = 0.f;
         const bool ok = f0 + fj < a.T;
-        for (int e = ph; e < a.d; e += 8) {
-            const float v = ok ? a.x[(long long)(f0 + fj) * a.ldx + e] : 0.f;
+        for (int e = ph; e < dP; e += 8) {
+            const float v = (ok && e < a.d) ? a.x[(long long)(f0 + fj) * a.ldx + e] : 0.f;
             res[fj * ld + e] = v;
             s += v * v;
         }
@@ -163,31 +236,60 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     }
     __syncthreads();
 
+    constexpr int PF = 4;                     // 8-column steps per register group; two groups in flight (software pipeline)
+    const int nj = dP >> 3, ng = (nj + PF - 1) / PF;
     const int nblk = a.CP / 32;               // 32-code blocks; wave w scans block pairs 2w, 2w + 8, ...
+    const float4* bp = reinterpret_cast<const float4*>(res + lr * ld + 4 * lh);          // + 2 j  (float4 units): residual[frame][8 j + 4 lh ..]
     for (int q = 0; q < a.Q; ++q) {
-        const float* Et = a.Et + (long long)q * a.d * a.CP;
+        const float4* Pq = reinterpret_cast<const float4*>(a.Et + (long long)q * dP * a.CP);
         const float* e2 = a.e2 + (long long)q * a.CP;
         const float xn = x2[lr];
         float best = INFINITY;
         int besti = 0x7fffffff;
-        // two 32-code blocks per pass share every residual (B) operand read; the k loop is unrolled so that several steps' loads are
-        // in flight ahead of the dependent MFMA chain
+        // two 32-code blocks per pass share every residual (B) operand read
         for (int cb = wave * 2; cb < nblk; cb += 8) {
             const bool two = cb + 1 < nblk;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            const float* ep = Et + cb * 32 + lr;
+            const float4* ap = Pq + (long long)lh * a.CP + cb * 32 + lr;                  // + 2 j CP per step
             const int o1 = two ? 32 : 0;
-#pragma unroll 8
-            for (int k = 0; k < a.d; k += 2) {
-                const int kk = k + lh;
-                const bool kok = kk < a.d;
-                const float av0 = kok ? ep[(long long)kk * a.CP] : 0.f;             // A[code][k]
-                const float av1 = kok ? ep[(long long)kk * a.CP + o1] : 0.f;
-                const float bv = kok ? res[lr * ld + kk] : 0.f;                      // B[k][frame]
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc1, 0, 0, 0);
+            float4 A0[2][PF], A1[2][PF], Bv[2][PF];
+            auto load_group = [&](auto bufc, int g) {
+                constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int j = g * PF + u;
+                    if (j < nj) {
+                        const float4* pj = ap + (long long)j * 2 * a.CP;
+                        A0[BUF][u] = pj[0];
+                        A1[BUF][u] = pj[o1];
+                        Bv[BUF][u] = bp[2 * j];
+                    } else {
+                        A0[BUF][u] = A1[BUF][u] = Bv[BUF][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            };
+            auto mfma_group = [&](auto bufc) {
+                constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const float a0v[4] = {A0[BUF][u].x, A0[BUF][u].y, A0[BUF][u].z, A0[BUF][u].w};
+                    const float a1v[4] = {A1[BUF][u].x, A1[BUF][u].y, A1[BUF][u].z, A1[BUF][u].w};
+                    const float bvv[4] = {Bv[BUF][u].x, Bv[BUF][u].y, Bv[BUF][u].z, Bv[BUF][u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], bvv[i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], bvv[i], acc1, 0, 0, 0);
+                    }
+                }
+            };
+            load_group(std::integral_constant<int, 0>{}, 0);
+            for (int g = 0; g < ng; g += 2) {
+                if (g + 1 < ng) load_group(std::integral_constant<int, 1>{}, g + 1);
+                mfma_group(std::integral_constant<int, 0>{});
+                if (g + 2 < ng) load_group(std::integral_constant<int, 0>{}, g + 2);
+                if (g + 1 < ng) mfma_group(std::integral_constant<int, 1>{});
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
@@ -279,6 +381,7 @@ extern "C" int alm_conv1d_causal(const float* x, const float* wp, const float* b
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0) return ALM_ERR_BAD_ARG;
     const int pad = dilation * (ksize - 1) + 1 - stride;
     if (pad < 0 || pad >= Tin || Tin < stride) return ALM_ERR_UNSUPPORTED;
+    if ((long long)(Cout + 32) * Tin * 4 >= 0x7fffffffLL || (long long)(Cin + 2) * Tin * 4 >= 0x7fffffffLL || (long long)ksize * (Cin + 1) * (Cout + 31) * 4 >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     const int Tout = (Tin - stride) / stride + 1;
     ConvArgs a{x, wp, bias, residual, out, B, Cin, (Cin + 1) & ~1, Cout, (Cout + 31) & ~31, Tin, Tout, ksize, stride, dilation, pad, elu};
     const int gx = (Tout + 255) / 256;
@@ -292,13 +395,16 @@ extern "C" int alm_conv1d_causal(const float* x, const float* wp, const float* b
 
 extern "C" int alm_rvq_padded_codes(int C) { return (C + 31) & ~31; }
 
-// E fp32 [Q][C][d] -> Et [Q][d][CP], e2 [Q][CP]  (CP = alm_rvq_padded_codes(C)); once per codebook update
+extern "C" int alm_rvq_padded_dim(int d) { return (d + 7) & ~7; }
+
+// E fp32 [Q][C][d] -> Et [Q][alm_rvq_padded_dim(d)][CP] floats (MFMA-ordered image), e2 [Q][CP]  (CP = alm_rvq_padded_codes(C)); once per
+// codebook update
 extern "C" int alm_rvq_pack(const float* E, float* Et, float* e2, int Q, int C, int d, void* stream) {
     if (Q <= 0 || C <= 0 || d <= 0) return ALM_ERR_BAD_ARG;
     const int CP = alm_rvq_padded_codes(C);
     for (int q = 0; q < Q; ++q)
         hipLaunchKernelGGL(rvq_pack_kernel, dim3((CP + 255) / 256), dim3(256), 0, (hipStream_t)stream, E + (long long)q * C * d,
-                           Et + (long long)q * d * CP, e2 + (long long)q * CP, C, d, CP);
+                           Et + (long long)q * alm_rvq_padded_dim(d) * CP, e2 + (long long)q * CP, C, d, CP);
     ALM_LAUNCH_CHECK();
     return 0;
 }
@@ -308,7 +414,7 @@ extern "C" int alm_rvq_encode(const float* x, long long ldx, const float* E, con
                               float* quant, long long ldq, int T, int d, int C, int Q, void* stream) {
     if (T <= 0) return 0;
     if (d <= 0 || C <= 0 || Q <= 0) return ALM_ERR_BAD_ARG;
-    const size_t smem = (size_t)(32 * (d + 1) + 32 + 128) * sizeof(float) + (128 + 32) * sizeof(int);
+    const size_t smem = (size_t)(32 * (alm_rvq_padded_dim(d) + 4) + 32 + 128) * sizeof(float) + (128 + 32) * sizeof(int);
     if (smem > 160 * 1024) return ALM_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {

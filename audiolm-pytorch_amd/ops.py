@@ -555,11 +555,11 @@ def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, 
 
 
 def rvq_pack(E):
-    """codebooks fp32 [Q, C, d] -> (Et [Q, d, Cpad], e2 [Q, Cpad])."""
+    """codebooks fp32 [Q, C, d] -> (Et [Q, dpad, Cpad] MFMA-ordered image, e2 [Q, Cpad])."""
     _chk(E, F32)
     Q, C, d = E.shape
     CP = _lib.query('alm_rvq_padded_codes', C)
-    Et = torch.empty((Q, d, CP), dtype=F32, device=E.device)
+    Et = torch.empty((Q, _lib.query('alm_rvq_padded_dim', d), CP), dtype=F32, device=E.device)
     e2 = torch.empty((Q, CP), dtype=F32, device=E.device)
     _lib.call('alm_rvq_pack', E.contiguous().data_ptr(), Et.data_ptr(), e2.data_ptr(), Q, C, d, _st())
     return Et, e2

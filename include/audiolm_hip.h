@@ -190,10 +190,11 @@ int alm_conv1d_packed_floats(int Cout, int Cin, int ksize);
 int alm_conv1d_pack(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream);
 int alm_conv1d_causal(const float* x, const float* wp, const float* bias, const float* residual, float* out, int B, int Cin, int Cout, int Tin,
                       int ksize, int stride, int dilation, int elu, void* stream);
-/* rvq: frames x [T][ldx] (d columns of one group), codebooks E [Q][C][d]; Et [Q][d][CP] / e2 [Q][CP] packed once by alm_rvq_pack
- * (CP = alm_rvq_padded_codes(C)); idx int64 [T][ldi] (Q columns): per quantizer argmin_e sqrt(clamp(|r|^2 + |e|^2 - 2 r.e, 0)) with
+/* rvq: frames x [T][ldx] (d columns of one group), codebooks E [Q][C][d]; Et [Q][alm_rvq_padded_dim(d)][CP] floats (MFMA-ordered image)
+ * / e2 [Q][CP] packed once by alm_rvq_pack (CP = alm_rvq_padded_codes(C)); idx int64 [T][ldi] (Q columns): per quantizer argmin_e sqrt(clamp(|r|^2 + |e|^2 - 2 r.e, 0)) with
  * first-index tie-breaking, r -= E[idx]; quant (optional) = sum of the selected code vectors. */
 int alm_rvq_padded_codes(int C);
+int alm_rvq_padded_dim(int d);
 int alm_rvq_pack(const float* E, float* Et, float* e2, int Q, int C, int d, void* stream);
 int alm_rvq_encode(const float* x, long long ldx, const float* E, const float* Et, const float* e2, long long* idx, long long ldi, float* quant,
                    long long ldq, int T, int d, int C, int Q, void* stream);

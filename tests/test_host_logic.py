@@ -135,3 +135,71 @@ def test_soundstream_module_tree_matches_reference_state_dict_names():
         A.SoundStream(codebook_size=32)                              # reference default use_local_attn=True is SURVEY §8(f)-3
     with pytest.raises(RuntimeError):
         ss.tokenize(torch.zeros(1, 640))                              # CPU tensor: no CPU fallback
+
+
+def _dense_from_table(tbl, index, scale):
+    """what the attention kernels compute from (table, index vectors): bias(h,i,j) = special ? tbl[h][0] : tbl[h][(qkey4[i]-kkey4[j])/4]"""
+    qkey4, kkey4, qattr, kattr = [t.long() for t in index]
+    LT = tbl.shape[1]
+    slot = (qkey4[:, None] - kkey4[None, :]) // 4
+    special = (qattr[:, None] & kattr[None, :]) != 0
+    inside = (slot >= 0) & (slot < LT)
+    vals = tbl[:, torch.where(special, torch.zeros_like(slot), slot).clamp(0, LT - 1)]
+    return torch.where((inside | special)[None], vals, torch.zeros_like(vals)) * scale
+
+
+def test_structured_bias_index_vectors_reproduce_the_reference_bias():
+    """relpos.toeplitz_index / fine_index + the MLP output laid out as a table == the dense (h, n, n) tensors the reference gathers
+    (oracle.rel_pos_bias :202-242, the Coarse override :924-936, oracle.fine_attn_bias :1229-1298) on every causally visible pair."""
+    from audiolm_pytorch_amd import relpos
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    H, d, scale = 4, 8, 64 ** -0.5
+    cpu = torch.device('cpu')
+
+    def mlp_sd(prefix, in_dim, nhid, seq):
+        sd, dims = {}, [in_dim] + [d] * (nhid + 1)
+        for li in range(nhid + 1):
+            name = f'{prefix}{li}.0.' if seq is None else f'{prefix}{2 * li}.'
+            sd[name + 'weight'], sd[name + 'bias'] = torch.randn(dims[li + 1], dims[li], generator=g) * 0.3, torch.randn(dims[li + 1], generator=g) * 0.3
+        name = f'{prefix}{nhid + 1}.' if seq is None else f'{prefix}{2 * (nhid + 1)}.'
+        sd[name + 'weight'], sd[name + 'bias'] = torch.randn(H, d, generator=g) * 0.3, torch.randn(H, generator=g) * 0.3
+        return sd
+
+    # ---- Semantic / Coarse
+    n = 29
+    sd = mlp_sd('rel_pos_bias.net.', 1, 2, None)
+    want = O.rel_pos_bias(sd, 'rel_pos_bias.', n, n)                                          # (h, n, n)
+    x = torch.arange(-n + 1, n).float()[:, None]
+    for li in range(3):
+        x = F.silu(F.linear(x, sd[f'rel_pos_bias.net.{li}.0.weight'], sd[f'rel_pos_bias.net.{li}.0.bias']))
+    T = F.linear(x, sd['rel_pos_bias.net.3.weight'], sd['rel_pos_bias.net.3.bias'])           # (2n-1, h): PosTableFn's rows
+    cross = torch.randn(H, 1, 1, generator=g)
+    tbl = torch.cat((cross.reshape(H, 1), T.t()), dim=1) / scale
+    causal = torch.ones(n, n, dtype=torch.bool).tril()
+    got = _dense_from_table(tbl, relpos.toeplitz_index(n, cpu), scale)
+    assert torch.allclose(got[:, causal], want[:, causal], atol=1e-5)
+    ns1 = 11                                                                                  # semantic_seq_len + 1 (:929)
+    is_sem = torch.arange(n) < ns1
+    want_c = torch.where(is_sem[:, None] ^ is_sem[None, :], cross, want)
+    got_c = _dense_from_table(tbl, relpos.toeplitz_index(n, cpu, num_leading=ns1), scale)
+    assert torch.allclose(got_c[:, causal], want_c[:, causal], atol=1e-5)
+
+    # ---- Fine (ragged coarse / fine lengths included)
+    Qc, Qf = 3, 5
+    for nc, nf in ((12, 20), (11, 17), (3, 1), (30, 4), (2, 14)):
+        sdf = mlp_sd('pos_bias_mlp.', 2, 1, 'seq')
+        sdf['null_pos_bias'] = torch.randn(H, 1, 1, generator=g)
+        cfg = O.Cfg(dim=2 * d, depth=1, heads=H, streams=1, num_semantic_tokens=0, codebook_size=16, num_coarse_quantizers=Qc, num_fine_quantizers=Qf)
+        want_f = O.fine_attn_bias(sdf, cfg, nc, nf, cpu)
+        grid, index = relpos.fine_index(nc, nf, Qc, Qf, cpu)
+        h = F.silu(F.linear(grid, sdf['pos_bias_mlp.0.weight'], sdf['pos_bias_mlp.0.bias']))
+        h = F.silu(F.linear(h, sdf['pos_bias_mlp.2.weight'], sdf['pos_bias_mlp.2.bias']))
+        Tf = F.linear(h, sdf['pos_bias_mlp.4.weight'], sdf['pos_bias_mlp.4.bias'])
+        tblf = torch.cat((sdf['null_pos_bias'].reshape(H, 1), Tf.t()), dim=1) / scale
+        N = nc + nf + 2
+        causal = torch.ones(N, N, dtype=torch.bool).tril()
+        got_f = _dense_from_table(tblf, index, scale)
+        assert torch.allclose(got_f[:, causal], want_f[:, causal], atol=1e-5), (nc, nf)
+        for t in index:
+            assert t.dtype == torch.int32 and t.shape == (N,)
