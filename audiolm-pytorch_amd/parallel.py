@@ -30,6 +30,7 @@ class DataParallelEngine:
     def __init__(self, model, dist, process_group=None, broadcast_parameters=True):
         self.model, self.dist, self.pg = model, dist, process_group
         self.world = dist.get_world_size(process_group)
+        self._avg_ok = str(dist.get_backend(process_group)).lower() == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
         if broadcast_parameters and self.world > 1:
             with torch.no_grad():
@@ -62,7 +63,7 @@ class DataParallelEngine:
             flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
             self._flat_cache[key] = flat
         torch.cat([g.reshape(-1).to(torch.float32) for g in grads], out=flat)
-        op = self.dist.ReduceOp.AVG if grads[0].is_cuda else self.dist.ReduceOp.SUM
+        op = self.dist.ReduceOp.AVG if self._avg_ok else self.dist.ReduceOp.SUM       # gloo has no AVG: sum, divide in finish()
         work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
         b = _Bucket()
         b.params, b.flat, b.work = list(params), flat, work

@@ -99,12 +99,20 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    # test hook (scripts/gpu_check.sh dp2): ALM_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, to exercise the multi-rank control flow
+    # (callbacks, bucket order, barriers) on a 1-GPU box; its numbers mean nothing
+    share = os.environ.get('ALM_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)          # backend "nccl" IS RCCL on ROCm
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)      # backend "nccl" IS RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
 
     import audiolm_pytorch_amd as A
@@ -160,8 +168,10 @@ def main():
     # ---- roofline of the dominant kernel: one instrumented step, HIP events (torch.cuda.Event on the launch stream = torch's current
     # stream, which is the stream every alm_* launch uses) around every MFMA GEMM launch.  The dominant kernel is the NT 256x256x64
     # 8-wave tile (gemm_kernel<256,256,2,4,false,*>): its launches are singled out; all GEMM launches are reported alongside.
+    # EVERY rank runs the instrumented step (with N > 1 it contains the gradient all-reduces: a step on rank 0 alone would dead-lock the
+    # collectives); only rank 0's numbers are reported.
     roof = None
-    if rank == 0:
+    if True:
         events = []
         orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn_splitk
 

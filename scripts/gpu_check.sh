@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: kernel parity, model parity, smoke, bench (+ rocprofv3 kernel stats).  Logs -> gpurun_out/.
-# usage: scripts/gpu_check.sh [tests|bench|prof|all]
+# usage: scripts/gpu_check.sh [tests|kbench|bench|prof|dp2|all]
 what=${1:-all}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
@@ -12,7 +12,7 @@ print('CUs', p.multi_processor_count, 'mem GB', p.total_memory / 2**30, 'host co
 PY
 cat gpurun_out/env.log
 if [[ $what == tests || $what == all ]]; then
-  timeout 1200 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/kernels.log 2>&1
+  timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_bias.py tests/test_gpu_codec.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/kernels.log 2>&1
   echo "kernels rc=$?"; tail -n 60 gpurun_out/kernels.log
   timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -s --timeout 600 > gpurun_out/parity.log 2>&1
   echo "parity rc=$?"; tail -n 80 gpurun_out/parity.log
@@ -26,6 +26,13 @@ fi
 if [[ $what == bench || $what == all ]]; then
   timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
   echo "bench rc=$?"; tail -n 12 gpurun_out/bench.log
+fi
+if [[ $what == dp2 ]]; then
+  # two ranks sharing the one GPU over gloo: exercises bench.py's multi-rank control flow (per-layer bucket callbacks, barriers, the
+  # instrumented step, the optimizer leg) on a 1-GPU box -- the numbers mean nothing
+  ALM_BENCH_SHARE_GPU=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
+    bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/dp2.log 2>&1
+  echo "dp2 rc=$?"; tail -n 3 gpurun_out/dp2.log | cut -c1-400
 fi
 if [[ $what == prof || $what == all ]]; then
   export TMPDIR=/tmp
