@@ -28,7 +28,8 @@ SIGNATURES = {
     'alm_ln_partial_blocks': [_I],
     'alm_layernorm_fwd': [_P, _I, _L, _P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
     'alm_layernorm_bwd': [_P, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
-    'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P],
+    'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P, _P],
+    'alm_colsum_chunks': [_I],
     'alm_geglu_partial_blocks': [_I],
     'alm_geglu_ln_fwd': [_P, _L, _I, _P, _P, _L, _P, _P, _I, _I, _I, _P],
     'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -130,29 +130,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------------
 // column sum: out[c] (+)= scale * sum_r in[r][c]   (fp32 or bf16 input)
 // ------------------------------------------------------------------------------------------------------------------
+// Two stages for tall inputs (deterministic, no atomics): stage 1 = grid (cols / 64, R row chunks), a block covers 64 columns (256 B per
+// row: whole cache lines) x 4 row lanes and writes ws[chunk][c]; stage 2 sums the R chunk rows.  Short inputs run stage 1 only (R = 1).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, long long ld, int rows, int cols, float* __restrict__ out,
-                                                     float scale, int accumulate) {
-    // block = 16 columns x 16 row-lanes: many more blocks than a 64-column tiling for the short-and-wide partial buffers this is
-    // used on (parameter-gradient partials: <= 1024 rows x up to 7k columns)
-    __shared__ float red[16][17];
-    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cx;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = ry; r < rows; r += 16) {
-            if constexpr (sizeof(T) == 2) s += bf2f(in[(long long)r * ld + c]);
-            else s += in[(long long)r * ld + c];
+                                                     float scale, int accumulate, int rows_per_chunk, int direct) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    auto ldv = [&](int r) -> float {
+        if constexpr (sizeof(T) == 2) return bf2f(in[(long long)r * ld + c]);
+        else return in[(long long)r * ld + c];
+    };
+    if (c < cols) {
+        int r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {
+            s0 += ldv(r); s1 += ldv(r + 4); s2 += ldv(r + 8); s3 += ldv(r + 12);
         }
-    red[ry][cx] = s;
+        for (; r < r1; r += 4) s0 += ldv(r);
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ry == 0 && c < cols) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += red[i][cx];
-        v *= scale;
-        out[c] = accumulate ? out[c] + v : v;
+        const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        if (direct) out[c] = accumulate ? out[c] + v * scale : v * scale;
+        else out[(long long)blockIdx.y * cols + c] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int chunks, int cols, float* __restrict__ out, float scale,
+                                                            int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float v = 0.f;
+    for (int k = 0; k < chunks; ++k) v += ws[(long long)k * cols + c];
+    v *= scale;
+    out[c] = accumulate ? out[c] + v : v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -385,14 +400,23 @@ extern "C" int alm_layernorm_bwd(const void* dy, long long lddy, const void* x, 
     return 0;
 }
 
-extern "C" int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate,
+// number of row chunks stage 1 uses; the caller provides `ws` = alm_colsum_chunks(rows) * cols floats when that is > 1
+extern "C" int alm_colsum_chunks(int rows) { return rows <= 128 ? 1 : min(16, (rows + 63) / 64); }
+
+extern "C" int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate, float* ws,
                           void* stream) {
     if (cols <= 0) return 0;
-    dim3 grid((cols + 15) / 16);
+    const int chunks = ws ? alm_colsum_chunks(rows) : 1;
+    const int rpc = (rows + chunks - 1) / chunks;
+    const int direct = chunks == 1;
+    dim3 grid((cols + 63) / 64, chunks);
+    float* o1 = direct ? out : ws;
     if (in_is_bf16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld, rows, cols, out, scale, accumulate);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld, rows, cols, o1, scale, accumulate, rpc, direct);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld, rows, cols, out, scale, accumulate);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld, rows, cols, o1, scale, accumulate, rpc, direct);
+    if (!direct)
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, chunks, cols, out, scale, accumulate);
     ALM_LAUNCH_CHECK();
     return 0;
 }

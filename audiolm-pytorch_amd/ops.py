@@ -148,7 +148,9 @@ def colsum(inp, out=None, scale=1.0, accumulate=False):
     rows, cols, ld = _rows_ld(inp)
     if out is None:
         out = torch.empty(cols, dtype=F32, device=inp.device)
-    _lib.call('alm_colsum', inp.data_ptr(), int(inp.dtype == BF16), ld, rows, cols, out.data_ptr(), float(scale), int(accumulate), _st())
+    chunks = _lib.query('alm_colsum_chunks', rows)
+    ws = torch.empty((chunks, cols), dtype=F32, device=inp.device) if chunks > 1 else None
+    _lib.call('alm_colsum', inp.data_ptr(), int(inp.dtype == BF16), ld, rows, cols, out.data_ptr(), float(scale), int(accumulate), _p(ws), _st())
     return out
 
 

@@ -71,7 +71,9 @@ int alm_layernorm_bwd(const void* dy_bf16, long long lddy, const void* x, int x_
                       const float* rstd, const float* gamma, const void* extra_bf16, long long lde, void* dx, int dx_is_bf16,
                       long long lddx, float* dgamma_part, int rows, int D, void* stream);
 /* out[c] (+)= scale * sum_r in[r][c]  (second stage of every parameter-gradient reduction; bias gradients) */
-int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate, void* stream);
+int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate, float* ws,
+               void* stream);          /* ws: alm_colsum_chunks(rows) * cols floats (two-stage reduction of tall inputs) or NULL */
+int alm_colsum_chunks(int rows);
 
 /* ---- GEGLU + inner LayerNorm: audiolm_pytorch.py:246-260 (gate = second half, exact-erf GELU, LN over int(dim*8/3)) -------- */
 int alm_geglu_partial_blocks(int rows);

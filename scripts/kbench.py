@@ -331,6 +331,50 @@ def bench_bias():
         del m, w
 
 
+def bench_host():
+    """is the headline step host-bound?  Python/ctypes time to ISSUE one step (no synchronisation) vs the GPU time of the step."""
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    torch.manual_seed(0)
+    m = A.CoarseTransformer(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=m, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
+    w.train()
+    sem, coarse = torch.randint(0, 500, (8, 509), device=dev), torch.randint(0, 1024, (8, 512, 3), device=dev)
+
+    def step():
+        m.transformer._cache.store.clear()
+        for p in m.parameters():
+            p.grad = None
+        w(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True).backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    n = 10
+    issue = []
+    t0 = time.perf_counter()
+    for _ in range(n):
+        a = time.perf_counter()
+        step()
+        issue.append(time.perf_counter() - a)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f'headline step: host issue time {sum(issue) / n * 1e3:.2f} ms/step (min {min(issue) * 1e3:.2f}), wall {(t2 - t0) / n * 1e3:.2f} ms/step, '
+          f'GPU tail after the last issue {(t2 - t1) * 1e3:.2f} ms')
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime')
+    st.print_stats(14)
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)

@@ -210,6 +210,17 @@ def test_colsum_reduce(ops):
     x = rnd(300, 130, seed=20)
     assert relmax(ops.colsum(x), x.double().sum(0)) <= 1e-6
     assert relmax(ops.colsum(x.to(BF16)), x.to(BF16).double().sum(0)) <= 1e-6
+    # short (single stage), tall (two stages), strided rows, scale + accumulate
+    for rows, cols, ldx in ((1, 7), (64, 64), (128, 7232), (129, 100), (768, 7232), (1024, 2730), (3000, 65)):
+        big = rnd(rows, cols + ldx, seed=rows + cols)
+        xv = big[:, :cols]
+        want = xv.double().sum(0)
+        assert relmax(ops.colsum(xv), want) <= 2e-6, (rows, cols)
+        o = rnd(cols, seed=3)
+        o0 = o.clone()
+        ops.colsum(xv, out=o, scale=0.25, accumulate=True)
+        assert relmax(o, o0.double() + 0.25 * want) <= 2e-6, (rows, cols)
+        assert relmax(ops.colsum(xv.to(BF16)), xv.to(BF16).double().sum(0)) <= 2e-6
     v = rnd(5000, seed=21)
     assert abs(float(ops.reduce_sum(v, 0.5)) - 0.5 * float(v.double().sum())) <= 1e-3
 
