@@ -211,8 +211,8 @@ def test_colsum_reduce(ops):
     assert relmax(ops.colsum(x), x.double().sum(0)) <= 1e-6
     assert relmax(ops.colsum(x.to(BF16)), x.to(BF16).double().sum(0)) <= 1e-6
     # short (single stage), tall (two stages), strided rows, scale + accumulate
-    for rows, cols, ldx in ((1, 7), (64, 64), (128, 7232), (129, 100), (768, 7232), (1024, 2730), (3000, 65)):
-        big = rnd(rows, cols + ldx, seed=rows + cols)
+    for rows, cols in ((1, 7), (64, 64), (128, 7232), (129, 100), (768, 7232), (1024, 2730), (3000, 65)):
+        big = rnd(rows, cols + 9, seed=rows + cols)
         xv = big[:, :cols]
         want = xv.double().sum(0)
         assert relmax(ops.colsum(xv), want) <= 2e-6, (rows, cols)
