@@ -24,6 +24,11 @@
 //   * two-level batch (blockIdx.y -> (z1, z2)) with element strides for the per-quantizer logit heads
 //     (einsum 'q c d, b n q d -> b n q c').
 // Requirements: NT: K % 8 == 0, lda/ldb % 8 == 0;  TN: lda/ldb % 8 == 0;  A/B 16-byte aligned; every operand view < 2 GiB.
+#include <algorithm>
+#include <array>
+#include <map>
+#include <vector>
+
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -51,6 +56,8 @@ struct GemmParams {
     long long sCk;
     int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel)
     int nsl;           // number of K slices (raster 1)
+    const int* units;  // non-null: BALANCED split -- 1-D grid, workgroup b executes work unit units[4b .. 4b+3] = (linear tile, first K-step,
+                       // K-steps, workspace slot) and writes a whole BM x BN fp32 partial tile to C + slot * BM * BN (see build_stream_plan)
 };
 
 // ---- epilogue (shared by every GEMM kernel) --------------------------------------------------------------------------------------------
@@ -181,7 +188,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn, zb, zs;
-    if (p.raster == 1) {
+    int ukbeg = 0, uksteps = 0, uslot = 0;
+    if (p.units) {
+        const int4 u = reinterpret_cast<const int4*>(p.units)[blockIdx.x];
+        if (u.x < 0) return;
+        const int per = tiles_m * tiles_n, r = u.x % per;
+        zb = u.x / per;
+        if (tiles_m >= tiles_n) { tm = r / tiles_n; tn = r % tiles_n; } else { tn = r / tiles_m; tm = r % tiles_m; }
+        zs = 0;
+        ukbeg = u.y; uksteps = u.z; uslot = u.w;
+    } else if (p.raster == 1) {
         // split-K weight gradients: the operand with MANY tile panels (e.g. dU: 22 panels of 256 columns) is the big one.  Panel q
         // (its K slices and the few tiles along the other dimension) is pinned to XCD q % 8 (workgroup L runs on XCD L % 8 -- observed
         // dispatch order; a wrong guess only costs speed), so each of its K slices is fetched from HBM once and shared through that
@@ -217,7 +233,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const int z1 = zb / p.nb2, z2 = zb % p.nb2;
     int kbeg = 0, Krem = p.K;
     long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
-    if (p.ksplit > 0) {
+    if (p.units) {
+        kbeg = ukbeg * BK;
+        Krem = min(p.K - kbeg, uksteps * BK);
+    } else if (p.ksplit > 0) {
         kbeg = zs * p.ksplit;
         Krem = min(p.K - kbeg, p.ksplit);
     }
@@ -391,6 +410,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     {
         constexpr int ES = OUT_F32 ? 4 : 2;
         static_assert(NW * 32 * (32 * TNB * ES) <= STAGES * STAGE, "epilogue slab");
+        if (OUT_F32 && p.units) {
+            // balanced split: the whole BM x BN partial tile (rows / columns beyond M / N hold exact zeros) goes to its workspace slot
+            GemmParams q = p;
+            q.C = reinterpret_cast<float*>(p.C) + (long long)uslot * BM * BN;
+            q.ldc = BN; q.M = BM; q.N = BN; q.accumulate = 0; q.bias = nullptr;
+            gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(q, acc, smem, 0, 0, 0, wave, wr, wc, lane, lr, lh);
+            return;
+        }
         const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
         gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
     }
@@ -511,6 +538,43 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmParams p) {
         gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem + STAGE, coff0, cm0, cn0, wave, wr, wc, lane, lr, lh);
         if (!more) break;
         v = vn;
+    }
+}
+
+// ---- balanced-split second stage: C tile = sum of its workspace slots [tile_first[t], tile_first[t+1]) (in K order: deterministic).
+// grid (tiles, BM / 16): a block sums 16 rows of one tile, 64 threads (float4 each) per row.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void stream_reduce_kernel(const float* __restrict__ ws, const int* __restrict__ tile_first, float* __restrict__ C,
+                                                            long long ldc, long long sC, int M, int N, int tiles_m, int tiles_n, int accumulate) {
+    static_assert(BN == 256, "64 float4 lanes per row");
+    const int tile = blockIdx.x;
+    const int per = tiles_m * tiles_n, r = tile % per, zb = tile / per;
+    int tm, tn;
+    if (tiles_m >= tiles_n) { tm = r / tiles_n; tn = r % tiles_n; } else { tn = r / tiles_m; tm = r % tiles_m; }
+    const int s0 = tile_first[tile], s1 = tile_first[tile + 1];
+    const int c4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
+    const int n = tn * BN + c4;
+    float* Cz = C + (long long)zb * sC;
+    const bool vec = (ldc & 3) == 0 && ((uintptr_t)Cz & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = blockIdx.y * 16 + it * 4 + rsub, m = tm * BM + row;
+        if (m >= M || n >= N) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = s0; sl < s1; ++sl) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + ((long long)sl * BM + row) * BN + c4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float* cp = Cz + (long long)m * ldc + n;
+        if (vec && n + 3 < N) {
+            if (accumulate) { const float4 w = *reinterpret_cast<const float4*>(cp); a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w; }
+            *reinterpret_cast<float4*>(cp) = a;
+        } else {
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (n + c < N) cp[c] = accumulate ? cp[c] + av[c] : av[c];
+        }
     }
 }
 
@@ -679,8 +743,102 @@ bool view_too_big(long long rows, long long ld) { return rows * ld * 2 >= 0x7fff
 
 // Split-K plan for `nb` same-shape problems: choose (tile, slices) minimising a simple time model --
 //   block waves over the chip x K-steps per block x measured time per K-step  +  workspace round trip through HBM.
-struct SplitPlan { int tile, slices; };
+struct SplitPlan { int tile, slices; bool stream; };
+
+// ---- balanced split ("stream-K" without fix-up waves) for long-K contractions with too few output tiles to fill the chip ------------------
+// The tiles x K-steps iteration space is cut into one contiguous, equally long range per CU: XCD x owns the x-th eighth (its tiles share
+// operand panels through that XCD's L2), each of its 32 CUs one range.  A range that crosses a tile boundary is cut there into pieces;
+// the first piece of every range is dispatched first, the remaining pieces follow in DECREASING length -- the CU whose first piece was
+// shortest frees up first and takes the longest remaining piece (its complement), so every CU ends up with the same number of K-steps:
+// no partial last wave, which is what costs the uniform split (e.g. dW1: 88 tiles x 5 slices = 440 workgroups on 256 CUs = 1.72 waves).
+// Workgroup b = j * 8 + x is the j-th unit of XCD x (workgroups are dispatched round-robin over the XCDs).  Every piece writes a whole
+// fp32 partial tile into its own workspace slot; slots of a tile are consecutive and in K order (stream_reduce_kernel: deterministic).
+struct StreamPlan { int nunits = 0, nslots = 0; int* d_units = nullptr; int* d_tile_first = nullptr; };
+std::map<std::array<long long, 4>, StreamPlan> g_stream_plans;
+
+struct Piece { int tile, kbeg, ksteps, slot; };
+
+int stream_plan_counts(int M, int N, int K, int nb, int* nslots_out) {
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256) * nb, S = (K + BK - 1) / BK;
+    const long long total = (long long)tiles * S;
+    const long long per_xcd = (total + 7) / 8;
+    int nslots = 0, maxlen = 0;
+    for (int x = 0; x < 8; ++x) {
+        const long long lo = x * per_xcd, hi = std::min(total, lo + per_xcd);
+        if (lo >= hi) continue;
+        const long long L = (hi - lo + 31) / 32;
+        int len = 0;
+        for (long long a = lo; a < hi; a += L) {
+            const long long b = std::min(hi, a + L);
+            len += (int)((b - 1) / S - a / S) + 1;
+        }
+        nslots += len;
+        maxlen = std::max(maxlen, len);
+    }
+    if (nslots_out) *nslots_out = nslots;
+    return maxlen * 8;
+}
+
+const StreamPlan* get_stream_plan(int M, int N, int K, int nb) {
+    const std::array<long long, 4> key{M, N, K, nb};
+    auto it = g_stream_plans.find(key);
+    if (it != g_stream_plans.end()) return &it->second;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256) * nb, S = (K + BK - 1) / BK;
+    const long long total = (long long)tiles * S;
+    const long long per_xcd = (total + 7) / 8;
+    std::vector<Piece> seq[8];
+    std::vector<Piece*> all;
+    for (int x = 0; x < 8; ++x) {
+        const long long lo = x * per_xcd, hi = std::min(total, lo + per_xcd);
+        if (lo >= hi) continue;
+        const long long L = (hi - lo + 31) / 32;
+        std::vector<Piece> first, rest;
+        for (long long a = lo; a < hi; a += L) {
+            const long long b = std::min(hi, a + L);
+            bool head = true;
+            for (long long c = a; c < b;) {
+                const long long tile = c / S, e = std::min(b, (tile + 1) * S);
+                (head ? first : rest).push_back(Piece{(int)tile, (int)(c - tile * S), (int)(e - c), 0});
+                head = false;
+                c = e;
+            }
+        }
+        std::stable_sort(rest.begin(), rest.end(), [](const Piece& a, const Piece& b) { return a.ksteps > b.ksteps; });
+        seq[x] = first;
+        seq[x].insert(seq[x].end(), rest.begin(), rest.end());
+    }
+    for (int x = 0; x < 8; ++x)
+        for (auto& pc : seq[x]) all.push_back(&pc);
+    std::stable_sort(all.begin(), all.end(), [](const Piece* a, const Piece* b) { return a->tile != b->tile ? a->tile < b->tile : a->kbeg < b->kbeg; });
+    std::vector<int> tile_first(tiles + 1, 0);
+    for (size_t i = 0; i < all.size(); ++i) {
+        all[i]->slot = (int)i;
+        tile_first[all[i]->tile + 1] = (int)i + 1;
+    }
+    for (int t = 1; t <= tiles; ++t) tile_first[t] = std::max(tile_first[t], tile_first[t - 1]);
+    size_t maxlen = 0;
+    for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, seq[x].size());
+    std::vector<int> units(maxlen * 8 * 4, -1);
+    for (int x = 0; x < 8; ++x)
+        for (size_t j = 0; j < seq[x].size(); ++j) {
+            int* u = &units[(j * 8 + x) * 4];
+            u[0] = seq[x][j].tile; u[1] = seq[x][j].kbeg; u[2] = seq[x][j].ksteps; u[3] = seq[x][j].slot;
+        }
+    StreamPlan pl;
+    pl.nunits = (int)maxlen * 8;
+    pl.nslots = (int)all.size();
+    if (hipMalloc(&pl.d_units, units.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMalloc(&pl.d_tile_first, tile_first.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(pl.d_units, units.data(), units.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (hipMemcpy(pl.d_tile_first, tile_first.data(), tile_first.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return &(g_stream_plans[key] = pl);
+}
 int g_dbg_tile = 0, g_dbg_slices = 0, g_dbg_raster = 1;     // tuning hook (alm_debug_splitk): 0 = automatic
+int g_dbg_stream = 0;                                        // balanced split: 0 never (default), 1 by the cost model, 2 always (when applicable)
+// NEGATIVE RESULT (MI355X, dW1 5460 x 1024 x 16384: 310 us vs 294 us uniform 5-slice split; dW2 198 vs 160 us): the balanced split removes
+// the partial last wave but the 32 workgroups of an XCD then walk DIFFERENT K ranges of their tiles at any moment, so operand panels are no
+// longer shared through the L2 (256 workgroups x 2 x 2.9 MB = 1.5 GB of operand traffic per GEMM, ~4.8 TB/s: traffic-bound), whereas the
+// uniform split + XCD-panel rasterisation fetches each (panel, slice) once per XCD.  Kept selectable (alm_debug_stream) and tested.
 
 // XCD-panel rasterisation pays only when the panels spread evenly over the 8 XCDs (measured: 22 panels +3 %, 11 panels -40 %)
 int pick_raster(int M, int N, int nb, int tile) {
@@ -693,9 +851,9 @@ int pick_raster(int M, int N, int nb, int tile) {
 SplitPlan splitk_plan(int M, int N, int K, int nb) {
     if (g_dbg_tile > 0 && g_dbg_slices > 0) {
         const int kc = ((K + g_dbg_slices - 1) / g_dbg_slices + BK - 1) / BK * BK;
-        return SplitPlan{(g_dbg_tile >= 2 && M >= 256 && N >= 256) ? g_dbg_tile : 1, (K + kc - 1) / kc};
+        return SplitPlan{(g_dbg_tile >= 2 && M >= 256 && N >= 256) ? g_dbg_tile : 1, (K + kc - 1) / kc, false};
     }
-    SplitPlan best{1, 1};
+    SplitPlan best{1, 1, false};
     double best_t = 1e30;
     for (int tile = 1; tile <= 2; ++tile) {
         if (tile == 2 && (M < 256 || N < 256)) continue;
@@ -711,8 +869,16 @@ SplitPlan splitk_plan(int M, int N, int K, int nb) {
             const double waves = ceil(tiles * s / slots);
             double t = waves * ((kc / BK) * us_per_kstep + 3.0);
             if (s > 1) t += (double)s * M * N * nb * 8.0 / 4.0e6 + 3.0;   // fp32 partials: written + read back at ~4 TB/s, + the reduce launch
-            if (t < best_t) { best_t = t; best = SplitPlan{tile, s}; }
+            if (t < best_t) { best_t = t; best = SplitPlan{tile, s, false}; }
         }
+    }
+    if (g_dbg_stream != 0 && M >= 256 && N >= 256 && K >= 1024) {
+        // balanced split over the 256 CUs (256 x 256 tiles): every CU runs ceil(total K-steps / 256) steps; partial tiles go through HBM
+        const double tiles = (double)((M + 255) / 256) * ((N + 255) / 256) * nb, S = (K + BK - 1) / BK;
+        int nslots = 0;
+        stream_plan_counts(M, N, K, nb, &nslots);
+        const double t = ceil(tiles * S / 256.0) * 2.0 + 6.0 + (double)nslots * 65536.0 * 8.0 / 4.0e6 + 3.0;
+        if ((tiles >= 16 && t < best_t) || g_dbg_stream == 2) best = SplitPlan{2, 0, true};
     }
     return best;
 }
@@ -758,11 +924,50 @@ extern "C" int alm_debug_splitk(int tile, int slices, int raster) {
     return 0;
 }
 
+extern "C" int alm_debug_stream(int mode) {          // balanced split: 0 never (default), 1 by the cost model, 2 whenever applicable
+    g_dbg_stream = mode;
+    return 0;
+}
+
 extern "C" int alm_gemm_splitk_slices(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).slices; }
+
+// fp32 workspace floats alm_gemm_bf16_{nt,tn}_splitk need for this problem (0: none)
+extern "C" int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb) {
+    nb = nb < 1 ? 1 : nb;
+    const SplitPlan pl = splitk_plan(M, N, K, nb);
+    long long fl = 0;
+    if (pl.stream) {
+        int nslots = 0;
+        stream_plan_counts(M, N, K, nb, &nslots);
+        fl = (long long)nslots * 65536;
+    } else if (pl.slices > 1) {
+        fl = (long long)pl.slices * nb * M * N;
+    }
+    return fl > 0x7fffffffLL ? -1 : (int)fl;
+}
 
 static int splitk_common(bool tn, const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                          long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, hipStream_t st) {
     const SplitPlan pl = splitk_plan(M, N, K, nb);
+    if (pl.stream) {
+        if (!ws) return ALM_ERR_BAD_ARG;
+        const StreamPlan* sp = get_stream_plan(M, N, K, nb);
+        if (!sp) return ALM_ERR_UNSUPPORTED;
+        GemmParams p{(const bf16_t*)A, (const bf16_t*)B, ws, nullptr, M, N, K, lda, ldb, 256, nb, 0, sA, 0, sB, 0, 0, alpha, 0, 0, 0, 0, 1, sp->d_units};
+        static bool attr_done[2] = {false, false};
+        auto kfn = tn ? gemm_kernel<256, 256, 2, 4, true, true> : gemm_kernel<256, 256, 2, 4, false, true>;
+        constexpr int smem = 2 * (256 + 256) * BK * 2;
+        if (!attr_done[tn]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr_done[tn] = true;
+        }
+        hipLaunchKernelGGL(kfn, dim3(sp->nunits), dim3(512), smem, st, p);
+        const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+        hipLaunchKernelGGL((stream_reduce_kernel<256, 256>), dim3(tiles_m * tiles_n * nb, 16), dim3(256), 0, st, (const float*)ws, sp->d_tile_first, C, ldc,
+                           sC, M, N, tiles_m, tiles_n, accumulate);
+        return 0;
+    }
     if (pl.slices <= 1) {
         GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, M, N, K, lda, ldb, ldc, nb, 0, sA, 0, sB, 0, sC, alpha, accumulate, 0, 0, pick_raster(M, N, nb, pl.tile), 1};
         return tn ? launch_gemm<true>(p, nb, 1, 1, pl.tile, st) : launch_gemm<false>(p, nb, 1, 1, pl.tile, st);

@@ -57,8 +57,10 @@ def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
 
 
 def _splitk(name, A, B, C, M, N, K, nb, sA, sB, sC, alpha, accumulate):
-    slices = _lib.query('alm_gemm_splitk_slices', M, N, K, nb)
-    ws = torch.empty((slices, nb, M, N), dtype=F32, device=A.device) if slices > 1 else None
+    nws = _lib.query('alm_gemm_splitk_ws_floats', M, N, K, nb)
+    if nws < 0:
+        raise _lib.AlmError('split-K workspace exceeds 2^31 floats')
+    ws = torch.empty(nws, dtype=F32, device=A.device) if nws > 0 else None
     _lib.call(name, A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(ws), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2), nb, sA, sB, sC,
               float(alpha), int(accumulate), _st())
     return C

@@ -34,13 +34,16 @@ int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, i
 int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                           long long ldc, float alpha, int out_f32, int accumulate, int tile, void* stream);
 /* split-K forms for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * op(A) . op(B),
- * deterministic two-stage reduction through `ws` (alm_gemm_splitk_slices(M,N,K,nb) * nb * M * N floats; may be NULL when that
- * query returns 1).  `nb` same-shape problems per launch with element strides sA / sB / sC between them (sA, sB % 8 == 0).
+ * deterministic two-stage reduction through `ws` (alm_gemm_splitk_ws_floats(M,N,K,nb) floats; may be NULL when that
+ * query returns 0).  A balanced split (one equally long K-step range per CU, whole fp32 partial tiles in `ws`,
+ * second-stage sum in K order) exists behind alm_debug_stream; it measured slower than uniform slices (operand-traffic bound) and is off by default.  `nb` same-shape problems per launch with element strides sA / sB / sC between them (sA, sB % 8 == 0).
  *   _nt_: A[M][K], B[N][K] (K-contiguous operands)
  *   _tn_: At[K][M], Bt[K][N] (contraction-major operands = the row-major activations themselves):
  *         dW[out][in] = sum_tokens dY[token][out] * X[token][in], the wgrad of every nn.Linear on the path
  *         (autograd of audiolm_pytorch.py:255-259, :351, :395, :961, :972) with no transposed copies; lda/ldb % 8 == 0. */
 int alm_gemm_splitk_slices(int M, int N, int K, int nb);
+int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb);
+int alm_debug_stream(int mode);     /* balanced split: 0 never (default), 1 by the cost model, 2 whenever applicable (benchmarks / tests) */
 /* tuning hook for benchmarks (process-global, not thread-safe; 0 = automatic): force the split-K tile (1 = 128x128, 2 = 256x256) and
  * slice count; raster 0 = plain grid, 1 = XCD-panel rasterisation of split-K launches (default) */
 int alm_debug_splitk(int tile, int slices, int raster);

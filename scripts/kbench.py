@@ -92,6 +92,28 @@ def bench_tn():
     _lib.call('alm_debug_splitk', 0, 0, 1)
 
 
+def bench_wgrad():
+    """every weight-gradient contraction of one layer (+ the coarse head) with the automatic split-K plan"""
+    T, I, Ip, D, H, dh = 16384, 2730, 2736, 1024, 8, 64
+    dU, XN2, dY, HN, AO, dQ, XN, dKV, X = rnd(T, 2 * Ip), rnd(T, D), rnd(T, D), rnd(T, Ip), rnd(T, H * dh), rnd(T, H * dh), rnd(T, D), rnd(T, 2 * dh), rnd(T, D)
+    cases = [
+        ('dW1 (x | gate batched)', lambda C: ops.gemm_tn_splitk(dU.view(T, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2, C), (2, I, D), 2 * I, D, 2),
+        ('dW2', lambda C: ops.gemm_tn_splitk(dY, HN[:, :I], C), (D, I), D, I, 1),
+        ('dWo', lambda C: ops.gemm_tn_splitk(dY, AO, C), (D, H * dh), D, H * dh, 1),
+        ('dWq', lambda C: ops.gemm_tn_splitk(dQ, XN, C), (H * dh, D), H * dh, D, 1),
+        ('dWkv', lambda C: ops.gemm_tn_splitk(dKV, X, C), (2 * dh, D), 2 * dh, D, 1),
+    ]
+    tot = 0.0
+    for name, fn, shape, M, N, nb in cases:
+        C = torch.empty(shape, dtype=F32, device=dev)
+        t = timeit(lambda: fn(C), iters=20)
+        sl = _lib.query('alm_gemm_splitk_slices', M // nb, N, T, nb)
+        fl = 2.0 * M * N * T
+        tot += t
+        print(f'{name:24s} [{M}x{N}] K={T}: slices {sl:2d}  {t * 1e3:7.1f} us  {fl / t / 1e9:5.0f} TF')
+    print(f'one layer: {tot * 1e3:.1f} us -> x6 = {tot * 6:.2f} ms/step; at the NT-256 rate (866 TF) it would be {313e9 / 866e12 * 6e3:.2f} ms')
+
+
 def bench_attn():
     B, N, H, dh = 8, 2048, 8, 64
     M = B * N

@@ -83,6 +83,38 @@ def test_gemm_tn_splitk(ops, M, N, K):
     assert relmax(C1, C0.double() + 0.25 * ref) <= 3e-5
 
 
+@pytest.mark.parametrize('M,N,K,nb', [(512, 1024, 4096, 1), (2730, 1024, 2048, 1), (1025, 300, 1100, 1), (1024, 2730, 16384, 1), (530, 512, 3000, 2), (256, 256, 1024, 1)])
+def test_gemm_balanced_split(ops, M, N, K, nb):
+    """the balanced split (one K-step range per CU, partial tiles in the workspace, second-stage sum) forced on, TN and NT, vs fp64;
+    and bit-identical results from two runs (no atomics, fixed summation order)."""
+    from audiolm_pytorch_amd import _lib
+    _lib.query('alm_debug_stream', 2)
+    try:
+        Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+        At, Bt = rnd(nb, K, Mp, seed=40, dtype=BF16), rnd(K, Np, seed=41, dtype=BF16)
+        A3 = At[:, :, :M] if nb > 1 else At[0, :, :M]
+        C = torch.full((nb, M, N) if nb > 1 else (M, N), float('nan'), dtype=F32, device=dev())
+        ops.gemm_tn_splitk(A3, Bt[:, :N], C)
+        ref = torch.einsum('bkm,kn->bmn', At[:, :, :M].double(), Bt[:, :N].double())
+        ref = ref if nb > 1 else ref[0]
+        assert relmax(C, ref) <= 3e-5
+        C2 = torch.empty_like(C)
+        ops.gemm_tn_splitk(A3, Bt[:, :N], C2)
+        assert torch.equal(C, C2)
+        C0 = rnd(*C.shape, seed=42)
+        C1 = C0.clone()
+        ops.gemm_tn_splitk(A3, Bt[:, :N], C1, alpha=0.5, accumulate=True)
+        assert relmax(C1, C0.double() + 0.5 * ref) <= 3e-5
+        if nb == 1:
+            Kp = (K + 7) // 8 * 8
+            A, B = rnd(M, Kp, seed=43, dtype=BF16), rnd(N, Kp, seed=44, dtype=BF16)
+            Cn = torch.full((M, N), float('nan'), dtype=F32, device=dev())
+            ops.gemm_nt_splitk(A, B, Cn)
+            assert relmax(Cn, A.double() @ B.double().t()) <= 3e-5
+    finally:
+        _lib.query('alm_debug_stream', 0)
+
+
 def test_gemm_tn_splitk_batched_halves(ops):
     """the FFN W1 weight gradient: both (x | gate) halves of dU against the same XN2 in ONE launch (batch stride = Ipad columns)."""
     T, I, Ip, D = 1000, 170, 176, 128
