@@ -222,41 +222,61 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
 class _SideStream:
     """Weight-gradient GEMMs are off the critical path of the backward chain (nothing downstream reads dW before the optimiser / the
-    gradient all-reduce), so they are issued on a second HIP stream and fill CUs the critical-path kernels leave idle (tails of the
+    gradient all-reduce), so they are issued on side HIP streams and fill CUs the critical-path kernels leave idle (tails of the
     causal attention grids, HBM-bound hyper-connection / LayerNorm kernels, launch gaps).  Inputs are pinned with record_stream so the
-    caching allocator cannot recycle them while the side stream still reads them."""
+    caching allocator cannot recycle them while a side stream still reads them.  With more than one side stream (ALM_SIDE_STREAMS) the
+    GEMMs are dealt round-robin, so the partial last wave of one weight gradient also overlaps the next one."""
     _streams = {}
 
     def __init__(self, dev, enabled=True):
         self.enabled = enabled and dev.type == 'cuda'
         if self.enabled:
-            key = (dev.type, dev.index)
+            key = (dev.type, dev.index, SIDE_STREAMS)
             if key not in _SideStream._streams:
-                _SideStream._streams[key] = torch.cuda.Stream(device=dev)
-            self.stream = _SideStream._streams[key]
+                _SideStream._streams[key] = [torch.cuda.Stream(device=dev) for _ in range(SIDE_STREAMS)]
+            self.streams = _SideStream._streams[key]
             self.main = torch.cuda.current_stream(dev)
+            self.turn = 0
+
+    def _issue(self, stream, fn, tensors):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        for t in tensors:
+            t.record_stream(stream)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev)
+            return fn()
 
     def run(self, fn, *tensors):
         if not self.enabled:
             return fn()
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        for t in tensors:
-            t.record_stream(self.stream)
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
+        stream = self.streams[self.turn % len(self.streams)]
+        self.turn += 1
+        return self._issue(stream, fn, tensors)
+
+    def run_after_all(self, fn, *tensors):
+        """fn on side stream 0, ordered after everything issued on every side stream so far (the per-layer gradient hand-off)"""
+        if not self.enabled:
             return fn()
+        s0 = self.streams[0]
+        for s in self.streams[1:]:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            s0.wait_event(ev)
+        return self._issue(s0, fn, tensors)
 
     def join(self):
-        """main stream waits for everything issued on the side stream so far"""
+        """main stream waits for everything issued on the side streams so far"""
         if self.enabled:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            self.main.wait_event(ev)
+            for s in self.streams:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                self.main.wait_event(ev)
 
 
 FUSE_LN_BWD = os.environ.get('ALM_FUSE_LN_BWD', '1') != '0'             # switch: pre-LayerNorm backward inside the hyper-connection kernel
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
+SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
 
 def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None):
@@ -375,7 +395,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         if on_layer_grads is not None:
             # the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the critical
             # path never waits for them
-            side.run(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
+            side.run_after_all(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
     dx = dR.view(B, N, D)
     dtbl = ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None
