@@ -14,6 +14,7 @@ from . import _lib  # noqa: F401  (fails loudly if libaudiolm_hip.so can neither
 from .attend import Attend
 from .audiolm_pytorch import (AudioLM, CoarseTransformer, CoarseTransformerWrapper, FineTransformer, FineTransformerWrapper,
                               SemanticTransformer, SemanticTransformerWrapper, Transformer, get_embeds)
+from .optimizer import FusedAdam, get_optimizer
 from .soundstream import SoundStream
 from .version import __version__
 
@@ -29,6 +30,8 @@ def install_as_reference():
     sys.modules['audiolm_pytorch'] = pkg
     sys.modules['audiolm_pytorch.audiolm_pytorch'] = audiolm_pytorch
     sys.modules['audiolm_pytorch.attend'] = attend
+    from . import optimizer
+    sys.modules['audiolm_pytorch.optimizer'] = optimizer          # trainer.py:32 `from audiolm_pytorch.optimizer import get_optimizer`
     try:
         from . import soundstream
         sys.modules['audiolm_pytorch.soundstream'] = soundstream

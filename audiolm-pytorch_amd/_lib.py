@@ -71,6 +71,9 @@ SIGNATURES = {
     'alm_cross_entropy_fwd': [_P, _L, _P, _P, _P, _L, _I, _I, _P],
     'alm_cross_entropy_bwd': [_P, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     'alm_reduce_sum': [_P, _L, _P, _F, _P],
+    'alm_opt_chunk_elems': [],
+    'alm_opt_grad_sumsq': [_P, _P, _I, _P, _P],
+    'alm_opt_adam_step': [_P, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
     'alm_conv1d_packed_floats': [_I, _I, _I],
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
     'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -111,6 +114,11 @@ def load(build_if_missing: bool = True):
         fn.restype = c_int
     _lib = lib
     return lib
+
+
+class AlmOptTensor(ctypes.Structure):
+    """mirror of AlmOptTensor in include/audiolm_hip.h"""
+    _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_longlong), ('wd', c_float), ('reserved', c_int)]
 
 
 class AlmPackJob(ctypes.Structure):

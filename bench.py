@@ -75,6 +75,9 @@ def cpu_baseline(max_seconds=30.0):
                 sample=f'oracle (CPU fp32 restatement of the reference, 4 residual streams) fwd+bwd, B=1 x N={SEQ}, best of {max(1, len(times) - 1)} after 1 warm-up')
 
 
+PRIME_STEPS = 10
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.json: FETCH_SIZE x 2
     per the MI355X guide's gfx950 correction + WRITE_SIZE), or None when the summary is absent.  Counters cannot be collected inside this
@@ -159,6 +162,10 @@ def main():
             dt = float(t)
         return dt
 
+    # untimed priming in addition to --warmup: the first steps grow the caching allocator's pools (main + side stream) and run at ramping
+    # clocks; measured on MI355X the step time only settles after ~10 steps (17.6 -> 16.4 ms).  The timed region below is exactly --steps steps.
+    for _ in range(PRIME_STEPS):
+        loss = step()
     for _ in range(args.warmup):
         loss = step()
     dt = timed(args.steps)
@@ -232,11 +239,44 @@ def main():
 
     opt_leg = None
     if not args.no_optimizer_leg:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.99))     # reference optimizer.py:get_optimizer (wd = 0 -> Adam)
-        step(opt)
-        dto = timed(max(3, args.steps // 2), opt)
+        # full training step as the reference trainer runs it (trainer.py:1241-1255): fwd + bwd (+ gradient all-reduce) + clip_grad_norm_(0.5)
+        # + Adam (optimizer.py:get_optimizer, wd = 0 -> Adam).  Ours: FusedAdam (two HIP launches, norm kept on the device); beside it the
+        # same step with torch.optim.Adam + torch.nn.utils.clip_grad_norm_ as the stock baseline.
         nst = max(3, args.steps // 2)
-        opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * B_PER_GPU * SEQ / (dto / nst), 1), optimizer='torch.optim.Adam')
+
+        def opt_step(opt, clip):
+            cache.store.clear()
+            for p in model.parameters():
+                p.grad = None
+            wrapper(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True).backward()
+            if engine is not None:
+                engine.finish()
+            clip(opt)
+            opt.step()
+
+        def timed_opt(opt, clip):
+            opt_step(opt, clip)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(nst):
+                opt_step(opt, clip)
+            barrier()
+            dt_ = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ = float(t)
+            return dt_
+        state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        fused = A.get_optimizer(model.parameters(), lr=1e-5, wd=0.)
+        dto = timed_opt(fused, lambda o: o.clip_grad_norm_(0.5))
+        del fused
+        model.load_state_dict(state0)
+        stock = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.99))
+        dts = timed_opt(stock, lambda o: torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5))
+        opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * B_PER_GPU * SEQ / (dto / nst), 1),
+                       optimizer='FusedAdam (alm_opt_grad_sumsq + alm_opt_adam_step): clip_grad_norm_(0.5) + Adam',
+                       torch_adam_ms_per_step=round(dts / nst * 1e3, 3))
 
     if rank == 0:
         out = {

@@ -186,6 +186,21 @@ int alm_cross_entropy_bwd(const float* logits, long long ld, const long long* la
                           long long ldd, long long rows, int C, int Cpad, int ignore_index, void* stream);
 int alm_reduce_sum(const float* in, long long n, float* out, float scale, void* stream);
 
+/* ---- fused optimiser step: global-norm clip (trainer.py:953-954 accelerator.clip_grad_norm_) + Adam / AdamW (optimizer.py:get_optimizer) over
+ * every parameter in two launches.  `tensors`: DEVICE array of AlmOptTensor; `chunks`: DEVICE int32 pairs (tensor index, chunk index), one
+ * per alm_opt_chunk_elems() elements of each tensor.  alm_opt_grad_sumsq writes one partial sum of squares per chunk (alm_reduce_sum over it =
+ * the squared global gradient norm, kept on the device); alm_opt_adam_step applies coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) to the
+ * gradients on the fly (sumsq NULL: no clipping), then torch.optim.Adam's update (decoupled_weight_decay 1: AdamW).  All fp32. */
+typedef struct AlmOptTensor {
+    void* p; const void* g; void* m; void* v;   /* parameter, gradient, exp_avg, exp_avg_sq */
+    long long n;                                /* elements */
+    float wd; int reserved;                     /* weight decay of this tensor */
+} AlmOptTensor;
+int alm_opt_chunk_elems(void);
+int alm_opt_grad_sumsq(const AlmOptTensor* tensors, const int* chunks, int nchunks, float* partial, void* stream);
+int alm_opt_adam_step(const AlmOptTensor* tensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
+                      int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream);
+
 /* ---- SoundStream tokenize path (encode only): soundstream.py:332-345, 362-380, 519-531 (causal conv encoder), :592-607 / :840 ----
  * (eval-mode GroupedResidualVQ of vector-quantize-pytorch, restated in oracle/rvq_restated.py).  All fp32: the code indices are an
  * argmin over float distances, so both kernels run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), never bf16.

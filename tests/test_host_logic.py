@@ -203,3 +203,20 @@ def test_structured_bias_index_vectors_reproduce_the_reference_bias():
         assert torch.allclose(got_f[:, causal], want_f[:, causal], atol=1e-5), (nc, nf)
         for t in index:
             assert t.dtype == torch.int32 and t.shape == (N,)
+
+
+def test_get_optimizer_grouping_matches_reference_rule():
+    """optimizer.py:3-37: wd == 0 -> Adam over the plain parameter list; wd > 0 -> AdamW with weight decay only on ndim >= 2 parameters."""
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.LayerNorm(3))
+    o = A.get_optimizer(m.parameters(), lr=3e-4, wd=0.)
+    assert len(o.param_groups) == 1 and o.param_groups[0]['weight_decay'] == 0 and not o.param_groups[0]['decoupled_weight_decay']
+    assert o.param_groups[0]['lr'] == 3e-4 and o.param_groups[0]['betas'] == (0.9, 0.99) and o.param_groups[0]['eps'] == 1e-8
+    o = A.get_optimizer(m.parameters(), lr=1e-4, wd=1e-2)
+    assert len(o.param_groups) == 2
+    assert all(p.ndim >= 2 for p in o.param_groups[0]['params']) and o.param_groups[0]['weight_decay'] == 1e-2
+    assert all(p.ndim < 2 for p in o.param_groups[1]['params']) and o.param_groups[1]['weight_decay'] == 0
+    assert all(g['decoupled_weight_decay'] for g in o.param_groups)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(Exception):                 # CPU parameters are refused at step time (no CPU fallback)
+        o.step()
