@@ -101,7 +101,7 @@ template <int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
 __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     using C = Coef<S>;
     constexpr int TPB = 4 / WPT;
-    constexpr int NV = (S == 4) ? 32 : 16;                       // slots: ss[S] | dots[S][S+2] | sums[S]
+    constexpr int NV = (S >= 3) ? 32 : 16;                       // slots: ss[S] | dots[S][S+2] | sums[S]  (S = 4: 32, 3: 21, 2: 12)
     constexpr int O_DOT = S, O_SUM = S + S * (S + 2);
     static_assert(O_SUM + S <= NV, "slot budget");
     __shared__ float red[TPB * WPT * NV];
@@ -304,7 +304,7 @@ template <int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
     constexpr int TPB = 4 / WPT;
-    constexpr int NV = (S == 4) ? 32 : 16;                       // width slots: dal[S][S+1] | (LNF) sum R_s [S] | <xhat, R_s> [S] | sum g | sum g xhat
+    constexpr int NV = (S >= 3) ? 32 : 16;                       // width slots: dal[S][S+1] | (LNF) sum R_s [S] | <xhat, R_s> [S] | sum g | sum g xhat
     constexpr int NB = S * (S + 1);
     constexpr int O_SR = NB, O_XR = NB + S, O_C1 = NB + 2 * S, O_C2 = NB + 2 * S + 1;
     static_assert(O_C2 < NV, "slot budget");
@@ -728,6 +728,7 @@ extern "C" int alm_hc_grads_width(int S, int D) { return D * (S + 4) + S * (S + 
 /* number of partial rows alm_hc_bwd writes for (mode, fused-LayerNorm or not): one per RESIDENT workgroup and token slot */
 extern "C" int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D) {
     if (S == 2) return bwd_rows<2>(mode, fused_ln != 0, tokens, D);
+    if (S == 3) return bwd_rows<3>(mode, fused_ln != 0, tokens, D);
     if (S == 4) return bwd_rows<4>(mode, fused_ln != 0, tokens, D);
     return 0;
 }
@@ -746,6 +747,7 @@ extern "C" int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev, 
                 (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, B, N, D};
     int rc;
     if (S == 2) rc = dispatch_fwd<2>(a, mode, (hipStream_t)stream);
+    else if (S == 3) rc = dispatch_fwd<3>(a, mode, (hipStream_t)stream);
     else if (S == 4) rc = dispatch_fwd<4>(a, mode, (hipStream_t)stream);
     else return ALM_ERR_UNSUPPORTED;
     if (rc) return rc;
@@ -773,6 +775,7 @@ extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long
                 B, N, D};
     int rc;
     if (S == 2) rc = dispatch_bwd<2>(a, mode, lnf, (hipStream_t)stream);
+    else if (S == 3) rc = dispatch_bwd<3>(a, mode, lnf, (hipStream_t)stream);
     else if (S == 4) rc = dispatch_bwd<4>(a, mode, lnf, (hipStream_t)stream);
     else return ALM_ERR_UNSUPPORTED;
     if (rc) return rc;
@@ -787,6 +790,7 @@ extern "C" int alm_hc_param_grads(const float* sums, const float* hc_gamma, cons
     HcParams hp{hc_gamma, Wa, nullptr, nullptr, wb, nullptr, nullptr};
     const int grid = (D + 255) / 256;
     if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
+    else if (S == 3) hipLaunchKernelGGL(hc_param_grads_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
     else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
     else return ALM_ERR_UNSUPPORTED;
     ALM_LAUNCH_CHECK();

@@ -335,7 +335,7 @@ def _hc_sd(hc):
             'dynamic_beta_fn': hc['wb'], 'dynamic_beta_scale': hc['sb'], 'static_beta': hc['Bb']}
 
 
-@pytest.mark.parametrize('S,D', [(4, 64), (4, 1024), (2, 256), (4, 512)])
+@pytest.mark.parametrize('S,D', [(4, 64), (4, 1024), (2, 256), (4, 512), (3, 128), (3, 1024)])
 def test_hyper_connections(ops, S, D):
     import audiolm_oracle as O
     B, N = 2, 9
@@ -375,7 +375,7 @@ def test_hyper_connections(ops, S, D):
         assert e <= 1e-2, f'hc grad {k} rel-max err {e}'
 
 
-@pytest.mark.parametrize('S,D,N', [(4, 1024, 19), (4, 256, 37), (2, 512, 10)])
+@pytest.mark.parametrize('S,D,N', [(4, 1024, 19), (4, 256, 37), (2, 512, 10), (3, 256, 21)])
 def test_hyper_connections_fused_modes(ops, S, D, N):
     """the fused product-path modes (depth of branch k + width of branch k+1 in one pass; final depth + stream sum + LayerNorm; width
     backward of branch k+1 + depth backward of branch k; stream-broadcast gradients) against the single-connection kernels that

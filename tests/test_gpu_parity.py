@@ -271,6 +271,17 @@ def test_fine_default_ctor_pos_bias_mlp_vs_oracle():
     _check('fine default ctor (pos_bias_mlp + null_pos_bias)', *res)
 
 
+@pytest.mark.parametrize('dim,heads,streams,depth,n,flash', [(192, 3, 2, 2, 77, True), (64, 1, 1, 3, 33, True), (320, 5, 4, 1, 130, True), (128, 6, 3, 2, 65, False),
+                                                             (96, 2, 4, 2, 257, False)])
+def test_odd_shapes_vs_oracle(dim, heads, streams, depth, n, flash):
+    """widths / head counts / stream counts / lengths that are not the benchmark's multiples of 256 / 4 / 64 (both attention variants)"""
+    g = torch.Generator().manual_seed(dim + n)
+    ctor = dict(dim=dim, depth=depth, heads=heads, num_semantic_tokens=50, num_residual_streams=streams, flash_attn=flash)
+    ids = torch.randint(0, 50, (3, n), generator=g)
+    res = _oracle_vs_ours('semantic', ctor, dict(ids=ids, forgetful_mask=None), dict(training=True, unique_consecutive=False, mask_prob=0.), seed=dim)
+    _check(f'semantic d{dim} h{heads} S{streams} depth{depth} n{n} flash={flash}', *res)
+
+
 def test_full_size_properties():
     """BASELINE configs[1]/[3] full size (dim=1024, depth=6, N=2048 per sequence): size-independent properties instead of the oracle:
     finite loss near ln(C)-scale, every parameter receives a finite gradient, run-to-run determinism of loss, and
