@@ -10,7 +10,7 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libaudiolm_hip.so')
+LIB_PATH = os.environ.get('ALM_LIB_PATH') or os.path.join(_HERE, 'libaudiolm_hip.so')      # ALM_LIB_PATH: A/B runs of an alternative build
 
 _P, _I, _L, _F = c_void_p, c_int, c_longlong, c_float
 
@@ -96,7 +96,7 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    if build_if_missing and not os.environ.get('ALM_LIB_PATH'):
         from . import build as _build
         try:
             _build.build(verbose=False)
