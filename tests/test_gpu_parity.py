@@ -308,6 +308,49 @@ def test_full_size_properties():
     assert abs(float(l2) - 0.5 * (float(la) + float(lb))) <= 1e-4 * abs(float(l2)), (float(l2), float(la), float(lb))
 
 
+@pytest.mark.parametrize('kind', ['coarse', 'fine'])
+def test_default_ctor_full_size_properties(kind):
+    """The reference's DEFAULT constructors (flash_attn=False: relative-position / cross-attention / frame x quantizer bias tables) at full
+    width and length (dim=1024, N=2048 / 2049): finite loss, every parameter incl. the bias MLPs gets a finite gradient, and the whole
+    backward -- table-gradient windows, integer LDS accumulation, partial-table flush -- is bit-reproducible run to run."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(6)
+    if kind == 'coarse':
+        model = A.CoarseTransformer(dim=1024, depth=2, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3).to(dev)
+        w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
+        kw = dict(semantic_token_ids=torch.randint(0, 500, (2, 509), generator=g).to(dev), coarse_token_ids=torch.randint(0, 1024, (2, 512, 3), generator=g).to(dev))
+    else:
+        model = A.FineTransformer(dim=1024, depth=2, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024).to(dev)
+        w = A.FineTransformerWrapper(transformer=model, codec=Codec(), mask_prob=0.15)
+        grid = torch.randint(0, 1024, (2, 256, 8), generator=g).to(dev)
+        kw = dict(coarse_token_ids=grid[..., :3], fine_token_ids=grid[..., 3:])
+    w.train()
+
+    def run():
+        torch.manual_seed(1)                                   # same forgetful mask both times
+        for p in model.parameters():
+            p.grad = None
+        loss = w(**kw, return_loss=True)
+        loss.backward()
+        return float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    l1, g1 = run()
+    l2, g2 = run()
+    assert l1 == l1 and abs(l1) < 1e3
+    bias_keys = [k for k in g1 if 'pos_bias' in k or 'cross_attn_bias' in k]
+    assert len(bias_keys) >= 6, bias_keys
+    missing = [k for k, p in model.named_parameters() if p.grad is None and 'proj_text_embed' not in k]
+    assert not missing, missing
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+    assert all(float(g1[k].abs().max()) > 0 for k in bias_keys)
+    assert l1 == l2
+    # embedding-table gradients are scatter-adds with fp32 atomics (like torch's embedding backward): reproducible to rounding only
+    exact = [k for k in g1 if 'embedding' not in k]
+    assert all(torch.equal(g1[k], g2[k]) for k in exact), [k for k in exact if not torch.equal(g1[k], g2[k])][:5]
+    assert all(_frob(g1[k], g2[k]) <= 1e-5 for k in g1 if 'embedding' in k)
+
+
 def test_fine_full_size_properties():
     """BASELINE configs[2]: FineTransformer dim=1024 depth=6, 3 coarse + 5 fine quantizers, 256 frames -> N = 2049 (NOT a multiple of the
     64-token attention / GEMM tiles): finite loss, every used parameter gets a finite gradient, deterministic forward, batch-row independence."""
