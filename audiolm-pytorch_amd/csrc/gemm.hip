@@ -25,6 +25,8 @@
 //     (einsum 'q c d, b n q d -> b n q c').
 // Requirements: NT: K % 8 == 0, lda/ldb % 8 == 0;  TN: lda/ldb % 8 == 0;  A/B 16-byte aligned; every operand view < 2 GiB.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 #include <array>
 #include <map>
 #include <vector>
@@ -168,16 +170,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {           // counted wait: at most N vector-memory operations (here: LDS DMA pieces) still in flight
-    static_assert(N == 0 || N == 6 || N == 8, "add the literal");
+    static_assert(N == 0 || N == 6 || N == 8 || N == 16, "add the literal");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
 // STAGES = 2: one __syncthreads per K-step, the next step's DMA is in flight during the current step's MFMAs (prefetch distance 1).
 // STAGES = 3: prefetch distance 2 -- the DMA of step k+2 is issued at step k and stays in flight ACROSS the barrier of step k: the barrier
 //             is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(pieces of one stage), so only step k+1's data is waited for.
-template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int NW = WM * WN;
@@ -358,51 +361,95 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (STAGES == 3) {
-            if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);       // (kt + 2) % 3: the buffer read during step kt - 1
+    // fragment reads of sub-step `ks` of the stage at `sb` into register set `fb`
+    bf16x8 a[2][TM], b[2][TNB];
+    auto load_frags = [&](const unsigned char* sb, int ks, auto fbc) {
+        constexpr int fb = decltype(fbc)::value;
+        if (!TNMODE) {
+            const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[fb][i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) b[fb][j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
         } else {
-            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        }
-        const unsigned char* sb = smem + buf * STAGE;
+            // k-groups ks*4 + (g>>1)*2 + {0, 1}; consecutive k-groups are (Bx/16)*128 bytes apart
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[TM], b[TNB];
-            if (!TNMODE) {
-                const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
-#pragma unroll
-                for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
-            } else {
-                // k-groups ks*4 + (g>>1)*2 + {0, 1}; consecutive k-groups are (Bx/16)*128 bytes apart
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned char* ad = sb + fragA[i] + ks * 4 * (BM / 16) * 128;
-                    a[i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BM / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-                for (int j = 0; j < TNB; ++j) {
-                    const unsigned char* ad = sb + fragB[j] + ks * 4 * (BN / 16) * 128;
-                    b[j] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BN / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+            for (int i = 0; i < TM; ++i) {
+                const unsigned char* ad = sb + fragA[i] + ks * 4 * (BM / 16) * 128;
+                a[fb][i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BM / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TNB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
+            for (int j = 0; j < TNB; ++j) {
+                const unsigned char* ad = sb + fragB[j] + ks * 4 * (BN / 16) * 128;
+                b[fb][j] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BN / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         }
-        if (STAGES == 3) {
-            // this wave's LDS reads of the step are complete (their results fed the MFMAs above); step kt+1's DMA must have landed,
-            // step kt+2's (just issued) may stay in flight
-            if (kt + 2 < nk) wait_vmcnt<NIA + NIB>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            buf = buf == 2 ? 0 : buf + 1;
-        } else {
-            __syncthreads();
+    };
+    auto mfmas = [&](auto fbc) {
+        constexpr int fb = decltype(fbc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[fb][j], a[fb][i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
+    };
+    using FB0 = std::integral_constant<int, 0>;
+    using FB1 = std::integral_constant<int, 1>;
+
+    int buf = 0;
+    if (PIPE) {
+        // Software-pipelined main loop (2 stages): the fragment reads of sub-step ks + 1 are issued BEFORE the MFMAs of sub-step ks into the
+        // other register set, with scheduling fences so that the compiler keeps that order (left to itself it emits read, wait, 4 MFMAs,
+        // read, wait, ...: every LDS latency exposed).  The hand-over barrier of a K-step sits before the LAST sub-step's MFMAs: by then this
+        // wave's reads of the stage are complete (its last fragments are in registers), so after the barrier the first fragments of the next
+        // stage are fetched underneath those MFMAs.
+        static_assert(!PIPE || STAGES == 2, "pipelined loop: 2 stages");
+        load_frags(smem, 0, FB0{});
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            const unsigned char* sb = smem + buf * STAGE;
+            load_frags(sb, 1, FB1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(FB0{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(sb, 2, FB0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(FB1{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(sb, 3, FB1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(FB0{});
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                   // reads of `buf` done (lgkmcnt 0), next stage landed (vmcnt 0), all waves agree
             buf ^= 1;
+            if (kt + 1 < nk) load_frags(smem + buf * STAGE, 0, FB0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(FB1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (STAGES == 3) {
+                if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);       // (kt + 2) % 3: the buffer read during step kt - 1
+            } else {
+                if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+            }
+            const unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                load_frags(sb, ks, FB0{});
+                mfmas(FB0{});
+            }
+            if (STAGES == 3) {
+                // this wave's LDS reads of the step are complete (their results fed the MFMAs above); step kt+1's DMA must have landed,
+                // step kt+2's (just issued) may stay in flight
+                if (kt + 2 < nk) wait_vmcnt<NIA + NIB>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                buf = buf == 2 ? 0 : buf + 1;
+            } else {
+                __syncthreads();
+                buf ^= 1;
+            }
         }
     }
 
@@ -683,11 +730,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs pj) {
 }
 
 // ---- launch plumbing ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int STAGES = 2, bool PIPE = false>
 int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
     static bool attr_done = false;                 // idempotent; a benign race sets the same value twice
-    auto kfn = gemm_kernel<BM, BN, WM, WN, TNMODE, OUT_F32, STAGES>;
+    auto kfn = gemm_kernel<BM, BN, WM, WN, TNMODE, OUT_F32, STAGES, PIPE>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -706,10 +753,10 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU), 3 = 256x128 with a 3-stage DMA ring (8 waves)
 int pick_tile(int M, int N, int ny, int tile) {
-    if (tile >= 1 && tile <= 4) return tile;
+    if (tile >= 1 && tile <= 7) return tile;
     if (M < 256 || N < 256) return 1;
     const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
-    return big >= 192 ? 2 : 1;                     // enough 256^2 tiles to occupy most of the 256 CUs
+    return big >= 192 ? 2 : 1;              // enough 256^2 tiles to occupy most of the 256 CUs
 }
 
 template <bool OUT_F32>
@@ -729,11 +776,16 @@ int launch_persist(const GemmParams& p, int ny, hipStream_t st) {
 
 template <bool TNMODE>
 int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
-    const int tl = pick_tile(p.M, p.N, ny * nz, tile);
+    int tl = pick_tile(p.M, p.N, ny * nz, tile);
+    static const int big_tile = [] { const char* e = getenv("ALM_GEMM_BIG_TILE"); return e ? atoi(e) : 2; }();
+    if (tl == 2) tl = big_tile;                    // ALM_GEMM_BIG_TILE=7: every 256 x 256 launch (incl. split-K plans) takes the pipelined loop
     if (tl == 4) {
         if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0) return ALM_ERR_UNSUPPORTED;
         return out_f32 ? launch_persist<true>(p, ny, st) : launch_persist<false>(p, ny, st);
     }
+    if (tl == 5) return out_f32 ? launch_cfg<256, 256, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 2, TNMODE, false>(p, ny, nz, st);   // 4 waves x (128 x 128)
+    if (tl == 6) return out_f32 ? launch_cfg<256, 256, 2, 2, TNMODE, true, 2, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 2, TNMODE, false, 2, true>(p, ny, nz, st);   // + pinned read / MFMA interleave
+    if (tl == 7) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true, 2, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false, 2, true>(p, ny, nz, st);   // 8 waves + pinned interleave
     if (tl == 3) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true, 3>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false, 3>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);
