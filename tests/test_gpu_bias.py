@@ -204,3 +204,30 @@ def test_pos_table_mlp(ops, in_dim, nhid, L, C, H):
         err = float((a.grad.cpu().double() - b.grad.double()).norm() / b.grad.double().norm().clamp(min=1e-30))
         assert err <= 5e-2, f'MLP parameter {i} grad rel-frob {err}'
     assert relmax(sp_g.grad.cpu(), sp_r.grad) <= 1e-5
+
+
+def test_attend_module_with_structured_bias():
+    """the Attend mirror (reference attend.py:98-146 signature: q (b h n d), k / v (b n d), mask, attn_bias) with a structured bias: output and
+    the gradients of q, k, v AND the bias table vs the oracle's math path fed the dense tensor"""
+    import audiolm_pytorch_amd as A
+    from audiolm_pytorch_amd import relpos
+    B, H, N, d = 2, 8, 150, 64
+    q = rnd(B, H, N, d, seed=60).requires_grad_(True)
+    k = rnd(B, N, d, seed=61).requires_grad_(True)
+    v = rnd(B, N, d, seed=62).requires_grad_(True)
+    g = torch.Generator().manual_seed(63)
+    mask = (torch.rand(B, N, generator=g) > 0.2)
+    mask[:, 0] = True
+    mask = mask.to(dev())
+    index = relpos.toeplitz_index(N, dev(), num_leading=40)
+    tbl = rnd(H, 2 * N, seed=64, scale=6.0).requires_grad_(True)
+    out = A.Attend(causal=True)(q, k, v, mask=mask, attn_bias=relpos.AttnBias(tbl, *index))
+    go = rnd(B, H, N, d, seed=65)
+    out.backward(go)
+    qr, kr, vr, tr = [t.detach().clone().requires_grad_(True) for t in (q, k, v, tbl)]
+    # the kernels see bf16 operands: give the reference the same rounded q / k / v
+    ref = O.attend(qr.bfloat16().float(), kr.bfloat16().float(), vr.bfloat16().float(), mask=mask, attn_bias=dense_bias(tr, index), causal=True)
+    ref.backward(go.bfloat16().float())
+    assert relmax(out, ref) <= 1.2e-2
+    for name, got, want in (('dq', q.grad, qr.grad), ('dk', k.grad, kr.grad), ('dv', v.grad, vr.grad), ('dtbl', tbl.grad, tr.grad)):
+        assert relmax(got, want) <= 2e-2, (name, relmax(got, want))
