@@ -220,3 +220,23 @@ def test_get_optimizer_grouping_matches_reference_rule():
         p.grad = torch.zeros_like(p)
     with pytest.raises(Exception):                 # CPU parameters are refused at step time (no CPU fallback)
         o.step()
+
+
+def test_install_as_reference_registers_the_reference_import_paths():
+    """after install_as_reference() the reference trainer's own import lines (trainer.py:32-48) resolve to this
+    package.  Run in a subprocess: it rewires sys.modules."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import audiolm_pytorch_amd as A\n"
+        "A.install_as_reference()\n"
+        "from audiolm_pytorch.audiolm_pytorch import SemanticTransformer, CoarseTransformer, FineTransformer, SemanticTransformerWrapper, "
+        "CoarseTransformerWrapper, FineTransformerWrapper\n"
+        "from audiolm_pytorch.soundstream import SoundStream\n"
+        "from audiolm_pytorch.optimizer import get_optimizer\n"
+        "from audiolm_pytorch.attend import Attend\n"
+        "assert SemanticTransformer is A.SemanticTransformer and SoundStream is A.SoundStream and get_optimizer is A.get_optimizer\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
