@@ -11,8 +11,10 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
   RelativePositionBias / pos_bias_mlp       -> relpos.PosTableFn         (`flash_attn=False` models: the bias stays a per-head table that
                                                                           the attention kernels index in place; no (h, n, n) tensor)
 
-Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning, kv-cache /
-generate(), arbitrary dense `attn_bias` tensors.
+  *TransformerWrapper.generate()            -> the same forward path, prefix recomputed every step (no kv cache yet); sampling helpers in torch
+
+Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning, kv / embed caches
+(generate() works but is O(n^2) forwards), waveform reconstruction (SoundStream decoder), dense `attn_bias` tensors.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
 from __future__ import annotations
@@ -81,6 +83,53 @@ def append_eos_id(ids, eos_id):                               # audiolm_pytorch.
 def batch_unique_consecutive(t, pad_value=0.):                # audiolm_pytorch.py:162-164
     unique_arr = [torch.unique_consecutive(el) for el in t.unbind(dim=0)]
     return pad_sequence(unique_arr, batch_first=True, padding_value=pad_value)
+
+
+# sampling helpers (audiolm_pytorch.py:96-130): integer / tiny (batch, vocab) bookkeeping of the generate() loops, in torch ops
+
+def log(t, eps=1e-20):
+    return torch.log(t + eps)
+
+
+def gumbel_noise(t):
+    noise = torch.zeros_like(t).uniform_(0, 1)
+    return -log(-log(noise))
+
+
+def gumbel_sample(t, temperature=1., dim=-1):
+    return ((t / temperature) + gumbel_noise(t)).argmax(dim=dim)
+
+
+def top_k(logits, thres=0.5):
+    num_logits = logits.shape[-1]
+    k = max(int((1 - thres) * num_logits), 1)
+    val, ind = torch.topk(logits, k)
+    probs = torch.full_like(logits, float('-inf'))
+    probs.scatter_(1, ind, val)
+    return probs
+
+
+def mask_out_after_eos_id(t, eos_id, mask_value=-1, keep_eos=True):
+    eos_mask = (t == eos_id).float()
+    if keep_eos:
+        eos_mask = F.pad(eos_mask, (1, -1))
+    after_eos_mask = eos_mask.cumsum(dim=-1) > 0
+    return t.masked_fill(after_eos_mask, mask_value)
+
+
+def all_rows_have_eos_id(t, eos_id):
+    eos_mask = (t == eos_id)
+    return torch.any(eos_mask, dim=-1).all()
+
+
+def eval_decorator(fn):                                        # audiolm_pytorch.py:71-78
+    def inner(model, *args, **kwargs):
+        was_training = model.training
+        model.eval()
+        out = fn(model, *args, **kwargs)
+        model.train(was_training)
+        return out
+    return inner
 
 
 def get_embeds(embeddings: nn.Embedding, codes: torch.Tensor, pad_id=-1, return_mask=False, mask_pad_pos_to=0):
@@ -399,8 +448,18 @@ class _TransformerBase(nn.Module):
         if exists(text) or exists(text_embeds) or self.has_condition:
             raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
 
-    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
-        raise NotImplementedError('classifier-free-guidance sampling (inference) is SURVEY.md §8(f) item 2')
+    def forward_with_cond_scale(self, *args, cond_scale=3, kv_cache=None, embed_cache=None, return_kv_cache=False, **kwargs):
+        """audiolm_pytorch.py:639-667 / :818-855 / :1082-1130 for un-conditioned models (`cond_scale == 1 or not self.has_condition` branch:
+        classifier-free guidance needs text conditioning, which is out of scope).  No kv / embed cache exists on this path yet: the prefix
+        is recomputed, which gives the same logits; the cache slots of the return value are None."""
+        if self.has_condition:
+            raise NotImplementedError('classifier-free guidance needs text / audio conditioning (out of scope, SURVEY.md §2 row 12)')
+        if exists(kv_cache) or exists(embed_cache):
+            raise NotImplementedError('kv-cache decoding is SURVEY.md §8(f) item 2: call without caches (the prefix is recomputed)')
+        out = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if not return_kv_cache:
+            return out
+        return out, ((None, None) if isinstance(out, tuple) else None)
 
     def _init_common(self, *, t5_name, has_condition, cond_dim, audio_text_condition, cond_drop_prob, dim):
         if audio_text_condition:
@@ -676,8 +735,8 @@ class _WrapperBase(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def generate(self, *a, **k):
-        raise NotImplementedError('autoregressive sampling is SURVEY.md §8(f) item 2 (out of scope this round)')
+    def _reconstruct(self, ids):
+        raise NotImplementedError('waveform reconstruction needs the SoundStream decoder (SURVEY.md §8(f) item 3): call with reconstruct_wave=False')
 
     def embed_text(self, text):
         raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
@@ -697,6 +756,41 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
         self.pad_id = pad_id
         self.eos_id = transformer.eos_id
         self.mask_prob = mask_prob
+
+    @eval_decorator
+    @torch.inference_mode()
+    def generate(self, *, max_length, text=None, text_embeds=None, prime_wave=None, prime_wave_input_sample_hz=None, prime_ids=None,
+                 batch_size=1, cond_scale=3, filter_thres=0.9, temperature=1., use_kv_cache=True, include_eos_in_output=True, **kwargs):
+        """audiolm_pytorch.py:1406-1511.  Same sampling semantics (top-k filter, gumbel-max, eos stop, mask after eos); the transformer call
+        recomputes the prefix each step on the HIP forward path (no kv cache yet): `use_kv_cache` only changes
+        speed in the reference, never the result."""
+        device = self.device
+        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
+            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        if exists(prime_wave):
+            assert not exists(prime_ids)
+            assert exists(self.wav2vec)
+            ids = self.wav2vec(prime_wave, flatten=False, input_sample_hz=prime_wave_input_sample_hz)
+        elif exists(prime_ids):
+            ids = prime_ids
+        else:
+            ids = torch.empty((batch_size, 0), dtype=torch.long, device=device)
+        if self.unique_consecutive:
+            ids = batch_unique_consecutive(ids, pad_value=self.pad_id)
+        batch = ids.shape[0]
+        start_length = ids.shape[-1]
+        sample_semantic_ids = ids.clone()
+        last_logit_indices = (ids != self.pad_id).sum(dim=-1).long()
+        for ind in range(start_length, max_length):
+            logits = self.transformer.forward_with_cond_scale(ids=sample_semantic_ids, cond_scale=cond_scale, **kwargs)
+            last_logits = logits.gather(1, last_logit_indices.view(batch, 1, 1).expand(batch, 1, logits.shape[-1])).squeeze(1)
+            filtered_logits = top_k(last_logits, thres=filter_thres)
+            sampled = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
+            sample_semantic_ids = torch.cat((sample_semantic_ids, sampled.unsqueeze(-1)), dim=-1)
+            if all_rows_have_eos_id(sample_semantic_ids, self.eos_id):
+                break
+            last_logit_indices += 1
+        return mask_out_after_eos_id(sample_semantic_ids, self.eos_id, keep_eos=False)
 
     def forward(self, *, semantic_token_ids=None, raw_wave=None, text=None, text_embeds=None, return_loss=False, **kwargs):
         assert exists(raw_wave) or exists(semantic_token_ids)
@@ -740,6 +834,47 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         self.semantic_eos_id = transformer.semantic_eos_id
         self.coarse_eos_id = transformer.coarse_eos_id
         self.mask_prob = mask_prob
+
+    @eval_decorator
+    @torch.inference_mode()
+    def generate(self, *, semantic_token_ids, prime_wave=None, prime_wave_input_sample_hz=None, prime_coarse_token_ids=None, text=None,
+                 text_embeds=None, max_time_steps=512, cond_scale=3., filter_thres=0.9, temperature=1., reconstruct_wave=False,
+                 use_kv_cache=True, **kwargs):
+        """audiolm_pytorch.py:1608-1740 (prefix recomputed each step; see SemanticTransformerWrapper.generate)."""
+        batch, device = semantic_token_ids.shape[0], self.device
+        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
+            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        semantic_token_ids = semantic_token_ids.to(device)
+        assert not (exists(prime_wave) and exists(prime_coarse_token_ids)), 'you can either pass in the prime as a raw wave (codec required) or as preprocessed acoustic token ids'
+        if exists(prime_coarse_token_ids):
+            coarse_token_ids = prime_coarse_token_ids
+        elif exists(prime_wave):
+            assert exists(self.codec)
+            self.codec.eval()
+            _, indices, _ = self.codec(prime_wave, return_encoded=True, input_sample_hz=prime_wave_input_sample_hz)
+            coarse_token_ids = _flatten_ids(indices[..., :self.num_coarse_quantizers])
+        else:
+            coarse_token_ids = torch.empty((batch, 0), device=device, dtype=torch.long)
+        if self.unique_consecutive:
+            semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
+        sampled_coarse_token_ids = coarse_token_ids.clone()
+        for time_step in range(0, max_time_steps):
+            for ind in range(self.num_coarse_quantizers):
+                just_finished_quantizer_step = (ind == 0 and time_step > 0)
+                _, coarse_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=sampled_coarse_token_ids,
+                                                                            semantic_token_ids=semantic_token_ids, cond_scale=cond_scale,
+                                                                            return_only_coarse_logits=True, **kwargs)
+                last_coarse_logits = coarse_logits[:, -1].clone()
+                if not just_finished_quantizer_step:
+                    last_coarse_logits[:, -1] = float('-inf')          # prevent from eos in the middle of a time step
+                filtered_logits = top_k(last_coarse_logits, thres=filter_thres)
+                sampled = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
+                sampled_coarse_token_ids = torch.cat((sampled_coarse_token_ids, sampled.unsqueeze(-1)), dim=-1)
+        sampled_coarse_token_ids = mask_out_after_eos_id(sampled_coarse_token_ids, self.coarse_eos_id, keep_eos=False)
+        sampled_coarse_token_ids = sampled_coarse_token_ids.reshape(batch, -1, self.num_coarse_quantizers)      # 'b (n q) -> b n q'
+        if not reconstruct_wave:
+            return sampled_coarse_token_ids
+        return self._reconstruct(sampled_coarse_token_ids)
 
     def forward(self, *, semantic_token_ids=None, raw_wave=None, raw_wave_for_codec=None, text=None, text_embeds=None,
                 coarse_token_ids=None, return_loss=False, **kwargs):
@@ -817,6 +952,51 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
         self.coarse_cross_entropy_loss_weight = coarse_cross_entropy_loss_weight
         self.mask_prob = mask_prob
 
+    @eval_decorator
+    @torch.inference_mode()
+    def generate(self, *, coarse_token_ids, prime_wave=None, prime_wave_input_sample_hz=None, prime_fine_token_ids=None, text=None,
+                 text_embeds=None, cond_scale=3., filter_thres=0.9, temperature=1., reconstruct_wave=False, use_kv_cache=True,
+                 mask_out_generated_fine_tokens=False, **kwargs):
+        """audiolm_pytorch.py:1896-2039 (prefix recomputed each step; see SemanticTransformerWrapper.generate)."""
+        coarse_token_ids = _flatten_ids(coarse_token_ids)
+        batch, device = coarse_token_ids.shape[0], self.device
+        coarse_token_ids = coarse_token_ids.to(device)
+        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
+            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        assert not (exists(prime_wave) and exists(prime_fine_token_ids)), 'you can either pass in the prime as a raw wave (codec required) or as preprocessed acoustic token ids'
+        if exists(prime_fine_token_ids):
+            fine_token_ids = prime_fine_token_ids
+        elif exists(prime_wave):
+            assert exists(self.codec)
+            self.codec.eval()
+            _, token_ids, _ = self.codec(prime_wave, return_encoded=True, input_sample_hz=prime_wave_input_sample_hz)
+            fine_token_ids = _flatten_ids(token_ids[..., self.num_coarse_quantizers:])
+        else:
+            fine_token_ids = torch.empty((batch, 0), device=device, dtype=torch.long)
+        init_fine_time_step = fine_token_ids.shape[-1] // self.num_fine_quantizers
+        max_time_steps = coarse_token_ids.shape[1] // self.num_coarse_quantizers
+        sampled_fine_token_ids = fine_token_ids.clone()
+        for time_step in range(init_fine_time_step, max_time_steps):
+            for ind in range(self.num_fine_quantizers):
+                just_finished_quantizer_step = (ind == 0 and time_step > 0)
+                _, fine_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=coarse_token_ids, fine_token_ids=sampled_fine_token_ids,
+                                                                          cond_scale=cond_scale, return_only_fine_logits=True, **kwargs)
+                last_fine_logits = fine_logits[:, -1].clone()
+                if not just_finished_quantizer_step:
+                    last_fine_logits[:, -1] = float('-inf')            # prevent from eos in the middle of a time step
+                filtered_logits = top_k(last_fine_logits, thres=filter_thres)
+                sampled = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
+                sampled_fine_token_ids = torch.cat((sampled_fine_token_ids, sampled.unsqueeze(-1)), dim=-1)
+        sampled_fine_token_ids = mask_out_after_eos_id(sampled_fine_token_ids, self.eos_id, keep_eos=False)
+        sampled_fine_token_ids = sampled_fine_token_ids.reshape(batch, -1, self.num_fine_quantizers)            # 'b (n q) -> b n q'
+        coarse_token_ids = coarse_token_ids.reshape(batch, -1, self.num_coarse_quantizers)
+        if mask_out_generated_fine_tokens:
+            pos_is_all_padding = (coarse_token_ids == self.pad_id).all(dim=-1, keepdim=True)
+            sampled_fine_token_ids = sampled_fine_token_ids.masked_fill(pos_is_all_padding, self.pad_id)
+        if not reconstruct_wave:
+            return sampled_fine_token_ids
+        return self._reconstruct(torch.cat((coarse_token_ids, sampled_fine_token_ids), dim=-1))
+
     def forward(self, *, raw_wave=None, text=None, text_embeds=None, token_ids=None, coarse_token_ids=None, fine_token_ids=None,
                 return_loss=False, **kwargs):
         assert exists(raw_wave) ^ (exists(token_ids) ^ (exists(coarse_token_ids) and exists(fine_token_ids)))
@@ -862,4 +1042,5 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
 class AudioLM(nn.Module):                                     # audiolm_pytorch.py:2141-2254
     def __init__(self, *args, **kwargs):
         super().__init__()
-        raise NotImplementedError('AudioLM (hierarchical sampling) is inference: SURVEY.md §8(f) item 2, out of scope this round')
+        raise NotImplementedError('AudioLM.forward ends in waveform reconstruction, which needs the SoundStream decoder (SURVEY.md §8(f) item 3); '
+                                  'token-level hierarchical sampling is available: Semantic/Coarse/FineTransformerWrapper.generate()')

@@ -241,8 +241,8 @@ def _grouped_logits(weights, pred, Q):
     n = pred.shape[1]
     nq = round_down_nearest_multiple(n, Q)
     g, r = pred[:, :nq], pred[:, nq:]
-    g = g.reshape(g.shape[0], nq // Q, Q, -1)
-    lg = torch.einsum('qcd,bnqd->bnqc', weights, g).reshape(g.shape[0], nq, -1)
+    g = g.reshape(g.shape[0], nq // Q, Q, pred.shape[-1])                        # explicit width: nq may be 0 (first sampling step)
+    lg = torch.einsum('qcd,bnqd->bnqc', weights, g).reshape(g.shape[0], nq, weights.shape[1])
     if r.shape[1] > 0:
         lr = torch.einsum('qcd,bqd->bqc', weights[:r.shape[1]], r)
         lg = torch.cat((lg, lr), dim=1)

@@ -240,3 +240,20 @@ def test_install_as_reference_registers_the_reference_import_paths():
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+def test_sampling_helpers_semantics():
+    """audiolm_pytorch.py:96-130: top-k keeps max(int((1 - thres) * n), 1) logits, the rest -inf; everything after the first eos is masked
+    (the eos itself too when keep_eos is False); all_rows_have_eos_id."""
+    lg = torch.tensor([[0.1, 2.0, -1.0, 0.5, 1.5, 0.0, -2.0, 0.3, 0.2, 0.05]])
+    out = AP.top_k(lg, thres=0.9)                                     # k = max(int(0.1 * 10), 1) = 1
+    assert int(torch.isfinite(out).sum()) == 1 and float(out[0, 1]) == 2.0
+    out = AP.top_k(lg, thres=0.7)                                     # k = 3
+    assert sorted(torch.isfinite(out)[0].nonzero().flatten().tolist()) == [1, 3, 4]
+    t = torch.tensor([[3, 9, 4, 9, 1], [1, 2, 3, 4, 5], [9, 1, 1, 1, 1]])
+    assert AP.mask_out_after_eos_id(t, 9, keep_eos=False).tolist() == [[3, -1, -1, -1, -1], [1, 2, 3, 4, 5], [-1, -1, -1, -1, -1]]
+    assert AP.mask_out_after_eos_id(t, 9, keep_eos=True).tolist() == [[3, 9, -1, -1, -1], [1, 2, 3, 4, 5], [9, -1, -1, -1, -1]]
+    assert not bool(AP.all_rows_have_eos_id(t, 9)) and bool(AP.all_rows_have_eos_id(t[[0, 2]], 9))
+    torch.manual_seed(0)
+    s = AP.gumbel_sample(torch.tensor([[0.0, 50.0, 0.0]]), temperature=1.)
+    assert int(s) == 1
