@@ -101,11 +101,12 @@ class DataParallelEngine:
                     n *= d
                 views.append(b.flat[o:o + n].view(shape))
                 o += n
+            have = [(p, v) for p, v in zip(b.params, views) if p.grad is not None]
+            if have:                                                   # one fused launch per bucket instead of one copy per parameter
+                torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
             for p, v in zip(b.params, views):
                 if p.grad is None:
                     p.grad = v.clone()
-                else:
-                    p.grad.copy_(v)
         self._inflight = []
 
     def remove(self):
