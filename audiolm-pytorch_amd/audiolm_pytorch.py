@@ -355,7 +355,8 @@ class Transformer(nn.Module):
         mask_u8 = None
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
-        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, self._layer_grad_hook, attn_bias,
+        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled())
+        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
                                            attn_bias.tbl if exists(attn_bias) else None, *self.flat_params())
         if return_flat_hidden:
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
@@ -363,6 +364,25 @@ class Transformer(nn.Module):
         if not return_kv_cache:
             return out
         return out, None
+
+
+    def _sample(self, tokens, self_attn_mask, state):
+        """One step of an autoregressive sampling run (kv cache, reference :360-394 / :560): tokens fp32 [b, n, d] = embeddings of the WHOLE
+        sequence so far, state = core.DecodeCache (state.bias: AttnBias laid out for state.nmax positions, or None).  First call: ordinary
+        forward over the n positions that also fills the cache; later calls: only the last position runs (n == state.length + 1), its
+        attention reads the cache.  -> hidden state of the last position, bf16 [b, d]."""
+        b, n, d = tokens.shape
+        mask_u8 = None if self_attn_mask is None else self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
+        bias = getattr(state, 'bias', None)
+        if state.length == 0:
+            pb = bias.sliced(n) if exists(bias) else None
+            hn = core.TransformerStackFn.apply(tokens, mask_u8, self.cfg, self._cache, dict(grad=False, kv_out=state), pb,
+                                               pb.tbl if exists(pb) else None, *self.flat_params())
+            return hn.view(b, n, d)[:, -1]
+        assert n == state.length + 1 and n <= state.nmax, (n, state.length, state.nmax)
+        x = tokens[:, -1:].contiguous()
+        return core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, dict(grad=False, decode=state), bias,
+                                             bias.tbl if exists(bias) else None, *self.flat_params())
 
 
 # ---------------------------------------------------------------------------------------------- embedding assembly
@@ -444,6 +464,14 @@ class _TransformerBase(nn.Module):
         self.load_state_dict(pkg['model'])
         return pkg
 
+    def _last_logits(self, h, weight3, bias, key, q):
+        """logits of head q for the last-position hidden states h bf16 [b, d] (sampling): every head of the group runs on the b rows (one
+        batched GEMM against the cached bf16 weights of the training path), head q is returned -> fp32 [b, C]"""
+        b, G = h.shape[0], weight3.shape[0]
+        idx = torch.arange(b, device=h.device, dtype=torch.int32)[None].expand(G, b).contiguous()
+        _, lg = heads.head_logits(h, weight3.detach(), None if bias is None else bias.detach(), idx, self._heads_cache(), ('head', key))
+        return lg.view(G, b, -1)[q, :, :weight3.shape[1]]
+
     def _reject_conditioning(self, text, text_embeds):
         if exists(text) or exists(text_embeds) or self.has_condition:
             raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
@@ -510,6 +538,21 @@ class SemanticTransformer(_TransformerBase):
             self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)                       # :716
         return self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True), b, n + 1
 
+    @torch.no_grad()
+    def sample_logits(self, ids, state, nmax):
+        """Sampling step with a kv cache: ids (b, n) = everything sampled so far -> (next-token logits fp32 (b, C + 1), state).  state None:
+        prefix forward that creates the cache for up to `nmax` positions (incl. the start token); afterwards only the last id is new."""
+        b, n = ids.shape
+        dev = ids.device
+        src_a = torch.cat((_const_code(1, b, dev), ids.to(torch.int32)), dim=1).contiguous()
+        tokens = EmbedAssembleFn.apply(src_a.reshape(-1), _neg(b, n + 1, dev).reshape(-1), b * (n + 1), self.dim,
+                                       self.semantic_embedding.weight, self.start_token).view(b, n + 1, self.dim)
+        if state is None:
+            state = core.DecodeCache(self.transformer.cfg, b, nmax, dev)
+            state.bias = self.transformer.rel_pos_bias(nmax, nmax) if exists(self.transformer.rel_pos_bias) else None
+        h = self.transformer._sample(tokens, None, state)
+        return self._last_logits(h, self.to_logits.weight.unsqueeze(0), self.to_logits.bias, 'semantic', 0), state
+
     def forward(self, *, ids=None, return_loss=False, text=None, text_embeds=None, self_attn_mask=None, cond_drop_prob=None,
                 unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
         self._reject_conditioning(text, text_embeds)
@@ -563,7 +606,7 @@ class CoarseTransformer(_TransformerBase):
         self.coarse_logit_weights = nn.Parameter(torch.randn(num_coarse_quantizers, codebook_size_with_eos, dim))
         self.dim = dim
 
-    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask):
+    def _assemble(self, semantic_token_ids, coarse_token_ids):
         b, dev = semantic_token_ids.shape[0], semantic_token_ids.device
         Q, C = self.num_coarse_quantizers, self.codebook_size
         coarse, sem = _flatten_ids(coarse_token_ids), _flatten_ids(semantic_token_ids)           # :894
@@ -578,6 +621,23 @@ class CoarseTransformer(_TransformerBase):
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.semantic_embedding.weight,
                                        self.coarse_embedding.weight, self.coarse_quantize_embedding.weight,
                                        self.semantic_start_token, self.coarse_start_token).view(b, N, self.dim)   # :913-918
+        return tokens, b, N, ns, nc
+
+    @torch.no_grad()
+    def sample_logits(self, semantic_token_ids, coarse_token_ids, state, nmax):
+        """Sampling step with a kv cache -> (logits of the NEXT coarse token fp32 (b, C + 1), state); see SemanticTransformer.sample_logits.
+        nmax = semantic length + 2 + the largest number of coarse tokens the run will hold."""
+        tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
+        if state is None:
+            state = core.DecodeCache(self.transformer.cfg, b, nmax, tokens.device)
+            state.bias = None
+            if exists(self.transformer.rel_pos_bias):
+                state.bias = self.transformer.rel_pos_bias(nmax, nmax, special=self.cross_attn_bias, num_leading=ns + 1)
+        h = self.transformer._sample(tokens, None, state)
+        return self._last_logits(h, self.coarse_logit_weights, None, 'coarse', nc % self.num_coarse_quantizers), state
+
+    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask):
+        tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
         attn_bias = None
         if exists(self.transformer.rel_pos_bias):
             # :924-936 -- relative positions everywhere except across the semantic / coarse boundary, where every pair gets the learned
@@ -665,11 +725,7 @@ class FineTransformer(_TransformerBase):
         self.fine_logit_weights = nn.Parameter(torch.randn(num_fine_quantizers, codebook_size, dim))
         self.dim = dim
 
-    def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
-                kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
-        self._reject_conditioning(text, text_embeds)
-        if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+    def _assemble(self, coarse_token_ids, fine_token_ids, self_attn_mask):
         b, dev = coarse_token_ids.shape[0], coarse_token_ids.device
         Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
         coarse, fine = _flatten_ids(coarse_token_ids), _flatten_ids(fine_token_ids)               # :1171
@@ -690,14 +746,39 @@ class FineTransformer(_TransformerBase):
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.coarse_embedding.weight,
                                        self.fine_embedding.weight, self.coarse_quantize_embedding.weight,
                                        self.fine_quantize_embedding.weight, self.coarse_start_token, self.fine_start_token).view(b, N, self.dim)
-        attn_bias = None
-        if exists(self.pos_bias_mlp):
-            # :1229-1298 -- the MLP over the (relative frame, relative quantizer) grid stays a table; start-token pairs read null_pos_bias
-            grid, index = relpos.fine_index(n, nf, Qc, Qf, dev)
-            mlp = self.pos_bias_mlp
-            tbl = relpos.PosTableFn.apply(grid, self.null_pos_bias, 64 ** 0.5, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
-                                          mlp[4].weight, mlp[4].bias)
-            attn_bias = relpos.AttnBias(tbl, *index)
+        return tokens, self_attn_mask, b, n, nf, N
+
+    def _attn_bias(self, n, nf, dev):
+        if not exists(self.pos_bias_mlp):
+            return None
+        # :1229-1298 -- the MLP over the (relative frame, relative quantizer) grid stays a table; start-token pairs read null_pos_bias
+        grid, index = relpos.fine_index(n, nf, self.num_coarse_quantizers, self.num_fine_quantizers, dev)
+        mlp = self.pos_bias_mlp
+        tbl = relpos.PosTableFn.apply(grid, self.null_pos_bias, 64 ** 0.5, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+                                      mlp[4].weight, mlp[4].bias)
+        return relpos.AttnBias(tbl, *index)
+
+    @torch.no_grad()
+    def sample_logits(self, coarse_token_ids, fine_token_ids, state, max_fine_length):
+        """Sampling step with a kv cache -> (logits of the NEXT fine token fp32 (b, C), state); see SemanticTransformer.sample_logits.  The
+        bias table / index vectors are laid out once for `max_fine_length` fine tokens (the reference's table does not change while the
+        number of fine frames stays <= the number of coarse frames, :1230)."""
+        tokens, mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, None)
+        if state is None:
+            state = core.DecodeCache(self.transformer.cfg, b, n + max_fine_length + 2, tokens.device)
+            state.bias = self._attn_bias(n, max_fine_length, tokens.device)
+        h = self.transformer._sample(tokens, mask, state)
+        return self._last_logits(h, self.fine_logit_weights, None, 'fine', nf % self.num_fine_quantizers), state
+
+    def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
+                kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
+        self._reject_conditioning(text, text_embeds)
+        if exists(kv_cache) or exists(embed_cache):
+            raise NotImplementedError('pass no kv_cache / embed_cache: the sampling cache of this package is driven through sample_logits()')
+        tokens, self_attn_mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, self_attn_mask)
+        dev = tokens.device
+        Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
+        attn_bias = self._attn_bias(n, nf, dev)
         hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, return_flat_hidden=True)
 
         n_fine = nf + 1                                                                           # tokens[:, n+1:]  (:1319)
@@ -761,9 +842,9 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
     @torch.inference_mode()
     def generate(self, *, max_length, text=None, text_embeds=None, prime_wave=None, prime_wave_input_sample_hz=None, prime_ids=None,
                  batch_size=1, cond_scale=3, filter_thres=0.9, temperature=1., use_kv_cache=True, include_eos_in_output=True, **kwargs):
-        """audiolm_pytorch.py:1406-1511.  Same sampling semantics (top-k filter, gumbel-max, eos stop, mask after eos); the transformer call
-        recomputes the prefix each step on the HIP forward path (no kv cache yet): `use_kv_cache` only changes
-        speed in the reference, never the result."""
+        """audiolm_pytorch.py:1406-1511.  Same sampling semantics (top-k filter, gumbel-max, eos stop, mask after eos).  use_kv_cache=True:
+        the prefix runs once through the training forward path, every further token costs one single-position pass whose attention reads
+        the per-layer key / value cache (alm_mqa_decode_attn); False: the whole prefix is recomputed each step (same logits, O(n) more work)."""
         device = self.device
         if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
             raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
@@ -781,9 +862,16 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
         start_length = ids.shape[-1]
         sample_semantic_ids = ids.clone()
         last_logit_indices = (ids != self.pad_id).sum(dim=-1).long()
+        # kv cache (native: core.DecodeCache through SemanticTransformer.sample_logits): usable when no prime row is padded, i.e. every row's
+        # next-token logits sit at the last position; ragged primes take the recompute path, which reproduces the reference's gather
+        use_cache = use_kv_cache and not kwargs and bool((ids != self.pad_id).all())
+        state = None
         for ind in range(start_length, max_length):
-            logits = self.transformer.forward_with_cond_scale(ids=sample_semantic_ids, cond_scale=cond_scale, **kwargs)
-            last_logits = logits.gather(1, last_logit_indices.view(batch, 1, 1).expand(batch, 1, logits.shape[-1])).squeeze(1)
+            if use_cache:
+                last_logits, state = self.transformer.sample_logits(sample_semantic_ids, state, max_length + 1)
+            else:
+                logits = self.transformer.forward_with_cond_scale(ids=sample_semantic_ids, cond_scale=cond_scale, **kwargs)
+                last_logits = logits.gather(1, last_logit_indices.view(batch, 1, 1).expand(batch, 1, logits.shape[-1])).squeeze(1)
             filtered_logits = top_k(last_logits, thres=filter_thres)
             sampled = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
             sample_semantic_ids = torch.cat((sample_semantic_ids, sampled.unsqueeze(-1)), dim=-1)
@@ -858,13 +946,19 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         if self.unique_consecutive:
             semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
         sampled_coarse_token_ids = coarse_token_ids.clone()
+        use_cache, state = use_kv_cache and not kwargs, None
+        nmax = semantic_token_ids.shape[1] + 2 + coarse_token_ids.shape[1] + max_time_steps * self.num_coarse_quantizers
         for time_step in range(0, max_time_steps):
             for ind in range(self.num_coarse_quantizers):
                 just_finished_quantizer_step = (ind == 0 and time_step > 0)
-                _, coarse_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=sampled_coarse_token_ids,
-                                                                            semantic_token_ids=semantic_token_ids, cond_scale=cond_scale,
-                                                                            return_only_coarse_logits=True, **kwargs)
-                last_coarse_logits = coarse_logits[:, -1].clone()
+                if use_cache:
+                    last_coarse_logits, state = self.transformer.sample_logits(semantic_token_ids, sampled_coarse_token_ids, state, nmax)
+                    last_coarse_logits = last_coarse_logits.clone()
+                else:
+                    _, coarse_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=sampled_coarse_token_ids,
+                                                                                semantic_token_ids=semantic_token_ids, cond_scale=cond_scale,
+                                                                                return_only_coarse_logits=True, **kwargs)
+                    last_coarse_logits = coarse_logits[:, -1].clone()
                 if not just_finished_quantizer_step:
                     last_coarse_logits[:, -1] = float('-inf')          # prevent from eos in the middle of a time step
                 filtered_logits = top_k(last_coarse_logits, thres=filter_thres)
@@ -976,12 +1070,19 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
         init_fine_time_step = fine_token_ids.shape[-1] // self.num_fine_quantizers
         max_time_steps = coarse_token_ids.shape[1] // self.num_coarse_quantizers
         sampled_fine_token_ids = fine_token_ids.clone()
+        use_cache, state = use_kv_cache and not kwargs, None
+        max_fine_length = fine_token_ids.shape[-1] + max(0, max_time_steps - init_fine_time_step) * self.num_fine_quantizers
         for time_step in range(init_fine_time_step, max_time_steps):
             for ind in range(self.num_fine_quantizers):
                 just_finished_quantizer_step = (ind == 0 and time_step > 0)
-                _, fine_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=coarse_token_ids, fine_token_ids=sampled_fine_token_ids,
-                                                                          cond_scale=cond_scale, return_only_fine_logits=True, **kwargs)
-                last_fine_logits = fine_logits[:, -1].clone()
+                if use_cache:
+                    last_fine_logits, state = self.transformer.sample_logits(coarse_token_ids, sampled_fine_token_ids, state, max_fine_length)
+                    last_fine_logits = last_fine_logits.clone()
+                else:
+                    _, fine_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=coarse_token_ids,
+                                                                              fine_token_ids=sampled_fine_token_ids, cond_scale=cond_scale,
+                                                                              return_only_fine_logits=True, **kwargs)
+                    last_fine_logits = fine_logits[:, -1].clone()
                 if not just_finished_quantizer_step:
                     last_fine_logits[:, -1] = float('-inf')            # prevent from eos in the middle of a time step
                 filtered_logits = top_k(last_fine_logits, thres=filter_thres)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libaudiolm_hip.so')
 STAMP = os.path.join(HERE, '.libaudiolm_hip.stamp')
-SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.hip', 'codec.hip', 'relpos.hip', 'optim.hip']
+SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.hip', 'codec.hip', 'relpos.hip', 'optim.hip', 'decode.hip']
 
 
 def _digest() -> str:

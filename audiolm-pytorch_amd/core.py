@@ -59,6 +59,15 @@ def _split_layer(flat, S):
     return a, f
 
 
+def tensor_version(t):
+    """in-place-update counter used as the cache key of packed weights; inference tensors (created under torch.inference_mode) have none
+    and cannot be updated in place: constant 0"""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0
+
+
 class WeightCache:
     """bf16 packed copies (W and W^T, zero padded) of the fp32 master weights; refreshed when a master's version changes
     (i.e. once per optimiser step) -- this is what `accelerator.autocast()` (trainer.py:1241) does per call, amortised."""
@@ -67,7 +76,7 @@ class WeightCache:
         self.store = {}
 
     def get(self, key, w, builder):
-        ver = (w.data_ptr(), w._version, tuple(w.shape))
+        ver = (w.data_ptr(), tensor_version(w), tuple(w.shape))
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -106,7 +115,7 @@ def _pack_w2(w, I, Ip):
 def layer_weights(cache: WeightCache, l, pa, pf, I, Ip):
     """bf16 packed (W, W^T) pairs of one layer's five dense weights; when any master changed, ALL are re-packed in one launch."""
     ws = (('wq', pa['wq']), ('wkv', pa['wkv']), ('wo', pa['wo']), ('w1', pf['w1']), ('w2', pf['w2']))
-    vers = {k: (w.data_ptr(), w._version, tuple(w.shape)) for k, w in ws}
+    vers = {k: (w.data_ptr(), tensor_version(w), tuple(w.shape)) for k, w in ws}
     hits = {k: cache.store.get((l, k)) for k, _ in ws}
     if all(h is not None and h[0] == vers[k] for k, h in hits.items()):
         return tuple(hits[k][1] for k, _ in ws)
@@ -142,9 +151,21 @@ def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
-def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None):
+class DecodeCache:
+    """Per-layer key / value cache of an autoregressive sampling run (reference kv_cache, audiolm_pytorch.py:360-394 / :560): bf16
+    [B, nmax, 2 * dim_head] per layer holding k | v, v already value-residual mixed (so a sampling step never re-mixes old positions).
+    `length` = number of cached positions."""
+
+    def __init__(self, cfg, B, nmax, device):
+        self.kv = [torch.zeros((B, nmax, 2 * cfg.dim_head), dtype=BF16, device=device) for _ in range(cfg.depth)]
+        self.B, self.nmax, self.length = B, nmax, 0
+
+
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None):
     """x fp32 [B, N, D] -> (hn bf16 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
-    audiolm_pytorch.py:500-506 / :532) or None."""
+    audiolm_pytorch.py:500-506 / :532) or None.  Sampling: `kv_out` (DecodeCache) is filled with every layer's k / v of this (prefix)
+    forward; `decode` (DecodeCache) means x holds ONE new position per sequence (N == 1) at index decode.length: its attention runs over
+    the cache (alm_mqa_decode_attn, which also appends the new k / v), everything else is the same launch sequence on B rows."""
     B, N, D = x.shape
     M, S, H, dh = B * N, cfg.streams, cfg.heads, cfg.dim_head
     I, Ip = cfg.inner, cfg.inner_pad
@@ -180,7 +201,14 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
             V = Vown
         if kv0 is None:
             kv0 = KV                                      # :534-535 (layer-0 values, pre-mix)
-        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
+        if decode is not None:
+            kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
+            AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias), None
+        else:
+            AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
+            if kv_out is not None:
+                kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
+                kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
         Y = _empty((M, D), BF16, dev)
         ops.gemm_nt(AO, Wo, Y)
 
@@ -217,6 +245,10 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])              # :555
     if need_grad:
         saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
+    if decode is not None:
+        decode.length += 1
+    if kv_out is not None:
+        kv_out.length = N
     return hn, saved
 
 
@@ -407,12 +439,16 @@ class TransformerStackFn(torch.autograd.Function):
     """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states bf16 [B*N, D]."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, cfg, cache, hooks, bias, tbl, *flat):
-        # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes its gradient
-        need = any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad)
+    def forward(ctx, x, mask_u8, cfg, cache, opts, bias, tbl, *flat):
+        # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes its gradient.
+        # opts: dict(hook = per-layer gradient callback | None, grad = torch.is_grad_enabled() AT THE CALL SITE (it is always off in here),
+        #            kv_out / decode = DecodeCache | None: sampling)
+        hooks = opts.get('hook')
+        need = bool(opts.get('grad', True)) and (any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad))
         xin = x.detach().contiguous().to(F32)
         bias = bias.detached() if bias is not None else None
-        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need, bias)
+        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need, bias, kv_out=opts.get('kv_out'),
+                                  decode=opts.get('decode'))
         ctx.saved, ctx.cfg, ctx.cache, ctx.mask, ctx.hooks, ctx.bias = saved, cfg, cache, mask_u8, hooks, bias
         ctx.flat = flat
         return hn

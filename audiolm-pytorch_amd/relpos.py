@@ -26,7 +26,26 @@ class AttnBias:
         self.tbl, self.qkey4, self.kkey4, self.qattr, self.kattr = tbl, qkey4, kkey4, qattr, kattr
 
     def detached(self):
-        return AttnBias(self.tbl.detach(), self.qkey4, self.kkey4, self.qattr, self.kattr)
+        out = AttnBias(self.tbl.detach(), self.qkey4, self.kkey4, self.qattr, self.kattr)
+        out._host = getattr(self, '_host', None)
+        return out
+
+    def sliced(self, n):
+        """the same bias restricted to the first n positions (prefix forward of a sampling run: slots do not depend on the length)"""
+        return AttnBias(self.tbl, self.qkey4[:n], self.kkey4[:n], self.qattr[:n], self.kattr[:n])
+
+    def _host_index(self):
+        if getattr(self, '_host', None) is None:                       # one device -> host copy per sampling run, not per step
+            self._host = (self.qkey4.cpu().tolist(), self.qattr.cpu().tolist())
+        return self._host
+
+    @property
+    def qkey4_host(self):
+        return self._host_index()[0]
+
+    @property
+    def qattr_host(self):
+        return self._host_index()[1]
 
 
 class PosTableFn(torch.autograd.Function):

@@ -20,7 +20,7 @@ from itertools import cycle
 import torch
 from torch import nn
 
-from . import ops
+from . import core, ops
 
 F32 = torch.float32
 
@@ -40,7 +40,7 @@ class CausalConv1d(nn.Module):                                   # soundstream.p
 
     def packed(self):
         w = self.conv.weight
-        ver = (w.data_ptr(), w._version)
+        ver = (w.data_ptr(), core.tensor_version(w))
         if self._packed is None or self._packed[0] != ver:
             self._packed = (ver, ops.conv1d_pack(w.detach().to(F32)))
         return self._packed[1]
@@ -114,7 +114,7 @@ class GroupedResidualVQ(nn.Module):
 
     def _pack(self):
         embeds = [[l._codebook.embed for l in r.layers] for r in self.rvqs]
-        ver = tuple((e.data_ptr(), e._version) for row in embeds for e in row)
+        ver = tuple((e.data_ptr(), core.tensor_version(e)) for row in embeds for e in row)
         if self._packed is None or self._packed[0] != ver:
             for r in self.rvqs:
                 for l in r.layers:

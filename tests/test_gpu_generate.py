@@ -44,8 +44,9 @@ def _check_choice(oracle_last_logits, chosen, allow_eos, filter_thres=0.9):
     assert bool((got >= best - TOL).all()), (got, best)
 
 
+@pytest.mark.parametrize('use_kv_cache', [True, False])
 @pytest.mark.parametrize('flash', [True, False])
-def test_semantic_generate_greedy_matches_oracle(greedy, flash):
+def test_semantic_generate_greedy_matches_oracle(greedy, flash, use_kv_cache):
     import audiolm_pytorch_amd as A
     torch.manual_seed(0)
     dev = torch.device('cuda:0')
@@ -55,7 +56,7 @@ def test_semantic_generate_greedy_matches_oracle(greedy, flash):
     w = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=False)
     g = torch.Generator().manual_seed(1)
     prime = torch.randint(0, 20, (3, 4), generator=g)
-    out = w.generate(max_length=12, prime_ids=prime.to(dev))
+    out = w.generate(max_length=12, prime_ids=prime.to(dev), use_kv_cache=use_kv_cache)
     assert out.dtype == torch.long and out.shape[0] == 3 and 5 <= out.shape[1] <= 12
     out = out.cpu()
     assert torch.equal(out[:, :4], prime)
@@ -74,8 +75,9 @@ def test_semantic_generate_greedy_matches_oracle(greedy, flash):
     assert not bool((out == 20).any())                                            # eos itself is masked out of the output
 
 
+@pytest.mark.parametrize('use_kv_cache', [True, False])
 @pytest.mark.parametrize('flash', [True, False])
-def test_coarse_generate_greedy_matches_oracle(greedy, flash):
+def test_coarse_generate_greedy_matches_oracle(greedy, flash, use_kv_cache):
     import audiolm_pytorch_amd as A
     torch.manual_seed(2)
     dev = torch.device('cuda:0')
@@ -85,7 +87,7 @@ def test_coarse_generate_greedy_matches_oracle(greedy, flash):
     w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False)
     g = torch.Generator().manual_seed(3)
     sem = torch.randint(0, 20, (2, 6), generator=g)
-    out = w.generate(semantic_token_ids=sem.to(dev), max_time_steps=3).cpu()
+    out = w.generate(semantic_token_ids=sem.to(dev), max_time_steps=3, use_kv_cache=use_kv_cache).cpu()
     assert out.shape == (2, 3, 3)
     flat = out.reshape(2, -1)
     cfg = O.Cfg(dim=64, depth=2, heads=2, streams=4, num_semantic_tokens=20, codebook_size=16, num_coarse_quantizers=3)
@@ -106,8 +108,9 @@ def test_coarse_generate_greedy_matches_oracle(greedy, flash):
             assert int(neg[0]) % 3 == 0
 
 
+@pytest.mark.parametrize('use_kv_cache', [True, False])
 @pytest.mark.parametrize('flash', [True, False])
-def test_fine_generate_greedy_matches_oracle(greedy, flash):
+def test_fine_generate_greedy_matches_oracle(greedy, flash, use_kv_cache):
     import audiolm_pytorch_amd as A
     torch.manual_seed(4)
     dev = torch.device('cuda:0')
@@ -117,7 +120,7 @@ def test_fine_generate_greedy_matches_oracle(greedy, flash):
     w = A.FineTransformerWrapper(transformer=model, codec=Codec())
     g = torch.Generator().manual_seed(5)
     coarse = torch.randint(0, 16, (2, 2, 3), generator=g)
-    out = w.generate(coarse_token_ids=coarse.to(dev)).cpu()
+    out = w.generate(coarse_token_ids=coarse.to(dev), use_kv_cache=use_kv_cache).cpu()
     assert out.shape == (2, 2, 5)
     flat = out.reshape(2, -1)
     cfg = O.Cfg(dim=64, depth=2, heads=2, streams=4, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5)
@@ -145,3 +148,85 @@ def test_generate_refuses_what_is_not_native():
         w.generate(semantic_token_ids=sem, max_time_steps=1, text=['a'])                        # conditioning
     with pytest.raises(NotImplementedError):
         A.AudioLM()
+
+
+@pytest.mark.parametrize('B,H,pos,nmax,use_mask,use_bias', [(2, 8, 0, 16, False, False), (3, 8, 70, 128, True, False), (2, 4, 129, 130, False, True),
+                                                            (1, 2, 300, 512, True, True), (4, 8, 63, 64, False, True)])
+def test_decode_attention_kernel(B, H, pos, nmax, use_mask, use_bias):
+    """alm_mqa_decode_attn vs an fp32 restatement: one query per sequence over a cache of pos + 1 keys (the new row included and appended
+    by the kernel), key mask, structured bias.  bf16 operands, fp32 statistics: 8e-3 rel-max (one bf16 rounding of the output)."""
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd import ops, relpos
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(pos + nmax)
+    d = 64
+    q = torch.randn(B, H * d, generator=g).to(dev).bfloat16()
+    cache = torch.randn(B, nmax, 2 * d, generator=g).to(dev).bfloat16()
+    kv_new = torch.randn(B, 2 * d, generator=g).to(dev).bfloat16()
+    mask = None
+    if use_mask:
+        mask = (torch.rand(B, pos + 1, generator=g) > 0.3)
+        mask[:, 0] = True
+        mask = mask.to(dev)
+    bias = None
+    if use_bias:
+        index = relpos.toeplitz_index(nmax, dev, num_leading=max(1, nmax // 3))
+        bias = relpos.AttnBias((torch.randn(H, 2 * nmax, generator=g) * 6).to(dev), *index)
+    before = cache.clone()
+    out = ops.mqa_decode_attn(q, cache, kv_new, pos, None if mask is None else mask.contiguous().view(torch.uint8), H, d, bias=bias)
+    # the kernel appended the new row and touched nothing else
+    assert torch.equal(cache[:, pos], kv_new)
+    keep = torch.ones(nmax, dtype=torch.bool, device=dev)
+    keep[pos] = False
+    assert torch.equal(cache[:, keep], before[:, keep])
+    k = cache[:, :pos + 1, :d].float()
+    v = cache[:, :pos + 1, d:].float()
+    qf = q.float().view(B, H, d)
+    sim = torch.einsum('bhd,bjd->bhj', qf, k)
+    if bias is not None:
+        slot = (bias.qkey4[pos].long() - bias.kkey4[:pos + 1].long()) // 4
+        special = (bias.qattr[pos] & bias.kattr[:pos + 1]) != 0
+        slot = torch.where(special, torch.zeros_like(slot), slot)
+        sim = sim + bias.tbl[:, slot][None]
+    sim = sim * d ** -0.5
+    if mask is not None:
+        sim = sim.masked_fill(~mask[:, None, :], float('-inf'))
+    ref = torch.einsum('bhj,bjd->bhd', sim.softmax(dim=-1), v).reshape(B, H * d)
+    err = float((out.float() - ref).abs().max() / ref.abs().max())
+    assert err <= 8e-3, err
+
+
+def test_cached_step_logits_equal_recomputed_logits():
+    """the same prefix through the two paths: (prefill + single-position steps with the cache) vs (full forward): next-token logits agree to
+    bf16 noise at every step -- for all three transformers with their bias tables (default constructors)."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    g = torch.Generator().manual_seed(8)
+
+    def close(a, b):
+        return float((a.float() - b.float()).abs().max()) <= 2e-2 * max(1.0, float(b.float().abs().max()))
+    m = A.SemanticTransformer(dim=64, depth=3, heads=2, num_semantic_tokens=20).to(dev).eval()
+    c = A.CoarseTransformer(dim=64, depth=3, heads=2, num_semantic_tokens=20, codebook_size=16, num_coarse_quantizers=3).to(dev).eval()
+    f = A.FineTransformer(dim=64, depth=3, heads=2, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5).to(dev).eval()
+    with torch.inference_mode():
+        ids = torch.randint(0, 20, (2, 9), generator=g).to(dev)
+        state = None
+        for n in range(3, 10):
+            lg, state = m.sample_logits(ids[:, :n], state, 12)
+            assert close(lg, m(ids=ids[:, :n])[:, -1]), ('semantic', n)
+        sem = torch.randint(0, 20, (2, 5), generator=g).to(dev)
+        co = torch.randint(0, 16, (2, 7), generator=g).to(dev)
+        state = None
+        for n in range(0, 8):
+            lg, state = c.sample_logits(sem, co[:, :n], state, 5 + 2 + 9)
+            _, full = c(semantic_token_ids=sem, coarse_token_ids=co[:, :n], return_only_coarse_logits=True)
+            assert close(lg, full[:, -1]), ('coarse', n)
+        coarse = torch.randint(0, 16, (2, 6), generator=g).to(dev)
+        coarse[0, 4] = -1                                                       # a padded coarse position: key-masked (:1175)
+        fi = torch.randint(0, 16, (2, 9), generator=g).to(dev)
+        state = None
+        for n in range(0, 10):
+            lg, state = f.sample_logits(coarse, fi[:, :n], state, 10)
+            _, full = f(coarse, fi[:, :n], return_only_fine_logits=True)
+            assert close(lg, full[:, -1]), ('fine', n)
