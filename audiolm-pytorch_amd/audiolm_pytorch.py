@@ -11,10 +11,11 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
   RelativePositionBias / pos_bias_mlp       -> relpos.PosTableFn         (`flash_attn=False` models: the bias stays a per-head table that
                                                                           the attention kernels index in place; no (h, n, n) tensor)
 
-  *TransformerWrapper.generate()            -> the same forward path, prefix recomputed every step (no kv cache yet); sampling helpers in torch
+  *TransformerWrapper.generate()            -> sample_logits(): prefix once through the training forward path, then one single-position pass per
+                                               token over a per-layer k/v cache (core.DecodeCache, alm_mqa_decode_attn); sampling helpers in torch
 
-Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning, kv / embed caches
-(generate() works but is O(n^2) forwards), waveform reconstruction (SoundStream decoder), dense `attn_bias` tensors.
+Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning (so no classifier-free
+guidance), the reference's kv_cache= / embed_cache= tensor arguments, waveform reconstruction (SoundStream decoder), dense `attn_bias` tensors.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
 from __future__ import annotations

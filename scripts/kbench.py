@@ -397,6 +397,24 @@ def bench_host():
     st.print_stats(14)
 
 
+def bench_gen():
+    """autoregressive sampling throughput: SemanticTransformerWrapper.generate (d=1024, depth=6, B=8) with and without the kv cache"""
+    torch.manual_seed(0)
+    for flash in (True, False):
+        m = A.SemanticTransformer(dim=1024, depth=6, num_semantic_tokens=500, flash_attn=flash).to(dev)
+        w = A.SemanticTransformerWrapper(transformer=m, unique_consecutive=False)
+        for use_cache, L in ((True, 512), (False, 128)):
+            w.generate(max_length=8, batch_size=8, use_kv_cache=use_cache)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = w.generate(max_length=L, batch_size=8, use_kv_cache=use_cache)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f'generate semantic d=1024 depth=6 B=8 flash_attn={flash} kv_cache={use_cache}: {out.shape[1]} steps in {dt:.2f} s -> '
+                  f'{dt / out.shape[1] * 1e3:.2f} ms/step, {8 * out.shape[1] / dt:.0f} tokens/s')
+        del m, w
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)
