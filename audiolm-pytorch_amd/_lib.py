@@ -77,7 +77,9 @@ SIGNATURES = {
     'alm_opt_adam_step': [_P, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
     'alm_conv1d_packed_floats': [_I, _I, _I],
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
-    'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'alm_phase_interleave': [_P, _P, _I, _I, _I, _I, _P],
+    'alm_rvq_decode': [_P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     'alm_rvq_padded_codes': [_I],
     'alm_rvq_padded_dim': [_I],
     'alm_rvq_pack': [_P, _P, _P, _I, _I, _I, _P],

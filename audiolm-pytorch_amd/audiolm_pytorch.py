@@ -817,8 +817,20 @@ class _WrapperBase(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def _reconstruct(self, ids):
-        raise NotImplementedError('waveform reconstruction needs the SoundStream decoder (SURVEY.md §8(f) item 3): call with reconstruct_wave=False')
+    def _reconstruct(self, ids, per_position_any_pad=True):
+        """codec.decode_from_codebook_indices on (b, n, q) ids; rows with padded (-1) positions are decoded one by one without them, like
+        the reference (audiolm_pytorch.py:1712-1740 / :2011-2039) -> (b, samples) tensor, or a list of 1-D waves (None: nothing to decode)."""
+        assert exists(self.codec)
+        pad = (ids == -1).any(dim=-1)                                        # (b, n)
+        if not bool(pad.any()):
+            return self.codec.decode_from_codebook_indices(ids).squeeze(1)   # 'b 1 n -> b n'
+        wavs = []
+        for sample, has_padding in zip(ids, pad):
+            if bool(has_padding.all()):
+                wavs.append(None)
+                continue
+            wavs.append(self.codec.decode_from_codebook_indices(sample[~has_padding].unsqueeze(0)).reshape(-1))
+        return wavs
 
     def embed_text(self, text):
         raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
@@ -1142,7 +1154,52 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
 
 
 class AudioLM(nn.Module):                                     # audiolm_pytorch.py:2141-2254
-    def __init__(self, *args, **kwargs):
+    """Hierarchical sampling: semantic -> coarse -> fine -> waveform, every stage on the native path (kv-cache sampling, SoundStream decoder).
+    Text / audio conditioning is out of scope, so the three transformers must be un-conditioned."""
+
+    def __init__(self, *, wav2vec, codec, semantic_transformer: SemanticTransformer, coarse_transformer: CoarseTransformer,
+                 fine_transformer: FineTransformer, audio_conditioner=None, unique_consecutive=True):
         super().__init__()
-        raise NotImplementedError('AudioLM.forward ends in waveform reconstruction, which needs the SoundStream decoder (SURVEY.md §8(f) item 3); '
-                                  'token-level hierarchical sampling is available: Semantic/Coarse/FineTransformerWrapper.generate()')
+        if exists(audio_conditioner):
+            raise NotImplementedError('audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        self.audio_conditioner = None
+        assert semantic_transformer.num_semantic_tokens == coarse_transformer.num_semantic_tokens
+        assert coarse_transformer.codebook_size == fine_transformer.codebook_size
+        assert coarse_transformer.num_coarse_quantizers == fine_transformer.num_coarse_quantizers
+        assert (fine_transformer.num_coarse_quantizers + fine_transformer.num_fine_quantizers) == codec.num_quantizers
+        self.semantic_has_condition = semantic_transformer.has_condition
+        self.coarse_has_condition = coarse_transformer.has_condition
+        self.fine_has_condition = fine_transformer.has_condition
+        self.needs_text = any([self.semantic_has_condition, self.coarse_has_condition, self.fine_has_condition])
+        if self.needs_text:
+            raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+        self.semantic = SemanticTransformerWrapper(wav2vec=wav2vec, transformer=semantic_transformer, unique_consecutive=unique_consecutive)
+        self.coarse = CoarseTransformerWrapper(wav2vec=wav2vec, codec=codec, transformer=coarse_transformer, unique_consecutive=unique_consecutive)
+        self.fine = FineTransformerWrapper(codec=codec, transformer=fine_transformer)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @eval_decorator
+    @torch.inference_mode()
+    def forward(self, *, batch_size=1, text=None, text_embeds=None, prime_wave=None, prime_wave_input_sample_hz=None, prime_wave_path=None,
+                max_length=2048, return_coarse_generated_wave=False, mask_out_generated_fine_tokens=False):
+        if exists(text) or exists(text_embeds):
+            raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+        assert not (exists(prime_wave) and exists(prime_wave_path)), 'prompt audio must be given as either `prime_wave: Tensor` or `prime_wave_path: str`'
+        if exists(prime_wave):
+            assert exists(prime_wave_input_sample_hz), 'the input sample frequency for the prompt audio must be given as `prime_wave_input_sample_hz: int`'
+            prime_wave = prime_wave.to(self.device)
+        elif exists(prime_wave_path):
+            raise NotImplementedError('loading audio files needs torchaudio (not part of this package): pass `prime_wave` as a tensor')
+        semantic_token_ids = self.semantic.generate(batch_size=batch_size, prime_wave=prime_wave,
+                                                    prime_wave_input_sample_hz=prime_wave_input_sample_hz, max_length=max_length)
+        coarse_token_ids_or_recon_wave = self.coarse.generate(semantic_token_ids=semantic_token_ids, prime_wave=prime_wave,
+                                                              prime_wave_input_sample_hz=prime_wave_input_sample_hz,
+                                                              reconstruct_wave=return_coarse_generated_wave)
+        if return_coarse_generated_wave:
+            return coarse_token_ids_or_recon_wave
+        return self.fine.generate(coarse_token_ids=coarse_token_ids_or_recon_wave, prime_wave=prime_wave,
+                                  prime_wave_input_sample_hz=prime_wave_input_sample_hz, reconstruct_wave=True,
+                                  mask_out_generated_fine_tokens=mask_out_generated_fine_tokens)

@@ -45,6 +45,7 @@ __device__ __forceinline__ float elu1(float v) {
 struct ConvArgs {
     const float* x; const float* wp; const float* bias; const float* residual; float* out;
     int B, Cin, CinP, Cout, CoutP, Tin, Tout, ks, stride, dil, pad, elu;
+    int zero_pad;       // 0: reflect left pad (CausalConv1d, soundstream.py:343); 1: zeros left of the signal (the k = 2 form of a transposed conv)
 };
 
 // grid: (ceil(Tout / 256), CoutP / (32 * NA), B); 4 waves along time, 64 output steps each
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int p = tin[j] + tap * a.dil;
-            p = p < 0 ? -p : p;                                    // reflect (F.pad mode='reflect'): index -i -> i
-            xvo[j] = (lh * a.Tin + p) * 4;
+            const bool left = p < 0;
+            p = left ? -p : p;                                     // reflect (F.pad mode='reflect'): index -i -> i
+            xvo[j] = (left && a.zero_pad) ? (int)0x80000000 : (lh * a.Tin + p) * 4;      // zero pad: out-of-range offset reads 0
         }
     };
     set_tap(0);
@@ -343,6 +345,35 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     }
 }
 
+// Transposed conv as a k = 2 causal conv: y[b][r * Cout + co][q] (r = output phase, s phases) -> out[b][co][q * s + r]
+__global__ __launch_bounds__(256) void phase_interleave_kernel(const float* __restrict__ y, float* __restrict__ out, int Cout, int s, int n) {
+    const long long To = (long long)n * s;
+    const long long total = (long long)Cout * To;
+    const int b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i / To);
+        const long long t = i % To;
+        const int q = (int)(t / s), r = (int)(t % s);
+        out[((long long)b * Cout + co) * To + t] = y[(((long long)b * s + r) * Cout + co) * n + q];
+    }
+}
+
+// code lookup of a residual VQ: out[t][0..d) = sum_q E[q][idx[t][q]][0..d)   (idx < 0 selects nothing)
+__global__ __launch_bounds__(256) void rvq_decode_kernel(const long long* __restrict__ idx, long long ldi, const float* __restrict__ E,
+                                                         float* __restrict__ out, long long ldo, int T, int d, int C, int Q) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    for (int e = lane; e < d; e += 64) {
+        float acc = 0.f;
+        for (int q = 0; q < Q; ++q) {
+            const long long c = idx[(long long)t * ldi + q];
+            if (c >= 0 && c < C) acc += E[((long long)q * C + c) * d + e];
+        }
+        out[(long long)t * ldo + e] = acc;
+    }
+}
+
 // [B][C][T] -> [B][T][C]  ('b c n -> b n c', soundstream.py:823)
 __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T) {
     __shared__ float tile[32][33];
@@ -377,13 +408,13 @@ extern "C" int alm_conv1d_pack(const float* w, float* wp, int Cout, int Cin, int
 // out[b][co][t] = act(bias[co] + sum_{ci,k} w[co][ci][k] * xpad[b][ci][t*stride + k*dilation]) (+ residual[b][co][t]),
 // xpad = x left-padded by dilation*(ksize-1) + 1 - stride in 'reflect' mode (soundstream.py:339-345); Tout = (Tin - stride) / stride + 1.
 extern "C" int alm_conv1d_causal(const float* x, const float* wp, const float* bias, const float* residual, float* out, int B, int Cin, int Cout,
-                                 int Tin, int ksize, int stride, int dilation, int elu, void* stream) {
+                                 int Tin, int ksize, int stride, int dilation, int elu, int zero_pad, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Tin <= 0 || ksize <= 0 || stride <= 0 || dilation <= 0) return ALM_ERR_BAD_ARG;
     const int pad = dilation * (ksize - 1) + 1 - stride;
     if (pad < 0 || pad >= Tin || Tin < stride) return ALM_ERR_UNSUPPORTED;
     if ((long long)(Cout + 32) * Tin * 4 >= 0x7fffffffLL || (long long)(Cin + 2) * Tin * 4 >= 0x7fffffffLL || (long long)ksize * (Cin + 1) * (Cout + 31) * 4 >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     const int Tout = (Tin - stride) / stride + 1;
-    ConvArgs a{x, wp, bias, residual, out, B, Cin, (Cin + 1) & ~1, Cout, (Cout + 31) & ~31, Tin, Tout, ksize, stride, dilation, pad, elu};
+    ConvArgs a{x, wp, bias, residual, out, B, Cin, (Cin + 1) & ~1, Cout, (Cout + 31) & ~31, Tin, Tout, ksize, stride, dilation, pad, elu, zero_pad};
     const int gx = (Tout + 255) / 256;
     if (a.CoutP % 64 == 0)
         hipLaunchKernelGGL(conv1d_causal_kernel<2>, dim3(gx, a.CoutP / 64, B), dim3(256), 0, (hipStream_t)stream, a);
@@ -431,6 +462,27 @@ extern "C" int alm_rvq_encode(const float* x, long long ldx, const float* E, con
 extern "C" int alm_bct_to_btc(const float* in, float* out, int B, int C, int T, void* stream) {
     if (B <= 0 || C <= 0 || T <= 0) return 0;
     hipLaunchKernelGGL(bct_to_btc_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, in, out, C, T);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// y [B][s * Cout][n] (phase-major channels) -> out [B][Cout][n * s]: the output interleave of CausalConvTranspose1d (soundstream.py:347-360)
+extern "C" int alm_phase_interleave(const float* y, float* out, int B, int Cout, int s, int n, void* stream) {
+    if (B <= 0 || Cout <= 0 || s <= 0 || n <= 0) return ALM_ERR_BAD_ARG;
+    const long long total = (long long)Cout * n * s;
+    const int gx = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(phase_interleave_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, y, out, Cout, s, n);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// idx int64 [T][ldi] (Q columns, -1 = no code), E fp32 [Q][C][d] -> out fp32 [T][ldo] (d columns): GroupedResidualVQ.get_output_from_indices
+// for one group (soundstream.py:697)
+extern "C" int alm_rvq_decode(const long long* idx, long long ldi, const float* E, float* out, long long ldo, int T, int d, int C, int Q,
+                              void* stream) {
+    if (T <= 0) return 0;
+    if (d <= 0 || C <= 0 || Q <= 0) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, idx, ldi, E, out, ldo, T, d, C, Q);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -563,8 +563,8 @@ def conv1d_pack(w):
     return wp
 
 
-def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, residual=None):
-    """x fp32 [B, Cin, T] -> fp32 [B, Cout, T // stride]: CausalConv1d (reflect left pad) + bias (+ ELU) (+ residual)."""
+def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, residual=None, zero_pad=False):
+    """x fp32 [B, Cin, T] -> fp32 [B, Cout, T // stride]: CausalConv1d (reflect left pad; zero_pad: zeros) + bias (+ ELU) (+ residual)."""
     _chk(x, F32)
     B, Cin, T = x.shape
     assert x.is_contiguous()
@@ -573,7 +573,26 @@ def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, 
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     _lib.call('alm_conv1d_causal', x.data_ptr(), wp.data_ptr(), bias.data_ptr(), _p(residual), out.data_ptr(), B, Cin, Cout, T, ksize, stride,
-              dilation, int(elu), _st())
+              dilation, int(elu), int(zero_pad), _st())
+    return out
+
+
+def phase_interleave(y, Cout, s):
+    """y fp32 [B, s * Cout, n] (phase-major channels) -> [B, Cout, n * s]: out[b, co, q * s + r] = y[b, r * Cout + co, q]."""
+    _chk(y, F32)
+    B, SC, n = y.shape
+    assert SC == s * Cout and y.is_contiguous()
+    out = torch.empty((B, Cout, n * s), dtype=F32, device=y.device)
+    _lib.call('alm_phase_interleave', y.data_ptr(), out.data_ptr(), B, Cout, s, n, _st())
+    return out
+
+
+def rvq_decode(idx, E, out):
+    """idx int64 [T, Q] (row stride arbitrary, -1 = no code), E fp32 [Q, C, d] -> out fp32 [T, d] view (row stride arbitrary): summed code vectors."""
+    _chk(E, F32), _chk(out, F32)
+    assert idx.dtype == torch.int64 and idx.stride(1) == 1 and out.stride(1) == 1 and E.is_contiguous()
+    T, Q = idx.shape
+    _lib.call('alm_rvq_decode', idx.data_ptr(), idx.stride(0), E.data_ptr(), out.data_ptr(), out.stride(0), T, E.shape[2], E.shape[1], Q, _st())
     return out
 
 

@@ -1,8 +1,9 @@
-"""Mirror of the reference's `audiolm_pytorch/soundstream.py` for the TOKENIZE path only:
-`SoundStream.tokenize(audio)` and `SoundStream.forward(x, return_encoded=True | return_codes_only=True)` -- the causal-conv encoder
-(soundstream.py:332-380, 519-531) and the eval-mode forward of the grouped residual VQ (soundstream.py:592-607, :840) run on the
-MI355X kernels of csrc/codec.hip (exact-fp32 MFMA).  Everything else the reference class does (decoder, discriminators, losses,
-training of the codec, local attention, LFQ / FSQ quantizers) is out of scope and raises.
+"""Mirror of the reference's `audiolm_pytorch/soundstream.py` for the TOKENIZE path and the DECODE path
+(§8(f) item 3, without local attention): `SoundStream.tokenize(audio)`, `SoundStream.forward(x, return_encoded=True |
+return_codes_only=True)` -- the causal-conv encoder (soundstream.py:332-380, 519-531) and the eval-mode forward of the grouped residual VQ
+(soundstream.py:592-607, :840) -- and `decode_from_codebook_indices` / `decode` (soundstream.py:691-709: code lookup, transposed-conv
+decoder :347-360, 382-395, 615-627) run on the MI355X kernels of csrc/codec.hip (exact-fp32 MFMA).  Everything else the reference class
+does (discriminators, losses, training of the codec, local attention, LFQ / FSQ quantizers) is out of scope and raises.
 
 The module tree keeps the reference's parameter / buffer NAMES for the parts it has, so `state_dict()` entries `encoder.*` and
 `rq.*` of a reference checkpoint load with `load_state_dict(..., strict=False)`:
@@ -10,6 +11,7 @@ The module tree keeps the reference's parameter / buffer NAMES for the parts it 
     encoder.{b}.{r}.fn.{0,2}.conv.{weight,bias}         ResidualUnit r of EncoderBlock b (k7 dilated conv, ELU, k1 conv, ELU, + x)
     encoder.{b}.3.conv.{weight,bias}                    strided down-sampling conv (k = 2 * stride)
     encoder.{last}.conv.{weight,bias}                   CausalConv1d(-> codebook_dim, 3)
+    decoder.0.conv / decoder.{b}.0.conv (ConvTranspose1d) / decoder.{b}.{1,2,3}.fn.{0,2}.conv / decoder.{last}.conv
     rq.rvqs.{g}.layers.{q}._codebook.{initted, cluster_size, embed_avg, embed (1, C, d)}
 """
 from __future__ import annotations
@@ -53,6 +55,40 @@ class CausalConv1d(nn.Module):                                   # soundstream.p
         return self.run(x)
 
 
+class CausalConvTranspose1d(nn.Module):                          # soundstream.py:347-360
+    """ConvTranspose1d(k = 2 * stride, stride) cut to n * stride outputs.  Output t = q * stride + r depends on input frames q and q - 1
+    only (taps r and r + stride), so it runs as the k = 2, zero-left-padded causal conv over `stride` phase-major copies of the output
+    channels (alm_conv1d_causal, exact-fp32 MFMA), followed by the phase interleave."""
+
+    def __init__(self, chan_in, chan_out, kernel_size, stride, **kwargs):
+        super().__init__()
+        if kernel_size != 2 * stride or kwargs:
+            raise NotImplementedError('only the reference decoder form is implemented: kernel_size = 2 * stride, default ConvTranspose1d options')
+        self.upsample_factor = stride
+        self.padding = kernel_size - 1
+        self.conv = nn.ConvTranspose1d(chan_in, chan_out, kernel_size, stride)
+        self._packed = None
+
+    def packed(self):
+        w, b = self.conv.weight, self.conv.bias
+        ver = (w.data_ptr(), core.tensor_version(w), core.tensor_version(b))
+        if self._packed is None or self._packed[0] != ver:
+            s = self.upsample_factor
+            cin, cout, _ = w.shape
+            wd = w.detach().to(F32)                                                  # [Cin, Cout, 2 s]
+            # W2[(r, co), ci, tap]: tap 0 <- x[q - 1] uses w[ci, co, r + s]; tap 1 <- x[q] uses w[ci, co, r]
+            w2 = torch.stack((wd[:, :, s:], wd[:, :, :s]), dim=-1)                   # [Cin, Cout, s(r), 2(tap)]
+            w2 = w2.permute(2, 1, 0, 3).reshape(s * cout, cin, 2).contiguous()
+            self._packed = (ver, ops.conv1d_pack(w2), b.detach().to(F32).repeat(s).contiguous())
+        return self._packed[1], self._packed[2]
+
+    def forward(self, x):
+        wp, b2 = self.packed()
+        s, cout = self.upsample_factor, self.conv.out_channels
+        y = ops.conv1d_causal(x, wp, b2, s * cout, 2, zero_pad=True)
+        return ops.phase_interleave(y, cout, s)
+
+
 class _ResidualFn(nn.Module):
     """holder with the reference's `.fn` Sequential naming: fn.0 = dilated k7 conv, fn.2 = k1 conv (fn.1 / fn.3 are ELUs)."""
 
@@ -79,6 +115,14 @@ def EncoderBlock(chan_in, chan_out, stride, cycle_dilations=(1, 3, 9), squeeze_e
                          ResidualUnit(chan_in, chan_in, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
                          ResidualUnit(chan_in, chan_in, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
                          CausalConv1d(chan_in, chan_out, 2 * stride, stride=stride, pad_mode=pad_mode))
+
+
+def DecoderBlock(chan_in, chan_out, stride, cycle_dilations=(1, 3, 9), squeeze_excite=False, pad_mode='reflect'):   # soundstream.py:382-395
+    it = cycle(cycle_dilations)
+    return nn.Sequential(CausalConvTranspose1d(chan_in, chan_out, 2 * stride, stride=stride),
+                         ResidualUnit(chan_out, chan_out, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
+                         ResidualUnit(chan_out, chan_out, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode),
+                         ResidualUnit(chan_out, chan_out, next(it), squeeze_excite=squeeze_excite, pad_mode=pad_mode))
 
 
 class _EuclideanCodebook(nn.Module):
@@ -142,6 +186,19 @@ class GroupedResidualVQ(nn.Module):
         return quant.view(b, n, dim), idx.view(self.groups, b, n, self.num_quantizers), torch.zeros((self.groups, self.num_quantizers), device=x.device)
 
 
+    @torch.no_grad()
+    def get_output_from_indices(self, indices):
+        """indices int (g, b, n, q) (-1 = no code) -> (b, n, dim): per group the sum of the selected code vectors (alm_rvq_decode)."""
+        g, b, n, q = indices.shape
+        assert g == self.groups and q <= self.num_quantizers
+        dg = self.dim // self.groups
+        out = torch.empty((b * n, self.dim), dtype=F32, device=indices.device)
+        idx = indices.to(torch.int64).reshape(g, b * n, q).contiguous()
+        for gi, (E, _, _) in enumerate(self._pack()):
+            ops.rvq_decode(idx[gi], E[:q].contiguous(), out[:, gi * dg:(gi + 1) * dg])
+        return out.view(b, n, self.dim)
+
+
 def curtail_to_multiple(t, mult, from_left=False):               # soundstream.py:86-90
     data_len = t.shape[-1]
     rounded = (data_len // mult) * mult
@@ -173,6 +230,12 @@ class SoundStream(nn.Module):
         self.encoder = nn.Sequential(CausalConv1d(input_channels, channels, 7, pad_mode=pad_mode), *blocks,
                                      CausalConv1d(layer_channels[-1], codebook_dim, 3, pad_mode=pad_mode))
         self.encoder_attn = None
+        self.decoder_attn = None
+        dec_cycle_dilations = kwargs.pop('dec_cycle_dilations', (1, 3, 9))          # remaining kwargs: attention / discriminator / loss options of
+                                                                                    # the parts that are not built here (ignored, like before)
+        dblocks = [DecoderBlock(co, ci, s, dec_cycle_dilations, squeeze_excite, pad_mode) for (ci, co), s in reversed(tuple(zip(pairs, strides)))]
+        self.decoder = nn.Sequential(CausalConv1d(codebook_dim, layer_channels[-1], 7, pad_mode=pad_mode), *dblocks,
+                                     CausalConv1d(channels, input_channels, 7, pad_mode=pad_mode))             # soundstream.py:615-627
         self.num_quantizers = rq_num_quantizers
         self.codebook_dim = codebook_dim
         self.rq_groups = rq_groups
@@ -231,5 +294,26 @@ class SoundStream(nn.Module):
         b, n = indices.shape[1], indices.shape[2]
         return quantized, indices.permute(1, 2, 0, 3).reshape(b, n, -1), commit_loss          # 'g b n q -> b n (g q)', :851
 
-    def decode_from_codebook_indices(self, quantized_indices):
-        raise NotImplementedError('the decoder is out of scope (SURVEY.md §8(f) item 3)')
+    @torch.no_grad()
+    def decode_from_codebook_indices(self, quantized_indices):               # soundstream.py:691-699
+        assert quantized_indices.dtype in (torch.long, torch.int32)
+        if quantized_indices.ndim == 3:
+            b, n, gq = quantized_indices.shape
+            quantized_indices = quantized_indices.reshape(b, n, self.rq_groups, gq // self.rq_groups).permute(2, 0, 1, 3)   # 'b n (g q) -> g b n q'
+        return self.decode(self.rq.get_output_from_indices(quantized_indices))
+
+    @torch.no_grad()
+    def decode(self, x, quantize=False):                                      # soundstream.py:701-709
+        """x fp32 (b, n, codebook_dim) -> wave (b, input_channels, n * prod(strides)): 'b n c -> b c n', then the causal transposed-conv decoder."""
+        if quantize:
+            x, *_ = self.rq(x)
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd.SoundStream runs on the MI355X only (no CPU fallback)')
+        h = ops.bct_to_btc(x.to(F32).contiguous())                           # the same per-batch 2-D transpose, applied to (n, c) -> (c, n)
+        for layer in self.decoder:
+            if isinstance(layer, CausalConv1d):
+                h = layer.run(h)
+            else:
+                for sub in layer:
+                    h = sub(h)
+        return h

@@ -219,7 +219,12 @@ int alm_opt_adam_step(const AlmOptTensor* tensors, const int* chunks, int nchunk
 int alm_conv1d_packed_floats(int Cout, int Cin, int ksize);
 int alm_conv1d_pack(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream);
 int alm_conv1d_causal(const float* x, const float* wp, const float* bias, const float* residual, float* out, int B, int Cin, int Cout, int Tin,
-                      int ksize, int stride, int dilation, int elu, void* stream);
+                      int ksize, int stride, int dilation, int elu, int zero_pad, void* stream);
+/* decoder side (soundstream.py:347-360, 382-395, 615-627, 691-709).  zero_pad = 1 above pads with zeros instead of reflecting: a
+ * CausalConvTranspose1d(k = 2 s, stride s) is that conv with k = 2 over s * Cout phase-major output channels (weights re-indexed on the host),
+ * followed by alm_phase_interleave: y [B][s * Cout][n] -> out [B][Cout][n * s].  alm_rvq_decode: codes -> summed code vectors. */
+int alm_phase_interleave(const float* y, float* out, int B, int Cout, int s, int n, void* stream);
+int alm_rvq_decode(const long long* idx, long long ldi, const float* E, float* out, long long ldo, int T, int d, int C, int Q, void* stream);
 /* rvq: frames x [T][ldx] (d columns of one group), codebooks E [Q][C][d]; Et [Q][alm_rvq_padded_dim(d)][CP] floats (MFMA-ordered image)
  * / e2 [Q][CP] packed once by alm_rvq_pack (CP = alm_rvq_padded_codes(C)); idx int64 [T][ldi] (Q columns): per quantizer argmin_e sqrt(clamp(|r|^2 + |e|^2 - 2 r.e, 0)) with
  * first-index tie-breaking, r -= E[idx]; quant (optional) = sum of the selected code vectors. */

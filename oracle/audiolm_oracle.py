@@ -474,6 +474,45 @@ def soundstream_encoder(sd, x, strides=(2, 4, 5, 8), dilations=(1, 3, 9), p='enc
     return causal_conv1d(x, sd[f'{p}{last}.conv.weight'], sd[f'{p}{last}.conv.bias'])
 
 
+def causal_conv_transpose1d(x, w, b, stride):               # soundstream.py:347-360: ConvTranspose1d(k, stride), output cut to n * stride
+    n = x.shape[-1]
+    return F.conv_transpose1d(x, w, b, stride=stride)[..., :n * stride]
+
+
+def soundstream_decoder(sd, x, strides=(2, 4, 5, 8), dilations=(1, 3, 9), p='decoder.'):
+    """soundstream.py:615-627: conv(k7) -> for the strides in REVERSE order [transposed conv(k = 2s, stride s), 3 x ResidualUnit] -> conv(k7).
+    x (b c n)."""
+    x = causal_conv1d(x, sd[p + '0.conv.weight'], sd[p + '0.conv.bias'])
+    for bi, s in enumerate(reversed(strides)):
+        bp = f'{p}{bi + 1}.'
+        x = causal_conv_transpose1d(x, sd[bp + '0.conv.weight'], sd[bp + '0.conv.bias'], s)
+        for ri, d in enumerate(dilations):
+            x = residual_unit(sd, f'{bp}{ri + 1}.', x, d)
+    last = len(strides) + 1
+    return causal_conv1d(x, sd[f'{p}{last}.conv.weight'], sd[f'{p}{last}.conv.bias'])
+
+
+def rvq_decode(indices, codebooks):
+    """(b, n, q) int -> (b, n, d): sum of the selected code vectors, -1 selects nothing (get_output_from_indices, soundstream.py:697)."""
+    out = 0.
+    for q, E in enumerate(codebooks):
+        idx = indices[..., q]
+        out = out + E[idx.clamp(min=0)].masked_fill((idx < 0).unsqueeze(-1), 0.)
+    return out
+
+
+def soundstream_decode_from_indices(sd, indices, *, strides=(2, 4, 5, 8), num_quantizers=8, groups=1):
+    """SoundStream.decode_from_codebook_indices (soundstream.py:691-709, use_local_attn=False): indices (b, n, (g q)) -> wave (b, 1, n * prod)."""
+    b, n, _ = indices.shape
+    ix = indices.reshape(b, n, groups, num_quantizers).permute(2, 0, 1, 3)          # 'b n (g q) -> g b n q'
+    outs = []
+    for g in range(groups):
+        cbs = [sd[f'rq.rvqs.{g}.layers.{q}._codebook.embed'][0] for q in range(num_quantizers)]
+        outs.append(rvq_decode(ix[g], cbs))
+    x = torch.cat(outs, dim=-1).transpose(1, 2)                                       # 'b n c -> b c n'
+    return soundstream_decoder(sd, x, strides=strides)
+
+
 def rvq_encode(x, codebooks):
     """x (b n d), codebooks (Q, C, d) -> indices (b n Q) int64.  See oracle/rvq_restated.py."""
     shape = x.shape

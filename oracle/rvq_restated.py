@@ -3,7 +3,7 @@ cpu_baseline leg may import this file; the product path never does.
 
 Restatement of `vector-quantize-pytorch` (`>=1.19.3`, /root/reference/setup.py:38; source NOT
 vendored, no lockfile) `GroupedResidualVQ` **eval-mode forward**, as constructed by the
-reference at audiolm_pytorch/soundstream.py:592-607 and called at soundstream.py:840.
+reference at audiolm_pytorch/soundstream.py:592-607 and called at soundstream.py:840, and `get_output_from_indices` (soundstream.py:697).
 
 PARITY UNPINNED: no upstream source / tests / golden vectors under /root/reference.  Restated
 from the published algorithm (SoundStream residual VQ, Zeghidour et al. 2021; lucidrains
@@ -74,6 +74,16 @@ class ResidualVQ(nn.Module):
             inds.append(ind)
         return out, torch.stack(inds, dim=-1), torch.zeros(1, len(self.layers), device=x.device)
 
+    def get_output_from_indices(self, indices):
+        """(b, n, q) int -> (b, n, d): sum over the quantizers of the selected code vectors; index -1 (quantize-dropout / padding) selects
+        nothing (upstream get_codes_from_indices masks those positions to 0).  project_out is the identity here (codebook_dim == dim)."""
+        out = 0.
+        for q, layer in enumerate(self.layers):
+            idx = indices[..., q]
+            codes = layer._codebook.embed[0][idx.clamp(min=0)]
+            out = out + codes.masked_fill((idx < 0).unsqueeze(-1), 0.)
+        return out
+
 
 class GroupedResidualVQ(nn.Module):
     def __init__(self, *, dim, groups=1, num_quantizers, codebook_size, **kwargs):
@@ -92,6 +102,10 @@ class GroupedResidualVQ(nn.Module):
         indices = torch.stack([o[1] for o in outs])                # (g, b, n, q)
         losses = torch.stack([o[2] for o in outs])
         return quantized, indices, losses
+
+    def get_output_from_indices(self, indices):
+        """(g, b, n, q) -> (b, n, dim): per-group outputs concatenated along the feature dim (soundstream.py:697)."""
+        return torch.cat([rvq.get_output_from_indices(ix) for rvq, ix in zip(self.rvqs, indices)], dim=-1)
 
 
 class _Unsupported(nn.Module):

@@ -178,7 +178,34 @@ def soundstream_case():
                 outputs=dict(indices=indices, tokenize=codes, encoder_out=enc, quantized=emb))
 
 
+def soundstream_decode_case():
+    """SoundStream.decode_from_codebook_indices of the REAL reference decoder (first-party code) around the restated RVQ lookup."""
+    torch.manual_seed(0)
+    ctor = dict(codebook_size=32, rq_num_quantizers=4, channels=4, codebook_dim=16, use_local_attn=False,
+                strides=(2, 4, 5, 8), target_sample_hz=16000)
+    ss = S.SoundStream(**ctor)
+    full_sd = ss.state_dict()
+    keep = {k: v for k, v in full_sd.items() if k.startswith('decoder.') or k.startswith('rq.')}
+    shapes = _shapes(keep)
+    new = synth_state_dict(shapes, 6)
+    full_sd.update(new)
+    ss.load_state_dict(full_sd)
+    ss.eval()
+    g = torch.Generator().manual_seed(12)
+    indices = torch.randint(0, 32, (2, 9, 4), generator=g)
+    indices[1, -2:, 2:] = -1                                  # dropped quantizers (quantize-dropout / variable-length padding)
+    with torch.no_grad():
+        wave = ss.decode_from_codebook_indices(indices)
+    return dict(name='soundstream_decode_small', kind='soundstream_decode', ctor=ctor, shapes=shapes, seed=6, restated=True,
+                inputs=dict(indices=indices), outputs=dict(wave=wave))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'soundstream_decode':      # add this fixture without touching the others
+        c = soundstream_decode_case()
+        torch.save(c, os.path.join(HERE, c['name'] + '.pt'))
+        print(c['name'], tuple(c['outputs']['wave'].shape))
+        return
     R = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
     cases = []
 
@@ -210,6 +237,7 @@ def main():
 
     cases.append(attend_case())
     cases.append(soundstream_case())
+    cases.append(soundstream_decode_case())
 
     for c in cases:
         path = os.path.join(HERE, c['name'] + '.pt')

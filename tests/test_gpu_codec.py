@@ -110,7 +110,7 @@ def test_soundstream_matches_reference_golden():
     fx = _load_fixture()
     ss = A.SoundStream(**fx['ctor'])
     missing, unexpected = ss.load_state_dict(synth_state_dict(fx['shapes'], fx['seed']), strict=False)
-    assert not unexpected and not missing, (missing, unexpected)
+    assert not unexpected and all(k.startswith('decoder.') for k in missing), (missing, unexpected)     # this fixture carries encoder.* + rq.*
     ss.to(dev())
     wave = fx['inputs']['wave'].to(dev())
     x, _ = ss.process_input(wave)
@@ -188,3 +188,75 @@ def test_end_to_end_raw_wave_to_coarse_loss_vs_oracle():
     ref = O.coarse_wrapper_loss(sd, cfg, sem, idx[..., :3], training=True, unique_consecutive=False)
     assert abs(float(loss) - float(ref)) <= 2e-3 * max(1.0, abs(float(ref))), (float(loss), float(ref))
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,n,stride', [(2, 8, 4, 19, 2), (1, 64, 32, 40, 4), (2, 16, 8, 33, 5), (1, 512, 256, 25, 8), (1, 3, 5, 7, 3)])
+def test_causal_conv_transpose1d(ops, B, Cin, Cout, n, stride):
+    """CausalConvTranspose1d (soundstream.py:347-360) as the k = 2 zero-padded conv over phase-major channels + interleave, vs
+    F.conv_transpose1d cut to n * stride (exact-fp32 MFMA: 2e-5 rel-max)."""
+    from audiolm_pytorch_amd import soundstream as SS
+    torch.manual_seed(stride)
+    m = SS.CausalConvTranspose1d(Cin, Cout, 2 * stride, stride).to(dev())
+    x = rnd(B, Cin, n, seed=70 + stride).to(dev())
+    got = m(x)
+    ref = F.conv_transpose1d(x, m.conv.weight, m.conv.bias, stride=stride)[..., :n * stride]
+    assert got.shape == ref.shape
+    assert relmax(got, ref) <= 2e-5
+
+
+def test_rvq_decode(ops):
+    g = torch.Generator().manual_seed(3)
+    Q, C, d, T = 5, 37, 24, 300
+    E = torch.randn(Q, C, d, generator=g).to(dev())
+    idx = torch.randint(0, C, (T, Q), generator=g)
+    idx[5, 2:] = -1
+    idx[17] = -1
+    out = torch.full((T, d + 3), float('nan'), device=dev())
+    ops.rvq_decode(idx.to(dev()), E, out[:, :d])
+    ref = O.rvq_decode(idx[None], [E[q].cpu() for q in range(Q)])[0]
+    assert relmax(out[:, :d].cpu(), ref) <= 1e-6 and bool(torch.isnan(out[:, d:]).all())
+
+
+def test_soundstream_decode_matches_reference_golden():
+    """tests/golden/soundstream_decode_small.pt: decode_from_codebook_indices of the REAL reference decoder (incl. dropped -1 codes)."""
+    import audiolm_pytorch_amd as A
+    fx = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_decode_small.pt'), weights_only=False)
+    ss = A.SoundStream(**fx['ctor'])
+    missing, unexpected = ss.load_state_dict(synth_state_dict(fx['shapes'], fx['seed']), strict=False)
+    assert not unexpected and all(k.startswith('encoder.') for k in missing), (missing, unexpected)
+    ss.to(dev())
+    wave = ss.decode_from_codebook_indices(fx['inputs']['indices'].to(dev()))
+    assert wave.shape == fx['outputs']['wave'].shape
+    assert relmax(wave, fx['outputs']['wave']) <= 2e-5
+
+
+def test_tokenize_decode_round_trip_shapes_and_generate_reconstruct():
+    """encode -> codes -> decode keeps the length (multiple of prod(strides)); CoarseTransformerWrapper.generate(reconstruct_wave=True) and
+    FineTransformerWrapper.generate(reconstruct_wave=True) end in a waveform produced by the native decoder."""
+    import audiolm_pytorch_amd as A
+    torch.manual_seed(0)
+    codec = A.SoundStream(codebook_size=16, rq_num_quantizers=8, channels=4, codebook_dim=16, use_local_attn=False, strides=(2, 4, 5, 8)).to(dev())
+    for r in codec.rq.rvqs:
+        for l in r.layers:
+            l._codebook.embed.normal_()
+            l._codebook.initted.fill_(True)
+    wave = rnd(2, 320 * 12 + 11, seed=80, scale=0.3).to(dev())
+    codes = codec.tokenize(wave)                                                   # (1, 2, 12, 8)
+    rec = codec.decode_from_codebook_indices(codes)
+    assert rec.shape == (2, 1, 320 * 12) and bool(torch.isfinite(rec).all())
+    coarse = A.CoarseTransformer(dim=64, depth=1, heads=2, num_semantic_tokens=20, codebook_size=16, num_coarse_quantizers=3, flash_attn=True).to(dev())
+    cw = A.CoarseTransformerWrapper(transformer=coarse, codec=codec, unique_consecutive=False)
+    sem = torch.randint(0, 20, (2, 5), device=dev())
+    out = cw.generate(semantic_token_ids=sem, max_time_steps=8, reconstruct_wave=True)      # >= 7 frames: reflect padding of the k = 7 convs
+    if isinstance(out, list):
+        assert all(w is None or w.dim() == 1 for w in out)
+    else:
+        assert out.shape == (2, 8 * 320)
+    fine = A.FineTransformer(dim=64, depth=1, heads=2, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5, flash_attn=True).to(dev())
+    fw = A.FineTransformerWrapper(transformer=fine, codec=codec)
+    cids = torch.randint(0, 16, (2, 8, 3), device=dev())
+    out = fw.generate(coarse_token_ids=cids, reconstruct_wave=True)
+    if isinstance(out, list):
+        assert all(w.dim() == 1 for w in out)
+    else:
+        assert out.shape == (2, 8 * 320)

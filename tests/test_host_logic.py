@@ -129,7 +129,10 @@ def test_soundstream_module_tree_matches_reference_state_dict_names():
     fx = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_small.pt'), weights_only=False)
     ss = A.SoundStream(**fx['ctor'])
     ours = {k: tuple(v.shape) for k, v in ss.state_dict().items()}
-    assert ours == {k: tuple(v) for k, v in fx['shapes'].items()}
+    fd = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_decode_small.pt'), weights_only=False)          # decoder.* + rq.* of the REAL reference
+    want = {k: tuple(v) for k, v in fx['shapes'].items()}
+    want.update({k: tuple(v) for k, v in fd['shapes'].items()})
+    assert ours == want, (sorted(set(ours) ^ set(want))[:10])
     assert ss.seq_len_multiple_of == 320 and ss.rq_groups == 1 and ss.num_quantizers == fx['ctor']['rq_num_quantizers']
     with pytest.raises(NotImplementedError):
         A.SoundStream(codebook_size=32)                              # reference default use_local_attn=True is SURVEY §8(f)-3

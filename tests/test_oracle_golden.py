@@ -134,3 +134,14 @@ def test_bookkeeping_helpers_bit_exact():
     assert torch.equal(O.append_eos_id(ids, 9)[:, -1], torch.tensor([9, 9]))
     m = O.generate_mask_with_prob((4, 20), 0.15, 'cpu')
     assert m.dtype == torch.bool and bool(m[:, 0].all()) and int((~m).sum()) == 4 * 3
+
+
+def test_soundstream_decode_matches_reference():
+    """oracle.soundstream_decode_from_indices vs the REAL reference decoder (soundstream.py:691-709, 615-627) around the restated code lookup,
+    incl. dropped (-1) quantizer indices."""
+    fx = _load('soundstream_decode_small')
+    c = fx['ctor']
+    sd = synth_state_dict(fx['shapes'], fx['seed'])
+    wave = O.soundstream_decode_from_indices(sd, fx['inputs']['indices'], strides=c['strides'], num_quantizers=c['rq_num_quantizers'])
+    assert wave.shape == fx['outputs']['wave'].shape
+    assert torch.allclose(wave, fx['outputs']['wave'], atol=1e-5, rtol=1e-5)
