@@ -415,6 +415,38 @@ def bench_gen():
         del m, w
 
 
+def bench_gen_notebook():
+    """the three sampling rates the reference's demo notebook prints (audiolm_pytorch_demo.ipynb:603-605: Tesla T4, v0.7.5, no kv cache;
+    semantic dim=1024, coarse / fine dim=512, depth 6, batch 1), on this path with the kv cache"""
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    torch.manual_seed(0)
+    sem = A.SemanticTransformer(dim=1024, depth=6, num_semantic_tokens=500).to(dev)
+    sw = A.SemanticTransformerWrapper(transformer=sem, unique_consecutive=False)
+    sw.generate(max_length=8, batch_size=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ids = sw.generate(max_length=256, batch_size=1)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f'semantic sampling (d=1024, depth 6, B=1, default ctor): {ids.shape[1] / dt:.1f} it/s   [notebook: 78.55 it/s on a T4, no kv cache]')
+    coarse = A.CoarseTransformer(dim=512, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3).to(dev)
+    cw = A.CoarseTransformerWrapper(transformer=coarse, codec=Codec(), unique_consecutive=False)
+    s_ids = torch.randint(0, 500, (1, 256), device=dev)
+    cw.generate(semantic_token_ids=s_ids, max_time_steps=2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    c = cw.generate(semantic_token_ids=s_ids, max_time_steps=128)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f'coarse sampling (d=512, depth 6, 3 quantizers, B=1): {128 / dt:.1f} it/s (1 it = 3 tokens)   [notebook: 34.83 it/s]')
+    fine = A.FineTransformer(dim=512, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024).to(dev)
+    fw = A.FineTransformerWrapper(transformer=fine, codec=Codec())
+    c_ids = torch.randint(0, 1024, (1, 128, 3), device=dev)
+    fw.generate(coarse_token_ids=c_ids[:, :8])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    f = fw.generate(coarse_token_ids=c_ids)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f'fine sampling (d=512, depth 6, 3 + 5 quantizers, B=1): {128 / dt:.1f} it/s (1 it = 5 tokens)   [notebook: 2.91 it/s]')
+
+
 def bench_misc():
     M, D, I, Ip = 16384, 1024, 2730, 2736
     U = rnd(M, 2 * Ip)
