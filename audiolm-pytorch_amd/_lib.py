@@ -71,7 +71,7 @@ SIGNATURES = {
     'alm_cross_entropy_fwd': [_P, _L, _P, _P, _P, _L, _I, _I, _P],
     'alm_cross_entropy_bwd': [_P, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     'alm_reduce_sum': [_P, _L, _P, _F, _P],
-    'alm_mqa_decode_attn': [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _P, _P],
+    'alm_mqa_decode_attn': [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     'alm_opt_chunk_elems': [],
     'alm_opt_grad_sumsq': [_P, _P, _I, _P, _P],
     'alm_opt_adam_step': [_P, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],

@@ -20,6 +20,7 @@ There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refu
 """
 from __future__ import annotations
 
+import os
 from functools import partial
 from pathlib import Path
 
@@ -33,6 +34,7 @@ from .attend import Attend
 from .version import __version__
 
 DEFAULT_T5_NAME = 'google/t5-v1_1-base'
+DECODE_GRAPH = os.environ.get('ALM_DECODE_GRAPH', '1') != '0'        # capture the single-position sampling step into a hipGraph
 _T5_DIMS = {'google/t5-v1_1-small': 512, 'google/t5-v1_1-base': 768, 'google/t5-v1_1-large': 1024,
             'google/t5-v1_1-xl': 2048, 'google/t5-v1_1-xxl': 4096, 't5-small': 512, 't5-base': 768, 't5-large': 1024}
 
@@ -371,19 +373,51 @@ class Transformer(nn.Module):
         """One step of an autoregressive sampling run (kv cache, reference :360-394 / :560): tokens fp32 [b, n, d] = embeddings of the WHOLE
         sequence so far, state = core.DecodeCache (state.bias: AttnBias laid out for state.nmax positions, or None).  First call: ordinary
         forward over the n positions that also fills the cache; later calls: only the last position runs (n == state.length + 1), its
-        attention reads the cache.  -> hidden state of the last position, bf16 [b, d]."""
+        attention reads the cache.  The single-position step is ~150 launches for ~0.3 ms of GPU work, i.e. bound by the host: after one
+        eager step it is captured into a hipGraph (torch.cuda.CUDAGraph; the position index lives on the device) and every further step is
+        ONE graph launch (ALM_DECODE_GRAPH=0 disables).  -> hidden state of the last position, bf16 [b, d]."""
         b, n, d = tokens.shape
         mask_u8 = None if self_attn_mask is None else self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
         bias = getattr(state, 'bias', None)
+        flat = self.flat_params()
         if state.length == 0:
             pb = bias.sliced(n) if exists(bias) else None
             hn = core.TransformerStackFn.apply(tokens, mask_u8, self.cfg, self._cache, dict(grad=False, kv_out=state), pb,
-                                               pb.tbl if exists(pb) else None, *self.flat_params())
+                                               pb.tbl if exists(pb) else None, *flat)
             return hn.view(b, n, d)[:, -1]
         assert n == state.length + 1 and n <= state.nmax, (n, state.length, state.nmax)
         x = tokens[:, -1:].contiguous()
-        return core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, dict(grad=False, decode=state), bias,
-                                             bias.tbl if exists(bias) else None, *self.flat_params())
+        tbl = bias.tbl if exists(bias) else None
+        if not DECODE_GRAPH:
+            return core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, dict(grad=False, decode=state), bias, tbl, *flat)
+        if state.pos_dev is None:
+            # first single-position step: eager, already in the device-position form (also warms every lazily initialised launch path up)
+            state.pos_dev = torch.full((1,), state.length, dtype=torch.int32, device=x.device)
+            if exists(mask_u8):
+                state.mask_in = torch.ones((b, state.nmax), dtype=torch.uint8, device=x.device)
+                state.mask_in[:, :n] = mask_u8
+            h = core.TransformerStackFn.apply(x, state.mask_in, self.cfg, self._cache, dict(grad=False, decode=state), bias, tbl, *flat)
+            state.pos_dev += 1
+            return h
+        if exists(state.mask_in):
+            state.mask_in[:, :n] = mask_u8
+        if state.graph is None:
+            state.x_in = x.clone()
+            graph = torch.cuda.CUDAGraph()
+            state.frozen = True
+            try:
+                with torch.cuda.graph(graph):
+                    state.h_out = core.TransformerStackFn.apply(state.x_in, state.mask_in, self.cfg, self._cache, dict(grad=False, decode=state),
+                                                                bias, tbl, *flat)
+            finally:
+                state.frozen = False
+            state.graph = graph
+        else:
+            state.x_in.copy_(x)
+        state.graph.replay()
+        state.length += 1
+        state.pos_dev += 1
+        return state.h_out
 
 
 # ---------------------------------------------------------------------------------------------- embedding assembly

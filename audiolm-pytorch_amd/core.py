@@ -159,6 +159,10 @@ class DecodeCache:
     def __init__(self, cfg, B, nmax, device):
         self.kv = [torch.zeros((B, nmax, 2 * cfg.dim_head), dtype=BF16, device=device) for _ in range(cfg.depth)]
         self.B, self.nmax, self.length = B, nmax, 0
+        # hipGraph replay of the single-position step (Transformer._sample): the position then lives on the device (`pos_dev` == length)
+        self.pos_dev = None
+        self.graph = self.x_in = self.h_out = self.mask_in = None
+        self.frozen = False             # True while a step is being CAPTURED (recorded, not executed): host bookkeeping must not advance
 
 
 def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None):
@@ -203,7 +207,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
             kv0 = KV                                      # :534-535 (layer-0 values, pre-mix)
         if decode is not None:
             kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
-            AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias), None
+            AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias, pos_dev=decode.pos_dev), None
         else:
             AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
             if kv_out is not None:
@@ -245,7 +249,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])              # :555
     if need_grad:
         saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
-    if decode is not None:
+    if decode is not None and not decode.frozen:
         decode.length += 1
     if kv_out is not None:
         kv_out.length = N

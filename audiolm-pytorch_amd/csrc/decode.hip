@@ -26,6 +26,9 @@ struct DecodeArgs {
     const int* kkey4; const int* kattr;
     int B, H, pos;
     float scale;
+    const int* pos_dev;                          // non-NULL: the position index lives on the device (hipGraph replay: the launch arguments are frozen)
+    const int* qkey4_vec; const int* qattr_vec;  // with pos_dev: per-position query offsets / attributes, indexed by the position
+    int nmax;
 };
 
 __global__ __launch_bounds__(1024) void mqa_decode_kernel(DecodeArgs a) {
@@ -33,6 +36,11 @@ __global__ __launch_bounds__(1024) void mqa_decode_kernel(DecodeArgs a) {
     __shared__ float ps[16][64];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    if (a.pos_dev) {
+        a.pos = *a.pos_dev;
+        if (a.pos < 0 || a.pos >= a.nmax) return;
+        if (a.tbl) { a.qkey4 = a.qkey4_vec[a.pos]; a.qattr = a.qattr_vec[a.pos]; }
+    }
     bf16_t* cb = a.cache + (long long)b * a.cache_stride;
     const bf16_t* kvn = a.kv_new + (long long)b * a.ldkv;
     // append the new row (wave 0 of the workgroup; the loop below takes the new row from kv_new directly, so no read-after-write)
@@ -88,15 +96,18 @@ __global__ __launch_bounds__(1024) void mqa_decode_kernel(DecodeArgs a) {
 
 // One new position per sequence: appends kv_new to the cache at `pos` and attends over positions 0 .. pos.
 // tbl / kkey4 / kattr (device) + qkey4 / qattr (the new position's values, by value): structured bias as in alm_mqa_attn_bias_fwd, or tbl NULL.
+// pos_dev (device int32) non-NULL: the position is read from it at run time (`pos`, `qkey4`, `qattr` are ignored; qkey4_vec / qattr_vec are
+// the per-position device vectors) -- the form a captured hipGraph replays.
 extern "C" int alm_mqa_decode_attn(const void* q, long long ldq, void* cache, long long cache_stride, const void* kv_new, long long ldkv,
                                    const unsigned char* mask, long long ldm, void* out, long long ldo, int B, int H, int dim_head, int pos,
                                    int nmax, float scale, const float* tbl, int LT, int qkey4, int qattr, const int* kkey4, const int* kattr,
-                                   void* stream) {
-    if (dim_head != DH || B <= 0 || H <= 0 || H > 16 || pos < 0 || pos >= nmax) return ALM_ERR_UNSUPPORTED;
+                                   const int* pos_dev, const int* qkey4_vec, const int* qattr_vec, void* stream) {
+    if (dim_head != DH || B <= 0 || H <= 0 || H > 16 || (!pos_dev && (pos < 0 || pos >= nmax))) return ALM_ERR_UNSUPPORTED;
+    if (pos_dev && tbl && (!qkey4_vec || !qattr_vec)) return ALM_ERR_BAD_ARG;
     if ((ldkv & 7) || ((uintptr_t)kv_new & 15) || ((uintptr_t)cache & 15) || (cache_stride & 7)) return ALM_ERR_BAD_ARG;
     if (tbl && (!kkey4 || !kattr || LT < 1)) return ALM_ERR_BAD_ARG;
     DecodeArgs a{(const bf16_t*)q, ldq, (bf16_t*)cache, cache_stride, (const bf16_t*)kv_new, ldkv, mask, ldm, (bf16_t*)out, ldo,
-                 tbl, LT, qkey4, qattr, kkey4, kattr, B, H, pos, scale};
+                 tbl, LT, qkey4, qattr, kkey4, kattr, B, H, pos, scale, pos_dev, qkey4_vec, qattr_vec, nmax};
     hipLaunchKernelGGL(mqa_decode_kernel, dim3(B), dim3(64 * (H < 1 ? 1 : H)), 0, (hipStream_t)stream, a);
     ALM_LAUNCH_CHECK();
     return 0;

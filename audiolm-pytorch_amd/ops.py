@@ -254,22 +254,28 @@ def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, d
     return dq, dkv
 
 
-def mqa_decode_attn(q, cache, kv_new, pos, mask, H, dim_head=64, bias=None):
+def mqa_decode_attn(q, cache, kv_new, pos, mask, H, dim_head=64, bias=None, pos_dev=None):
     """One new position per sequence.  q bf16 [B, H*dh]; cache bf16 [B, Nmax, 2*dh] (k | v); kv_new bf16 [B, 2*dh] (appended at `pos` by the
-    kernel); mask uint8 [B, >= pos+1] | None; bias: relpos.AttnBias whose index vectors cover position `pos` -> out bf16 [B, H*dh]."""
+    kernel); mask uint8 [B, >= pos+1] | None; bias: relpos.AttnBias whose index vectors cover position `pos` -> out bf16 [B, H*dh].
+    pos_dev (int32 device scalar): the kernel reads the position from it instead (hipGraph replay)."""
     _chk(q, BF16), _chk(cache, BF16), _chk(kv_new, BF16)
     B, Nmax = cache.shape[0], cache.shape[1]
     assert cache.is_contiguous() and cache.shape[2] == 2 * dim_head and kv_new.shape == (B, 2 * dim_head) and kv_new.stride(1) == 1
     out = torch.empty((B, H * dim_head), dtype=BF16, device=q.device)
+    qk = qa = 0
+    tb = (None, 0)
+    vecs = (None, None, None, None)
     if bias is not None:
         tbl = _chk(bias.tbl, F32)
-        assert tbl.is_contiguous() and tbl.shape[0] == H
-        b_args = (tbl.data_ptr(), tbl.shape[1], int(bias.qkey4_host[pos]), int(bias.qattr_host[pos]), bias.kkey4.data_ptr(), bias.kattr.data_ptr())
-    else:
-        b_args = (None, 0, 0, 0, None, None)
+        assert tbl.is_contiguous() and tbl.shape[0] == H and bias.kkey4.shape[0] >= Nmax
+        tb = (tbl.data_ptr(), tbl.shape[1])
+        if pos_dev is None:
+            qk, qa = int(bias.qkey4_host[pos]), int(bias.qattr_host[pos])
+        vecs = (bias.kkey4.data_ptr(), bias.kattr.data_ptr(), bias.qkey4.data_ptr(), bias.qattr.data_ptr())
     _lib.call('alm_mqa_decode_attn', q.data_ptr(), q.stride(0), cache.data_ptr(), cache.stride(0), kv_new.data_ptr(), kv_new.stride(0), _p(mask),
               mask.stride(0) if mask is not None else 0, out.data_ptr(), out.stride(0), B, H, dim_head, int(pos), Nmax, float(dim_head) ** -0.5,
-              *b_args, _st())
+              tb[0], tb[1], qk, qa, vecs[0], vecs[1], _p(pos_dev), vecs[2] if pos_dev is not None else None,
+              vecs[3] if pos_dev is not None else None, _st())
     return out
 
 

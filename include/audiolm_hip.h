@@ -191,10 +191,12 @@ int alm_reduce_sum(const float* in, long long n, float* out, float scale, void* 
  * audiolm_pytorch.py:360-394, driven by the generate() loops :1476-1507, :1677-1706, :1965-1994).  cache bf16 [B][nmax][128] (k | v, v already
  * value-residual mixed); kv_new bf16 [B][ldkv] is appended at index `pos` by the call; keys 0 .. pos are attended (mask uint8 [B][ldm], 1 =
  * attend, or NULL).  Structured score bias as in alm_mqa_attn_bias_fwd: tbl [H][LT] + per-key kkey4 / kattr (device) and the new position's
- * qkey4 / qattr BY VALUE; tbl NULL = none. */
+ * qkey4 / qattr BY VALUE; tbl NULL = none.  pos_dev (device int32) non-NULL: the position is read from the device at run time and the
+ * query-side values from qkey4_vec / qattr_vec [nmax] -- the launch a captured hipGraph replays for every sampling step. */
 int alm_mqa_decode_attn(const void* q, long long ldq, void* cache, long long cache_stride, const void* kv_new, long long ldkv,
                         const unsigned char* mask, long long ldm, void* out, long long ldo, int B, int H, int dim_head, int pos, int nmax,
-                        float scale, const float* tbl, int LT, int qkey4, int qattr, const int* kkey4, const int* kattr, void* stream);
+                        float scale, const float* tbl, int LT, int qkey4, int qattr, const int* kkey4, const int* kattr, const int* pos_dev,
+                        const int* qkey4_vec, const int* qattr_vec, void* stream);
 
 /* ---- fused optimiser step: global-norm clip (trainer.py:953-954 accelerator.clip_grad_norm_) + Adam / AdamW (optimizer.py:get_optimizer) over
  * every parameter in two launches.  `tensors`: DEVICE array of AlmOptTensor; `chunks`: DEVICE int32 pairs (tensor index, chunk index), one
