@@ -200,7 +200,7 @@ class RelativePositionBias(nn.Module):                        # audiolm_pytorch.
         """-> relpos.AttnBias: the (2j - 1)-row MLP table (:234-238) kept as a table + the index vectors that replace the gather
         `x[rel_pos]` (:229-241); the (h, i, j) tensor is never built.  special / num_leading: the Coarse cross-attention override (:929-936)."""
         if i != j:
-            raise NotImplementedError('kv-cache inference (i < j) is SURVEY.md §8(f) item 2')
+            raise NotImplementedError('RelativePositionBias(i, j) with i < j (cached decoding) is not used here: sampling builds the table for the full length once')
         dev = self.device
         x = torch.arange(-j + 1, j, device=dev).float().unsqueeze(-1)                             # :234-235
         ws = []
@@ -518,7 +518,7 @@ class _TransformerBase(nn.Module):
         if self.has_condition:
             raise NotImplementedError('classifier-free guidance needs text / audio conditioning (out of scope, SURVEY.md §2 row 12)')
         if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError('kv-cache decoding is SURVEY.md §8(f) item 2: call without caches (the prefix is recomputed)')
+            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         out = self.forward(*args, cond_drop_prob=0., **kwargs)
         if not return_kv_cache:
             return out
@@ -592,7 +592,7 @@ class SemanticTransformer(_TransformerBase):
                 unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
         self._reject_conditioning(text, text_embeds)
         if exists(kv_cache):
-            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         if return_loss:
             ids = ids[:, :-1]                                                                # :706-707 (the reference drops the labels)
         hn, b, N = self._hidden(ids, self_attn_mask)
@@ -700,7 +700,7 @@ class CoarseTransformer(_TransformerBase):
                 return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None):
         self._reject_conditioning(text, text_embeds)
         if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError('kv-cache inference is SURVEY.md §8(f) item 2')
+            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask)
         dev = hn.device
         if exists(labels):                                                                        # fused loss path: (sem_labels, coarse_labels)
