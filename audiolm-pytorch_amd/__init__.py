@@ -10,8 +10,11 @@ from __future__ import annotations
 import sys
 import types
 
-from . import _lib  # noqa: F401  (fails loudly if libaudiolm_hip.so can neither be found nor built)
-from .attend import Attend
+from . import _lib
+
+_lib.load()            # no fallback path exists: fail at import, loudly, if libaudiolm_hip.so can neither be found nor built
+
+from .attend import Attend  # noqa: E402
 from .audiolm_pytorch import (AudioLM, CoarseTransformer, CoarseTransformerWrapper, FineTransformer, FineTransformerWrapper,
                               SemanticTransformer, SemanticTransformerWrapper, Transformer, get_embeds)
 from .optimizer import FusedAdam, get_optimizer

@@ -51,3 +51,22 @@ def test_ops_refuse_cpu_tensors():
     from audiolm_pytorch_amd import ops
     with pytest.raises(_lib.AlmError):
         ops.gemm_nt(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8))
+
+
+def test_import_fails_loudly_without_the_library(tmp_path):
+    """No silent fallback: with the shared library unreachable the package import itself raises (nothing on the product path can run)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ALM_LIB_PATH=str(tmp_path / 'nowhere.so'), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-c', 'import audiolm_pytorch_amd'], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'ImportError' in r.stderr and 'nowhere.so' in r.stderr, r.stderr[-500:]
+
+
+def test_product_modules_do_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import it"""
+    pkg = os.path.join(ROOT, 'audiolm-pytorch_amd')
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
