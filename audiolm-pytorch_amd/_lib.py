@@ -108,6 +108,10 @@ def load(build_if_missing: bool = True):
                 raise ImportError(f'libaudiolm_hip.so is missing and could not be built: {e}') from e
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"`')
+    # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64, and whichever copy enters the process first serves both torch
+    # and this library (same SONAME).  Loaded the other way round, torch ends up on the system runtime it was not built against and every
+    # launch fails with hipErrorNoDevice (seen on MI355X when the package was imported before torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name, None)

@@ -524,3 +524,17 @@ def test_cross_entropy(ops, C):
     d = ops.cross_entropy_bwd(logits, labels, lse, gs, C, Cp)
     assert relmax(d[:, :C], lr.grad) <= 4e-3 and float(d[:, C:].float().abs().max()) == 0.0
     assert float(d[::7].float().abs().max()) == 0.0
+
+
+def test_package_import_before_torch():
+    """Import order must not matter: the package loads torch's bundled HIP runtime before its own library (a process that imported the
+    package first used to fail every launch with hipErrorNoDevice)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import audiolm_pytorch_amd as A\nimport torch\nfrom audiolm_pytorch_amd import ops\n"
+            "x = torch.randn(64, 1024, device='cuda')\nout = ops.layernorm_fwd(x, torch.ones(1024, device='cuda'))\n"
+            "torch.cuda.synchronize()\nassert torch.isfinite(out[0].float()).all()\nprint('import-order-ok')\n")
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'import-order-ok' in r.stdout, (r.stdout[-300:], r.stderr[-800:])
