@@ -588,6 +588,172 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmParams p) {
     }
 }
 
+// ---- NT kernel with the B operand streamed from L2 straight into registers (256x256x64, 8 waves; tiles 8 / 9) ------------------------------
+// The plain 256x256 tile keeps the LDS port as busy as the matrix cores (per 64-deep K-step: 192 KB of fragment reads + 64 KB of DMA writes at
+// 128 B/clk = 2030 cycles vs 2048 MFMA cycles per SIMD), and re-ordering its issue slots does not help.  Here only A goes
+// through the LDS; every lane fetches its own B fragments (row n0 + wc*64 + j*32 + lr, 16-byte k-chunk 2*ks + lh -- exactly the MFMA operand
+// layout, so no shuffle is needed) with buffer_load_dwordx4 one K-step ahead into a second register set.  LDS traffic per K-step: 128 KB of A
+// fragment reads + 32 KB of DMA writes = 160 KB (-38 %); the price is 64 KB per K-step of L2 -> register traffic per CU (the two waves that
+// share a B row block fetch it twice; the second fetch hits the vector L1) and 32 more VGPRs.  Same accumulation order as the plain tile:
+// bit-identical results.  PIPE: A fragment reads of sub-step ks + 1 issued before the MFMAs of sub-step ks (second fragment register set).
+// NEGATIVE RESULT (MI355X, profiles/r1_run12_ab_gemm.log): 22-30 % SLOWER than the plain tile on every shape (W1 fwd 231 vs 179 us, 8192^3
+// 1197 vs 832 us), plain and pipelined loop alike -- so the limit moved from the LDS to the vector-memory path: the MFMA operand layout gives
+// a row only 2 lanes, i.e. every buffer_load_dwordx4 touches 32 cache lines for 32 bytes each (~32 tag cycles instead of 16 data cycles),
+// 8 loads x 8 waves = 2048 cycles per K-step before the A DMA is counted.  Kept selectable (tiles 8 / 9) and tested; not used.
+template <bool OUT_F32, bool PIPE>
+__global__ __launch_bounds__(512) void gemm_nt_bdirect_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int TM = 4, TNB = 2, NIA = 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int m0, n0;
+    {
+        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM;
+        n0 = ((bid % per_group) / gsz) * BN;
+    }
+    const int zb = blockIdx.y;
+    const int z1 = zb / p.nb2, z2 = zb % p.nb2;
+    const long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
+    const long long coff0 = z1 * p.sC1 + z2 * p.sC2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const bf16_t* Ab = p.A + zoffA + (long long)m0 * p.lda;
+    const bf16_t* Bb = p.B + zoffB + (long long)n0 * p.ldb;
+    const long long extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2;
+    const long long extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + p.K) * 2;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)min(extA, 0x7fffffffLL), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)min(extB, 0x7fffffffLL), 0x00020000);
+
+    unsigned offA[NIA], offBd[TNB];
+    int kc;                                                     // K coordinate (within a stage) of this lane's DMA pieces
+    {
+        const int row0 = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row0 >> 1) & 7);           // (row >> 1) & 7 is the same for every piece of a lane (pieces are 64 rows apart)
+        kc = c * 8;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) offA[j] = (unsigned)(((j * NW + wave) * 8 + (lane >> 3)) * p.lda * 2 + c * 16);
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) offBd[j] = (unsigned)((wc * 64 + j * 32 + lr) * p.ldb * 2 + lh * 16);
+    }
+    unsigned fragA[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((wr * 128 + i * 32 + lr) * 128);
+    const unsigned sw = (unsigned)((lr >> 1) & 7);
+
+    auto stage_a = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * A_BYTES;
+        const bool kok = kc < p.K - kt * BK;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, kok ? offA[j] : OOB, kt * (BK * 2), 0, 0);
+    };
+    bf16x8 bq[2][TNB][4];                                       // B fragments of two K-steps: [set][32-column block][sub-step]
+    auto load_b = [&](int kt, auto setc) {
+        constexpr int st = decltype(setc)::value;
+        const int kleft = p.K - kt * BK;
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned vo = ((ks * 2 + lh) * 8 < kleft) ? offBd[j] + ks * 32 : OOB;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, kt * (BK * 2), 0);
+                bq[st][j][ks] = __builtin_bit_cast(bf16x8, raw);
+            }
+    };
+    bf16x8 a[2][TM];
+    auto load_a = [&](const unsigned char* sb, int ks, auto fbc) {
+        constexpr int fb = decltype(fbc)::value;
+        const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[fb][i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+    };
+    f32x16 acc[TM][TNB];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfmas = [&](auto fbc, auto setc, auto ksc) {
+        constexpr int fb = decltype(fbc)::value, st = decltype(setc)::value, ks = decltype(ksc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[st][j][ks], a[fb][i], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    const int nk = (p.K + BK - 1) / BK;
+    int buf = 0;
+    stage_a(0, 0);
+    load_b(0, I0{});
+    __syncthreads();
+    if (PIPE) load_a(smem, 0, I0{});
+    auto kstep = [&](int kt, auto cur, auto nxt) {
+        // UNCONDITIONAL prefetch (beyond the last K-step every offset is out of bounds: zeros, no traffic): with an `if` around it the
+        // compiler has to place s_waitcnt for the path WITHOUT the new loads, i.e. vmcnt(7) instead of vmcnt(19), which makes the MFMAs of
+        // this K-step wait for the loads issued a moment ago
+        stage_a(kt + 1, buf ^ 1);
+        load_b(kt + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch at the top of the K-step (the scheduler otherwise sinks it to the end)
+        const unsigned char* sb = smem + buf * A_BYTES;
+        if (PIPE) {
+            load_a(sb, 1, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{}, cur, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(sb, 2, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{}, cur, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(sb, 3, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{}, cur, I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                   // reads of `buf` done, next stage (DMA + B registers) landed, all waves agree
+            buf ^= 1;
+            load_a(smem + buf * A_BYTES, 0, I0{});               // (after the last K-step: zeros, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{}, cur, I3{});
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            load_a(sb, 0, I0{});
+            mfmas(I0{}, cur, I0{});
+            load_a(sb, 1, I0{});
+            mfmas(I0{}, cur, I1{});
+            load_a(sb, 2, I0{});
+            mfmas(I0{}, cur, I2{});
+            load_a(sb, 3, I0{});
+            mfmas(I0{}, cur, I3{});
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        kstep(kt, I0{}, I1{});
+        if (kt + 1 < nk) kstep(kt + 1, I1{}, I0{});
+    }
+    static_assert(NW * 32 * (32 * TNB * (OUT_F32 ? 4 : 2)) <= 2 * A_BYTES, "epilogue slab");
+    gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+}
+
 // ---- balanced-split second stage: C tile = sum of its workspace slots [tile_first[t], tile_first[t+1]) (in K order: deterministic).
 // grid (tiles, BM / 16): a block sums 16 rows of one tile, 64 threads (float4 each) per row.
 template <int BM, int BN>
@@ -753,7 +919,7 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU), 3 = 256x128 with a 3-stage DMA ring (8 waves)
 int pick_tile(int M, int N, int ny, int tile) {
-    if (tile >= 1 && tile <= 7) return tile;
+    if (tile >= 1 && tile <= 9) return tile;
     if (M < 256 || N < 256) return 1;
     const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
     return big >= 192 ? 2 : 1;              // enough 256^2 tiles to occupy most of the 256 CUs
@@ -774,6 +940,14 @@ int launch_persist(const GemmParams& p, int ny, hipStream_t st) {
     return 0;
 }
 
+template <bool OUT_F32, bool PIPE>
+int launch_bdirect(const GemmParams& p, int ny, hipStream_t st) {
+    constexpr int smem = 2 * 256 * BK * 2;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_nt_bdirect_kernel<OUT_F32, PIPE>), dim3(tiles, ny), dim3(512), smem, st, p);
+    return 0;
+}
+
 template <bool TNMODE>
 int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
     int tl = pick_tile(p.M, p.N, ny * nz, tile);
@@ -782,6 +956,11 @@ int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipS
     if (tl == 4) {
         if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0) return ALM_ERR_UNSUPPORTED;
         return out_f32 ? launch_persist<true>(p, ny, st) : launch_persist<false>(p, ny, st);
+    }
+    if (tl == 8 || tl == 9) {                      // B operand streamed into registers (NT only): 8 = plain loop, 9 = pipelined A fragment reads
+        if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0 || p.units) return ALM_ERR_UNSUPPORTED;
+        if (tl == 8) return out_f32 ? launch_bdirect<true, false>(p, ny, st) : launch_bdirect<false, false>(p, ny, st);
+        return out_f32 ? launch_bdirect<true, true>(p, ny, st) : launch_bdirect<false, true>(p, ny, st);
     }
     if (tl == 5) return ALM_ERR_UNSUPPORTED;       // 4 waves x (128 x 128) with the plain loop: measured 10-20 % slower than tile 2, superseded by tile 6
     if (tl == 6 || tl == 7) {                      // hand software-pipelined main loop (NT only): 6 = 4 waves x (128 x 128), 7 = 8 waves x (128 x 64)
