@@ -11,10 +11,15 @@ backward.  It is not a general DDP replacement.
   * parameters that never receive a gradient (proj_text_embed -- the reason the reference needs find_unused_parameters=True,
     trainer.py:75) are simply never bucketed; DDP's per-forward buffer broadcast is skipped (only constant zero `beta` buffers exist)
   * `finish()` must be called after backward(): it waits for the collectives and writes the averaged gradients back into p.grad
+  * gradient accumulation (trainer.py:1237 `no_sync`): `with engine.no_sync():` micro-steps only accumulate locally; the next synchronising
+    step then reduces the ACCUMULATED p.grad in `finish()` (bucketed per layer, not overlapped: the fresh per-layer gradients handed to the
+    callback are only that micro-step's share)
 
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 
@@ -52,6 +57,20 @@ class DataParallelEngine:
             if id(p) not in self._stack_param_ids or (self._stack is not None and p is self._stack_flat[-1]):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_loose_grad))
         self._n_loose_heads = None
+        self._sync = True                     # False inside no_sync()
+        self._dirty = False                   # p.grad holds local, not yet reduced micro-step gradients
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient-accumulation micro-steps: backward() + finish() inside this context exchange nothing."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
+    def _overlapped(self):
+        return self._sync and not self._dirty
 
     # ---- bucket launch -------------------------------------------------------------------------------------------
     def _launch(self, key, params, grads):
@@ -72,13 +91,16 @@ class DataParallelEngine:
 
     def _on_layer_grads(self, layer, grads):
         """core.stack_backward callback: `grads` are the fresh gradients of layer `layer` (order == Transformer.flat_params)."""
+        if not self._overlapped():
+            return
         self._flush_loose(('loose', 'pre', layer))       # whatever accumulated so far (logit heads, final norm) goes first
         params = self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl]
         pg = [(p, g) for p, g in zip(params, grads) if g is not None and p.requires_grad]
         self._launch(('layer', layer), [p for p, _ in pg], [g for _, g in pg])
 
     def _on_loose_grad(self, p):
-        self._loose.params.append(p)
+        if self._overlapped():
+            self._loose.params.append(p)
 
     def _flush_loose(self, key):
         if self._loose.params:
@@ -89,6 +111,22 @@ class DataParallelEngine:
     # ---- end of backward ------------------------------------------------------------------------------------------
     def finish(self):
         """Call after loss.backward(): waits for every in-flight all-reduce and stores the mean gradients in p.grad."""
+        if not self._sync:
+            self._dirty = True
+            return
+        if self._dirty:                                               # accumulated micro-steps: reduce p.grad itself, layer by layer
+            self._dirty = False
+            groups = []
+            if self._stack is not None:
+                loose = [p for p in self.params if id(p) not in self._stack_param_ids or p is self._stack_flat[-1]]
+                groups.append(('acc', 'loose', loose))
+                for layer in reversed(range(self._stack.depth)):
+                    groups.append(('acc', layer, self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl]))
+            else:
+                groups.append(('acc', 'all', self.params))
+            for *key, params in groups:
+                ps = [p for p in params if p.requires_grad and p.grad is not None]
+                self._launch(tuple(key), ps, [p.grad for p in ps])
         self._flush_loose(('loose', 'post'))
         for b, op in self._inflight:
             b.work.wait()

@@ -69,6 +69,68 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_accum(rank, world, port, out):
+    """two micro-steps: the first inside no_sync(), the second synchronising -> mean over ranks of the SUM of both micro-step gradients"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(99)
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    ids_all = torch.arange(24).reshape(4, 6) % 10                  # rows 0, 1: micro-step 0 of ranks 0, 1; rows 2, 3: micro-step 1
+    flat = model.transformer.flat_params()
+
+    def micro(ids):
+        before = [None if p.grad is None else p.grad.clone() for p in flat]
+        _loss(model, ids).backward()
+        for l in reversed(range(model.transformer.depth)):
+            fresh = [p.grad - b if b is not None else p.grad.clone() for p, b in zip(flat[l * 2:(l + 1) * 2], before[l * 2:(l + 1) * 2])]
+            eng._on_layer_grads(l, fresh)
+        eng.finish()
+    with eng.no_sync():
+        micro(ids_all[rank:rank + 1])
+    micro(ids_all[2 + rank:3 + rank])
+    assert not eng._inflight and not eng._dirty
+    # a following ordinary step must take the overlapped path again
+    for p in model.parameters():
+        p.grad = None
+    micro(ids_all[rank:rank + 1])
+    g3 = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    with eng.no_sync():
+        micro(ids_all[rank:rank + 1])
+    micro(ids_all[2 + rank:3 + rank])
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().clone() for k, v in model.state_dict().items()}, grads=grads, g3=g3, ids=ids_all), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_gradient_accumulation_no_sync(tmp_path):
+    out = str(tmp_path / 'acc.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_accum, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    ids = r['ids']
+    ((_loss(model, ids[0:1]) + _loss(model, ids[1:2])) / 2 + (_loss(model, ids[2:3]) + _loss(model, ids[3:4])) / 2).backward()
+    for k, p in model.named_parameters():
+        if k == 'unused':
+            assert r['grads'][k] is None
+            continue
+        assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
+    model.zero_grad()
+    ((_loss(model, ids[0:1]) + _loss(model, ids[1:2])) / 2).backward()
+    for k, p in model.named_parameters():
+        if k != 'unused':
+            assert torch.allclose(r['g3'][k], p.grad, atol=1e-6), k
+
+
 def test_dp_engine_world2_matches_big_batch(tmp_path):
     out = str(tmp_path / 'r0.pt')
     port = 29500 + (os.getpid() % 2000)
