@@ -255,8 +255,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const bf16_t* Bb;
     long long extA, extB;
     if (!TNMODE) {
+#if defined(ALM_GEMM_WHATIF) && (ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7)
+        Ab = p.A + zoffA + kbeg;
+        Bb = p.B + zoffB + kbeg;
+#else
         Ab = p.A + zoffA + (long long)m0 * p.lda + kbeg;
         Bb = p.B + zoffB + (long long)n0 * p.ldb + kbeg;
+#endif
         extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + Krem) * 2;
         extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + Krem) * 2;
     } else {
@@ -432,14 +437,50 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             if (STAGES == 3) {
                 if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);       // (kt + 2) % 3: the buffer read during step kt - 1
             } else {
+#if defined(ALM_GEMM_WHATIF) && (ALM_GEMM_WHATIF == 3 || ALM_GEMM_WHATIF == 8)      // no DMA after the first stage
+                if (kt + 1 < nk && kt < 0) stage(kt + 1, buf ^ 1);
+#else
                 if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+#endif
             }
             const unsigned char* sb = smem + buf * STAGE;
+#ifdef ALM_GEMM_WHATIF      // diagnostic builds (WRONG results; scripts/ab_gemm.py): which resource bounds the main loop
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#if ALM_GEMM_WHATIF == 1        // no B fragment reads
+                if (kt == 0 && ks == 0) load_frags(sb, ks, FB0{});
+                else {
+                    const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+                }
+                mfmas(FB0{});
+#elif ALM_GEMM_WHATIF == 2 || ALM_GEMM_WHATIF == 8      // no fragment reads at all (8: and no DMA: MFMA issue + barriers only)
+                if (kt == 0 && ks == 0) load_frags(sb, ks, FB0{});
+                mfmas(FB0{});
+#elif ALM_GEMM_WHATIF == 5 || ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7     // DMA only (6: every workgroup fetches tile (0, 0): all L2 hits; 7: MFMA + DMA, no fragment reads, tile (0, 0))
+#if ALM_GEMM_WHATIF == 7
+                if (kt == 0 && ks == 0) load_frags(sb, ks, FB0{});
+                mfmas(FB0{});
+#endif
+#elif ALM_GEMM_WHATIF == 4      // no MFMAs
+                load_frags(sb, ks, FB0{});
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(a[0][i]));
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) asm volatile("" ::"v"(b[0][j]));
+#else
+                load_frags(sb, ks, FB0{});
+                mfmas(FB0{});
+#endif
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 load_frags(sb, ks, FB0{});
                 mfmas(FB0{});
             }
+#endif
             if (STAGES == 3) {
                 // this wave's LDS reads of the step are complete (their results fed the MFMAs above); step kt+1's DMA must have landed,
                 // step kt+2's (just issued) may stay in flight
