@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const bf16_t* Bb;
     long long extA, extB;
     if (!TNMODE) {
-#if defined(ALM_GEMM_WHATIF) && (ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7)
+#if defined(ALM_GEMM_WHATIF) && (ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7 || ALM_GEMM_WHATIF == 9 || ALM_GEMM_WHATIF == 10)
         Ab = p.A + zoffA + kbeg;
         Bb = p.B + zoffB + kbeg;
 #else
@@ -315,6 +315,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     auto stage = [&](int kt, int buf) {
         unsigned char* base = smem + buf * STAGE;
         const int kleft = Krem - kt * BK;
+#if defined(ALM_GEMM_WHATIF) && ALM_GEMM_WHATIF == 9
+#pragma unroll
+        for (int j = 0; j < NIA + NIB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+        return;
+#elif defined(ALM_GEMM_WHATIF) && ALM_GEMM_WHATIF == 10
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) { u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[j], kt * kstepA, 0); asm volatile("" ::"v"(v)); }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) { u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[j], kt * kstepB, 0); asm volatile("" ::"v"(v)); }
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
@@ -325,6 +338,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
         }
+    };
+
+    // one quarter of a stage (STAGES == 2, NT: NIA == NIB == 4 on the 8-wave tile): piece j of A and piece j of B.  Issued one quarter per
+    // sub-step, the DMA instructions queue up behind the memory pipeline while this wave's MFMAs run, instead of blocking the wave's
+    // in-order issue for the whole burst at the top of the K-step
+    auto stage_part = [&](int kt, int buf, int j0, int j1) {
+        unsigned char* base = smem + buf * STAGE;
+        const int kleft = Krem - kt * BK;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j)
+            if (j >= j0 && j < j1) {
+                const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j)
+            if (j >= j0 && j < j1) {
+                const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
+            }
     };
 
     // ---- fragment read addresses (bytes, within a stage) -------------------------------------------------------------------
@@ -439,6 +472,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             } else {
 #if defined(ALM_GEMM_WHATIF) && (ALM_GEMM_WHATIF == 3 || ALM_GEMM_WHATIF == 8)      // no DMA after the first stage
                 if (kt + 1 < nk && kt < 0) stage(kt + 1, buf ^ 1);
+#elif defined(ALM_GEMM_SPREAD)
+                // issued in quarters inside the sub-step loop below
 #else
                 if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
 #endif
@@ -458,8 +493,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 #elif ALM_GEMM_WHATIF == 2 || ALM_GEMM_WHATIF == 8      // no fragment reads at all (8: and no DMA: MFMA issue + barriers only)
                 if (kt == 0 && ks == 0) load_frags(sb, ks, FB0{});
                 mfmas(FB0{});
-#elif ALM_GEMM_WHATIF == 5 || ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7     // DMA only (6: every workgroup fetches tile (0, 0): all L2 hits; 7: MFMA + DMA, no fragment reads, tile (0, 0))
-#if ALM_GEMM_WHATIF == 7
+#elif ALM_GEMM_WHATIF == 5 || ALM_GEMM_WHATIF == 6 || ALM_GEMM_WHATIF == 7 || ALM_GEMM_WHATIF == 9 || ALM_GEMM_WHATIF == 10     // (9: as 7, DMA sources confined to 1 KB = L1 hits; 10: as 7, plain register loads instead of the LDS DMA)
+                // DMA only (6: every workgroup fetches tile (0, 0): all L2 hits; 7: MFMA + DMA, no fragment reads, tile (0, 0))
+#if ALM_GEMM_WHATIF == 7 || ALM_GEMM_WHATIF == 9 || ALM_GEMM_WHATIF == 10
                 if (kt == 0 && ks == 0) load_frags(sb, ks, FB0{});
                 mfmas(FB0{});
 #endif
@@ -473,6 +509,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
                 load_frags(sb, ks, FB0{});
                 mfmas(FB0{});
 #endif
+            }
+#elif defined(ALM_GEMM_SPREAD)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                load_frags(sb, ks, FB0{});
+                if (STAGES == 2 && kt + 1 < nk) stage_part(kt + 1, buf ^ 1, ks * NIA / 4, (ks + 1) * NIA / 4);
+                mfmas(FB0{});
             }
 #else
 #pragma unroll
@@ -795,6 +838,136 @@ __global__ __launch_bounds__(512) void gemm_nt_bdirect_kernel(GemmParams p) {
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
 }
 
+// ---- NT kernels with a deep DMA ring (32-deep K-steps, NST stages; tile 10: 256x256 / 8 waves / 4 x 32 KB, tile 12: 256x128 / 4 waves /
+// 3 x 24 KB with two workgroups per CU) ---------------------------------------------------------------------------------------------------
+// Built to test "the 2-stage loop is latency-bound on the operand fetch": NST - 1 stages in flight, a COUNTED s_waitcnt (only the stage about
+// to be read), one s_barrier per K-step that both publishes that stage and frees the buffer read in the previous K-step, which is refilled
+// at once.  LDS image: [row][32 k] (64-byte rows); the DMA destination is lane-linear (16 rows x 64 B per instruction), so the
+// conflict-avoiding swizzle slot ^= (row >> 2) & 3 is applied to the source chunk and again on the ds_read_b128 fragment reads (16
+// consecutive rows x one chunk = 16 distinct 16-byte bank groups).  The prefetch is unconditional (beyond K every offset is out of bounds:
+// zeros, no traffic) so the vmcnt accounting is uniform.  Same accumulation order as the 2-stage tile: bit-identical results.
+// NEGATIVE RESULT (MI355X, profiles/r1_run15_ab_gemm_ring.log): tile 10 is 2-5 % SLOWER than the 2-stage tile (4 and 5 stages alike: prefetch
+// depth is not the limit), tile 12 25-30 % slower (1.5x the L2 -> LDS bytes per flop).  Together with the what-if builds this says the
+// operand fetch is a THROUGHPUT cost that only partly overlaps the MFMAs -- fewer bytes per flop is the lever, not more stages.
+template <bool OUT_F32, int NST, int BN, int WN>
+__global__ __launch_bounds__(2 * WN * 64) void gemm_nt_ring_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the host pass needs the stub only (and drops the stub silently when it instantiates this body)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int BM = 256, WM = 2, NW = WM * WN, KB = 32;
+    constexpr int A_BYTES = BM * KB * 2, B_BYTES = BN * KB * 2, STAGE = A_BYTES + B_BYTES;      // 16 KB + 16 KB (BN = 256) / 16 KB + 8 KB (BN = 128)
+    constexpr int TM = 4, TNB = 2, NIA = BM * KB * 2 / 1024 / NW, NIB = BN * KB * 2 / 1024 / NW;   // DMA pieces per wave per stage
+    constexpr int DIST = NST - 1;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int m0, n0;
+    {
+        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (bid % per_group) % gsz) * BM;
+        n0 = ((bid % per_group) / gsz) * BN;
+    }
+    const int zb = blockIdx.y;
+    const int z1 = zb / p.nb2, z2 = zb % p.nb2;
+    const long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
+    const long long coff0 = z1 * p.sC1 + z2 * p.sC2;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const bf16_t* Ab = p.A + zoffA + (long long)m0 * p.lda;
+    const bf16_t* Bb = p.B + zoffB + (long long)n0 * p.ldb;
+    const long long extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + p.K) * 2;
+    const long long extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + p.K) * 2;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)min(extA, 0x7fffffffLL), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)min(extB, 0x7fffffffLL), 0x00020000);
+
+    unsigned offA[NIA], offB[NIB];
+    int kc;                                                     // K coordinate (within a stage) of this lane's chunk
+    {
+        const int r0 = lane >> 2;                               // row within a 16-row piece
+        const int c = (lane & 3) ^ ((r0 >> 2) & 3);             // pieces start at multiples of 16 rows: (row >> 2) & 3 == (r0 >> 2) & 3
+        kc = c * 8;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) offA[j] = (unsigned)(((j * NW + wave) * 16 + r0) * p.lda * 2 + c * 16);
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) offB[j] = (unsigned)(((j * NW + wave) * 16 + r0) * p.ldb * 2 + c * 16);
+    }
+    unsigned fragA[TM], fragB[TNB];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((wr * 128 + i * 32 + lr) * 64);
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) fragB[j] = (unsigned)(A_BYTES + (wc * 64 + j * 32 + lr) * 64);      // wave tile 128 x 64 in both geometries
+    const unsigned sw = (unsigned)((lr >> 2) & 3);
+
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * STAGE;
+        const bool kok = kc < p.K - kt * KB;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, kok ? offA[j] : OOB, kt * (KB * 2), 0, 0);
+#pragma unroll
+        for (int j = 0; j < NIB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, kok ? offB[j] : OOB, kt * (KB * 2), 0, 0);
+    };
+
+    f32x16 acc[TM][TNB];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + KB - 1) / KB;
+#pragma unroll
+    for (int s0 = 0; s0 < DIST; ++s0) stage(s0, s0);
+    int buf = 0, fill = DIST;                                   // fill: the buffer stage kt + DIST goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most (DIST - 1) * 2 * NI of this wave's DMA instructions are still in flight
+        constexpr int INFLIGHT = (DIST - 1) * (NIA + NIB);
+        static_assert(INFLIGHT == 0 || INFLIGHT == 6 || INFLIGHT == 8 || INFLIGHT == 12 || INFLIGHT == 16 || INFLIGHT == 18, "add the literal");
+        if constexpr (INFLIGHT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (INFLIGHT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (INFLIGHT == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#if defined(ALM_GEMM_WHATIF) && ALM_GEMM_WHATIF == 8        // MFMA + fragment reads + barriers, no DMA in the loop
+        if (kt < 0)
+#endif
+        stage(kt + DIST, fill);
+        fill = fill + 1 == NST ? 0 : fill + 1;
+        const unsigned char* sb = smem + buf * STAGE;
+        buf = buf + 1 == NST ? 0 : buf + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TM], b[TNB];
+            const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the (zero-filling) prefetches beyond K target the buffers the epilogue reuses
+    __syncthreads();
+    static_assert(NW * 32 * (32 * TNB * (OUT_F32 ? 4 : 2)) <= NST * STAGE, "epilogue slab");
+    gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+#endif
+}
+
 // ---- balanced-split second stage: C tile = sum of its workspace slots [tile_first[t], tile_first[t+1]) (in K order: deterministic).
 // grid (tiles, BM / 16): a block sums 16 rows of one tile, 64 threads (float4 each) per row.
 template <int BM, int BN>
@@ -960,7 +1133,7 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
 
 // tile: 0 = auto, 1 = 128x128 (4 waves, 2 blocks / CU), 2 = 256x256 (8 waves, 1 block / CU), 3 = 256x128 with a 3-stage DMA ring (8 waves)
 int pick_tile(int M, int N, int ny, int tile) {
-    if (tile >= 1 && tile <= 9) return tile;
+    if (tile >= 1 && tile <= 13) return tile;
     if (M < 256 || N < 256) return 1;
     const long long big = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
     return big >= 192 ? 2 : 1;              // enough 256^2 tiles to occupy most of the 256 CUs
@@ -989,6 +1162,21 @@ int launch_bdirect(const GemmParams& p, int ny, hipStream_t st) {
     return 0;
 }
 
+template <bool OUT_F32, int NST, int BNX, int WNX>
+int launch_ring(const GemmParams& p, int ny, hipStream_t st) {
+    constexpr int smem = NST * (256 + BNX) * 32 * 2;
+    static bool attr_done = false;
+    void (*kfn)(GemmParams) = &gemm_nt_ring_kernel<OUT_F32, NST, BNX, WNX>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + BNX - 1) / BNX);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<OUT_F32, NST, BNX, WNX>), dim3(tiles, ny), dim3(2 * WNX * 64), smem, st, p);
+    return 0;
+}
+
 template <bool TNMODE>
 int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st) {
     int tl = pick_tile(p.M, p.N, ny * nz, tile);
@@ -998,6 +1186,13 @@ int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipS
         if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0) return ALM_ERR_UNSUPPORTED;
         return out_f32 ? launch_persist<true>(p, ny, st) : launch_persist<false>(p, ny, st);
     }
+    if (tl == 10 || tl == 12) {                    // deep DMA ring, 32-deep K-steps (NT only): 10 = 256 x 256 on 8 waves, 4 stages;
+                                                   // 12 = 256 x 128 on 4 waves, 3 stages, TWO workgroups per CU
+        if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0 || p.units) return ALM_ERR_UNSUPPORTED;
+        if (tl == 10) return out_f32 ? launch_ring<true, 4, 256, 4>(p, ny, st) : launch_ring<false, 4, 256, 4>(p, ny, st);
+        return out_f32 ? launch_ring<true, 3, 128, 2>(p, ny, st) : launch_ring<false, 3, 128, 2>(p, ny, st);
+    }
+    if (tl == 11 || tl == 13) return ALM_ERR_UNSUPPORTED;
     if (tl == 8 || tl == 9) {                      // B operand streamed into registers (NT only): 8 = plain loop, 9 = pipelined A fragment reads
         if (TNMODE || nz != 1 || p.ksplit > 0 || p.raster != 0 || p.units) return ALM_ERR_UNSUPPORTED;
         if (tl == 8) return out_f32 ? launch_bdirect<true, false>(p, ny, st) : launch_bdirect<false, false>(p, ny, st);

@@ -32,7 +32,8 @@ int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, i
 /* tile-selectable, un-batched form of alm_gemm_bf16_nt (tuning / benchmarks): tile 0 = auto, 1 = 128x128x64 (4 waves),
  * 2 = 256x256x64 (8 waves; the production tile), 3 = 256x128 with a 3-stage DMA ring, 4 = persistent 256x256, 6 / 7 = 256x256 with the
  * hand software-pipelined main loop on 4 / 8 waves, 8 / 9 = 256x256 with the B operand streamed from L2 into registers (plain / pipelined
- * A fragment reads) (3-9: measured experiments). */
+ * A fragment reads), 10 / 12 = 32-deep K-steps with a 4- / 3-stage DMA ring (256x256 on 8 waves / 256x128 on 4 waves, two workgroups per CU)
+ * (3-12: measured experiments). */
 int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                           long long ldc, float alpha, int out_f32, int accumulate, int tile, void* stream);
 /* split-K forms for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * op(A) . op(B),

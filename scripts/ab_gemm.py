@@ -1,7 +1,7 @@
 """A/B of GEMM main-loop variants in ONE process: the production library against alternative builds of csrc/gemm.hip
 (any `scripts/ubench/bin/libgemm_v*.so`, e.g. `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -D<switch> -o scripts/ubench/bin/libgemm_v1.so
 csrc/gemm.hip`), for every tile id given.  The libraries are timed round-robin on the same buffers, so clock
-ramps and box-to-box differences cancel.  Usage: python scripts/ab_gemm.py [tile ...]   (default tiles: 2 7 8 9)
+ramps and box-to-box differences cancel.  Usage: python scripts/ab_gemm.py [tile ...]   (default tiles: 2 7 10 12)
 """
 import ctypes
 import glob
@@ -27,7 +27,7 @@ def bind(path):
 
 
 def main():
-    tiles = [int(a) for a in sys.argv[1:]] or [2, 7, 8, 9]
+    tiles = [int(a) for a in sys.argv[1:]] or [2, 7, 10, 12]
     libs = [('prod', _lib.load())] + [(os.path.basename(p)[3:-3], bind(p)) for p in sorted(glob.glob(os.path.join(ROOT, 'scripts/ubench/bin/libgemm_v*.so')))]
     T = 16384
     shapes = [('W1 fwd', T, 5472, 1024), ('W2 fwd', T, 1024, 2736), ('dHN dgrad', T, 2736, 1024), ('dXN2 dgrad', T, 1024, 5472), ('square 8192', 8192, 8192, 8192)]

@@ -49,7 +49,7 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 6, 7, 8, 9, 10, 12])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192), (1536, 5472, 128), (4096, 2736, 192)])
 def test_gemm_nt_tile_configs(ops, M, N, K, tile):
     """every block-tile configuration (128x128x64 / 4 waves, 256x256x64 / 8 waves, 256x128x64 with the 3-stage counted-vmcnt DMA ring: 1, 2, 3
