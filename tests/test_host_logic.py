@@ -85,6 +85,31 @@ def test_semantic_wrapper_bookkeeping_bit_exact():
     assert torch.equal(seen['kwargs']['ids'], inp_ids) and torch.equal(seen['kwargs']['labels'], labels)
 
 
+def test_fine_wrapper_bookkeeping_bit_exact():
+    """FineTransformerWrapper.forward (audiolm_pytorch.py:2041-2137): flatten, labels = (coarse, fine) un-shifted, fine input [:, :-1],
+    forgetful mask of width nc + nf_in + 2, no eos appended, ids stay int64."""
+    fx = _load('fine_s1_bias_mask')
+    model = A.FineTransformer(**fx['ctor'])
+    seen = _capture(model)
+    w = A.FineTransformerWrapper(transformer=model, codec=Codec(), mask_prob=0.15)
+    w.train()
+    inp = fx['inputs']
+    orig = AP.generate_mask_with_prob
+    AP.generate_mask_with_prob = lambda shape, prob, device: inp['forgetful_mask'].clone()
+    try:
+        w(coarse_token_ids=inp['coarse_token_ids'], fine_token_ids=inp['fine_token_ids'], return_loss=True)
+    finally:
+        AP.generate_mask_with_prob = orig
+    b = inp['coarse_token_ids'].shape[0]
+    coarse, fine = inp['coarse_token_ids'].reshape(b, -1), inp['fine_token_ids'].reshape(b, -1)
+    k = seen['kwargs']
+    assert torch.equal(k['coarse_token_ids'], coarse) and torch.equal(k['fine_token_ids'], fine[:, :-1])
+    assert torch.equal(k['labels'][0], coarse) and torch.equal(k['labels'][1], fine)
+    assert torch.equal(k['self_attn_mask'], inp['forgetful_mask'])
+    assert k['self_attn_mask'].shape == (b, coarse.shape[1] + fine.shape[1] - 1 + 2)
+    assert k['coarse_token_ids'].dtype == torch.int64 and k['fine_token_ids'].dtype == torch.int64
+
+
 @pytest.mark.parametrize('B,N,start,n,Q', [(3, 40, 5, 22, 3), (2, 33, 0, 33, 1), (2, 50, 10, 40, 5), (1, 20, 3, 7, 3)])
 def test_head_regrouping_equals_reference_einsum(B, N, start, n, Q):
     """'q c d, b n q d -> b n q c' + remainder with W[:r] (audiolm_pytorch.py:965-983)  ==  per-quantizer row gather + matmul."""
