@@ -15,7 +15,8 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
                                                token over a per-layer k/v cache (core.DecodeCache, alm_mqa_decode_attn); sampling helpers in torch
 
 Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning (so no classifier-free
-guidance), the reference's kv_cache= / embed_cache= tensor arguments, waveform reconstruction (SoundStream decoder), dense `attn_bias` tensors.
+guidance), the reference's kv_cache= / embed_cache= tensor arguments (the native sampling cache replaces them), dense `attn_bias` tensors.
+Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
 from __future__ import annotations
@@ -346,7 +347,8 @@ class Transformer(nn.Module):
     def forward(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, return_kv_cache=False, kv_cache=None,
                 return_flat_hidden=False):
         if exists(context) or exists(kv_cache):
-            raise NotImplementedError('conditioning / kv-cache inference are out of scope this round (SURVEY.md §8(f))')
+            raise NotImplementedError('a conditioning context is out of scope (SURVEY.md §2 row 12), and the reference kv_cache tensor is not accepted: '
+                                      'the native sampling cache is driven through sample_logits() / generate()')
         if not x.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
         b, n, d = x.shape
