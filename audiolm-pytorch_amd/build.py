@@ -25,18 +25,38 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _fresh(dig: str) -> bool:
+    return os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+    if not force and _fresh(dig):
         return LIB
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value', '-o', LIB] + srcs
-    if verbose:
-        print('[audiolm_pytorch_amd] building', os.path.basename(LIB), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    with open(STAMP, 'w') as fh:
-        fh.write(dig)
+    # one builder at a time (N ranks of a torch.distributed.run launch import the package concurrently): exclusive lock, re-check, compile
+    # into a temporary file and rename it into place, so that no process can ever dlopen a half-written library
+    import fcntl
+    with open(os.path.join(HERE, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _fresh(dig):
+                return LIB
+            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+            srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+            tmp = LIB + f'.tmp{os.getpid()}'
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value', '-o', tmp] + srcs
+            if verbose:
+                print('[audiolm_pytorch_amd] building', os.path.basename(LIB), file=sys.stderr)
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            with open(STAMP, 'w') as fh:
+                fh.write(dig)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
