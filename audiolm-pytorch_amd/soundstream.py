@@ -282,17 +282,26 @@ class SoundStream(nn.Module):
         return self.forward(audio, return_codes_only=True)
 
     @torch.no_grad()
-    def forward(self, x, target=None, is_denoising=None, return_encoded=False, return_codes_only=False, input_sample_hz=None,
-                curtail_from_left=False, **kwargs):
-        if target is not None or is_denoising is not None or not (return_encoded or return_codes_only) or any(kwargs.values()):
-            raise NotImplementedError('only forward(..., return_encoded=True) / return_codes_only=True (the tokenize path) is implemented')
-        x, _ = self.process_input(x, input_sample_hz=input_sample_hz, curtail_from_left=curtail_from_left)
+    def forward(self, x, target=None, is_denoising=None, return_encoded=False, return_codes_only=False, return_discr_loss=False,
+                return_discr_losses_separately=False, return_loss_breakdown=False, return_recons_only=False, input_sample_hz=None,
+                apply_grad_penalty=False, curtail_from_left=False):
+        """The eval-mode branches of soundstream.py:802-862 (same positional order): return_codes_only -> indices (g, b, n, q);
+        return_encoded -> (quantized, indices 'b n (g q)', commit_loss); return_recons_only -> the reconstructed wave.  The training
+        branches (discriminators, losses) are out of scope."""
+        if target is not None or is_denoising is not None or return_discr_loss or return_discr_losses_separately or return_loss_breakdown \
+                or apply_grad_penalty or not (return_encoded or return_codes_only or return_recons_only):
+            raise NotImplementedError('only the eval-mode branches forward(..., return_codes_only=True | return_encoded=True | '
+                                      'return_recons_only=True) are implemented (SoundStream training is out of scope)')
+        x, lead = self.process_input(x, input_sample_hz=input_sample_hz, curtail_from_left=curtail_from_left)
         feats = self.encode(x)
         quantized, indices, commit_loss = self.rq(feats)
         if return_codes_only:
             return indices                                       # (g, b, n, q), soundstream.py:847-848
         b, n = indices.shape[1], indices.shape[2]
-        return quantized, indices.permute(1, 2, 0, 3).reshape(b, n, -1), commit_loss          # 'g b n q -> b n (g q)', :851
+        if return_encoded:
+            return quantized, indices.permute(1, 2, 0, 3).reshape(b, n, -1), commit_loss          # 'g b n q -> b n (g q)', :851
+        recon = self.decode(quantized)                           # :857-866 (no decoder_attn: use_local_attn=False), unpack(recon_x, ps, '* c n')
+        return recon.reshape(*lead, recon.shape[-2], recon.shape[-1])
 
     @torch.no_grad()
     def decode_from_codebook_indices(self, quantized_indices):               # soundstream.py:691-699

@@ -200,7 +200,53 @@ def soundstream_decode_case():
                 inputs=dict(indices=indices), outputs=dict(wave=wave))
 
 
+def signatures_case():
+    """Constructor / forward / generate parameter lists (name, kind, default) of the REAL reference's boundary classes:
+    tests/test_host_logic.py holds this package's mirror against them."""
+    import inspect
+    import json
+    from audiolm_pytorch.optimizer import get_optimizer
+
+    def sig(fn):
+        out = []
+        if fn.__name__ == 'inner' and fn.__closure__:                  # @eval_decorator (audiolm_pytorch.py:140-147) hides the signature
+            fn = [c.cell_contents for c in fn.__closure__ if callable(c.cell_contents)][0]
+        for name, prm in inspect.signature(fn).parameters.items():
+            d = prm.default
+            if d is inspect.Parameter.empty:
+                d = '<required>'
+            elif not isinstance(d, (int, float, bool, str, type(None), tuple)):
+                d = '<object>'
+            out.append([name, prm.kind.name, list(d) if isinstance(d, tuple) else d])
+        return out
+    table = {}
+    for cls in (A.SemanticTransformer, A.CoarseTransformer, A.FineTransformer, A.Transformer):
+        table[cls.__name__ + '.__init__'] = sig(cls.__init__)
+        table[cls.__name__ + '.forward'] = sig(cls.forward)
+        if hasattr(cls, 'forward_with_cond_scale'):
+            table[cls.__name__ + '.forward_with_cond_scale'] = sig(cls.forward_with_cond_scale)
+    for cls in (A.SemanticTransformerWrapper, A.CoarseTransformerWrapper, A.FineTransformerWrapper):
+        table[cls.__name__ + '.__init__'] = sig(cls.__init__)
+        table[cls.__name__ + '.forward'] = sig(cls.forward)
+        table[cls.__name__ + '.generate'] = sig(cls.generate)
+    table['AudioLM.__init__'] = sig(A.AudioLM.__init__)
+    table['AudioLM.forward'] = sig(A.AudioLM.forward)
+    table['Attend.__init__'] = sig(AT.Attend.__init__)
+    table['Attend.forward'] = sig(AT.Attend.forward)
+    table['SoundStream.__init__'] = sig(S.SoundStream.__init__)
+    table['SoundStream.forward'] = sig(S.SoundStream.forward)
+    table['SoundStream.tokenize'] = sig(S.SoundStream.tokenize)
+    table['SoundStream.decode_from_codebook_indices'] = sig(S.SoundStream.decode_from_codebook_indices)
+    table['get_optimizer'] = sig(get_optimizer)
+    with open(os.path.join(HERE, 'signatures.json'), 'w') as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    print('signatures.json:', len(table), 'callables')
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'signatures':
+        signatures_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'soundstream_decode':      # add this fixture without touching the others
         c = soundstream_decode_case()
         torch.save(c, os.path.join(HERE, c['name'] + '.pt'))

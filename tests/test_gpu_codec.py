@@ -244,6 +244,16 @@ def test_tokenize_decode_round_trip_shapes_and_generate_reconstruct():
     codes = codec.tokenize(wave)                                                   # (1, 2, 12, 8)
     rec = codec.decode_from_codebook_indices(codes)
     assert rec.shape == (2, 1, 320 * 12) and bool(torch.isfinite(rec).all())
+    # forward(return_recons_only=True) (soundstream.py:857-866) is encode -> quantize -> decode in one call (the quantized sum comes from
+    # the encode kernel instead of the code lookup: same values up to fp32 summation order); positional call in the reference's argument
+    # order; a 1-D clip comes back as (channels, n)
+    rec2 = codec(wave, return_recons_only=True)
+    assert rec2.shape == rec.shape and relmax(rec2, rec) <= 1e-5, relmax(rec2, rec)
+    rec3 = codec(wave, None, None, False, False, False, False, False, True)
+    assert torch.equal(rec3, rec2)
+    assert codec(wave[0], return_recons_only=True).shape == (1, 320 * 12)
+    with pytest.raises(NotImplementedError):
+        codec(wave, return_discr_loss=True)
     coarse = A.CoarseTransformer(dim=64, depth=1, heads=2, num_semantic_tokens=20, codebook_size=16, num_coarse_quantizers=3, flash_attn=True).to(dev())
     cw = A.CoarseTransformerWrapper(transformer=coarse, codec=codec, unique_consecutive=False)
     sem = torch.randint(0, 20, (2, 5), device=dev())

@@ -285,3 +285,52 @@ def test_sampling_helpers_semantics():
     torch.manual_seed(0)
     s = AP.gumbel_sample(torch.tensor([[0.0, 50.0, 0.0]]), temperature=1.)
     assert int(s) == 1
+
+
+def test_boundary_signatures_match_reference_snapshot():
+    """every constructor / forward / generate of the drop-in classes accepts the reference's parameters -- same names, same
+    order, same kinds, same defaults (tests/golden/signatures.json, taken from the REAL reference by make_golden.py signatures).  Extra
+    keyword parameters of ours (labels=, return_flat_hidden=, zero_pad-like extensions) must come with defaults."""
+    import inspect
+    import json
+    import audiolm_pytorch_amd.attend as AT
+    import audiolm_pytorch_amd.optimizer as OPT
+    import audiolm_pytorch_amd.soundstream as SS
+    ref = json.load(open(os.path.join(GOLDEN_DIR, 'signatures.json')))
+    owners = {'SemanticTransformer': AP, 'CoarseTransformer': AP, 'FineTransformer': AP, 'Transformer': AP, 'SemanticTransformerWrapper': AP,
+              'CoarseTransformerWrapper': AP, 'FineTransformerWrapper': AP, 'AudioLM': AP, 'Attend': AT, 'SoundStream': SS}
+    problems = []
+    for key, want in sorted(ref.items()):
+        if key == 'get_optimizer':
+            fn = OPT.get_optimizer
+        else:
+            cls, meth = key.split('.')
+            fn = getattr(getattr(owners[cls], cls), meth)
+        if fn.__name__ == 'inner' and fn.__closure__:
+            fn = [c.cell_contents for c in fn.__closure__ if callable(c.cell_contents)][0]
+        have = inspect.signature(fn).parameters
+        var_kw = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in have.values())
+        pos_ref = [n for n, kind, _ in want if kind == 'POSITIONAL_OR_KEYWORD']
+        pos_have = [n for n, p in have.items() if p.kind is inspect.Parameter.POSITIONAL_OR_KEYWORD]
+        if pos_have[:len(pos_ref)] != pos_ref:
+            problems.append(f'{key}: positional parameters {pos_have} vs reference {pos_ref}')
+        for name, kind, default in want:
+            if kind in ('VAR_POSITIONAL', 'VAR_KEYWORD'):
+                continue
+            if name not in have:
+                if not var_kw:
+                    problems.append(f'{key}: parameter {name!r} missing')
+                continue
+            p = have[name]
+            if p.kind.name != kind:
+                problems.append(f'{key}: {name} is {p.kind.name}, reference {kind}')
+            d = '<required>' if p.default is inspect.Parameter.empty else p.default
+            if isinstance(d, tuple):
+                d = list(d)
+            if default != '<object>' and d != default and not (isinstance(d, float) and isinstance(default, (int, float)) and d == default):
+                problems.append(f'{key}: default of {name} is {d!r}, reference {default!r}')
+        for name, p in have.items():                       # our extensions never become mandatory
+            if name not in {n for n, _, _ in want} and p.kind in (inspect.Parameter.POSITIONAL_OR_KEYWORD, inspect.Parameter.KEYWORD_ONLY):
+                if p.default is inspect.Parameter.empty:
+                    problems.append(f'{key}: extra parameter {name!r} has no default')
+    assert not problems, '\n'.join(problems)
