@@ -64,14 +64,18 @@ def round_down_nearest_multiple(val, mult):
     return (val // mult) * mult
 
 
-def generate_mask_with_prob(shape, mask_prob, device):        # audiolm_pytorch.py:82-89
-    seq = shape[-1]
-    rand = torch.randn(shape, device=device)
-    rand[:, 0] = -torch.finfo(rand.dtype).max
-    num_mask = min(int(seq * mask_prob), seq - 1)
-    indices = rand.topk(num_mask, dim=-1).indices
-    mask = ~torch.zeros(shape, device=device).scatter(1, indices, 1.).bool()
-    return mask
+def generate_mask_with_prob(shape, mask_prob, device):
+    """Forgetful causal mask (reference audiolm_pytorch.py:82-89): True = key kept.  Per row, the int(n * mask_prob) keys (at most n - 1) with
+    the largest Gaussian draw are dropped; key 0 (the start token) is never dropped.  ONE randn(shape) draw on `device`, like the reference,
+    so a seeded run masks the same keys."""
+    n = shape[-1]
+    drop_count = min(int(n * mask_prob), n - 1)
+    score = torch.randn(shape, device=device)
+    score[:, 0] = -torch.finfo(score.dtype).max                  # never among the top draws
+    keep = torch.ones(shape, dtype=torch.bool, device=device)
+    if drop_count > 0:
+        keep.scatter_(1, score.topk(drop_count, dim=-1).indices, False)
+    return keep
 
 
 def grad_shrink(t, alpha=0.1):

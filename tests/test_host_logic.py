@@ -334,3 +334,15 @@ def test_boundary_signatures_match_reference_snapshot():
                 if p.default is inspect.Parameter.empty:
                     problems.append(f'{key}: extra parameter {name!r} has no default')
     assert not problems, '\n'.join(problems)
+
+
+@pytest.mark.parametrize('shape,prob', [((4, 64), 0.15), ((2, 7), 0.9), ((3, 5), 0.0), ((1, 2048), 0.15), ((2, 3), 1.0)])
+def test_forgetful_mask_matches_oracle_draw_for_draw(shape, prob):
+    """int(n p) keys capped at n - 1, key 0 never masked, and the SAME keys as the reference for the same seed."""
+    torch.manual_seed(123)
+    ours = AP.generate_mask_with_prob(shape, prob, 'cpu')
+    torch.manual_seed(123)
+    ref = O.generate_mask_with_prob(shape, prob, 'cpu')
+    assert ours.dtype == torch.bool and torch.equal(ours, ref)
+    assert bool(ours[:, 0].all())
+    assert bool(((~ours).sum(-1) == min(int(shape[-1] * prob), shape[-1] - 1)).all())
