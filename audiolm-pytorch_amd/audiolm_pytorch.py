@@ -21,6 +21,7 @@ There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refu
 """
 from __future__ import annotations
 
+import functools
 import os
 from functools import partial
 from pathlib import Path
@@ -28,7 +29,6 @@ from pathlib import Path
 import torch
 import torch.nn.functional as F
 from torch import nn
-from torch.nn.utils.rnn import pad_sequence
 
 from . import core, heads, ops, relpos
 from .attend import Attend
@@ -82,62 +82,69 @@ def grad_shrink(t, alpha=0.1):
     return t * alpha + t.detach() * (1 - alpha)
 
 
-def append_eos_id(ids, eos_id):                               # audiolm_pytorch.py:155-160
-    b, device = ids.shape[0], ids.device
-    eos_ids = torch.full((b, 1), eos_id, dtype=torch.long, device=device)
-    return torch.cat((ids, eos_ids), dim=-1)
+def append_eos_id(ids, eos_id):                               # semantics of audiolm_pytorch.py:155-160
+    """(b, n) int64 -> (b, n + 1): one eos column on the right"""
+    return F.pad(ids, (0, 1), value=eos_id)
 
 
-def batch_unique_consecutive(t, pad_value=0.):                # audiolm_pytorch.py:162-164
-    unique_arr = [torch.unique_consecutive(el) for el in t.unbind(dim=0)]
-    return pad_sequence(unique_arr, batch_first=True, padding_value=pad_value)
+def batch_unique_consecutive(t, pad_value=0.):                # semantics of audiolm_pytorch.py:162-164
+    """per row: collapse runs of equal ids; rows are ragged afterwards and right-padded with pad_value to the longest one
+    (data-dependent width -> a host loop over the batch, as in the reference)"""
+    rows = [torch.unique_consecutive(row) for row in t]
+    out = t.new_full((len(rows), max(r.numel() for r in rows)), pad_value)
+    for i, r in enumerate(rows):
+        out[i, :r.numel()] = r
+    return out
 
 
-# sampling helpers (audiolm_pytorch.py:96-130): integer / tiny (batch, vocab) bookkeeping of the generate() loops, in torch ops
+# sampling helpers (semantics of audiolm_pytorch.py:96-130): integer / tiny (batch, vocab) bookkeeping of the generate() loops, in torch ops
 
 def log(t, eps=1e-20):
-    return torch.log(t + eps)
+    """log with a floor"""
+    return (t + eps).log()
 
 
 def gumbel_noise(t):
-    noise = torch.zeros_like(t).uniform_(0, 1)
-    return -log(-log(noise))
+    """-log(-log u), u ~ U(0, 1): one in-place uniform draw of t's shape (the reference's RNG consumption)"""
+    u = torch.empty_like(t).uniform_(0, 1)
+    return log(log(u).neg()).neg()
 
 
 def gumbel_sample(t, temperature=1., dim=-1):
-    return ((t / temperature) + gumbel_noise(t)).argmax(dim=dim)
+    """Gumbel-max draw from softmax(t / temperature)"""
+    return (t / temperature + gumbel_noise(t)).argmax(dim=dim)
 
 
 def top_k(logits, thres=0.5):
-    num_logits = logits.shape[-1]
-    k = max(int((1 - thres) * num_logits), 1)
-    val, ind = torch.topk(logits, k)
-    probs = torch.full_like(logits, float('-inf'))
-    probs.scatter_(1, ind, val)
-    return probs
+    """each row keeps exactly k = max(int((1 - thres) * n), 1) largest logits, the rest become -inf"""
+    k = max(int((1 - thres) * logits.shape[-1]), 1)
+    vals, idx = logits.topk(k, dim=-1)
+    return torch.full_like(logits, float('-inf')).scatter(-1, idx, vals)
 
 
 def mask_out_after_eos_id(t, eos_id, mask_value=-1, keep_eos=True):
-    eos_mask = (t == eos_id).float()
+    """everything after the first eos of a row becomes mask_value -- the eos itself too unless keep_eos"""
+    from_eos = (t == eos_id).cumsum(dim=-1) > 0                # at or after the first eos
     if keep_eos:
-        eos_mask = F.pad(eos_mask, (1, -1))
-    after_eos_mask = eos_mask.cumsum(dim=-1) > 0
-    return t.masked_fill(after_eos_mask, mask_value)
+        from_eos = F.pad(from_eos[..., :-1], (1, 0), value=False)   # strictly after it
+    return t.masked_fill(from_eos, mask_value)
 
 
 def all_rows_have_eos_id(t, eos_id):
-    eos_mask = (t == eos_id)
-    return torch.any(eos_mask, dim=-1).all()
+    return (t == eos_id).any(dim=-1).all()
 
 
-def eval_decorator(fn):                                        # audiolm_pytorch.py:71-78
-    def inner(model, *args, **kwargs):
-        was_training = model.training
+def eval_decorator(fn):                                        # semantics of audiolm_pytorch.py:71-78
+    """run a module method in eval mode and put the previous training flag back afterwards (also when it raises)"""
+    @functools.wraps(fn)
+    def run_in_eval(model, *args, **kwargs):
+        mode = model.training
         model.eval()
-        out = fn(model, *args, **kwargs)
-        model.train(was_training)
-        return out
-    return inner
+        try:
+            return fn(model, *args, **kwargs)
+        finally:
+            model.train(mode)
+    return run_in_eval
 
 
 def get_embeds(embeddings: nn.Embedding, codes: torch.Tensor, pad_id=-1, return_mask=False, mask_pad_pos_to=0):

@@ -346,3 +346,50 @@ def test_forgetful_mask_matches_oracle_draw_for_draw(shape, prob):
     assert ours.dtype == torch.bool and torch.equal(ours, ref)
     assert bool(ours[:, 0].all())
     assert bool(((~ours).sum(-1) == min(int(shape[-1] * prob), shape[-1] - 1)).all())
+
+
+def test_integer_helpers_match_oracle_on_random_inputs():
+    """append_eos_id / batch_unique_consecutive (ragged -> padded, pad -1) against the oracle's restatement of audiolm_pytorch.py:155-164;
+    mask_out_after_eos_id against a position-by-position definition; dtype stays int64."""
+    g = torch.Generator().manual_seed(5)
+    for _ in range(20):
+        b, n, vocab = int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(1, 30, (1,), generator=g)), int(torch.randint(2, 6, (1,), generator=g))
+        ids = torch.randint(0, vocab, (b, n), generator=g)
+        assert torch.equal(AP.append_eos_id(ids, vocab), O.append_eos_id(ids, vocab))
+        ours, ref = AP.batch_unique_consecutive(ids, pad_value=-1), O.batch_unique_consecutive(ids, pad_value=-1)
+        assert ours.dtype == torch.int64 and torch.equal(ours, ref)
+        for keep in (True, False):
+            m = AP.mask_out_after_eos_id(ids, 1, mask_value=-7, keep_eos=keep)
+            for r in range(b):
+                row = ids[r].tolist()
+                first = row.index(1) if 1 in row else None
+                want = list(row)
+                if first is not None:
+                    for j in range(first + (1 if keep else 0), n):
+                        want[j] = -7
+                assert m[r].tolist() == want
+    lg = torch.randn(6, 40, generator=g)
+    for thres in (0.0, 0.5, 0.9, 0.999):
+        out = AP.top_k(lg, thres)
+        k = max(int((1 - thres) * 40), 1)
+        assert bool((torch.isfinite(out).sum(-1) == k).all())
+        assert torch.equal(out.max(-1).values, lg.max(-1).values) and bool((out[torch.isfinite(out)] == lg[torch.isfinite(out)]).all())
+
+
+def test_eval_decorator_restores_mode_even_on_error():
+    class M(torch.nn.Module):
+        @AP.eval_decorator
+        def ok(self):
+            return self.training
+
+        @AP.eval_decorator
+        def boom(self):
+            raise ValueError('x')
+    m = M().train()
+    assert m.ok() is False and m.training is True
+    with pytest.raises(ValueError):
+        m.boom()
+    assert m.training is True
+    m.eval()
+    m.ok()
+    assert m.training is False
