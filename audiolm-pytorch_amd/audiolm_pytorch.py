@@ -79,7 +79,9 @@ def generate_mask_with_prob(shape, mask_prob, device):
 
 
 def grad_shrink(t, alpha=0.1):
-    return t * alpha + t.detach() * (1 - alpha)
+    """forward identity, gradient scaled by alpha (audiolm_pytorch.py:93-94).  API compatibility only: the fused stack applies the factor to
+    the input gradient itself (core.stack_backward)."""
+    return torch.lerp(t.detach(), t, alpha)
 
 
 def append_eos_id(ids, eos_id):                               # semantics of audiolm_pytorch.py:155-160
@@ -148,15 +150,14 @@ def eval_decorator(fn):                                        # semantics of au
 
 
 def get_embeds(embeddings: nn.Embedding, codes: torch.Tensor, pad_id=-1, return_mask=False, mask_pad_pos_to=0):
-    """audiolm_pytorch.py:168-186 (kept for API compatibility; the transformers use EmbedAssembleFn)."""
-    pad_mask = codes == pad_id
-    codes_without_pad = codes.masked_fill(pad_mask, 0)
-    embeds = embeddings(codes_without_pad)
-    if exists(mask_pad_pos_to):
-        embeds = embeds.masked_fill(pad_mask.unsqueeze(-1), mask_pad_pos_to)
-    if return_mask:
-        return embeds, ~pad_mask
-    return embeds
+    """Pad-aware embedding lookup with the semantics of audiolm_pytorch.py:168-186: positions holding pad_id read row 0 and are then overwritten
+    with mask_pad_pos_to (None: left as row 0); optionally also returns the not-pad mask.  Exported for API compatibility only -- the
+    transformers never call it (their lookup is alm_embed_assemble, which applies the same rule inside the kernel)."""
+    is_pad = codes.eq(pad_id)
+    rows = embeddings(torch.where(is_pad, torch.zeros_like(codes), codes))
+    if mask_pad_pos_to is not None:
+        rows = torch.where(is_pad[..., None], torch.full_like(rows, mask_pad_pos_to), rows)
+    return (rows, ~is_pad) if return_mask else rows
 
 
 def _flatten_ids(t):

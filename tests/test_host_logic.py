@@ -393,3 +393,20 @@ def test_eval_decorator_restores_mode_even_on_error():
     m.eval()
     m.ok()
     assert m.training is False
+
+
+def test_api_compat_helpers_get_embeds_and_grad_shrink():
+    """exported for API compatibility (not on the product path): same values as the oracle's restatement of audiolm_pytorch.py:93-94, 168-186"""
+    g = torch.Generator().manual_seed(3)
+    emb = torch.nn.Embedding(7, 5)
+    codes = torch.randint(-1, 7, (3, 11), generator=g)
+    ours, mask = AP.get_embeds(emb, codes, pad_id=-1, return_mask=True)
+    ref = O.get_embeds(emb.weight, codes, pad_id=-1)
+    assert torch.equal(ours, ref) and torch.equal(mask, codes != -1)
+    keep_row0 = AP.get_embeds(emb, codes, pad_id=-1, mask_pad_pos_to=None)
+    assert torch.equal(keep_row0[codes == -1], emb.weight[0].expand(int((codes == -1).sum()), -1))
+    x = torch.randn(4, 3, generator=g, requires_grad=True)
+    y = AP.grad_shrink(x, alpha=0.1)
+    assert torch.allclose(y, x, atol=1e-7)
+    y.sum().backward()
+    assert torch.allclose(x.grad, torch.full_like(x, 0.1))
