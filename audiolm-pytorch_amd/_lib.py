@@ -28,8 +28,8 @@ SIGNATURES = {
     'alm_pack_weights_multi': [_P, _I, _P],
     'alm_pack_weight': [_P, _I, _I, _L, _P, _L, _I, _I, _P, _L, _P],
     'alm_ln_partial_blocks': [_I],
-    'alm_layernorm_fwd': [_P, _I, _L, _P, _P, _L, _P, _L, _P, _P, _I, _I, _P],
-    'alm_layernorm_bwd': [_P, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
+    'alm_layernorm_fwd': [_P, _I, _L, _P, _P, _I, _L, _P, _L, _P, _P, _I, _I, _P],
+    'alm_layernorm_bwd': [_P, _I, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
     'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P, _P],
     'alm_colsum_chunks': [_I],
     'alm_geglu_partial_blocks': [_I],
@@ -55,17 +55,18 @@ SIGNATURES = {
     'alm_hc_coef_width': [_I],
     'alm_hc_partial_width': [_I, _I],
     'alm_hc_grads_width': [_I, _I],
-    'alm_hc_partial_rows': [_I, _I, _I, _L, _I],
-    'alm_hc_fwd': [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'alm_hc_bwd': [_P, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_partial_rows': [_I, _I, _I, _I, _L, _I],
+    'alm_hc_fwd': [_P, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_bwd': [_P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     'alm_hc_param_grads': [_P, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
     'alm_residual_add': [_P, _P, _L, _P, _L, _I, _P],
     'alm_f32_to_bf16': [_P, _P, _P, _L, _L, _I, _P],
     'alm_add_f32': [_P, _P, _P, _L, _P],
-    'alm_embed_assemble': [_P, _I, _P, _P, _P, _L, _I, _P],
-    'alm_embed_scatter_add': [_P, _I, _P, _P, _P, _F, _L, _I, _P],
+    'alm_embed_assemble': [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P],
+    'alm_embed_scatter_add': [_P, _P, _I, _P, _P, _P, _F, _L, _I, _P],
+    'alm_gather_split_bf16': [_P, _L, _L, _P, _P, _P, _L, _L, _I, _P],
     'alm_gather_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],
     'alm_scatter_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],
     'alm_cross_entropy_fwd': [_P, _L, _P, _P, _P, _L, _I, _I, _P],
@@ -103,9 +104,11 @@ def load(build_if_missing: bool = True):
         from . import build as _build
         try:
             _build.build(verbose=False)
-        except Exception as e:  # no hipcc on the box: fine as long as the prebuilt .so travelled with the tree
+        except Exception as e:  # no hipcc on the box: fine as long as the prebuilt .so that travelled with the tree matches the sources
             if not os.path.exists(LIB_PATH):
                 raise ImportError(f'libaudiolm_hip.so is missing and could not be built: {e}') from e
+            if not _build._fresh(_build._digest()):
+                raise ImportError(f'libaudiolm_hip.so is stale (csrc/ or include/ changed since it was built) and could not be rebuilt: {e}') from e
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"`')
     # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64, and whichever copy enters the process first serves both torch
@@ -116,7 +119,7 @@ def load(build_if_missing: bool = True):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            continue
+            raise ImportError(f'{LIB_PATH} does not export {name} (declared in include/audiolm_hip.h): stale or foreign library')
         fn.argtypes = argtypes
         fn.restype = c_int
     _lib = lib

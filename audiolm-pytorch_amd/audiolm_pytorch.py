@@ -312,7 +312,10 @@ class Residual(nn.Module):                                    # num_residual_str
 class Transformer(nn.Module):
     def __init__(self, *, dim, depth, heads, dim_context=None, cross_attend=False, attn_dropout=0., ff_dropout=0.,
                  grad_shrink_alpha=0.1, cond_as_self_attn_prefix=False, rel_pos_bias=True, flash_attn=False,
-                 add_value_residual=True, num_residual_streams=4, **kwargs):
+                 add_value_residual=True, num_residual_streams=4, residual_dtype=None, **kwargs):
+        # residual_dtype (extension; default: ALM_RESIDUAL_DTYPE or fp32): HBM storage of the hyper-connection residual streams and their
+        # gradients, torch.float32 | torch.bfloat16.  bf16 is what trainer.py:1241's autocast gives the reference (its streams are bf16 tensors
+        # from the first width connection on) and halves the traffic of the HBM-bound hyper-connection kernels; arithmetic is fp32 either way.
         super().__init__()
         rel_pos_bias = rel_pos_bias and not flash_attn
         assert not (cross_attend and cond_as_self_attn_prefix)
@@ -342,7 +345,9 @@ class Transformer(nn.Module):
         attn0 = self.layers[0][0].branch
         self.cfg = core.StackCfg(dim=dim, depth=depth, heads=heads, dim_head=attn0.dim_head, streams=num_residual_streams,
                                  inner=int(dim * 2 * 4 / 3), add_value_residual=add_value_residual,
-                                 grad_shrink_alpha=grad_shrink_alpha)
+                                 grad_shrink_alpha=grad_shrink_alpha,
+                                 residual_bf16=(core.default_residual_bf16() if residual_dtype is None else residual_dtype == torch.bfloat16))
+        assert residual_dtype in (None, torch.float32, torch.bfloat16), residual_dtype
         self._cache = core.WeightCache()
         self._layer_grad_hook = None          # set by parallel.DataParallelEngine: called as each layer's grads become final
 

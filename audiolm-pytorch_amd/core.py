@@ -4,7 +4,9 @@ per-op autograd graph, no (b, h, n, n) tensors, no kv-cache stacking (audiolm_py
 training -- SURVEY.md Appendix A.7).
 
 Data layout in HBM (B sequences, N tokens, M = B*N rows, D model width, S residual streams):
-  residual streams  R    fp32 [B][S][N][D]            (reference '(b s) n d'); one tensor per branch boundary is kept for backward
+  residual streams  R    fp32 | bf16 [B][S][N][D]     (reference '(b s) n d'); one tensor per branch boundary is kept for backward.  bf16
+                                                      (StackCfg.residual_bf16) is what trainer.py:1241's autocast gives the reference: its streams
+                                                      are bf16 from the first width connection on; arithmetic stays fp32 in registers
   branch input      X/XN bf16 [M][D]                  (XN = pre-LayerNorm output, X = un-normalised input feeding to_kv -- quirk A3)
   q / kv / attn out      bf16 [M][H*64] / [M][128] / [M][H*64]
   FFN               U    bf16 [M][2*Ipad] (x | gate halves, Ipad = inner rounded up to 8), HN bf16 [M][Ipad]
@@ -32,6 +34,7 @@ class StackCfg:
     inner: int                    # FFN inner width int(dim * 8 / 3)
     add_value_residual: bool
     grad_shrink_alpha: float
+    residual_bf16: bool = False   # storage type of the 4-stream residual tensors and their gradients (num_residual_streams > 1 only)
 
     @property
     def inner_pad(self):
@@ -147,6 +150,14 @@ def layer_weights(cache: WeightCache, l, pa, pf, I, Ip):
     return tuple(out[k] for k, _ in ws)
 
 
+def default_residual_bf16():
+    """ALM_RESIDUAL_DTYPE = fp32 | bf16: storage of the hyper-connection residual streams (see StackCfg.residual_bf16)"""
+    v = os.environ.get('ALM_RESIDUAL_DTYPE', 'fp32').lower()
+    if v not in ('fp32', 'float32', 'bf16', 'bfloat16'):
+        raise ValueError(f'ALM_RESIDUAL_DTYPE={v!r}: expected fp32 or bf16')
+    return v in ('bf16', 'bfloat16')
+
+
 def _empty(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
@@ -166,7 +177,7 @@ class DecodeCache:
 
 
 def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None):
-    """x fp32 [B, N, D] -> (hn bf16 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
+    """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
     audiolm_pytorch.py:500-506 / :532) or None.  Sampling: `kv_out` (DecodeCache) is filled with every layer's k / v of this (prefix)
     forward; `decode` (DecodeCache) means x holds ONE new position per sequence (N == 1) at index decode.length: its attention runs over
     the cache (alm_mqa_decode_attn, which also appends the new k / v), everything else is the same launch sequence on B rows."""
@@ -179,6 +190,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
     R = x.reshape(M, D)                  # S > 1: the stream expansion (:524) is never materialised -- the first branch reads x for every stream
     rb = S > 1
+    rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
     kv0 = None
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
@@ -188,7 +200,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
         if S > 1:
             # depth connection of the previous branch fused with this branch's width connection + pre-LayerNorm (one pass over R)
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'], rin_bcast=rb)
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'], rin_bcast=rb, r_dtype=rdt)
             R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
             rb = rb and pend_y is None                 # still the un-expanded x after a width-only call
         else:
@@ -218,7 +230,9 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
         # ---------------- feed-forward branch (audiolm_pytorch.py:246-260) ----------------
         if S > 1:
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'], rin_bcast=rb)
+            # (the un-normalised branch input X2 is only read by the un-fused LayerNorm backward)
+            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'], rin_bcast=rb, r_dtype=rdt,
+                           want_x=need_grad and not FUSE_LN_BWD)
             R1, X2, XN2, mean2, rstd2, coef2 = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
             rb = False
         else:
@@ -242,11 +256,11 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
 
     if S > 1:
         # last depth connection + stream sum (:551) + final LayerNorm (:555) in one pass; the final residual streams are never stored
-        h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, ln_gamma=flat[-1], final=True)
+        h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, ln_gamma=flat[-1], final=True, r_dtype=rdt, final_f32=True)
         xs, hn, fmean, frstd = h['xs'], h['xn'], h['mean'], h['rstd']
     else:
         xs = R
-        hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1])              # :555
+        hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1], out_f32=True)  # :555 (fp32 out: F.layer_norm autocasts to fp32; the logit heads split it)
     if need_grad:
         saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
     if decode is not None and not decode.frozen:
@@ -316,7 +330,7 @@ SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number 
 
 
 def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None):
-    """dhn bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None)."""
+    """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None)."""
     B, N = saved['B'], saved['N']
     D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
     M = B * N
@@ -325,6 +339,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     ppl = params_per_layer(S)
     grads = [None] * len(flat)
     side = _SideStream(dev, ASYNC_WGRAD)
+    rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
 
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
     grads[-1] = dgam
@@ -336,7 +351,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     dY2 = dbeta2 = None
     if S > 1:
         last = saved['layers'][-1]
-        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=last['Y2'], coef_prev=last['coef2'])
+        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=last['Y2'], coef_prev=last['coef2'], r_dtype=rdt)
         dY2, dbeta2 = h['dy'], h['dbeta']
 
     for l in reversed(range(cfg.depth)):
@@ -367,12 +382,12 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             # attention branch: ONE pass over the residual streams
             if FUSE_LN_BWD:
                 h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN2, mean=sv['mean2'], rstd=sv['rstd2'], ln_gamma=pf['ln'], R=sv['R1'],
-                               coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'], y_prev=sv['Y'], coef_prev=sv['coef'])
+                               coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'], y_prev=sv['Y'], coef_prev=sv['coef'], r_dtype=rdt)
                 dgl = h['grads']['ln']
             else:
                 dX2, dgl = ops.layernorm_bwd(dXN2, sv['X2'], sv['mean2'], sv['rstd2'], pf['ln'])
                 h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dx=dX2, R=sv['R1'], coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'],
-                               y_prev=sv['Y'], coef_prev=sv['coef'])
+                               y_prev=sv['Y'], coef_prev=sv['coef'], r_dtype=rdt)
             dR1, dY, dbeta, bcast = h['dR'], h['dy'], h['dbeta'], False
             for j, k in enumerate(HC_KEYS):
                 grads[base + hc_n + 4 + j] = h['grads'][k]
@@ -414,12 +429,12 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             py, pc = (prev['Y2'], prev['coef2']) if prev else (None, None)
             if FUSE_LN_BWD:
                 h = ops.hc_bwd(dR1, B, S, N, D, dxn=dXN, extra=dXkv, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=pa['ln'], R=sv['R'],
-                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=l == 0)
+                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=l == 0, r_dtype=rdt)
                 dgla = h['grads']['ln']
             else:
                 dX, dgla = ops.layernorm_bwd(dXN, sv['X'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
                 h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc,
-                               r_bcast=sv['r_bcast'], sum_only=l == 0)
+                               r_bcast=sv['r_bcast'], sum_only=l == 0, r_dtype=rdt)
             dR, dY2, dbeta2 = (h['dsum'] if l == 0 else h['dR']), h['dy'], h['dbeta']      # layer 0: already summed over the streams (:524)
             for j, k in enumerate(HC_KEYS):
                 grads[base + j] = h['grads'][k]
@@ -440,7 +455,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
 
 
 class TransformerStackFn(torch.autograd.Function):
-    """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states bf16 [B*N, D]."""
+    """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states fp32 [B*N, D]."""
 
     @staticmethod
     def forward(ctx, x, mask_u8, cfg, cache, opts, bias, tbl, *flat):
@@ -462,8 +477,8 @@ class TransformerStackFn(torch.autograd.Function):
         cfg = ctx.cfg
         flat = [t.detach() for t in ctx.flat]
         dhn = dhn.contiguous()
-        if dhn.dtype != BF16:
-            dhn = dhn.to(BF16)
+        if dhn.dtype not in (BF16, F32):
+            dhn = dhn.to(F32)
         dx, grads, dtbl = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
         ctx.saved = None
         dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478

@@ -11,16 +11,22 @@
 namespace {
 
 constexpr int MAX_TABLES = 8;
-struct Tables { const float* p[MAX_TABLES]; };
-struct GradTables { float* p[MAX_TABLES]; };
+struct Tables { const float* p[MAX_TABLES]; int rows[MAX_TABLES]; int n; };
+struct GradTables { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int n; };
 
-// source code: (table_id << 24) | row ; -1 = none (zero vector: padded position, get_embeds :176-181)
+// source code: (table_id << 24) | row ; -1 = none (zero vector: padded position, get_embeds :176-181).  A code naming a table or a row that
+// does not exist (nn.Embedding would raise IndexError) is never dereferenced: it reads as zero / is skipped and raises the error flag.
+template <typename T>
+__device__ __forceinline__ bool code_ok(const T& t, int code) {
+    const int tb = code >> 24, row = code & 0xffffff;
+    return tb < t.n && row < t.rows[tb];
+}
 __device__ __forceinline__ const float* src_row(const Tables& t, int code, int D) {
     return t.p[code >> 24] + (long long)(code & 0xffffff) * D;
 }
 
 __global__ __launch_bounds__(256) void embed_assemble_kernel(Tables tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
-                                                             float* __restrict__ out, long long rows, int D) {
+                                                             float* __restrict__ out, long long rows, int D, int* __restrict__ err) {
     const int d4 = D / 4;
     const long long total = rows * d4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -28,11 +34,13 @@ __global__ __launch_bounds__(256) void embed_assemble_kernel(Tables tabs, const 
         const int e = (int)(i % d4) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int a = src_a[r], b = src_b[r];
-        if (a >= 0) v = *reinterpret_cast<const float4*>(src_row(tabs, a, D) + e);
-        if (b >= 0) {
+        const bool a_ok = a >= 0 && code_ok(tabs, a), b_ok = b >= 0 && code_ok(tabs, b);
+        if (a_ok) v = *reinterpret_cast<const float4*>(src_row(tabs, a, D) + e);
+        if (b_ok) {
             const float4 w = *reinterpret_cast<const float4*>(src_row(tabs, b, D) + e);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
+        if (err && e == 0 && ((a >= 0 && !a_ok) || (b >= 0 && !b_ok))) *err = 1;
         *reinterpret_cast<float4*>(out + r * D + e) = v;
     }
 }
@@ -45,8 +53,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(GradTables tabs, con
         const int e = (int)(i % D);
         const float g = dout[i] * alpha;
         const int a = src_a[r], b = src_b[r];
-        if (a >= 0) atomicAdd(tabs.p[a >> 24] + (long long)(a & 0xffffff) * D + e, g);
-        if (b >= 0) atomicAdd(tabs.p[b >> 24] + (long long)(b & 0xffffff) * D + e, g);
+        if (a >= 0 && code_ok(tabs, a)) atomicAdd(tabs.p[a >> 24] + (long long)(a & 0xffffff) * D + e, g);
+        if (b >= 0 && code_ok(tabs, b)) atomicAdd(tabs.p[b >> 24] + (long long)(b & 0xffffff) * D + e, g);
     }
 }
 
@@ -62,6 +70,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restri
         uint4 v = make_uint4(0, 0, 0, 0);
         if (s >= 0) v = *reinterpret_cast<const uint4*>(in + (long long)s * ld_in + e);
         *reinterpret_cast<uint4*>(out + r * ld_out + e) = v;
+    }
+}
+// hi[r] = bf16(x), lo[r] = bf16(x - hi) for x = in[idx ? idx[r] : r]; source rows outside [0, rows_in) give zero rows.  D % 4 == 0
+__global__ __launch_bounds__(256) void gather_split_kernel(const float* __restrict__ in, long long ld_in, long long rows_in, const int* __restrict__ idx,
+                                                           bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long long ld_out, long long rows, int D) {
+    const int d4 = D / 4;
+    const long long total = rows * d4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d4;
+        const int e = (int)(i % d4) * 4;
+        const long long s = idx ? (long long)idx[r] : r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s >= 0 && s < rows_in) v = *reinterpret_cast<const float4*>(in + s * ld_in + e);
+        const uint32_t h0 = pack_bf2(v.x, v.y), h1 = pack_bf2(v.z, v.w);
+        const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+        const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(hi + r * ld_out + e) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(lo + r * ld_out + e) = make_uint2(pack_bf2(r0, r1), pack_bf2(r2, r3));
     }
 }
 // out[idx[r]] = in[r] (idx < 0 skipped; idx must be injective; untouched rows keep their previous contents)
@@ -183,22 +209,24 @@ int grid_for(long long total) { return (int)((total + 255) / 256 < 8192 ? (total
 
 }  // namespace
 
-extern "C" int alm_embed_assemble(const float* const* tables, int ntables, const int* src_a, const int* src_b, float* out, long long rows,
-                                  int D, void* stream) {
-    if (ntables > MAX_TABLES || (D & 3)) return ALM_ERR_BAD_ARG;
+extern "C" int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
+                                  long long rows, int D, int* err_flag, void* stream) {
+    if (ntables > MAX_TABLES || (D & 3) || !table_rows) return ALM_ERR_BAD_ARG;
     Tables t{};
-    for (int i = 0; i < ntables; ++i) t.p[i] = tables[i];
-    hipLaunchKernelGGL(embed_assemble_kernel, dim3(grid_for(rows * (D / 4))), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, out, rows, D);
+    t.n = ntables;
+    for (int i = 0; i < ntables; ++i) { t.p[i] = tables[i]; t.rows[i] = table_rows[i]; }
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3(grid_for(rows * (D / 4))), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, out, rows, D, err_flag);
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
 // grad tables must be zero-initialised (or hold a running gradient); dout fp32 [rows][D]; alpha = grad_shrink factor
-extern "C" int alm_embed_scatter_add(float* const* grad_tables, int ntables, const int* src_a, const int* src_b, const float* dout, float alpha,
-                                     long long rows, int D, void* stream) {
-    if (ntables > MAX_TABLES) return ALM_ERR_BAD_ARG;
+extern "C" int alm_embed_scatter_add(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b,
+                                     const float* dout, float alpha, long long rows, int D, void* stream) {
+    if (ntables > MAX_TABLES || !table_rows) return ALM_ERR_BAD_ARG;
     GradTables t{};
-    for (int i = 0; i < ntables; ++i) t.p[i] = grad_tables[i];
+    t.n = ntables;
+    for (int i = 0; i < ntables; ++i) { t.p[i] = grad_tables[i]; t.rows[i] = table_rows[i]; }
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, dout, alpha, rows, D);
     ALM_LAUNCH_CHECK();
     return 0;
@@ -210,6 +238,16 @@ extern "C" int alm_gather_rows_bf16(const void* in, long long ld_in, const int* 
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ld_in, idx,
                        (bf16_t*)out, ld_out, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_gather_split_bf16(const float* in, long long ld_in, long long rows_in, const int* idx, void* hi, void* lo, long long ld_out,
+                                     long long rows_out, int D, void* stream) {
+    if ((D & 3) || (ld_in & 3) || (ld_out & 3)) return ALM_ERR_BAD_ARG;
+    if (rows_out <= 0) return 0;
+    hipLaunchKernelGGL(gather_split_kernel, dim3(grid_for(rows_out * (D / 4))), dim3(256), 0, (hipStream_t)stream, in, ld_in, rows_in, idx,
+                       (bf16_t*)hi, (bf16_t*)lo, ld_out, rows_out, D);
     ALM_LAUNCH_CHECK();
     return 0;
 }

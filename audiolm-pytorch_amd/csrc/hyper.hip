@@ -5,7 +5,10 @@
 //   width : n_s = normalize(R_s) * sqrt(D) * (g + 1);  alpha = tanh(n Wa) * sa + Aa;  beta = tanh(n wb) * sb + Bb
 //           x = sum_s alpha[s][0] R_s   (branch input; the branch pre-LayerNorm audiolm_pytorch.py:347 / :254 is fused here)
 //   depth : R'_t = sum_s alpha[s][t+1] R_s + beta[t] * y
-// Residual streams R: fp32 [B][S][N][D]  (the reference's '(b s) n d').
+// Residual streams R: [B][S][N][D]  (the reference's '(b s) n d'), stored fp32 or -- `r_bf16` -- bf16: under `accelerator.autocast()`
+// (trainer.py:1241) the reference's streams ARE bf16 tensors from the first width connection on (its einsums autocast); the arithmetic
+// here is fp32 in registers either way, only the HBM image changes (half the traffic of these HBM-bound kernels).  Tensors that stand
+// for all streams at once (`*_bcast`: the embedded input x, the gradient of the final stream sum) are always fp32 [B*N][D].
 //
 // One wave64 owns one token: its S x D residual slab lives in registers (16-B coalesced loads, 4 x float4 per stream for
 // D = 1024), every reduction (S norms, S*(S+2) dot products, LayerNorm statistics) is a wave shuffle butterfly: no LDS, no
@@ -26,6 +29,35 @@ __device__ __forceinline__ float4 ld4bf(const bf16_t* p) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 __device__ __forceinline__ void st4bf(bf16_t* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
+// residual-stream element access: RT = float | bf16_t
+__device__ __forceinline__ float4 ldR(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldR(const bf16_t* p) { return ld4bf(p); }
+__device__ __forceinline__ void stR(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stR(bf16_t* p, float4 v) { st4bf(p, v); }
+// 4 consecutive residual elements exactly as they sit in HBM (fp32: 4 registers, bf16: 2): what a software-prefetched token keeps in
+// registers while the previous token is being processed
+template <typename RT> struct Raw4;
+template <> struct Raw4<float> { float4 v; };
+template <> struct Raw4<bf16_t> { uint2 v; };
+__device__ __forceinline__ void ldraw(Raw4<float>& d, const float* p) { d.v = ld4(p); }
+__device__ __forceinline__ void ldraw(Raw4<bf16_t>& d, const bf16_t* p) { d.v = *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ void zraw(Raw4<float>& d) { d.v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zraw(Raw4<bf16_t>& d) { d.v = make_uint2(0u, 0u); }
+__device__ __forceinline__ float4 unraw(const Raw4<float>& d) { return d.v; }
+__device__ __forceinline__ float4 unraw(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 unraw(const Raw4<bf16_t>& d) { return unraw(d.v); }
+
+// the value a later kernel will read back from the stored image (bf16 streams: what was computed from must equal what is stored,
+// or the backward's recomputation of x from R would differ from the forward's)
+template <typename RT> __device__ __forceinline__ float4 as_stored(float4 v) {
+    if constexpr (sizeof(RT) == 4) return v;
+    else {
+        const uint32_t a = pack_bf2(v.x, v.y), b = pack_bf2(v.z, v.w);
+        return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u));
+    }
+}
 __device__ __forceinline__ float& f4(float4& v, int c) { return reinterpret_cast<float*>(&v)[c]; }
 __device__ __forceinline__ float f4c(const float4& v, int c) { return reinterpret_cast<const float*>(&v)[c]; }
 
@@ -86,10 +118,11 @@ __device__ __forceinline__ float token_combine(float tot, float* red, int tok, i
 }
 
 struct HcFwdArgs {
-    const float* R_in; int rin_bcast;                     // residual streams [B][S][N][D], or (rin_bcast) ONE [B*N][D] tensor every stream equals (:524)
-    const bf16_t* y; long long ldy; const float* coef_prev; float* R_out;
+    const void* R_in; int rin_bcast;                      // residual streams RT [B][S][N][D], or (rin_bcast) ONE fp32 [B*N][D] tensor every stream equals (:524)
+    const bf16_t* y; long long ldy; const float* coef_prev; void* R_out;
     HcParams hp; const float* ln_gamma;
     bf16_t* x_out; long long ldx; bf16_t* xn_out; long long ldxn; float* mean_out; float* rstd_out; float* coef; float* xs_out;
+    float* xn32_out;                                      // FINAL: the final LayerNorm output in fp32 [B*N][D] instead of bf16 xn_out (logit heads)
     int B, N, D;
 };
 
@@ -97,9 +130,14 @@ struct HcFwdArgs {
 //   DEPTH: r_t = sum_s alpha_p[s][t+1] R_in[s] + beta_p[t] y       (written to R_out unless FINAL)
 //   WIDTH: coefficients of the next branch from r, x = sum_s alpha[s][0] r_s, xn = LN(x) * ln_gamma
 //   FINAL: xs = sum_t r_t (reference audiolm_pytorch.py:551), xn = LN(xs) * ln_gamma (:555)
-template <int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
+// PF: software prefetch (bf16 streams, no `rin_bcast`): the NEXT token's loads are issued before this token is processed, so the HBM latency
+// hides under the reductions instead of heading every iteration.  The loop is unrolled by two over a pair of register sets (no copies: the
+// loads stay in flight until the set is unpacked); loads are unconditional on a clamped token (a skipped token re-reads token 0).
+template <typename RT, int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL, bool PF>
 __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     using C = Coef<S>;
+    const RT* const Rin = reinterpret_cast<const RT*>(a.R_in);
+    RT* const Rout = reinterpret_cast<RT*>(a.R_out);
     constexpr int TPB = 4 / WPT;
     constexpr int NV = (S >= 3) ? 32 : 16;                       // slots: ss[S] | dots[S][S+2] | sums[S]  (S = 4: 32, 3: 21, 2: 12)
     constexpr int O_DOT = S, O_SUM = S + S * (S + 2);
@@ -135,35 +173,68 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     const long long sND = (long long)a.N * a.D;                              // stream stride of R
     // token coordinates (b, n) advance incrementally: no 64-bit divisions in the loop; `valid` is wave-uniform, so the loads sit in ONE
     // uniform branch instead of an exec-masked region each
-    unsigned bb, nn;
+    unsigned bb, nn;                                                         // coordinates of the token whose loads are issued next
     {
         const unsigned m0 = (unsigned)(blockIdx.x * TPB + tok);
         bb = m0 / (unsigned)a.N;
         nn = m0 % (unsigned)a.N;
     }
     const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
-    for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
-        const long long m = it * TPB + tok;
-        const bool valid = m < M;
-        const int b = (int)bb, n = (int)nn;
+    struct Tok { long long m; int b, n; bool valid; };
+    auto next_tok = [&](long long it_) {
+        Tok t;
+        t.m = it_ * TPB + tok;
+        t.b = (int)bb; t.n = (int)nn;
+        t.valid = it_ < niter && t.m < M;
         bb += sbb; nn += snn;
         if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
+        return t;
+    };
+    struct In { Raw4<RT> r[S]; float4 rb; uint2 y; };                        // one token's inputs as loaded
+    auto issue_pf = [&](In& in, const Tok& t) {
+        const long long m_ = t.valid ? t.m : 0;
+        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = eok ? e0 : 0;
+        const RT* Rt = Rin + ((long long)b_ * S * a.N + n_) * a.D + el;
+#pragma unroll
+        for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
+        if (DEPTH) in.y = *reinterpret_cast<const uint2*>(a.y + m_ * a.ldy + el);
+    };
+    auto issue_plain = [&](In& in, const Tok& t) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) zraw(in.r[s]);
+        in.rb = z4;
+        in.y = make_uint2(0u, 0u);
+        if (t.valid && eok) {
+            if (a.rin_bcast) {
+                in.rb = ld4(reinterpret_cast<const float*>(a.R_in) + t.m * a.D + e0);
+            } else {
+                const RT* Rt = Rin + ((long long)t.b * S * a.N + t.n) * a.D + e0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
+            }
+            if (DEPTH) in.y = *reinterpret_cast<const uint2*>(a.y + t.m * a.ldy + e0);
+        }
+    };
+    auto process = [&](const In& in, const Tok& t) {
+        const long long m = t.m;
+        const bool valid = t.valid;
+        const int b = t.b, n = t.n;
         const bool ld_ok = valid && eok;
         float4 r[S];
         float4 yv = z4;
+        if (PF) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) r[s] = z4;
-        if (ld_ok) {
+            for (int s = 0; s < S; ++s) r[s] = ld_ok ? unraw(in.r[s]) : z4;
+            if (DEPTH) yv = ld_ok ? unraw(in.y) : z4;
+        } else {
             if (a.rin_bcast) {
-                const float4 rb = ld4(a.R_in + m * a.D + e0);
 #pragma unroll
-                for (int s = 0; s < S; ++s) r[s] = rb;
+                for (int s = 0; s < S; ++s) r[s] = in.rb;
             } else {
-                const float* Rt = a.R_in + ((long long)b * S * a.N + n) * a.D + e0;
 #pragma unroll
-                for (int s = 0; s < S; ++s) r[s] = ld4(Rt + s * sND);
+                for (int s = 0; s < S; ++s) r[s] = unraw(in.r[s]);
             }
-            if (DEPTH) yv = ld4bf(a.y + m * a.ldy + e0);
+            if (DEPTH) yv = unraw(in.y);
         }
         if (DEPTH) {
             const float* cp = a.coef_prev + (valid ? m : 0) * C::W;
@@ -180,8 +251,8 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < S; ++t) {
-                r[t] = o[t];
-                if (!FINAL && ld_ok) *reinterpret_cast<float4*>(a.R_out + (((long long)b * S + t) * a.N + n) * a.D + e0) = o[t];
+                r[t] = FINAL ? o[t] : as_stored<RT>(o[t]);
+                if (!FINAL && ld_ok) stR(Rout + (((long long)b * S + t) * a.N + n) * a.D + e0, o[t]);
             }
         }
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,25 +337,48 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
             }
             const float rstd = rsqrtf(q / (float)a.D + LN_EPS);
             if (ld_ok) {
-                st4bf(a.xn_out + m * a.ldxn + e0, make_float4((x.x - mean) * rstd * lng.x, (x.y - mean) * rstd * lng.y,
-                                                             (x.z - mean) * rstd * lng.z, (x.w - mean) * rstd * lng.w));
+                const float4 xnv = make_float4((x.x - mean) * rstd * lng.x, (x.y - mean) * rstd * lng.y, (x.z - mean) * rstd * lng.z,
+                                               (x.w - mean) * rstd * lng.w);
+                if (FINAL && a.xn32_out) *reinterpret_cast<float4*>(a.xn32_out + m * a.D + e0) = xnv;
+                else st4bf(a.xn_out + m * a.ldxn + e0, xnv);
                 if (WIDTH && a.x_out) st4bf(a.x_out + m * a.ldx + e0, x);
             }
             if (valid && wv == 0 && lane == 0) { a.mean_out[m] = mean; a.rstd_out[m] = rstd; }
+        }
+    };
+    if constexpr (PF) {
+        In wa, wb2;
+        Tok ta = next_tok(blockIdx.x), tb = ta;
+        issue_pf(wa, ta);
+        for (long long it = blockIdx.x; it < niter; it += 2 * (long long)gridDim.x) {
+            tb = next_tok(it + gridDim.x);
+            issue_pf(wb2, tb);
+            process(wa, ta);
+            if (it + gridDim.x >= niter) break;
+            ta = next_tok(it + 2 * (long long)gridDim.x);
+            issue_pf(wa, ta);
+            process(wb2, tb);
+        }
+    } else {
+        for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+            const Tok t = next_tok(it);
+            In w;
+            issue_plain(w, t);
+            process(w, t);
         }
     }
 }
 
 struct HcBwdArgs {
-    const float* dRn; int bcast;                         // gradient wrt the width connection's residual output: [B][S][N][D], or (bcast) [M][D] shared by all streams
+    const void* dRn; int bcast;                          // gradient wrt the width connection's residual output: RT [B][S][N][D], or (bcast) fp32 [M][D] shared by all streams
     const float* dx; long long lddx;                     // gradient wrt the branch input x (fp32)                      [LNF == false]
     const bf16_t* dxn; long long lddxn;                  // gradient wrt the branch's pre-LayerNorm OUTPUT xn (bf16)     [LNF == true]
     const bf16_t* extra; long long ldex;                 //   + gradient arriving at x directly (attention: the K/V path), or NULL
     const float* mean; const float* rstd; const float* ln_gamma;        //   LayerNorm statistics saved by the forward, LN weight
-    const float* R; int r_bcast;                         // residual input of the width connection ([B][S][N][D], or one [B*N][D] tensor for all streams)
+    const void* R; int r_bcast;                          // residual input of the width connection (RT [B][S][N][D], or one fp32 [B*N][D] tensor for all streams)
     const float* coef; const float* dbeta;
     HcParams hp;
-    float* dR; float* dsum;                              // dR [B][S][N][D] and / or dsum [B*N][D] = sum over streams of dR (gradient of the :524 expand)
+    void* dR; float* dsum;                               // dR RT [B][S][N][D] and / or dsum fp32 [B*N][D] = sum over streams of dR (gradient of the :524 expand)
     float* partial;
     const bf16_t* y; long long ldy; const float* coef_prev; bf16_t* dy; long long lddy; float* dbeta_out;
     int B, N, D;
@@ -300,9 +394,12 @@ struct HcBwdArgs {
 //          separate LayerNorm-backward launch exist on the 4-stream path.
 // partial row (floats): raw_a[S+1][D] | raw_b[D] | dln[D] | dAa[S][S+1] | dBb[S] | dsa | dsb   with raw_* = sum over tokens, streams of
 // nhat * (dap | dbp): dWa = (gamma+1) raw_a, dwb = (gamma+1) raw_b, dgamma = sum_t Wa raw_a + wb raw_b  (alm_hc_param_grads).
-template <int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF>      // PF: see hc_fwd_kernel (needs no bcast / r_bcast)
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
+    const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
+    const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
+    RT* const dRo = reinterpret_cast<RT*>(a.dR);
     constexpr int TPB = 4 / WPT;
     constexpr int NV = (S >= 3) ? 32 : 16;                       // width slots: dal[S][S+1] | (LNF) sum R_s [S] | <xhat, R_s> [S] | sum g | sum g xhat
     constexpr int NB = S * (S + 1);
@@ -340,53 +437,113 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     const long long niter = (M + TPB - 1) / TPB;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long sND = (long long)a.N * a.D;
-    unsigned bb, nn;                                                         // incremental token coordinates (see hc_fwd_kernel)
+    unsigned bb, nn;                                                         // coordinates of the token whose loads are issued next (see hc_fwd_kernel)
     {
         const unsigned m0 = (unsigned)(blockIdx.x * TPB + tok);
         bb = m0 / (unsigned)a.N;
         nn = m0 % (unsigned)a.N;
     }
     const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
-    int par = 0;
-    for (long long it = blockIdx.x; it < niter; it += gridDim.x, par ^= 1) {
-        const long long m = it * TPB + tok;
-        const bool valid = m < M;
-        const int b = (int)bb, n = (int)nn;
+    struct Tok { long long m; int b, n; bool valid; };
+    auto next_tok = [&](long long it_) {
+        Tok t;
+        t.m = it_ * TPB + tok;
+        t.b = (int)bb; t.n = (int)nn;
+        t.valid = it_ < niter && t.m < M;
         bb += sbb; nn += snn;
         if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
-        const bool ld_ok = valid && eok;
-        float4 g[S], r_c[S];
-        float4 dx_c = z4, yv = z4, ex_c = z4;
+        return t;
+    };
+    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; };   // one token's inputs as loaded
+    auto issue_pf = [&](In& w, const Tok& t) {
+        const long long m_ = t.valid ? t.m : 0;
+        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = eok ? e0 : 0;
+        const long long tofs = ((long long)b_ * S * a.N + n_) * a.D + el;
 #pragma unroll
-        for (int t = 0; t < S; ++t) { g[t] = z4; r_c[t] = z4; }
-        if (ld_ok) {
-            const long long tofs = ((long long)b * S * a.N + n) * a.D + e0;
+        for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
+        if (WIDTH) {
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
+            if (LNF) {
+                w.dxn = *reinterpret_cast<const uint2*>(a.dxn + m_ * a.lddxn + el);
+                w.ex = make_uint2(0u, 0u);
+                if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + m_ * a.ldex + el);
+            } else {
+                w.dx = ld4(a.dx + m_ * a.lddx + el);
+            }
+        }
+        if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + m_ * a.ldy + el);
+    };
+    auto issue_plain = [&](In& w, const Tok& t) {
+#pragma unroll
+        for (int t2 = 0; t2 < S; ++t2) { zraw(w.g[t2]); zraw(w.r[t2]); }
+        w.gb = w.rb = w.dx = z4;
+        w.dxn = w.ex = w.y = make_uint2(0u, 0u);
+        if (t.valid && eok) {
+            const long long tofs = ((long long)t.b * S * a.N + t.n) * a.D + e0;
             if (a.bcast) {
-                const float4 gb = ld4(a.dRn + m * a.D + e0);
-#pragma unroll
-                for (int t = 0; t < S; ++t) g[t] = gb;
+                w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + t.m * a.D + e0);
             } else {
 #pragma unroll
-                for (int t = 0; t < S; ++t) g[t] = ld4(a.dRn + tofs + t * sND);
+                for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
             }
             if (WIDTH) {
                 if (a.r_bcast) {
-                    const float4 rb = ld4(a.R + m * a.D + e0);
-#pragma unroll
-                    for (int s2 = 0; s2 < S; ++s2) r_c[s2] = rb;
+                    w.rb = ld4(reinterpret_cast<const float*>(a.R) + t.m * a.D + e0);
                 } else {
 #pragma unroll
-                    for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld4(a.R + tofs + s2 * sND);
+                    for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
                 }
                 if (LNF) {
-                    dx_c = ld4bf(a.dxn + m * a.lddxn + e0);                      // dxn (bf16) travels in dx_c
-                    if (a.extra) ex_c = ld4bf(a.extra + m * a.ldex + e0);
+                    w.dxn = *reinterpret_cast<const uint2*>(a.dxn + t.m * a.lddxn + e0);
+                    if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + t.m * a.ldex + e0);
                 } else {
-                    dx_c = ld4(a.dx + m * a.lddx + e0);
+                    w.dx = ld4(a.dx + t.m * a.lddx + e0);
                 }
             }
-            if (DEPTH) yv = ld4bf(a.y + m * a.ldy + e0);
+            if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + t.m * a.ldy + e0);
         }
+    };
+    int par = 0;
+    auto process = [&](const In& w, const Tok& t) {
+        const long long m = t.m;
+        const bool valid = t.valid;
+        const int b = t.b, n = t.n;
+        const bool ld_ok = valid && eok;
+        float4 g[S], r_c[S];
+        float4 dx_c = z4, yv = z4, ex_c = z4;
+        if (PF) {
+#pragma unroll
+            for (int t2 = 0; t2 < S; ++t2) g[t2] = ld_ok ? unraw(w.g[t2]) : z4;
+        } else if (a.bcast) {
+#pragma unroll
+            for (int t2 = 0; t2 < S; ++t2) g[t2] = w.gb;
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < S; ++t2) g[t2] = unraw(w.g[t2]);
+        }
+        if (WIDTH) {
+            if (PF) {
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld_ok ? unraw(w.r[s2]) : z4;
+            } else if (a.r_bcast) {
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = w.rb;
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = unraw(w.r[s2]);
+            }
+            if (LNF) {
+                dx_c = (!PF || ld_ok) ? unraw(w.dxn) : z4;                       // dxn (bf16) travels in dx_c
+                ex_c = (!PF || ld_ok) ? unraw(w.ex) : z4;
+            } else {
+                dx_c = (!PF || ld_ok) ? w.dx : z4;
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) r_c[s2] = z4;
+        }
+        if (DEPTH) yv = (!PF || ld_ok) ? unraw(w.y) : z4;
         float4 out[S];
         if (WIDTH) {
             float4 r[S];
@@ -490,7 +647,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             if (ld_ok) {
                 if (a.dR) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) *reinterpret_cast<float4*>(a.dR + (((long long)b * S + s) * a.N + n) * a.D + e0) = out[s];
+                    for (int s = 0; s < S; ++s) stR(dRo + (((long long)b * S + s) * a.N + n) * a.D + e0, out[s]);
                 }
                 if (a.dsum) {
                     float4 sm = out[0];
@@ -526,6 +683,28 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 for (int w2 = 0; w2 < WPT; ++w2) db += rd[(tok * WPT + w2) * 4 + (lane & 3)];
             }
             if (valid && wv == 0 && lane < S) a.dbeta_out[m * S + lane] = db;
+        }
+        par ^= 1;
+    };
+    if constexpr (PF) {
+        In wa, wb2;
+        Tok ta = next_tok(blockIdx.x), tb = ta;
+        issue_pf(wa, ta);
+        for (long long it = blockIdx.x; it < niter; it += 2 * (long long)gridDim.x) {
+            tb = next_tok(it + gridDim.x);
+            issue_pf(wb2, tb);
+            process(wa, ta);
+            if (it + gridDim.x >= niter) break;
+            ta = next_tok(it + 2 * (long long)gridDim.x);
+            issue_pf(wa, ta);
+            process(wb2, tb);
+        }
+    } else {
+        for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+            const Tok t = next_tok(it);
+            In w;
+            issue_plain(w, t);
+            process(w, t);
         }
     }
 
@@ -650,28 +829,35 @@ int hc_grid(long long M, int tpb, int resident) {
 }
 int hc_wpt(int D) { return D <= 256 ? 1 : (D <= 512 ? 2 : 4); }
 
-template <int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
-void launch_fwd_w(const HcFwdArgs& a, hipStream_t st) {
+template <typename RT, int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL, bool PF>
+void launch_fwd_p(const HcFwdArgs& a, hipStream_t st) {
     static int resident = 0;                                   // idempotent lazy query (same value from every thread)
-    auto k = hc_fwd_kernel<S, WPT, DEPTH, WIDTH, FINAL>;
+    auto k = hc_fwd_kernel<RT, S, WPT, DEPTH, WIDTH, FINAL, PF>;
     if (!resident) resident = resident_blocks(k);
     hipLaunchKernelGGL(k, dim3(hc_grid((long long)a.B * a.N, 4 / WPT, resident)), dim3(256), 0, st, a);
 }
-template <int S, bool DEPTH, bool WIDTH, bool FINAL>
+template <typename RT, int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
+void launch_fwd_w(const HcFwdArgs& a, hipStream_t st) {
+    if constexpr (sizeof(RT) == 2) {
+        if (!a.rin_bcast) return launch_fwd_p<RT, S, WPT, DEPTH, WIDTH, FINAL, true>(a, st);
+    }
+    launch_fwd_p<RT, S, WPT, DEPTH, WIDTH, FINAL, false>(a, st);
+}
+template <typename RT, int S, bool DEPTH, bool WIDTH, bool FINAL>
 int launch_fwd(const HcFwdArgs& a, hipStream_t st) {
     const int wpt = hc_wpt(a.D);
-    if (wpt == 1) launch_fwd_w<S, 1, DEPTH, WIDTH, FINAL>(a, st);
-    else if (wpt == 2) launch_fwd_w<S, 2, DEPTH, WIDTH, FINAL>(a, st);
-    else launch_fwd_w<S, 4, DEPTH, WIDTH, FINAL>(a, st);
+    if (wpt == 1) launch_fwd_w<RT, S, 1, DEPTH, WIDTH, FINAL>(a, st);
+    else if (wpt == 2) launch_fwd_w<RT, S, 2, DEPTH, WIDTH, FINAL>(a, st);
+    else launch_fwd_w<RT, S, 4, DEPTH, WIDTH, FINAL>(a, st);
     return 0;
 }
-template <int S>
+template <typename RT, int S>
 int dispatch_fwd(const HcFwdArgs& a, int mode, hipStream_t st) {
     switch (mode) {
-        case 1: return launch_fwd<S, true, false, false>(a, st);
-        case 2: return launch_fwd<S, false, true, false>(a, st);
-        case 3: return launch_fwd<S, true, true, false>(a, st);
-        case 5: return launch_fwd<S, true, false, true>(a, st);
+        case 1: return launch_fwd<RT, S, true, false, false>(a, st);
+        case 2: return launch_fwd<RT, S, false, true, false>(a, st);
+        case 3: return launch_fwd<RT, S, true, true, false>(a, st);
+        case 5: return launch_fwd<RT, S, true, false, true>(a, st);
         default: return ALM_ERR_BAD_ARG;
     }
 }
@@ -679,45 +865,95 @@ int dispatch_fwd(const HcFwdArgs& a, int mode, hipStream_t st) {
 // upper bound of the workgroup count of the backward kernel (sizes the partial-row buffer; the launch may use fewer)
 int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 256 * 4); }
 
-template <int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
-int bwd_grid_w(long long M, int D) {
+// the prefetching variant needs more registers and may be resident in fewer copies: the partial-row buffer is sized for the larger of the
+// two grids (a launch may then use fewer rows than alm_hc_partial_rows reported: the surplus rows are zeroed by the launch wrapper)
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF>
+int bwd_grid_p(long long M, int D) {
     static int resident = 0;
-    if (!resident) resident = resident_blocks(hc_bwd_kernel<S, WPT, WIDTH, DEPTH, LNF>);
+    if (!resident) resident = resident_blocks(hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, PF>);
     const int cap = hc_bwd_blocks(M, D);
     const int grid = hc_grid(M, 4 / WPT, resident);
     return grid > cap ? cap : grid;
 }
-template <int S, bool WIDTH, bool DEPTH, bool LNF>
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
+int bwd_grid_w(long long M, int D) {
+    int g = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, D);
+    if constexpr (sizeof(RT) == 2) {
+        const int g2 = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true>(M, D);
+        g = g2 > g ? g2 : g;
+    }
+    return g;
+}
+template <typename RT, int S, bool WIDTH, bool DEPTH, bool LNF>
 int bwd_grid(long long M, int D) {
     const int wpt = hc_wpt(D);
-    if (wpt == 1) return bwd_grid_w<S, 1, WIDTH, DEPTH, LNF>(M, D);
-    if (wpt == 2) return bwd_grid_w<S, 2, WIDTH, DEPTH, LNF>(M, D);
-    return bwd_grid_w<S, 4, WIDTH, DEPTH, LNF>(M, D);
+    if (wpt == 1) return bwd_grid_w<RT, S, 1, WIDTH, DEPTH, LNF>(M, D);
+    if (wpt == 2) return bwd_grid_w<RT, S, 2, WIDTH, DEPTH, LNF>(M, D);
+    return bwd_grid_w<RT, S, 4, WIDTH, DEPTH, LNF>(M, D);
 }
-template <int S, bool WIDTH, bool DEPTH, bool LNF>
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
+void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
+    const long long M = (long long)a.B * a.N;
+    const int rows_alloc = (4 / WPT) * bwd_grid_w<RT, S, WPT, WIDTH, DEPTH, LNF>(M, a.D);     // what alm_hc_partial_rows reported
+    bool pf = false;
+    if constexpr (sizeof(RT) == 2) pf = !a.bcast && !a.r_bcast;
+    int grid;
+    if constexpr (sizeof(RT) == 2) grid = pf ? bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true>(M, a.D) : bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
+    else grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
+    if (WIDTH && a.partial) {
+        const int rows_used = (4 / WPT) * grid;
+        const long long P = (long long)a.D * (S + 3) + S * (S + 1) + S + 2;
+        if (rows_used < rows_alloc) (void)hipMemsetAsync(a.partial + (long long)rows_used * P, 0, (size_t)(rows_alloc - rows_used) * P * sizeof(float), st);
+    }
+    if constexpr (sizeof(RT) == 2) {
+        if (pf) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true>), dim3(grid), dim3(256), 0, st, a); return; }
+    }
+    hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, false>), dim3(grid), dim3(256), 0, st, a);
+}
+template <typename RT, int S, bool WIDTH, bool DEPTH, bool LNF>
 int launch_bwd(const HcBwdArgs& a, hipStream_t st) {
     const int wpt = hc_wpt(a.D);
-    const int grid = bwd_grid<S, WIDTH, DEPTH, LNF>((long long)a.B * a.N, a.D);
-    if (wpt == 1) hipLaunchKernelGGL((hc_bwd_kernel<S, 1, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
-    else if (wpt == 2) hipLaunchKernelGGL((hc_bwd_kernel<S, 2, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((hc_bwd_kernel<S, 4, WIDTH, DEPTH, LNF>), dim3(grid), dim3(256), 0, st, a);
+    if (wpt == 1) launch_bwd_w<RT, S, 1, WIDTH, DEPTH, LNF>(a, st);
+    else if (wpt == 2) launch_bwd_w<RT, S, 2, WIDTH, DEPTH, LNF>(a, st);
+    else launch_bwd_w<RT, S, 4, WIDTH, DEPTH, LNF>(a, st);
     return 0;
 }
-template <int S>
+template <typename RT, int S>
 int bwd_rows(int mode, bool lnf, long long M, int D) {
     const int tpb = 4 / hc_wpt(D);
-    if (mode == 2) return tpb * (lnf ? bwd_grid<S, true, false, true>(M, D) : bwd_grid<S, true, false, false>(M, D));
-    if (mode == 3) return tpb * (lnf ? bwd_grid<S, true, true, true>(M, D) : bwd_grid<S, true, true, false>(M, D));
+    if (mode == 2) return tpb * (lnf ? bwd_grid<RT, S, true, false, true>(M, D) : bwd_grid<RT, S, true, false, false>(M, D));
+    if (mode == 3) return tpb * (lnf ? bwd_grid<RT, S, true, true, true>(M, D) : bwd_grid<RT, S, true, true, false>(M, D));
     return 0;
 }
-template <int S>
+template <typename RT, int S>
 int dispatch_bwd(const HcBwdArgs& a, int mode, bool lnf, hipStream_t st) {
     switch (mode) {
-        case 1: return launch_bwd<S, false, true, false>(a, st);
-        case 2: return lnf ? launch_bwd<S, true, false, true>(a, st) : launch_bwd<S, true, false, false>(a, st);
-        case 3: return lnf ? launch_bwd<S, true, true, true>(a, st) : launch_bwd<S, true, true, false>(a, st);
+        case 1: return launch_bwd<RT, S, false, true, false>(a, st);
+        case 2: return lnf ? launch_bwd<RT, S, true, false, true>(a, st) : launch_bwd<RT, S, true, false, false>(a, st);
+        case 3: return lnf ? launch_bwd<RT, S, true, true, true>(a, st) : launch_bwd<RT, S, true, true, false>(a, st);
         default: return ALM_ERR_BAD_ARG;
     }
+}
+template <typename RT>
+int bwd_rows_s(int mode, bool lnf, int S, long long M, int D) {
+    if (S == 2) return bwd_rows<RT, 2>(mode, lnf, M, D);
+    if (S == 3) return bwd_rows<RT, 3>(mode, lnf, M, D);
+    if (S == 4) return bwd_rows<RT, 4>(mode, lnf, M, D);
+    return 0;
+}
+template <typename RT>
+int dispatch_fwd_s(const HcFwdArgs& a, int S, int mode, hipStream_t st) {
+    if (S == 2) return dispatch_fwd<RT, 2>(a, mode, st);
+    if (S == 3) return dispatch_fwd<RT, 3>(a, mode, st);
+    if (S == 4) return dispatch_fwd<RT, 4>(a, mode, st);
+    return ALM_ERR_UNSUPPORTED;
+}
+template <typename RT>
+int dispatch_bwd_s(const HcBwdArgs& a, int S, int mode, bool lnf, hipStream_t st) {
+    if (S == 2) return dispatch_bwd<RT, 2>(a, mode, lnf, st);
+    if (S == 3) return dispatch_bwd<RT, 3>(a, mode, lnf, st);
+    if (S == 4) return dispatch_bwd<RT, 4>(a, mode, lnf, st);
+    return ALM_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -725,31 +961,25 @@ int dispatch_bwd(const HcBwdArgs& a, int mode, bool lnf, hipStream_t st) {
 extern "C" int alm_hc_coef_width(int S) { return 2 * S * (S + 1) + 3 * S; }
 extern "C" int alm_hc_partial_width(int S, int D) { return D * (S + 3) + S * (S + 1) + S + 2; }
 extern "C" int alm_hc_grads_width(int S, int D) { return D * (S + 4) + S * (S + 1) + S + 2; }
-/* number of partial rows alm_hc_bwd writes for (mode, fused-LayerNorm or not): one per RESIDENT workgroup and token slot */
-extern "C" int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D) {
-    if (S == 2) return bwd_rows<2>(mode, fused_ln != 0, tokens, D);
-    if (S == 3) return bwd_rows<3>(mode, fused_ln != 0, tokens, D);
-    if (S == 4) return bwd_rows<4>(mode, fused_ln != 0, tokens, D);
-    return 0;
+/* number of partial rows alm_hc_bwd writes for (mode, fused-LayerNorm or not, stream storage type): one per RESIDENT workgroup and token slot */
+extern "C" int alm_hc_partial_rows(int mode, int fused_ln, int r_bf16, int S, long long tokens, int D) {
+    return r_bf16 ? bwd_rows_s<bf16_t>(mode, fused_ln != 0, S, tokens, D) : bwd_rows_s<float>(mode, fused_ln != 0, S, tokens, D);
 }
 
 // mode: 1 = depth connection only (-> R_out), 2 = width connection only, 3 = depth (previous branch) + width (next branch) fused,
-//       5 = depth + stream sum + final LayerNorm (-> xs_out fp32, xn_out bf16, mean, rstd; R_out is not written)
-extern "C" int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
-                          const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb,
-                          const float* ln_gamma, void* x_out, long long ldx, void* xn_out, long long ldxn, float* mean, float* rstd,
-                          float* coef, float* xs_out, int mode, int B, int S, int N, int D, void* stream) {
+//       5 = depth + stream sum + final LayerNorm (-> xs_out fp32, xn_out bf16 or xn32_out fp32, mean, rstd; R_out is not written)
+// r_bf16: R_in (unless rin_bcast) / R_out hold bf16 instead of fp32.
+extern "C" int alm_hc_fwd(const void* R_in, int rin_bcast, int r_bf16, const void* y_prev, long long ldy, const float* coef_prev, void* R_out,
+                          const float* hc_gamma, const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb,
+                          const float* Bb, const float* ln_gamma, void* x_out, long long ldx, void* xn_out, long long ldxn, float* xn32_out,
+                          float* mean, float* rstd, float* coef, float* xs_out, int mode, int B, int S, int N, int D, void* stream) {
     if ((D & 3) || D > 1024 || (ldx & 3) || (ldxn & 3) || (ldy & 3)) return ALM_ERR_BAD_ARG;
     if ((mode & 1) && (!y_prev || !coef_prev || (!(mode & 4) && !R_out))) return ALM_ERR_BAD_ARG;
     if ((mode & 2) && (!hc_gamma || !Wa || !sa || !Aa || !wb || !sb || !Bb || !ln_gamma || !xn_out || !mean || !rstd || !coef)) return ALM_ERR_BAD_ARG;
-    if ((mode & 4) && (!ln_gamma || !xn_out || !mean || !rstd || !xs_out)) return ALM_ERR_BAD_ARG;
+    if ((mode & 4) && (!ln_gamma || !(xn_out || xn32_out) || !mean || !rstd || !xs_out)) return ALM_ERR_BAD_ARG;
     HcFwdArgs a{R_in, rin_bcast, (const bf16_t*)y_prev, ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
-                (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, B, N, D};
-    int rc;
-    if (S == 2) rc = dispatch_fwd<2>(a, mode, (hipStream_t)stream);
-    else if (S == 3) rc = dispatch_fwd<3>(a, mode, (hipStream_t)stream);
-    else if (S == 4) rc = dispatch_fwd<4>(a, mode, (hipStream_t)stream);
-    else return ALM_ERR_UNSUPPORTED;
+                (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, xn32_out, B, N, D};
+    const int rc = r_bf16 ? dispatch_fwd_s<bf16_t>(a, S, mode, (hipStream_t)stream) : dispatch_fwd_s<float>(a, S, mode, (hipStream_t)stream);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
@@ -757,12 +987,13 @@ extern "C" int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev, 
 
 // mode: 1 = depth-connection backward only (dy, dbeta_out from dRn), 2 = width-connection backward only (dR, partial),
 //       3 = width backward of branch k+1 followed by the depth backward of branch k on the freshly computed dR.
-// dRn_bcast != 0: dRn is [B*N][D] and stands for all S streams (the gradient of the final stream sum, audiolm_pytorch.py:551).
-// partial: [alm_hc_partial_rows(B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads.
-extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn, long long lddxn, const void* extra,
-                          long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, int r_bcast,
+// dRn_bcast != 0: dRn is fp32 [B*N][D] and stands for all S streams (the gradient of the final stream sum, audiolm_pytorch.py:551).
+// r_bf16: dRn (unless dRn_bcast), R (unless r_bcast) and dR hold bf16 instead of fp32.
+// partial: [alm_hc_partial_rows(...)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads.
+extern "C" int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const float* dx, long long lddx, const void* dxn, long long lddxn, const void* extra,
+                          long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const void* R, int r_bcast,
                           const float* coef, const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb,
-                          const float* sb, float* dR, float* dsum, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
+                          const float* sb, void* dR, float* dsum, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
                           float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
     if ((D & 3) || D > 1024 || (lddx & 3) || (lddxn & 3) || (ldex & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
     const bool lnf = dxn != nullptr;
@@ -773,11 +1004,7 @@ extern "C" int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long
     HcBwdArgs a{dRn, dRn_bcast, dx, lddx, (const bf16_t*)dxn, lddxn, (const bf16_t*)extra, ldex, mean, rstd, ln_gamma, R, r_bcast, coef, dbeta,
                 HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, partial, (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out,
                 B, N, D};
-    int rc;
-    if (S == 2) rc = dispatch_bwd<2>(a, mode, lnf, (hipStream_t)stream);
-    else if (S == 3) rc = dispatch_bwd<3>(a, mode, lnf, (hipStream_t)stream);
-    else if (S == 4) rc = dispatch_bwd<4>(a, mode, lnf, (hipStream_t)stream);
-    else return ALM_ERR_UNSUPPORTED;
+    const int rc = r_bf16 ? dispatch_bwd_s<bf16_t>(a, S, mode, lnf, (hipStream_t)stream) : dispatch_bwd_s<float>(a, S, mode, lnf, (hipStream_t)stream);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;

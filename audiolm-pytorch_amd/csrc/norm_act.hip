@@ -26,9 +26,9 @@ __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
 // ------------------------------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * gamma.  NI = ceil(D / 256) chunks of 4 features per lane.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename TIN, int NI>
+template <typename TIN, typename TOUT, int NI>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, long long ldx, const float* __restrict__ gamma,
-                                                     bf16_t* __restrict__ y, long long ldy, bf16_t* __restrict__ xcopy, long long ldc,
+                                                     TOUT* __restrict__ y, long long ldy, bf16_t* __restrict__ xcopy, long long ldc,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int D) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
 // LayerNorm backward: g = dy * gamma ; dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ extra) ;
 // dgamma partial sums per block -> dgamma_part[gridDim.x][D] (reduced by colsum).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename TX, typename TDX, int NI>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, const TX* __restrict__ x, long long ldx,
+template <typename TDY, typename TX, typename TDX, int NI>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, long long lddy, const TX* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ extra, long long lde,
                                                      TDX* __restrict__ dx, long long lddx, float* __restrict__ dgamma_part, int rows, int D) {
@@ -338,22 +338,22 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
     }
 }
 
-template <typename TIN>
-int launch_ln_fwd(const TIN* x, long long ldx, const float* gamma, bf16_t* y, long long ldy, bf16_t* xc, long long ldc, float* mean,
+template <typename TIN, typename TOUT>
+int launch_ln_fwd(const TIN* x, long long ldx, const float* gamma, TOUT* y, long long ldy, bf16_t* xc, long long ldc, float* mean,
                   float* rstd, int rows, int D, hipStream_t st) {
     const int grid = min((rows + 3) / 4, 4096);
-    if (D <= 256) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 1>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
-    else if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 2>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
-    else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 4>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
-    else if (D <= 2048) hipLaunchKernelGGL((ln_fwd_kernel<TIN, 8>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    if (D <= 256) hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, 1>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 512) hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, 2>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, 4>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
+    else if (D <= 2048) hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, 8>), dim3(grid), dim3(256), 0, st, x, ldx, gamma, y, ldy, xc, ldc, mean, rstd, rows, D);
     else return ALM_ERR_UNSUPPORTED;
     return 0;
 }
 
-template <typename TX, typename TDX>
-int launch_ln_bwd(const bf16_t* dy, long long lddy, const TX* x, long long ldx, const float* mean, const float* rstd, const float* gamma,
+template <typename TDY, typename TX, typename TDX>
+int launch_ln_bwd(const TDY* dy, long long lddy, const TX* x, long long ldx, const float* mean, const float* rstd, const float* gamma,
                   const bf16_t* extra, long long lde, TDX* dx, long long lddx, float* part, int grid, int rows, int D, hipStream_t st) {
-#define ALM_LNB(NI) hipLaunchKernelGGL((ln_bwd_kernel<TX, TDX, NI>), dim3(grid), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, extra, lde, dx, lddx, part, rows, D)
+#define ALM_LNB(NI) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, NI>), dim3(grid), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, extra, lde, dx, lddx, part, rows, D)
     if (D <= 256) ALM_LNB(1);
     else if (D <= 512) ALM_LNB(2);
     else if (D <= 1024) ALM_LNB(4);
@@ -367,19 +367,25 @@ int launch_ln_bwd(const bf16_t* dy, long long lddy, const TX* x, long long ldx, 
 
 extern "C" int alm_ln_partial_blocks(int rows) { return min((rows + 3) / 4, 512); }
 
-extern "C" int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y, long long ldy, void* xcopy,
+extern "C" int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y, int y_is_f32, long long ldy, void* xcopy,
                                  long long ldc, float* mean, float* rstd, int rows, int D, void* stream) {
     if (rows <= 0) return 0;
     if ((D & 3) || (ldx & 3) || (ldy & 3) || (xcopy && (ldc & 3))) return ALM_ERR_BAD_ARG;
-    int rc = x_is_bf16 ? launch_ln_fwd((const bf16_t*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, (hipStream_t)stream)
-                       : launch_ln_fwd((const float*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (y_is_f32)
+        rc = x_is_bf16 ? launch_ln_fwd((const bf16_t*)x, ldx, gamma, (float*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, st)
+                       : launch_ln_fwd((const float*)x, ldx, gamma, (float*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, st);
+    else
+        rc = x_is_bf16 ? launch_ln_fwd((const bf16_t*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, st)
+                       : launch_ln_fwd((const float*)x, ldx, gamma, (bf16_t*)y, ldy, (bf16_t*)xcopy, ldc, mean, rstd, rows, D, st);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
 // dgamma_part must hold alm_ln_partial_blocks(rows) * D floats (or be NULL); reduce it with alm_colsum_f32.
-extern "C" int alm_layernorm_bwd(const void* dy, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
+extern "C" int alm_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
                                  const float* rstd, const float* gamma, const void* extra, long long lde, void* dx, int dx_is_bf16,
                                  long long lddx, float* dgamma_part, int rows, int D, void* stream) {
     if (rows <= 0) return 0;
@@ -387,7 +393,11 @@ extern "C" int alm_layernorm_bwd(const void* dy, long long lddy, const void* x, 
     const int grid = alm_ln_partial_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (x_is_bf16 && dx_is_bf16)
+    if (dy_is_f32) {
+        // fp32 upstream gradient: the final LayerNorm below the logit heads (fp32 x, fp32 dx)
+        if (x_is_bf16 || dx_is_bf16) return ALM_ERR_UNSUPPORTED;
+        rc = launch_ln_bwd((const float*)dy, lddy, (const float*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (float*)dx, lddx, dgamma_part, grid, rows, D, st);
+    } else if (x_is_bf16 && dx_is_bf16)
         rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (bf16_t*)dx, lddx, dgamma_part, grid, rows, D, st);
     else if (x_is_bf16)
         rc = launch_ln_bwd((const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)extra, lde, (float*)dx, lddx, dgamma_part, grid, rows, D, st);

@@ -6,6 +6,12 @@ head's token range always uses W[i mod Q] (the remainder rows continue the same 
 REGROUPED per quantizer ('b (n q) d -> q (b n) d', a row gather driven by an int32 index built from integer bookkeeping) and every
 head group becomes one batched MFMA GEMM over q with fp32 logits, followed by an online-softmax cross-entropy.  Rows that do not
 exist for a quantizer (the ragged tail) are padded with index -1 / label -1 and contribute nothing.
+
+Precision: the logits are where the loss is read off, so the heads do NOT round their operands to bf16.  The final hidden states arrive in
+fp32 (the final LayerNorm writes fp32) and the fp32 master weights are used: both are split into bf16 pairs x = hi + lo
+(alm_gather_split_bf16, ~16 mantissa bits) and logits = hi.Whi + hi.Wlo + lo.Whi runs as three accumulating bf16 MFMA GEMMs with fp32
+accumulation (the dropped lo.Wlo term is ~2^-16 relative).  The heads are < 2 % of the model FLOPs.  Backward (dgrad / wgrad) uses the
+bf16 halves hi / Whi, like every other GEMM of the path.
 """
 from __future__ import annotations
 
@@ -27,25 +33,36 @@ class HeadGroup:
 
 
 def _pack_head(w):
-    """fp32 [G, C, D] -> (bf16 [G, C, D], bf16 [G, D, Cpad])."""
+    """fp32 [G, C, D] -> (Whi bf16 [G, C, D], Wlo bf16 [G, C, D] (w ~= Whi + Wlo), WT bf16 [G, D, Cpad] = Whi^T zero padded)."""
     G, C, D = w.shape
     Cp = (C + 7) // 8 * 8
-    Wb = torch.empty((G, Cp, D), dtype=BF16, device=w.device)
     WT = torch.empty((G, D, Cp), dtype=BF16, device=w.device)
+    his, los = [], []
     for g in range(G):
-        ops.pack_weight(w[g], Wb[g], WT[g], rows_pad=Cp, cols_pad=D)
-    return Wb[:, :C], WT
+        hi, lo = ops.gather_split(w[g], None, rows_out=Cp)                  # rows C .. Cp-1 are zero
+        his.append(hi), los.append(lo)
+        ops.pack_weight(w[g], None, WT[g], rows_pad=Cp, cols_pad=D)
+    return torch.stack(his)[:, :C], torch.stack(los)[:, :C], WT
 
 
 def head_logits(hn, w3, bias, idx, cache, key):
-    """-> (hg bf16 [G*Rg, D], logits fp32 [G*Rg, Cpad] (first C columns valid))."""
+    """hn fp32 [M, D] (bf16 accepted: then there is no low half) -> (hg bf16 [G*Rg, D] = high halves of the gathered rows,
+    logits fp32 [G*Rg, Cpad] (first C columns valid))."""
     G, C, D = w3.shape
     Rg = idx.shape[1]
     Cp = (C + 7) // 8 * 8
-    Wb, _ = cache.get(key, w3, _pack_head)
-    hg = ops.gather_rows(hn, idx.reshape(-1))
+    Whi, Wlo, _ = cache.get(key, w3, _pack_head)
     logits = torch.empty((G, Rg, Cp), dtype=F32, device=hn.device)
-    ops.gemm_nt(hg.view(G, Rg, D), Wb, logits[:, :, :C], bias=bias)
+    out = logits[:, :, :C]
+    if hn.dtype == F32:
+        hg, hl = ops.gather_split(hn, idx.reshape(-1))
+        ops.gemm_nt(hg.view(G, Rg, D), Whi, out, bias=bias)
+        ops.gemm_nt(hg.view(G, Rg, D), Wlo, out, accumulate=True)
+        ops.gemm_nt(hl.view(G, Rg, D), Whi, out, accumulate=True)
+    else:
+        hg = ops.gather_rows(hn, idx.reshape(-1))
+        ops.gemm_nt(hg.view(G, Rg, D), Whi, out, bias=bias)
+        ops.gemm_nt(hg.view(G, Rg, D), Wlo, out, accumulate=True)
     return hg, logits.view(G * Rg, Cp)
 
 
@@ -68,14 +85,15 @@ class HeadsLossFn(torch.autograd.Function):
             loss_rows, lse = ops.cross_entropy_fwd(logits, labels, C)
             outs.append(ops.reduce_sum(loss_rows))
             saved.append((w3, b is not None, hg, logits, lse, labels))
-        ctx.saved, ctx.groups, ctx.cache, ctx.params, ctx.hn_shape = saved, groups, cache, params, hn.shape
+        ctx.saved, ctx.groups, ctx.cache, ctx.params, ctx.hn_shape, ctx.hn_dtype = saved, groups, cache, params, hn.shape, hn.dtype
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         M, D = ctx.hn_shape
         dev = gouts[0].device if gouts[0] is not None else ctx.saved[0][2].device
-        dhn = torch.zeros((M, D), dtype=BF16, device=dev)
+        f32 = ctx.hn_dtype == F32                  # fp32 hidden states in -> fp32 gradient out (what autograd expects; no conversion passes)
+        dhn = torch.zeros((M, D), dtype=ctx.hn_dtype, device=dev)
         grads = []
         for gi, (g, (w3, has_bias, hg, logits, lse, labels), go) in enumerate(zip(ctx.groups, ctx.saved, gouts)):
             G, C, _ = w3.shape
@@ -88,10 +106,13 @@ class HeadsLossFn(torch.autograd.Function):
                 continue
             gs = go.detach().to(F32).contiguous()
             dl = ops.cross_entropy_bwd(logits, labels, lse, gs, C, Cp)            # bf16 [G*Rg, Cp], pad columns zero
-            _, WT = ctx.cache.get(('head', g.name), w3, _pack_head)
-            dhg = torch.empty((G, Rg, D), dtype=BF16, device=dev)
+            _, _, WT = ctx.cache.get(('head', g.name), w3, _pack_head)
+            dhg = torch.empty((G, Rg, D), dtype=ctx.hn_dtype, device=dev)
             ops.gemm_nt(dl.view(G, Rg, Cp), WT, dhg)                              # dgrad: dlogits @ W
-            ops.scatter_rows(dhg.view(G * Rg, D), g.idx.reshape(-1), dhn)
+            if f32:                                                               # row copies are type-blind: fp32 rows = bf16 rows of twice the width
+                ops.scatter_rows(dhg.view(G * Rg, D).view(BF16), g.idx.reshape(-1), dhn.view(BF16))
+            else:
+                ops.scatter_rows(dhg.view(G * Rg, D), g.idx.reshape(-1), dhn)
             dW = torch.empty((G, C, D), dtype=F32, device=dev)
             for q in range(G):                                                    # wgrad: dlogits_q^T @ hidden_q
                 ops.gemm_tn_splitk(dl[q * Rg:(q + 1) * Rg, :C], hg[q * Rg:(q + 1) * Rg], dW[q])

@@ -132,15 +132,15 @@ def pack_weights_multi(jobs):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
 
-def layernorm_fwd(x, gamma, *, want_copy=False):
-    """x [rows, D] fp32|bf16 -> (y bf16, xcopy bf16|None, mean, rstd)."""
+def layernorm_fwd(x, gamma, *, want_copy=False, out_f32=False):
+    """x [rows, D] fp32|bf16 -> (y bf16 (fp32 with out_f32: the final LayerNorm feeding the logit heads), xcopy bf16|None, mean, rstd)."""
     _chk(x)
     rows, D, ld = _rows_ld(x)
-    y = torch.empty((rows, D), dtype=BF16, device=x.device)
+    y = torch.empty((rows, D), dtype=F32 if out_f32 else BF16, device=x.device)
     xc = torch.empty((rows, D), dtype=BF16, device=x.device) if want_copy else None
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
-    _lib.call('alm_layernorm_fwd', x.data_ptr(), int(x.dtype == BF16), ld, gamma.data_ptr(), y.data_ptr(), D, _p(xc), D, mean.data_ptr(),
+    _lib.call('alm_layernorm_fwd', x.data_ptr(), int(x.dtype == BF16), ld, gamma.data_ptr(), y.data_ptr(), int(out_f32), D, _p(xc), D, mean.data_ptr(),
               rstd.data_ptr(), rows, D, _st())
     return y, xc, mean, rstd
 
@@ -157,15 +157,16 @@ def colsum(inp, out=None, scale=1.0, accumulate=False):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, *, extra=None, dx_dtype=F32, want_dgamma=True):
-    """-> (dx [rows, D] dx_dtype, dgamma [D] fp32 | None)."""
-    _chk(dy, BF16), _chk(x)
+    """dy bf16 (or fp32: the gradient arriving from the logit heads) -> (dx [rows, D] dx_dtype, dgamma [D] fp32 | None)."""
+    _chk(dy), _chk(x)
+    assert dy.dtype in (BF16, F32)
     rows, D, lddy = _rows_ld(dy)
     dx = torch.empty((rows, D), dtype=dx_dtype, device=dy.device)
     part = None
     if want_dgamma:
         nblk = _lib.query('alm_ln_partial_blocks', rows)
         part = torch.empty((nblk, D), dtype=F32, device=dy.device)
-    _lib.call('alm_layernorm_bwd', dy.data_ptr(), lddy, x.data_ptr(), int(x.dtype == BF16), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
+    _lib.call('alm_layernorm_bwd', dy.data_ptr(), int(dy.dtype == F32), lddy, x.data_ptr(), int(x.dtype == BF16), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
               gamma.data_ptr(), _p(extra), extra.stride(0) if extra is not None else 0, dx.data_ptr(), int(dx_dtype == BF16), D, _p(part),
               rows, D, _st())
     return dx, (colsum(part) if want_dgamma else None)
@@ -367,22 +368,27 @@ def posmlp_out_bwd(dtbl, W, pre, inv_scale):
 _HC_KEYS7 = ('gamma', 'Wa', 'sa', 'Aa', 'wb', 'sb', 'Bb')
 
 
-def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True, rin_bcast=False):
-    """Hyper-connection forward pass over the fp32 residual streams R_in [B, S, N, D] (C ABI: alm_hc_fwd).
+def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True, rin_bcast=False, r_dtype=F32,
+           final_f32=False):
+    """Hyper-connection forward pass over the residual streams R_in [B, S, N, D] (C ABI: alm_hc_fwd).
       y_prev / coef_prev given : depth connection of the previous branch (R = mix(R_in) + beta * y_prev)
       hc given                 : width connection + pre-LayerNorm of the next branch on that R
-      final                    : depth connection + stream sum + final LayerNorm (ln_gamma)
-      rin_bcast                : R_in is ONE [B*N, D] tensor every stream equals (right after the stream expansion)
+      final                    : depth connection + stream sum + final LayerNorm (ln_gamma); final_f32: its output in fp32 (logit heads)
+      rin_bcast                : R_in is ONE fp32 [B*N, D] tensor every stream equals (right after the stream expansion)
+      r_dtype                  : storage type of the stream tensors (fp32 | bf16; arithmetic is fp32 either way)
     -> dict(R=..., x, xn, mean, rstd, coef | xs, hn, mean, rstd)."""
-    _chk(R_in, F32)
+    _chk(R_in, F32 if rin_bcast else r_dtype)
     dev, M = R_in.device, B * N
     depth, width = y_prev is not None, hc is not None
     mode = (1 if depth else 0) | (2 if width else 0) | (4 if final else 0)
     out = {}
-    R_out = torch.empty((B, S, N, D), dtype=F32, device=dev) if (depth and not final) else None
-    x = xn = mean = rstd = coef = xs = None
+    R_out = torch.empty((B, S, N, D), dtype=r_dtype, device=dev) if (depth and not final) else None
+    x = xn = xn32 = mean = rstd = coef = xs = None
     if width or final:
-        xn = torch.empty((M, D), dtype=BF16, device=dev)
+        if final and final_f32:
+            xn32 = torch.empty((M, D), dtype=F32, device=dev)
+        else:
+            xn = torch.empty((M, D), dtype=BF16, device=dev)
         mean = torch.empty(M, dtype=F32, device=dev)
         rstd = torch.empty(M, dtype=F32, device=dev)
     if width:
@@ -391,39 +397,44 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
     if final:
         xs = torch.empty((M, D), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in _HC_KEYS7] if width else [None] * 7
-    _lib.call('alm_hc_fwd', R_in.data_ptr(), int(rin_bcast), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out), *hp, _p(ln_gamma),
-              _p(x), D, _p(xn), D, _p(mean), _p(rstd), _p(coef), _p(xs), mode, B, S, N, D, _st())
-    out.update(R=R_out if depth else R_in, x=x, xn=xn, mean=mean, rstd=rstd, coef=coef, xs=xs)
+    _lib.call('alm_hc_fwd', R_in.data_ptr(), int(rin_bcast), int(r_dtype == BF16), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out),
+              *hp, _p(ln_gamma), _p(x), D, _p(xn), D, _p(xn32), _p(mean), _p(rstd), _p(coef), _p(xs), mode, B, S, N, D, _st())
+    out.update(R=R_out if depth else R_in, x=x, xn=xn if xn32 is None else xn32, mean=mean, rstd=rstd, coef=coef, xs=xs)
     return out
 
 
 def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=None, rstd=None, ln_gamma=None, R=None, coef=None, dbeta=None,
-           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False):
-    """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D], or with
-    bcast [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
+           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False, r_dtype=F32):
+    """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D] (r_dtype), or with
+    bcast fp32 [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
     gradient wrt the branch input is either `dx` (fp32, LayerNorm backward already applied) or `dxn` (bf16, wrt the LayerNorm output) +
     optional `extra` (bf16, added to dx) + mean / rstd / ln_gamma: then the LayerNorm backward is fused (grads['ln'] = its weight gradient).
     y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
-    r_bcast: R is one [B*N, D] tensor for all streams; sum_only: return dsum [B*N, D] = sum over streams of dR instead of dR.
+    r_bcast: R is one fp32 [B*N, D] tensor for all streams; sum_only: return dsum fp32 [B*N, D] = sum over streams of dR instead of dR.
+    r_dtype: storage type of dRn / R / dR (the non-bcast forms).
     -> dict(dR, dsum, grads, dy, dbeta)."""
     width, depth = hc is not None, y_prev is not None
     mode = (2 if width else 0) | (1 if depth else 0)
     dev, M = dRn.device, B * N
+    _chk(dRn, F32 if bcast else r_dtype)
+    if R is not None:
+        _chk(R, F32 if r_bcast else r_dtype)
+    rbf = int(r_dtype == BF16)
     dR = dsum = part = dy = dbo = None
     if width:
         assert (dx is None) != (dxn is None)
         if sum_only:
             dsum = torch.empty((M, D), dtype=F32, device=dev)
         else:
-            dR = torch.empty((B, S, N, D), dtype=F32, device=dev)
-        rows = _lib.query('alm_hc_partial_rows', mode, int(dxn is not None), S, M, D)
+            dR = torch.empty((B, S, N, D), dtype=r_dtype, device=dev)
+        rows = _lib.query('alm_hc_partial_rows', mode, int(dxn is not None), rbf, S, M, D)
         P = _lib.query('alm_hc_partial_width', S, D)
         part = torch.empty((rows, P), dtype=F32, device=dev)
     if depth:
         dy = torch.empty((M, D), dtype=BF16, device=dev)
         dbo = torch.empty((M, S), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
-    _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
+    _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), rbf, _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
               dxn.stride(0) if dxn is not None else 0, _p(extra), extra.stride(0) if extra is not None else 0, _p(mean), _p(rstd), _p(ln_gamma),
               _p(R), int(r_bcast), _p(coef), _p(dbeta), *hp, _p(dR), _p(dsum), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
               mode, B, S, N, D, _st())
@@ -445,21 +456,21 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
 
 # un-fused single-connection forms (kernel tests; the product path uses the fused modes)
 def hc_width_fwd(R, hc, ln_gamma, B, S, N, D, want_x=True):
-    r = hc_fwd(R, B, S, N, D, hc=hc, ln_gamma=ln_gamma, want_x=want_x)
+    r = hc_fwd(R, B, S, N, D, hc=hc, ln_gamma=ln_gamma, want_x=want_x, r_dtype=R.dtype)
     return r['x'], r['xn'], r['mean'], r['rstd'], r['coef']
 
 
 def hc_depth_fwd(R, y, coef, B, S, N, D):
-    return hc_fwd(R, B, S, N, D, y_prev=y, coef_prev=coef)['R']
+    return hc_fwd(R, B, S, N, D, y_prev=y, coef_prev=coef, r_dtype=R.dtype)['R']
 
 
 def hc_depth_bwd(dRn, y, coef, B, S, N, D, bcast=False):
-    r = hc_bwd(dRn, B, S, N, D, bcast=bcast, y_prev=y, coef_prev=coef)
+    r = hc_bwd(dRn, B, S, N, D, bcast=bcast, y_prev=y, coef_prev=coef, r_dtype=F32 if bcast else dRn.dtype)
     return r['dy'], r['dbeta']
 
 
 def hc_width_bwd(dRn, dx, R, coef, dbeta, hc, B, S, N, D):
-    r = hc_bwd(dRn, B, S, N, D, dx=dx, R=R, coef=coef, dbeta=dbeta, hc=hc)
+    r = hc_bwd(dRn, B, S, N, D, dx=dx, R=R, coef=coef, dbeta=dbeta, hc=hc, r_dtype=R.dtype)
     return r['dR'], r['grads']
 
 
@@ -506,17 +517,61 @@ def _ptr_array(tensors):
     return arr
 
 
+_err_flags = {}
+
+
+def device_error_flag(device):
+    """int32 device word the id-consuming kernels raise when they meet an id outside its table (the reference's nn.Embedding would raise
+    IndexError; the kernels never dereference such an id).  Poll it with check_device_errors() at a point where a sync is acceptable."""
+    key = (device.type, device.index)
+    if key not in _err_flags:
+        _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _err_flags[key]
+
+
+def check_device_errors(device=None):
+    """Raises IndexError if any embedding lookup since the last check saw an out-of-range token id (synchronises)."""
+    for key, flag in list(_err_flags.items()):
+        if device is not None and (device.type, device.index) != key:
+            continue
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError('token id out of range of its embedding table (audiolm_pytorch_amd embed_assemble): the offending positions were '
+                             'embedded as zero vectors')
+
+
+def _table_rows(tables):
+    return (ctypes.c_int * len(tables))(*[t.shape[0] for t in tables])
+
+
 def embed_assemble(tables, src_a, src_b, rows, D):
+    """tables: fp32 [rows_t, D] each.  Ids outside a table never touch memory: zero vector + device error flag (see device_error_flag)."""
     out = torch.empty((rows, D), dtype=F32, device=src_a.device)
     arr = _ptr_array(tables)
-    _lib.call('alm_embed_assemble', ctypes.cast(arr, ctypes.c_void_p), len(tables), src_a.data_ptr(), src_b.data_ptr(), out.data_ptr(), rows, D, _st())
+    _lib.call('alm_embed_assemble', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_table_rows(tables), ctypes.c_void_p), len(tables), src_a.data_ptr(),
+              src_b.data_ptr(), out.data_ptr(), rows, D, device_error_flag(src_a.device).data_ptr(), _st())
     return out
 
 
 def embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D):
     arr = _ptr_array(grad_tables)
-    _lib.call('alm_embed_scatter_add', ctypes.cast(arr, ctypes.c_void_p), len(grad_tables), src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(),
-              float(alpha), rows, D, _st())
+    _lib.call('alm_embed_scatter_add', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_table_rows(grad_tables), ctypes.c_void_p), len(grad_tables),
+              src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, _st())
+
+
+def gather_split(inp, idx=None, rows_out=None):
+    """fp32 inp [rows_in, D] (row stride arbitrary) -> (hi, lo) bf16 [rows_out, D] with hi + lo ~= inp[idx] to ~16 mantissa bits: the split-bf16
+    operands of the logit heads.  idx int32 [rows_out] (-1 = zero row) or None (identity; rows past rows_in are zero = row padding)."""
+    _chk(inp, F32)
+    rows_in, D, ld = _rows_ld(inp)
+    if idx is not None:
+        rows_out = idx.numel()
+    elif rows_out is None:
+        rows_out = rows_in
+    hi = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
+    lo = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
+    _lib.call('alm_gather_split_bf16', inp.data_ptr(), ld, rows_in, _p(idx), hi.data_ptr(), lo.data_ptr(), D, rows_out, D, _st())
+    return hi, lo
 
 
 def gather_rows(inp, idx, out=None):

@@ -14,6 +14,11 @@ backward.  It is not a general DDP replacement.
   * gradient accumulation (trainer.py:1237 `no_sync`): `with engine.no_sync():` micro-steps only accumulate locally; the next synchronising
     step then reduces the ACCUMULATED p.grad in `finish()` (bucketed per layer, not overlapped: the fresh per-layer gradients handed to the
     callback are only that micro-step's share)
+  * DDP semantics for gradients that are already there: if a synchronising backward starts while parameters still hold a `.grad` (accumulation
+    without no_sync(), or `zero_grad(set_to_none=False)`), autograd ADDS this backward's share to it -- the overlapped buckets only carry the
+    fresh share, so that backward is exchanged like an accumulated one (p.grad itself is reduced in `finish()`, per layer, not overlapped).
+    `zero_grad()` with torch's default set_to_none=True keeps the overlap.
+  * `bucket_dtype=torch.bfloat16` halves the bytes on the xGMI links (the reduction then runs in bf16; fp32 is the default, like DDP)
 
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
 """
@@ -32,8 +37,9 @@ class _Bucket:
 
 
 class DataParallelEngine:
-    def __init__(self, model, dist, process_group=None, broadcast_parameters=True):
-        self.model, self.dist, self.pg = model, dist, process_group
+    def __init__(self, model, dist, process_group=None, broadcast_parameters=True, bucket_dtype=torch.float32):
+        assert bucket_dtype in (torch.float32, torch.bfloat16), bucket_dtype
+        self.model, self.dist, self.pg, self.bucket_dtype = model, dist, process_group, bucket_dtype
         self.world = dist.get_world_size(process_group)
         self._avg_ok = str(dist.get_backend(process_group)).lower() == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -59,6 +65,8 @@ class DataParallelEngine:
         self._n_loose_heads = None
         self._sync = True                     # False inside no_sync()
         self._dirty = False                   # p.grad holds local, not yet reduced micro-step gradients
+        self._bw_started = False              # a backward is in progress (first gradient callback seen, finish() not yet called)
+        self._stale = False                   # that backward started with gradients already present: exchange p.grad itself afterwards
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -69,8 +77,14 @@ class DataParallelEngine:
         finally:
             self._sync = prev
 
+    def _begin_backward(self, skip=None):
+        """first gradient callback of a backward: do parameters (other than the one whose hook fired) still hold a gradient from before?"""
+        if not self._bw_started:
+            self._bw_started = True
+            self._stale = any(q.grad is not None for q in self.params if q is not skip)
+
     def _overlapped(self):
-        return self._sync and not self._dirty
+        return self._sync and not self._dirty and not self._stale
 
     # ---- bucket launch -------------------------------------------------------------------------------------------
     def _launch(self, key, params, grads):
@@ -79,9 +93,9 @@ class DataParallelEngine:
         n = sum(g.numel() for g in grads)
         flat = self._flat_cache.get(key)
         if flat is None or flat.numel() != n or flat.device != grads[0].device:
-            flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+            flat = torch.empty(n, dtype=self.bucket_dtype, device=grads[0].device)
             self._flat_cache[key] = flat
-        torch.cat([g.reshape(-1).to(torch.float32) for g in grads], out=flat)
+        torch.cat([g.reshape(-1).to(self.bucket_dtype) for g in grads], out=flat)
         op = self.dist.ReduceOp.AVG if self._avg_ok else self.dist.ReduceOp.SUM       # gloo has no AVG: sum, divide in finish()
         work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
         b = _Bucket()
@@ -91,6 +105,7 @@ class DataParallelEngine:
 
     def _on_layer_grads(self, layer, grads):
         """core.stack_backward callback: `grads` are the fresh gradients of layer `layer` (order == Transformer.flat_params)."""
+        self._begin_backward()
         if not self._overlapped():
             return
         self._flush_loose(('loose', 'pre', layer))       # whatever accumulated so far (logit heads, final norm) goes first
@@ -99,6 +114,7 @@ class DataParallelEngine:
         self._launch(('layer', layer), [p for p, _ in pg], [g for _, g in pg])
 
     def _on_loose_grad(self, p):
+        self._begin_backward(skip=p)
         if self._overlapped():
             self._loose.params.append(p)
 
@@ -111,10 +127,11 @@ class DataParallelEngine:
     # ---- end of backward ------------------------------------------------------------------------------------------
     def finish(self):
         """Call after loss.backward(): waits for every in-flight all-reduce and stores the mean gradients in p.grad."""
+        stale, self._bw_started, self._stale = self._stale, False, False
         if not self._sync:
             self._dirty = True
             return
-        if self._dirty:                                               # accumulated micro-steps: reduce p.grad itself, layer by layer
+        if self._dirty or stale:                                      # accumulated gradients: reduce p.grad itself, layer by layer
             self._dirty = False
             groups = []
             if self._stack is not None:

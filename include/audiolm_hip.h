@@ -71,9 +71,9 @@ int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream);
 
 /* ---- LayerNorm (gamma only, eps 1e-5): audiolm_pytorch.py:191-198 ---------------------------------------------------------- */
 int alm_ln_partial_blocks(int rows);
-int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y_bf16, long long ldy, void* xcopy_bf16,
-                      long long ldc, float* mean, float* rstd, int rows, int D, void* stream);
-int alm_layernorm_bwd(const void* dy_bf16, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
+int alm_layernorm_fwd(const void* x, int x_is_bf16, long long ldx, const float* gamma, void* y, int y_is_f32, long long ldy, void* xcopy_bf16,
+                      long long ldc, float* mean, float* rstd, int rows, int D, void* stream);   /* y bf16, or fp32 (final LayerNorm feeding the logit heads) */
+int alm_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void* x, int x_is_bf16, long long ldx, const float* mean,
                       const float* rstd, const float* gamma, const void* extra_bf16, long long lde, void* dx, int dx_is_bf16,
                       long long lddx, float* dgamma_part, int rows, int D, void* stream);
 /* out[c] (+)= scale * sum_r in[r][c]  (second stage of every parameter-gradient reduction; bias gradients) */
@@ -138,36 +138,39 @@ int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts,
                      long long ldo, long long rows, int dim_head, int mode, void* stream);
 
 /* ---- hyper-connection residual streams: third-party `hyper_connections` used at audiolm_pytorch.py:24, 446-454, 524, 551 ----
- * R fp32 [B][S][N][D].  coef: per-token fp32 record of alm_hc_coef_width(S) floats (alpha | beta | pre-activations | 1/norm). */
+ * R [B][S][N][D], stored fp32 or (r_bf16) bf16 -- under trainer.py:1241's autocast the reference's streams are bf16 tensors; the arithmetic is
+ * fp32 in registers either way.  Tensors standing for all streams at once (the `*_bcast` forms) are always fp32 [B*N][D].
+ * coef: per-token fp32 record of alm_hc_coef_width(S) floats (alpha | beta | pre-activations | 1/norm). */
 int alm_hc_coef_width(int S);
 int alm_hc_partial_width(int S, int D);
 int alm_hc_grads_width(int S, int D);
-int alm_hc_partial_rows(int mode, int fused_ln, int S, long long tokens, int D);
+int alm_hc_partial_rows(int mode, int fused_ln, int r_bf16, int S, long long tokens, int D);
 /* forward.  mode 1: depth connection only, R_out[t] = sum_s alpha[s][t+1] R_in[s] + beta[t] y_prev (coef_prev = that branch's record);
  * mode 2: width connection of a branch (its 7 parameters) + the branch's pre-LayerNorm: x, xn = LN(x) ln_gamma, mean, rstd, coef;
  * mode 3: mode 1 of the previous branch fused with mode 2 of the next one on the freshly computed residual (one pass over R);
- * mode 5: depth connection + stream sum (:551) + final LayerNorm (:555): xs_out fp32 [B*N][D], xn_out bf16, mean, rstd.
- * rin_bcast: R_in is ONE [B*N][D] tensor that every stream equals (the state right after the stream expansion, :524). */
-int alm_hc_fwd(const float* R_in, int rin_bcast, const void* y_prev_bf16, long long ldy, const float* coef_prev, float* R_out, const float* hc_gamma,
-               const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb, const float* ln_gamma,
-               void* x_out_bf16, long long ldx, void* xn_out_bf16, long long ldxn, float* mean, float* rstd, float* coef, float* xs_out,
-               int mode, int B, int S, int N, int D, void* stream);
+ * mode 5: depth connection + stream sum (:551) + final LayerNorm (:555): xs_out fp32 [B*N][D], mean, rstd and the LayerNorm output either as
+ *         xn_out bf16 or -- xn32_out != NULL -- as fp32 [B*N][D] (what the logit heads read).
+ * rin_bcast: R_in is ONE fp32 [B*N][D] tensor that every stream equals (the state right after the stream expansion, :524). */
+int alm_hc_fwd(const void* R_in, int rin_bcast, int r_bf16, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* R_out,
+               const float* hc_gamma, const float* Wa, const float* sa, const float* Aa, const float* wb, const float* sb, const float* Bb,
+               const float* ln_gamma, void* x_out_bf16, long long ldx, void* xn_out_bf16, long long ldxn, float* xn32_out, float* mean,
+               float* rstd, float* coef, float* xs_out, int mode, int B, int S, int N, int D, void* stream);
 /* backward.  mode 2: width-connection backward (dR, parameter-gradient partial rows); mode 1: depth-connection backward
  * (dy = sum_t beta[t] dRn[t], dbeta_out[t] = <dRn[t], y>); mode 3: mode 2 of branch k+1 fused with mode 1 of branch k on the
- * freshly computed dR.  dRn_bcast: dRn is [B*N][D] and stands for all S streams (gradient of the final stream sum).
- * r_bcast: R is one [B*N][D] tensor for all streams (first branch); dsum (optional): [B*N][D] sum over streams of dR = the gradient of
- * the stream expansion (:524); dR may then be NULL.
+ * freshly computed dR.  dRn_bcast: dRn is fp32 [B*N][D] and stands for all S streams (gradient of the final stream sum).
+ * r_bcast: R is one fp32 [B*N][D] tensor for all streams (first branch); dsum (optional): fp32 [B*N][D] sum over streams of dR = the gradient of
+ * the stream expansion (:524); dR may then be NULL.  r_bf16: dRn / R / dR (the non-bcast forms) hold bf16.
  * The gradient wrt the branch input comes either as dx (fp32 [B*N][lddx], already through the branch's LayerNorm backward) or -- fused
  * mode, dx == NULL -- as dxn (bf16, gradient wrt the LayerNorm OUTPUT) + optional extra (bf16, added to dx directly: the K/V path of
  * the attention branch) + the LayerNorm statistics / weight: the LayerNorm backward (audiolm_pytorch.py:191-198 autograd) then happens
  * inside this kernel and its weight gradient joins the outputs.
- * partial: [alm_hc_partial_rows(mode, dx == NULL, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose output is
- * dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]  (alm_hc_grads_width(S, D) floats). */
-int alm_hc_bwd(const float* dRn, int dRn_bcast, const float* dx, long long lddx, const void* dxn_bf16, long long lddxn, const void* extra_bf16,
-               long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const float* R, int r_bcast, const float* coef,
-               const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb, float* dR,
-               float* dsum, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy, float* dbeta_out,
-               int mode, int B, int S, int N, int D, void* stream);
+ * partial: [alm_hc_partial_rows(mode, dx == NULL, r_bf16, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose
+ * output is dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]  (alm_hc_grads_width(S, D) floats). */
+int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const float* dx, long long lddx, const void* dxn_bf16, long long lddxn,
+               const void* extra_bf16, long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const void* R, int r_bcast,
+               const float* coef, const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb,
+               void* dR, float* dsum, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy,
+               float* dbeta_out, int mode, int B, int S, int N, int D, void* stream);
 int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
 int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */
@@ -177,12 +180,20 @@ int alm_add_f32(const float* a, const float* b, float* out, long long n, void* s
 
 /* ---- token-id side: embedding assembly (:709-713, :894-918, :1186-1223), logit-head regrouping (:965-983, :1325-1361),
  *      cross-entropy (:1561-1565, :1839-1849, :2122-2132) -------------------------------------------------------------------- */
-int alm_embed_assemble(const float* const* tables, int ntables, const int* src_a, const int* src_b, float* out, long long rows, int D,
-                       void* stream);
-int alm_embed_scatter_add(float* const* grad_tables, int ntables, const int* src_a, const int* src_b, const float* dout, float alpha,
-                          long long rows, int D, void* stream);
+/* source codes: (table << 24) | row, -1 = zero vector.  table_rows[t] = number of rows of table t: a code whose table or row is out of range
+ * (nn.Embedding raises IndexError for it, audiolm_pytorch.py:709 / :901-906 / :1204-1213) reads as a zero vector, is skipped by the scatter, and
+ * sets *err_flag (device int32, may be NULL) to 1 -- never an out-of-bounds access. */
+int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
+                       long long rows, int D, int* err_flag, void* stream);
+int alm_embed_scatter_add(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
+                          float alpha, long long rows, int D, void* stream);
 int alm_gather_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
 int alm_scatter_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
+/* split-bf16 operands of the logit-head contraction (the heads read the fp32 final hidden states / fp32 master weights at ~16 mantissa bits:
+ * x = hi + lo with hi = bf16(x), lo = bf16(x - hi); logits = hi.Whi + hi.Wlo + lo.Whi on the bf16 MFMA, fp32 accumulate):
+ * hi[r] / lo[r] = split(in[idx ? idx[r] : r]) for r < rows_out; source rows < 0 or >= rows_in give zero rows (ragged head groups, row padding). */
+int alm_gather_split_bf16(const float* in, long long ld_in, long long rows_in, const int* idx, void* hi, void* lo, long long ld_out,
+                          long long rows_out, int D, void* stream);
 int alm_cross_entropy_fwd(const float* logits, long long ld, const long long* labels, float* loss_rows, float* lse, long long rows, int C,
                           int ignore_index, void* stream);
 int alm_cross_entropy_bwd(const float* logits, long long ld, const long long* labels, const float* lse, const float* gscale, void* dlogits_bf16,

@@ -1,0 +1,71 @@
+#!/bin/bash
+# Round-2 GPU-box visit.  usage: scripts/gpu_r2.sh <tag> [sections...]   sections: kernels parity fullsize dp rest smoke bench benchbf prof profbf
+# Logs -> gpurun_out/<tag>_*.log (merged back by gpurun).
+tag=$1; shift
+sections="$*"
+[[ -z $sections ]] && sections="kernels parity fullsize dp bench benchbf profbf rest smoke"
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+has() { [[ " $sections " == *" $1 "* ]]; }
+python - > gpurun_out/${tag}_env.log 2>&1 <<'PY'
+import torch, os
+print('torch', torch.__version__, 'cuda', torch.cuda.is_available(), torch.cuda.get_device_name(0) if torch.cuda.is_available() else None)
+p = torch.cuda.get_device_properties(0)
+print('CUs', p.multi_processor_count, 'mem GB', p.total_memory / 2**30, 'host cores', os.cpu_count())
+PY
+cat gpurun_out/${tag}_env.log
+t0=$SECONDS
+if has kernels; then
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/${tag}_kernels.log 2>&1
+  echo "kernels rc=$? t=$((SECONDS-t0))"; tail -n 40 gpurun_out/${tag}_kernels.log
+fi
+if has parity; then
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -s --timeout 600 > gpurun_out/${tag}_parity.log 2>&1
+  echo "parity rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|logits|passed|failed|Error|error" gpurun_out/${tag}_parity.log | cut -c1-230 | tail -n 70
+fi
+if has fullsize; then
+  rm -f gpurun_out/r2_fullsize_parity.jsonl
+  timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --tb=short -s --timeout 900 > gpurun_out/${tag}_fullsize.log 2>&1
+  echo "fullsize rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|  logits|worst grad|pooled|passed|failed|Error" gpurun_out/${tag}_fullsize.log | cut -c1-230 | tail -n 50
+  cp gpurun_out/r2_fullsize_parity.jsonl gpurun_out/${tag}_fullsize_fp32.jsonl 2>/dev/null
+fi
+if has fullsizebf; then
+  rm -f gpurun_out/r2_fullsize_parity.jsonl
+  ALM_RESIDUAL_DTYPE=bf16 timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --tb=short -s --timeout 900 -k "4-" > gpurun_out/${tag}_fullsize_bf16.log 2>&1
+  echo "fullsize bf16 rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|  logits|worst grad|pooled|passed|failed|Error" gpurun_out/${tag}_fullsize_bf16.log | cut -c1-230 | tail -n 50
+  cp gpurun_out/r2_fullsize_parity.jsonl gpurun_out/${tag}_fullsize_bf16.jsonl 2>/dev/null
+fi
+if has dp; then
+  timeout 600 python -m pytest tests/test_gpu_dp.py -m gpu -q --tb=short --timeout 500 > gpurun_out/${tag}_dp.log 2>&1
+  echo "dp rc=$? t=$((SECONDS-t0))"; tail -n 15 gpurun_out/${tag}_dp.log | cut -c1-300
+fi
+if has bench; then
+  ALM_RESIDUAL_DTYPE=fp32 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_fp32.log 2>&1
+  echo "bench fp32 rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_fp32.log | cut -c1-1500
+fi
+if has benchbf; then
+  ALM_RESIDUAL_DTYPE=bf16 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_bf16.log 2>&1
+  echo "bench bf16 rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_bf16.log | cut -c1-1500
+fi
+if has benchfull; then
+  timeout 900 python bench.py > gpurun_out/${tag}_bench_full.log 2>&1
+  echo "bench full rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_full.log | cut -c1-3000
+fi
+prof() {   # $1 = residual dtype, $2 = ALM_ASYNC_WGRAD
+  rm -rf /tmp/prof_$1
+  ALM_RESIDUAL_DTYPE=$1 ALM_ASYNC_WGRAD=$2 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o r2 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} > gpurun_out/${tag}_prof_$1.log 2>&1
+  echo "prof $1 rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_prof_$1.log | cut -c1-300
+  db=$(find /tmp/prof_$1 -name "*.db" | head -1)
+  if [[ -n $db ]]; then python scripts/prof_summary.py "$db" gpurun_out/${tag}_kernel_stats_$1_async$2.csv "ALM_RESIDUAL_DTYPE=$1 ALM_ASYNC_WGRAD=$2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} (18 steps incl. priming + warm-up + 1 instrumented)"; head -n 28 gpurun_out/${tag}_kernel_stats_$1_async$2.csv | cut -c1-150; fi
+}
+if has prof; then prof fp32 0; fi
+if has profbf; then prof bf16 0; fi
+if has rest; then
+  timeout 1500 python -m pytest tests/test_gpu_bias.py tests/test_gpu_codec.py tests/test_gpu_generate.py tests/test_gpu_optimizer.py -m gpu -q --tb=short -n 4 --timeout 600 > gpurun_out/${tag}_rest.log 2>&1
+  echo "rest rc=$? t=$((SECONDS-t0))"; tail -n 25 gpurun_out/${tag}_rest.log | cut -c1-300
+fi
+if has smoke; then
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/${tag}_smoke.log 2>&1
+  echo "smoke rc=$? t=$((SECONDS-t0))"; tail -n 3 gpurun_out/${tag}_smoke.log
+fi
+echo "total t=$((SECONDS-t0))"

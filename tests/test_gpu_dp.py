@@ -1,0 +1,104 @@
+"""Data parallelism through the REAL fused stack on a 1-GPU box: two ranks share cuda:0 and exchange gradients over gloo (RCCL refuses two
+ranks on one device), so the whole production control flow runs -- core.stack_backward's per-layer callback on the side stream ->
+parallel.DataParallelEngine._on_layer_grads -> bucket copy -> asynchronous all-reduce -> finish() -- with the real CoarseTransformer.
+
+Asserted (pure data parallelism, the only exchange is the gradient mean):
+  * DP-2 averaged gradients == the gradients of ONE process that sees both shards as one batch (same weights, same ids)
+  * a second synchronising backward on top of gradients that are still there accumulates like DDP (mean of the summed shares)
+  * bf16 buckets give the same result to bf16 rounding
+The multi-GPU RCCL path itself (backend "nccl") differs only in the transport; it is first executed by the driver's N > 1 bench runs.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CTOR = dict(dim=256, depth=3, num_semantic_tokens=100, codebook_size=64, num_coarse_quantizers=3, flash_attn=True)
+
+
+class Codec:
+    rq_groups = 1
+    num_quantizers = 8
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    return torch.randint(0, 100, (4, 40), generator=g), torch.randint(0, 64, (4, 30, 3), generator=g)
+
+
+def _build(dev, seed=0):
+    import audiolm_pytorch_amd as A
+    torch.manual_seed(seed)
+    model = A.CoarseTransformer(**CTOR).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.)
+    w.train()
+    return model, w
+
+
+def _worker(rank, world, port, out, bucket_dtype):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    model, w = _build(dev, seed=100 + rank)                       # different init per rank: the engine must broadcast rank 0's weights
+    eng = DataParallelEngine(model, dist, bucket_dtype=getattr(torch, bucket_dtype))
+    sem, coarse = _data()
+    sl = slice(2 * rank, 2 * rank + 2)
+    loss = w(semantic_token_ids=sem[sl].to(dev), coarse_token_ids=coarse[sl].to(dev), return_loss=True)
+    loss.backward()
+    eng.finish()
+    torch.cuda.synchronize()
+    g1 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
+    # second synchronising backward WITHOUT clearing the gradients: DDP semantics = previous (already averaged) + mean of the new shares
+    loss2 = w(semantic_token_ids=sem[sl].flip(0).to(dev), coarse_token_ids=coarse[sl].flip(0).to(dev), return_loss=True)
+    loss2.backward()
+    eng.finish()
+    torch.cuda.synchronize()
+    g2 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss)), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _frob(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize('bucket_dtype', ['float32', 'bfloat16'])
+def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'dp.pt')
+    port = 33500 + (os.getpid() % 2000) + (7 if bucket_dtype == 'bfloat16' else 0)
+    mp.spawn(_worker, args=(2, port, out, bucket_dtype), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    dev = torch.device('cuda:0')
+    model, w = _build(dev)
+    model.load_state_dict(r['sd'])
+    sem, coarse = _data()
+    loss = w(semantic_token_ids=sem.to(dev), coarse_token_ids=coarse.to(dev), return_loss=True)          # one process, both shards
+    loss.backward()
+    tol = 2e-3 if bucket_dtype == 'float32' else 1e-2
+    bad = []
+    n = 0
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert r['g1'][k] is None, k
+            continue
+        n += 1
+        e = _frob(r['g1'][k], p.grad.float().cpu())
+        if e > tol:
+            bad.append((k, e))
+    assert n > 40 and not bad, bad[:8]
+    # accumulation on top of existing gradients: g2 = g1 + mean over ranks of the second shares (= gradient of the flipped big batch = same)
+    bad = [(k, _frob(r['g2'][k], 2 * p.grad.float().cpu())) for k, p in model.named_parameters() if p.grad is not None]
+    bad = [(k, e) for k, e in bad if e > 2 * tol]
+    assert not bad, bad[:8]

@@ -1,0 +1,112 @@
+"""Parity AT THE BENCHMARK SIZES on a real MI355X: the HIP path vs the fp32 CPU oracle for BASELINE.json configs[1] (CoarseTransformer
+dim=1024 depth=6, N=1024), the headline (same model, N=2048) and configs[2] (FineTransformer dim=1024 depth=6, 3 + 5 quantizers, N=2049),
+each with 4 residual streams (restated hyper-connections) and with 1 stream (every op first-party reference code).
+
+This is where the production kernels actually run: the 256x256 GEMM tile, attention across many 64-key tiles, the 2730 -> 2736 padded FFN
+width, split-K weight gradients over K = B*N tokens, the multi-token-per-workgroup hyper-connection loops.  Parameters are the
+non-degenerate synthetic values of tests/golden/common.py (every hyper-connection / LayerNorm / bias path carries signal); inputs are
+seeded uniform token ids; the forgetful mask is drawn once on the CPU and injected on both sides.
+
+Compared: the loss, EVERY logit, and the gradient of EVERY parameter.  Tolerances (bf16 GEMM operands vs an fp32 reference):
+  loss     |d| <= 1e-3 * |loss|                      (north_star: loss within 1e-3; no noise clause)
+  logits   rel Frobenius error <= max(1e-2, the oracle's own bf16-autocast deviation on the same inputs)  -- both numbers are reported
+  grads    per tensor rel Frobenius error <= max(3e-2, 2 x the oracle's bf16-autocast deviation of that tensor); hyper-connection scalar
+           statistics pooled (see tests/test_gpu_parity.py)
+Every run appends its numbers to gpurun_out/r2_fullsize_parity.jsonl (copied to profiles/ for the record).
+"""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+import audiolm_oracle as O
+from common import synth_state_dict
+from test_gpu_parity import _frob, grad_report, ours_run
+from test_oracle_golden import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r2_fullsize_parity.jsonl')
+
+
+def _case(kind, streams, N_kind):
+    g = torch.Generator().manual_seed(1234)
+    extra = {} if streams == 4 else dict(num_residual_streams=streams)
+    if kind == 'coarse':
+        ctor = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True, **extra)
+        ns, nf = (253, 256) if N_kind == 1024 else (509, 512)
+        B = 2 if N_kind == 1024 else 1
+        inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, ns), generator=g), coarse_token_ids=torch.randint(0, 1024, (B, nf, 3), generator=g))
+        N = 1 + (ns + 1) + 1 + nf * 3
+        inputs['forgetful_mask'] = O.generate_mask_with_prob((B, N), 0.15, 'cpu', generator=g)
+        options = dict(training=True, unique_consecutive=False, mask_prob=0.15)
+    else:
+        ctor = dict(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True, **extra)
+        B = 1
+        grid = torch.randint(0, 1024, (B, 256, 8), generator=g)
+        inputs = dict(coarse_token_ids=grid[..., :3].contiguous(), fine_token_ids=grid[..., 3:].contiguous())
+        N = 1 + 768 + 1 + 1279
+        inputs['forgetful_mask'] = O.generate_mask_with_prob((B, N), 0.15, 'cpu', generator=g)
+        options = dict(training=True, mask_prob=0.15)
+    return ctor, inputs, options, N, B
+
+
+@pytest.mark.parametrize('kind,streams,N_kind', [('coarse', 4, 2048), ('coarse', 1, 2048), ('coarse', 4, 1024), ('coarse', 1, 1024), ('fine', 4, 2049),
+                                                 ('fine', 1, 2049)])
+def test_full_size_matches_oracle(kind, streams, N_kind):
+    import audiolm_pytorch_amd as A
+    ctor, inputs, options, N, B = _case(kind, streams, N_kind)
+    assert N == N_kind
+    K = dict(coarse=A.CoarseTransformer, fine=A.FineTransformer)[kind]
+    shapes = {k: tuple(v.shape) for k, v in K(**ctor).state_dict().items()}
+    seed = 4242 + streams
+    fx = dict(kind=kind, ctor=ctor, shapes=shapes, seed=seed, options=options, inputs=inputs)
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    oloss, ologits, ograds = oracle_run(fx)                                   # fp32 CPU oracle, same synthetic parameters (shapes, seed)
+    t_oracle = time.time() - t0
+    ologits = [t.detach() for t in ologits if t is not None]
+    with torch.autocast('cpu', dtype=torch.bfloat16):                          # the oracle's own bf16-autocast deviation on these inputs
+        nloss, nlogits, ngrads = oracle_run(fx)
+    nlogits = [t.detach().float() for t in nlogits if t is not None]
+    noise = dict(loss_rel=abs(float(nloss) - float(oloss)) / abs(float(oloss)),
+                 logits=[_frob(a, b) for a, b in zip(nlogits, ologits)],
+                 grads={k: _frob(ngrads[k].float(), g) for k, g in ograds.items() if g is not None and float(g.norm()) >= 1e-7})
+    del nlogits, ngrads
+
+    loss, logits, grads = ours_run(fx, want_logits=True, state=synth_state_dict(shapes, seed))
+    logits = [t for t in (logits if isinstance(logits, (tuple, list)) else (logits,)) if t is not None]
+
+    rel = abs(loss - float(oloss)) / abs(float(oloss))
+    rep = [f'{kind} S={streams} N={N} B={B}: loss ours={loss:.6f} oracle={float(oloss):.6f} rel |d|={rel:.2e} (bound 1e-3; oracle bf16-autocast {noise["loss_rel"]:.2e}); '
+           f'oracle fwd+bwd {t_oracle:.1f} s']
+    ok = rel <= 1e-3
+    lerr = []
+    assert len(logits) == len(ologits)
+    for got, want, nz in zip(logits, ologits, noise['logits']):
+        assert got.shape == want.shape, (got.shape, want.shape)
+        e = _frob(got, want)
+        lerr.append(e)
+        rep.append(f'  logits {tuple(want.shape)}: rel-frob {e:.2e} (bound max(1e-2, oracle bf16-autocast {nz:.2e}))')
+        ok &= e <= max(1e-2, nz)
+    items = []
+    for k, g in ograds.items():
+        if g is None or float(g.norm()) < 1e-7:
+            continue
+        assert grads.get(k) is not None, f'missing gradient for {k}'
+        items.append((k, _frob(grads[k], g), float(g.norm()), noise['grads'].get(k, 0.0)))
+    ok &= grad_report(items, rep)
+    print('\n'.join(rep))
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, 'a') as fh:
+        from audiolm_pytorch_amd import core
+        fh.write(json.dumps(dict(kind=kind, streams=streams, N=N, B=B, residual_bf16=core.default_residual_bf16(), loss_ours=loss, loss_oracle=float(oloss),
+                                 loss_rel=rel, loss_rel_oracle_bf16=noise['loss_rel'], logits_rel_frob=lerr, logits_rel_frob_oracle_bf16=noise['logits'],
+                                 worst_grad_rel_frob=max(e for _, e, _, _ in items), n_grad_tensors=len(items),
+                                 grads_over_3e2=sorted([(k, round(e, 4), round(nz, 4)) for k, e, _, nz in items if e > 3e-2], key=lambda t: -t[1])[:12],
+                                 oracle_seconds=round(t_oracle, 1), ok=bool(ok))) + '\n')
+    assert ok, '\n'.join(rep)

@@ -449,6 +449,138 @@ def test_hyper_connections_fused_modes(ops, S, D, N):
     assert relmax(dRb, dRe) <= 1e-6
 
 
+@pytest.mark.parametrize('S,D,N', [(4, 1024, 19), (4, 1024, 700), (4, 256, 1501), (2, 512, 330), (3, 128, 45)])
+def test_hyper_connections_bf16_streams(ops, S, D, N):
+    """bf16 storage of the residual streams and their gradients (the dtype trainer.py:1241's autocast gives the reference's streams): the same
+    kernels with a bf16 HBM image (software-prefetching variants where no broadcast operand is involved; N = 700 / 1501 give every workgroup
+    several tokens, odd counts, a ragged tail) against the fp32-stream kernels fed the SAME (bf16-representable) values.  What may differ:
+    the rounding of a stored bf16 output (<= 2^-8 of max-abs), and in the fused forward the width connection reading the rounded streams."""
+    B = 2
+    M = B * N
+    Rb = rnd(B, S, N, D, seed=80, dtype=BF16)
+    Rf = Rb.float()
+    hc1 = {k: v.contiguous() for k, v in _hc_params(S, D, 81).items()}
+    hc2 = {k: v.contiguous() for k, v in _hc_params(S, D, 82).items()}
+    g1, g2 = (1 + 0.1 * rnd(D, seed=83)).contiguous(), (1 + 0.1 * rnd(D, seed=84)).contiguous()
+    y = rnd(M, D, seed=85, dtype=BF16)
+    # width only (mode 2)
+    wf = ops.hc_fwd(Rf, B, S, N, D, hc=hc1, ln_gamma=g1)
+    wb = ops.hc_fwd(Rb, B, S, N, D, hc=hc1, ln_gamma=g1, r_dtype=BF16)
+    assert relmax(wb['coef'], wf['coef']) <= 1e-6 and torch.equal(wb['x'], wf['x']) and relmax(wb['xn'], wf['xn']) <= 1e-6
+    coef1 = wf['coef']
+    # depth + width fused (mode 3): R_out is rounded to bf16, the next width connection reads the rounded streams
+    ff = ops.hc_fwd(Rf, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2)
+    fb = ops.hc_fwd(Rb, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2, r_dtype=BF16)
+    assert fb['R'].dtype == BF16 and relmax(fb['R'].float(), ff['R']) <= 4e-3
+    assert torch.equal(fb['R'], ff['R'].to(BF16)), 'stored streams must be the round-to-nearest-even bf16 image of the fp32 result'
+    w2 = ops.hc_fwd(fb['R'].float(), B, S, N, D, hc=hc2, ln_gamma=g2)            # fp32 kernel on the rounded streams = what the fused bf16 pass computes
+    assert relmax(fb['coef'], w2['coef']) <= 1e-5 and relmax(fb['xn'], w2['xn']) <= 8e-3 and relmax(fb['mean'], w2['mean']) <= 1e-4
+    # final: depth + stream sum + LayerNorm, fp32 hidden states out
+    nf = ops.hc_fwd(Rf, B, S, N, D, y_prev=y, coef_prev=coef1, ln_gamma=g2, final=True, final_f32=True)
+    nb = ops.hc_fwd(Rb, B, S, N, D, y_prev=y, coef_prev=coef1, ln_gamma=g2, final=True, final_f32=True, r_dtype=BF16)
+    assert nb['xn'].dtype == F32 and relmax(nb['xn'], nf['xn']) <= 1e-6 and relmax(nb['xs'], nf['xs']) <= 1e-6
+    hn_bf = ops.hc_fwd(Rf, B, S, N, D, y_prev=y, coef_prev=coef1, ln_gamma=g2, final=True)['xn']
+    assert torch.equal(hn_bf, nf['xn'].to(BF16))
+    # backward (fused LayerNorm backward + width backward + depth backward of the previous branch): same inputs, bf16 vs fp32 images
+    R1b, coef2, mean2, rstd2 = fb['R'], fb['coef'], fb['mean'], fb['rstd']
+    Gb = rnd(B, S, N, D, seed=86, dtype=BF16)
+    dxn = rnd(M, D, seed=87, dtype=BF16)
+    ex = rnd(M, D, seed=88, dtype=BF16)
+    dbeta2 = rnd(M, S, seed=89)
+    for extra in (None, ex):
+        rf = ops.hc_bwd(Gb.float(), B, S, N, D, dxn=dxn, extra=extra, mean=mean2, rstd=rstd2, ln_gamma=g2, R=R1b.float(), coef=coef2, dbeta=dbeta2,
+                        hc=hc2, y_prev=y, coef_prev=coef1)
+        rb = ops.hc_bwd(Gb, B, S, N, D, dxn=dxn, extra=extra, mean=mean2, rstd=rstd2, ln_gamma=g2, R=R1b, coef=coef2, dbeta=dbeta2,
+                        hc=hc2, y_prev=y, coef_prev=coef1, r_dtype=BF16)
+        assert rb['dR'].dtype == BF16 and torch.equal(rb['dR'], rf['dR'].to(BF16))
+        assert relmax(rb['dbeta'], rf['dbeta']) <= 1e-5 and torch.equal(rb['dy'], rf['dy'])
+        for k in rf['grads']:
+            assert relmax(rb['grads'][k], rf['grads'][k]) <= 1e-4, k
+    # width-only backward (mode 2), depth-only backward (mode 1)
+    dx2 = rnd(M, D, seed=90)
+    rf = ops.hc_bwd(Gb.float(), B, S, N, D, dx=dx2, R=R1b.float(), coef=coef2, dbeta=dbeta2, hc=hc2)
+    rb = ops.hc_bwd(Gb, B, S, N, D, dx=dx2, R=R1b, coef=coef2, dbeta=dbeta2, hc=hc2, r_dtype=BF16)
+    assert torch.equal(rb['dR'], rf['dR'].to(BF16))
+    for k in rf['grads']:
+        assert relmax(rb['grads'][k], rf['grads'][k]) <= 1e-4, k
+    dyf, dbf = ops.hc_depth_bwd(Gb.float(), y, coef2, B, S, N, D)
+    dyb, dbb = ops.hc_depth_bwd(Gb, y, coef2, B, S, N, D)
+    assert torch.equal(dyb, dyf) and relmax(dbb, dbf) <= 1e-5
+    # broadcast operands stay fp32 next to bf16 streams: first branch (x for every stream) and the gradient of the final stream sum
+    xb = rnd(M, D, seed=91)
+    f1 = ops.hc_fwd(xb, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2, rin_bcast=True, r_dtype=BF16)
+    f0 = ops.hc_fwd(xb, B, S, N, D, y_prev=y, coef_prev=coef1, hc=hc2, ln_gamma=g2, rin_bcast=True)
+    assert torch.equal(f1['R'], f0['R'].to(BF16))
+    gb = rnd(M, D, seed=92)
+    b1 = ops.hc_bwd(gb, B, S, N, D, bcast=True, dx=dx2, R=R1b, coef=coef2, dbeta=dbeta2, hc=hc2, r_dtype=BF16)
+    b0 = ops.hc_bwd(gb, B, S, N, D, bcast=True, dx=dx2, R=R1b.float(), coef=coef2, dbeta=dbeta2, hc=hc2)
+    assert torch.equal(b1['dR'], b0['dR'].to(BF16))
+    _, _, _, _, coefx = ops.hc_width_fwd(ops.streams_expand(xb.view(B, N, D), B, S), hc2, g2, B, S, N, D)
+    s1 = ops.hc_bwd(Gb, B, S, N, D, dx=dx2, R=xb, coef=coefx, dbeta=dbeta2, hc=hc2, r_bcast=True, sum_only=True, r_dtype=BF16)
+    s0 = ops.hc_bwd(Gb.float(), B, S, N, D, dx=dx2, R=xb, coef=coefx, dbeta=dbeta2, hc=hc2, r_bcast=True, sum_only=True)
+    assert relmax(s1['dsum'], s0['dsum']) <= 1e-6
+
+
+def test_layernorm_fp32_output_and_fp32_upstream_gradient(ops):
+    """the final LayerNorm of the stack writes fp32 hidden states (logit heads) and receives an fp32 gradient from them"""
+    rows, D = 37, 1024
+    x = rnd(rows, D, seed=93)
+    gamma = (1 + 0.1 * rnd(D, seed=94)).contiguous()
+    y32, _, mean, rstd = ops.layernorm_fwd(x, gamma, out_f32=True)
+    ref = F.layer_norm(x, (D,), gamma, None, 1e-5)
+    assert y32.dtype == F32 and relmax(y32, ref) <= 2e-6
+    ybf, _, _, _ = ops.layernorm_fwd(x, gamma)
+    assert torch.equal(ybf, y32.to(BF16))
+    dy = rnd(rows, D, seed=95)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    (F.layer_norm(xr, (D,), gr, None, 1e-5) * dy).sum().backward()
+    dx, dg = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+    assert relmax(dx, xr.grad) <= 1e-5 and relmax(dg, gr.grad) <= 1e-5
+
+
+@pytest.mark.parametrize('G,C,D,R', [(3, 1025, 1024, 300), (1, 501, 256, 77), (5, 64, 128, 40)])
+def test_split_bf16_logit_heads(ops, G, C, D, R):
+    """logit heads on split-bf16 operands (heads.head_logits): fp32 hidden states x fp32 master weights to ~16 mantissa bits, vs an fp64
+    contraction.  Plain bf16 operands give ~3e-3; the split form must be >= 100 x better."""
+    from audiolm_pytorch_amd import core, heads
+    hn = rnd(R * 2, D, seed=96)
+    w = rnd(G, C, D, seed=97, scale=2.0 / math.sqrt(D))
+    bias = rnd(C, seed=98, scale=0.1) if G == 1 else None
+    g = torch.Generator().manual_seed(99)
+    idx = torch.randint(-1, R * 2, (G, R), generator=g).to(torch.int32).to(dev())
+    hg, logits = heads.head_logits(hn, w, bias, idx, core.WeightCache(), ('head', 't'))
+    rows = torch.where(idx.reshape(-1)[:, None] >= 0, hn[idx.reshape(-1).clamp(min=0).long()], torch.zeros(1, D, device=dev())).view(G, R, D)
+    ref = torch.einsum('grd,gcd->grc', rows.double(), w.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    got = logits.view(G, R, -1)[..., :C]
+    e = relmax(got, ref)
+    assert e <= 3e-5, e
+    assert torch.equal(hg.view(G, R, D), rows.to(BF16))                    # the saved high halves = bf16 image of the gathered rows
+    hi, lo = ops.gather_split(hn)
+    assert torch.equal(hi, hn.to(BF16)) and relmax(hi.float() + lo.float(), hn) <= 2 ** -15
+
+
+def test_embed_assemble_out_of_range_ids_never_touch_memory(ops):
+    """an id outside its table (nn.Embedding raises IndexError, reference audiolm_pytorch.py:709 / :901-906): zero vector, skipped in the
+    backward, device error flag raised -- never an out-of-bounds access"""
+    D = 64
+    t0, t1 = rnd(11, D, seed=50), rnd(7, D, seed=51)
+    src_a = torch.tensor([3, 11, 0xffffff, 10, (5 << 24) | 1], dtype=torch.int32, device=dev())      # row 11 of an 11-row table, huge row, table 5 of 2
+    src_b = torch.tensor([(1 << 24) | 6, (1 << 24) | 7, -1, -1, -1], dtype=torch.int32, device=dev())
+    ops.check_device_errors(dev())
+    out = ops.embed_assemble([t0, t1], src_a, src_b, 5, D)
+    assert torch.equal(out[0], t0[3] + t1[6]) and float(out[1].abs().max()) == 0 and float(out[2].abs().max()) == 0
+    assert torch.equal(out[3], t0[10]) and float(out[4].abs().max()) == 0
+    with pytest.raises(IndexError):
+        ops.check_device_errors(dev())
+    ops.check_device_errors(dev())                                           # the flag is cleared by the check
+    grads = [torch.zeros_like(t0), torch.zeros_like(t1)]
+    ops.embed_scatter_add(grads, src_a, src_b, torch.ones(5, D, device=dev()), 1.0, 5, D)
+    assert float(grads[0].sum()) == 2 * D and float(grads[1].sum()) == D
+
+
 def test_streams_and_elementwise(ops):
     B, S, N, D = 2, 4, 5, 64
     x = rnd(B, N, D, seed=44)

@@ -3,8 +3,11 @@ the REAL reference and (b) the fp32 CPU oracle on seeded random inputs at the re
 
 Tolerances (bf16 GEMM operands / fp32 statistics and residual stream -- the precision `accelerator.autocast()` (trainer.py:1241)
 gives the reference -- compared with the fp32 reference / oracle):
-  loss                 |d| <= max(1e-3 * max(1, |loss|), 2 x N_loss)          (north_star: loss within 1e-3)
-  logits               rel Frobenius error <= 1e-2
+  loss                 |d| <= max(1e-3 * max(1, |loss|), N_loss)              (north_star: loss within 1e-3; the report says which clause held)
+  logits               rel Frobenius error <= min(1e-2, N_logits): never worse than the REFERENCE'S OWN bf16-autocast run on the same
+                       fixture (tests/golden/bf16_noise.pt `logits`, 7e-3 .. 1.3e-2).  north_star's 1e-3 is not reachable with bf16 GEMM
+                       operands by anyone -- the reference included: one rounding of each operand already costs ~2e-3 per contraction.
+                       bf16 residual streams (`residual_dtype=torch.bfloat16`, the reference's autocast storage): <= 1.25 x N_logits
   parameter gradients  rel Frobenius error <= max(3e-2, 2 x N_grad[k]) per tensor; the hyper-connection scalar statistics
                        (static_alpha/static_beta/dynamic_*_scale: heavily cancelling sums over all tokens, so |error| is set by
                        the term magnitudes, not by the net sum) may instead satisfy the POOLED bound over that class:
@@ -44,13 +47,13 @@ def _frob(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-def ours_run(fx, want_logits=True, state=None):
+def ours_run(fx, want_logits=True, state=None, residual_dtype=None):
     import audiolm_pytorch_amd as A
     from audiolm_pytorch_amd import audiolm_pytorch as AP
     dev = torch.device('cuda:0')
     kind, ctor, opt, inp = fx['kind'], fx['ctor'], fx['options'], fx['inputs']
     K = dict(semantic=A.SemanticTransformer, coarse=A.CoarseTransformer, fine=A.FineTransformer)[kind]
-    model = K(**ctor)
+    model = K(**ctor) if residual_dtype is None else K(**ctor, residual_dtype=residual_dtype)
     model.load_state_dict(state if state is not None else synth_state_dict(fx['shapes'], fx['seed']), strict=True)
     model.to(dev)
     mask = inp.get('forgetful_mask')
@@ -131,15 +134,21 @@ FLASH_FIXTURES = ['semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_fla
 BIAS_FIXTURES = ['coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask']
 
 
-@pytest.mark.parametrize('name', FLASH_FIXTURES + BIAS_FIXTURES)
-def test_hip_path_matches_reference_golden(name):
+S4_FIXTURES = ['semantic_s4_flash', 'coarse_s4_flash_mask', 'fine_s4_flash', 'coarse_s4_bias']       # 4 residual streams: bf16 stream storage applies
+
+
+@pytest.mark.parametrize('name,residual', [(n, 'fp32') for n in FLASH_FIXTURES + BIAS_FIXTURES] + [(n, 'bf16') for n in S4_FIXTURES])
+def test_hip_path_matches_reference_golden(name, residual):
     fx = _load(name)
-    loss, logits, grads = ours_run(fx)
+    loss, logits, grads = ours_run(fx, residual_dtype=torch.bfloat16 if residual == 'bf16' else torch.float32)
     ref = fx['outputs']
     rl = float(ref['loss'])
     noise = BF16_NOISE[name]
-    ltol = max(1e-3 * max(1.0, abs(rl)), 2 * noise['loss_abs'])
-    report = [f'{name}: loss ours={loss:.6f} ref={rl:.6f} |d|={abs(loss - rl):.2e} (tol {ltol:.2e}; reference bf16 noise {noise["loss_abs"]:.2e})']
+    strict = 1e-3 * max(1.0, abs(rl))
+    ltol = max(strict, noise['loss_abs'])
+    report = [f'{name} [residual streams {residual}]: loss ours={loss:.6f} ref={rl:.6f} |d|={abs(loss - rl):.2e} rel={abs(loss - rl) / abs(rl):.2e} '
+              f'({"within 1e-3" if abs(loss - rl) <= strict else "OVER 1e-3, within the reference bf16-autocast deviation"}; '
+              f'reference bf16 noise {noise["loss_abs"]:.2e})']
     ok = abs(loss - rl) <= ltol
     if fx['kind'] == 'semantic':
         pairs = [('logits', logits, ref['logits'])]
@@ -148,13 +157,14 @@ def test_hip_path_matches_reference_golden(name):
     else:
         pairs = [('coarse_logits', logits[0], ref['coarse_logits']), ('fine_logits', logits[1], ref['fine_logits'])]
     # NOTE: the logits-only call re-draws nothing (mask injected) but for the semantic wrapper it embeds one more id (reference quirk :1542-1544)
-    for k, got, want in pairs:
+    for (k, got, want), nz in zip(pairs, noise['logits']):
         if got is None or got.shape != want.shape:
             report.append(f'  {k}: shape ours={None if got is None else tuple(got.shape)} ref={tuple(want.shape)} (skipped)')
             continue
         e = _frob(got, want)
-        report.append(f'  {k}: rel-frob {e:.2e}')
-        ok &= e <= 1e-2
+        bound = min(1e-2, nz) if residual == 'fp32' else 1.25 * nz
+        report.append(f'  {k}: rel-frob {e:.2e} (reference bf16-autocast run: {nz:.2e}; bound {bound:.2e}; north_star 1e-3)')
+        ok &= e <= bound
     items = []
     for k, dg in ref['grads'].items():
         if dg is None:
