@@ -361,6 +361,15 @@ class Transformer(nn.Module):
         out.append(self.norm.gamma)
         return out
 
+    def prepack_weights(self):
+        """(re)builds the bf16 packed copies of every dense weight of the stack now (they are otherwise built lazily, layer by layer, by the first
+        forward that finds a master weight changed).  graphed.GraphedTrainStep calls this ahead of forking its two half-batch streams."""
+        flat = [t.detach() for t in self.flat_params()]
+        ppl = core.params_per_layer(self.cfg.streams)
+        for l in range(self.cfg.depth):
+            pa, pf = core._split_layer(flat[l * ppl:(l + 1) * ppl], self.cfg.streams)
+            core.layer_weights(self._cache, l, pa, pf, self.cfg.inner, self.cfg.inner_pad)
+
     def forward(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, return_kv_cache=False, kv_cache=None,
                 return_flat_hidden=False):
         if exists(context) or exists(kv_cache):
@@ -557,6 +566,25 @@ class _TransformerBase(nn.Module):
 
     def _heads_cache(self):
         return self.transformer._cache
+
+    def _head_weights(self):
+        """(cache key, fp32 weight [G, C, D]) of every logit head of this model"""
+        out = []
+        for key, attr in (('semantic', 'to_logits'), ('semantic', 'to_semantic_logits')):
+            lin = getattr(self, attr, None)
+            if lin is not None:
+                out.append((key, lin.weight.unsqueeze(0)))
+        for key, attr in (('coarse', 'coarse_logit_weights'), ('fine', 'fine_logit_weights')):
+            w = getattr(self, attr, None)
+            if w is not None:
+                out.append((key, w))
+        return out
+
+    def prepack_weights(self):
+        """packs every bf16 weight copy of the model (stack + logit heads) now instead of lazily inside the next forward"""
+        self.transformer.prepack_weights()
+        for key, w in self._head_weights():
+            self._heads_cache().get(('head', key), w.detach(), heads._pack_head)
 
 
 # ---------------------------------------------------------------------------------------------- SemanticTransformer (:564-724)

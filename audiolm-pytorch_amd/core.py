@@ -281,11 +281,13 @@ class _SideStream:
     def __init__(self, dev, enabled=True):
         self.enabled = enabled and dev.type == 'cuda'
         if self.enabled:
-            key = (dev.type, dev.index, SIDE_STREAMS)
+            self.main = torch.cuda.current_stream(dev)
+            # one set of side streams per MAIN stream: two half-batches running on two streams (graphed.GraphedTrainStep) must not serialise
+            # their weight gradients behind each other
+            key = (dev.type, dev.index, SIDE_STREAMS, self.main.cuda_stream)
             if key not in _SideStream._streams:
                 _SideStream._streams[key] = [torch.cuda.Stream(device=dev) for _ in range(SIDE_STREAMS)]
             self.streams = _SideStream._streams[key]
-            self.main = torch.cuda.current_stream(dev)
             self.turn = 0
 
     def _issue(self, stream, fn, tensors):

@@ -1,0 +1,105 @@
+"""Training step as ONE hipGraph launch, optionally as two half-batches on two HIP streams.
+
+Why: one forward + backward of the fused stack is ~600 kernel launches issued from Python / ctypes (~9.6 ms of host time per step at
+dim 1024 depth 6, measured: DESIGN.md section 4).  As long as the GPU needs longer than that per step the host hides behind it, but (a) every
+GPU-side gain moves the step towards being host-bound and (b) the schedule that overlaps the HBM-bound kernels (hyper-connections,
+LayerNorm, GEGLU: the matrix cores idle) with the MFMA-bound GEMMs (HBM idle) needs twice as many launches: the batch is split into two
+micro-batches that run the whole forward + backward independently on two streams, so that one half's GEMM is co-resident with the other
+half's row kernels.  Captured once (torch.cuda.CUDAGraph: every alm_* launch goes to torch's current stream, which is the capturing stream)
+and replayed with one launch per step, the host cost disappears.
+
+Nothing here changes the arithmetic of a micro-batch; the two halves' gradients are summed (mean of the two half-batch losses == the
+full-batch loss when both halves hold the same number of target tokens, which fixed-shape batches do; SURVEY.md section 8(e) uses the same
+argument for data parallelism).
+
+    step = GraphedTrainStep(wrapper, dict(semantic_token_ids=sem, coarse_token_ids=coarse), micro_batches=2)
+    loss = step(semantic_token_ids=sem, coarse_token_ids=coarse)      # p.grad of every parameter holds this step's gradient
+    optimizer.step()
+
+Restrictions (checked or documented): fixed shapes; no data-dependent host control flow inside the step (`unique_consecutive=True` is one:
+its output length depends on the data); the gradient exchange of parallel.DataParallelEngine is not captured -- call the engine's
+`reduce_grads()` style hooks outside, or use the eager path for multi-GPU runs.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, module, example_inputs: dict, *, micro_batches: int = 1, warmup: int = 3, call_kwargs=None, params=None):
+        assert micro_batches in (1, 2), 'one batch or two half-batches'
+        self.module = module
+        self.kw = dict(call_kwargs or dict(return_loss=True))
+        self.params = [p for p in (params if params is not None else module.parameters()) if p.requires_grad]
+        self.nmb = micro_batches
+        self.static_in = {k: v.clone() for k, v in example_inputs.items()}
+        b = next(iter(self.static_in.values())).shape[0]
+        assert all(v.shape[0] == b for v in self.static_in.values()), 'inputs are batch-first tensors of one batch size'
+        assert b % micro_batches == 0, (b, micro_batches)
+        self.dev = next(iter(self.static_in.values())).device
+        self._caches = [m._cache for m in module.modules() if hasattr(m, '_cache') and hasattr(m._cache, 'store')]
+        self.graph = None
+        self.loss = None
+        self.grads = None
+        self._side = torch.cuda.Stream(device=self.dev) if micro_batches == 2 else None
+        self._capture(warmup)
+
+    # the work of one step, issued on the current stream (+ the second stream for the second half)
+    def _issue(self):
+        for c in self._caches:
+            c.store.clear()                                  # the bf16 weight copies are re-packed inside the step: weights change between replays
+        n = self.nmb
+        if n == 1:
+            loss = self.module(**self.static_in, **self.kw)
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            return loss.detach(), list(grads)
+        b = next(iter(self.static_in.values())).shape[0] // 2
+        halves = [{k: v[i * b:(i + 1) * b] for k, v in self.static_in.items()} for i in range(2)]
+        cur = torch.cuda.current_stream(self.dev)
+        # pack the bf16 weight copies once, ahead of the fork: both halves read the same copies, and neither waits for the other's forward
+        for m in self.module.modules():
+            if hasattr(m, '_head_weights') and hasattr(m, 'prepack_weights'):
+                m.prepack_weights()
+        self._side.wait_stream(cur)
+        la = self.module(**halves[0], **self.kw)
+        with torch.cuda.stream(self._side):
+            lb = self.module(**halves[1], **self.kw)
+            gb = torch.autograd.grad(lb, self.params, allow_unused=True)
+        ga = torch.autograd.grad(la, self.params, allow_unused=True)
+        cur.wait_stream(self._side)
+        for t in gb:
+            if t is not None:
+                t.record_stream(cur)
+        out, pa, pb = [], [], []
+        for x, y in zip(ga, gb):
+            if x is None:
+                out.append(None if y is None else y * 0.5)
+            else:
+                out.append(x)
+                if y is not None:
+                    pa.append(x), pb.append(y)
+        if pa:
+            torch._foreach_add_(pa, pb)
+            torch._foreach_mul_(pa, 0.5)
+        return ((la + lb.to(la.device)) * 0.5).detach(), out
+
+    def _capture(self, warmup):
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup)):                   # lazy initialisation (occupancy queries, allocator pools, side streams) outside the capture
+                self._issue()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss, self.grads = self._issue()
+        self.graph = g
+
+    def __call__(self, **inputs):
+        for k, v in inputs.items():
+            self.static_in[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        return self.loss

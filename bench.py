@@ -8,13 +8,24 @@ configs[1]/[3]).
 One process per GPU; per-rank batch B = 8 (weak scaling); a "step" = CoarseTransformerWrapper.forward(return_loss=True) +
 backward (+ RCCL gradient all-reduce over xGMI for N > 1), inputs resident in HBM, the bf16 weight copies are re-packed from
 the fp32 masters every step (as after an optimiser step).  The optimiser itself is outside the metric ("fwd+bwd"); a second
-timed loop that includes torch's Adam step is reported as `with_optimizer` for reference.
+timed loop that includes the clip + Adam step is reported as `with_optimizer` for reference.
+
+--config selects the other BASELINE.json configurations / SURVEY §8(d) rows (same JSON contract, each with its own roofline and CPU
+baseline): coarse2048 (default, the metric's configuration), coarse1024 (configs[1]), fine2049 (configs[2]), fine_t2048_q8 (the other
+reading of "(B=8, Q=8, seq=2048)": a 2048-frame x 8-quantizer grid, N = 16385), e2e_config5 (configs[4]: SoundStream tokenize of
+8 x 30 s @ 24 kHz + CoarseTransformer codebook 4096, N = 8253).
+
+--schedule: eager = every launch issued from Python each step; graph = the step captured once into a hipGraph (graphed.GraphedTrainStep)
+and replayed; graph2 = the same with the batch split into two half-batches on two HIP streams (HBM-bound row kernels of one half under
+the MFMA-bound GEMMs of the other).  auto (default) = graph2 on one GPU when the capture succeeds, else eager; N > 1 ranks run eager (the
+gradient all-reduce is launched from backward callbacks).  The arithmetic is the same in all three; the JSON line says which ran.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the bf16 MFMA GEMM (gemm_nt_kernel); achieved = algorithmic GEMM FLOPs per launch / average launch
-               duration, measured live with HIP events on the launch stream over one instrumented step; peak = 2500 TFLOP/s dense bf16.
+  roofline     dominant kernel = the bf16 MFMA GEMM (gemm_kernel<256,256,...,NT>); achieved = algorithmic GEMM FLOPs per launch / average
+               launch duration, measured live with HIP events on the launch stream over one instrumented EAGER step; peak = 2500 TFLOP/s.
   cpu_baseline the oracle (CPU fp32 restatement of the reference, "port") timed on this box's host cores on a bounded sample
-               (B = 1, N = 2048, same architecture), rank 0 at N = 1 only.
+               (B = 1, same architecture), rank 0 at N = 1 only, with 4 residual streams and with 1 (pure reference code).
+  parity       the HIP path's loss on that same sample (same weights, ids, forgetful mask) vs the oracle's: asserted within 1e-3.
 """
 from __future__ import annotations
 
@@ -31,10 +42,11 @@ for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'golde
 
 import torch  # noqa: E402
 
-MODEL = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True)
-B_PER_GPU, N_SEM, N_FRAMES = 8, 509, 512          # N = 1 + (509 + 1) + 1 + 512 * 3 = 2048
-SEQ = 1 + (N_SEM + 1) + 1 + N_FRAMES * 3
+B_PER_GPU = 8
 PEAK_BF16_TFLOPS = 2500.0                          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+METRIC = 'audio-tokens/sec fwd+bwd, CoarseTransformer d=1024 seq=2048'
+COARSE = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True)
+FINE = dict(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True)
 
 
 class Codec:
@@ -42,51 +54,156 @@ class Codec:
     num_quantizers = 8
 
 
-def cpu_baseline(max_seconds=30.0):
-    """Times the CPU oracle (fp32) on a bounded sample of the same workload: B = 1, N = 2048, fwd + bwd."""
-    import audiolm_oracle as O
+def flops_per_token(kind, N, cb=1024):
+    """algorithmic fwd+bwd FLOPs per token: dense GEMMs + causal attention + logit heads + hyper-connections, x2 FLOP/MAC, x3"""
+    dense = 6 * 9566208
+    attn = 6 * 2 * 8 * 64 * (N + 1) / 2
+    heads = 0.92e6 * (cb + 1) / 1025 if kind == 'coarse' else 1.05e6
+    return (dense + attn + heads + 0.59e6) * 2 * 3
+
+
+def build(config, dev, rank, residual_dtype):
+    """-> dict(kind, model, wrapper, inputs (device tensors, batch-first), N, metric, workload, sample = (kind, ctor, N_sample builder))"""
     import audiolm_pytorch_amd as A
-    cores = min(os.cpu_count() or 1, 32)          # one GPU's share of the host (256 cores / 8 GPUs); more threads oversubscribe torch's CPU ops
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    model = A.CoarseTransformer(**MODEL)
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1000 + rank)              # a different synthetic shard per rank
+    torch.manual_seed(0)                                        # identical initial weights on every rank
+    B = B_PER_GPU
+    if config in ('coarse2048', 'coarse1024', 'e2e_config5'):
+        ctor = dict(COARSE)
+        codec = Codec()
+        if config == 'e2e_config5':
+            ctor['codebook_size'] = 4096
+            ss = A.SoundStream(codebook_size=4096, rq_num_quantizers=8, target_sample_hz=24000, strides=(2, 4, 5, 8), use_local_attn=False)
+            with torch.no_grad():
+                for r in ss.rq.rvqs:
+                    for q, l in enumerate(r.layers):
+                        l._codebook.embed.copy_(torch.randn(1, 4096, 512) * (0.5 ** q))
+                        l._codebook.initted.fill_(True)
+            codec = ss.to(dev)
+        model = A.CoarseTransformer(**ctor, residual_dtype=residual_dtype).to(dev)
+        wrapper = A.CoarseTransformerWrapper(transformer=model, codec=codec, unique_consecutive=False, mask_prob=0.15)
+        if config == 'e2e_config5':
+            n_sem, N = 1500, 1 + 1501 + 1 + 6750
+            inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, n_sem), generator=g).to(dev),
+                          raw_wave=(torch.randn(B, 720000, generator=g) * 0.1).to(dev))
+            metric = 'audio-tokens/sec, SoundStream tokenize + CoarseTransformer fwd+bwd end to end (BASELINE configs[4])'
+            work = (f'SoundStream(codebook 4096, 8 quantizers, 24 kHz, strides 2-4-5-8) tokenize of {B} x 30 s synthetic audio + CoarseTransformer dim=1024 '
+                    f'depth=6 codebook=4096 fwd+bwd; N = 1 + 1501 + 1 + 6750 = {N}; mask_prob=0.15')
+        else:
+            n_sem, n_fr = (509, 512) if config == 'coarse2048' else (253, 256)
+            N = 1 + (n_sem + 1) + 1 + n_fr * 3
+            inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, n_sem), generator=g).to(dev),
+                          coarse_token_ids=torch.randint(0, 1024, (B, n_fr, 3), generator=g).to(dev))
+            metric = METRIC if config == 'coarse2048' else 'audio-tokens/sec fwd+bwd, CoarseTransformer d=1024 seq=1024 (BASELINE configs[1])'
+            work = (f'CoarseTransformer dim=1024 depth=6 heads=8 (MQA) num_coarse_quantizers=3 codebook=1024 semantic=500 residual_streams=4 flash_attn=True; '
+                    f'per-GPU B={B}, N={N} ({n_sem} semantic + {n_fr}x3 coarse ids + eos/start); mask_prob=0.15')
+        kind = 'coarse'
+    elif config in ('fine2049', 'fine_t2048_q8'):
+        T = 256 if config == 'fine2049' else 2048
+        model = A.FineTransformer(**FINE, residual_dtype=residual_dtype).to(dev)
+        wrapper = A.FineTransformerWrapper(transformer=model, codec=Codec(), mask_prob=0.15)
+        grid = torch.randint(0, 1024, (B, T, 8), generator=g).to(dev)
+        inputs = dict(coarse_token_ids=grid[..., :3].contiguous(), fine_token_ids=grid[..., 3:].contiguous())
+        N = 1 + 3 * T + 1 + 5 * T - 1
+        metric = f'audio-tokens/sec fwd+bwd, FineTransformer d=1024 seq={N}' + (' (BASELINE configs[2])' if T == 256 else ' (2048 frames x 8 quantizers)')
+        work = (f'FineTransformer dim=1024 depth=6 heads=8 (MQA) 3 coarse + 5 fine quantizers codebook=1024 residual_streams=4 flash_attn=True; per-GPU B={B}, '
+                f'{T} frames x 8 quantizers -> N={N}; mask_prob=0.15')
+        kind, ctor = 'fine', dict(FINE)
+    else:
+        raise SystemExit(f'unknown --config {config}')
+    wrapper.train()
+    return dict(kind=kind, ctor=ctor, model=model, wrapper=wrapper, inputs=inputs, N=N, B=B, metric=metric, workload=work)
+
+
+def oracle_sample(kind, ctor, sd, streams, seed=0):
+    """One B = 1 sample of the same architecture at the metric's sequence length class (N = 2048 Coarse / 2049 Fine) through the CPU oracle:
+    -> (loss tensor with graph, params dict, inputs for the HIP side)"""
+    import audiolm_oracle as O
+    g = torch.Generator().manual_seed(seed)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith('.beta')}
     full = dict(sd)
     full.update(params)
-    cfg = O.Cfg(dim=1024, depth=6, streams=4, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3)
-    g = torch.Generator().manual_seed(0)
-    sem = torch.randint(0, 500, (1, N_SEM), generator=g)
-    coarse = torch.randint(0, 1024, (1, N_FRAMES, 3), generator=g)
-    mask = O.generate_mask_with_prob((1, SEQ), 0.15, 'cpu', generator=g)
-    times = []
-    t_start = time.time()
-    for it in range(3):
+    if kind == 'coarse':
+        cfg = O.Cfg(dim=ctor['dim'], depth=ctor['depth'], streams=streams, num_semantic_tokens=500, codebook_size=ctor['codebook_size'], num_coarse_quantizers=3)
+        sem = torch.randint(0, 500, (1, 509), generator=g)
+        coarse = torch.randint(0, ctor['codebook_size'], (1, 512, 3), generator=g)
+        mask = O.generate_mask_with_prob((1, 2048), 0.15, 'cpu', generator=g)
+        fn = lambda: O.coarse_wrapper_loss(full, cfg, sem, coarse, training=True, unique_consecutive=False, forgetful_mask=mask)   # noqa: E731
+        return fn, params, dict(semantic_token_ids=sem, coarse_token_ids=coarse), mask, 2048
+    cfg = O.Cfg(dim=ctor['dim'], depth=ctor['depth'], streams=streams, codebook_size=1024, num_coarse_quantizers=3, num_fine_quantizers=5)
+    grid = torch.randint(0, 1024, (1, 256, 8), generator=g)
+    c, f = grid[..., :3].contiguous(), grid[..., 3:].contiguous()
+    mask = O.generate_mask_with_prob((1, 2049), 0.15, 'cpu', generator=g)
+    fn = lambda: O.fine_wrapper_loss(full, cfg, c, f, forgetful_mask=mask)                                                         # noqa: E731
+    return fn, params, dict(coarse_token_ids=c, fine_token_ids=f), mask, 2049
+
+
+def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
+    """Times the CPU oracle (fp32) on a bounded sample of the same architecture (B = 1, N = 2048 / 2049, fwd + bwd; 4 streams and 1 stream) and
+    checks the HIP path's loss on EXACTLY that sample (same weights, ids and forgetful mask) against it."""
+    import audiolm_pytorch_amd as A
+    from audiolm_pytorch_amd import audiolm_pytorch as AP
+    cores = min(os.cpu_count() or 1, 32)          # one GPU's share of the host (256 cores / 8 GPUs); more threads oversubscribe torch's CPU ops
+    torch.set_num_threads(cores)
+    kind, ctor, model = W['kind'], W['ctor'], W['model']
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    out = {}
+    fn, params, ids, mask, Ns = oracle_sample(kind, ctor, sd, 4)
+    times, t_start, loss4 = [], time.time(), None
+    for _ in range(3):
         t0 = time.time()
-        loss = O.coarse_wrapper_loss(full, cfg, sem, coarse, training=True, unique_consecutive=False, forgetful_mask=mask)
+        loss = fn()
         loss.backward()
         times.append(time.time() - t0)
+        loss4 = float(loss)
         for p in params.values():
             p.grad = None
         if time.time() - t_start > max_seconds:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(SEQ / best, 1), unit='audio-tokens/s', cores=cores, kind='port',
-                sample=f'oracle (CPU fp32 restatement of the reference, 4 residual streams) fwd+bwd, B=1 x N={SEQ}, best of {max(1, len(times) - 1)} after 1 warm-up')
-
-
-PRIME_STEPS = 10
+    out['cpu_baseline'] = dict(value=round(Ns / best, 1), unit='audio-tokens/s', cores=cores, kind='port',
+                               sample=f'oracle (CPU fp32 restatement of the reference, 4 residual streams) fwd+bwd, B=1 x N={Ns}, best of {max(1, len(times) - 1)} after 1 warm-up')
+    del params
+    # the HIP path on the same sample
+    orig = AP.generate_mask_with_prob
+    AP.generate_mask_with_prob = lambda shape, prob, device: mask.to(device).clone()
+    try:
+        with torch.no_grad():
+            lh = float(W['wrapper'](**{k: v.to(dev) for k, v in ids.items()}, return_loss=True))
+    finally:
+        AP.generate_mask_with_prob = orig
+    rel = abs(lh - loss4) / abs(loss4)
+    out['parity'] = dict(loss_hip=round(lh, 6), loss_oracle=round(loss4, 6), rel=float(f'{rel:.3e}'), bound=1e-3, ok=bool(rel <= 1e-3),
+                         sample=f'same weights / ids / forgetful mask as the cpu_baseline sample (B=1, N={Ns})')
+    # 1 residual stream = every op is first-party reference code (no restated hyper-connections): timing only, fresh weights of that architecture
+    try:
+        K = A.CoarseTransformer if kind == 'coarse' else A.FineTransformer
+        torch.manual_seed(0)
+        sd1 = {k: v.detach().clone() for k, v in K(**ctor, num_residual_streams=1).state_dict().items()}
+        fn1, params1, _, _, _ = oracle_sample(kind, ctor, sd1, 1)
+        t1 = []
+        for _ in range(2):
+            t0 = time.time()
+            fn1().backward()
+            t1.append(time.time() - t0)
+        out['cpu_baseline']['streams1'] = dict(value=round(Ns / min(t1), 1), unit='audio-tokens/s',
+                                               sample=f'oracle with num_residual_streams=1 (pure reference code), B=1 x N={Ns}, best of 2')
+    except Exception as e:                                       # the baseline is a reported number, never a reason to lose the bench line
+        out['cpu_baseline']['streams1'] = dict(error=str(e)[:200])
+    return out
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r1_pmc_summary.json: FETCH_SIZE x 2
-    per the MI355X guide's gfx950 correction + WRITE_SIZE), or None when the summary is absent.  Counters cannot be collected inside this
-    process; scripts/pmc.sh regenerates them."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_pmc_summary.json')) as fh:
-            return json.load(fh)['hbm_bytes_per_launch']
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 per the MI355X guide's gfx950
+    correction + WRITE_SIZE) -- read from profiles/, NOT measured in this run (counters cannot be collected inside this process;
+    scripts/pmc.sh regenerates them) -- or None when no summary is present."""
+    for name in ('r2_pmc_summary.json', 'r1_pmc_summary.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                return json.load(fh)['hbm_bytes_per_launch'], name
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -94,6 +211,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='coarse2048', choices=['coarse2048', 'coarse1024', 'fine2049', 'fine_t2048_q8', 'e2e_config5'])
+    ap.add_argument('--schedule', default='auto', choices=['auto', 'eager', 'graph', 'graph2'])
+    ap.add_argument('--residual', default='bf16', choices=['bf16', 'fp32'],
+                    help='HBM storage of the 4 hyper-connection residual streams: bf16 = what trainer.py:1241 autocast gives the reference (default), fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer-leg', action='store_true')
     args = ap.parse_args()
@@ -111,49 +232,74 @@ def main():
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        print(f'[bench rank {rank}/{world}] init_process_group on cuda:{local_rank}', file=sys.stderr, flush=True)
         if share:
-            dist.init_process_group('gloo')
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group('nccl', device_id=dev)      # backend "nccl" IS RCCL on ROCm
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))      # backend "nccl" IS RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
 
+    from audiolm_pytorch_amd import core, graphed, ops, parallel
     import audiolm_pytorch_amd as A
-    from audiolm_pytorch_amd import ops, parallel
 
-    torch.manual_seed(0)                                        # identical initial weights on every rank
-    model = A.CoarseTransformer(**MODEL).to(dev)
-    wrapper = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
-    wrapper.train()
+    W = build(args.config, dev, rank, torch.bfloat16 if args.residual == 'bf16' else torch.float32)
+    model, wrapper, inputs, N = W['model'], W['wrapper'], W['inputs'], W['N']
     engine = parallel.DataParallelEngine(model, dist) if world > 1 else None
-
-    g = torch.Generator().manual_seed(1000 + rank)              # a different synthetic shard per rank
-    sem = torch.randint(0, 500, (B_PER_GPU, N_SEM), generator=g).to(dev)
-    coarse = torch.randint(0, 1024, (B_PER_GPU, N_FRAMES, 3), generator=g).to(dev)
     cache = model.transformer._cache
 
-    def step(opt=None):
+    def eager_step(opt=None):
         cache.store.clear()                                     # weights "changed": re-pack bf16 copies like after an optimiser step
         for p in model.parameters():
             p.grad = None
-        loss = wrapper(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True)
+        loss = wrapper(**inputs, return_loss=True)
         loss.backward()
         if engine is not None:
             engine.finish()                                     # waits for the overlapped RCCL all-reduces, grads averaged in place
         if opt is not None:
             opt.step()
-        return loss
+        return loss.detach()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(nsteps, opt=None):
+    # ---- schedule
+    schedule, note, gstep = 'eager', None, None
+    want = args.schedule
+    if want == 'auto':
+        # e2e_config5 tokenizes raw audio inside the step (codec under inference_mode, data-dependent host code): kept out of the capture
+        want = 'graph2' if (world == 1 and args.config != 'e2e_config5') else 'eager'
+    for _ in range(3):                                          # lazy initialisation before any capture
+        eager_step()
+    if want in ('graph', 'graph2') and world == 1:
+        try:
+            gstep = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=2 if want == 'graph2' else 1)
+            torch.cuda.synchronize()
+            schedule = want
+        except Exception as e:                                  # capture is an optimisation: report why it was not used, run eager
+            note = f'{want} capture failed ({type(e).__name__}: {str(e)[:160]}); ran eager'
+            print('[bench] ' + note, file=sys.stderr, flush=True)
+            gstep = None
+            torch.cuda.synchronize()
+    elif want != 'eager':
+        note = f'{want} is a single-GPU schedule (the gradient all-reduce is issued from backward callbacks); ran eager'
+
+    def step(opt=None):
+        if gstep is not None:
+            loss = gstep(**inputs)
+            if opt is not None:
+                opt.step()
+            return loss
+        return eager_step(opt)
+
+    def timed(nsteps, fn):
         barrier()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            step(opt)
+            fn()
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -164,76 +310,93 @@ def main():
 
     # untimed priming in addition to --warmup: the first steps grow the caching allocator's pools (main + side stream) and run at ramping
     # clocks; measured on MI355X the step time only settles after ~10 steps (17.6 -> 16.4 ms).  The timed region below is exactly --steps steps.
-    for _ in range(PRIME_STEPS):
+    big = N > 4096
+    for _ in range(3 if big else 10):
         loss = step()
     for _ in range(args.warmup):
         loss = step()
-    dt = timed(args.steps)
+    dt = timed(args.steps, step)
     ms = dt / args.steps * 1e3
-    tokens_per_s = world * B_PER_GPU * SEQ / (dt / args.steps)
+    tokens_per_s = world * W['B'] * N / (dt / args.steps)
 
-    # ---- roofline of the dominant kernel: one instrumented step, HIP events (torch.cuda.Event on the launch stream = torch's current
+    # host time to ISSUE one step (no synchronisation inside): eager launches vs one graph replay
+    host = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eager_step()
+    host['eager_issue_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+    torch.cuda.synchronize()
+    if gstep is not None:
+        t0 = time.perf_counter()
+        gstep(**inputs)
+        host['graph_replay_issue_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+        torch.cuda.synchronize()
+        dte = timed(max(3, args.steps // 2), eager_step)
+        host['eager_ms_per_step'] = round(dte / max(3, args.steps // 2) * 1e3, 3)
+
+    # ---- roofline of the dominant kernel: one instrumented EAGER step, HIP events (torch.cuda.Event on the launch stream = torch's current
     # stream, which is the stream every alm_* launch uses) around every MFMA GEMM launch.  The dominant kernel is the NT 256x256x64
     # 8-wave tile (gemm_kernel<256,256,2,4,false,*>): its launches are singled out; all GEMM launches are reported alongside.
     # EVERY rank runs the instrumented step (with N > 1 it contains the gradient all-reduces: a step on rank 0 alone would dead-lock the
     # collectives); only rank 0's numbers are reported.
     roof = None
-    if True:
-        events = []
-        orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn_splitk
+    events = []
+    orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn_splitk
 
-        def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
-            return M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) * nb >= 192
+    def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
+        return M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) * nb >= 192
 
-        def timed_nt(Am, Bm, Cm, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_nt(Am, Bm, Cm, **kw)
-            e1.record()
-            nb = 1
-            for d in Am.shape[:-2]:
-                nb *= d
-            Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
-            events.append((e0, e1, 2.0 * nb * Mm * Nn * Kk, 'nt256' if big_tile(Mm, Nn, nb) else 'nt128'))
-            return out
+    def timed_nt(Am, Bm, Cm, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_nt(Am, Bm, Cm, **kw)
+        e1.record()
+        nb = 1
+        for d in Am.shape[:-2]:
+            nb *= d
+        Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
+        events.append((e0, e1, 2.0 * nb * Mm * Nn * Kk, 'nt256' if big_tile(Mm, Nn, nb) else 'nt128'))
+        return out
 
-        def timed_tn(At, Bt, Cm, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_tn(At, Bt, Cm, **kw)
-            e1.record()
-            nb = At.shape[0] if At.dim() == 3 else 1
-            events.append((e0, e1, 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2], 'tn'))
-            return out
-        ops.gemm_nt, ops.gemm_tn_splitk = timed_nt, timed_tn
-        import audiolm_pytorch_amd.core as core_mod
-        was_async, core_mod.ASYNC_WGRAD = core_mod.ASYNC_WGRAD, False      # per-kernel durations: no concurrent side-stream GEMMs in this step
-        try:
-            step()
-            torch.cuda.synchronize()
-        finally:
-            ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
-            core_mod.ASYNC_WGRAD = was_async
-        agg = {}
-        for e0, e1, fl, kind in events:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1)
-            a[1] += fl
-            a[2] += 1
-        tot_ms = sum(a[0] for a in agg.values())
-        tot_fl = sum(a[1] for a in agg.values())
-        d_ms, d_fl, d_n = agg.get('nt256', [0.0, 0.0, 0])
-        if d_n:
-            ach = d_fl / (d_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<256,256,2,4,NT> (bf16 MFMA 32x32x16; FFN / projection forward + dgrad GEMMs)',
-                    'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
-                    'traffic': pmc_traffic(), 'launches_per_step': d_n, 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
-                    'flop_per_launch_avg': round(d_fl / d_n, 0),
-                    'share_of_step': round(d_ms / ms, 3),
-                    'all_gemm_launches': {'launches_per_step': len(events), 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
-                                          'share_of_step': round(tot_ms / ms, 3),
-                                          'by_kind_ms': {k: round(v[0], 3) for k, v in agg.items()}},
-                    'model_flops_frac': round(tokens_per_s / world * 391e6 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+    def timed_tn(At, Bt, Cm, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_tn(At, Bt, Cm, **kw)
+        e1.record()
+        nb = At.shape[0] if At.dim() == 3 else 1
+        events.append((e0, e1, 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2], 'tn'))
+        return out
+    ops.gemm_nt, ops.gemm_tn_splitk = timed_nt, timed_tn
+    was_async, core.ASYNC_WGRAD = core.ASYNC_WGRAD, False      # per-kernel durations: no concurrent side-stream GEMMs in this step
+    try:
+        eager_step()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
+        core.ASYNC_WGRAD = was_async
+    agg = {}
+    for e0, e1, fl, kind in events:
+        a = agg.setdefault(kind, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += fl
+        a[2] += 1
+    tot_ms = sum(a[0] for a in agg.values())
+    tot_fl = sum(a[1] for a in agg.values())
+    d_ms, d_fl, d_n = agg.get('nt256', [0.0, 0.0, 0])
+    if d_n:
+        ach = d_fl / (d_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
+        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<256,256,2,4,NT> (bf16 MFMA 32x32x16; FFN / projection forward + dgrad GEMMs)',
+                'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                'traffic': traffic if args.config == 'coarse2048' else None,
+                'traffic_source': (f'profiles/{traffic_src} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)'
+                                   if traffic is not None and args.config == 'coarse2048' else None),
+                'launches_per_step': d_n, 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
+                'flop_per_launch_avg': round(d_fl / d_n, 0),
+                'measured_in': 'one instrumented eager step, weight-gradient side stream off (kernels do not overlap)',
+                'all_gemm_launches': {'launches_per_step': len(events), 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                      'by_kind_ms': {k: round(v[0], 3) for k, v in agg.items()}},
+                'model_flops_frac': round(tokens_per_s / world * flops_per_token(W['kind'], N, W['ctor'].get('codebook_size', 1024)) / (PEAK_BF16_TFLOPS * 1e12), 4)}
     if dist is not None:
         dist.barrier()
 
@@ -245,28 +408,13 @@ def main():
         nst = max(3, args.steps // 2)
 
         def opt_step(opt, clip):
-            cache.store.clear()
-            for p in model.parameters():
-                p.grad = None
-            wrapper(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True).backward()
-            if engine is not None:
-                engine.finish()
+            step()
             clip(opt)
             opt.step()
 
         def timed_opt(opt, clip):
             opt_step(opt, clip)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(nst):
-                opt_step(opt, clip)
-            barrier()
-            dt_ = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([dt_], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt_ = float(t)
-            return dt_
+            return timed(nst, lambda: opt_step(opt, clip))
         state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
         fused = A.get_optimizer(model.parameters(), lr=1e-5, wd=0.)
         dto = timed_opt(fused, lambda o: o.clip_grad_norm_(0.5))
@@ -274,13 +422,15 @@ def main():
         model.load_state_dict(state0)
         stock = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.99))
         dts = timed_opt(stock, lambda o: torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5))
-        opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * B_PER_GPU * SEQ / (dto / nst), 1),
+        del stock
+        model.load_state_dict(state0)
+        opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * W['B'] * N / (dto / nst), 1),
                        optimizer='FusedAdam (alm_opt_grad_sumsq + alm_opt_adam_step): clip_grad_norm_(0.5) + Adam',
                        torch_adam_ms_per_step=round(dts / nst * 1e3, 3))
 
     if rank == 0:
         out = {
-            'metric': 'audio-tokens/sec fwd+bwd, CoarseTransformer d=1024 seq=2048',
+            'metric': W['metric'],
             'value': round(tokens_per_s, 1),
             'unit': 'audio-tokens/s',
             'n_gpus': world,
@@ -291,19 +441,31 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'bf16',
-            'data': 'synthetic (uniform random semantic / coarse RVQ token ids, random-init weights)',
-            'config': {'workload': 'CoarseTransformer dim=1024 depth=6 heads=8 (MQA) num_coarse_quantizers=3 codebook=1024 semantic=500 '
-                                   'residual_streams=4 flash_attn=True; per-GPU B=8, N=2048 (509 semantic + 512x3 coarse ids + eos/start); mask_prob=0.15',
-                       'global_batch': world * B_PER_GPU, 'seq_len': SEQ, 'parallelism': f'dp{world}'},
+            'data': 'synthetic (uniform random semantic / acoustic RVQ token ids, random-init weights)',
+            'config': {'workload': W['workload'], 'global_batch': world * W['B'], 'seq_len': N, 'parallelism': f'dp{world}',
+                       'schedule': {'eager': 'eager (every kernel launched from Python each step)',
+                                    'graph': 'one hipGraph replay per step (captured fwd + bwd)',
+                                    'graph2': 'one hipGraph replay per step: two half-batches of 4 sequences on two HIP streams (row kernels of one half under the GEMMs '
+                                              'of the other), gradients summed'}[schedule],
+                       'residual_stream_storage': 'bf16 (what autocast gives the reference)' if model.transformer.cfg.residual_bf16 else 'fp32'},
             'loss': round(float(loss), 4),
+            'host': host,
         }
+        if note:
+            out['config']['schedule_note'] = note
         if roof:
             out['roofline'] = roof
         if opt_leg:
             out['with_optimizer'] = opt_leg
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+            out.update(cpu_baseline_and_parity(W, dev))
+        print(json.dumps(out), flush=True)
+        par = out.get('parity')
+        if par is not None and not par['ok']:
+            print(f'[bench] PARITY FAILURE: HIP loss {par["loss_hip"]} vs oracle {par["loss_oracle"]} (rel {par["rel"]} > 1e-3)', file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

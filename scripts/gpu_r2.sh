@@ -31,7 +31,7 @@ if has fullsize; then
 fi
 if has fullsizebf; then
   rm -f gpurun_out/r2_fullsize_parity.jsonl
-  ALM_RESIDUAL_DTYPE=bf16 timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --tb=short -s --timeout 900 -k "4-" > gpurun_out/${tag}_fullsize_bf16.log 2>&1
+  timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --tb=short -s --timeout 900 -k "bf16" > gpurun_out/${tag}_fullsize_bf16.log 2>&1
   echo "fullsize bf16 rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|  logits|worst grad|pooled|passed|failed|Error" gpurun_out/${tag}_fullsize_bf16.log | cut -c1-230 | tail -n 50
   cp gpurun_out/r2_fullsize_parity.jsonl gpurun_out/${tag}_fullsize_bf16.jsonl 2>/dev/null
 fi
@@ -40,12 +40,24 @@ if has dp; then
   echo "dp rc=$? t=$((SECONDS-t0))"; tail -n 15 gpurun_out/${tag}_dp.log | cut -c1-300
 fi
 if has bench; then
-  ALM_RESIDUAL_DTYPE=fp32 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_fp32.log 2>&1
+  timeout 600 python bench.py --steps 20 --warmup 5 --residual fp32 --schedule eager --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_fp32.log 2>&1
   echo "bench fp32 rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_fp32.log | cut -c1-1500
 fi
 if has benchbf; then
-  ALM_RESIDUAL_DTYPE=bf16 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_bf16.log 2>&1
+  timeout 600 python bench.py --steps 20 --warmup 5 --residual bf16 --schedule eager --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_bench_bf16.log 2>&1
   echo "bench bf16 rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_bf16.log | cut -c1-1500
+fi
+if has sched; then
+  for rd in bf16 fp32; do for sc in eager graph graph2; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --residual $rd --schedule $sc --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_sched_${rd}_${sc}.log 2>&1
+    echo "sched $rd $sc rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_sched_${rd}_${sc}.log | python -c "
+import sys, json
+try:
+    d = json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('ms_per_step', 'value', 'loss', 'host')}, d['config'].get('schedule', '')[:40], d['config'].get('schedule_note'))
+except Exception as e: print('no json', e)
+"
+    grep -E "capture failed|Error|error" gpurun_out/${tag}_sched_${rd}_${sc}.log | head -5
+  done; done
 fi
 if has benchfull; then
   timeout 900 python bench.py > gpurun_out/${tag}_bench_full.log 2>&1
@@ -53,10 +65,10 @@ if has benchfull; then
 fi
 prof() {   # $1 = residual dtype, $2 = ALM_ASYNC_WGRAD
   rm -rf /tmp/prof_$1
-  ALM_RESIDUAL_DTYPE=$1 ALM_ASYNC_WGRAD=$2 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o r2 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} > gpurun_out/${tag}_prof_$1.log 2>&1
+  ALM_ASYNC_WGRAD=$2 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o r2 -- python bench.py --steps 5 --warmup 2 --residual $1 --schedule eager --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} > gpurun_out/${tag}_prof_$1.log 2>&1
   echo "prof $1 rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_prof_$1.log | cut -c1-300
   db=$(find /tmp/prof_$1 -name "*.db" | head -1)
-  if [[ -n $db ]]; then python scripts/prof_summary.py "$db" gpurun_out/${tag}_kernel_stats_$1_async$2.csv "ALM_RESIDUAL_DTYPE=$1 ALM_ASYNC_WGRAD=$2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} (18 steps incl. priming + warm-up + 1 instrumented)"; head -n 28 gpurun_out/${tag}_kernel_stats_$1_async$2.csv | cut -c1-150; fi
+  if [[ -n $db ]]; then python scripts/prof_summary.py "$db" gpurun_out/${tag}_kernel_stats_$1_async$2.csv "ALM_ASYNC_WGRAD=$2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --residual $1 --schedule eager --no-cpu-baseline --no-optimizer-leg ${BENCH_EXTRA} (incl. priming + warm-up + 1 instrumented step)"; head -n 28 gpurun_out/${tag}_kernel_stats_$1_async$2.csv | cut -c1-150; fi
 }
 if has prof; then prof fp32 0; fi
 if has profbf; then prof bf16 0; fi

@@ -3,11 +3,11 @@ the REAL reference and (b) the fp32 CPU oracle on seeded random inputs at the re
 
 Tolerances (bf16 GEMM operands / fp32 statistics and residual stream -- the precision `accelerator.autocast()` (trainer.py:1241)
 gives the reference -- compared with the fp32 reference / oracle):
-  loss                 |d| <= max(1e-3 * max(1, |loss|), N_loss)              (north_star: loss within 1e-3; the report says which clause held)
+  loss                 |d| <= 1e-3 * max(1, |loss|)                           (north_star: loss within 1e-3; no noise clause)
   logits               rel Frobenius error <= min(1e-2, N_logits): never worse than the REFERENCE'S OWN bf16-autocast run on the same
                        fixture (tests/golden/bf16_noise.pt `logits`, 7e-3 .. 1.3e-2).  north_star's 1e-3 is not reachable with bf16 GEMM
                        operands by anyone -- the reference included: one rounding of each operand already costs ~2e-3 per contraction.
-                       bf16 residual streams (`residual_dtype=torch.bfloat16`, the reference's autocast storage): <= 1.25 x N_logits
+                       bf16 residual streams (`residual_dtype=torch.bfloat16`, the reference's autocast storage): <= N_logits as well
   parameter gradients  rel Frobenius error <= max(3e-2, 2 x N_grad[k]) per tensor; the hyper-connection scalar statistics
                        (static_alpha/static_beta/dynamic_*_scale: heavily cancelling sums over all tokens, so |error| is set by
                        the term magnitudes, not by the net sum) may instead satisfy the POOLED bound over that class:
@@ -145,7 +145,7 @@ def test_hip_path_matches_reference_golden(name, residual):
     rl = float(ref['loss'])
     noise = BF16_NOISE[name]
     strict = 1e-3 * max(1.0, abs(rl))
-    ltol = max(strict, noise['loss_abs'])
+    ltol = strict                                            # north_star: loss within 1e-3 -- no noise clause (measured: 4e-5 .. 9e-4 on the 11 runs)
     report = [f'{name} [residual streams {residual}]: loss ours={loss:.6f} ref={rl:.6f} |d|={abs(loss - rl):.2e} rel={abs(loss - rl) / abs(rl):.2e} '
               f'({"within 1e-3" if abs(loss - rl) <= strict else "OVER 1e-3, within the reference bf16-autocast deviation"}; '
               f'reference bf16 noise {noise["loss_abs"]:.2e})']
@@ -162,7 +162,7 @@ def test_hip_path_matches_reference_golden(name, residual):
             report.append(f'  {k}: shape ours={None if got is None else tuple(got.shape)} ref={tuple(want.shape)} (skipped)')
             continue
         e = _frob(got, want)
-        bound = min(1e-2, nz) if residual == 'fp32' else 1.25 * nz
+        bound = min(1e-2, nz) if residual == 'fp32' else nz
         report.append(f'  {k}: rel-frob {e:.2e} (reference bf16-autocast run: {nz:.2e}; bound {bound:.2e}; north_star 1e-3)')
         ok &= e <= bound
     items = []
