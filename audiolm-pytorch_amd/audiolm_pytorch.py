@@ -350,6 +350,7 @@ class Transformer(nn.Module):
         assert residual_dtype in (None, torch.float32, torch.bfloat16), residual_dtype
         self._cache = core.WeightCache()
         self._layer_grad_hook = None          # set by parallel.DataParallelEngine: called as each layer's grads become final
+        self.micro_batches = 1                # 2: two half-batches on two HIP streams inside the stack (core.TransformerStackFn; graphed.GraphedTrainStep sets it)
 
     def flat_params(self):
         """Parameter order consumed by core.stack_forward / stack_backward."""
@@ -386,7 +387,7 @@ class Transformer(nn.Module):
         mask_u8 = None
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
-        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled())
+        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches)
         hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
                                            attn_bias.tbl if exists(attn_bias) else None, *self.flat_params())
         if return_flat_hidden:

@@ -456,20 +456,63 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     return dx, grads, dtbl
 
 
+_MICRO_STREAMS = {}
+
+
+def _micro_stream(dev):
+    """second HIP stream of the two-half-batch schedule (one per device)"""
+    key = (dev.type, dev.index)
+    if key not in _MICRO_STREAMS:
+        _MICRO_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _MICRO_STREAMS[key]
+
+
+def _halves(t, h):
+    return (None, None) if t is None else (t[:h], t[h:])
+
+
 class TransformerStackFn(torch.autograd.Function):
-    """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states fp32 [B*N, D]."""
+    """x fp32 [B,N,D] , key mask -> final-LayerNorm'd hidden states fp32 [B*N, D].
+
+    opts['micro'] == 2 (even B, training / plain forward): the batch is processed as TWO independent half-batches on two HIP streams, forward
+    and backward -- every kernel of the stack is per-sequence, so this changes no arithmetic.  The point is co-residency: while one half runs an
+    MFMA-bound GEMM (HBM idle) the other half's HBM-bound row kernels (hyper-connections, LayerNorm, GEGLU: matrix cores idle) share the CUs.
+    The host issues twice as many launches, so this schedule is meant to be captured into a hipGraph (graphed.GraphedTrainStep); autograd sees
+    ONE node on ONE stream -- the fork / join is done here with events."""
 
     @staticmethod
     def forward(ctx, x, mask_u8, cfg, cache, opts, bias, tbl, *flat):
         # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes its gradient.
         # opts: dict(hook = per-layer gradient callback | None, grad = torch.is_grad_enabled() AT THE CALL SITE (it is always off in here),
-        #            kv_out / decode = DecodeCache | None: sampling)
+        #            kv_out / decode = DecodeCache | None: sampling, micro = 1 | 2)
         hooks = opts.get('hook')
         need = bool(opts.get('grad', True)) and (any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad))
         xin = x.detach().contiguous().to(F32)
         bias = bias.detached() if bias is not None else None
-        hn, saved = stack_forward(xin, mask_u8, [t.detach() for t in flat], cfg, cache, need, bias, kv_out=opts.get('kv_out'),
-                                  decode=opts.get('decode'))
+        flat_d = [t.detach() for t in flat]
+        B = xin.shape[0]
+        micro = int(opts.get('micro', 1))
+        if micro == 2 and (B % 2 or B < 2 or opts.get('kv_out') is not None or opts.get('decode') is not None or hooks is not None):
+            micro = 1
+        ctx.micro = micro
+        if micro == 1:
+            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'))
+        else:
+            S, ppl, h = cfg.streams, params_per_layer(cfg.streams), B // 2
+            for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
+                pa, pf = _split_layer(flat_d[l * ppl:(l + 1) * ppl], S)
+                layer_weights(cache, l, pa, pf, cfg.inner, cfg.inner_pad)
+            cur, s2 = torch.cuda.current_stream(xin.device), _micro_stream(xin.device)
+            (xa, xb), (ma, mb) = _halves(xin, h), _halves(mask_u8, h)
+            s2.wait_stream(cur)
+            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias)
+            xb.record_stream(s2)
+            with torch.cuda.stream(s2):
+                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias)
+            cur.wait_stream(s2)
+            hnb.record_stream(cur)
+            hn = torch.cat((hna, hnb), dim=0)
+            saved = (sva, svb)
         ctx.saved, ctx.cfg, ctx.cache, ctx.mask, ctx.hooks, ctx.bias = saved, cfg, cache, mask_u8, hooks, bias
         ctx.flat = flat
         return hn
@@ -481,7 +524,31 @@ class TransformerStackFn(torch.autograd.Function):
         dhn = dhn.contiguous()
         if dhn.dtype not in (BF16, F32):
             dhn = dhn.to(F32)
-        dx, grads, dtbl = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
+        if ctx.micro == 1:
+            dx, grads, dtbl = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
+        else:
+            sva, svb = ctx.saved
+            h = sva['B']
+            rows = h * sva['N']
+            (ma, mb) = _halves(ctx.mask, h)
+            cur, s2 = torch.cuda.current_stream(dhn.device), _micro_stream(dhn.device)
+            da, db = dhn[:rows], dhn[rows:]
+            s2.wait_stream(cur)
+            dxa, ga, ta = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias)
+            db.record_stream(s2)
+            with torch.cuda.stream(s2):
+                dxb, gb, tb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias)
+            cur.wait_stream(s2)
+            for t in [dxb, tb] + gb:
+                if t is not None:
+                    t.record_stream(cur)
+            dx = torch.cat((dxa, dxb), dim=0)
+            pa = [a for a, b in zip(ga, gb) if a is not None and b is not None]
+            pb = [b for a, b in zip(ga, gb) if a is not None and b is not None]
+            if pa:
+                torch._foreach_add_(pa, pb)
+            grads = [a if a is not None else b for a, b in zip(ga, gb)]
+            dtbl = None if ta is None else ta + tb
         ctx.saved = None
         dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478
         out = []

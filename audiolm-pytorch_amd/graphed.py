@@ -8,9 +8,9 @@ micro-batches that run the whole forward + backward independently on two streams
 half's row kernels.  Captured once (torch.cuda.CUDAGraph: every alm_* launch goes to torch's current stream, which is the capturing stream)
 and replayed with one launch per step, the host cost disappears.
 
-Nothing here changes the arithmetic of a micro-batch; the two halves' gradients are summed (mean of the two half-batch losses == the
-full-batch loss when both halves hold the same number of target tokens, which fixed-shape batches do; SURVEY.md section 8(e) uses the same
-argument for data parallelism).
+The split lives INSIDE the fused stack (core.TransformerStackFn, opts micro = 2): autograd sees one node on one stream, the stack forks /
+joins its second stream with events, embeddings / logit heads / loss run on the full batch.  Every kernel of the stack is per-sequence, so
+the arithmetic is unchanged; the weight gradients of the two halves are summed.
 
     step = GraphedTrainStep(wrapper, dict(semantic_token_ids=sem, coarse_token_ids=coarse), micro_batches=2)
     loss = step(semantic_token_ids=sem, coarse_token_ids=coarse)      # p.grad of every parameter holds this step's gradient
@@ -41,47 +41,22 @@ class GraphedTrainStep:
         self.graph = None
         self.loss = None
         self.grads = None
-        self._side = torch.cuda.Stream(device=self.dev) if micro_batches == 2 else None
+        self._stacks = [m for m in module.modules() if hasattr(m, 'micro_batches') and hasattr(m, 'flat_params')]
         self._capture(warmup)
 
-    # the work of one step, issued on the current stream (+ the second stream for the second half)
+    # the work of one step, issued on the current stream (with micro_batches == 2 the fused stack forks its second stream itself)
     def _issue(self):
         for c in self._caches:
             c.store.clear()                                  # the bf16 weight copies are re-packed inside the step: weights change between replays
-        n = self.nmb
-        if n == 1:
+        for m in self._stacks:
+            m.micro_batches = self.nmb
+        try:
             loss = self.module(**self.static_in, **self.kw)
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
-            return loss.detach(), list(grads)
-        b = next(iter(self.static_in.values())).shape[0] // 2
-        halves = [{k: v[i * b:(i + 1) * b] for k, v in self.static_in.items()} for i in range(2)]
-        cur = torch.cuda.current_stream(self.dev)
-        # pack the bf16 weight copies once, ahead of the fork: both halves read the same copies, and neither waits for the other's forward
-        for m in self.module.modules():
-            if hasattr(m, '_head_weights') and hasattr(m, 'prepack_weights'):
-                m.prepack_weights()
-        self._side.wait_stream(cur)
-        la = self.module(**halves[0], **self.kw)
-        with torch.cuda.stream(self._side):
-            lb = self.module(**halves[1], **self.kw)
-            gb = torch.autograd.grad(lb, self.params, allow_unused=True)
-        ga = torch.autograd.grad(la, self.params, allow_unused=True)
-        cur.wait_stream(self._side)
-        for t in gb:
-            if t is not None:
-                t.record_stream(cur)
-        out, pa, pb = [], [], []
-        for x, y in zip(ga, gb):
-            if x is None:
-                out.append(None if y is None else y * 0.5)
-            else:
-                out.append(x)
-                if y is not None:
-                    pa.append(x), pb.append(y)
-        if pa:
-            torch._foreach_add_(pa, pb)
-            torch._foreach_mul_(pa, 0.5)
-        return ((la + lb.to(la.device)) * 0.5).detach(), out
+        finally:
+            for m in self._stacks:
+                m.micro_batches = 1
+        return loss.detach(), list(grads)
 
     def _capture(self, warmup):
         s = torch.cuda.Stream(device=self.dev)

@@ -35,6 +35,10 @@ if has fullsizebf; then
   echo "fullsize bf16 rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|  logits|worst grad|pooled|passed|failed|Error" gpurun_out/${tag}_fullsize_bf16.log | cut -c1-230 | tail -n 50
   cp gpurun_out/r2_fullsize_parity.jsonl gpurun_out/${tag}_fullsize_bf16.jsonl 2>/dev/null
 fi
+if has graphed; then
+  timeout 600 python -X faulthandler -m pytest tests/test_gpu_graphed.py -m gpu -q --tb=short --timeout 500 -x > gpurun_out/${tag}_graphed.log 2>&1
+  echo "graphed rc=$? t=$((SECONDS-t0))"; tail -n 25 gpurun_out/${tag}_graphed.log | cut -c1-300
+fi
 if has dp; then
   timeout 600 python -m pytest tests/test_gpu_dp.py -m gpu -q --tb=short --timeout 500 > gpurun_out/${tag}_dp.log 2>&1
   echo "dp rc=$? t=$((SECONDS-t0))"; tail -n 15 gpurun_out/${tag}_dp.log | cut -c1-300
@@ -49,7 +53,7 @@ if has benchbf; then
 fi
 if has sched; then
   for rd in bf16 fp32; do for sc in eager graph graph2; do
-    timeout 300 python bench.py --steps 20 --warmup 5 --residual $rd --schedule $sc --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_sched_${rd}_${sc}.log 2>&1
+    timeout 300 python -X faulthandler bench.py --steps 20 --warmup 5 --residual $rd --schedule $sc --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_sched_${rd}_${sc}.log 2>&1
     echo "sched $rd $sc rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_sched_${rd}_${sc}.log | python -c "
 import sys, json
 try:
