@@ -328,10 +328,11 @@ class _SideStream:
 
 FUSE_LN_BWD = os.environ.get('ALM_FUSE_LN_BWD', '1') != '0'             # switch: pre-LayerNorm backward inside the hyper-connection kernel
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
+MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
 
-def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None):
+def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None, async_wgrad=True):
     """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None)."""
     B, N = saved['B'], saved['N']
     D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
@@ -340,7 +341,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     dev = dhn.device
     ppl = params_per_layer(S)
     grads = [None] * len(flat)
-    side = _SideStream(dev, ASYNC_WGRAD)
+    side = _SideStream(dev, ASYNC_WGRAD and async_wgrad)
     rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
 
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
@@ -534,10 +535,12 @@ class TransformerStackFn(torch.autograd.Function):
             cur, s2 = torch.cuda.current_stream(dhn.device), _micro_stream(dhn.device)
             da, db = dhn[:rows], dhn[rows:]
             s2.wait_stream(cur)
-            dxa, ga, ta = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias)
+            # no weight-gradient side streams here: the other half already fills the idle CUs, and nested stream forks do not survive
+            # hipStreamEndCapture on ROCm 7.0 (segmentation fault)
+            dxa, ga, ta = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
             db.record_stream(s2)
             with torch.cuda.stream(s2):
-                dxb, gb, tb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias)
+                dxb, gb, tb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
             cur.wait_stream(s2)
             for t in [dxb, tb] + gb:
                 if t is not None:

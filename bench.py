@@ -212,7 +212,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='coarse2048', choices=['coarse2048', 'coarse1024', 'fine2049', 'fine_t2048_q8', 'e2e_config5'])
-    ap.add_argument('--schedule', default='auto', choices=['auto', 'eager', 'graph', 'graph2'])
+    ap.add_argument('--schedule', default='auto', choices=['auto', 'eager', 'eager2', 'graph', 'graph2'])
     ap.add_argument('--residual', default='bf16', choices=['bf16', 'fp32'],
                     help='HBM storage of the 4 hyper-connection residual streams: bf16 = what trainer.py:1241 autocast gives the reference (default), fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -272,6 +272,9 @@ def main():
     if want == 'auto':
         # e2e_config5 tokenizes raw audio inside the step (codec under inference_mode, data-dependent host code): kept out of the capture
         want = 'graph2' if (world == 1 and args.config != 'e2e_config5') else 'eager'
+    if want == 'eager2':                                        # diagnostic: the two-half-batch schedule without a graph (host-bound)
+        model.transformer.micro_batches = 2
+        schedule = 'eager2'
     for _ in range(3):                                          # lazy initialisation before any capture
         eager_step()
     if want in ('graph', 'graph2') and world == 1:
@@ -284,7 +287,7 @@ def main():
             print('[bench] ' + note, file=sys.stderr, flush=True)
             gstep = None
             torch.cuda.synchronize()
-    elif want != 'eager':
+    elif want not in ('eager', 'eager2'):
         note = f'{want} is a single-GPU schedule (the gradient all-reduce is issued from backward callbacks); ran eager'
 
     def step(opt=None):
@@ -444,6 +447,7 @@ def main():
             'data': 'synthetic (uniform random semantic / acoustic RVQ token ids, random-init weights)',
             'config': {'workload': W['workload'], 'global_batch': world * W['B'], 'seq_len': N, 'parallelism': f'dp{world}',
                        'schedule': {'eager': 'eager (every kernel launched from Python each step)',
+                                    'eager2': 'eager, two half-batches on two HIP streams inside the stack (diagnostic: host-bound)',
                                     'graph': 'one hipGraph replay per step (captured fwd + bwd)',
                                     'graph2': 'one hipGraph replay per step: two half-batches of 4 sequences on two HIP streams (row kernels of one half under the GEMMs '
                                               'of the other), gradients summed'}[schedule],

@@ -52,7 +52,7 @@ if has benchbf; then
   echo "bench bf16 rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_bf16.log | cut -c1-1500
 fi
 if has sched; then
-  for rd in bf16 fp32; do for sc in eager graph graph2; do
+  for rd in ${SCHED_RD:-bf16 fp32}; do for sc in ${SCHED_SC:-eager graph graph2}; do
     timeout 300 python -X faulthandler bench.py --steps 20 --warmup 5 --residual $rd --schedule $sc --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_sched_${rd}_${sc}.log 2>&1
     echo "sched $rd $sc rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_sched_${rd}_${sc}.log | python -c "
 import sys, json
