@@ -14,8 +14,11 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
   *TransformerWrapper.generate()            -> sample_logits(): prefix once through the training forward path, then one single-position pass per
                                                token over a per-layer k/v cache (core.DecodeCache, alm_mqa_decode_attn); sampling helpers in torch
 
-Out of scope this round (raise NotImplementedError instead of silently falling back): text / audio conditioning (so no classifier-free
-guidance), the reference's kv_cache= / embed_cache= tensor arguments (the native sampling cache replaces them), dense `attn_bias` tensors.
+Conditioning (`has_condition=True`, reference :325-375, :450-455, :640-668, :818-855, :1097-1134): cross-attention layers with a null key / value,
+`cond_as_self_attn_prefix`, per-sample condition dropping and classifier-free guidance all run natively from pre-computed `text_embeds`
+(xattn.py / csrc/xattn.hip); the T5 text encoder is out of scope (`text=` raises).
+Not accepted (NotImplementedError, nothing falls back silently): the reference's stacked kv_cache= / embed_cache= TENSOR arguments (the native
+sampling cache replaces them), dense `attn_bias` tensors, dropout > 0.
 Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
@@ -162,6 +165,42 @@ def get_embeds(embeddings: nn.Embedding, codes: torch.Tensor, pad_id=-1, return_
 
 def _flatten_ids(t):
     return t.reshape(t.shape[0], -1)
+
+
+def prob_mask_like(shape, prob, device):                      # semantics of audiolm_pytorch.py:144-150 (same RNG consumption)
+    """bool mask, True with probability `prob`; the degenerate probabilities draw nothing"""
+    if prob == 1:
+        return torch.ones(shape, device=device, dtype=torch.bool)
+    if prob == 0:
+        return torch.zeros(shape, device=device, dtype=torch.bool)
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
+class LinearNoBiasFn(torch.autograd.Function):
+    """y = x W^T on the bf16 MFMA GEMM (fp32 in / out): `proj_text_embed` (audiolm_pytorch.py:605 / :777 / :1043) -- the one dense layer of the
+    conditioning path outside the fused stack."""
+
+    @staticmethod
+    def forward(ctx, x, w, cache, key):
+        shape = x.shape
+        x2 = x.detach().reshape(-1, shape[-1]).to(torch.bfloat16).contiguous()
+        W, WT = cache.get(key, w.detach(), core._pack_plain)
+        y = torch.empty((x2.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        ops.gemm_nt(x2, W, y)
+        ctx.x2, ctx.WT, ctx.shape, ctx.wshape, ctx.need_dx = x2, WT, shape, w.shape, x.requires_grad
+        return y.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=dy.device)
+        ops.gemm_tn_splitk(dy2, ctx.x2, dw)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty((dy2.shape[0], ctx.wshape[1]), dtype=torch.float32, device=dy.device)
+            ops.gemm_nt(dy2, ctx.WT, dx)
+            dx = dx.view(ctx.shape)
+        return dx, dw, None, None
 
 
 # ---------------------------------------------------------------------------------------------- parameter containers
@@ -319,8 +358,6 @@ class Transformer(nn.Module):
         super().__init__()
         rel_pos_bias = rel_pos_bias and not flash_attn
         assert not (cross_attend and cond_as_self_attn_prefix)
-        if cross_attend or cond_as_self_attn_prefix:
-            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
         if attn_dropout != 0. or ff_dropout != 0.:
             raise NotImplementedError('dropout > 0 is not implemented in the fused stack (reference default is 0.)')
         self.dim = dim
@@ -337,7 +374,8 @@ class Transformer(nn.Module):
         for _ in range(depth):
             self.layers.append(nn.ModuleList([
                 hc(dim=dim, branch=Attention(dim=dim, heads=heads, dropout=attn_dropout, flash=flash_attn, causal=True, **kwargs)),
-                None,
+                hc(dim=dim, branch=Attention(dim=dim, heads=heads, dropout=attn_dropout, dim_context=dim_context, flash=flash_attn, num_null_kv=1,
+                                             norm_context=True, **kwargs)) if cross_attend else None,          # :450
                 hc(dim=dim, branch=FeedForward(dim=dim, dropout=ff_dropout))
             ]))
         self.norm = LayerNorm(dim)
@@ -346,7 +384,11 @@ class Transformer(nn.Module):
         self.cfg = core.StackCfg(dim=dim, depth=depth, heads=heads, dim_head=attn0.dim_head, streams=num_residual_streams,
                                  inner=int(dim * 2 * 4 / 3), add_value_residual=add_value_residual,
                                  grad_shrink_alpha=grad_shrink_alpha,
-                                 residual_bf16=(core.default_residual_bf16() if residual_dtype is None else residual_dtype == torch.bfloat16))
+                                 residual_bf16=(core.default_residual_bf16() if residual_dtype is None else residual_dtype == torch.bfloat16),
+                                 cross_attend=cross_attend, prefix=cond_as_self_attn_prefix, dim_context=self.dim_context)
+        self.cross_attend = cross_attend
+        if cond_as_self_attn_prefix:
+            assert self.dim_context == dim, 'cond_as_self_attn_prefix feeds the context through the self-attention to_kv: dim_context must equal dim'
         assert residual_dtype in (None, torch.float32, torch.bfloat16), residual_dtype
         self._cache = core.WeightCache()
         self._layer_grad_hook = None          # set by parallel.DataParallelEngine: called as each layer's grads become final
@@ -355,9 +397,12 @@ class Transformer(nn.Module):
     def flat_params(self):
         """Parameter order consumed by core.stack_forward / stack_backward."""
         out = []
-        for attn, _, ff in self.layers:
+        for attn, cross, ff in self.layers:
             a, f = attn.branch, ff.branch
             out += attn.hc_params() + [a.norm.gamma, a.to_q.weight, a.to_kv.weight, a.to_out[0].weight]
+            if cross is not None:
+                c = cross.branch
+                out += cross.hc_params() + [c.norm.gamma, c.context_norm.gamma, c.null_kv, c.to_q.weight, c.to_kv.weight, c.to_out[0].weight]
             out += ff.hc_params() + [f[0].gamma, f[1].weight, f[3].gamma, f[5].weight]
         out.append(self.norm.gamma)
         return out
@@ -366,16 +411,20 @@ class Transformer(nn.Module):
         """(re)builds the bf16 packed copies of every dense weight of the stack now (they are otherwise built lazily, layer by layer, by the first
         forward that finds a master weight changed).  graphed.GraphedTrainStep calls this ahead of forking its two half-batch streams."""
         flat = [t.detach() for t in self.flat_params()]
-        ppl = core.params_per_layer(self.cfg.streams)
-        for l in range(self.cfg.depth):
-            pa, pf = core._split_layer(flat[l * ppl:(l + 1) * ppl], self.cfg.streams)
-            core.layer_weights(self._cache, l, pa, pf, self.cfg.inner, self.cfg.inner_pad)
+        cfg = self.cfg
+        ppl = core.params_per_layer(cfg.streams, cfg.cross_attend)
+        for l in range(cfg.depth):
+            core.layer_weights(self._cache, l, core._split_layer(flat[l * ppl:(l + 1) * ppl], cfg.streams, cfg.cross_attend), cfg.inner, cfg.inner_pad)
 
     def forward(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, return_kv_cache=False, kv_cache=None,
                 return_flat_hidden=False):
-        if exists(context) or exists(kv_cache):
-            raise NotImplementedError('a conditioning context is out of scope (SURVEY.md §2 row 12), and the reference kv_cache tensor is not accepted: '
-                                      'the native sampling cache is driven through sample_logits() / generate()')
+        if exists(kv_cache):
+            raise NotImplementedError("the reference's stacked kv_cache tensor is not accepted here: the *Transformer classes map `kv_cache=` onto the "
+                                      'native per-layer cache (core.DecodeCache), see _TransformerBase.forward_with_cond_scale / sample_logits')
+        assert not (self.cond_as_self_attn_prefix and not exists(context))                          # :471
+        assert exists(context) == (self.cross_attend or self.cond_as_self_attn_prefix), 'a conditioning context needs (and is needed by) a conditioned Transformer'
+        assert not (exists(context) and context.shape[-1] != self.dim_context), \
+            f'you had specified a conditioning dimension of {self.dim_context}, yet what was received by the transformer has dimension of {context.shape[-1]}'
         if not x.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
         b, n, d = x.shape
@@ -387,9 +436,9 @@ class Transformer(nn.Module):
         mask_u8 = None
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
-        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches)
+        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches, context_mask=context_mask)
         hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
-                                           attn_bias.tbl if exists(attn_bias) else None, *self.flat_params())
+                                           attn_bias.tbl if exists(attn_bias) else None, context, *self.flat_params())
         if return_flat_hidden:
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
         out = hn.view(b, n, d)
@@ -398,7 +447,7 @@ class Transformer(nn.Module):
         return out, None
 
 
-    def _sample(self, tokens, self_attn_mask, state):
+    def _sample(self, tokens, self_attn_mask, state, context=None, context_mask=None):
         """One step of an autoregressive sampling run (kv cache, reference :360-394 / :560): tokens fp32 [b, n, d] = embeddings of the WHOLE
         sequence so far, state = core.DecodeCache (state.bias: AttnBias laid out for state.nmax positions, or None).  First call: ordinary
         forward over the n positions that also fills the cache; later calls: only the last position runs (n == state.length + 1), its
@@ -411,21 +460,23 @@ class Transformer(nn.Module):
         flat = self.flat_params()
         if state.length == 0:
             pb = bias.sliced(n) if exists(bias) else None
-            hn = core.TransformerStackFn.apply(tokens, mask_u8, self.cfg, self._cache, dict(grad=False, kv_out=state), pb,
-                                               pb.tbl if exists(pb) else None, *flat)
+            hn = core.TransformerStackFn.apply(tokens, mask_u8, self.cfg, self._cache, dict(grad=False, kv_out=state, context_mask=context_mask), pb,
+                                               pb.tbl if exists(pb) else None, context, *flat)
             return hn.view(b, n, d)[:, -1]
         assert n == state.length + 1 and n <= state.nmax, (n, state.length, state.nmax)
         x = tokens[:, -1:].contiguous()
         tbl = bias.tbl if exists(bias) else None
         if not DECODE_GRAPH:
-            return core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, dict(grad=False, decode=state), bias, tbl, *flat)
+            return core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, dict(grad=False, decode=state, context_mask=context_mask), bias, tbl,
+                                                 context, *flat)
         if state.pos_dev is None:
             # first single-position step: eager, already in the device-position form (also warms every lazily initialised launch path up)
             state.pos_dev = torch.full((1,), state.length, dtype=torch.int32, device=x.device)
             if exists(mask_u8):
                 state.mask_in = torch.ones((b, state.nmax), dtype=torch.uint8, device=x.device)
                 state.mask_in[:, :n] = mask_u8
-            h = core.TransformerStackFn.apply(x, state.mask_in, self.cfg, self._cache, dict(grad=False, decode=state), bias, tbl, *flat)
+            h = core.TransformerStackFn.apply(x, state.mask_in, self.cfg, self._cache, dict(grad=False, decode=state, context_mask=context_mask), bias, tbl,
+                                              context, *flat)
             state.pos_dev += 1
             return h
         if exists(state.mask_in):
@@ -436,8 +487,8 @@ class Transformer(nn.Module):
             state.frozen = True
             try:
                 with torch.cuda.graph(graph):
-                    state.h_out = core.TransformerStackFn.apply(state.x_in, state.mask_in, self.cfg, self._cache, dict(grad=False, decode=state),
-                                                                bias, tbl, *flat)
+                    state.h_out = core.TransformerStackFn.apply(state.x_in, state.mask_in, self.cfg, self._cache,
+                                                                dict(grad=False, decode=state, context_mask=context_mask), bias, tbl, context, *flat)
             finally:
                 state.frozen = False
             state.graph = graph
@@ -536,22 +587,58 @@ class _TransformerBase(nn.Module):
         _, lg = heads.head_logits(h, weight3.detach(), None if bias is None else bias.detach(), idx, self._heads_cache(), ('head', key))
         return lg.view(G, b, -1)[q, :, :weight3.shape[1]]
 
-    def _reject_conditioning(self, text, text_embeds):
-        if exists(text) or exists(text_embeds) or self.has_condition:
-            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+    def _condition(self, b, device, text, text_embeds, cond_drop_prob, mask_from_embeds):
+        """Conditioning of one forward (audiolm_pytorch.py:685-704 / :873-892 / :1150-1169): -> (context [b, m, dim] | None, context_mask bool
+        [b, m] | None).  `text_embeds` are the pre-computed T5 / MuLaN embeddings (the text encoder itself is out of scope); positions whose
+        embedding is all zero are padding.  Quirk kept: Semantic- and FineTransformer derive the mask only when they ran the text encoder
+        themselves (:692-695, :1156-1160), so with pre-computed embeddings they have no mask and `cond_drop_prob` has nothing to drop
+        (mask_from_embeds=False); CoarseTransformer takes the mask from the embeddings (:882-883)."""
+        has_text = exists(text) or exists(text_embeds)
+        assert not (self.has_condition ^ has_text)
+        if not has_text:
+            return None, None
+        text_mask = None
+        if not exists(text_embeds):
+            with torch.inference_mode():
+                text_embeds = self.embed_text(text, output_device=device)
+            if not mask_from_embeds:
+                text_mask = torch.any(text_embeds != 0, dim=-1)
+        if mask_from_embeds:
+            text_mask = torch.any(text_embeds != 0, dim=-1)
+        if isinstance(self.proj_text_embed, nn.Linear):
+            text_embeds = LinearNoBiasFn.apply(text_embeds.to(device).float(), self.proj_text_embed.weight, self._heads_cache(), ('proj_text_embed',))
+        cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
+        if exists(text_mask) and cond_drop_prob > 0:
+            keep_mask = prob_mask_like((b,), 1 - cond_drop_prob, device=device)
+            text_mask = keep_mask[:, None] & text_mask
+        return text_embeds, text_mask
 
     def forward_with_cond_scale(self, *args, cond_scale=3, kv_cache=None, embed_cache=None, return_kv_cache=False, **kwargs):
-        """audiolm_pytorch.py:639-667 / :818-855 / :1082-1130 for un-conditioned models (`cond_scale == 1 or not self.has_condition` branch:
-        classifier-free guidance needs text conditioning, which is out of scope).  No kv / embed cache exists on this path yet: the prefix
-        is recomputed, which gives the same logits; the cache slots of the return value are None."""
-        if self.has_condition:
-            raise NotImplementedError('classifier-free guidance needs text / audio conditioning (out of scope, SURVEY.md §2 row 12)')
+        """Classifier-free guidance (audiolm_pytorch.py:640-667 / :818-855 / :1097-1134): logits with the conditioning kept (cond_drop_prob = 0) and,
+        for conditioned models at cond_scale != 1, with every text position masked out (cond_drop_prob = 1: cross-attention then sees only its
+        null key / value); result = null + (cond - null) * cond_scale.  The reference's stacked kv / embed cache TENSORS are not accepted on this
+        entry: cached sampling runs through sample_logits() (core.DecodeCache), which the wrappers' generate() use; here the prefix is
+        recomputed, which gives the same logits, and the cache slots of the return value are None."""
         if exists(kv_cache) or exists(embed_cache):
             raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         out = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale != 1 and self.has_condition:
+            null = self.forward(*args, cond_drop_prob=1., **kwargs)
+            mix = lambda c, n: None if c is None else n + (c - n) * cond_scale                        # noqa: E731
+            out = tuple(mix(c, n) for c, n in zip(out, null)) if isinstance(out, tuple) else mix(out, null)
         if not return_kv_cache:
             return out
         return out, ((None, None) if isinstance(out, tuple) else None)
+
+    def _sample_guided(self, one, state, cond_scale):
+        """cached sampling step of a conditioned model: `one(state, cond_drop_prob)` -> (logits, state).  cond_scale == 1: one pass with the
+        conditioning kept; otherwise the guided pair (conditioned, unconditioned) on two caches, mixed like forward_with_cond_scale."""
+        st = state if isinstance(state, list) else [state, None]
+        lg, st[0] = one(st[0], 0.)
+        if cond_scale != 1:
+            null, st[1] = one(st[1], 1.)
+            lg = null + (lg - null) * cond_scale
+        return lg, st
 
     def _init_common(self, *, t5_name, has_condition, cond_dim, audio_text_condition, cond_drop_prob, dim):
         if audio_text_condition:
@@ -563,7 +650,7 @@ class _TransformerBase(nn.Module):
         self.proj_text_embed = nn.Linear(text_dim, dim, bias=False) if text_dim != dim else nn.Identity()
 
     def embed_text(self, *a, **k):
-        raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+        raise NotImplementedError('the T5 text encoder is out of scope (SURVEY.md §2): pass pre-computed `text_embeds` (b, m, cond_dim) instead of `text`')
 
     def _heads_cache(self):
         return self.transformer._cache
@@ -609,7 +696,7 @@ class SemanticTransformer(_TransformerBase):
         self.to_logits = nn.Linear(dim, num_semantic_tokens + 1)
         self.dim = dim
 
-    def _hidden(self, ids, self_attn_mask):
+    def _hidden(self, ids, self_attn_mask, context=None, context_mask=None):
         b, n = ids.shape
         dev = ids.device
         sem = ids.to(torch.int32)                                                              # table 0; pad (-1) -> zero vector (:176-181)
@@ -619,13 +706,20 @@ class SemanticTransformer(_TransformerBase):
                                        self.semantic_embedding.weight, self.start_token).view(b, n + 1, self.dim)
         if exists(self_attn_mask):
             self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)                       # :716
-        return self.transformer(tokens, self_attn_mask=self_attn_mask, return_flat_hidden=True), b, n + 1
+        return self.transformer(tokens, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask, return_flat_hidden=True), b, n + 1
 
     @torch.no_grad()
-    def sample_logits(self, ids, state, nmax):
+    def sample_logits(self, ids, state, nmax, text_embeds=None, cond_scale=1.):
         """Sampling step with a kv cache: ids (b, n) = everything sampled so far -> (next-token logits fp32 (b, C + 1), state).  state None:
-        prefix forward that creates the cache for up to `nmax` positions (incl. the start token); afterwards only the last id is new."""
+        prefix forward that creates the cache for up to `nmax` positions (incl. the start token); afterwards only the last id is new.
+        Conditioned models (cross-attention): `text_embeds`; cond_scale != 1 runs the guided pair of passes on two caches (:640-667)."""
+        if self.has_condition:
+            return self._sample_guided(lambda st, cdp: self._sample_one(ids, st, nmax, text_embeds, cdp), state, cond_scale)
+        return self._sample_one(ids, state, nmax, None, None)
+
+    def _sample_one(self, ids, state, nmax, text_embeds, cond_drop_prob):
         b, n = ids.shape
+        context, cmask = self._condition(b, ids.device, None, text_embeds, cond_drop_prob, mask_from_embeds=False)
         dev = ids.device
         src_a = torch.cat((_const_code(1, b, dev), ids.to(torch.int32)), dim=1).contiguous()
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), _neg(b, n + 1, dev).reshape(-1), b * (n + 1), self.dim,
@@ -633,17 +727,17 @@ class SemanticTransformer(_TransformerBase):
         if state is None:
             state = core.DecodeCache(self.transformer.cfg, b, nmax, dev)
             state.bias = self.transformer.rel_pos_bias(nmax, nmax) if exists(self.transformer.rel_pos_bias) else None
-        h = self.transformer._sample(tokens, None, state)
+        h = self.transformer._sample(tokens, None, state, context, cmask)
         return self._last_logits(h, self.to_logits.weight.unsqueeze(0), self.to_logits.bias, 'semantic', 0), state
 
     def forward(self, *, ids=None, return_loss=False, text=None, text_embeds=None, self_attn_mask=None, cond_drop_prob=None,
                 unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
-        self._reject_conditioning(text, text_embeds)
+        context, context_mask = self._condition(ids.shape[0], ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
         if exists(kv_cache):
             raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         if return_loss:
             ids = ids[:, :-1]                                                                # :706-707 (the reference drops the labels)
-        hn, b, N = self._hidden(ids, self_attn_mask)
+        hn, b, N = self._hidden(ids, self_attn_mask, context, context_mask)
         idx, i_grid, valid = _group_index(b, N, 0, N, 1, ids.device)
         if exists(labels):                                                                   # fused loss path (wrapper)
             grp = heads.HeadGroup('semantic', self.to_logits.weight, self.to_logits.bias, idx, _group_labels(labels, i_grid, valid, N))
@@ -707,26 +801,33 @@ class CoarseTransformer(_TransformerBase):
         return tokens, b, N, ns, nc
 
     @torch.no_grad()
-    def sample_logits(self, semantic_token_ids, coarse_token_ids, state, nmax):
+    def sample_logits(self, semantic_token_ids, coarse_token_ids, state, nmax, text_embeds=None, cond_scale=1.):
         """Sampling step with a kv cache -> (logits of the NEXT coarse token fp32 (b, C + 1), state); see SemanticTransformer.sample_logits.
         nmax = semantic length + 2 + the largest number of coarse tokens the run will hold."""
+        if self.has_condition:
+            return self._sample_guided(lambda st, cdp: self._sample_one(semantic_token_ids, coarse_token_ids, st, nmax, text_embeds, cdp), state, cond_scale)
+        return self._sample_one(semantic_token_ids, coarse_token_ids, state, nmax, None, None)
+
+    def _sample_one(self, semantic_token_ids, coarse_token_ids, state, nmax, text_embeds, cond_drop_prob):
         tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
+        context, cmask = self._condition(b, tokens.device, None, text_embeds, cond_drop_prob, mask_from_embeds=True)
         if state is None:
             state = core.DecodeCache(self.transformer.cfg, b, nmax, tokens.device)
             state.bias = None
             if exists(self.transformer.rel_pos_bias):
                 state.bias = self.transformer.rel_pos_bias(nmax, nmax, special=self.cross_attn_bias, num_leading=ns + 1)
-        h = self.transformer._sample(tokens, None, state)
+        h = self.transformer._sample(tokens, None, state, context, cmask)
         return self._last_logits(h, self.coarse_logit_weights, None, 'coarse', nc % self.num_coarse_quantizers), state
 
-    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask):
+    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask, context=None, context_mask=None):
         tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
         attn_bias = None
         if exists(self.transformer.rel_pos_bias):
             # :924-936 -- relative positions everywhere except across the semantic / coarse boundary, where every pair gets the learned
             # per-head cross_attn_bias (is_semantic = arange(N) < ns + 1)
             attn_bias = self.transformer.rel_pos_bias(N, N, special=self.cross_attn_bias, num_leading=ns + 1)
-        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, return_flat_hidden=True)
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, context=context, context_mask=context_mask,
+                              return_flat_hidden=True)
         return hn, b, N, ns, nc
 
     def _groups(self, b, N, ns, nc, dev, semantic_labels=None, coarse_labels=None, only_coarse=False):
@@ -746,10 +847,10 @@ class CoarseTransformer(_TransformerBase):
 
     def forward(self, *, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text=None, text_embeds=None, cond_drop_prob=None,
                 return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None):
-        self._reject_conditioning(text, text_embeds)
+        context, context_mask = self._condition(semantic_token_ids.shape[0], semantic_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=True)
         if exists(kv_cache) or exists(embed_cache):
             raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
-        hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask)
+        hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask, context, context_mask)
         dev = hn.device
         if exists(labels):                                                                        # fused loss path: (sem_labels, coarse_labels)
             sem_labels, coarse_labels = labels
@@ -842,27 +943,34 @@ class FineTransformer(_TransformerBase):
         return relpos.AttnBias(tbl, *index)
 
     @torch.no_grad()
-    def sample_logits(self, coarse_token_ids, fine_token_ids, state, max_fine_length):
+    def sample_logits(self, coarse_token_ids, fine_token_ids, state, max_fine_length, text_embeds=None, cond_scale=1.):
         """Sampling step with a kv cache -> (logits of the NEXT fine token fp32 (b, C), state); see SemanticTransformer.sample_logits.  The
         bias table / index vectors are laid out once for `max_fine_length` fine tokens (the reference's table does not change while the
         number of fine frames stays <= the number of coarse frames, :1230)."""
+        if self.has_condition:
+            return self._sample_guided(lambda st, cdp: self._sample_one(coarse_token_ids, fine_token_ids, st, max_fine_length, text_embeds, cdp), state, cond_scale)
+        return self._sample_one(coarse_token_ids, fine_token_ids, state, max_fine_length, None, None)
+
+    def _sample_one(self, coarse_token_ids, fine_token_ids, state, max_fine_length, text_embeds, cond_drop_prob):
         tokens, mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, None)
+        context, cmask = self._condition(b, tokens.device, None, text_embeds, cond_drop_prob, mask_from_embeds=False)
         if state is None:
             state = core.DecodeCache(self.transformer.cfg, b, n + max_fine_length + 2, tokens.device)
             state.bias = self._attn_bias(n, max_fine_length, tokens.device)
-        h = self.transformer._sample(tokens, mask, state)
+        h = self.transformer._sample(tokens, mask, state, context, cmask)
         return self._last_logits(h, self.fine_logit_weights, None, 'fine', nf % self.num_fine_quantizers), state
 
     def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
                 kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
-        self._reject_conditioning(text, text_embeds)
+        context, context_mask = self._condition(coarse_token_ids.shape[0], coarse_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
         if exists(kv_cache) or exists(embed_cache):
             raise NotImplementedError('pass no kv_cache / embed_cache: the sampling cache of this package is driven through sample_logits()')
         tokens, self_attn_mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, self_attn_mask)
         dev = tokens.device
         Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
         attn_bias = self._attn_bias(n, nf, dev)
-        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, return_flat_hidden=True)
+        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, context=context, context_mask=context_mask,
+                              return_flat_hidden=True)
 
         n_fine = nf + 1                                                                           # tokens[:, n+1:]  (:1319)
         want_coarse = exists(self.coarse_logit_weights) and not return_only_fine_logits
@@ -915,7 +1023,21 @@ class _WrapperBase(nn.Module):
         return wavs
 
     def embed_text(self, text):
-        raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+        return self.transformer.embed_text(text, output_device=self.device)
+
+    def _resolve_text(self, text, text_embeds, wave, namespace):
+        """conditioning inputs of generate() / forward() (audiolm_pytorch.py:1446-1458, :1525-1528 and the Coarse / Fine twins): joint audio-text
+        embeddings from the audio conditioner (any callable: MuLaN wrapper) when a wave is there, else `text` through the text encoder,
+        else the pre-computed `text_embeds`"""
+        if exists(self.audio_conditioner) and exists(wave):
+            assert not exists(text) and not exists(text_embeds)
+            text_embeds = self.audio_conditioner(wavs=wave, namespace=namespace)
+        has_text = exists(text) or exists(text_embeds)
+        assert not (self.transformer.has_condition ^ has_text)
+        if not exists(text_embeds) and exists(text):
+            with torch.inference_mode():
+                text_embeds = self.transformer.embed_text(text, output_device=self.device)
+        return text_embeds
 
 
 class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.py:1372-1567
@@ -941,8 +1063,6 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
         the prefix runs once through the training forward path, every further token costs one single-position pass whose attention reads
         the per-layer key / value cache (alm_mqa_decode_attn); False: the whole prefix is recomputed each step (same logits, O(n) more work)."""
         device = self.device
-        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
-            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
         if exists(prime_wave):
             assert not exists(prime_ids)
             assert exists(self.wav2vec)
@@ -953,19 +1073,21 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
             ids = torch.empty((batch_size, 0), dtype=torch.long, device=device)
         if self.unique_consecutive:
             ids = batch_unique_consecutive(ids, pad_value=self.pad_id)
+        text_embeds = self._resolve_text(text, text_embeds, prime_wave, 'semantic')
         batch = ids.shape[0]
         start_length = ids.shape[-1]
         sample_semantic_ids = ids.clone()
         last_logit_indices = (ids != self.pad_id).sum(dim=-1).long()
         # kv cache (native: core.DecodeCache through SemanticTransformer.sample_logits): usable when no prime row is padded, i.e. every row's
         # next-token logits sit at the last position; ragged primes take the recompute path, which reproduces the reference's gather
-        use_cache = use_kv_cache and not kwargs and bool((ids != self.pad_id).all())
+        # (prefix conditioning: the reference turns the kv cache off, audiolm_pytorch.py:481-482)
+        use_cache = use_kv_cache and not kwargs and bool((ids != self.pad_id).all()) and not self.transformer.transformer.cond_as_self_attn_prefix
         state = None
         for ind in range(start_length, max_length):
             if use_cache:
-                last_logits, state = self.transformer.sample_logits(sample_semantic_ids, state, max_length + 1)
+                last_logits, state = self.transformer.sample_logits(sample_semantic_ids, state, max_length + 1, text_embeds=text_embeds, cond_scale=cond_scale)
             else:
-                logits = self.transformer.forward_with_cond_scale(ids=sample_semantic_ids, cond_scale=cond_scale, **kwargs)
+                logits = self.transformer.forward_with_cond_scale(ids=sample_semantic_ids, text_embeds=text_embeds, cond_scale=cond_scale, **kwargs)
                 last_logits = logits.gather(1, last_logit_indices.view(batch, 1, 1).expand(batch, 1, logits.shape[-1])).squeeze(1)
             filtered_logits = top_k(last_logits, thres=filter_thres)
             sampled = gumbel_sample(filtered_logits, temperature=temperature, dim=-1)
@@ -977,8 +1099,10 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
 
     def forward(self, *, semantic_token_ids=None, raw_wave=None, text=None, text_embeds=None, return_loss=False, **kwargs):
         assert exists(raw_wave) or exists(semantic_token_ids)
-        if exists(self.audio_conditioner):
-            raise NotImplementedError('audio conditioning is out of scope')
+        if exists(self.audio_conditioner):                                                          # :1525-1528
+            assert exists(raw_wave)
+            assert not exists(text) and not exists(text_embeds)
+            text_embeds = self.audio_conditioner(wavs=raw_wave, namespace='semantic')
         if not exists(semantic_token_ids):
             assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
             semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
@@ -1025,9 +1149,8 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
                  use_kv_cache=True, **kwargs):
         """audiolm_pytorch.py:1608-1740 (prefix recomputed each step; see SemanticTransformerWrapper.generate)."""
         batch, device = semantic_token_ids.shape[0], self.device
-        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
-            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
         semantic_token_ids = semantic_token_ids.to(device)
+        text_embeds = self._resolve_text(text, text_embeds, prime_wave, 'coarse')
         assert not (exists(prime_wave) and exists(prime_coarse_token_ids)), 'you can either pass in the prime as a raw wave (codec required) or as preprocessed acoustic token ids'
         if exists(prime_coarse_token_ids):
             coarse_token_ids = prime_coarse_token_ids
@@ -1041,18 +1164,19 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         if self.unique_consecutive:
             semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
         sampled_coarse_token_ids = coarse_token_ids.clone()
-        use_cache, state = use_kv_cache and not kwargs, None
+        use_cache, state = use_kv_cache and not kwargs and not self.transformer.transformer.cond_as_self_attn_prefix, None
         nmax = semantic_token_ids.shape[1] + 2 + coarse_token_ids.shape[1] + max_time_steps * self.num_coarse_quantizers
         for time_step in range(0, max_time_steps):
             for ind in range(self.num_coarse_quantizers):
                 just_finished_quantizer_step = (ind == 0 and time_step > 0)
                 if use_cache:
-                    last_coarse_logits, state = self.transformer.sample_logits(semantic_token_ids, sampled_coarse_token_ids, state, nmax)
+                    last_coarse_logits, state = self.transformer.sample_logits(semantic_token_ids, sampled_coarse_token_ids, state, nmax,
+                                                                               text_embeds=text_embeds, cond_scale=cond_scale)
                     last_coarse_logits = last_coarse_logits.clone()
                 else:
                     _, coarse_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=sampled_coarse_token_ids,
-                                                                                semantic_token_ids=semantic_token_ids, cond_scale=cond_scale,
-                                                                                return_only_coarse_logits=True, **kwargs)
+                                                                                semantic_token_ids=semantic_token_ids, text_embeds=text_embeds,
+                                                                                cond_scale=cond_scale, return_only_coarse_logits=True, **kwargs)
                     last_coarse_logits = coarse_logits[:, -1].clone()
                 if not just_finished_quantizer_step:
                     last_coarse_logits[:, -1] = float('-inf')          # prevent from eos in the middle of a time step
@@ -1071,8 +1195,10 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         raw_wave_for_codec = default(raw_wave_for_codec, raw_wave)
         assert exists(raw_wave_for_codec) or exists(coarse_token_ids)
         assert not all(map(exists, (raw_wave, raw_wave_for_codec, semantic_token_ids, coarse_token_ids)))
-        if exists(self.audio_conditioner):
-            raise NotImplementedError('audio conditioning is out of scope')
+        if exists(self.audio_conditioner):                                                          # :1761-1764
+            assert exists(raw_wave)
+            assert not exists(text) and not exists(text_embeds)
+            text_embeds = self.audio_conditioner(wavs=raw_wave, namespace='coarse')
         if not exists(semantic_token_ids):
             assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
             semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
@@ -1150,8 +1276,7 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
         coarse_token_ids = _flatten_ids(coarse_token_ids)
         batch, device = coarse_token_ids.shape[0], self.device
         coarse_token_ids = coarse_token_ids.to(device)
-        if exists(text) or exists(text_embeds) or exists(self.audio_conditioner):
-            raise NotImplementedError('text / audio conditioning is out of scope (SURVEY.md §2 row 12)')
+        text_embeds = self._resolve_text(text, text_embeds, prime_wave, 'fine')
         assert not (exists(prime_wave) and exists(prime_fine_token_ids)), 'you can either pass in the prime as a raw wave (codec required) or as preprocessed acoustic token ids'
         if exists(prime_fine_token_ids):
             fine_token_ids = prime_fine_token_ids
@@ -1165,18 +1290,19 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
         init_fine_time_step = fine_token_ids.shape[-1] // self.num_fine_quantizers
         max_time_steps = coarse_token_ids.shape[1] // self.num_coarse_quantizers
         sampled_fine_token_ids = fine_token_ids.clone()
-        use_cache, state = use_kv_cache and not kwargs, None
+        use_cache, state = use_kv_cache and not kwargs and not self.transformer.transformer.cond_as_self_attn_prefix, None
         max_fine_length = fine_token_ids.shape[-1] + max(0, max_time_steps - init_fine_time_step) * self.num_fine_quantizers
         for time_step in range(init_fine_time_step, max_time_steps):
             for ind in range(self.num_fine_quantizers):
                 just_finished_quantizer_step = (ind == 0 and time_step > 0)
                 if use_cache:
-                    last_fine_logits, state = self.transformer.sample_logits(coarse_token_ids, sampled_fine_token_ids, state, max_fine_length)
+                    last_fine_logits, state = self.transformer.sample_logits(coarse_token_ids, sampled_fine_token_ids, state, max_fine_length,
+                                                                             text_embeds=text_embeds, cond_scale=cond_scale)
                     last_fine_logits = last_fine_logits.clone()
                 else:
                     _, fine_logits = self.transformer.forward_with_cond_scale(coarse_token_ids=coarse_token_ids,
-                                                                              fine_token_ids=sampled_fine_token_ids, cond_scale=cond_scale,
-                                                                              return_only_fine_logits=True, **kwargs)
+                                                                              fine_token_ids=sampled_fine_token_ids, text_embeds=text_embeds,
+                                                                              cond_scale=cond_scale, return_only_fine_logits=True, **kwargs)
                     last_fine_logits = fine_logits[:, -1].clone()
                 if not just_finished_quantizer_step:
                     last_fine_logits[:, -1] = float('-inf')            # prevent from eos in the middle of a time step
@@ -1196,8 +1322,10 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
     def forward(self, *, raw_wave=None, text=None, text_embeds=None, token_ids=None, coarse_token_ids=None, fine_token_ids=None,
                 return_loss=False, **kwargs):
         assert exists(raw_wave) ^ (exists(token_ids) ^ (exists(coarse_token_ids) and exists(fine_token_ids)))
-        if exists(self.audio_conditioner):
-            raise NotImplementedError('audio conditioning is out of scope')
+        if exists(self.audio_conditioner):                                                          # :2055-2058
+            assert exists(raw_wave)
+            assert not exists(text) and not exists(text_embeds)
+            text_embeds = self.audio_conditioner(wavs=raw_wave, namespace='fine')
         if exists(raw_wave):
             assert exists(self.codec), 'Codec must be provided if given raw wave for training'
             with torch.inference_mode():                                                          # :2063-2071
@@ -1237,14 +1365,12 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
 
 class AudioLM(nn.Module):                                     # audiolm_pytorch.py:2141-2254
     """Hierarchical sampling: semantic -> coarse -> fine -> waveform, every stage on the native path (kv-cache sampling, SoundStream decoder).
-    Text / audio conditioning is out of scope, so the three transformers must be un-conditioned."""
+    Conditioned transformers take pre-computed `text_embeds` (or an audio conditioner callable); the T5 text encoder itself is out of scope."""
 
     def __init__(self, *, wav2vec, codec, semantic_transformer: SemanticTransformer, coarse_transformer: CoarseTransformer,
                  fine_transformer: FineTransformer, audio_conditioner=None, unique_consecutive=True):
         super().__init__()
-        if exists(audio_conditioner):
-            raise NotImplementedError('audio conditioning is out of scope (SURVEY.md §2 row 12)')
-        self.audio_conditioner = None
+        self.audio_conditioner = audio_conditioner
         assert semantic_transformer.num_semantic_tokens == coarse_transformer.num_semantic_tokens
         assert coarse_transformer.codebook_size == fine_transformer.codebook_size
         assert coarse_transformer.num_coarse_quantizers == fine_transformer.num_coarse_quantizers
@@ -1253,11 +1379,11 @@ class AudioLM(nn.Module):                                     # audiolm_pytorch.
         self.coarse_has_condition = coarse_transformer.has_condition
         self.fine_has_condition = fine_transformer.has_condition
         self.needs_text = any([self.semantic_has_condition, self.coarse_has_condition, self.fine_has_condition])
-        if self.needs_text:
-            raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
-        self.semantic = SemanticTransformerWrapper(wav2vec=wav2vec, transformer=semantic_transformer, unique_consecutive=unique_consecutive)
-        self.coarse = CoarseTransformerWrapper(wav2vec=wav2vec, codec=codec, transformer=coarse_transformer, unique_consecutive=unique_consecutive)
-        self.fine = FineTransformerWrapper(codec=codec, transformer=fine_transformer)
+        self.semantic = SemanticTransformerWrapper(wav2vec=wav2vec, transformer=semantic_transformer, audio_conditioner=audio_conditioner,
+                                                   unique_consecutive=unique_consecutive)
+        self.coarse = CoarseTransformerWrapper(wav2vec=wav2vec, codec=codec, transformer=coarse_transformer, audio_conditioner=audio_conditioner,
+                                               unique_consecutive=unique_consecutive)
+        self.fine = FineTransformerWrapper(codec=codec, transformer=fine_transformer, audio_conditioner=audio_conditioner)
 
     @property
     def device(self):
@@ -1267,21 +1393,23 @@ class AudioLM(nn.Module):                                     # audiolm_pytorch.
     @torch.inference_mode()
     def forward(self, *, batch_size=1, text=None, text_embeds=None, prime_wave=None, prime_wave_input_sample_hz=None, prime_wave_path=None,
                 max_length=2048, return_coarse_generated_wave=False, mask_out_generated_fine_tokens=False):
-        if exists(text) or exists(text_embeds):
-            raise NotImplementedError('text conditioning is out of scope (SURVEY.md §2 row 12)')
+        assert not (self.needs_text and (not exists(text) and not exists(text_embeds))), 'text needs to be passed in if one of the transformer requires conditioning'
+        if self.needs_text and exists(text):
+            text_embeds = self.semantic.embed_text(text)
         assert not (exists(prime_wave) and exists(prime_wave_path)), 'prompt audio must be given as either `prime_wave: Tensor` or `prime_wave_path: str`'
         if exists(prime_wave):
             assert exists(prime_wave_input_sample_hz), 'the input sample frequency for the prompt audio must be given as `prime_wave_input_sample_hz: int`'
             prime_wave = prime_wave.to(self.device)
         elif exists(prime_wave_path):
             raise NotImplementedError('loading audio files needs torchaudio (not part of this package): pass `prime_wave` as a tensor')
-        semantic_token_ids = self.semantic.generate(batch_size=batch_size, prime_wave=prime_wave,
-                                                    prime_wave_input_sample_hz=prime_wave_input_sample_hz, max_length=max_length)
-        coarse_token_ids_or_recon_wave = self.coarse.generate(semantic_token_ids=semantic_token_ids, prime_wave=prime_wave,
+        semantic_token_ids = self.semantic.generate(text_embeds=text_embeds if self.semantic_has_condition else None, batch_size=batch_size,
+                                                    prime_wave=prime_wave, prime_wave_input_sample_hz=prime_wave_input_sample_hz, max_length=max_length)
+        coarse_token_ids_or_recon_wave = self.coarse.generate(text_embeds=text_embeds if self.coarse_has_condition else None,
+                                                              semantic_token_ids=semantic_token_ids, prime_wave=prime_wave,
                                                               prime_wave_input_sample_hz=prime_wave_input_sample_hz,
                                                               reconstruct_wave=return_coarse_generated_wave)
         if return_coarse_generated_wave:
             return coarse_token_ids_or_recon_wave
-        return self.fine.generate(coarse_token_ids=coarse_token_ids_or_recon_wave, prime_wave=prime_wave,
-                                  prime_wave_input_sample_hz=prime_wave_input_sample_hz, reconstruct_wave=True,
+        return self.fine.generate(text_embeds=text_embeds if self.fine_has_condition else None, coarse_token_ids=coarse_token_ids_or_recon_wave,
+                                  prime_wave=prime_wave, prime_wave_input_sample_hz=prime_wave_input_sample_hz, reconstruct_wave=True,
                                   mask_out_generated_fine_tokens=mask_out_generated_fine_tokens)

@@ -19,7 +19,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import ops
+from . import ops, xattn
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -35,6 +35,9 @@ class StackCfg:
     add_value_residual: bool
     grad_shrink_alpha: float
     residual_bf16: bool = False   # storage type of the 4-stream residual tensors and their gradients (num_residual_streams > 1 only)
+    cross_attend: bool = False    # a cross-attention branch between attention and feed-forward (reference Transformer(cross_attend=True), :450)
+    prefix: bool = False          # cond_as_self_attn_prefix: the conditioning context is prepended to the self-attention keys (:330-345, :510-515)
+    dim_context: int = 0
 
     @property
     def inner_pad(self):
@@ -42,24 +45,30 @@ class StackCfg:
 
 
 HC_KEYS = ('Bb', 'Aa', 'Wa', 'sa', 'wb', 'sb', 'gamma')   # static_beta, static_alpha, dynamic_alpha_fn, dynamic_alpha_scale, dynamic_beta_fn, dynamic_beta_scale, norm.gamma
+BRANCH_KEYS = dict(attn=('ln', 'wq', 'wkv', 'wo'), cross=('ln', 'ctx_ln', 'null_kv', 'wq', 'wkv', 'wo'), ff=('ln', 'w1', 'ln3', 'w2'))
 
 
-def params_per_layer(S):
+def branch_kinds(cfg_or_cross):
+    cross = cfg_or_cross if isinstance(cfg_or_cross, bool) else cfg_or_cross.cross_attend
+    return ('attn', 'cross', 'ff') if cross else ('attn', 'ff')
+
+
+def params_per_layer(S, cross=False):
     hc = len(HC_KEYS) if S > 1 else 0
-    return (hc + 4) + (hc + 4)
+    return sum(hc + len(BRANCH_KEYS[k]) for k in branch_kinds(bool(cross)))
 
 
-def _split_layer(flat, S):
-    """flat per-layer parameter list -> (attn dict, ff dict) (see Transformer.flat_params for the order)."""
-    i = 0
-    a, f = {}, {}
-    if S > 1:
-        a['hc'] = dict(zip(HC_KEYS, flat[i:i + 7])); i += 7
-    a['ln'], a['wq'], a['wkv'], a['wo'] = flat[i:i + 4]; i += 4
-    if S > 1:
-        f['hc'] = dict(zip(HC_KEYS, flat[i:i + 7])); i += 7
-    f['ln'], f['w1'], f['ln3'], f['w2'] = flat[i:i + 4]
-    return a, f
+def _split_layer(flat, S, cross=False):
+    """flat per-layer parameter list -> [(kind, params dict, first index within the layer)] in execution order (see Transformer.flat_params)."""
+    i, out = 0, []
+    for kind in branch_kinds(bool(cross)):
+        d, first = {}, i
+        if S > 1:
+            d['hc'] = dict(zip(HC_KEYS, flat[i:i + 7])); i += 7
+        keys = BRANCH_KEYS[kind]
+        d.update(zip(keys, flat[i:i + len(keys)])); i += len(keys)
+        out.append((kind, d, first))
+    return out
 
 
 def tensor_version(t):
@@ -115,39 +124,50 @@ def _pack_w2(w, I, Ip):
     return W, WT
 
 
-def layer_weights(cache: WeightCache, l, pa, pf, I, Ip):
-    """bf16 packed (W, W^T) pairs of one layer's five dense weights; when any master changed, ALL are re-packed in one launch."""
-    ws = (('wq', pa['wq']), ('wkv', pa['wkv']), ('wo', pa['wo']), ('w1', pf['w1']), ('w2', pf['w2']))
+def layer_weights(cache: WeightCache, l, branches, I, Ip):
+    """bf16 packed (W, W^T) pairs of one layer's dense weights -> {kind: {name: (W, WT)}}; when any master changed, ALL of the layer are re-packed
+    (one launch per 8 weights).  branches: _split_layer() of the layer's detached parameters."""
+    ws = []
+    for kind, d, _ in branches:
+        for name in ('wq', 'wkv', 'wo', 'w1', 'w2'):
+            if name in d:
+                ws.append(((kind, name), d[name]))
     vers = {k: (w.data_ptr(), tensor_version(w), tuple(w.shape)) for k, w in ws}
-    hits = {k: cache.store.get((l, k)) for k, _ in ws}
-    if all(h is not None and h[0] == vers[k] for k, h in hits.items()):
-        return tuple(hits[k][1] for k, _ in ws)
-    out, jobs = {}, []
-    with torch.no_grad():
-        for k, w in ws[:3]:
-            w = w.detach()
-            rows, cols = w.shape
-            rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
-            W = torch.empty((rp, cp), dtype=BF16, device=w.device)
-            WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
-            jobs.append((w, W, WT, rp, cp))
-            out[k] = (W[:rows], WT[:cols])
-        w1 = pf['w1'].detach()
-        D = w1.shape[1]
-        W1 = torch.empty((2 * Ip, D), dtype=BF16, device=w1.device)
-        W1T = torch.empty((D, 2 * Ip), dtype=BF16, device=w1.device)
-        jobs.append((w1[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
-        jobs.append((w1[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
-        out['w1'] = (W1, W1T)
-        w2 = pf['w2'].detach()
-        W2 = torch.empty((D, Ip), dtype=BF16, device=w2.device)
-        W2T = torch.empty((Ip, D), dtype=BF16, device=w2.device)
-        jobs.append((w2, W2, W2T, D, Ip))
-        out['w2'] = (W2, W2T)
-        ops.pack_weights_multi(jobs)
-    for k, _ in ws:
-        cache.store[(l, k)] = (vers[k], out[k])
-    return tuple(out[k] for k, _ in ws)
+    hits = {k: cache.store.get((l,) + k) for k, _ in ws}
+    if not all(h is not None and h[0] == vers[k] for k, h in hits.items()):
+        out, jobs = {}, []
+        with torch.no_grad():
+            for k, w in ws:
+                w = w.detach()
+                if k[1] == 'w1':
+                    D = w.shape[1]
+                    W1 = torch.empty((2 * Ip, D), dtype=BF16, device=w.device)
+                    W1T = torch.empty((D, 2 * Ip), dtype=BF16, device=w.device)
+                    jobs.append((w[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
+                    jobs.append((w[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
+                    out[k] = (W1, W1T)
+                elif k[1] == 'w2':
+                    D = w.shape[0]
+                    W2 = torch.empty((D, Ip), dtype=BF16, device=w.device)
+                    W2T = torch.empty((Ip, D), dtype=BF16, device=w.device)
+                    jobs.append((w, W2, W2T, D, Ip))
+                    out[k] = (W2, W2T)
+                else:
+                    rows, cols = w.shape
+                    rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+                    W = torch.empty((rp, cp), dtype=BF16, device=w.device)
+                    WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
+                    jobs.append((w, W, WT, rp, cp))
+                    out[k] = (W[:rows], WT[:cols])
+            for j in range(0, len(jobs), 8):
+                ops.pack_weights_multi(jobs[j:j + 8])
+        for k, _ in ws:
+            cache.store[(l,) + k] = (vers[k], out[k])
+        hits = {k: cache.store[(l,) + k] for k, _ in ws}
+    res = {}
+    for (kind, name), h in hits.items():
+        res.setdefault(kind, {})[name] = h[1]
+    return res
 
 
 def default_residual_bf16():
@@ -176,83 +196,151 @@ class DecodeCache:
         self.frozen = False             # True while a step is being CAPTURED (recorded, not executed): host bookkeeping must not advance
 
 
-def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None):
+class Context:
+    """Conditioning context of one forward (reference Transformer.forward(context=, context_mask=), audiolm_pytorch.py:461-470): text embeddings
+    already projected to the model / context width.  x bf16 [B*m, Dc] (row (b m)), mask uint8 [B, m] | None."""
+
+    def __init__(self, x, mask_u8, B, m):
+        self.x, self.mask, self.B, self.m = x, mask_u8, B, m
+
+
+def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx):
+    """self-attention branch (audiolm_pytorch.py:307-406): -> (Y bf16 [M, D], saved dict)."""
+    M, D, H, dh, dev = B * N, cfg.dim, cfg.heads, cfg.dim_head, X.device
+    (Wq, _), (Wkv, _), (Wo, _) = W['wq'], W['wkv'], W['wo']
+    Q = _empty((M, H * dh), BF16, dev)
+    ops.gemm_nt(XN, Wq, Q)
+    KV = _empty((M, 2 * dh), BF16, dev)
+    ops.gemm_nt(X, Wkv, KV)                              # k / v from the UN-normalised branch input (:325 vs :347)
+    K, Vown = KV[:, :dh], KV[:, dh:]
+    if cfg.add_value_residual and st['kv0'] is not None:
+        V = ops.value_residual_mix(Vown, st['kv0'][:, dh:])  # :357-358
+    else:
+        V = Vown
+    if st['kv0'] is None:
+        st['kv0'] = KV                                   # :534-535 (layer-0 values, pre-mix)
+    sv = dict(Q=Q, KV=KV, V=V, mixed=V is not Vown)
+    pre = None
+    if cfg.prefix:
+        # cond_as_self_attn_prefix (:330-345): keys / values of the prepended context come from the SAME to_kv, un-normalised like x; its values
+        # take part in the value residual (orig_v covers the prefix rows too, :353-358)
+        m = ctx.m
+        KVp = _empty((B * m, 2 * dh), BF16, dev)
+        ops.gemm_nt(ctx.x, Wkv, KVp)
+        Vp = KVp[:, dh:]
+        if cfg.add_value_residual and st['kvp0'] is not None:
+            Vp = ops.value_residual_mix(Vp, st['kvp0'][:, dh:])
+        if st['kvp0'] is None:
+            st['kvp0'] = KVp
+        pre = dict(KVp=KVp, ke=KVp[:, :dh].reshape(B, m, dh), ve=Vp.reshape(B, m, dh), pmixed=Vp is not KVp[:, dh:])
+    if decode is not None:
+        assert pre is None, 'the reference turns the kv cache off for prefix conditioning (audiolm_pytorch.py:481-482)'
+        kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
+        AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias, pos_dev=decode.pos_dev), None
+    else:
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
+        if pre is not None:
+            AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE)
+            pre['xs'] = xs
+        if kv_out is not None:
+            kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
+            kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
+    Y = _empty((M, D), BF16, dev)
+    ops.gemm_nt(AO, Wo, Y)
+    sv.update(AO=AO, LSE=LSE, pre=pre)
+    return Y, sv
+
+
+def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
+    """cross-attention branch (Attention(dim_context, num_null_kv=1, norm_context=True, causal=False), :450; forward :307-406 with `context`):
+    q from the pre-LayerNorm'd stream, k / v from context_norm(context), value residual across the cross-attention layers (:541-544), one
+    learned null key / value in front (:372-376) which the context mask never hides (:384-385)."""
+    M, D, H, dh, dev = B * N, cfg.dim, cfg.heads, cfg.dim_head, XN.device
+    (Wq, _), (Wkv, _), (Wo, _) = W['wq'], W['wkv'], W['wo']
+    m = ctx.m
+    Q = _empty((M, H * dh), BF16, dev)
+    ops.gemm_nt(XN, Wq, Q)
+    CN, _, cmean, crstd = ops.layernorm_fwd(ctx.x, prm['ctx_ln'])              # context_norm (:323)
+    KVc = _empty((B * m, 2 * dh), BF16, dev)
+    ops.gemm_nt(CN, Wkv, KVc)
+    Vc = KVc[:, dh:]
+    if cfg.add_value_residual and st['kvc0'] is not None:
+        Vc = ops.value_residual_mix(Vc, st['kvc0'][:, dh:])
+    if st['kvc0'] is None:
+        st['kvc0'] = KVc
+    nkv = prm['null_kv'].to(BF16)                                              # [2, 1, dh]
+    ke = torch.cat((nkv[0].expand(B, 1, dh), KVc[:, :dh].reshape(B, m, dh)), dim=1)
+    ve = torch.cat((nkv[1].expand(B, 1, dh), Vc.reshape(B, m, dh)), dim=1)
+    emask = None
+    if ctx.mask is not None:
+        emask = torch.cat((torch.ones((B, 1), dtype=torch.uint8, device=dev), ctx.mask), dim=1).contiguous()
+    AO, LSE, xs = xattn.extra_attn_fwd(Q, ke, ve, emask, B, N, H, dh, float(dh) ** -0.5)
+    Y = _empty((M, D), BF16, dev)
+    ops.gemm_nt(AO, Wo, Y)
+    return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=Vc is not KVc[:, dh:], AO=AO, xs=xs)
+
+
+def _run_ff(cfg, W, prm, XN, M):
+    """feed-forward branch (audiolm_pytorch.py:246-260)"""
+    I, Ip, dev = cfg.inner, cfg.inner_pad, XN.device
+    (W1, _), (W2, _) = W['w1'], W['w2']
+    U = _empty((M, 2 * Ip), BF16, dev)
+    ops.gemm_nt(XN, W1, U)
+    HN, mean3, rstd3 = ops.geglu_ln_fwd(U, prm['ln3'], I, Ip)
+    Y = _empty((M, cfg.dim), BF16, dev)
+    ops.gemm_nt(HN, W2, Y)
+    return Y, dict(U=U, HN=HN, mean3=mean3, rstd3=rstd3)
+
+
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None):
     """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
-    audiolm_pytorch.py:500-506 / :532) or None.  Sampling: `kv_out` (DecodeCache) is filled with every layer's k / v of this (prefix)
-    forward; `decode` (DecodeCache) means x holds ONE new position per sequence (N == 1) at index decode.length: its attention runs over
-    the cache (alm_mqa_decode_attn, which also appends the new k / v), everything else is the same launch sequence on B rows."""
+    audiolm_pytorch.py:500-506 / :532) or None.  ctx: Context (cross-attention layers / self-attention prefix) or None.  Sampling: `kv_out`
+    (DecodeCache) is filled with every layer's k / v of this (prefix) forward; `decode` (DecodeCache) means x holds ONE new position per
+    sequence (N == 1) at index decode.length: its attention runs over the cache (alm_mqa_decode_attn, which also appends the new k / v),
+    everything else is the same launch sequence on B rows.
+
+    Every layer is a sequence of BRANCHES (attention, [cross-attention], feed-forward), each wrapped by a hyper-connection (S > 1: the depth
+    connection of the previous branch is fused with the width connection + pre-LayerNorm of the next one: one pass over the residual
+    streams per branch) or by a plain residual (S == 1)."""
     B, N, D = x.shape
-    M, S, H, dh = B * N, cfg.streams, cfg.heads, cfg.dim_head
+    M, S = B * N, cfg.streams
     I, Ip = cfg.inner, cfg.inner_pad
-    dev = x.device
-    ppl = params_per_layer(S)
-    saved = dict(layers=[], B=B, N=N) if need_grad else None
+    ppl = params_per_layer(S, cfg.cross_attend)
+    assert (ctx is not None) == (cfg.cross_attend or cfg.prefix), 'conditioned stack <-> conditioning context'
+    saved = dict(branches=[], B=B, N=N) if need_grad else None
 
     R = x.reshape(M, D)                  # S > 1: the stream expansion (:524) is never materialised -- the first branch reads x for every stream
     rb = S > 1
     rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
-    kv0 = None
+    st = dict(kv0=None, kvp0=None, kvc0=None)
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
-        pa, pf = _split_layer(flat[l * ppl:(l + 1) * ppl], S)
-        (Wq, WqT), (Wkv, WkvT), (Wo, WoT), (W1, W1T), (W2, W2T) = layer_weights(cache, l, pa, pf, I, Ip)
-
-        # ---------------- attention branch (audiolm_pytorch.py:307-406) ----------------
-        if S > 1:
-            # depth connection of the previous branch fused with this branch's width connection + pre-LayerNorm (one pass over R)
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=pa['hc'], ln_gamma=pa['ln'], rin_bcast=rb, r_dtype=rdt)
-            R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
-            rb = rb and pend_y is None                 # still the un-expanded x after a width-only call
-        else:
-            XN, X, mean, rstd = ops.layernorm_fwd(R, pa['ln'], want_copy=True)
-            coef = None
-        Q = _empty((M, H * dh), BF16, dev)
-        ops.gemm_nt(XN, Wq, Q)
-        KV = _empty((M, 2 * dh), BF16, dev)
-        ops.gemm_nt(X, Wkv, KV)                          # k / v from the UN-normalised branch input (:325 vs :347)
-        K, Vown = KV[:, :dh], KV[:, dh:]
-        if cfg.add_value_residual and kv0 is not None:
-            V = ops.value_residual_mix(Vown, kv0[:, dh:])  # :357-358
-        else:
-            V = Vown
-        if kv0 is None:
-            kv0 = KV                                      # :534-535 (layer-0 values, pre-mix)
-        if decode is not None:
-            kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
-            AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias, pos_dev=decode.pos_dev), None
-        else:
-            AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
-            if kv_out is not None:
-                kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
-                kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
-        Y = _empty((M, D), BF16, dev)
-        ops.gemm_nt(AO, Wo, Y)
-
-        # ---------------- feed-forward branch (audiolm_pytorch.py:246-260) ----------------
-        if S > 1:
-            # (the un-normalised branch input X2 is only read by the un-fused LayerNorm backward)
-            h = ops.hc_fwd(R, B, S, N, D, y_prev=Y, coef_prev=coef, hc=pf['hc'], ln_gamma=pf['ln'], rin_bcast=rb, r_dtype=rdt,
-                           want_x=need_grad and not FUSE_LN_BWD)
-            R1, X2, XN2, mean2, rstd2, coef2 = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
-            rb = False
-        else:
-            R1 = ops.residual_add(R, Y)
-            XN2, X2, mean2, rstd2 = ops.layernorm_fwd(R1, pf['ln'], want_copy=False)
-            coef2 = None
-        U = _empty((M, 2 * Ip), BF16, dev)
-        ops.gemm_nt(XN2, W1, U)
-        HN, mean3, rstd3 = ops.geglu_ln_fwd(U, pf['ln3'], I, Ip)
-        Y2 = _empty((M, D), BF16, dev)
-        ops.gemm_nt(HN, W2, Y2)
-
-        if need_grad:
-            saved['layers'].append(dict(R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Q=Q, KV=KV, V=V, AO=AO, LSE=LSE, Y=Y,
-                                        R1=R1, X2=X2, XN2=XN2, mean2=mean2, rstd2=rstd2, coef2=coef2, U=U, HN=HN, mean3=mean3,
-                                        rstd3=rstd3, Y2=Y2, mixed=V is not Vown, r_bcast=(S > 1 and l == 0)))
-        if S > 1:
-            R, pend_y, pend_coef = R1, Y2, coef2
-        else:
-            R = ops.residual_add(R1, Y2)
+        branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
+        LW = layer_weights(cache, l, branches, I, Ip)
+        for kind, prm, first in branches:
+            want_x = kind == 'attn'                  # only to_kv reads the un-normalised branch input
+            if S > 1:
+                h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=prm['hc'], ln_gamma=prm['ln'], rin_bcast=rb, r_dtype=rdt,
+                               want_x=want_x)
+                r_bcast = pend_y is None                 # R is still the un-expanded x (first branch only)
+                R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
+                rb = rb and pend_y is None               # still the un-expanded x after a width-only call
+            else:
+                XN, X, mean, rstd = ops.layernorm_fwd(R, prm['ln'], want_copy=want_x)
+                coef, r_bcast = None, False
+            if kind == 'attn':
+                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx)
+            elif kind == 'cross':
+                Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx)
+            else:
+                Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M)
+            if need_grad:
+                sv.update(kind=kind, layer=l, first=l * ppl + first, R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Y=Y, r_bcast=r_bcast)
+                saved['branches'].append(sv)
+            if S > 1:
+                pend_y, pend_coef = Y, coef
+            else:
+                R = ops.residual_add(R, Y)
 
     if S > 1:
         # last depth connection + stream sum (:551) + final LayerNorm (:555) in one pass; the final residual streams are never stored
@@ -262,7 +350,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         xs = R
         hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1], out_f32=True)  # :555 (fp32 out: F.layer_norm autocasts to fp32; the logit heads split it)
     if need_grad:
-        saved.update(xs=xs, fmean=fmean, frstd=frstd, kv0=kv0)
+        saved.update(xs=xs, fmean=fmean, frstd=frstd, st=st, ctx=ctx)
     if decode is not None and not decode.frozen:
         decode.length += 1
     if kv_out is not None:
@@ -326,135 +414,173 @@ class _SideStream:
                 self.main.wait_event(ev)
 
 
-FUSE_LN_BWD = os.environ.get('ALM_FUSE_LN_BWD', '1') != '0'             # switch: pre-LayerNorm backward inside the hyper-connection kernel
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
 MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
 
+def _vgrad_mode(acc, mixed):
+    """alm_kv_grad_pack mode: 0 no value residual, 1 this layer's v was mixed (half of dv goes to layer 0's accumulator), 2 layer 0 (receives it)"""
+    return 0 if acc is None else (1 if mixed else 2)
+
+
 def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None, async_wgrad=True):
-    """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None)."""
+    """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None,
+    d(loss)/d(context) fp32 [B*m, Dc] | None)."""
     B, N = saved['B'], saved['N']
     D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
     M = B * N
     I, Ip = cfg.inner, cfg.inner_pad
     dev = dhn.device
-    ppl = params_per_layer(S)
+    ppl = params_per_layer(S, cfg.cross_attend)
     grads = [None] * len(flat)
     side = _SideStream(dev, ASYNC_WGRAD and async_wgrad)
     rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
+    ctx = saved['ctx']
+    brs = saved['branches']
+    scale = float(dh) ** -0.5
 
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
     grads[-1] = dgam
-    acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if cfg.add_value_residual and cfg.depth > 1 else None
-    # S > 1: dR = gradient wrt the residual streams after the current branch; right after the final stream sum it is dxs for every
-    # stream (`bcast`).  dY2 / dbeta2 (depth-connection backward of the FF branch) are produced one step ahead by the fused kernels.
+    multi = cfg.add_value_residual and cfg.depth > 1
+    acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if multi else None
+    acc_vp0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.prefix) else None
+    acc_vc0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.cross_attend) else None
+    dctx = None                                                                # fp32 [B*m, Dc], summed over layers
     dtbl_part = ops.attn_bias_part(B, N, H, bias.tbl.shape[1], dev) if bias is not None else None
+    # S > 1: dR = gradient wrt the residual streams after the current branch; right after the final stream sum it is dxs for every
+    # stream (`bcast`).  dY / dbeta (depth-connection backward of the branch about to be processed) are produced one step ahead by the
+    # fused kernels.
     dR, bcast = dxs, S > 1
-    dY2 = dbeta2 = None
+    dY = dbeta = None
     if S > 1:
-        last = saved['layers'][-1]
-        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=last['Y2'], coef_prev=last['coef2'], r_dtype=rdt)
-        dY2, dbeta2 = h['dy'], h['dbeta']
+        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=brs[-1]['Y'], coef_prev=brs[-1]['coef'], r_dtype=rdt)
+        dY, dbeta = h['dy'], h['dbeta']
 
-    for l in reversed(range(cfg.depth)):
-        sv = saved['layers'][l]
-        base = l * ppl
-        pa, pf = _split_layer(flat[base:base + ppl], S)
-        (Wq, WqT), (Wkv, WkvT), (Wo, WoT), (W1, W1T), (W2, W2T) = layer_weights(cache, l, pa, pf, I, Ip)
+    def add_ctx(g):
+        nonlocal dctx
+        dctx = g if dctx is None else ops.add_f32(dctx, g)
+
+    LW, LW_layer = None, -1
+    for bi in reversed(range(len(brs))):
+        sv = brs[bi]
+        kind, l, first = sv['kind'], sv['layer'], sv['first']
+        if l != LW_layer:
+            branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
+            LW, LW_layer = layer_weights(cache, l, branches, I, Ip), l
+            prms = {k: (d, f) for k, d, f in branches}
+        prm = prms[kind][0]
         hc_n = 7 if S > 1 else 0
-        ia = base + hc_n                      # index of attn ln gamma
-        iff = base + hc_n + 4 + hc_n          # index of ff ln gamma
-
-        # ================= feed-forward branch =================
+        ip = first + hc_n                                                      # index of this branch's first non-hyper-connection parameter
         if S == 1:
-            dY2 = ops.f32_to_bf16(dR)
-        dHN = _empty((M, Ip), BF16, dev)
-        ops.gemm_nt(dY2, W2T, dHN)                                            # dHN = dY2 @ W2
-        dW2 = _empty((D, I), F32, dev)
-        HNs = sv['HN']
-        side.run(lambda: ops.gemm_tn_splitk(dY2, HNs[:, :I], dW2), dY2, HNs, dW2)      # dW2 = dY2^T @ HN
-        dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], pf['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
-        dXN2 = _empty((M, D), BF16, dev)
-        ops.gemm_nt(dU, W1T, dXN2)                                            # dXN2 = dU @ W1
-        dW1 = _empty((2 * I, D), F32, dev)
-        XN2s = sv['XN2']
-        side.run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2s, dW1.view(2, I, D)), dU, XN2s, dW1)   # dW1 = dU^T @ XN2
-        if S > 1:
-            # the FF branch's pre-LayerNorm backward + its width-connection backward + the depth-connection backward of this layer's
-            # attention branch: ONE pass over the residual streams
-            if FUSE_LN_BWD:
-                h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN2, mean=sv['mean2'], rstd=sv['rstd2'], ln_gamma=pf['ln'], R=sv['R1'],
-                               coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'], y_prev=sv['Y'], coef_prev=sv['coef'], r_dtype=rdt)
-                dgl = h['grads']['ln']
-            else:
-                dX2, dgl = ops.layernorm_bwd(dXN2, sv['X2'], sv['mean2'], sv['rstd2'], pf['ln'])
-                h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dx=dX2, R=sv['R1'], coef=sv['coef2'], dbeta=dbeta2, hc=pf['hc'],
-                               y_prev=sv['Y'], coef_prev=sv['coef'], r_dtype=rdt)
-            dR1, dY, dbeta, bcast = h['dR'], h['dy'], h['dbeta'], False
-            for j, k in enumerate(HC_KEYS):
-                grads[base + hc_n + 4 + j] = h['grads'][k]
+            dY = ops.f32_to_bf16(dR)
+        extra = None
+        W = LW[kind]
+        if kind == 'ff':
+            (_, W1T), (_, W2T) = W['w1'], W['w2']
+            dHN = _empty((M, Ip), BF16, dev)
+            ops.gemm_nt(dY, W2T, dHN)                                             # dHN = dY @ W2
+            dW2 = _empty((D, I), F32, dev)
+            HNs, dYs = sv['HN'], dY
+            side.run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2), dYs, HNs, dW2)      # dW2 = dY^T @ HN
+            dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
+            dXN = _empty((M, D), BF16, dev)
+            ops.gemm_nt(dU, W1T, dXN)                                             # dXN = dU @ W1
+            dW1 = _empty((2 * I, D), F32, dev)
+            XNs = sv['XN']
+            side.run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
+            grads[ip + 1], grads[ip + 2], grads[ip + 3] = dW1, dg3, dW2
+        elif kind == 'cross':
+            (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
+            m = ctx.m
+            dAO = _empty((M, H * dh), BF16, dev)
+            ops.gemm_nt(dY, WoT, dAO)
+            dWo = _empty((D, H * dh), F32, dev)
+            AOs, dYs = sv['AO'], dY
+            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo), dYs, AOs, dWo)
+            nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
+            dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, sv['xs'], nd, B, N, H, dh, scale)
+            dnull = torch.stack((dke[:, 0].sum(0), dve[:, 0].sum(0))).reshape(2, 1, dh)           # null_kv is shared by the batch (:373)
+            dkv32 = torch.cat((dke[:, 1:].reshape(B * m, dh), dve[:, 1:].reshape(B * m, dh)), dim=1).contiguous()
+            dKVc = ops.kv_grad_pack(dkv32, acc_vc0, _vgrad_mode(acc_vc0, sv['cmixed']), dh)
+            dXN = _empty((M, D), BF16, dev)
+            ops.gemm_nt(dQ, WqT, dXN)
+            dWq = _empty((H * dh, D), F32, dev)
+            XNs = sv['XN']
+            side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
+            dCN = _empty((B * m, cfg.dim_context), BF16, dev)
+            ops.gemm_nt(dKVc, WkvT, dCN)
+            dWkv = _empty((2 * dh, cfg.dim_context), F32, dev)
+            CNs = sv['CN']
+            side.run(lambda: ops.gemm_tn_splitk(dKVc, CNs, dWkv), dKVc, CNs, dWkv)
+            dc, dgc = ops.layernorm_bwd(dCN, ctx.x, sv['cmean'], sv['crstd'], prm['ctx_ln'])      # context_norm backward -> d(context)
+            add_ctx(dc)
+            grads[ip + 1], grads[ip + 2], grads[ip + 3], grads[ip + 4], grads[ip + 5] = dgc, dnull, dWq, dWkv, dWo
         else:
-            dX2, dgl = ops.layernorm_bwd(dXN2, sv['R1'], sv['mean2'], sv['rstd2'], pf['ln'])
-            dR1 = ops.add_f32(dR, dX2)
-            dY = ops.f32_to_bf16(dR1)
-        grads[iff], grads[iff + 1], grads[iff + 2], grads[iff + 3] = dgl, dW1, dg3, dW2
+            (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
+            dAO = _empty((M, H * dh), BF16, dev)
+            ops.gemm_nt(dY, WoT, dAO)
+            dWo = _empty((D, H * dh), F32, dev)
+            AOs, dYs = sv['AO'], dY
+            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo), dYs, AOs, dWo)
+            KV = sv['KV']
+            # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
+            dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
+            dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh)
+            dKVp = None
+            pre = sv['pre']
+            if pre is not None:
+                m = ctx.m
+                nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
+                dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, pre['xs'], nd, B, N, H, dh, scale, dq=dQ)
+                dkvp32 = torch.cat((dke.reshape(B * m, dh), dve.reshape(B * m, dh)), dim=1).contiguous()
+                dKVp = ops.kv_grad_pack(dkvp32, acc_vp0, _vgrad_mode(acc_vp0, pre['pmixed']), dh)
+                dcp = _empty((B * m, D), F32, dev)
+                ops.gemm_nt(dKVp, WkvT, dcp)                                      # the prefix enters to_kv un-normalised: d(context) directly
+                add_ctx(dcp)
+            dXN = _empty((M, D), BF16, dev)
+            ops.gemm_nt(dQ, WqT, dXN)
+            dWq = _empty((H * dh, D), F32, dev)
+            XNs = sv['XN']
+            side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
+            extra = _empty((M, D), BF16, dev)
+            ops.gemm_nt(dKV, WkvT, extra)                                         # K/V-path gradient: reaches the un-normalised branch input directly
+            dWkv = _empty((2 * dh, D), F32, dev)
+            Xs, cx = sv['X'], (ctx.x if dKVp is not None else None)
 
-        # ================= attention branch =================
-        dAO = _empty((M, H * dh), BF16, dev)
-        ops.gemm_nt(dY, WoT, dAO)
-        dWo = _empty((D, H * dh), F32, dev)
-        AOs = sv['AO']
-        side.run(lambda: ops.gemm_tn_splitk(dY, AOs, dWo), dY, AOs, dWo)
-        KV = sv['KV']
-        dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
-        if acc_v0 is None:
-            mode = 0
-        elif sv['mixed']:
-            mode = 1
-        else:
-            mode = 2                                                          # layer 0: receives every later layer's 0.5 * dV
-        dKV = ops.kv_grad_pack(dkv32, acc_v0, mode, dh)
-        dXN = _empty((M, D), BF16, dev)
-        ops.gemm_nt(dQ, WqT, dXN)
-        dWq = _empty((H * dh, D), F32, dev)
-        XNs = sv['XN']
-        side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
-        dXkv = _empty((M, D), BF16, dev)
-        ops.gemm_nt(dKV, WkvT, dXkv)
-        dWkv = _empty((2 * dh, D), F32, dev)
-        Xs = sv['X']
-        side.run(lambda: ops.gemm_tn_splitk(dKV, Xs, dWkv), dKV, Xs, dWkv)
+            def wkv_grad():
+                ops.gemm_tn_splitk(dKV, Xs, dWkv)
+                if dKVp is not None:
+                    ops.gemm_tn_splitk(dKVp, cx, dWkv, accumulate=True)
+            side.run(wkv_grad, *[t for t in (dKV, Xs, dWkv, dKVp, cx) if t is not None])
+            grads[ip + 1], grads[ip + 2], grads[ip + 3] = dWq, dWkv, dWo
+
+        # ---- this branch's pre-LayerNorm backward + width-connection backward + the depth-connection backward of the previous branch: ONE pass
+        prev = brs[bi - 1] if bi > 0 else None
         if S > 1:
-            # pre-LayerNorm backward (+ the K/V-path gradient dXkv, which reaches the un-normalised branch input directly) + width-connection
-            # backward of the attention branch (+ depth-connection backward of the previous layer's FF branch)
-            prev = saved['layers'][l - 1] if l > 0 else None
-            py, pc = (prev['Y2'], prev['coef2']) if prev else (None, None)
-            if FUSE_LN_BWD:
-                h = ops.hc_bwd(dR1, B, S, N, D, dxn=dXN, extra=dXkv, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=pa['ln'], R=sv['R'],
-                               coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=l == 0, r_dtype=rdt)
-                dgla = h['grads']['ln']
-            else:
-                dX, dgla = ops.layernorm_bwd(dXN, sv['X'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
-                h = ops.hc_bwd(dR1, B, S, N, D, dx=dX, R=sv['R'], coef=sv['coef'], dbeta=dbeta, hc=pa['hc'], y_prev=py, coef_prev=pc,
-                               r_bcast=sv['r_bcast'], sum_only=l == 0, r_dtype=rdt)
-            dR, dY2, dbeta2 = (h['dsum'] if l == 0 else h['dR']), h['dy'], h['dbeta']      # layer 0: already summed over the streams (:524)
+            py, pc = (prev['Y'], prev['coef']) if prev is not None else (None, None)
+            h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN, extra=extra, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=prm['ln'], R=sv['R'],
+                           coef=sv['coef'], dbeta=dbeta, hc=prm['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=prev is None,
+                           r_dtype=rdt)
+            dR, dY, dbeta, bcast = (h['dsum'] if prev is None else h['dR']), h['dy'], h['dbeta'], False     # first branch: summed over the streams (:524)
             for j, k in enumerate(HC_KEYS):
-                grads[base + j] = h['grads'][k]
+                grads[first + j] = h['grads'][k]
+            grads[ip] = h['grads']['ln']
         else:
-            dX, dgla = ops.layernorm_bwd(dXN, sv['R'], sv['mean'], sv['rstd'], pa['ln'], extra=dXkv)
-            dR = ops.add_f32(dR1, dX)
-        grads[ia], grads[ia + 1], grads[ia + 2], grads[ia + 3] = dgla, dWq, dWkv, dWo
+            dX, dgl = ops.layernorm_bwd(dXN, sv['R'], sv['mean'], sv['rstd'], prm['ln'], extra=extra)
+            dR = ops.add_f32(dR, dX)
+            grads[ip] = dgl
         sv.clear()
-        if on_layer_grads is not None:
+        if on_layer_grads is not None and (prev is None or prev['layer'] != l):
             # the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the critical
             # path never waits for them
+            base = l * ppl
             side.run_after_all(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
     dx = dR.view(B, N, D)
     dtbl = ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None
     side.join()                                    # autograd hands the gradients to consumers on the main stream
-    return dx, grads, dtbl
+    return dx, grads, dtbl, dctx
 
 
 _MICRO_STREAMS = {}
@@ -482,34 +608,47 @@ class TransformerStackFn(torch.autograd.Function):
     ONE node on ONE stream -- the fork / join is done here with events."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, cfg, cache, opts, bias, tbl, *flat):
+    def forward(ctx, x, mask_u8, cfg, cache, opts, bias, tbl, context, *flat):
         # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes its gradient.
+        # context: conditioning embeddings [B, m, dim_context] (cross-attention layers / self-attention prefix) | None; its key mask (bool / uint8
+        #          [B, m]) travels in opts['context_mask'].
         # opts: dict(hook = per-layer gradient callback | None, grad = torch.is_grad_enabled() AT THE CALL SITE (it is always off in here),
         #            kv_out / decode = DecodeCache | None: sampling, micro = 1 | 2)
         hooks = opts.get('hook')
-        need = bool(opts.get('grad', True)) and (any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad))
+        need = bool(opts.get('grad', True)) and (any(t.requires_grad for t in flat) or x.requires_grad or (tbl is not None and tbl.requires_grad)
+                                                 or (context is not None and context.requires_grad))
         xin = x.detach().contiguous().to(F32)
         bias = bias.detached() if bias is not None else None
         flat_d = [t.detach() for t in flat]
         B = xin.shape[0]
+        cx = None
+        if context is not None:
+            m = context.shape[1]
+            cm = opts.get('context_mask')
+            cm = None if cm is None else cm.to(torch.bool).contiguous().view(torch.uint8)
+            cx = Context(context.detach().to(BF16).reshape(B * m, -1).contiguous(), cm, B, m)
+        ctx.ctx_meta = None if context is None else (context.shape, context.dtype)
         micro = int(opts.get('micro', 1))
         if micro == 2 and (B % 2 or B < 2 or opts.get('kv_out') is not None or opts.get('decode') is not None or hooks is not None):
             micro = 1
         ctx.micro = micro
         if micro == 1:
-            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'))
+            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx)
         else:
-            S, ppl, h = cfg.streams, params_per_layer(cfg.streams), B // 2
+            S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
-                pa, pf = _split_layer(flat_d[l * ppl:(l + 1) * ppl], S)
-                layer_weights(cache, l, pa, pf, cfg.inner, cfg.inner_pad)
+                layer_weights(cache, l, _split_layer(flat_d[l * ppl:(l + 1) * ppl], S, cfg.cross_attend), cfg.inner, cfg.inner_pad)
             cur, s2 = torch.cuda.current_stream(xin.device), _micro_stream(xin.device)
             (xa, xb), (ma, mb) = _halves(xin, h), _halves(mask_u8, h)
+            ca = cb = None
+            if cx is not None:
+                (cma, cmb) = _halves(cx.mask, h)
+                ca, cb = Context(cx.x[:h * cx.m], cma, h, cx.m), Context(cx.x[h * cx.m:], cmb, B - h, cx.m)
             s2.wait_stream(cur)
-            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias)
+            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca)
             xb.record_stream(s2)
             with torch.cuda.stream(s2):
-                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias)
+                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb)
             cur.wait_stream(s2)
             hnb.record_stream(cur)
             hn = torch.cat((hna, hnb), dim=0)
@@ -526,7 +665,7 @@ class TransformerStackFn(torch.autograd.Function):
         if dhn.dtype not in (BF16, F32):
             dhn = dhn.to(F32)
         if ctx.micro == 1:
-            dx, grads, dtbl = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
+            dx, grads, dtbl, dctx = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
         else:
             sva, svb = ctx.saved
             h = sva['B']
@@ -537,12 +676,12 @@ class TransformerStackFn(torch.autograd.Function):
             s2.wait_stream(cur)
             # no weight-gradient side streams here: the other half already fills the idle CUs, and nested stream forks do not survive
             # hipStreamEndCapture on ROCm 7.0 (segmentation fault)
-            dxa, ga, ta = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
+            dxa, ga, ta, ca = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
             db.record_stream(s2)
             with torch.cuda.stream(s2):
-                dxb, gb, tb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
+                dxb, gb, tb, cb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
             cur.wait_stream(s2)
-            for t in [dxb, tb] + gb:
+            for t in [dxb, tb, cb] + gb:
                 if t is not None:
                     t.record_stream(cur)
             dx = torch.cat((dxa, dxb), dim=0)
@@ -552,9 +691,13 @@ class TransformerStackFn(torch.autograd.Function):
                 torch._foreach_add_(pa, pb)
             grads = [a if a is not None else b for a, b in zip(ga, gb)]
             dtbl = None if ta is None else ta + tb
+            dctx = None if ca is None else torch.cat((ca, cb), dim=0)
         ctx.saved = None
         dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478
         out = []
         for p, g in zip(ctx.flat, grads):
             out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
-        return (dx, None, None, None, None, None, dtbl, *out)
+        dcontext = None
+        if dctx is not None and ctx.ctx_meta is not None:
+            dcontext = dctx.reshape(ctx.ctx_meta[0]).to(ctx.ctx_meta[1])
+        return (dx, None, None, None, None, None, dtbl, dcontext, *out)

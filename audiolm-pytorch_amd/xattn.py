@@ -1,0 +1,81 @@
+"""Attention over a short, always-visible key set -- the conditioning paths of the reference's Attention.forward
+(audiolm_pytorch.py:307-406): cross-attention layers ([null_kv | to_kv(context_norm(text embeds))], non-causal, :372-388) and
+`cond_as_self_attn_prefix` (text embeds prepended to the causal self-attention keys, :330-345).
+
+The key set is tens to a few hundred positions and shared by all heads (MQA), so its scores are small dense matrices: the three contractions
+run on the bf16 MFMA GEMM (ops.gemm_nt / the TN split-K form), the row-wise softmax pieces are csrc/xattn.hip.  A causal self-attention part
+(flash kernels) is merged through its log-sum-exp; with the JOINT lse / output, both parts' backward formulas stay exact (see xattn.hip).
+
+Layouts: q / o / do bf16 [B*N, H*dh] (row (b n), column (h d)) == [B, N*H, dh]; ke / ve bf16 [B, Me, dh]; statistics fp32 [B, H, N].
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _transpose_pad(t, Mp):
+    """bf16 [B, Me, dh] -> [B, dh, Mp] (zero-filled pad columns): the K-contiguous operand of `P @ V` / `dS @ K`"""
+    B, Me, dh = t.shape
+    out = torch.empty((B, dh, Mp), dtype=BF16, device=t.device)
+    for b in range(B):
+        _lib.call('alm_transpose_bf16', t[b].data_ptr(), out[b].data_ptr(), Me, dh, t.stride(1), Mp, Mp, ops._st())
+    return out
+
+
+def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=None):
+    """-> (o bf16 [B*N, H*dh], lse_tot fp32 [B, H, N], saved) ; emask uint8 [B, Me] (1 = attend) | None."""
+    dev = q.device
+    Me = ke.shape[1]
+    Mp = _pad8(Me)
+    ke, ve = ke.contiguous(), ve.contiguous()
+    S = torch.empty((B, N * H, Mp), dtype=F32, device=dev)
+    ops.gemm_nt(q.view(B, N * H, dh), ke, S[:, :, :Me])
+    P = torch.empty((B * N * H, Mp), dtype=BF16, device=dev)
+    lse = torch.empty((B, H, N), dtype=F32, device=dev)
+    fself = torch.empty(B * N * H, dtype=F32, device=dev) if o_self is not None else None
+    _lib.call('alm_xattn_softmax_fwd', S.data_ptr(), Mp, ops._p(emask), ops._p(lse_self), float(scale), P.data_ptr(), Mp, lse.data_ptr(), ops._p(fself),
+              B, N, H, Me, ops._st())
+    veT = _transpose_pad(ve, Mp)
+    Oe = torch.empty((B, N * H, dh), dtype=F32, device=dev)
+    ops.gemm_nt(P.view(B, N * H, Mp), veT, Oe)
+    o = torch.empty((B * N, H * dh), dtype=BF16, device=dev)
+    _lib.call('alm_xattn_combine', ops._p(o_self), o_self.stride(0) if o_self is not None else 0, ops._p(fself), Oe.data_ptr(), o.data_ptr(), H * dh,
+              B * N, H, dh, ops._st())
+    return o, lse, dict(P=P, ke=ke, ve=ve, Me=Me, Mp=Mp)
+
+
+def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None):
+    """dout bf16 [B*N, H*dh]; ndelta fp32 [B, H, N] = -rowsum(dO o O_joint).  dq given (the flash backward's bf16 dQ of the self part): the
+    extra part is ACCUMULATED into it; else a new dq is returned.  -> (dq bf16, dke fp32 [B, Me, dh], dve fp32 [B, Me, dh])."""
+    dev = q.device
+    P, ke, ve, Me, Mp = saved['P'], saved['ke'], saved['ve'], saved['Me'], saved['Mp']
+    dP = torch.empty((B, N * H, Mp), dtype=F32, device=dev)
+    ops.gemm_nt(dout.view(B, N * H, dh), ve, dP[:, :, :Me])
+    dS = torch.empty((B * N * H, Mp), dtype=BF16, device=dev)
+    _lib.call('alm_xattn_softmax_bwd', P.data_ptr(), Mp, dP.data_ptr(), Mp, ndelta.data_ptr(), float(scale), dS.data_ptr(), Mp, Me, B, N, H, ops._st())
+    keT = _transpose_pad(ke, Mp)
+    acc = dq is not None
+    if dq is None:
+        dq = torch.empty((B * N, H * dh), dtype=BF16, device=dev)
+    ops.gemm_nt(dS.view(B, N * H, Mp), keT, dq.view(B, N * H, dh), accumulate=acc)
+    K = N * H
+    dke = torch.empty((B, Mp, dh), dtype=F32, device=dev)
+    dve = torch.empty((B, Mp, dh), dtype=F32, device=dev)
+    ops._splitk('alm_gemm_bf16_tn_splitk', dS.view(B, K, Mp), q.view(B, K, dh), dke, Mp, dh, K, B, K * Mp, K * dh, Mp * dh, 1.0, False)
+    ops._splitk('alm_gemm_bf16_tn_splitk', P.view(B, K, Mp), dout.view(B, K, dh), dve, Mp, dh, K, B, K * Mp, K * dh, Mp * dh, 1.0, False)
+    return dq, dke[:, :Me], dve[:, :Me]
+
+
+def attn_delta(o, dout, B, N, H, dh):
+    """ndelta fp32 [B, H, N] = -rowsum(dO o O) (pure cross-attention: no flash backward fills it)"""
+    nd = torch.empty((B, H, N), dtype=F32, device=o.device)
+    _lib.call('alm_xattn_delta', o.data_ptr(), o.stride(0), dout.data_ptr(), dout.stride(0), nd.data_ptr(), B, N, H, dh, ops._st())
+    return nd

@@ -131,6 +131,24 @@ int alm_posmlp_out_fwd(const void* act_bf16, const float* W, const float* b, con
                        float inv_scale, void* stream);
 int alm_posmlp_out_bwd(const float* dtbl, const float* W, const float* pre, void* g_bf16, void* dpre_bf16, float* dspecial, int L, int C, int H,
                        int Hp, float inv_scale, void* stream);
+/* ---- attention over a short, always-visible key set: the conditioning paths of Attention.forward (audiolm_pytorch.py:307-406) ----------------
+ * cross-attention layers (Transformer(cross_attend=True), :450: keys = [null_kv | to_kv(context_norm(text embeds))], non-causal, :372-388) and
+ * `cond_as_self_attn_prefix` (:330-345: the text embeds prepended to the causal self-attention keys).  The three small contractions
+ * S_e = Q K_e^T [B][N*H][Me], O_e = P_e V_e, and their gradients run on alm_gemm_bf16_*; these entries are the row-wise softmax pieces.
+ * Row r = (b*N + n)*H + h; statistics (lse, ndelta) use the flash kernels' [B][H][N] layout.
+ *   softmax_fwd: P = exp(S*scale - lse_tot) on unmasked keys (emask uint8 [B][Me], NULL = all), lse_tot = logaddexp(lse_self, lse_e)
+ *                (lse_self NULL: no causal self part), fself[r] = exp(lse_self - lse_tot): the weight of the self part's output.
+ *   combine:     O[(b n)][h*dh + d] = fself[r] * O_self + O_e[r][d]        (O_self / fself NULL: cross-attention)
+ *   softmax_bwd: dS = P o (dP + ndelta) * scale, ndelta[b][h][n] = -sum_d dO*O of the JOINT output (alm_xattn_delta, or the workspace
+ *                alm_mqa_attn_bwd filled when a self part exists). */
+int alm_xattn_softmax_fwd(const float* S, long long ldS, const unsigned char* emask, const float* lse_self, float scale, void* P_bf16, long long ldP,
+                          float* lse_tot, float* fself, int B, int N, int H, int Me, void* stream);
+int alm_xattn_combine(const void* o_self_bf16, long long ldos, const float* fself, const float* o_e, void* out_bf16, long long ldo, long long tokens,
+                      int H, int dim_head, void* stream);
+int alm_xattn_softmax_bwd(const void* P_bf16, long long ldP, const float* dP, long long lddP, const float* ndelta, float scale, void* dS_bf16,
+                          long long lddS, int Me, int B, int N, int H, void* stream);
+int alm_xattn_delta(const void* o_bf16, long long ldo, const void* dout_bf16, long long lddo, float* ndelta, int B, int N, int H, int dim_head,
+                    void* stream);
 /* value residual, audiolm_pytorch.py:353-358 / :534-535 */
 int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long long ldv0, void* out, long long ldo, long long rows,
                            int dim_head, void* stream);

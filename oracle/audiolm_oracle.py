@@ -107,19 +107,40 @@ def feedforward(sd, p, x):                       # audiolm_pytorch.py:246-260
     return F.linear(x, sd[p + '5.weight'])
 
 
-def attention(sd, p, x, heads, mask=None, attn_bias=None, value_residual=None):
-    """Self-attention branch, audiolm_pytorch.py:307-406 (training path: no context / kv-cache /
-    null-kv / prefix).  Returns (out, orig_v)."""
-    kv_input = x                                  # :325  -- bound BEFORE the pre-norm (reference quirk)
+def attention(sd, p, x, heads, mask=None, attn_bias=None, value_residual=None, context=None, prefix_context=None,
+              prefix_context_mask=None, causal=True):
+    """Attention.forward, audiolm_pytorch.py:307-406 (no kv-cache).  Self-attention: context None.  Cross-attention (:450: dim_context,
+    num_null_kv=1, norm_context=True, causal=False): `context` (b m dc), `mask` = context mask.  cond_as_self_attn_prefix: `prefix_context`
+    (b m d) is prepended to the self-attention key / value inputs (:330-345).  Returns (out, orig_v)."""
+    b, n, _ = x.shape
+    if context is not None and (p + 'context_norm.gamma') in sd:
+        context = layer_norm(context, sd[p + 'context_norm.gamma'])      # :322-323
+    kv_input = x if context is None else context                          # :325  -- bound BEFORE the pre-norm (reference quirk)
+    if prefix_context is not None:                                        # :330-345
+        kv_input = torch.cat((prefix_context, kv_input), dim=-2)
+        m = prefix_context.shape[-2]
+        if mask is None:
+            mask = torch.ones((b, n), device=x.device, dtype=torch.bool)
+        if prefix_context_mask is not None:
+            mask = torch.cat((prefix_context_mask, mask), dim=-1)
+        else:
+            mask = F.pad(mask, (m, 0), value=True)
+        if attn_bias is not None:
+            attn_bias = F.pad(attn_bias, (m, 0), value=0.)
     xn = layer_norm(x, sd[p + 'norm.gamma'])      # :347
     q = F.linear(xn, sd[p + 'to_q.weight'])       # :351
     k, v = F.linear(kv_input, sd[p + 'to_kv.weight']).chunk(2, dim=-1)
     orig_v = v
     if value_residual is not None:                # :357-358
         v = 0.5 * (v + value_residual)
-    b, n, _ = q.shape
+    if (p + 'null_kv') in sd:                     # :372-376 (after the value residual: the null value is never mixed)
+        nk, nv = sd[p + 'null_kv'][0], sd[p + 'null_kv'][1]
+        k = torch.cat((nk.expand(b, -1, -1), k), dim=-2)
+        v = torch.cat((nv.expand(b, -1, -1), v), dim=-2)
+        if mask is not None:                      # :384-385
+            mask = F.pad(mask, (nk.shape[0], 0), value=True)
     q = q.reshape(b, n, heads, -1).transpose(1, 2)            # 'b n (h d) -> b h n d'
-    out = attend(q, k, v, mask=mask, attn_bias=attn_bias, causal=True)
+    out = attend(q, k, v, mask=mask, attn_bias=attn_bias, causal=causal)
     out = out.transpose(1, 2).reshape(b, n, -1)               # 'b h n d -> b n (h d)'
     return F.linear(out, sd[p + 'to_out.0.weight']), orig_v
 
@@ -164,36 +185,62 @@ def rel_pos_bias(sd, p, i, j):                    # audiolm_pytorch.py:202-242
 
 
 def transformer(sd, p, x, *, depth, heads, streams=4, self_attn_mask=None, attn_bias=None,
-                grad_shrink_alpha=0.1, add_value_residual=True):
-    """audiolm_pytorch.py:461-560 (training path).  `p` is e.g. 'transformer.'."""
+                grad_shrink_alpha=0.1, add_value_residual=True, context=None, context_mask=None, cond_as_self_attn_prefix=False):
+    """audiolm_pytorch.py:461-560 (no kv-cache).  `p` is e.g. 'transformer.'.  A conditioning `context` goes to the cross-attention layers
+    (present in `sd` as layers.{l}.1.*) or, with cond_as_self_attn_prefix, in front of the self-attention keys."""
     n = x.shape[1]
     x = x * grad_shrink_alpha + x.detach() * (1 - grad_shrink_alpha)     # :93-94, :478
     if attn_bias is None and (p + 'rel_pos_bias.net.0.0.weight') in sd:  # :500-503
         attn_bias = rel_pos_bias(sd, p + 'rel_pos_bias.', n, n)
-    value_residual = None
+    self_kw = dict(prefix_context=context, prefix_context_mask=context_mask) if cond_as_self_attn_prefix else {}     # :510-515
+    value_residual = cross_value_residual = None
     if streams > 1:
         x = x.repeat_interleave(streams, dim=0)                            # :524  'b ... -> (b s) ...'
-    for l in range(depth):
-        pa, pf = f'{p}layers.{l}.0.', f'{p}layers.{l}.2.'
+
+    def branch(pp, fn):
+        nonlocal x
         if streams > 1:
-            bi, Rp, beta = hc_width(sd, pa, x, streams)
-            out, values = attention(sd, pa + 'branch.', bi, heads, mask=self_attn_mask, attn_bias=attn_bias,
-                                    value_residual=value_residual)
+            bi, Rp, beta = hc_width(sd, pp, x, streams)
+            out = fn(bi)
+            out, extra = out if isinstance(out, tuple) else (out, None)
             x = hc_depth(out, Rp, beta)
         else:
-            out, values = attention(sd, pa + 'branch.', x, heads, mask=self_attn_mask, attn_bias=attn_bias,
-                                    value_residual=value_residual)
+            out = fn(x)
+            out, extra = out if isinstance(out, tuple) else (out, None)
             x = out + x
+        return extra
+
+    for l in range(depth):
+        pa, pc, pf = f'{p}layers.{l}.0.', f'{p}layers.{l}.1.', f'{p}layers.{l}.2.'
+        values = branch(pa, lambda t: attention(sd, pa + 'branch.', t, heads, mask=self_attn_mask, attn_bias=attn_bias,
+                                                value_residual=value_residual, **self_kw))
         if add_value_residual and value_residual is None:                  # :534-535
             value_residual = values
-        if streams > 1:
-            bi, Rp, beta = hc_width(sd, pf, x, streams)
-            x = hc_depth(feedforward(sd, pf + 'branch.', bi), Rp, beta)
-        else:
-            x = feedforward(sd, pf + 'branch.', x) + x
+        if (pc + 'branch.to_q.weight') in sd:                              # :539-544 cross attention
+            assert context is not None
+            cvalues = branch(pc, lambda t: attention(sd, pc + 'branch.', t, heads, mask=context_mask, context=context,
+                                                     value_residual=cross_value_residual, causal=False))
+            if add_value_residual and cross_value_residual is None:
+                cross_value_residual = cvalues
+        branch(pf, lambda t: feedforward(sd, pf + 'branch.', t))
     if streams > 1:
         x = x.reshape(x.shape[0] // streams, streams, *x.shape[1:]).sum(dim=1)   # :551
     return layer_norm(x, sd[p + 'norm.gamma'])                             # :555
+
+
+def condition(sd, cfg, b, text_embeds, cond_drop_keep=None, mask_from_embeds=True):
+    """audiolm_pytorch.py:685-704 / :873-892 / :1150-1169 with pre-computed text embeddings: -> (context, context_mask).  `cond_drop_keep`:
+    bool (b,) = the `prob_mask_like((b,), 1 - cond_drop_prob)` draw (None: cond_drop_prob == 0).  Semantic- and FineTransformer derive the text
+    mask only when they ran the text encoder themselves (:692-695, :1156-1160): with pre-computed embeddings they have NO mask, so nothing is
+    padded out and the condition is never dropped (mask_from_embeds=False); CoarseTransformer takes it from the embeddings (:882-883)."""
+    if text_embeds is None:
+        return None, None
+    text_mask = torch.any(text_embeds != 0, dim=-1) if mask_from_embeds else None
+    if 'proj_text_embed.weight' in sd:
+        text_embeds = F.linear(text_embeds, sd['proj_text_embed.weight'])
+    if text_mask is not None and cond_drop_keep is not None:
+        text_mask = cond_drop_keep[:, None] & text_mask
+    return text_embeds, text_mask
 
 
 # ----------------------------------------------------------------------------------------------
@@ -213,22 +260,25 @@ class Cfg:
     grad_shrink_alpha: float = 0.1
     add_value_residual: bool = True
     pad_id: int = -1
+    cond_as_self_attn_prefix: bool = False
 
 
 # ----------------------------------------------------------------------------------------------
 # A8 SemanticTransformer.forward  (audiolm_pytorch.py:671-724)
 # ----------------------------------------------------------------------------------------------
 
-def semantic_forward(sd, cfg: Cfg, ids, self_attn_mask=None):
+def semantic_forward(sd, cfg: Cfg, ids, self_attn_mask=None, text_embeds=None, cond_drop_keep=None):
     tokens = get_embeds(sd['semantic_embedding.weight'], ids)                    # :709
     b = ids.shape[0]
     start = sd['start_token'].expand(b, 1, -1)                                  # :711
     tokens = torch.cat((start, tokens), dim=1)
     if self_attn_mask is not None:
         self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)              # :716
+    context, context_mask = condition(sd, cfg, b, text_embeds, cond_drop_keep, mask_from_embeds=False)
     tokens = transformer(sd, 'transformer.', tokens, depth=cfg.depth, heads=cfg.heads, streams=cfg.streams,
                          self_attn_mask=self_attn_mask, grad_shrink_alpha=cfg.grad_shrink_alpha,
-                         add_value_residual=cfg.add_value_residual)
+                         add_value_residual=cfg.add_value_residual, context=context, context_mask=context_mask,
+                         cond_as_self_attn_prefix=cfg.cond_as_self_attn_prefix)
     return F.linear(tokens, sd['to_logits.weight'], sd['to_logits.bias'])        # :719
 
 
@@ -249,8 +299,9 @@ def _grouped_logits(weights, pred, Q):
     return lg
 
 
-def coarse_forward(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, self_attn_mask=None):
+def coarse_forward(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text_embeds=None, cond_drop_keep=None):
     b = semantic_token_ids.shape[0]
+    context, context_mask = condition(sd, cfg, b, text_embeds, cond_drop_keep)
     dev = semantic_token_ids.device
     Q, C = cfg.num_coarse_quantizers, cfg.codebook_size
     coarse_token_ids = coarse_token_ids.reshape(b, -1)
@@ -274,7 +325,8 @@ def coarse_forward(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, self_attn
         attn_bias = torch.where(is_cross, sd['cross_attn_bias'], attn_bias)
     tokens = transformer(sd, 'transformer.', tokens, depth=cfg.depth, heads=cfg.heads, streams=cfg.streams,
                          self_attn_mask=self_attn_mask, attn_bias=attn_bias,
-                         grad_shrink_alpha=cfg.grad_shrink_alpha, add_value_residual=cfg.add_value_residual)
+                         grad_shrink_alpha=cfg.grad_shrink_alpha, add_value_residual=cfg.add_value_residual,
+                         context=context, context_mask=context_mask, cond_as_self_attn_prefix=cfg.cond_as_self_attn_prefix)
     pred_sem, pred_coarse = tokens[:, :semantic_seq_len], tokens[:, semantic_seq_len + 1:]   # :957
     semantic_logits = None
     if 'to_semantic_logits.weight' in sd:                                        # :961
@@ -319,8 +371,9 @@ def fine_attn_bias(sd, cfg: Cfg, coarse_length, fine_length, dev):
     return torch.where(start_mask, sd['null_pos_bias'], bias)
 
 
-def fine_forward(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, self_attn_mask=None):
+def fine_forward(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, self_attn_mask=None, text_embeds=None, cond_drop_keep=None):
     b = coarse_token_ids.shape[0]
+    context, context_mask = condition(sd, cfg, b, text_embeds, cond_drop_keep, mask_from_embeds=False)       # :1155-1169: like Semantic, no mask from pre-computed embeds
     dev = coarse_token_ids.device
     Qc, Qf, C = cfg.num_coarse_quantizers, cfg.num_fine_quantizers, cfg.codebook_size
     eos_id = C                                                                    # :1040
@@ -347,7 +400,8 @@ def fine_forward(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, self_attn_mask=
         attn_bias = fine_attn_bias(sd, cfg, n, nf, dev)
     tokens = transformer(sd, 'transformer.', tokens, depth=cfg.depth, heads=cfg.heads, streams=cfg.streams,
                          self_attn_mask=self_attn_mask, attn_bias=attn_bias,
-                         grad_shrink_alpha=cfg.grad_shrink_alpha, add_value_residual=cfg.add_value_residual)
+                         grad_shrink_alpha=cfg.grad_shrink_alpha, add_value_residual=cfg.add_value_residual,
+                         context=context, context_mask=context_mask, cond_as_self_attn_prefix=cfg.cond_as_self_attn_prefix)
     pred_coarse, pred_fine = tokens[:, :n], tokens[:, n + 1:]                    # :1319
     coarse_logits = None
     if 'coarse_logit_weights' in sd:                                             # :1325-1339 (zero-pad then slice)
@@ -376,11 +430,11 @@ def semantic_wrapper_bookkeeping(semantic_token_ids, eos_id, *, training=True, u
 
 
 def semantic_wrapper_loss(sd, cfg: Cfg, semantic_token_ids, *, training=True, unique_consecutive=True,
-                          forgetful_mask=None):
+                          forgetful_mask=None, text_embeds=None, cond_drop_keep=None):
     """audiolm_pytorch.py:1513-1567 with return_loss=True."""
     input_ids, labels = semantic_wrapper_bookkeeping(semantic_token_ids, cfg.num_semantic_tokens, training=training,
                                                      unique_consecutive=unique_consecutive, pad_id=cfg.pad_id)
-    logits = semantic_forward(sd, cfg, input_ids, self_attn_mask=forgetful_mask)
+    logits = semantic_forward(sd, cfg, input_ids, self_attn_mask=forgetful_mask, text_embeds=text_embeds, cond_drop_keep=cond_drop_keep)
     return F.cross_entropy(logits.transpose(1, 2), labels, ignore_index=cfg.pad_id)
 
 
@@ -404,14 +458,14 @@ def coarse_wrapper_bookkeeping(semantic_token_ids, coarse_token_ids, semantic_eo
 
 
 def coarse_wrapper_loss(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, *, training=True, unique_consecutive=True,
-                        forgetful_mask=None, semantic_ce_weight=1.):
+                        forgetful_mask=None, semantic_ce_weight=1., text_embeds=None, cond_drop_keep=None):
     """audiolm_pytorch.py:1742-1854 with return_loss=True (ids supplied, no codec/wav2vec)."""
     sem_in, coarse_in, sem_labels, coarse_labels, mask = coarse_wrapper_bookkeeping(
         semantic_token_ids, coarse_token_ids, cfg.num_semantic_tokens, cfg.codebook_size,
         training=training, unique_consecutive=unique_consecutive, pad_id=cfg.pad_id)
     if forgetful_mask is not None:
         mask = mask & forgetful_mask                                             # :1809-1810
-    sem_logits, coarse_logits = coarse_forward(sd, cfg, sem_in, coarse_in, self_attn_mask=mask)
+    sem_logits, coarse_logits = coarse_forward(sd, cfg, sem_in, coarse_in, self_attn_mask=mask, text_embeds=text_embeds, cond_drop_keep=cond_drop_keep)
     if unique_consecutive:                                                       # :1828-1831
         num_coarse, num_sem = coarse_labels.numel(), (sem_labels != cfg.pad_id).sum()
     else:
@@ -424,7 +478,8 @@ def coarse_wrapper_loss(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, *, t
     return (sem_loss * n_sem * semantic_ce_weight + coarse_loss * num_coarse) / (n_sem + num_coarse)
 
 
-def fine_wrapper_loss(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, *, forgetful_mask=None, coarse_ce_weight=1.):
+def fine_wrapper_loss(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, *, forgetful_mask=None, coarse_ce_weight=1., text_embeds=None,
+                      cond_drop_keep=None):
     """audiolm_pytorch.py:2041-2137 with return_loss=True (ids supplied)."""
     b = coarse_token_ids.shape[0]
     coarse = coarse_token_ids.reshape(b, -1)
@@ -432,7 +487,7 @@ def fine_wrapper_loss(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, *, forgetf
     coarse_labels, fine_labels = coarse, fine
     fine_in = fine[:, :-1]
     mask = None if forgetful_mask is None else forgetful_mask.clone()            # (b, nc + nf_in + 2)  :2090-2096
-    coarse_logits, fine_logits = fine_forward(sd, cfg, coarse, fine_in, self_attn_mask=mask)
+    coarse_logits, fine_logits = fine_forward(sd, cfg, coarse, fine_in, self_attn_mask=mask, text_embeds=text_embeds, cond_drop_keep=cond_drop_keep)
     n_fine = fine_logits.shape[1]
     n_coarse, coarse_loss = 0, 0.
     if coarse_ce_weight > 0 and coarse_logits is not None:

@@ -32,8 +32,10 @@ def run(fx, autocast):
         nq = ctor['num_coarse_quantizers'] + ctor['num_fine_quantizers']
         w = A.FineTransformerWrapper(transformer=model, codec=MG._Codec(nq), mask_prob=opt['mask_prob'])
         kw = dict(coarse_token_ids=inp['coarse_token_ids'], fine_token_ids=inp['fine_token_ids'])
+    if inp.get('text_embeds') is not None:
+        kw['text_embeds'] = inp['text_embeds']
     with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
-        loss, logits, grads = MG._run(model, w, kw, opt.get('training', True), inp.get('forgetful_mask'))
+        loss, logits, grads = MG._run(model, w, kw, opt.get('training', True), inp.get('forgetful_mask'), inp.get('cond_keep'))
     lg = logits if isinstance(logits, (tuple, list)) else (logits,)
     return float(loss), {k: (g.float().clone() if g is not None else None) for k, g in grads.items()}, [t.detach().float().clone() for t in lg if t is not None]
 
@@ -41,7 +43,8 @@ def run(fx, autocast):
 def main():
     out = {}
     for name in ('semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_flash_mask', 'fine_s4_flash',
-                 'coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask'):
+                 'coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask',
+                 'coarse_s4_cond_cross', 'coarse_s1_cond_cross_drop_bias', 'semantic_s4_cond_prefix_bias', 'fine_s4_cond_prefix_flash_drop', 'fine_s1_cond_cross'):
         fx = torch.load(os.path.join(HERE, name + '.pt'), weights_only=False)
         l32, g32, lg32 = run(fx, False)
         l16, g16, lg16 = run(fx, True)

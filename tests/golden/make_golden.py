@@ -50,12 +50,21 @@ def _forgetful(shape, prob, seed):
     return ~torch.zeros(shape).scatter(1, idx, 1.).bool()
 
 
-def _run(model, wrapper, wrapper_kwargs, training, mask):
-    """forward(return_loss=True) + backward on the real reference.  `mask` replaces the RNG draw."""
+def _run(model, wrapper, wrapper_kwargs, training, mask, cond_keep=None):
+    """forward(return_loss=True) + backward on the real reference.  `mask` replaces the RNG draw of the forgetful mask, `cond_keep` (bool (b,))
+    the `prob_mask_like` draw of the per-sample condition dropping (audiolm_pytorch.py:703 / :890 / :1167)."""
     wrapper.train(training)
     model.zero_grad(set_to_none=True)
     orig = A.generate_mask_with_prob
+    orig_pml = A.prob_mask_like
     seen = {}
+
+    def fake_pml(shape, prob, device):
+        assert cond_keep is not None and tuple(shape) == tuple(cond_keep.shape), (shape, cond_keep)
+        seen['cond_prob'] = prob
+        return cond_keep.clone()
+    if cond_keep is not None:
+        A.prob_mask_like = fake_pml
 
     def fake(shape, prob, device):
         seen['shape'] = tuple(shape)
@@ -68,6 +77,7 @@ def _run(model, wrapper, wrapper_kwargs, training, mask):
         loss = wrapper(**wrapper_kwargs, return_loss=True)
     finally:
         A.generate_mask_with_prob = orig
+        A.prob_mask_like = orig_pml
         hook.remove()
     logits = seen['logits']
     loss.backward()
@@ -75,7 +85,22 @@ def _run(model, wrapper, wrapper_kwargs, training, mask):
     return loss.detach(), logits, grads
 
 
-def semantic_case(name, *, ctor, ids, training=True, unique_consecutive=True, mask_prob=0., seed=1, full=True):
+def _cond_inputs(cond, b, seed):
+    """cond = dict(dim, m, drop (bool: inject a keep mask), zero_rows (padding positions))"""
+    if cond is None:
+        return {}, None, {}
+    g = torch.Generator().manual_seed(seed + 500)
+    te = torch.randn(b, cond['m'], cond['dim'], generator=g)
+    for (bi, mi) in cond.get('zero_rows', ()):
+        te[bi, mi] = 0.                                    # all-zero embedding = padding position (text_mask, :883)
+    keep = None
+    if cond.get('drop'):
+        keep = torch.rand(b, generator=g) < 0.5
+        keep[0], keep[-1] = True, False                    # both branches present
+    return dict(text_embeds=te), keep, dict(text_embeds=te, cond_keep=keep)
+
+
+def semantic_case(name, *, ctor, ids, training=True, unique_consecutive=True, mask_prob=0., seed=1, full=True, cond=None):
     torch.manual_seed(0)
     model = A.SemanticTransformer(**ctor)
     shapes = _shapes(model.state_dict())
@@ -86,15 +111,16 @@ def semantic_case(name, *, ctor, ids, training=True, unique_consecutive=True, ma
         import audiolm_oracle as O
         inp, _ = O.semantic_wrapper_bookkeeping(ids, model.eos_id, training=training, unique_consecutive=unique_consecutive)
         mask = _forgetful(tuple(inp.shape), mask_prob, seed + 100)
-    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=ids), training, mask)
+    ckw, keep, cin = _cond_inputs(cond, ids.shape[0], seed)
+    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=ids, **ckw), training, mask, keep)
     return dict(name=name, kind='semantic', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
                 options=dict(training=training, unique_consecutive=unique_consecutive, mask_prob=mask_prob),
-                inputs=dict(ids=ids, forgetful_mask=mask),
+                inputs=dict(ids=ids, forgetful_mask=mask, **cin),
                 outputs=dict(loss=loss, logits=logits.detach() if full else logits.detach()[:, ::16].clone(),
                              grads=grad_digest(grads, full)))
 
 
-def coarse_case(name, *, ctor, sem, coarse, training=True, unique_consecutive=True, mask_prob=0., seed=2, full=True):
+def coarse_case(name, *, ctor, sem, coarse, training=True, unique_consecutive=True, mask_prob=0., seed=2, full=True, cond=None, cfg_scale=None):
     torch.manual_seed(0)
     model = A.CoarseTransformer(**ctor)
     shapes = _shapes(model.state_dict())
@@ -106,15 +132,22 @@ def coarse_case(name, *, ctor, sem, coarse, training=True, unique_consecutive=Tr
         *_, km = O.coarse_wrapper_bookkeeping(sem, coarse, model.semantic_eos_id, model.coarse_eos_id, training=training,
                                               unique_consecutive=unique_consecutive)
         mask = _forgetful(tuple(km.shape), mask_prob, seed + 100)
-    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=sem, coarse_token_ids=coarse), training, mask)
+    ckw, keep, cin = _cond_inputs(cond, sem.shape[0], seed)
+    loss, logits, grads = _run(model, wrapper, dict(semantic_token_ids=sem, coarse_token_ids=coarse, **ckw), training, mask, keep)
     sl, cl = logits
+    out = dict(loss=loss, semantic_logits=sl.detach(), coarse_logits=cl.detach(), grads=grad_digest(grads, full))
+    if cfg_scale is not None:                                # classifier-free guidance, eval mode (audiolm_pytorch.py:818-855)
+        model.eval()
+        with torch.no_grad():
+            gs, gc = model.forward_with_cond_scale(semantic_token_ids=sem, coarse_token_ids=coarse.reshape(coarse.shape[0], -1), cond_scale=cfg_scale, **ckw)
+        out.update(cfg_scale=cfg_scale, cfg_semantic_logits=gs, cfg_coarse_logits=gc)
     return dict(name=name, kind='coarse', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
                 options=dict(training=training, unique_consecutive=unique_consecutive, mask_prob=mask_prob),
-                inputs=dict(semantic_token_ids=sem, coarse_token_ids=coarse, forgetful_mask=mask),
-                outputs=dict(loss=loss, semantic_logits=sl.detach(), coarse_logits=cl.detach(), grads=grad_digest(grads, full)))
+                inputs=dict(semantic_token_ids=sem, coarse_token_ids=coarse, forgetful_mask=mask, **cin),
+                outputs=out)
 
 
-def fine_case(name, *, ctor, coarse, fine, training=True, mask_prob=0., seed=3, full=True):
+def fine_case(name, *, ctor, coarse, fine, training=True, mask_prob=0., seed=3, full=True, cond=None):
     torch.manual_seed(0)
     model = A.FineTransformer(**ctor)
     shapes = _shapes(model.state_dict())
@@ -125,11 +158,12 @@ def fine_case(name, *, ctor, coarse, fine, training=True, mask_prob=0., seed=3, 
     if mask_prob > 0 and training:
         b = coarse.shape[0]
         mask = _forgetful((b, coarse.reshape(b, -1).shape[1] + fine.reshape(b, -1).shape[1] - 1 + 2), mask_prob, seed + 100)
-    loss, logits, grads = _run(model, wrapper, dict(coarse_token_ids=coarse, fine_token_ids=fine), training, mask)
+    ckw, keep, cin = _cond_inputs(cond, coarse.shape[0], seed)
+    loss, logits, grads = _run(model, wrapper, dict(coarse_token_ids=coarse, fine_token_ids=fine, **ckw), training, mask, keep)
     cl, fl = logits
     return dict(name=name, kind='fine', ctor=ctor, shapes=shapes, seed=seed, restated=ctor.get('num_residual_streams', 4) > 1,
                 options=dict(training=training, mask_prob=mask_prob),
-                inputs=dict(coarse_token_ids=coarse, fine_token_ids=fine, forgetful_mask=mask),
+                inputs=dict(coarse_token_ids=coarse, fine_token_ids=fine, forgetful_mask=mask, **cin),
                 outputs=dict(loss=loss, coarse_logits=cl.detach(), fine_logits=fl.detach(), grads=grad_digest(grads, full)))
 
 
@@ -243,6 +277,30 @@ def signatures_case():
     print('signatures.json:', len(table), 'callables')
 
 
+def cond_cases(R):
+    """text / audio conditioning from pre-computed embeddings (has_condition=True): cross-attention layers with a null key / value and value
+    residual (:450, :539-544), per-sample condition dropping (:888-892), classifier-free guidance (:818-855), cond_as_self_attn_prefix
+    (:330-345, :510-515).  cond_dim 24 / 40 -> proj_text_embed is a Linear(cond_dim, 64)."""
+    cc = dict(dim=64, depth=2, num_semantic_tokens=6, codebook_size=16, num_coarse_quantizers=3)
+    fc = dict(dim=64, depth=2, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5)
+    cases = []
+    cases.append(coarse_case('coarse_s4_cond_cross', ctor=dict(cc, flash_attn=True, has_condition=True, cond_dim=24, cond_drop_prob=0.),
+                             sem=R(6, (3, 9), 21), coarse=R(16, (3, 5, 3), 22), unique_consecutive=False, mask_prob=0.15, seed=21,
+                             cond=dict(dim=24, m=5, zero_rows=((1, 4), (2, 3), (2, 4))), cfg_scale=3.))
+    cases.append(coarse_case('coarse_s1_cond_cross_drop_bias', ctor=dict(cc, num_residual_streams=1, has_condition=True, cond_dim=24),
+                             sem=R(6, (4, 8), 23), coarse=R(16, (4, 4, 3), 24), unique_consecutive=False, mask_prob=0., seed=23,
+                             cond=dict(dim=24, m=6, drop=True, zero_rows=((0, 5),))))
+    cases.append(semantic_case('semantic_s4_cond_prefix_bias', ctor=dict(dim=64, depth=2, num_semantic_tokens=20, has_condition=True, cond_dim=40,
+                                                                         cond_as_self_attn_prefix=True, cond_drop_prob=0.),
+                               ids=R(20, (3, 15), 25), unique_consecutive=False, mask_prob=0.15, seed=25, cond=dict(dim=40, m=4)))
+    cases.append(fine_case('fine_s4_cond_prefix_flash_drop', ctor=dict(fc, flash_attn=True, has_condition=True, cond_dim=40, cond_as_self_attn_prefix=True),
+                           coarse=R(16, (3, 4, 3), 26), fine=R(16, (3, 4, 5), 27), mask_prob=0.15, seed=26,
+                           cond=dict(dim=40, m=5, drop=True, zero_rows=((0, 4), (1, 3)))))
+    cases.append(fine_case('fine_s1_cond_cross', ctor=dict(fc, num_residual_streams=1, flash_attn=True, has_condition=True, cond_dim=24, cond_drop_prob=0.),
+                           coarse=R(16, (2, 5, 3), 28), fine=R(16, (2, 5, 5), 29), seed=28, cond=dict(dim=24, m=3)))
+    return cases
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'signatures':
         signatures_case()
@@ -254,6 +312,13 @@ def main():
         return
     R = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
     cases = []
+    if len(sys.argv) > 1 and sys.argv[1] == 'cond':                    # the conditioning fixtures only (added in round 2)
+        cases = cond_cases(R)
+        for c in cases:
+            path = os.path.join(HERE, c['name'] + '.pt')
+            torch.save(c, path)
+            print(f'{c["name"]:28s} {os.path.getsize(path) / 1024:8.1f} KiB', 'loss=%s' % float(c['outputs']['loss']))
+        return
 
     # BASELINE.json configs[0]: SemanticTransformer dim=256 depth=2 seq=256 on CPU
     cases.append(semantic_case('semantic_cfg0', ctor=dict(dim=256, depth=2, num_semantic_tokens=500),

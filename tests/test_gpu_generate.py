@@ -251,3 +251,34 @@ def test_audiolm_end_to_end_hierarchical_sampling():
     for w in waves:
         assert w is None or (w.dim() == 1 and w.numel() % 320 == 0 and bool(torch.isfinite(w).all()))
     assert lm.training is False or True
+
+
+@pytest.mark.parametrize('kind', ['semantic', 'coarse'])
+def test_guided_generation_cached_equals_recomputed(kind):
+    """generate() of a CONDITIONED model with classifier-free guidance (cond_scale 3): the kv-cache path (two caches: conditioned /
+    unconditioned, cross-attention recomputed per step) must pick the same tokens as the recompute path (forward_with_cond_scale on the whole
+    prefix) under greedy sampling (filter_thres ~ 1 -> top-1)."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    te = torch.randn(2, 6, 32, generator=g).to(dev)
+    te[1, 4:] = 0.                                                # padded text positions
+    if kind == 'semantic':
+        model = A.SemanticTransformer(dim=128, depth=2, num_semantic_tokens=30, has_condition=True, cond_dim=32, flash_attn=True).to(dev)
+        w = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=False)
+        kw = dict(max_length=12, prime_ids=torch.randint(0, 30, (2, 3), generator=g).to(dev), text_embeds=te, cond_scale=3., filter_thres=0.999, temperature=1e-4)
+    else:
+        model = A.CoarseTransformer(dim=128, depth=2, num_semantic_tokens=30, codebook_size=40, num_coarse_quantizers=3, has_condition=True, cond_dim=32).to(dev)
+
+        class Codec:
+            rq_groups = 1
+            num_quantizers = 8
+        w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False)
+        kw = dict(semantic_token_ids=torch.randint(0, 30, (2, 7), generator=g).to(dev), text_embeds=te, max_time_steps=4, cond_scale=3., filter_thres=0.999,
+                  temperature=1e-4)
+    a = w.generate(use_kv_cache=True, **kw)
+    b = w.generate(use_kv_cache=False, **kw)
+    assert a.shape == b.shape and a.dtype == torch.long
+    same = float((a == b).float().mean())
+    assert same >= 0.9, (a, b)                                    # greedy picks may differ at a bf16 near-tie, never systematically

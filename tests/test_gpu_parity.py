@@ -59,6 +59,11 @@ def ours_run(fx, want_logits=True, state=None, residual_dtype=None):
     mask = inp.get('forgetful_mask')
     orig = AP.generate_mask_with_prob
     AP.generate_mask_with_prob = lambda shape, prob, device: mask.to(device).clone()
+    te, keep = inp.get('text_embeds'), inp.get('cond_keep')          # conditioning fixtures: pre-computed text embeds, injected condition-drop draw
+    ckw = {} if te is None else dict(text_embeds=te.to(dev))
+    orig_pml = AP.prob_mask_like
+    if keep is not None:
+        AP.prob_mask_like = lambda shape, prob, device: keep.to(device).clone()
     try:
         if kind == 'semantic':
             w = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=opt['unique_consecutive'], mask_prob=opt['mask_prob'])
@@ -71,7 +76,7 @@ def ours_run(fx, want_logits=True, state=None, residual_dtype=None):
             w = A.FineTransformerWrapper(transformer=model, codec=Codec(nq), mask_prob=opt['mask_prob'])
             kw = dict(coarse_token_ids=inp['coarse_token_ids'].to(dev), fine_token_ids=inp['fine_token_ids'].to(dev))
         w.train(opt.get('training', True))
-        loss = w(**kw, return_loss=True)
+        loss = w(**kw, **ckw, return_loss=True)
         loss.backward()
         logits = None
         if want_logits:                       # logits for exactly the ids / mask the loss path saw (bookkeeping from the oracle helpers)
@@ -80,19 +85,20 @@ def ours_run(fx, want_logits=True, state=None, residual_dtype=None):
                 if kind == 'semantic':
                     ids_in, _ = O.semantic_wrapper_bookkeeping(inp['ids'], model.eos_id, training=opt['training'],
                                                                unique_consecutive=opt['unique_consecutive'])
-                    logits = model(ids=ids_in.to(dev), self_attn_mask=fm)
+                    logits = model(ids=ids_in.to(dev), self_attn_mask=fm, **ckw)
                 elif kind == 'coarse':
                     s_in, c_in, _, _, km = O.coarse_wrapper_bookkeeping(inp['semantic_token_ids'], inp['coarse_token_ids'], model.semantic_eos_id,
                                                                          model.coarse_eos_id, training=opt['training'],
                                                                          unique_consecutive=opt['unique_consecutive'])
                     km = km.to(dev) if fm is None else (km.to(dev) & fm)
-                    logits = model(semantic_token_ids=s_in.to(dev), coarse_token_ids=c_in.to(dev), self_attn_mask=km)
+                    logits = model(semantic_token_ids=s_in.to(dev), coarse_token_ids=c_in.to(dev), self_attn_mask=km, **ckw)
                 else:
                     b = inp['coarse_token_ids'].shape[0]
                     logits = model(inp['coarse_token_ids'].reshape(b, -1).to(dev), inp['fine_token_ids'].reshape(b, -1)[:, :-1].to(dev),
-                                   self_attn_mask=None if fm is None else fm.clone())
+                                   self_attn_mask=None if fm is None else fm.clone(), **ckw)
     finally:
         AP.generate_mask_with_prob = orig
+        AP.prob_mask_like = orig_pml
     grads = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     return float(loss), logits, grads
 
@@ -134,10 +140,13 @@ FLASH_FIXTURES = ['semantic_s4_flash', 'coarse_s1_flash_uc_mask', 'coarse_s4_fla
 BIAS_FIXTURES = ['coarse_s4_bias', 'coarse_s1_bias_eval', 'fine_s1_bias_mask']
 
 
-S4_FIXTURES = ['semantic_s4_flash', 'coarse_s4_flash_mask', 'fine_s4_flash', 'coarse_s4_bias']       # 4 residual streams: bf16 stream storage applies
+# text / audio conditioning from pre-computed embeddings (has_condition=True): cross-attention + null kv, condition dropping, prefix conditioning
+COND_FIXTURES = ['coarse_s4_cond_cross', 'coarse_s1_cond_cross_drop_bias', 'semantic_s4_cond_prefix_bias', 'fine_s4_cond_prefix_flash_drop', 'fine_s1_cond_cross']
+S4_FIXTURES = ['semantic_s4_flash', 'coarse_s4_flash_mask', 'fine_s4_flash', 'coarse_s4_bias', 'coarse_s4_cond_cross',
+               'semantic_s4_cond_prefix_bias']                                                    # 4 residual streams: bf16 stream storage applies
 
 
-@pytest.mark.parametrize('name,residual', [(n, 'fp32') for n in FLASH_FIXTURES + BIAS_FIXTURES] + [(n, 'bf16') for n in S4_FIXTURES])
+@pytest.mark.parametrize('name,residual', [(n, 'fp32') for n in FLASH_FIXTURES + BIAS_FIXTURES + COND_FIXTURES] + [(n, 'bf16') for n in S4_FIXTURES])
 def test_hip_path_matches_reference_golden(name, residual):
     fx = _load(name)
     loss, logits, grads = ours_run(fx, residual_dtype=torch.bfloat16 if residual == 'bf16' else torch.float32)
@@ -384,3 +393,23 @@ def test_fine_full_size_properties():
     la = w(coarse_token_ids=coarse[:1], fine_token_ids=fine[:1], return_loss=True)
     lb = w(coarse_token_ids=coarse[1:], fine_token_ids=fine[1:], return_loss=True)
     assert abs(float(l2) - 0.5 * (float(la) + float(lb))) <= 1e-4 * abs(float(l2)), (float(l2), float(la), float(lb))
+
+
+def test_classifier_free_guidance_matches_reference():
+    """forward_with_cond_scale (audiolm_pytorch.py:818-855) vs the REAL reference's guided logits (fixture coarse_s4_cond_cross, cond_scale 3):
+    guidance amplifies the difference of two passes, so the bound is the single-pass bound times (2 * cond_scale - 1)."""
+    import audiolm_pytorch_amd as A
+    fx = _load('coarse_s4_cond_cross')
+    dev = torch.device('cuda:0')
+    model = A.CoarseTransformer(**fx['ctor'])
+    model.load_state_dict(synth_state_dict(fx['shapes'], fx['seed']), strict=True)
+    model.to(dev).eval()
+    inp, out = fx['inputs'], fx['outputs']
+    b = inp['semantic_token_ids'].shape[0]
+    with torch.no_grad():
+        gs, gc = model.forward_with_cond_scale(semantic_token_ids=inp['semantic_token_ids'].to(dev), coarse_token_ids=inp['coarse_token_ids'].reshape(b, -1).to(dev),
+                                               text_embeds=inp['text_embeds'].to(dev), cond_scale=out['cfg_scale'])
+    es, ec = _frob(gs, out['cfg_semantic_logits']), _frob(gc, out['cfg_coarse_logits'])
+    print(f'classifier-free guidance (cond_scale {out["cfg_scale"]}): rel-frob semantic {es:.2e} coarse {ec:.2e}')
+    bound = 1e-2 * (2 * out['cfg_scale'] - 1)
+    assert es <= bound and ec <= bound, (es, ec, bound)

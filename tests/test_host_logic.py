@@ -140,7 +140,14 @@ def test_product_refuses_cpu_and_out_of_scope_features():
     with pytest.raises(RuntimeError):
         m(ids=torch.randint(0, 10, (2, 5)))
     with pytest.raises(NotImplementedError):
-        A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, has_condition=True)
+        A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, attn_dropout=0.1)
+    # conditioning is native from pre-computed text embeddings; the T5 text encoder itself is out of scope
+    mc = A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, has_condition=True)
+    assert 'transformer.layers.0.1.branch.null_kv' in mc.state_dict()
+    with pytest.raises(NotImplementedError):
+        mc.embed_text(['a dog barking'])
+    with pytest.raises(AssertionError):                          # reference :687: a conditioned model needs its conditioning
+        mc(ids=torch.randint(0, 10, (2, 5)))
 
 
 def test_soundstream_module_tree_matches_reference_state_dict_names():

@@ -22,7 +22,8 @@ def _cfg(fx):
     c = fx['ctor']
     return O.Cfg(dim=c['dim'], depth=c['depth'], heads=c.get('heads', 8), streams=c.get('num_residual_streams', 4),
                  num_semantic_tokens=c.get('num_semantic_tokens', 0), codebook_size=c.get('codebook_size', 0),
-                 num_coarse_quantizers=c.get('num_coarse_quantizers', 0), num_fine_quantizers=c.get('num_fine_quantizers', 0))
+                 num_coarse_quantizers=c.get('num_coarse_quantizers', 0), num_fine_quantizers=c.get('num_fine_quantizers', 0),
+                 cond_as_self_attn_prefix=c.get('cond_as_self_attn_prefix', False))
 
 
 def oracle_run(fx):
@@ -32,13 +33,14 @@ def oracle_run(fx):
     full = dict(sd)
     full.update(params)
     cfg, inp, opt = _cfg(fx), fx['inputs'], fx['options']
+    ckw = dict(text_embeds=inp.get('text_embeds'), cond_drop_keep=inp.get('cond_keep'))       # conditioning fixtures (has_condition=True)
     captured = {}
     if fx['kind'] == 'semantic':
         orig = O.semantic_forward
         O.semantic_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
         try:
             loss = O.semantic_wrapper_loss(full, cfg, inp['ids'], training=opt['training'],
-                                           unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'])
+                                           unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'], **ckw)
         finally:
             O.semantic_forward = orig
         logits = (captured['l'],)
@@ -47,7 +49,7 @@ def oracle_run(fx):
         O.coarse_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
         try:
             loss = O.coarse_wrapper_loss(full, cfg, inp['semantic_token_ids'], inp['coarse_token_ids'], training=opt['training'],
-                                         unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'])
+                                         unique_consecutive=opt['unique_consecutive'], forgetful_mask=inp['forgetful_mask'], **ckw)
         finally:
             O.coarse_forward = orig
         logits = captured['l']
@@ -55,7 +57,7 @@ def oracle_run(fx):
         orig = O.fine_forward
         O.fine_forward = lambda *a, **k: captured.setdefault('l', orig(*a, **k))
         try:
-            loss = O.fine_wrapper_loss(full, cfg, inp['coarse_token_ids'], inp['fine_token_ids'], forgetful_mask=inp['forgetful_mask'])
+            loss = O.fine_wrapper_loss(full, cfg, inp['coarse_token_ids'], inp['fine_token_ids'], forgetful_mask=inp['forgetful_mask'], **ckw)
         finally:
             O.fine_forward = orig
         logits = captured['l']
@@ -68,7 +70,24 @@ MODEL_FIXTURES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join
 
 
 def test_fixtures_present():
-    assert len(MODEL_FIXTURES) >= 9, MODEL_FIXTURES
+    assert len(MODEL_FIXTURES) >= 14, MODEL_FIXTURES
+    assert sum('_cond_' in n for n in MODEL_FIXTURES) >= 5
+
+
+def test_oracle_classifier_free_guidance_matches_reference():
+    """forward_with_cond_scale (audiolm_pytorch.py:818-855): eval-mode logits with the conditioning kept and with every text position masked
+    (cond_drop_prob = 1 -> keep mask all False), mixed as null + (cond - null) * cond_scale"""
+    fx = _load('coarse_s4_cond_cross')
+    sd = synth_state_dict(fx['shapes'], fx['seed'])
+    cfg, inp, out = _cfg(fx), fx['inputs'], fx['outputs']
+    b = inp['semantic_token_ids'].shape[0]
+    coarse = inp['coarse_token_ids'].reshape(b, -1)
+    with torch.no_grad():
+        cs, cc = O.coarse_forward(sd, cfg, inp['semantic_token_ids'], coarse, text_embeds=inp['text_embeds'])
+        ns, nc = O.coarse_forward(sd, cfg, inp['semantic_token_ids'], coarse, text_embeds=inp['text_embeds'], cond_drop_keep=torch.zeros(b, dtype=torch.bool))
+    w = out['cfg_scale']
+    assert torch.allclose(ns + (cs - ns) * w, out['cfg_semantic_logits'], atol=5e-4, rtol=1e-4)
+    assert torch.allclose(nc + (cc - nc) * w, out['cfg_coarse_logits'], atol=5e-4, rtol=1e-4)
 
 
 @pytest.mark.parametrize('name', MODEL_FIXTURES)
