@@ -227,12 +227,12 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
         m = ctx.m
         KVp = _empty((B * m, 2 * dh), BF16, dev)
         ops.gemm_nt(ctx.x, Wkv, KVp)
-        Vp = KVp[:, dh:]
+        Vp, pmixed = KVp[:, dh:], False
         if cfg.add_value_residual and st['kvp0'] is not None:
-            Vp = ops.value_residual_mix(Vp, st['kvp0'][:, dh:])
+            Vp, pmixed = ops.value_residual_mix(Vp, st['kvp0'][:, dh:]), True
         if st['kvp0'] is None:
             st['kvp0'] = KVp
-        pre = dict(KVp=KVp, ke=KVp[:, :dh].reshape(B, m, dh), ve=Vp.reshape(B, m, dh), pmixed=Vp is not KVp[:, dh:])
+        pre = dict(KVp=KVp, ke=KVp[:, :dh].reshape(B, m, dh), ve=Vp.reshape(B, m, dh), pmixed=pmixed)
     if decode is not None:
         assert pre is None, 'the reference turns the kv cache off for prefix conditioning (audiolm_pytorch.py:481-482)'
         kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
@@ -263,9 +263,9 @@ def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
     CN, _, cmean, crstd = ops.layernorm_fwd(ctx.x, prm['ctx_ln'])              # context_norm (:323)
     KVc = _empty((B * m, 2 * dh), BF16, dev)
     ops.gemm_nt(CN, Wkv, KVc)
-    Vc = KVc[:, dh:]
+    Vc, cmixed = KVc[:, dh:], False
     if cfg.add_value_residual and st['kvc0'] is not None:
-        Vc = ops.value_residual_mix(Vc, st['kvc0'][:, dh:])
+        Vc, cmixed = ops.value_residual_mix(Vc, st['kvc0'][:, dh:]), True
     if st['kvc0'] is None:
         st['kvc0'] = KVc
     nkv = prm['null_kv'].to(BF16)                                              # [2, 1, dh]
@@ -277,7 +277,7 @@ def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
     AO, LSE, xs = xattn.extra_attn_fwd(Q, ke, ve, emask, B, N, H, dh, float(dh) ** -0.5)
     Y = _empty((M, D), BF16, dev)
     ops.gemm_nt(AO, Wo, Y)
-    return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=Vc is not KVc[:, dh:], AO=AO, xs=xs)
+    return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=cmixed, AO=AO, xs=xs)
 
 
 def _run_ff(cfg, W, prm, XN, M):
