@@ -193,6 +193,7 @@ class DecodeCache:
         # hipGraph replay of the single-position step (Transformer._sample): the position then lives on the device (`pos_dev` == length)
         self.pos_dev = None
         self.graph = self.x_in = self.h_out = self.mask_in = None
+        self.ctx = None                 # (context, context_mask) of a conditioned run, projected once (audiolm_pytorch._state_condition)
         self.frozen = False             # True while a step is being CAPTURED (recorded, not executed): host bookkeeping must not advance
 
 
