@@ -17,8 +17,9 @@ reading of "(B=8, Q=8, seq=2048)": a 2048-frame x 8-quantizer grid, N = 16385), 
 
 --schedule: eager = every launch issued from Python each step; graph = the step captured once into a hipGraph (graphed.GraphedTrainStep)
 and replayed; graph2 = the same with the batch split into two half-batches on two HIP streams (HBM-bound row kernels of one half under
-the MFMA-bound GEMMs of the other).  auto (default) = graph2 on one GPU when the capture succeeds, else eager; N > 1 ranks run eager (the
-gradient all-reduce is launched from backward callbacks).  The arithmetic is the same in all three; the JSON line says which ran.
+the MFMA-bound GEMMs of the other); eager2 = that split without the graph.  auto (default) = eager: measured, the captured schedules are
+SLOWER here (see main()); N > 1 ranks always run eager (the gradient all-reduce is launched from backward callbacks).  The arithmetic is
+the same in all of them; the JSON line says which ran.
 
 Extra objects on the JSON line:
   roofline     dominant kernel = the bf16 MFMA GEMM (gemm_kernel<256,256,...,NT>); achieved = algorithmic GEMM FLOPs per launch / average
@@ -270,8 +271,11 @@ def main():
     schedule, note, gstep = 'eager', None, None
     want = args.schedule
     if want == 'auto':
-        # e2e_config5 tokenizes raw audio inside the step (codec under inference_mode, data-dependent host code): kept out of the capture
-        want = 'graph2' if (world == 1 and args.config != 'e2e_config5') else 'eager'
+        # measured on MI355X (profiles/r2_schedules.log): eager 15.5 ms, graph 16.2 ms, graph2 17.1 ms per step -- the GPU, not the host, is the
+        # limit (host issue ~10-12 ms < 15.5 ms), a replayed graph adds a per-node gap to ~700 kernels and the two half-batches lose more to
+        # half-size GEMM tiles / the missing weight-gradient side stream than they win by co-residency (the 246-VGPR hyper-connection backward
+        # cannot share a SIMD with the 8-wave GEMM).  The captured schedules stay selectable; eager is the default.
+        want = 'eager'
     if want == 'eager2':                                        # diagnostic: the two-half-batch schedule without a graph (host-bound)
         model.transformer.micro_batches = 2
         schedule = 'eager2'

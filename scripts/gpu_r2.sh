@@ -63,6 +63,12 @@ except Exception as e: print('no json', e)
     grep -E "capture failed|Error|error" gpurun_out/${tag}_sched_${rd}_${sc}.log | head -5
   done; done
 fi
+if has configs; then
+  for cf in ${CONFIGS:-coarse1024 fine2049 fine_t2048_q8 e2e_config5}; do
+    timeout 900 python bench.py --config $cf --steps 5 --warmup 2 > gpurun_out/${tag}_config_${cf}.log 2>&1
+    echo "config $cf rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_config_${cf}.log | cut -c1-2500
+  done
+fi
 if has benchfull; then
   timeout 900 python bench.py > gpurun_out/${tag}_bench_full.log 2>&1
   echo "bench full rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_bench_full.log | cut -c1-3000
