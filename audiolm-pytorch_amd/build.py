@@ -104,5 +104,42 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+LAB_SRC = os.path.join(CSRC, 'lab', 'gemm_lab.hip')
+LAB_LIB = os.path.join(HERE, 'libaudiolm_gemm_lab.so')
+
+
+def build_lab(force: bool = False) -> str:
+    """bench-only library of the GEMM variants that were measured and not adopted (csrc/lab/gemm_lab.hip).  The package never loads it:
+    scripts/ab_gemm.py, scripts/kbench.py and tests/test_gpu_gemm_lab.py do."""
+    import fcntl
+    h = hashlib.sha256(_headers() + ' '.join(FLAGS).encode())
+    for f in (LAB_SRC, os.path.join(CSRC, 'lab', 'gemm_lab.h')):
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    dig, stamp = h.hexdigest(), LAB_LIB + '.stamp'
+    fresh = lambda: os.path.exists(LAB_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig
+    if not force and fresh():
+        return LAB_LIB
+    with open(os.path.join(HERE, '.build_lab.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():
+                return LAB_LIB
+            tmp = LAB_LIB + f'.tmp{os.getpid()}'
+            try:
+                subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), *FLAGS, '-Wno-unused-function', '-shared', '-o', tmp, LAB_SRC], check=True)
+                os.replace(tmp, LAB_LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            with open(stamp, 'w') as fh:
+                fh.write(dig)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LAB_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    if '--lab' in sys.argv:
+        print(build_lab(force='--force' in sys.argv))

@@ -22,7 +22,7 @@ SLOWER here (see main()); N > 1 ranks always run eager (the gradient all-reduce 
 the same in all of them; the JSON line says which ran.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the bf16 MFMA GEMM (gemm_kernel<256,256,...,NT>); achieved = algorithmic GEMM FLOPs per launch / average
+  roofline     dominant kernel = the bf16 MFMA NT GEMM on the big tiles (gemm_stag_kernel<NT> 256x256x64 / gemm_kernel<384,256,...,NT>); achieved = algorithmic GEMM FLOPs per launch / average
                launch duration, measured live with HIP events on the launch stream over one instrumented EAGER step; peak = 2500 TFLOP/s.
   cpu_baseline the oracle (CPU fp32 restatement of the reference, "port") timed on this box's host cores on a bounded sample
                (B = 1, same architecture), rank 0 at N = 1 only, with 4 residual streams and with 1 (pure reference code).
@@ -342,8 +342,9 @@ def main():
         host['eager_ms_per_step'] = round(dte / max(3, args.steps // 2) * 1e3, 3)
 
     # ---- roofline of the dominant kernel: one instrumented EAGER step, HIP events (torch.cuda.Event on the launch stream = torch's current
-    # stream, which is the stream every alm_* launch uses) around every MFMA GEMM launch.  The dominant kernel is the NT 256x256x64
-    # 8-wave tile (gemm_kernel<256,256,2,4,false,*>): its launches are singled out; all GEMM launches are reported alongside.
+    # stream, which is the stream every alm_* launch uses) around every MFMA GEMM launch.  The dominant kernel is the NT big-tile GEMM (8 waves: gemm_stag_kernel
+    # <false,*> 256x256x64 with staggered wave rows, or gemm_kernel<384,256,2,4,false,*> where pick_tile() prefers the coarser tiling): its
+    # launches are singled out; all GEMM launches are reported alongside.
     # EVERY rank runs the instrumented step (with N > 1 it contains the gradient all-reduces: a step on rank 0 alone would dead-lock the
     # collectives); only rank 0's numbers are reported.
     roof = None
@@ -393,7 +394,7 @@ def main():
     if d_n:
         ach = d_fl / (d_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
-        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<256,256,2,4,NT> (bf16 MFMA 32x32x16; FFN / projection forward + dgrad GEMMs)',
+        roof = {'bound': 'mfma', 'kernel': 'gemm_stag_kernel<NT> 256x256x64 + gemm_kernel<384,256,2,4,NT> (8-wave bf16 MFMA 32x32x16 big tiles; FFN / projection forward + dgrad GEMMs)',
                 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
                 'traffic': traffic if args.config == 'coarse2048' else None,
                 'traffic_source': (f'profiles/{traffic_src} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)'

@@ -29,27 +29,20 @@ extern "C" {
 int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                      long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
                      long long sC2, float alpha, int out_f32, int accumulate, void* stream);
-/* tile-selectable, un-batched form of alm_gemm_bf16_nt (tuning / benchmarks): tile 0 = auto, 1 = 128x128x64 (4 waves),
- * 2 = 256x256x64 (8 waves; the production tile), 3 = 256x128 with a 3-stage DMA ring, 4 = persistent 256x256, 6 / 7 = 256x256 with the
- * hand software-pipelined main loop on 4 / 8 waves, 8 / 9 = 256x256 with the B operand streamed from L2 into registers (plain / pipelined
- * A fragment reads), 10 / 12 = 32-deep K-steps with a 4- / 3-stage DMA ring (256x256 on 8 waves / 256x128 on 4 waves, two workgroups per CU)
- * (3-12: measured experiments). */
+/* tile-selectable, un-batched form of alm_gemm_bf16_nt (tests / benchmarks): tile 0 = auto, 1 = 128x128x64 (4 waves), 2 = 256x256x64
+ * (8 waves, lock-step), 13 = 256x256x64 with staggered wave rows (the production big tile), 11 = 384x256x64 (8 waves); other ids ->
+ * ALM_ERR_UNSUPPORTED (the variants that were measured and not adopted live in the bench-only csrc/lab/gemm_lab.hip). */
 int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                           long long ldc, float alpha, int out_f32, int accumulate, int tile, void* stream);
 /* split-K forms for long-K / few-tile contractions (weight gradients: K = B*N tokens): fp32 C (+)= alpha * op(A) . op(B),
  * deterministic two-stage reduction through `ws` (alm_gemm_splitk_ws_floats(M,N,K,nb) floats; may be NULL when that
- * query returns 0).  A balanced split (one equally long K-step range per CU, whole fp32 partial tiles in `ws`,
- * second-stage sum in K order) exists behind alm_debug_stream; it measured slower than uniform slices (operand-traffic bound) and is off by default.  `nb` same-shape problems per launch with element strides sA / sB / sC between them (sA, sB % 8 == 0).
+ * query returns 0).  `nb` same-shape problems per launch with element strides sA / sB / sC between them (sA, sB % 8 == 0).
  *   _nt_: A[M][K], B[N][K] (K-contiguous operands)
  *   _tn_: At[K][M], Bt[K][N] (contraction-major operands = the row-major activations themselves):
  *         dW[out][in] = sum_tokens dY[token][out] * X[token][in], the wgrad of every nn.Linear on the path
  *         (autograd of audiolm_pytorch.py:255-259, :351, :395, :961, :972) with no transposed copies; lda/ldb % 8 == 0. */
 int alm_gemm_splitk_slices(int M, int N, int K, int nb);
 int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb);
-int alm_debug_stream(int mode);     /* balanced split: 0 never (default), 1 by the cost model, 2 whenever applicable (benchmarks / tests) */
-/* tuning hook for benchmarks (process-global, not thread-safe; 0 = automatic): force the split-K tile (1 = 128x128, 2 = 256x256) and
- * slice count; raster 0 = plain grid, 1 = XCD-panel rasterisation of split-K launches (default) */
-int alm_debug_splitk(int tile, int slices, int raster);
 int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,

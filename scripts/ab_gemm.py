@@ -1,7 +1,8 @@
-"""A/B of GEMM main-loop variants in ONE process: the production library against alternative builds of csrc/gemm.hip
-(any `scripts/ubench/bin/libgemm_v*.so`, e.g. `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -D<switch> -o scripts/ubench/bin/libgemm_v1.so
-csrc/gemm.hip`), for every tile id given.  The libraries are timed round-robin on the same buffers, so clock
-ramps and box-to-box differences cancel.  Usage: python scripts/ab_gemm.py [tile ...]   (default tiles: 2 7 10 12)
+"""A/B of GEMM main-loop variants in ONE process: the bench-only library (csrc/lab/gemm_lab.hip: every tile id, incl. the ones that were
+not adopted) and any alternative build of it (`scripts/ubench/bin/libgemm_v*.so`, e.g. `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared
+-DALM_GEMM_WHATIF=8 -o scripts/ubench/bin/libgemm_v1.so audiolm-pytorch_amd/csrc/lab/gemm_lab.hip`), for every tile id given.  The libraries are
+timed round-robin on the same buffers, so clock ramps and box-to-box differences cancel.
+Usage: python scripts/ab_gemm.py [tile ...]   (default tiles: 2 13 11 7 10 12)
 """
 import ctypes
 import glob
@@ -19,16 +20,12 @@ dev = torch.device('cuda')
 BF16 = torch.bfloat16
 
 
-def bind(path):
-    lib = ctypes.CDLL(path)
-    lib.alm_gemm_bf16_nt_tile.argtypes = _lib.SIGNATURES['alm_gemm_bf16_nt_tile']
-    lib.alm_gemm_bf16_nt_tile.restype = ctypes.c_int
-    return lib
+import gemm_lab  # noqa: E402
 
 
 def main():
-    tiles = [int(a) for a in sys.argv[1:]] or [2, 7, 10, 12]
-    libs = [('prod', _lib.load())] + [(os.path.basename(p)[3:-3], bind(p)) for p in sorted(glob.glob(os.path.join(ROOT, 'scripts/ubench/bin/libgemm_v*.so')))]
+    tiles = [int(a) for a in sys.argv[1:]] or [2, 13, 11, 7, 10, 12]
+    libs = [('lab', gemm_lab.bind())] + [(os.path.basename(p)[3:-3], gemm_lab.bind(p)) for p in sorted(glob.glob(os.path.join(ROOT, 'scripts/ubench/bin/libgemm_v*.so')))]
     T = 16384
     shapes = [('W1 fwd', T, 5472, 1024), ('W2 fwd', T, 1024, 2736), ('dHN dgrad', T, 2736, 1024), ('dXN2 dgrad', T, 1024, 5472), ('square 8192', 8192, 8192, 8192)]
     st = torch.cuda.current_stream().cuda_stream
@@ -39,10 +36,10 @@ def main():
         ref = None
         for tile in tiles:
             def run(lib):
-                rc = lib.alm_gemm_bf16_nt_tile(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, A.stride(0), B.stride(0), C.stride(0), 1.0, 0, 0, tile, st)
+                rc = lib.almlab_gemm_bf16_nt_tile(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, A.stride(0), B.stride(0), C.stride(0), 1.0, 0, 0, tile, st)
                 assert rc == 0, rc
             best = {n: 1e9 for n, _ in libs}
-            for n, lib in libs:                               # correctness of every variant against the production build
+            for n, lib in libs:                               # correctness of every variant against the first library
                 C.zero_()
                 run(lib)
                 torch.cuda.synchronize()

@@ -19,6 +19,14 @@ if has kernels; then
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/${tag}_kernels.log 2>&1
   echo "kernels rc=$? t=$((SECONDS-t0))"; tail -n 40 gpurun_out/${tag}_kernels.log
 fi
+if has lab; then
+  timeout 900 python -m pytest tests/test_gpu_gemm_lab.py -m gpu -q --tb=short -n 4 --timeout 300 > gpurun_out/${tag}_lab.log 2>&1
+  echo "lab rc=$? t=$((SECONDS-t0))"; tail -n 8 gpurun_out/${tag}_lab.log
+fi
+if has ab; then
+  timeout 600 python scripts/ab_gemm.py ${AB_TILES:-2 13 11} > gpurun_out/${tag}_ab_gemm.log 2>&1
+  echo "ab rc=$? t=$((SECONDS-t0))"; cat gpurun_out/${tag}_ab_gemm.log
+fi
 if has parity; then
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -s --timeout 600 > gpurun_out/${tag}_parity.log 2>&1
   echo "parity rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|logits|passed|failed|Error|error" gpurun_out/${tag}_parity.log | cut -c1-230 | tail -n 70

@@ -54,7 +54,7 @@ def bench_gemm():
         t = timeit(lambda: torch.matmul(Am, Bm.t(), out=C))
         ref = C.clone()
         line += f'  blas {t:.3f} ms {fl / t / 1e9:7.0f} TF |'
-        for tile in (1, 2):
+        for tile in (1, 2, 13, 11):
             if tile >= 2 and (M < 256 or N < 256):
                 continue
             C.zero_()
@@ -75,21 +75,30 @@ def bench_gemm():
 
 
 def bench_tn():
-    """split-K plan / rasterisation sweep for the two big weight-gradient shapes (tuning hook alm_debug_splitk)."""
+    """split-K plan / rasterisation sweep for the two big weight-gradient shapes, on the bench-only library (tuning hook almlab_debug_splitk)."""
+    import gemm_lab
+    lab = gemm_lab.bind()
     T, I, Ip, D = 16384, 2730, 2736, 1024
     dU, XN2 = rnd(T, 2 * Ip), rnd(T, D)
     dW1 = torch.empty((2, I, D), dtype=F32, device=dev)
     dY2, HN = rnd(T, D), rnd(T, Ip)
     dW2 = torch.empty((D, I), dtype=F32, device=dev)
-    f1 = lambda: ops.gemm_tn_splitk(dU.view(T, 2, Ip).permute(1, 0, 2)[:, :, :I], XN2, dW1)
-    f2 = lambda: ops.gemm_tn_splitk(dY2, HN[:, :I], dW2)
+    ws = torch.empty(1 << 28, dtype=F32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def f1():
+        assert lab.almlab_gemm_bf16_tn_splitk(dU.data_ptr(), XN2.data_ptr(), dW1.data_ptr(), ws.data_ptr(), I, D, T, 2 * Ip, D, D, 2, Ip, 0, I * D, 1.0, 0, st) == 0
+
+    def f2():
+        assert lab.almlab_gemm_bf16_tn_splitk(dY2.data_ptr(), HN.data_ptr(), dW2.data_ptr(), ws.data_ptr(), D, I, T, D, Ip, I, 1, 0, 0, 0, 1.0, 0, st) == 0
     fl1, fl2 = 2.0 * 2 * I * D * T, 2.0 * D * I * T
-    for raster in (0,):
+    for raster in (0, 1):
         for tile, sl in [(0, 0), (2, 2), (2, 5), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6)]:
-            _lib.call('alm_debug_splitk', tile, sl, raster)
+            lab.almlab_debug_splitk(tile, sl, raster)
+            assert lab.almlab_gemm_splitk_ws_floats(I, D, T, 2) <= ws.numel() and lab.almlab_gemm_splitk_ws_floats(D, I, T, 1) <= ws.numel()
             t1, t2 = timeit(f1, iters=10), timeit(f2, iters=10)
             print(f'raster {raster} tile {tile} slices {sl}:  dW1(batched x2) {t1:.3f} ms {fl1 / t1 / 1e9:5.0f} TF | dW2 {t2:.3f} ms {fl2 / t2 / 1e9:5.0f} TF', flush=True)
-    _lib.call('alm_debug_splitk', 0, 0, 1)
+    lab.almlab_debug_splitk(0, 0, 1)
 
 
 def bench_wgrad():

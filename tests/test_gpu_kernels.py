@@ -49,13 +49,13 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 6, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize('tile', [1, 2, 11, 13])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192), (1536, 5472, 128), (4096, 2736, 192)])
 def test_gemm_nt_tile_configs(ops, M, N, K, tile):
-    """every block-tile configuration (128x128x64 / 4 waves, 256x256x64 / 8 waves, 256x128x64 with the 3-stage counted-vmcnt DMA ring: 1, 2, 3
-    and more K-steps exercise its prologue / steady state / drain; 4 = persistent 256x256 kernel: shapes with more tiles than CUs make
-    every workgroup walk several tiles with the cross-tile prefetch) on full, ragged and K-tail shapes; an asymmetric
-    B catches operand / output transposes."""
+    """every block-tile configuration of the product library (1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves lock-step, 13 = 256x256x64
+    with staggered wave rows -- 1, 2, 3 and more K-steps exercise its slot pipeline's fill / steady state / drain --, 11 = 384x256x64) on
+    full, ragged and K-tail shapes; an asymmetric B catches operand / output transposes.  (The variants that were measured and not adopted
+    are tested in tests/test_gpu_gemm_lab.py against the bench-only library.)"""
     A, B = rnd(M, K, seed=11, dtype=BF16), rnd(N, K, seed=12, dtype=BF16)
     for dt, tol in ((F32, 2e-5), (BF16, 4e-3)):
         C = torch.full((M + 3, N + 5), float('nan'), dtype=dt, device=dev())
@@ -81,38 +81,6 @@ def test_gemm_tn_splitk(ops, M, N, K):
     C1 = C0.clone()
     ops.gemm_tn_splitk(At, Bt, C1, alpha=0.25, accumulate=True)
     assert relmax(C1, C0.double() + 0.25 * ref) <= 3e-5
-
-
-@pytest.mark.parametrize('M,N,K,nb', [(512, 1024, 4096, 1), (2730, 1024, 2048, 1), (1025, 300, 1100, 1), (1024, 2730, 16384, 1), (530, 512, 3000, 2), (256, 256, 1024, 1)])
-def test_gemm_balanced_split(ops, M, N, K, nb):
-    """the balanced split (one K-step range per CU, partial tiles in the workspace, second-stage sum) forced on, TN and NT, vs fp64;
-    and bit-identical results from two runs (no atomics, fixed summation order)."""
-    from audiolm_pytorch_amd import _lib
-    _lib.query('alm_debug_stream', 2)
-    try:
-        Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
-        At, Bt = rnd(nb, K, Mp, seed=40, dtype=BF16), rnd(K, Np, seed=41, dtype=BF16)
-        A3 = At[:, :, :M] if nb > 1 else At[0, :, :M]
-        C = torch.full((nb, M, N) if nb > 1 else (M, N), float('nan'), dtype=F32, device=dev())
-        ops.gemm_tn_splitk(A3, Bt[:, :N], C)
-        ref = torch.einsum('bkm,kn->bmn', At[:, :, :M].double(), Bt[:, :N].double())
-        ref = ref if nb > 1 else ref[0]
-        assert relmax(C, ref) <= 3e-5
-        C2 = torch.empty_like(C)
-        ops.gemm_tn_splitk(A3, Bt[:, :N], C2)
-        assert torch.equal(C, C2)
-        C0 = rnd(*C.shape, seed=42)
-        C1 = C0.clone()
-        ops.gemm_tn_splitk(A3, Bt[:, :N], C1, alpha=0.5, accumulate=True)
-        assert relmax(C1, C0.double() + 0.5 * ref) <= 3e-5
-        if nb == 1:
-            Kp = (K + 7) // 8 * 8
-            A, B = rnd(M, Kp, seed=43, dtype=BF16), rnd(N, Kp, seed=44, dtype=BF16)
-            Cn = torch.full((M, N), float('nan'), dtype=F32, device=dev())
-            ops.gemm_nt_splitk(A, B, Cn)
-            assert relmax(Cn, A.double() @ B.double().t()) <= 3e-5
-    finally:
-        _lib.query('alm_debug_stream', 0)
 
 
 def test_gemm_tn_splitk_batched_halves(ops):
