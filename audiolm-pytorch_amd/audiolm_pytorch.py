@@ -17,8 +17,9 @@ parameter containers + integer bookkeeping; every floating-point op of the path 
 Conditioning (`has_condition=True`, reference :325-375, :450-455, :640-668, :818-855, :1097-1134): cross-attention layers with a null key / value,
 `cond_as_self_attn_prefix`, per-sample condition dropping and classifier-free guidance all run natively from pre-computed `text_embeds`
 (xattn.py / csrc/xattn.hip); the T5 text encoder is out of scope (`text=` raises).
-Not accepted (NotImplementedError, nothing falls back silently): the reference's stacked kv_cache= / embed_cache= TENSOR arguments (the native
-sampling cache replaces them), dense `attn_bias` tensors, dropout > 0.
+The reference's stacked kv_cache= / embed_cache= TENSOR protocol is accepted on forward() / forward_with_cond_scale()
+(Transformer.forward_kv_protocol: the one-new-token step runs the same single-position kernels); generate() drives the native cache directly.
+Not accepted (NotImplementedError, nothing falls back silently): dense `attn_bias` tensors, dropout > 0.
 Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
@@ -418,9 +419,10 @@ class Transformer(nn.Module):
 
     def forward(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, return_kv_cache=False, kv_cache=None,
                 return_flat_hidden=False):
-        if exists(kv_cache):
-            raise NotImplementedError("the reference's stacked kv_cache tensor is not accepted here: the *Transformer classes map `kv_cache=` onto the "
-                                      'native per-layer cache (core.DecodeCache), see _TransformerBase.forward_with_cond_scale / sample_logits')
+        if exists(kv_cache) or return_kv_cache:                 # the reference's cache protocol: inference only (the outputs carry no autograd graph)
+            out, new_cache = self.forward_kv_protocol(x, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask,
+                                                      attn_bias=attn_bias, kv_cache=kv_cache)
+            return (out, new_cache) if return_kv_cache else out
         assert not (self.cond_as_self_attn_prefix and not exists(context))                          # :471
         assert exists(context) == (self.cross_attend or self.cond_as_self_attn_prefix), 'a conditioning context needs (and is needed by) a conditioned Transformer'
         assert not (exists(context) and context.shape[-1] != self.dim_context), \
@@ -441,10 +443,51 @@ class Transformer(nn.Module):
                                            attn_bias.tbl if exists(attn_bias) else None, context, *self.flat_params())
         if return_flat_hidden:
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
-        out = hn.view(b, n, d)
-        if not return_kv_cache:
-            return out
-        return out, None
+        return hn.view(b, n, d)
+
+    @torch.no_grad()
+    def forward_kv_protocol(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, kv_cache=None):
+        """The reference's kv-cache TENSOR protocol (audiolm_pytorch.py:360-370 store / concat, :487-496 `x = x[:, cache_len:]`, :560 stack):
+        x fp32 [b, n, d] = embeddings of the WHOLE sequence, kv_cache [depth, 2 (k | v), b, cache_len, dim_head] | None
+        -> (final-norm hidden states of the positions cache_len .. n-1, fp32 [b, n - cache_len, d];  new kv_cache fp32 [depth, 2, b, n, dim_head]).
+        The cached v is the value-residual-mixed one, as in the reference (:357-366).  Inference only (no autograd graph).
+        One new position (the sampling case): the tensor is loaded into a core.DecodeCache and the single-position kernels run
+        (alm_mqa_decode_attn).  No cache, or more than one new position: the whole sequence is recomputed -- the same numbers, the reference's
+        incremental saving only exists for the one-token step.  `cond_as_self_attn_prefix` ignores an incoming cache like the reference (:481)."""
+        assert not (self.cond_as_self_attn_prefix and not exists(context))
+        assert exists(context) == (self.cross_attend or self.cond_as_self_attn_prefix), 'a conditioning context needs (and is needed by) a conditioned Transformer'
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
+        b, n, d = x.shape
+        cfg, dh = self.cfg, self.cfg.dim_head
+        cache_len = 0
+        if exists(kv_cache) and not self.cond_as_self_attn_prefix:
+            assert tuple(kv_cache.shape[:3]) == (cfg.depth, 2, b) and kv_cache.shape[-1] == dh, \
+                f'kv_cache must be [depth={cfg.depth}, 2, b={b}, cached positions, dim_head={dh}], got {tuple(kv_cache.shape)}'
+            cache_len = kv_cache.shape[-2]
+            assert cache_len <= n
+        if exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias):
+            raise NotImplementedError('a dense (h, n, n) attn_bias tensor is not supported: pass the structured relpos.AttnBias')
+        if not exists(attn_bias) and exists(self.rel_pos_bias):
+            attn_bias = self.rel_pos_bias(n, n)
+        tbl = attn_bias.tbl if exists(attn_bias) else None
+        mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8) if exists(self_attn_mask) else None
+        state = core.DecodeCache(cfg, b, n, x.device)
+        flat = self.flat_params()
+        if cache_len > 0 and n - cache_len == 1:
+            for l in range(cfg.depth):
+                state.kv[l][:, :cache_len, :dh] = kv_cache[l, 0]
+                state.kv[l][:, :cache_len, dh:] = kv_cache[l, 1]
+            state.length = cache_len
+            h = core.TransformerStackFn.apply(x[:, -1:].contiguous(), mask_u8, cfg, self._cache, dict(grad=False, decode=state, context_mask=context_mask),
+                                              attn_bias, tbl, context, *flat)
+            hidden = h.view(b, 1, d)
+        else:
+            hn = core.TransformerStackFn.apply(x, mask_u8, cfg, self._cache, dict(grad=False, kv_out=state, context_mask=context_mask), attn_bias, tbl,
+                                               context, *flat)
+            hidden = hn.view(b, n, d)[:, cache_len:]
+        new_cache = torch.stack([torch.stack((kv[:, :n, :dh], kv[:, :n, dh:])) for kv in state.kv]).float()
+        return hidden.float(), new_cache
 
 
     def _sample(self, tokens, self_attn_mask, state, context=None, context_mask=None):
@@ -616,19 +659,49 @@ class _TransformerBase(nn.Module):
     def forward_with_cond_scale(self, *args, cond_scale=3, kv_cache=None, embed_cache=None, return_kv_cache=False, **kwargs):
         """Classifier-free guidance (audiolm_pytorch.py:640-667 / :818-855 / :1097-1134): logits with the conditioning kept (cond_drop_prob = 0) and,
         for conditioned models at cond_scale != 1, with every text position masked out (cond_drop_prob = 1: cross-attention then sees only its
-        null key / value); result = null + (cond - null) * cond_scale.  The reference's stacked kv / embed cache TENSORS are not accepted on this
-        entry: cached sampling runs through sample_logits() (core.DecodeCache), which the wrappers' generate() use; here the prefix is
-        recomputed, which gives the same logits, and the cache slots of the return value are None."""
-        if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
-        out = self.forward(*args, cond_drop_prob=0., **kwargs)
+        null key / value); result = null + (cond - null) * cond_scale.
+        kv_cache / embed_cache: the reference's stacked cache tensors -- one entry per pass ([cond] or [cond, null]), each a
+        Transformer.forward_kv_protocol cache [depth, 2, b, n, dim_head] / hidden states [b, n, dim]; with return_kv_cache the new stacks are
+        returned the same way (SemanticTransformer: logits, kv; Coarse / Fine: logits, (kv, embed)).  The wrappers' generate() do not go through
+        this tensor protocol: they drive the native core.DecodeCache (sample_logits), which also replays the step as a hipGraph."""
+        two = not isinstance(self, SemanticTransformer)
+        if not (exists(kv_cache) or exists(embed_cache) or return_kv_cache):
+            out = self.forward(*args, cond_drop_prob=0., **kwargs)
+            if cond_scale != 1 and self.has_condition:
+                null = self.forward(*args, cond_drop_prob=1., **kwargs)
+                mix = lambda c, n: None if c is None else n + (c - n) * cond_scale                        # noqa: E731
+                out = tuple(mix(c, n) for c, n in zip(out, null)) if isinstance(out, tuple) else mix(out, null)
+            return out
+        it_kv, it_em = iter(default(kv_cache, [])), iter(default(embed_cache, []))
+        new_kv, new_em = [], []
+
+        def one(cdp):
+            if two:
+                lg, (kv, em) = self.forward(*args, cond_drop_prob=cdp, return_cache=True, kv_cache=next(it_kv, None), embed_cache=next(it_em, None), **kwargs)
+                new_em.append(em)
+            else:
+                lg, kv = self.forward(*args, cond_drop_prob=cdp, return_kv_cache=True, kv_cache=next(it_kv, None), **kwargs)
+            new_kv.append(kv)
+            return lg
+        out = one(0.)
         if cond_scale != 1 and self.has_condition:
-            null = self.forward(*args, cond_drop_prob=1., **kwargs)
-            mix = lambda c, n: None if c is None else n + (c - n) * cond_scale                        # noqa: E731
-            out = tuple(mix(c, n) for c, n in zip(out, null)) if isinstance(out, tuple) else mix(out, null)
+            null = one(1.)
+            mix = lambda c, n: None if c is None else n + (c - n) * cond_scale                            # noqa: E731
+            out = tuple(mix(c, n) for c, n in zip(out, null)) if two else mix(out, null)
         if not return_kv_cache:
             return out
-        return out, ((None, None) if isinstance(out, tuple) else None)
+        return out, ((torch.stack(new_kv), torch.stack(new_em)) if two else torch.stack(new_kv))
+
+    def _protocol_hidden(self, tokens, self_attn_mask, attn_bias, context, context_mask, kv_cache, embed_cache):
+        """hidden states of ALL positions through the reference's cache protocol: the transformer runs on the positions the kv cache does not
+        cover, the rest comes from `embed_cache` (audiolm_pytorch.py:950-953 / :1312-1315) -> (flat fp32 [b*n, d], new kv cache, new embed cache)"""
+        h, new_kv = self.transformer.forward_kv_protocol(tokens, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask,
+                                                         attn_bias=attn_bias, kv_cache=kv_cache)
+        if exists(embed_cache):
+            h = torch.cat((embed_cache.to(h.dtype), h), dim=-2)
+        b, n, d = h.shape
+        assert n == tokens.shape[1], f'kv_cache / embed_cache cover {n} of {tokens.shape[1]} positions: pass both caches of the same call'
+        return h.reshape(b * n, d).contiguous(), new_kv, h
 
     def _state_condition(self, state, b, device, text_embeds, cond_drop_prob, mask_from_embeds):
         """conditioning context of a cached sampling run: projected ONCE and kept in the sampling state -- the text does not change during a run,
@@ -703,7 +776,7 @@ class SemanticTransformer(_TransformerBase):
         self.to_logits = nn.Linear(dim, num_semantic_tokens + 1)
         self.dim = dim
 
-    def _hidden(self, ids, self_attn_mask, context=None, context_mask=None):
+    def _tokens(self, ids, self_attn_mask):
         b, n = ids.shape
         dev = ids.device
         sem = ids.to(torch.int32)                                                              # table 0; pad (-1) -> zero vector (:176-181)
@@ -713,7 +786,12 @@ class SemanticTransformer(_TransformerBase):
                                        self.semantic_embedding.weight, self.start_token).view(b, n + 1, self.dim)
         if exists(self_attn_mask):
             self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)                       # :716
-        return self.transformer(tokens, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask, return_flat_hidden=True), b, n + 1
+        return tokens, self_attn_mask
+
+    def _hidden(self, ids, self_attn_mask, context=None, context_mask=None):
+        tokens, self_attn_mask = self._tokens(ids, self_attn_mask)
+        b, n1 = tokens.shape[:2]
+        return self.transformer(tokens, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask, return_flat_hidden=True), b, n1
 
     @torch.no_grad()
     def sample_logits(self, ids, state, nmax, text_embeds=None, cond_scale=1.):
@@ -741,11 +819,17 @@ class SemanticTransformer(_TransformerBase):
     def forward(self, *, ids=None, return_loss=False, text=None, text_embeds=None, self_attn_mask=None, cond_drop_prob=None,
                 unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
         context, context_mask = self._condition(ids.shape[0], ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
-        if exists(kv_cache):
-            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
         if return_loss:
             ids = ids[:, :-1]                                                                # :706-707 (the reference drops the labels)
-        hn, b, N = self._hidden(ids, self_attn_mask, context, context_mask)
+        new_kv = None
+        if exists(kv_cache) or return_kv_cache:                                              # the reference's cache protocol (:719): inference only
+            assert not exists(labels)
+            tokens, mask = self._tokens(ids, self_attn_mask)
+            h, new_kv = self.transformer.forward_kv_protocol(tokens, self_attn_mask=mask, context=context, context_mask=context_mask, kv_cache=kv_cache)
+            b, N = h.shape[:2]                                                               # only the positions the cache did not cover
+            hn = h.reshape(b * N, self.dim).contiguous()
+        else:
+            hn, b, N = self._hidden(ids, self_attn_mask, context, context_mask)
         idx, i_grid, valid = _group_index(b, N, 0, N, 1, ids.device)
         if exists(labels):                                                                   # fused loss path (wrapper)
             grp = heads.HeadGroup('semantic', self.to_logits.weight, self.to_logits.bias, idx, _group_labels(labels, i_grid, valid, N))
@@ -757,7 +841,7 @@ class SemanticTransformer(_TransformerBase):
         logits = _ungroup_logits(lg, b, N, 1, C)
         if not return_kv_cache:
             return logits
-        return logits, None
+        return logits, new_kv
 
 
 # ---------------------------------------------------------------------------------------------- CoarseTransformer (:726-990)
@@ -857,9 +941,15 @@ class CoarseTransformer(_TransformerBase):
     def forward(self, *, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text=None, text_embeds=None, cond_drop_prob=None,
                 return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None):
         context, context_mask = self._condition(semantic_token_ids.shape[0], semantic_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=True)
-        if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError("the reference's kv_cache= / embed_cache= tensors are not accepted: the native sampling cache is driven through sample_logits() / generate()")
-        hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask, context, context_mask)
+        caches = (None, None)
+        if exists(kv_cache) or exists(embed_cache) or return_cache:                               # the reference's cache protocol (:938-953): inference only
+            assert not exists(labels)
+            tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
+            attn_bias = self.transformer.rel_pos_bias(N, N, special=self.cross_attn_bias, num_leading=ns + 1) if exists(self.transformer.rel_pos_bias) else None
+            hn, new_kv, new_em = self._protocol_hidden(tokens, self_attn_mask, attn_bias, context, context_mask, kv_cache, embed_cache)
+            caches = (new_kv, new_em)
+        else:
+            hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask, context, context_mask)
         dev = hn.device
         if exists(labels):                                                                        # fused loss path: (sem_labels, coarse_labels)
             sem_labels, coarse_labels = labels
@@ -880,7 +970,7 @@ class CoarseTransformer(_TransformerBase):
         logits = (semantic_logits, coarse_logits)
         if not return_cache:
             return logits
-        return logits, (None, None)
+        return logits, caches
 
 
 # ---------------------------------------------------------------------------------------------- FineTransformer (:992-1368)
@@ -973,14 +1063,18 @@ class FineTransformer(_TransformerBase):
     def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
                 kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
         context, context_mask = self._condition(coarse_token_ids.shape[0], coarse_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
-        if exists(kv_cache) or exists(embed_cache):
-            raise NotImplementedError('pass no kv_cache / embed_cache: the sampling cache of this package is driven through sample_logits()')
         tokens, self_attn_mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, self_attn_mask)
         dev = tokens.device
         Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
         attn_bias = self._attn_bias(n, nf, dev)
-        hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, context=context, context_mask=context_mask,
-                              return_flat_hidden=True)
+        caches = (None, None)
+        if exists(kv_cache) or exists(embed_cache) or return_cache:                               # the reference's cache protocol (:1300-1315): inference only
+            assert not exists(labels)
+            hn, new_kv, new_em = self._protocol_hidden(tokens, self_attn_mask, attn_bias, context, context_mask, kv_cache, embed_cache)
+            caches = (new_kv, new_em)
+        else:
+            hn = self.transformer(tokens, self_attn_mask=self_attn_mask, attn_bias=attn_bias, context=context, context_mask=context_mask,
+                                  return_flat_hidden=True)
 
         n_fine = nf + 1                                                                           # tokens[:, n+1:]  (:1319)
         want_coarse = exists(self.coarse_logit_weights) and not return_only_fine_logits
@@ -1007,7 +1101,7 @@ class FineTransformer(_TransformerBase):
         logits = (coarse_logits, fine_logits)
         if not return_cache:
             return logits
-        return logits, (None, None)
+        return logits, caches
 
 
 # ---------------------------------------------------------------------------------------------- training wrappers

@@ -27,6 +27,10 @@ if has ab; then
   timeout 600 python scripts/ab_gemm.py ${AB_TILES:-2 13 11} > gpurun_out/${tag}_ab_gemm.log 2>&1
   echo "ab rc=$? t=$((SECONDS-t0))"; cat gpurun_out/${tag}_ab_gemm.log
 fi
+if has proto; then
+  timeout 600 python -m pytest tests/test_gpu_cache_protocol.py -m gpu -q --tb=short --timeout 300 > gpurun_out/${tag}_proto.log 2>&1
+  echo "proto rc=$? t=$((SECONDS-t0))"; tail -n 30 gpurun_out/${tag}_proto.log | cut -c1-400
+fi
 if has parity; then
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -s --timeout 600 > gpurun_out/${tag}_parity.log 2>&1
   echo "parity rc=$? t=$((SECONDS-t0))"; grep -E "loss ours|logits|passed|failed|Error|error" gpurun_out/${tag}_parity.log | cut -c1-230 | tail -n 70

@@ -301,6 +301,57 @@ def cond_cases(R):
     return cases
 
 
+def cache_protocol_case(R):
+    """The reference's kv_cache / embed_cache TENSOR protocol (audiolm_pytorch.py:360-370, :487-496, :560, :719, :938-953, :1300-1315) run on
+    the REAL reference, eval mode: a prefix call that returns the caches, then one-token steps that consume them; and the guided form
+    (forward_with_cond_scale, stacked [cond, null] caches).  Recorded: every call's logits, the cache shapes, the final caches."""
+    out = dict(name='cache_protocol', kind='cache_protocol', models={})
+
+    def build(K, ctor, seed):
+        torch.manual_seed(0)
+        m = K(**ctor)
+        shapes = _shapes(m.state_dict())
+        m.load_state_dict(synth_state_dict(shapes, seed))
+        m.eval()
+        return m, shapes
+
+    with torch.no_grad():
+        # SemanticTransformer, 1 residual stream (100 % reference code), relative position bias
+        ctor = dict(dim=64, depth=2, num_semantic_tokens=20, num_residual_streams=1)
+        m, shapes = build(A.SemanticTransformer, ctor, 41)
+        ids = R(20, (2, 9), 41)
+        calls, kv = [], None
+        for n in (6, 7, 8, 9):
+            lg, kv = m(ids=ids[:, :n], kv_cache=kv, return_kv_cache=True)
+            calls.append(dict(n=n, logits=lg.clone(), kv_shape=tuple(kv.shape)))
+        out['models']['semantic'] = dict(ctor=ctor, shapes=shapes, seed=41, ids=ids, calls=calls, kv=kv.clone())
+
+        # CoarseTransformer, 4 streams (restated hyper-connections around the reference's own cache code), bias + cross_attn_bias
+        ctor = dict(dim=64, depth=2, num_semantic_tokens=6, codebook_size=16, num_coarse_quantizers=3)
+        m, shapes = build(A.CoarseTransformer, ctor, 42)
+        sem, coarse = R(6, (2, 7), 42), R(16, (2, 8), 43)
+        calls, kv, em = [], None, None
+        for n in (4, 5, 6, 7):
+            (sl, cl), (kv, em) = m(semantic_token_ids=sem, coarse_token_ids=coarse[:, :n], kv_cache=kv, embed_cache=em, return_cache=True)
+            calls.append(dict(n=n, semantic_logits=sl.clone(), coarse_logits=cl.clone(), kv_shape=tuple(kv.shape), embed_shape=tuple(em.shape)))
+        out['models']['coarse'] = dict(ctor=ctor, shapes=shapes, seed=42, sem=sem, coarse=coarse, calls=calls, kv=kv.clone(), embed=em.clone())
+
+        # FineTransformer, 1 stream, flash (no bias), conditioned (cross-attention) and GUIDED: stacked [cond, null] caches
+        ctor = dict(dim=64, depth=2, codebook_size=16, num_coarse_quantizers=3, num_fine_quantizers=5, num_residual_streams=1, flash_attn=True,
+                    has_condition=True, cond_dim=24)
+        m, shapes = build(A.FineTransformer, ctor, 44)
+        coarse, fine = R(16, (2, 6), 44), R(16, (2, 9), 45)
+        te = torch.randn(2, 4, 24, generator=torch.Generator().manual_seed(46))
+        calls, kv, em = [], None, None
+        for n in (5, 6, 7):
+            (cl, fl), (kv, em) = m.forward_with_cond_scale(coarse, fine[:, :n], text_embeds=te, cond_scale=3., kv_cache=kv, embed_cache=em,
+                                                           return_kv_cache=True)
+            calls.append(dict(n=n, coarse_logits=cl.clone(), fine_logits=fl.clone(), kv_shape=tuple(kv.shape), embed_shape=tuple(em.shape)))
+        out['models']['fine_guided'] = dict(ctor=ctor, shapes=shapes, seed=44, coarse=coarse, fine=fine, text_embeds=te, cond_scale=3., calls=calls,
+                                            kv=kv.clone(), embed=em.clone())
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'signatures':
         signatures_case()
@@ -312,6 +363,14 @@ def main():
         return
     R = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
     cases = []
+    if len(sys.argv) > 1 and sys.argv[1] == 'cache':                   # the kv / embed cache protocol fixture only (added in round 2)
+        c = cache_protocol_case(R)
+        path = os.path.join(HERE, c['name'] + '.pt')
+        torch.save(c, path)
+        for k, v in c['models'].items():
+            print(k, [cc.get('kv_shape') for cc in v['calls']], [cc.get('embed_shape') for cc in v['calls']])
+        print(f'{c["name"]} {os.path.getsize(path) / 1024:.1f} KiB')
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'cond':                    # the conditioning fixtures only (added in round 2)
         cases = cond_cases(R)
         for c in cases:
