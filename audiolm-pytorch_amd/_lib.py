@@ -88,6 +88,9 @@ SIGNATURES = {
     'alm_rvq_pack': [_P, _P, _P, _I, _I, _I, _P],
     'alm_rvq_encode': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     'alm_bct_to_btc': [_P, _P, _I, _I, _I, _P],
+    'alm_layernorm_bct': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    'alm_geglu_bct': [_P, _P, _I, _I, _I, _P],
+    'alm_local_attn': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
 }
 
 _lib = None

@@ -687,3 +687,37 @@ def bct_to_btc(x):
     out = torch.empty((B, T, C), dtype=F32, device=x.device)
     _lib.call('alm_bct_to_btc', x.data_ptr(), out.data_ptr(), B, C, T, _st())
     return out
+
+
+# ---- SoundStream LocalTransformer (csrc/local_attn.hip), fp32, codec layout [B, C, T]
+
+def layernorm_bct(x, gamma, beta, eps=1e-5):
+    _chk(x, F32)
+    B, C, T = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.call('alm_layernorm_bct', x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, C, T, float(eps), _st())
+    return out
+
+
+def geglu_bct(x):
+    """x fp32 [B, 2 I, T] -> [B, I, T]: x[:, :I] * gelu(x[:, I:])"""
+    _chk(x, F32)
+    B, C2, T = x.shape
+    assert x.is_contiguous() and C2 % 2 == 0
+    out = torch.empty((B, C2 // 2, T), dtype=F32, device=x.device)
+    _lib.call('alm_geglu_bct', x.data_ptr(), out.data_ptr(), B, C2 // 2, T, _st())
+    return out
+
+
+def local_attn(qkv, q_scale, k_scale, cos_t, sin_t, xpos_t, gates, heads, dim_head, window, scale):
+    """qkv fp32 [B, 3 H dh, T], gates fp32 [B, H, T] | None, slot tables [2 window, dh] -> [B, H dh, T]"""
+    _chk(qkv, F32)
+    B, C3, T = qkv.shape
+    assert qkv.is_contiguous() and C3 == 3 * heads * dim_head
+    for t in (cos_t, sin_t, xpos_t):
+        assert t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (2 * window, dim_head) and t.device == qkv.device
+    out = torch.empty((B, heads * dim_head, T), dtype=F32, device=qkv.device)
+    _lib.call('alm_local_attn', qkv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), xpos_t.data_ptr(), _p(gates),
+              out.data_ptr(), B, heads, dim_head, T, window, float(scale), _st())
+    return out

@@ -1,9 +1,12 @@
 """Mirror of the reference's `audiolm_pytorch/soundstream.py` for the TOKENIZE path and the DECODE path
-(§8(f) item 3, without local attention): `SoundStream.tokenize(audio)`, `SoundStream.forward(x, return_encoded=True |
+(§8(f) item 3, incl. the LocalTransformer of the reference-default `use_local_attn=True`): `SoundStream.tokenize(audio)`, `SoundStream.forward(x, return_encoded=True |
 return_codes_only=True)` -- the causal-conv encoder (soundstream.py:332-380, 519-531) and the eval-mode forward of the grouped residual VQ
 (soundstream.py:592-607, :840) -- and `decode_from_codebook_indices` / `decode` (soundstream.py:691-709: code lookup, transposed-conv
 decoder :347-360, 382-395, 615-627) run on the MI355X kernels of csrc/codec.hip (exact-fp32 MFMA).  Everything else the reference class
-does (discriminators, losses, training of the codec, local attention, LFQ / FSQ quantizers) is out of scope and raises.
+does (discriminators, losses, training of the codec, LFQ / FSQ quantizers) is out of scope and raises.
+`encoder_attn` / `decoder_attn` (soundstream.py:397-440, 545, 613): local-attention's LocalMHA + FeedForward (third-party source, not vendored:
+restated, parity unpinned -- oracle/local_attention_restated.py) run in the codec's [B, C, T] layout: LayerNorm / windowed causal attention with
+qk-l2norm, rotary + xpos and per-head value gates / GEGLU are csrc/local_attn.hip, the Linear layers are k = 1 convs on the exact-fp32 MFMA kernel.
 
 The module tree keeps the reference's parameter / buffer NAMES for the parts it has, so `state_dict()` entries `encoder.*` and
 `rq.*` of a reference checkpoint load with `load_state_dict(..., strict=False)`:
@@ -11,6 +14,8 @@ The module tree keeps the reference's parameter / buffer NAMES for the parts it 
     encoder.{b}.{r}.fn.{0,2}.conv.{weight,bias}         ResidualUnit r of EncoderBlock b (k7 dilated conv, ELU, k1 conv, ELU, + x)
     encoder.{b}.3.conv.{weight,bias}                    strided down-sampling conv (k = 2 * stride)
     encoder.{last}.conv.{weight,bias}                   CausalConv1d(-> codebook_dim, 3)
+    {encoder,decoder}_attn.layers.{i}.0.{norm.{weight,bias}, to_qkv.weight, q_scale, k_scale, attn_fn.rel_pos.inv_freq, to_v_gate.0.{weight,bias},
+                                         to_out.weight}   LocalMHA;   .layers.{i}.1.{0.{weight,bias}, 1.weight, 4.weight}   FeedForward
     decoder.0.conv / decoder.{b}.0.conv (ConvTranspose1d) / decoder.{b}.{1,2,3}.fn.{0,2}.conv / decoder.{last}.conv
     rq.rvqs.{g}.layers.{q}._codebook.{initted, cluster_size, embed_avg, embed (1, C, d)}
 """
@@ -199,6 +204,124 @@ class GroupedResidualVQ(nn.Module):
         return out.view(b, n, self.dim)
 
 
+# ---------------------------------------------------------------------------------------------- LocalTransformer (soundstream.py:397-440)
+
+class _Linear1x1:
+    """an nn.Linear applied along the channel axis of [B, C, T] = a k = 1 conv on the exact-fp32 MFMA kernel; packed weight cached per version"""
+
+    def __init__(self):
+        self._packed = None
+
+    def __call__(self, lin, x, residual=None):
+        w, b = lin.weight, lin.bias
+        ver = (w.data_ptr(), core.tensor_version(w), None if b is None else core.tensor_version(b))
+        if self._packed is None or self._packed[0] != ver:
+            bias = b.detach().to(F32).contiguous() if b is not None else torch.zeros(w.shape[0], dtype=F32, device=w.device)
+            self._packed = (ver, ops.conv1d_pack(w.detach().to(F32).unsqueeze(-1).contiguous()), bias)
+        return ops.conv1d_causal(x, self._packed[1], self._packed[2], w.shape[0], 1, residual=residual)
+
+
+class _SinusoidalEmbeddings(nn.Module):                          # local-attention rotary.py (holder of the `inv_freq` buffer)
+    def __init__(self, dim, scale_base, theta=10000):
+        super().__init__()
+        self.register_buffer('inv_freq', 1. / (theta ** (torch.arange(0, dim, 2).float() / dim)))
+        self.dim, self.scale_base = dim, scale_base
+
+    def tables(self, slots, device):
+        """rotary angle cos / sin and the xpos scale for slots 0 .. slots-1 of the (look-back | own) window pair, fp32 [slots, dim] each,
+        computed on the host exactly like the library does (t * inv_freq, scale ** ((t - slots // 2) / scale_base))"""
+        inv = self.inv_freq.detach().float().cpu()
+        t = torch.arange(slots).float()
+        freqs = torch.einsum('i,j->ij', t, inv)
+        freqs = torch.cat((freqs, freqs), dim=-1)
+        base = (torch.arange(0, self.dim, 2) + 0.4 * self.dim) / (1.4 * self.dim)
+        scale = base ** ((t - (slots // 2)) / self.scale_base)[:, None]
+        scale = torch.cat((scale, scale), dim=-1)
+        return tuple(x.float().contiguous().to(device) for x in (freqs.cos(), freqs.sin(), scale))
+
+
+class _LocalAttention(nn.Module):
+    def __init__(self, dim_head, window_size, xpos_scale_base):
+        super().__init__()
+        self.rel_pos = _SinusoidalEmbeddings(dim_head, scale_base=xpos_scale_base if xpos_scale_base is not None else window_size // 2)
+
+
+class LocalMHA(nn.Module):
+    """local-attention's LocalMHA in the one configuration the reference builds (soundstream.py:418-427): prenorm LayerNorm, causal, look-back of
+    one window with the exact window size, qk_rmsnorm (attention scale 8), rotary + xpos, per-head sigmoid value gates."""
+
+    def __init__(self, *, dim, window_size, dim_head=64, heads=8, xpos_scale_base=None, qk_scale=8):
+        super().__init__()
+        inner = dim_head * heads
+        self.norm = nn.LayerNorm(dim)
+        self.heads, self.dim_head, self.window_size, self.qk_scale = heads, dim_head, window_size, qk_scale
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.q_scale = nn.Parameter(torch.ones(dim_head))
+        self.k_scale = nn.Parameter(torch.ones(dim_head))
+        self.attn_fn = _LocalAttention(dim_head, window_size, xpos_scale_base)
+        self.to_v_gate = nn.Sequential(nn.Linear(dim, heads))
+        self.to_out = nn.Linear(inner, dim, bias=False)
+        self._lin = [_Linear1x1() for _ in range(3)]
+        self._tables = None
+
+    def run(self, x, add_residual=True):
+        """x fp32 [B, dim, T] -> attn(x) (+ x), same layout"""
+        inv = self.attn_fn.rel_pos.inv_freq
+        key = (inv.data_ptr(), core.tensor_version(inv), x.device)
+        if self._tables is None or self._tables[0] != key:
+            self._tables = (key, self.attn_fn.rel_pos.tables(2 * self.window_size, x.device))
+        cos_t, sin_t, xpos_t = self._tables[1]
+        xn = ops.layernorm_bct(x, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps)
+        qkv = self._lin[0](self.to_qkv, xn)
+        gates = self._lin[1](self.to_v_gate[0], xn)                      # from the NORMED input (LocalMHA.forward re-binds x)
+        o = ops.local_attn(qkv, self.q_scale.detach(), self.k_scale.detach(), cos_t, sin_t, xpos_t, gates, self.heads, self.dim_head,
+                           self.window_size, self.qk_scale)
+        return self._lin[2](self.to_out, o, residual=x if add_residual else None)
+
+    def forward(self, x):
+        """reference layout: x (b, n, dim) -> attention output WITHOUT the residual (the caller adds it, soundstream.py:437)"""
+        return ops.bct_to_btc(self.run(ops.bct_to_btc(x.to(F32).contiguous()), add_residual=False))      # (n, c) -> (c, n) and back
+
+
+class _GEGLU(nn.Module):
+    def forward(self, x):
+        raise NotImplementedError('runs fused inside LocalTransformer (csrc/local_attn.hip alm_geglu_bct)')
+
+
+def _local_feed_forward(dim, mult=4):                                # local_attention.transformer.FeedForward: same Sequential indices
+    inner = int(dim * mult * 2 / 3)
+    return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner * 2, bias=False), _GEGLU(), nn.Dropout(0.), nn.Linear(inner, dim, bias=False))
+
+
+class LocalTransformer(nn.Module):
+    def __init__(self, *, dim, depth, heads, window_size, dynamic_pos_bias=False, **kwargs):
+        super().__init__()
+        if dynamic_pos_bias:
+            raise NotImplementedError('attn_dynamic_pos_bias=True (DynamicPositionBias instead of rotary) is not implemented (reference default False)')
+        kwargs.pop('prenorm', None), kwargs.pop('causal', None)           # always True in the reference (soundstream.py:541-542)
+        self.window_size = window_size
+        self.pos_bias = None
+        self.layers = nn.ModuleList([nn.ModuleList([LocalMHA(dim=dim, heads=heads, window_size=window_size, **kwargs), _local_feed_forward(dim)])
+                                     for _ in range(depth)])
+        self._ff_lin = [[_Linear1x1(), _Linear1x1()] for _ in range(depth)]
+
+    def run_bct(self, x):
+        """x fp32 [B, dim, T] (codec layout) -> same: x = attn(x) + x; x = ff(x) + x per layer (soundstream.py:436-438)"""
+        for (attn, ff), lins in zip(self.layers, self._ff_lin):
+            x = attn.run(x)
+            h = ops.layernorm_bct(x, ff[0].weight.detach(), ff[0].bias.detach(), ff[0].eps)
+            h = ops.geglu_bct(lins[0](ff[1], h))
+            x = lins[1](ff[4], h, residual=x)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (b, n, dim) -> (b, n, dim)"""
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd.SoundStream runs on the MI355X only (no CPU fallback)')
+        return ops.bct_to_btc(self.run_bct(ops.bct_to_btc(x.to(F32).contiguous())))
+
+
 def curtail_to_multiple(t, mult, from_left=False):               # soundstream.py:86-90
     data_len = t.shape[-1]
     rounded = (data_len // mult) * mult
@@ -212,10 +335,9 @@ class SoundStream(nn.Module):
                  finite_scalar_quantizer_levels=None, rq_num_quantizers=8, rq_commitment_weight=1., rq_ema_decay=0.95,
                  rq_quantize_dropout_multiple_of=1, rq_groups=1, rq_stochastic_sample_codes=False, rq_rotation_trick=True, rq_kwargs: dict = {},
                  use_lookup_free_quantizer=False, use_finite_scalar_quantizer=False, input_channels=1, enc_cycle_dilations=(1, 3, 9),
-                 target_sample_hz=16000, use_local_attn=True, use_gate_loop_layers=False, squeeze_excite=False, pad_mode='reflect', **kwargs):
+                 target_sample_hz=16000, use_local_attn=True, attn_window_size=128, attn_dim_head=64, attn_heads=8, attn_depth=1,
+                 attn_xpos_scale_base=None, attn_dynamic_pos_bias=False, use_gate_loop_layers=False, squeeze_excite=False, pad_mode='reflect', **kwargs):
         super().__init__()
-        if use_local_attn:
-            raise NotImplementedError('encoder local attention (soundstream.py:414-429) is SURVEY.md §8(f) item 3: construct with use_local_attn=False')
         if use_lookup_free_quantizer or use_finite_scalar_quantizer or finite_scalar_quantizer_levels is not None:
             raise NotImplementedError('LFQ / FSQ quantizers are out of scope (SURVEY.md §2)')
         if use_gate_loop_layers or squeeze_excite or rq_stochastic_sample_codes:
@@ -229,8 +351,10 @@ class SoundStream(nn.Module):
         blocks = [EncoderBlock(ci, co, s, enc_cycle_dilations, squeeze_excite, pad_mode) for (ci, co), s in zip(pairs, strides)]
         self.encoder = nn.Sequential(CausalConv1d(input_channels, channels, 7, pad_mode=pad_mode), *blocks,
                                      CausalConv1d(layer_channels[-1], codebook_dim, 3, pad_mode=pad_mode))
-        self.encoder_attn = None
-        self.decoder_attn = None
+        attn_kwargs = dict(dim=codebook_dim, dim_head=attn_dim_head, heads=attn_heads, depth=attn_depth, window_size=attn_window_size,
+                           xpos_scale_base=attn_xpos_scale_base, dynamic_pos_bias=attn_dynamic_pos_bias, prenorm=True, causal=True)   # soundstream.py:533-543
+        self.encoder_attn = LocalTransformer(**attn_kwargs) if use_local_attn else None
+        self.decoder_attn = LocalTransformer(**attn_kwargs) if use_local_attn else None
         dec_cycle_dilations = kwargs.pop('dec_cycle_dilations', (1, 3, 9))          # remaining kwargs: attention / discriminator / loss options of
                                                                                     # the parts that are not built here (ignored, like before)
         dblocks = [DecoderBlock(co, ci, s, dec_cycle_dilations, squeeze_excite, pad_mode) for (ci, co), s in reversed(tuple(zip(pairs, strides)))]
@@ -274,6 +398,8 @@ class SoundStream(nn.Module):
             else:
                 for sub in layer:
                     h = sub(h) if isinstance(sub, _ResidualFn) else sub.run(h)
+        if self.encoder_attn is not None:                        # :830-833 ('b c n -> b n c' first there; here the layout is kept)
+            h = self.encoder_attn.run_bct(h)
         return ops.bct_to_btc(h)
 
     @torch.no_grad()
@@ -300,7 +426,7 @@ class SoundStream(nn.Module):
         b, n = indices.shape[1], indices.shape[2]
         if return_encoded:
             return quantized, indices.permute(1, 2, 0, 3).reshape(b, n, -1), commit_loss          # 'g b n q -> b n (g q)', :851
-        recon = self.decode(quantized)                           # :857-866 (no decoder_attn: use_local_attn=False), unpack(recon_x, ps, '* c n')
+        recon = self.decode(quantized)                           # :857-866, unpack(recon_x, ps, '* c n')
         return recon.reshape(*lead, recon.shape[-2], recon.shape[-1])
 
     @torch.no_grad()
@@ -319,6 +445,8 @@ class SoundStream(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd.SoundStream runs on the MI355X only (no CPU fallback)')
         h = ops.bct_to_btc(x.to(F32).contiguous())                           # the same per-batch 2-D transpose, applied to (n, c) -> (c, n)
+        if self.decoder_attn is not None:                                    # :705-706
+            h = self.decoder_attn.run_bct(h)
         for layer in self.decoder:
             if isinstance(layer, CausalConv1d):
                 h = layer.run(h)

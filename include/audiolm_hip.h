@@ -260,6 +260,18 @@ int alm_rvq_pack(const float* E, float* Et, float* e2, int Q, int C, int d, void
 int alm_rvq_encode(const float* x, long long ldx, const float* E, const float* Et, const float* e2, long long* idx, long long ldi, float* quant,
                    long long ldq, int T, int d, int C, int Q, void* stream);
 int alm_bct_to_btc(const float* in, float* out, int B, int C, int T, void* stream);   /* 'b c n -> b n c', soundstream.py:823 */
+/* SoundStream LocalTransformer (soundstream.py:397-440 = local-attention's LocalMHA + FeedForward; third-party, restated), fp32, in the codec's
+ * [B][C][T] layout; the Linear layers are k = 1 alm_conv1d_causal calls.
+ *   alm_layernorm_bct : nn.LayerNorm over the channel axis (weight gamma, bias beta)
+ *   alm_geglu_bct     : out[b][i][t] = x[b][i][t] * gelu(x[b][I + i][t])                          (x [B][2 I][T])
+ *   alm_local_attn    : qkv [B][3 H dh][T] (q | k | v channel blocks) -> out [B][H dh][T]: l2-normalised q / k times q_scale / k_scale [dh]
+ *                       (qk_rmsnorm) and `scale`, rotary + xpos from the slot tables cos_t / sin_t / xpos_t [2 window][dh] (slot s of the
+ *                       (look-back | own) window pair; queries sit in slots window .. 2 window - 1), key j visible to query i iff
+ *                       0 <= i - j <= window, softmax, values, times sigmoid(gates [B][H][T]) (gates may be NULL).  dh in {32, 64}, window <= 256. */
+int alm_layernorm_bct(const float* x, const float* gamma, const float* beta, float* out, int B, int C, int T, float eps, void* stream);
+int alm_geglu_bct(const float* x, float* out, int B, int I, int T, void* stream);
+int alm_local_attn(const float* qkv, const float* q_scale, const float* k_scale, const float* cos_t, const float* sin_t, const float* xpos_t,
+                   const float* gates, float* out, int B, int H, int dim_head, int T, int window, float scale, void* stream);
 
 #ifdef __cplusplus
 }

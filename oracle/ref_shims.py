@@ -7,7 +7,8 @@ Recipe = SURVEY.md Appendix B (verified in the build container):
  1. import transformers BEFORE stubbing (it probes torchaudio.__spec__)
  2. sys.modules stubs for the third-party packages that are not installed
     (beartype, torchaudio, fairseq, encodec, local_attention, gateloop_transformer,
-     vector_quantize_pytorch -> oracle/rvq_restated.py, hyper_connections -> oracle/hyper_connections_restated.py)
+     vector_quantize_pytorch -> oracle/rvq_restated.py, hyper_connections -> oracle/hyper_connections_restated.py,
+     local_attention -> oracle/local_attention_restated.py)
  3. bypass audiolm_pytorch/__init__.py (it imports trainer.py -> wandb, ema_pytorch, ...)
  4. get_encoded_dim -> 768 (constructor otherwise hits the HF hub; audiolm_pytorch.py:604/776/1042)
 """
@@ -57,6 +58,7 @@ def load_reference():
         sys.path.insert(0, here)
     import hyper_connections_restated
     import rvq_restated
+    import local_attention_restated
 
     ident = lambda f=None, *a, **k: f if callable(f) else (lambda g: g)
     _mod('beartype', beartype=ident)
@@ -86,8 +88,9 @@ def load_reference():
         def __init__(self, *a, **k):
             raise NotImplementedError('third-party module not installed and not restated')
 
-    la = _mod('local_attention', LocalMHA=_Absent)
-    la.transformer = _mod('local_attention.transformer', FeedForward=_Absent, DynamicPositionBias=_Absent)
+    la = _mod('local_attention', LocalMHA=local_attention_restated.LocalMHA)
+    la.transformer = _mod('local_attention.transformer', FeedForward=local_attention_restated.FeedForward,
+                          DynamicPositionBias=local_attention_restated.DynamicPositionBias)
     _mod('gateloop_transformer', SimpleGateLoopLayer=_Absent)
     _mod('vector_quantize_pytorch', GroupedResidualVQ=rvq_restated.GroupedResidualVQ,
          GroupedResidualLFQ=rvq_restated.GroupedResidualLFQ, GroupedResidualFSQ=rvq_restated.GroupedResidualFSQ,

@@ -234,6 +234,40 @@ def soundstream_decode_case():
                 inputs=dict(indices=indices), outputs=dict(wave=wave))
 
 
+def soundstream_local_attn_case():
+    """The REAL reference SoundStream in its DEFAULT form (use_local_attn=True, soundstream.py:545, 613, 830-833, 705-706) around the RESTATED
+    local-attention modules (oracle/local_attention_restated.py; third-party source not vendored -> restated=True): tokenize + decode.
+    150 frames at window 64: two full windows and a ragged third one (autopad); every attention / feed-forward parameter non-trivial."""
+    torch.manual_seed(0)
+    ctor = dict(codebook_size=32, rq_num_quantizers=4, channels=4, codebook_dim=16, strides=(2, 4, 5, 8), target_sample_hz=16000,
+                attn_window_size=64, attn_dim_head=32, attn_heads=2, attn_depth=2)
+    ss = S.SoundStream(**ctor)
+    full_sd = ss.state_dict()
+    keep = {k: v for k, v in full_sd.items() if k.split('.')[0] in ('encoder', 'decoder', 'rq', 'encoder_attn', 'decoder_attn')}
+    shapes = _shapes(keep)
+    new = synth_state_dict(shapes, 8)
+    for k in list(new):
+        if k.endswith('rel_pos.inv_freq'):
+            new[k] = full_sd[k].clone()                        # the rotary frequencies are a constant buffer, not a parameter
+    full_sd.update(new)
+    ss.load_state_dict(full_sd)
+    ss.eval()
+    g = torch.Generator().manual_seed(13)
+    wave = torch.randn(2, 320 * 150 + 31, generator=g) * 0.3
+    with torch.no_grad():
+        emb, indices, _ = ss(wave, return_encoded=True)
+        codes = ss.tokenize(wave)
+        x, _ = ss.process_input(wave)
+        enc = ss.encoder(x).transpose(1, 2)
+        enc_attn = ss.encoder_attn(enc)
+        mha = ss.encoder_attn.layers[0][0](enc)               # LocalMHA alone (no residual)
+        recon = ss.decode_from_codebook_indices(indices)
+    return dict(name='soundstream_local_attn_small', kind='soundstream_local_attn', ctor=ctor, shapes=shapes, seed=8, restated=True,
+                const_keys=[k for k in shapes if k.endswith('rel_pos.inv_freq')],
+                inputs=dict(wave=wave),
+                outputs=dict(indices=indices, tokenize=codes, encoder_out=enc, encoder_attn_out=enc_attn, mha0_out=mha, quantized=emb, recon=recon))
+
+
 def signatures_case():
     """Constructor / forward / generate parameter lists (name, kind, default) of the REAL reference's boundary classes:
     tests/test_host_logic.py holds this package's mirror against them."""
@@ -355,6 +389,12 @@ def cache_protocol_case(R):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'signatures':
         signatures_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'soundstream_local_attn':  # default-constructor SoundStream (local attention), added in round 2
+        c = soundstream_local_attn_case()
+        torch.save(c, os.path.join(HERE, c['name'] + '.pt'))
+        print(c['name'], {k: tuple(v.shape) for k, v in c['outputs'].items()})
+        print(sorted(k for k in c['shapes'] if 'attn' in k)[:14])
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'soundstream_decode':      # add this fixture without touching the others
         c = soundstream_decode_case()

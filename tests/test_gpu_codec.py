@@ -270,3 +270,84 @@ def test_tokenize_decode_round_trip_shapes_and_generate_reconstruct():
         assert all(w.dim() == 1 for w in out)
     else:
         assert out.shape == (2, 8 * 320)
+
+
+# ---------------------------------------------------------------------------------------------- LocalTransformer
+
+def _state_for(fx, module):
+    sd = synth_state_dict(fx['shapes'], fx['seed'])
+    own = module.state_dict()
+    for k in fx.get('const_keys', ()):
+        sd[k] = own[k].clone()                                      # rotary inv_freq: a constant buffer on both sides
+    return sd
+
+
+@pytest.mark.parametrize('B,T,dim,heads,dh,W,depth', [(2, 300, 512, 8, 64, 128, 1), (1, 129, 64, 2, 32, 64, 2), (3, 64, 48, 3, 32, 64, 1), (1, 1000, 128, 4, 64, 128, 1),
+                                                       (2, 50, 32, 2, 32, 16, 1)])
+def test_local_transformer_vs_restated_library(B, T, dim, heads, dh, W, depth):
+    """soundstream.LocalTransformer (csrc/local_attn.hip: direct form, key j visible iff 0 <= i - j <= window; k = 1 convs for the Linear layers) vs
+    the literal restatement of local-attention's bucketed implementation (oracle/local_attention_restated.py: look_around, pad value -1,
+    causal / exact-window / pad masks, rotary + xpos on the window pair), fp32 on both sides: full windows, a ragged last window (autopad),
+    a sequence shorter than one window, the reference-default geometry (dim 512, 8 heads x 64, window 128)."""
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd import soundstream as SS
+    import local_attention_restated as LR
+
+    class RefLocalTransformer(torch.nn.Module):                     # = the reference's own LocalTransformer.forward (soundstream.py:397-440)
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.ModuleList([
+                LR.LocalMHA(dim=dim, heads=heads, dim_head=dh, qk_rmsnorm=True, window_size=W, use_rotary_pos_emb=True, gate_values_per_head=True,
+                            use_xpos=True, prenorm=True, causal=True), LR.FeedForward(dim=dim)]) for _ in range(depth)])
+
+        def forward(self, x):
+            for attn, ff in self.layers:
+                x = attn(x) + x
+                x = ff(x) + x
+            return x
+    torch.manual_seed(B * 1000 + T)
+    ref = RefLocalTransformer()
+    for n, p in ref.named_parameters():                             # non-trivial norms / scales / gates
+        with torch.no_grad():
+            if p.dim() == 1:
+                p.copy_(1.0 + 0.3 * torch.randn_like(p) if ('scale' in n or n.endswith('weight')) else 0.2 * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) * p.shape[1] ** -0.5)
+    ours = SS.LocalTransformer(dim=dim, depth=depth, heads=heads, window_size=W, dim_head=dh, prenorm=True, causal=True)
+    missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)    # same parameter / buffer names as the library modules
+    ours.to(dev())
+    x = rnd(B, T, dim, seed=T)
+    with torch.no_grad():
+        want = ref(x)
+        want_mha = ref.layers[0][0](x)
+    got = ours(x.to(dev()))
+    assert relmax(got, want) <= 3e-5, relmax(got, want)
+    assert relmax(ours.layers[0][0](x.to(dev())), want_mha) <= 3e-5
+
+
+def test_soundstream_default_ctor_local_attention_golden():
+    """tests/golden/soundstream_local_attn_small.pt: the REAL reference SoundStream with its default use_local_attn=True (soundstream.py:545, 613,
+    830-833, 705-706) around the restated local-attention modules: encoder + encoder_attn output, every code index, and the decoded wave."""
+    import audiolm_pytorch_amd as A
+    fx = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_local_attn_small.pt'), weights_only=False)
+    ss = A.SoundStream(**fx['ctor'])
+    assert ss.encoder_attn is not None and ss.decoder_attn is not None
+    assert {k: tuple(v.shape) for k, v in ss.state_dict().items()} == {k: tuple(v) for k, v in fx['shapes'].items()}
+    ss.load_state_dict(_state_for(fx, ss))
+    ss.to(dev())
+    wave = fx['inputs']['wave'].to(dev())
+    x, _ = ss.process_input(wave)
+    assert relmax(ss.encode(x), fx['outputs']['encoder_attn_out']) <= 3e-5
+    enc = fx['outputs']['encoder_out'].to(dev())
+    assert relmax(ss.encoder_attn(enc), fx['outputs']['encoder_attn_out']) <= 3e-5
+    assert relmax(ss.encoder_attn.layers[0][0](enc), fx['outputs']['mha0_out']) <= 3e-5
+    emb, indices, _ = ss(wave, return_encoded=True)
+    b, n, q = indices.shape
+    cbs = [ss.rq.rvqs[0].layers[i]._codebook.embed[0].detach().cpu() for i in range(q)]
+    _check_indices(indices.reshape(b * n, q).cpu(), fx['outputs']['encoder_attn_out'].reshape(b * n, -1), cbs)
+    same = (indices.cpu() == fx['outputs']['indices']).all(dim=-1).float().mean()
+    assert float(same) >= 0.99, float(same)
+    assert torch.equal(ss.tokenize(wave).cpu()[0], indices.cpu())
+    recon = ss.decode_from_codebook_indices(fx['outputs']['indices'].to(dev()))
+    assert recon.shape == fx['outputs']['recon'].shape and relmax(recon, fx['outputs']['recon']) <= 5e-5

@@ -166,8 +166,13 @@ def test_soundstream_module_tree_matches_reference_state_dict_names():
     want.update({k: tuple(v) for k, v in fd['shapes'].items()})
     assert ours == want, (sorted(set(ours) ^ set(want))[:10])
     assert ss.seq_len_multiple_of == 320 and ss.rq_groups == 1 and ss.num_quantizers == fx['ctor']['rq_num_quantizers']
+    dflt = A.SoundStream(codebook_size=32)                           # the reference-default constructor: use_local_attn=True
+    fl = torch.load(os.path.join(GOLDEN_DIR, 'soundstream_local_attn_small.pt'), weights_only=False)
+    la = A.SoundStream(**fl['ctor'])
+    assert {k: tuple(v.shape) for k, v in la.state_dict().items()} == {k: tuple(v) for k, v in fl['shapes'].items()}   # names / shapes of the REAL reference module tree
+    assert 'encoder_attn.layers.0.0.attn_fn.rel_pos.inv_freq' in dflt.state_dict() and dflt.encoder_attn.layers[0][0].to_qkv.weight.shape == (1536, 512)
     with pytest.raises(NotImplementedError):
-        A.SoundStream(codebook_size=32)                              # reference default use_local_attn=True is SURVEY §8(f)-3
+        A.SoundStream(codebook_size=32, attn_dynamic_pos_bias=True)
     with pytest.raises(RuntimeError):
         ss.tokenize(torch.zeros(1, 640))                              # CPU tensor: no CPU fallback
 
