@@ -94,6 +94,13 @@ prof() {   # $1 = residual dtype, $2 = ALM_ASYNC_WGRAD
 }
 if has prof; then prof fp32 0; fi
 if has profbf; then prof bf16 0; fi
+if has pmc; then
+  for grp in "FETCH_SIZE:fetch_size" "WRITE_SIZE:write_size" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE:mfma_busy" "SQ_INSTS_VALU_MFMA_MOPS_BF16:mfma"; do
+    cnt=${grp%%:*}; nm=${grp##*:}
+    ALM_ASYNC_WGRAD=0 bash scripts/pmc.sh "$cnt" ${tag}_$nm > gpurun_out/${tag}_pmc_$nm.out 2>&1
+    echo "pmc $nm rc=$? t=$((SECONDS-t0))"; head -n 12 gpurun_out/pmc_${tag}_$nm.csv | cut -c1-220
+  done
+fi
 if has rest; then
   timeout 1500 python -m pytest tests/test_gpu_bias.py tests/test_gpu_codec.py tests/test_gpu_generate.py tests/test_gpu_optimizer.py -m gpu -q --tb=short -n 4 --timeout 600 > gpurun_out/${tag}_rest.log 2>&1
   echo "rest rc=$? t=$((SECONDS-t0))"; tail -n 25 gpurun_out/${tag}_rest.log | cut -c1-300
