@@ -47,7 +47,8 @@ SIGNATURES = {
     'alm_silu_bwd': [_P, _P, _P, _L, _P],
     'alm_posmlp_out_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     'alm_posmlp_out_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    'alm_xattn_softmax_fwd': [_P, _L, _P, _P, _F, _P, _L, _P, _P, _I, _I, _I, _I, _P],
+    'alm_xattn_softmax_fwd': [_P, _L, _P, _P, _F, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    'alm_xattn_dbias': [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     'alm_xattn_combine': [_P, _L, _P, _P, _P, _L, _L, _I, _I, _P],
     'alm_xattn_softmax_bwd': [_P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _I, _P],
     'alm_xattn_delta': [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],

@@ -1,16 +1,17 @@
 """Mirror of the reference's `audiolm_pytorch/attend.py` (Attend, attend.py:35-146) on the MI355X flash-MQA kernels.
 
 forward(q (b h n d), k (b n d), v (b n d), mask (b n) bool | None, attn_bias) -> (b h n d); causal multi-query attention with
-d == 64.  The math path's attn_bias (attend.py:118-121) is accepted in its STRUCTURED form (relpos.AttnBias: per-head table + index
-vectors, what RelativePositionBias / the Coarse and Fine transformers build); an arbitrary dense (h, n, n) tensor is refused; dropout must
-be 0.  No (b, h, n, n) tensor is ever materialised and there is no CPU fallback.
+d == 64.  The math path's attn_bias (attend.py:118-121) in its STRUCTURED form (relpos.AttnBias: per-head table + index vectors, what
+RelativePositionBias / the Coarse and Fine transformers build) runs on the flash kernels: no (b, h, n, n) tensor is ever materialised.
+An arbitrary DENSE attn_bias tensor ((h, i, j) or broadcastable to it), and non-causal attention, take the reference's math path as three MFMA
+GEMMs + the row-softmax kernels of csrc/xattn.hip (AttendMathFn: O(n^2) memory, like the reference).  Dropout must be 0.  No CPU fallback.
 """
 from __future__ import annotations
 
 import torch
 from torch import nn
 
-from . import ops, relpos
+from . import ops, relpos, xattn
 
 
 class AttendFn(torch.autograd.Function):
@@ -42,6 +43,41 @@ class AttendFn(torch.autograd.Function):
         return dq, dk, dv, None, None, dtbl
 
 
+class AttendMathFn(torch.autograd.Function):
+    """attend.py:98-146 (flash=False): sim = q k^T * scale (+ attn_bias), key mask, causal triu(j - i + 1), softmax, attn v -- multi-query
+    (k / v (b j d) shared by the heads).  q (b h i d), dense bias fp32 (h, i, j) | None."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, bias, causal):
+        b, h, n, d = q.shape
+        m = k.shape[1]
+        q2 = q.detach().permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
+        k2 = k.detach().to(torch.bfloat16).contiguous()
+        v2 = v.detach().to(torch.bfloat16).contiguous()
+        bd = None if bias is None else bias.detach().to(torch.float32).expand(h, n, m).contiguous()
+        o, lse, saved = xattn.extra_attn_fwd(q2, k2, v2, mask_u8, b, n, h, d, float(d) ** -0.5, bias=bd, causal=causal)
+        ctx.save_for_backward(q2, o)
+        ctx.saved, ctx.shape, ctx.dtypes, ctx.m = saved, (b, h, n, d), (q.dtype, k.dtype, v.dtype), m
+        ctx.bias_meta = None if bias is None else (bias.shape, bias.dtype, bias.requires_grad)
+        return o.view(b, n, h, d).permute(0, 2, 1, 3).to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, o = ctx.saved_tensors
+        b, h, n, d = ctx.shape
+        do = dout.permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
+        nd = xattn.attn_delta(o, do, b, n, h, d)
+        dbias = None
+        if ctx.bias_meta is not None and ctx.bias_meta[2]:
+            dbias = torch.empty((h, n, ctx.m), dtype=torch.float32, device=do.device)
+        dq, dke, dve = xattn.extra_attn_bwd(q2, do, ctx.saved, nd, b, n, h, d, float(d) ** -0.5, dbias=dbias)
+        if dbias is not None:
+            shape, dtype, _ = ctx.bias_meta
+            dbias = dbias.sum_to_size(shape) if tuple(shape) != (h, n, ctx.m) else dbias
+            dbias = dbias.to(dtype)
+        return dq.view(b, n, h, d).permute(0, 2, 1, 3).to(ctx.dtypes[0]), dke.to(ctx.dtypes[1]), dve.to(ctx.dtypes[2]), None, dbias, None
+
+
 class Attend(nn.Module):
     def __init__(self, dropout=0., causal=False, flash=False):
         super().__init__()
@@ -52,13 +88,18 @@ class Attend(nn.Module):
         self.flash = flash
 
     def forward(self, q, k, v, mask=None, attn_bias=None):
-        if attn_bias is not None and not isinstance(attn_bias, relpos.AttnBias):
-            raise NotImplementedError('a dense (h, n, n) attn_bias tensor is not supported: pass the structured relpos.AttnBias')
-        if not self.causal:
-            raise NotImplementedError('only causal attention is on the hot path (audiolm_pytorch.py:452)')
         if self.dropout != 0. and self.training:
             raise NotImplementedError('attention dropout > 0 is not implemented (reference default 0.)')
         if not q.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd.Attend runs on the MI355X only (no CPU fallback)')
         mask_u8 = None if mask is None else mask.to(torch.bool).contiguous().view(torch.uint8)
+        dense = attn_bias is not None and not isinstance(attn_bias, relpos.AttnBias)
+        if dense or not self.causal or k.shape[1] != q.shape[2]:
+            if isinstance(attn_bias, relpos.AttnBias):
+                raise NotImplementedError('the structured relpos.AttnBias belongs to causal self-attention (the flash kernels)')
+            if dense:
+                while attn_bias.dim() > 3:                          # (1, h, i, j)
+                    assert attn_bias.shape[0] == 1, 'one (h, i, j) bias for every sample (attend.py:118-121)'
+                    attn_bias = attn_bias[0]
+            return AttendMathFn.apply(q, k, v, mask_u8, attn_bias if dense else None, self.causal)
         return AttendFn.apply(q, k, v, mask_u8, attn_bias, attn_bias.tbl if attn_bias is not None else None)

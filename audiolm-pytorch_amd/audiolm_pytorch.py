@@ -19,7 +19,8 @@ Conditioning (`has_condition=True`, reference :325-375, :450-455, :640-668, :818
 (xattn.py / csrc/xattn.hip); the T5 text encoder is out of scope (`text=` raises).
 The reference's stacked kv_cache= / embed_cache= TENSOR protocol is accepted on forward() / forward_with_cond_scale()
 (Transformer.forward_kv_protocol: the one-new-token step runs the same single-position kernels); generate() drives the native cache directly.
-Not accepted (NotImplementedError, nothing falls back silently): dense `attn_bias` tensors, dropout > 0.
+An arbitrary dense `attn_bias` tensor takes the reference's O(n^2) math path (relpos.DenseBias, xattn.py) instead of the flash kernels.
+Not accepted (NotImplementedError, nothing falls back silently): dropout > 0.
 Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
@@ -430,9 +431,10 @@ class Transformer(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only: move the model and its inputs to cuda (no CPU fallback)')
         b, n, d = x.shape
-        if exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias):
-            raise NotImplementedError('a dense (h, n, n) attn_bias tensor is not supported: pass the structured relpos.AttnBias '
-                                      '(RelativePositionBias.forward / FineTransformer build it) -- the kernels index the bias table in place')
+        if exists(attn_bias) and not isinstance(attn_bias, (relpos.AttnBias, relpos.DenseBias)):
+            # an arbitrary dense bias (reference :500-503 takes any tensor): the O(n^2) math path (xattn.py); the model family's own biases are
+            # structured (RelativePositionBias.forward / FineTransformer build relpos.AttnBias) and stay on the flash kernels
+            attn_bias = relpos.DenseBias.wrap(attn_bias, self.cfg.heads, n)
         if not exists(attn_bias) and exists(self.rel_pos_bias):
             attn_bias = self.rel_pos_bias(n, n)                                                   # :500-503
         mask_u8 = None
@@ -467,7 +469,7 @@ class Transformer(nn.Module):
             cache_len = kv_cache.shape[-2]
             assert cache_len <= n
         if exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias):
-            raise NotImplementedError('a dense (h, n, n) attn_bias tensor is not supported: pass the structured relpos.AttnBias')
+            raise NotImplementedError('the kv-cache protocol takes the structured relpos.AttnBias only (a dense attn_bias runs through forward())')
         if not exists(attn_bias) and exists(self.rel_pos_bias):
             attn_bias = self.rel_pos_bias(n, n)
         tbl = attn_bias.tbl if exists(attn_bias) else None

@@ -19,7 +19,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import ops, xattn
+from . import ops, relpos, xattn
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -234,10 +234,17 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
         if st['kvp0'] is None:
             st['kvp0'] = KVp
         pre = dict(KVp=KVp, ke=KVp[:, :dh].reshape(B, m, dh), ve=Vp.reshape(B, m, dh), pmixed=pmixed)
+    dense = isinstance(bias, relpos.DenseBias)
+    if dense and (pre is not None or decode is not None):
+        raise NotImplementedError('a dense attn_bias tensor with prefix conditioning or a kv cache is not implemented (the structured relpos.AttnBias is)')
     if decode is not None:
         assert pre is None, 'the reference turns the kv cache off for prefix conditioning (audiolm_pytorch.py:481-482)'
         kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
         AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias, pos_dev=decode.pos_dev), None
+    elif dense:
+        # an arbitrary dense attn_bias (reference math path, attend.py:98-146): GEMM scores + bias + causal / key mask + softmax + GEMM values
+        AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, K.reshape(B, N, dh), V.reshape(B, N, dh), mask_u8, B, N, H, dh, float(dh) ** -0.5,
+                                                    bias=bias.tbl, causal=True)
     else:
         AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
         if pre is not None:
@@ -448,7 +455,9 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     acc_vp0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.prefix) else None
     acc_vc0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.cross_attend) else None
     dctx = None                                                                # fp32 [B*m, Dc], summed over layers
-    dtbl_part = ops.attn_bias_part(B, N, H, bias.tbl.shape[1], dev) if bias is not None else None
+    dense = isinstance(bias, relpos.DenseBias)
+    dtbl_part = ops.attn_bias_part(B, N, H, bias.tbl.shape[1], dev) if (bias is not None and not dense) else None
+    ddense = torch.zeros_like(bias.tbl) if dense else None                     # gradient of a dense attn_bias, summed over the layers
     # S > 1: dR = gradient wrt the residual streams after the current branch; right after the final stream sum it is dxs for every
     # stream (`bcast`).  dY / dbeta (depth-connection backward of the branch about to be processed) are produced one step ahead by the
     # fused kernels.
@@ -526,7 +535,14 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo), dYs, AOs, dWo)
             KV = sv['KV']
             # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
-            dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
+            if dense:
+                nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
+                dbl = torch.empty_like(ddense)
+                dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, sv['dense'], nd, B, N, H, dh, scale, dbias=dbl)
+                ddense += dbl
+                dkv32 = torch.cat((dke.reshape(M, dh), dve.reshape(M, dh)), dim=1).contiguous()
+            else:
+                dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
             dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh)
             dKVp = None
             pre = sv['pre']
@@ -579,7 +595,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             side.run_after_all(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
     dx = dR.view(B, N, D)
-    dtbl = ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None
+    dtbl = ddense if dense else (ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None)
     side.join()                                    # autograd hands the gradients to consumers on the main stream
     return dx, grads, dtbl, dctx
 

@@ -10,6 +10,10 @@
 // Backward: with the JOINT lse and the JOINT output O (delta = rowsum(dO o O)), dS_e = P_e o (dP_e - delta) * scale is exact for the extra
 // keys, and the flash backward kernels given the same lse / O are exact for the self keys.
 // Row r = (b * N + n) * H + h  <->  statistics index (b * H + h) * N + n  (the flash kernels' [B][H][N] layout).
+//   * the reference's MATH path with an arbitrary DENSE `attn_bias` tensor (attend.py:98-146: sim = q k^T * scale + attn_bias, key mask, causal
+//     triu(j - i + 1), softmax, attn v): the same three GEMMs over the sequence's own keys with `bias` [H][N][ldbias] added to the scaled scores
+//     and the causal rule "key e visible to query n iff e <= n + causal_off" (causal_off = Me - N; INT_MAX: not causal) -- O(N^2) memory like
+//     the reference's math path; the structured biases of the model family never take it (attention.hip indexes their table in place).
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -20,6 +24,7 @@ namespace {
 __global__ __launch_bounds__(256) void extra_softmax_fwd_kernel(const float* __restrict__ S, long long ldS, const uint8_t* __restrict__ emask,
                                                                 const float* __restrict__ lse_self, float scale, bf16_t* __restrict__ P,
                                                                 long long ldP, float* __restrict__ lse_tot, float* __restrict__ fself,
+                                                                const float* __restrict__ bias, long long ldbias, int causal_off,
                                                                 int B, int N, int H, int Me) {
     const int lane = threadIdx.x & 63;
     const long long rows = (long long)B * N * H;
@@ -30,14 +35,16 @@ __global__ __launch_bounds__(256) void extra_softmax_fwd_kernel(const float* __r
         const long long si = ((long long)b * H + h) * N + n;
         const float* sp = S + r * ldS;
         const uint8_t* mp = emask ? emask + (long long)b * Me : nullptr;
+        const float* bp = bias ? bias + ((long long)h * N + n) * ldbias : nullptr;
+        const int elast = (causal_off == 0x7fffffff) ? Me - 1 : min(Me - 1, n + causal_off);     // last visible key of this query
         float mx = -INFINITY;
-        for (int e = lane; e < Me; e += 64)
-            if (!mp || mp[e]) mx = fmaxf(mx, sp[e] * scale);
+        for (int e = lane; e <= elast; e += 64)
+            if (!mp || mp[e]) mx = fmaxf(mx, sp[e] * scale + (bp ? bp[e] : 0.f));
         mx = wave_max(mx);
         float sum = 0.f;
         if (mx != -INFINITY)
-            for (int e = lane; e < Me; e += 64)
-                if (!mp || mp[e]) sum += __expf(sp[e] * scale - mx);
+            for (int e = lane; e <= elast; e += 64)
+                if (!mp || mp[e]) sum += __expf(sp[e] * scale + (bp ? bp[e] : 0.f) - mx);
         sum = wave_sum(sum);
         const float lse_e = (mx == -INFINITY) ? -INFINITY : mx + logf(sum);
         const float ls = lse_self ? lse_self[si] : -INFINITY;
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256) void extra_softmax_fwd_kernel(const float* __r
         bf16_t* pp = P + r * ldP;
         for (int e = lane; e < (int)ldP; e += 64) {
             float v = 0.f;
-            if (e < Me && (!mp || mp[e]) && lt != -INFINITY) v = __expf(sp[e] * scale - lt);
+            if (e <= elast && (!mp || mp[e]) && lt != -INFINITY) v = __expf(sp[e] * scale + (bp ? bp[e] : 0.f) - lt);
             pp[e] = f2bf(v);
         }
         if (lane == 0) {
@@ -112,15 +119,36 @@ __global__ __launch_bounds__(256) void xattn_delta_kernel(const bf16_t* __restri
     }
 }
 
+// dbias[h][n][e] = sum_b P[r(b, n, h)][e] * (dP[r][e] + ndelta[b][h][n])      (gradient of the dense attn_bias: the un-scaled dS summed over the batch;
+// one wave per (n, h), fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void xattn_dbias_kernel(const bf16_t* __restrict__ P, long long ldP, const float* __restrict__ dP, long long lddP,
+                                                          const float* __restrict__ ndelta, float* __restrict__ dbias, long long lddb, int Me, int B, int N,
+                                                          int H) {
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)N * H;
+    for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < rows; q += (long long)gridDim.x * 4) {
+        const int h = (int)(q % H), n = (int)(q / H);
+        for (int e = lane; e < Me; e += 64) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const long long r = ((long long)b * N + n) * H + h;
+                acc += bf2f(P[r * ldP + e]) * (dP[r * lddP + e] + ndelta[((long long)b * H + h) * N + n]);
+            }
+            dbias[((long long)h * N + n) * lddb + e] = acc;
+        }
+    }
+}
+
 int rows_grid(long long rows) { const long long g = (rows + 3) / 4; return (int)(g < 16384 ? (g < 1 ? 1 : g) : 16384); }
 
 }  // namespace
 
 extern "C" int alm_xattn_softmax_fwd(const float* S, long long ldS, const unsigned char* emask, const float* lse_self, float scale, void* P,
-                                     long long ldP, float* lse_tot, float* fself, int B, int N, int H, int Me, void* stream) {
-    if (Me < 1 || ldS < Me || ldP < Me || !S || !P || !lse_tot) return ALM_ERR_BAD_ARG;
+                                     long long ldP, float* lse_tot, float* fself, const float* bias, long long ldbias, int causal_off, int B, int N,
+                                     int H, int Me, void* stream) {
+    if (Me < 1 || ldS < Me || ldP < Me || !S || !P || !lse_tot || (bias && ldbias < Me)) return ALM_ERR_BAD_ARG;
     hipLaunchKernelGGL(extra_softmax_fwd_kernel, dim3(rows_grid((long long)B * N * H)), dim3(256), 0, (hipStream_t)stream, S, ldS, emask, lse_self,
-                       scale, (bf16_t*)P, ldP, lse_tot, fself, B, N, H, Me);
+                       scale, (bf16_t*)P, ldP, lse_tot, fself, bias, ldbias, causal_off, B, N, H, Me);
     ALM_LAUNCH_CHECK();
     return 0;
 }
@@ -149,6 +177,15 @@ extern "C" int alm_xattn_delta(const void* o, long long ldo, const void* dout, l
                                void* stream) {
     hipLaunchKernelGGL(xattn_delta_kernel, dim3(rows_grid((long long)B * N * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)o, ldo,
                        (const bf16_t*)dout, lddo, ndelta, B, N, H, dim_head);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_xattn_dbias(const void* P, long long ldP, const float* dP, long long lddP, const float* ndelta, float* dbias, long long lddb,
+                               int Me, int B, int N, int H, void* stream) {
+    if (Me < 1 || ldP < Me || lddP < Me || lddb < Me) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(xattn_dbias_kernel, dim3(rows_grid((long long)N * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)P, ldP, dP, lddP, ndelta,
+                       dbias, lddb, Me, B, N, H);
     ALM_LAUNCH_CHECK();
     return 0;
 }

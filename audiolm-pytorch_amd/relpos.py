@@ -48,6 +48,31 @@ class AttnBias:
         return self._host_index()[1]
 
 
+class DenseBias:
+    """An arbitrary dense attn_bias of the reference's math path (attend.py:118-121): tbl fp32 [H, N, N] contiguous, added to the scaled scores.
+    Attention then runs the O(N^2)-memory GEMM path of xattn.py instead of the flash kernels (the model family's own biases never need this:
+    they stay structured, class AttnBias)."""
+
+    def __init__(self, tbl):
+        assert tbl.dim() == 3 and tbl.dtype == F32, (tbl.shape, tbl.dtype)
+        self.tbl = tbl
+
+    @staticmethod
+    def wrap(attn_bias, H, N, Mk=None):
+        """any tensor broadcastable to (H, N, Mk) -> DenseBias (keeps the autograd link of `attn_bias`)"""
+        Mk = N if Mk is None else Mk
+        t = attn_bias.to(F32)
+        while t.dim() < 3:
+            t = t.unsqueeze(0)
+        if t.dim() == 4:                                               # (1, h, i, j)
+            assert t.shape[0] == 1, 'a per-sample attn_bias is not supported (the reference adds one (h, i, j) bias to every sample)'
+            t = t[0]
+        return DenseBias(t.expand(H, N, Mk).contiguous())
+
+    def detached(self):
+        return DenseBias(self.tbl.detach())
+
+
 class PosTableFn(torch.autograd.Function):
     """x fp32 [L, in] (in = 1 | 2), special [H] | None, weights (W0, b0, W1, b1, ..., Wout, bout) -> tbl fp32 [H, L + 1] = MLP(x)^T / scale
     with slot 0 = special / scale.  First / last layers and SiLU: csrc/relpos.hip; the C x C layers: bf16 MFMA GEMMs."""

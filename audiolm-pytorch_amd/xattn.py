@@ -6,6 +6,9 @@ The key set is tens to a few hundred positions and shared by all heads (MQA), so
 run on the bf16 MFMA GEMM (ops.gemm_nt / the TN split-K form), the row-wise softmax pieces are csrc/xattn.hip.  A causal self-attention part
 (flash kernels) is merged through its log-sum-exp; with the JOINT lse / output, both parts' backward formulas stay exact (see xattn.hip).
 
+The same pieces are the reference's MATH path for an arbitrary dense `attn_bias` tensor (attend.py:98-146): keys = the sequence itself, bias fp32
+[H, N, Me] added to the scaled scores, causal rule e <= n + (Me - N) -- O(N^2) memory like the reference's math path (relpos.DenseBias).
+
 Layouts: q / o / do bf16 [B*N, H*dh] (row (b n), column (h d)) == [B, N*H, dh]; ke / ve bf16 [B, Me, dh]; statistics fp32 [B, H, N].
 """
 from __future__ import annotations
@@ -30,8 +33,12 @@ def _transpose_pad(t, Mp):
     return out
 
 
-def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=None):
-    """-> (o bf16 [B*N, H*dh], lse_tot fp32 [B, H, N], saved) ; emask uint8 [B, Me] (1 = attend) | None."""
+NOT_CAUSAL = 0x7fffffff
+
+
+def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=None, bias=None, causal=False):
+    """-> (o bf16 [B*N, H*dh], lse_tot fp32 [B, H, N], saved) ; emask uint8 [B, Me] (1 = attend) | None; bias fp32 [H, N, >= Me] contiguous | None
+    (dense attn_bias, added to the scaled scores); causal: key e visible to query n iff e <= n + (Me - N) (attend.py:131-134)."""
     dev = q.device
     Me = ke.shape[1]
     Mp = _pad8(Me)
@@ -41,8 +48,10 @@ def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=N
     P = torch.empty((B * N * H, Mp), dtype=BF16, device=dev)
     lse = torch.empty((B, H, N), dtype=F32, device=dev)
     fself = torch.empty(B * N * H, dtype=F32, device=dev) if o_self is not None else None
+    if bias is not None:
+        assert bias.dtype == F32 and bias.is_contiguous() and bias.dim() == 3 and bias.shape[0] == H and bias.shape[1] == N and bias.shape[2] >= Me, tuple(bias.shape)
     _lib.call('alm_xattn_softmax_fwd', S.data_ptr(), Mp, ops._p(emask), ops._p(lse_self), float(scale), P.data_ptr(), Mp, lse.data_ptr(), ops._p(fself),
-              B, N, H, Me, ops._st())
+              ops._p(bias), bias.shape[2] if bias is not None else 0, (Me - N) if causal else NOT_CAUSAL, B, N, H, Me, ops._st())
     veT = _transpose_pad(ve, Mp)
     Oe = torch.empty((B, N * H, dh), dtype=F32, device=dev)
     ops.gemm_nt(P.view(B, N * H, Mp), veT, Oe)
@@ -52,15 +61,19 @@ def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=N
     return o, lse, dict(P=P, ke=ke, ve=ve, Me=Me, Mp=Mp)
 
 
-def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None):
+def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None, dbias=None):
     """dout bf16 [B*N, H*dh]; ndelta fp32 [B, H, N] = -rowsum(dO o O_joint).  dq given (the flash backward's bf16 dQ of the self part): the
-    extra part is ACCUMULATED into it; else a new dq is returned.  -> (dq bf16, dke fp32 [B, Me, dh], dve fp32 [B, Me, dh])."""
+    extra part is ACCUMULATED into it; else a new dq is returned.  dbias fp32 [H, N, Me] (contiguous) given: receives the gradient of a dense
+    attn_bias (sum over the batch of the un-scaled dS).  -> (dq bf16, dke fp32 [B, Me, dh], dve fp32 [B, Me, dh])."""
     dev = q.device
     P, ke, ve, Me, Mp = saved['P'], saved['ke'], saved['ve'], saved['Me'], saved['Mp']
     dP = torch.empty((B, N * H, Mp), dtype=F32, device=dev)
     ops.gemm_nt(dout.view(B, N * H, dh), ve, dP[:, :, :Me])
     dS = torch.empty((B * N * H, Mp), dtype=BF16, device=dev)
     _lib.call('alm_xattn_softmax_bwd', P.data_ptr(), Mp, dP.data_ptr(), Mp, ndelta.data_ptr(), float(scale), dS.data_ptr(), Mp, Me, B, N, H, ops._st())
+    if dbias is not None:
+        assert dbias.dtype == F32 and dbias.is_contiguous() and tuple(dbias.shape) == (H, N, Me)
+        _lib.call('alm_xattn_dbias', P.data_ptr(), Mp, dP.data_ptr(), Mp, ndelta.data_ptr(), dbias.data_ptr(), Me, Me, B, N, H, ops._st())
     keT = _transpose_pad(ke, Mp)
     acc = dq is not None
     if dq is None:

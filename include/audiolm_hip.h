@@ -133,9 +133,14 @@ int alm_posmlp_out_bwd(const float* dtbl, const float* W, const float* pre, void
  *                (lse_self NULL: no causal self part), fself[r] = exp(lse_self - lse_tot): the weight of the self part's output.
  *   combine:     O[(b n)][h*dh + d] = fself[r] * O_self + O_e[r][d]        (O_self / fself NULL: cross-attention)
  *   softmax_bwd: dS = P o (dP + ndelta) * scale, ndelta[b][h][n] = -sum_d dO*O of the JOINT output (alm_xattn_delta, or the workspace
- *                alm_mqa_attn_bwd filled when a self part exists). */
+ *                alm_mqa_attn_bwd filled when a self part exists).
+ * The same pieces serve the reference's MATH path with an arbitrary dense attn_bias (attend.py:98-146: sim = q k^T * scale + attn_bias, key mask,
+ * causal triu(j - i + 1)): `bias` fp32 [H][N][ldbias] (NULL: none) is added to the scaled scores, `causal_off` makes key e visible to query n iff
+ * e <= n + causal_off (Me - N for the reference's rule; 0x7fffffff: not causal); alm_xattn_dbias: dbias[h][n][e] = sum_b P o (dP + ndelta). */
 int alm_xattn_softmax_fwd(const float* S, long long ldS, const unsigned char* emask, const float* lse_self, float scale, void* P_bf16, long long ldP,
-                          float* lse_tot, float* fself, int B, int N, int H, int Me, void* stream);
+                          float* lse_tot, float* fself, const float* bias, long long ldbias, int causal_off, int B, int N, int H, int Me, void* stream);
+int alm_xattn_dbias(const void* P_bf16, long long ldP, const float* dP, long long lddP, const float* ndelta, float* dbias, long long lddb, int Me, int B,
+                    int N, int H, void* stream);
 int alm_xattn_combine(const void* o_self_bf16, long long ldos, const float* fself, const float* o_e, void* out_bf16, long long ldo, long long tokens,
                       int H, int dim_head, void* stream);
 int alm_xattn_softmax_bwd(const void* P_bf16, long long ldP, const float* dP, long long lddP, const float* ndelta, float scale, void* dS_bf16,

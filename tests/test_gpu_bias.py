@@ -8,11 +8,14 @@ Tolerances: attention outputs / dq / dk / dv as in test_gpu_kernels (bf16 operan
 (bf16 GEMM operands, the precision the reference's autocast gives these Linears; first-layer bias / weight gradients pass through three bf16
 roundings of the chain: 5e-2, cf. the reference's own bf16 noise of 3-9 % on these tensors in tests/golden/bf16_noise.pt).
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
 
 import audiolm_oracle as O
+from common import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 
@@ -231,3 +234,79 @@ def test_attend_module_with_structured_bias():
     assert relmax(out, ref) <= 1.2e-2
     for name, got, want in (('dq', q.grad, qr.grad), ('dk', k.grad, kr.grad), ('dv', v.grad, vr.grad), ('dtbl', tbl.grad, tr.grad)):
         assert relmax(got, want) <= 2e-2, (name, relmax(got, want))
+
+
+# ---------------------------------------------------------------------------------------------- dense attn_bias: the reference's math path
+
+def test_attend_dense_bias_matches_real_reference_golden():
+    """tests/golden/attend.pt: outputs of the REAL reference Attend (attend.py:98-146) incl. `math_mask_bias` = key mask + an arbitrary dense
+    (h, n, n) attn_bias tensor.  Our Attend takes the same tensor (math path on the MFMA GEMMs + csrc/xattn.hip) -- head dim 16, n = 37."""
+    import audiolm_pytorch_amd as A
+    fx = torch.load(os.path.join(GOLDEN_DIR, 'attend.pt'), weights_only=False)
+    i, o = fx['inputs'], fx['outputs']
+    q, k, v, mask, bias = (i[n].to(dev()) for n in ('q', 'k', 'v', 'mask', 'bias'))
+    att = A.Attend(causal=True)
+    assert relmax(att(q, k, v, mask=mask, attn_bias=bias).cpu(), o['math_mask_bias']) <= 1.2e-2
+    assert relmax(att(q, k, v, mask=mask, attn_bias=torch.zeros_like(bias)).cpu(), o['math_mask']) <= 1.2e-2
+    assert relmax(att(q, k, v, attn_bias=torch.zeros(1, 1, 1, device=dev())).cpu(), o['math_plain']) <= 1.2e-2      # broadcastable bias
+
+
+@pytest.mark.parametrize('B,H,N,M,d,causal', [(2, 8, 150, 150, 64, True), (1, 4, 64, 200, 64, False), (3, 2, 33, 33, 32, True), (2, 4, 100, 37, 64, False)])
+def test_attend_math_path_dense_bias_forward_backward(B, H, N, M, d, causal):
+    """the math path vs the oracle's attend: output and the gradients of q, k, v and of the DENSE bias; causal and non-causal, key counts
+    different from the query count (cross-attention shapes), a broadcast (h, 1, j) bias"""
+    import audiolm_pytorch_amd as A
+    q = rnd(B, H, N, d, seed=70).requires_grad_(True)
+    k = rnd(B, M, d, seed=71).requires_grad_(True)
+    v = rnd(B, M, d, seed=72).requires_grad_(True)
+    g = torch.Generator().manual_seed(73)
+    mask = (torch.rand(B, M, generator=g) > 0.2)
+    mask[:, 0] = True
+    mask = mask.to(dev())
+    full = N == M
+    bias = (rnd(H, N, M, seed=74, scale=2.0) if full else rnd(H, 1, M, seed=74, scale=2.0)).requires_grad_(True)
+    out = A.Attend(causal=causal)(q, k, v, mask=mask, attn_bias=bias)
+    go = rnd(B, H, N, d, seed=75)
+    out.backward(go)
+    qr, kr, vr, br = [t.detach().clone().requires_grad_(True) for t in (q, k, v, bias)]
+    ref = O.attend(qr.bfloat16().float(), kr.bfloat16().float(), vr.bfloat16().float(), mask=mask, attn_bias=br, causal=causal)
+    ref.backward(go.bfloat16().float())
+    assert relmax(out, ref) <= 1.2e-2
+    for name, got, want in (('dq', q.grad, qr.grad), ('dk', k.grad, kr.grad), ('dv', v.grad, vr.grad), ('dbias', bias.grad, br.grad)):
+        assert got.shape == want.shape and relmax(got, want) <= 2e-2, (name, relmax(got, want))
+
+
+@pytest.mark.parametrize('streams', [1, 4])
+def test_transformer_with_dense_attn_bias_vs_oracle(streams):
+    """Transformer.forward(attn_bias=<any tensor>) (reference audiolm_pytorch.py:500-503 takes whatever it is given): the fused stack routes the
+    self-attention through the math path; output, parameter gradients and the gradient of the bias tensor vs the fp32 oracle."""
+    import audiolm_pytorch_amd as A
+    from common import synth_state_dict
+    dim, depth, heads, n, b = 128, 2, 4, 70, 2
+    torch.manual_seed(0)
+    tr = A.audiolm_pytorch.Transformer(dim=dim, depth=depth, heads=heads, num_residual_streams=streams, rel_pos_bias=False)
+    shapes = {k: tuple(v.shape) for k, v in tr.state_dict().items()}
+    sd = synth_state_dict(shapes, 77)
+    tr.load_state_dict(sd)
+    tr.to(dev())
+    x = rnd(b, n, dim, seed=78).requires_grad_(True)
+    bias = rnd(heads, n, n, seed=79, scale=1.5).requires_grad_(True)
+    g = torch.Generator().manual_seed(80)
+    mask = (torch.rand(b, n, generator=g) > 0.15)
+    mask[:, 0] = True
+    out = tr(x, self_attn_mask=mask.to(dev()), attn_bias=bias)
+    go = rnd(b, n, dim, seed=81)
+    out.backward(go)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, br = x.detach().cpu().clone().requires_grad_(True), bias.detach().cpu().clone().requires_grad_(True)
+    ref = O.transformer(sdr, '', xr, depth=depth, heads=heads, streams=streams, self_attn_mask=mask, attn_bias=br)
+    ref.backward(go.cpu())
+    fro = lambda a, w: float((a.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp(min=1e-30))
+    assert fro(out, ref) <= 1.5e-2, fro(out, ref)
+    assert fro(bias.grad, br.grad) <= 5e-2, fro(bias.grad, br.grad)
+    assert fro(x.grad, xr.grad) <= 5e-2
+    # the hyper-connection scalar statistics (cancelling sums) are compared through their per-feature siblings: see tests/test_gpu_parity.py
+    from test_gpu_parity import HC_SCALARS
+    worst = max((fro(p.grad, sdr[k].grad), k) for k, p in tr.named_parameters()
+                if sdr[k].grad is not None and float(sdr[k].grad.norm()) > 1e-7 and not k.endswith(HC_SCALARS))
+    assert worst[0] <= 8e-2, worst
