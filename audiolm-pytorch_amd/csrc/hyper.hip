@@ -83,25 +83,111 @@ struct HcParams {
 // with 31 shuffles instead of 6 per value, one LDS exchange combines the WPT waves, and lane l post-processes slot l
 // (one tanh per lane).  Per-element weights and parameter-gradient accumulators live in registers across the token loop.
 // ------------------------------------------------------------------------------------------------------------------
+// lane-permute primitives (VALU only, no LDS round trip)
+__device__ __forceinline__ float dpp_xor1(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float dpp_xor2(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float dpp_ror4(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x124, 0xF, 0xF, true)); }  // row_ror:4
+__device__ __forceinline__ float dpp_ror8(float v) { return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xF, 0xF, true)); }  // row_ror:8 (= lane ^ 8)
+// v_permlane32_swap: lanes 32..63 of `a` <-> lanes 0..31 of `b`; afterwards a + b = (a[l] + a[l+32]) in the lower half, (b[l-32] + b[l]) in the upper
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v_permlane16_swap: odd 16-lane rows of `a` <-> even rows of `b`; afterwards a + b = a-pair sums in even rows, b-pair sums in odd rows
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 64 lanes, every lane gets it: 4 DPP adds + 2 swap-adds instead of 6 ds_bpermute round trips
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_ror4(v);
+    v += dpp_ror8(v);
+    v = swap16_add(v, v);
+    return swap32_add(v, v);
+}
+
+// Slot <-> lane maps of the multi-value butterflies below.  NV < 32: slot = lane & (NV - 1).  NV = 32: the halving stages are ordered so that
+// the stages with MANY value pairs use the cheapest exchanges -- 16 pairs on v_permlane32_swap (lane bit 5), 8 on v_permlane16_swap (bit 4),
+// 4 on DPP quad_perm xor 1 (bit 0), 2 on DPP xor 2 (bit 1), 1 on a shuffle (bit 2), and the last all-reduce over bit 3 is one DPP row_ror:8:
+// 71 VALU instructions instead of 31 x (2 selects + ds_bpermute + add) -- so slot bits (0,1,2,3,4) <-> lane bits (5,4,0,1,2), and the two
+// lanes l, l ^ 8 hold the same slot (`primary`: the one with bit 3 clear).
+template <int NV> struct SlotMap {
+    static __device__ __forceinline__ int slot(int lane) { return lane & (NV - 1); }
+    static constexpr int lane_of(int s) { return s; }
+    static __device__ __forceinline__ int lane_of_dyn(int s) { return s; }
+    static __device__ __forceinline__ bool primary(int lane) { return lane < NV; }
+};
+template <> struct SlotMap<32> {
+    static __device__ __forceinline__ int slot(int l) { return ((l >> 5) & 1) | (((l >> 4) & 1) << 1) | ((l & 1) << 2) | (((l >> 1) & 1) << 3) | (((l >> 2) & 1) << 4); }
+    static constexpr int lane_of(int s) { return ((s & 1) << 5) | (((s >> 1) & 1) << 4) | ((s >> 2) & 1) | (((s >> 3) & 1) << 1) | (((s >> 4) & 1) << 2); }
+    static __device__ __forceinline__ int lane_of_dyn(int s) { return lane_of(s); }
+    static __device__ __forceinline__ bool primary(int lane) { return (lane & 8) == 0; }
+};
+
 template <int NV>
 __device__ __forceinline__ float bfly(float (&v)[NV], int lane) {
-    // NV (power of two <= 32) values per lane -> lane l returns the sum over the 64 lanes of slot l & (NV - 1)
-    int st = 0;
+    // NV (power of two <= 32) values per lane -> every lane returns the sum over the 64 lanes of slot SlotMap<NV>::slot(lane)
+    if constexpr (NV == 32) {
 #pragma unroll
-    for (int n = NV / 2; n >= 1; n >>= 1, ++st) {
-        const bool up = (lane >> st) & 1;
+        for (int i = 0; i < 16; ++i) v[i] = swap32_add(v[2 * i], v[2 * i + 1]);
 #pragma unroll
-        for (int i = 0; i < n; ++i) {
-            const float keep = up ? v[2 * i + 1] : v[2 * i];
-            const float send = up ? v[2 * i] : v[2 * i + 1];
-            v[i] = keep + __shfl_xor(send, 1 << st, 64);
+        for (int i = 0; i < 8; ++i) v[i] = swap16_add(v[2 * i], v[2 * i + 1]);
+        const bool u0 = lane & 1, u1 = (lane >> 1) & 1, u2 = (lane >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ta = v[2 * i] + dpp_xor1(v[2 * i]), tb = v[2 * i + 1] + dpp_xor1(v[2 * i + 1]);
+            v[i] = u0 ? tb : ta;
         }
-    }
-    float r = v[0];
 #pragma unroll
-    for (int m = NV; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
-    return r;
+        for (int i = 0; i < 2; ++i) {
+            const float ta = v[2 * i] + dpp_xor2(v[2 * i]), tb = v[2 * i + 1] + dpp_xor2(v[2 * i + 1]);
+            v[i] = u1 ? tb : ta;
+        }
+        const float keep = u2 ? v[1] : v[0], send = u2 ? v[0] : v[1];
+        float r = keep + __shfl_xor(send, 4, 64);
+        return r + dpp_ror8(r);
+    } else {
+        int st = 0;
+#pragma unroll
+        for (int n = NV / 2; n >= 1; n >>= 1, ++st) {
+            const bool up = (lane >> st) & 1;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const float keep = up ? v[2 * i + 1] : v[2 * i];
+                const float send = up ? v[2 * i] : v[2 * i + 1];
+                v[i] = keep + __shfl_xor(send, 1 << st, 64);
+            }
+        }
+        float r = v[0];
+#pragma unroll
+        for (int m = NV; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
+        return r;
+    }
 }
+
+// 4 values per lane -> every lane gets the 64-lane sum of slot (lane >> 5) | ((lane >> 4) & 1) << 1: two swap-adds, then an all-reduce inside the
+// 16-lane row (3 DPP adds + ... all VALU)
+__device__ __forceinline__ float bfly4(float (&v)[4]) {
+    const float a = swap32_add(v[0], v[1]), b = swap32_add(v[2], v[3]);
+    float r = swap16_add(a, b);
+    r += dpp_xor1(r);
+    r += dpp_xor2(r);
+    r += dpp_ror4(r);
+    return r + dpp_ror8(r);
+}
+__device__ __forceinline__ int bfly4_slot(int lane) { return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1); }
+__device__ __forceinline__ int bfly4_lane_of(int s) { return ((s & 1) << 5) | (((s >> 1) & 1) << 4); }
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) with the hardware exponential and reciprocal: |error| <= ~2e-7 absolute (the library tanhf costs ~40
+// instructions with its range selects; this value feeds alpha = tanh(.) * scale + static, where an absolute 2e-7 is far below the bf16 GEMM noise)
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(2.f * fminf(fmaxf(x, -15.f), 15.f));
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+// 1 / max(sqrt(ss), NORM_EPS)  (F.normalize's eps clamp) as min(rsqrt(ss), 1 / NORM_EPS): one v_rsq instead of sqrt + IEEE divide
+__device__ __forceinline__ float inv_norm(float ss) { return fminf(__builtin_amdgcn_rsqf(ss), 1.f / NORM_EPS); }
 
 __device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
@@ -109,19 +195,21 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __in
 template <int WPT, int NV>
 __device__ __forceinline__ float token_combine(float tot, float* red, int tok, int wv, int lane) {
     if (WPT == 1) return tot;
-    if (lane < NV) red[(tok * WPT + wv) * NV + lane] = tot;
+    using SM = SlotMap<NV>;
+    const int sl = SM::slot(lane);
+    if (SM::primary(lane)) red[(tok * WPT + wv) * NV + sl] = tot;
     __syncthreads();
     float r = 0.f;
 #pragma unroll
-    for (int w = 0; w < WPT; ++w) r += red[(tok * WPT + w) * NV + (lane & (NV - 1))];
+    for (int w = 0; w < WPT; ++w) r += red[(tok * WPT + w) * NV + sl];
     return r;
 }
 
 struct HcFwdArgs {
     const void* R_in; int rin_bcast;                      // residual streams RT [B][S][N][D], or (rin_bcast) ONE fp32 [B*N][D] tensor every stream equals (:524)
-    const bf16_t* y; long long ldy; const float* coef_prev; void* R_out;
+    const bf16_t* y; int ldy; const float* coef_prev; void* R_out;           // row strides: int (fewer SGPRs / SALU ops in the token loop)
     HcParams hp; const float* ln_gamma;
-    bf16_t* x_out; long long ldx; bf16_t* xn_out; long long ldxn; float* mean_out; float* rstd_out; float* coef; float* xs_out;
+    bf16_t* x_out; int ldx; bf16_t* xn_out; int ldxn; float* mean_out; float* rstd_out; float* coef; float* xs_out;
     float* xn32_out;                                      // FINAL: the final LayerNorm output in fp32 [B*N][D] instead of bf16 xn_out (logit heads)
     int B, N, D;
 };
@@ -150,7 +238,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     const int e0 = (wv * 64 + lane) * 4;
     const bool eok = e0 < a.D;
     const long long M = (long long)a.B * a.N;
-    const float cD = sqrtf((float)a.D);
+    const float cD = sqrtf((float)a.D), invD = 1.f / (float)a.D;
 
     float w[S + 2][4];
     float4 lng = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -168,7 +256,17 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
         }
     }
 
-    const long long niter = (M + TPB - 1) / TPB;
+    // slot role of this lane in the width connection's reduction (loop-invariant; see SlotMap): ss[S] | dots[S][S+2] | sums[S]
+    using SM = SlotMap<NV>;
+    const int l = SM::slot(lane);
+    const int di = l - O_DOT;
+    const bool is_dot = di >= 0 && di < S * (S + 2);
+    const int ds = is_dot ? di / (S + 2) : 0, dt = is_dot ? di % (S + 2) : 0;
+    const bool is_beta = dt == S + 1;
+    float stat = 0.f;                                                        // static part of this lane's coefficient
+    if (WIDTH && is_dot) stat = is_beta ? a.hp.Bb[ds] : a.hp.Aa[ds * (S + 1) + dt];
+
+    const int niter = (int)((M + TPB - 1) / TPB);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long sND = (long long)a.N * a.D;                              // stream stride of R
     // token coordinates (b, n) advance incrementally: no 64-bit divisions in the loop; `valid` is wave-uniform, so the loads sit in ONE
@@ -180,8 +278,8 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
         nn = m0 % (unsigned)a.N;
     }
     const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
-    struct Tok { long long m; int b, n; bool valid; };
-    auto next_tok = [&](long long it_) {
+    struct Tok { int m; int b, n; bool valid; };                             // m = b * N + n < 2^31 (checked by the launcher)
+    auto next_tok = [&](int it_) {
         Tok t;
         t.m = it_ * TPB + tok;
         t.b = (int)bb; t.n = (int)nn;
@@ -190,42 +288,47 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
         if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
         return t;
     };
-    struct In { Raw4<RT> r[S]; float4 rb; uint2 y; };                        // one token's inputs as loaded
+    struct In { Raw4<RT> r[S]; float4 rb; uint2 y; float cf; };              // one token's inputs as loaded; cf: lane l = coef_prev[m][l] (DEPTH)
+    const int cl = lane < C::W ? lane : 0;                                   // this lane's entry of a token's coefficient record
     auto issue_pf = [&](In& in, const Tok& t) {
-        const long long m_ = t.valid ? t.m : 0;
-        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = eok ? e0 : 0;
-        const RT* Rt = Rin + ((long long)b_ * S * a.N + n_) * a.D + el;
+        const int m_ = t.valid ? t.m : 0;
+        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0;                  // PF: D == WPT * 256, every lane in range
+        const RT* Rt = Rin + ((long long)b_ * S * a.N + n_) * a.D + e0;
 #pragma unroll
         for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
-        if (DEPTH) in.y = *reinterpret_cast<const uint2*>(a.y + m_ * a.ldy + el);
+        if (DEPTH) { in.y = *reinterpret_cast<const uint2*>(a.y + (long long)m_ * a.ldy + e0); in.cf = a.coef_prev[(long long)m_ * C::W + cl]; }
     };
     auto issue_plain = [&](In& in, const Tok& t) {
 #pragma unroll
         for (int s = 0; s < S; ++s) zraw(in.r[s]);
         in.rb = z4;
         in.y = make_uint2(0u, 0u);
+        in.cf = 0.f;
+        if (DEPTH) in.cf = a.coef_prev[(t.valid ? t.m : 0) * C::W + cl];
         if (t.valid && eok) {
             if (a.rin_bcast) {
-                in.rb = ld4(reinterpret_cast<const float*>(a.R_in) + t.m * a.D + e0);
+                in.rb = ld4(reinterpret_cast<const float*>(a.R_in) + (long long)t.m * a.D + e0);
             } else {
                 const RT* Rt = Rin + ((long long)t.b * S * a.N + t.n) * a.D + e0;
 #pragma unroll
                 for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
             }
-            if (DEPTH) in.y = *reinterpret_cast<const uint2*>(a.y + t.m * a.ldy + e0);
+            if (DEPTH) in.y = *reinterpret_cast<const uint2*>(a.y + (long long)t.m * a.ldy + e0);
         }
     };
     auto process = [&](const In& in, const Tok& t) {
-        const long long m = t.m;
+        const int m = t.m;
         const bool valid = t.valid;
         const int b = t.b, n = t.n;
         const bool ld_ok = valid && eok;
         float4 r[S];
         float4 yv = z4;
         if (PF) {
+            // every lane owns 4 real elements (the launcher takes this path only for D == WPT * 256) and a skipped token re-reads token 0:
+            // whatever is computed from it is never stored, so no zero-selects are needed
 #pragma unroll
-            for (int s = 0; s < S; ++s) r[s] = ld_ok ? unraw(in.r[s]) : z4;
-            if (DEPTH) yv = ld_ok ? unraw(in.y) : z4;
+            for (int s = 0; s < S; ++s) r[s] = unraw(in.r[s]);
+            if (DEPTH) yv = unraw(in.y);
         } else {
             if (a.rin_bcast) {
 #pragma unroll
@@ -237,15 +340,16 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
             if (DEPTH) yv = unraw(in.y);
         }
         if (DEPTH) {
-            const float* cp = a.coef_prev + (valid ? m : 0) * C::W;
+            // the previous branch's coefficients arrived with the token's other loads (one lane-distributed record): no load sits between the
+            // prefetch of the next token and the end of this one, so that prefetch really stays in flight
             float4 o[S];
 #pragma unroll
             for (int t = 0; t < S; ++t) {
-                const float bt = cp[C::Bt + t];
+                const float bt = lane_bcast(in.cf, C::Bt + t);
                 o[t] = make_float4(bt * yv.x, bt * yv.y, bt * yv.z, bt * yv.w);
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const float al = cp[C::A + s * (S + 1) + t + 1];
+                    const float al = lane_bcast(in.cf, C::A + s * (S + 1) + t + 1);
                     o[t].x += al * r[s].x; o[t].y += al * r[s].y; o[t].z += al * r[s].z; o[t].w += al * r[s].w;
                 }
             }
@@ -273,44 +377,38 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
                 }
             float tot = bfly<NV>(v, lane);
             tot = token_combine<WPT, NV>(tot, red, tok, wv, lane);
-            // lane l post-processes slot l
-            const int l = lane & (NV - 1);
+            // every lane post-processes its slot
             float rn[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) rn[s] = 1.f / fmaxf(sqrtf(lane_bcast(tot, s)), NORM_EPS);
-            const int di = l - O_DOT;
-            const bool is_dot = di >= 0 && di < S * (S + 2);
-            const int ds = is_dot ? di / (S + 2) : 0, dt = is_dot ? di % (S + 2) : 0;
+            for (int s = 0; s < S; ++s) rn[s] = inv_norm(lane_bcast(tot, SM::lane_of(s)));
             float rn_l = rn[0];
 #pragma unroll
             for (int s = 1; s < S; ++s) rn_l = (ds == s) ? rn[s] : rn_l;
             const float pre = tot * rn_l * cD;
-            const float th = tanhf(pre);
-            const bool is_beta = dt == S + 1;
-            const float stat = is_dot ? (is_beta ? a.hp.Bb[ds] : a.hp.Aa[ds * (S + 1) + dt]) : 0.f;
+            const float th = tanh_fast(pre);
             const float coefv = th * (is_beta ? sb : sa) + stat;             // alpha[ds][dt] or beta[ds]
-            if (valid && wv == 0 && lane < NV) {
-                float* cp = a.coef + m * C::W;
+            if (valid && wv == 0 && SM::primary(lane)) {
+                float* cp = a.coef + (long long)m * C::W;
                 if (is_dot) {
                     if (is_beta) { cp[C::Bt + ds] = coefv; cp[C::BP + ds] = pre; }
                     else { cp[C::A + ds * (S + 1) + dt] = coefv; cp[C::AP + ds * (S + 1) + dt] = pre; }
                 } else if (l < S) {
-                    cp[C::RN + l] = 1.f / fmaxf(sqrtf(tot), NORM_EPS);
+                    cp[C::RN + l] = inv_norm(tot);
                 }
             }
             float msum = 0.f;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const float a0 = lane_bcast(coefv, O_DOT + s * (S + 2));
+                const float a0 = lane_bcast(coefv, SM::lane_of(O_DOT + s * (S + 2)));
                 x.x += a0 * r[s].x; x.y += a0 * r[s].y; x.z += a0 * r[s].z; x.w += a0 * r[s].w;
-                msum += a0 * lane_bcast(tot, O_SUM + s);
+                msum += a0 * lane_bcast(tot, SM::lane_of(O_SUM + s));
             }
-            mean = msum / (float)a.D;
+            mean = msum * invD;
         }
         if (FINAL) {
 #pragma unroll
             for (int s = 0; s < S; ++s) { x.x += r[s].x; x.y += r[s].y; x.z += r[s].z; x.w += r[s].w; }
-            float sm = wave_sum(x.x + x.y + x.z + x.w);
+            float sm = wave_sum_fast(x.x + x.y + x.z + x.w);
             if (WPT > 1) {
                 if (lane == 0) red2[0][tok * WPT + wv] = sm;
                 __syncthreads();
@@ -318,8 +416,8 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 #pragma unroll
                 for (int q = 0; q < WPT; ++q) sm += red2[0][tok * WPT + q];
             }
-            mean = sm / (float)a.D;
-            if (ld_ok) *reinterpret_cast<float4*>(a.xs_out + m * a.D + e0) = x;
+            mean = sm * invD;
+            if (ld_ok) *reinterpret_cast<float4*>(a.xs_out + (long long)m * a.D + e0) = x;
         }
         if (WIDTH || FINAL) {
             float q = 0.f;
@@ -327,7 +425,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
                 const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
                 q = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
-            q = wave_sum(q);
+            q = wave_sum_fast(q);
             if (WPT > 1) {
                 if (lane == 0) red2[1][tok * WPT + wv] = q;
                 __syncthreads();
@@ -335,13 +433,13 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < WPT; ++j) q += red2[1][tok * WPT + j];
             }
-            const float rstd = rsqrtf(q / (float)a.D + LN_EPS);
+            const float rstd = rsqrtf(q * invD + LN_EPS);
             if (ld_ok) {
                 const float4 xnv = make_float4((x.x - mean) * rstd * lng.x, (x.y - mean) * rstd * lng.y, (x.z - mean) * rstd * lng.z,
                                                (x.w - mean) * rstd * lng.w);
-                if (FINAL && a.xn32_out) *reinterpret_cast<float4*>(a.xn32_out + m * a.D + e0) = xnv;
-                else st4bf(a.xn_out + m * a.ldxn + e0, xnv);
-                if (WIDTH && a.x_out) st4bf(a.x_out + m * a.ldx + e0, x);
+                if (FINAL && a.xn32_out) *reinterpret_cast<float4*>(a.xn32_out + (long long)m * a.D + e0) = xnv;
+                else st4bf(a.xn_out + (long long)m * a.ldxn + e0, xnv);
+                if (WIDTH && a.x_out) st4bf(a.x_out + (long long)m * a.ldx + e0, x);
             }
             if (valid && wv == 0 && lane == 0) { a.mean_out[m] = mean; a.rstd_out[m] = rstd; }
         }
@@ -350,17 +448,17 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
         In wa, wb2;
         Tok ta = next_tok(blockIdx.x), tb = ta;
         issue_pf(wa, ta);
-        for (long long it = blockIdx.x; it < niter; it += 2 * (long long)gridDim.x) {
+        for (int it = blockIdx.x; it < niter; it += 2 * (int)gridDim.x) {
             tb = next_tok(it + gridDim.x);
             issue_pf(wb2, tb);
             process(wa, ta);
             if (it + gridDim.x >= niter) break;
-            ta = next_tok(it + 2 * (long long)gridDim.x);
+            ta = next_tok(it + 2 * (int)gridDim.x);
             issue_pf(wa, ta);
             process(wb2, tb);
         }
     } else {
-        for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+        for (int it = blockIdx.x; it < niter; it += gridDim.x) {
             const Tok t = next_tok(it);
             In w;
             issue_plain(w, t);
@@ -371,16 +469,16 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 
 struct HcBwdArgs {
     const void* dRn; int bcast;                          // gradient wrt the width connection's residual output: RT [B][S][N][D], or (bcast) fp32 [M][D] shared by all streams
-    const float* dx; long long lddx;                     // gradient wrt the branch input x (fp32)                      [LNF == false]
-    const bf16_t* dxn; long long lddxn;                  // gradient wrt the branch's pre-LayerNorm OUTPUT xn (bf16)     [LNF == true]
-    const bf16_t* extra; long long ldex;                 //   + gradient arriving at x directly (attention: the K/V path), or NULL
+    const float* dx; int lddx;                           // gradient wrt the branch input x (fp32)                      [LNF == false]   (row strides: int -- fewer SGPRs / SALU ops in the token loop)
+    const bf16_t* dxn; int lddxn;                        // gradient wrt the branch's pre-LayerNorm OUTPUT xn (bf16)     [LNF == true]
+    const bf16_t* extra; int ldex;                       //   + gradient arriving at x directly (attention: the K/V path), or NULL
     const float* mean; const float* rstd; const float* ln_gamma;        //   LayerNorm statistics saved by the forward, LN weight
     const void* R; int r_bcast;                          // residual input of the width connection (RT [B][S][N][D], or one fp32 [B*N][D] tensor for all streams)
     const float* coef; const float* dbeta;
     HcParams hp;
     void* dR; float* dsum;                               // dR RT [B][S][N][D] and / or dsum fp32 [B*N][D] = sum over streams of dR (gradient of the :524 expand)
     float* partial;
-    const bf16_t* y; long long ldy; const float* coef_prev; bf16_t* dy; long long lddy; float* dbeta_out;
+    const bf16_t* y; int ldy; const float* coef_prev; bf16_t* dy; int lddy; float* dbeta_out;
     int B, N, D;
 };
 
@@ -434,7 +532,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         }
     }
 
-    const long long niter = (M + TPB - 1) / TPB;
+    const int niter = (int)((M + TPB - 1) / TPB);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const long long sND = (long long)a.N * a.D;
     unsigned bb, nn;                                                         // coordinates of the token whose loads are issued next (see hc_fwd_kernel)
@@ -444,8 +542,29 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         nn = m0 % (unsigned)a.N;
     }
     const unsigned tstride = gridDim.x * TPB, sbb = tstride / (unsigned)a.N, snn = tstride % (unsigned)a.N;
-    struct Tok { long long m; int b, n; bool valid; };
-    auto next_tok = [&](long long it_) {
+    // slot roles of this lane (loop-invariant): slots 0 .. NB-1 = alpha pre-activation (s, t), NB .. NB+S-1 = beta of stream s
+    using SM = SlotMap<NV>;
+    const int slot = SM::slot(lane);
+    const bool prim = SM::primary(lane);
+    const bool is_a = prim && slot < NB, is_b = prim && slot >= NB && slot < NB + S;
+    const int sl = is_a ? slot / (S + 1) : (is_b ? slot - NB : 0);
+    const bool is_dx = slot < NB && slot % (S + 1) == 0;                     // <dx, R_s> slots (both lanes of a slot keep them consistent)
+    const int sl0 = (slot < NB) ? slot / (S + 1) : 0;
+    const int src_sr = SM::lane_of_dyn(O_SR + sl0), src_xr = SM::lane_of_dyn(O_XR + sl0);
+    const int cl = lane < C::W ? lane : 0;                                   // this lane's entry of a coefficient record
+    const int pre_idx = is_a ? C::AP + slot : C::BP + sl;
+    auto issue_scalars = [&](auto& w, long long m_) {
+        w.cf = w.cfp = w.pre = w.upb = w.ms = 0.f;
+        if (WIDTH) {
+            w.cf = a.coef[(long long)m_ * C::W + cl];
+            w.pre = a.coef[(long long)m_ * C::W + pre_idx];
+            w.upb = a.dbeta[(long long)m_ * S + sl];
+            if (LNF) w.ms = (lane & 1) ? a.rstd[m_] : a.mean[m_];
+        }
+        if (DEPTH) w.cfp = a.coef_prev[(long long)m_ * C::W + cl];
+    };
+    struct Tok { int m; int b, n; bool valid; };                             // m = b * N + n < 2^31 (checked by the launcher)
+    auto next_tok = [&](int it_) {
         Tok t;
         t.m = it_ * TPB + tok;
         t.b = (int)bb; t.n = (int)nn;
@@ -454,67 +573,75 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         if (nn >= (unsigned)a.N) { nn -= (unsigned)a.N; ++bb; }
         return t;
     };
-    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; };   // one token's inputs as loaded
+    // one token's inputs as loaded.  cf / cfp: lane l = entry l of the token's coefficient record / of the previous branch's (every per-token
+    // scalar is then a v_readlane away); pre / upb: this lane's pre-activation and (beta slots) upstream gradient; ms: lane 0 mean, lane 1 rstd.
+    // With them NO load sits between the prefetch of the next token and the end of this one: the prefetch really stays in flight (vmcnt
+    // retires in order: a late scalar load would force a wait for everything issued before it, i.e. for the whole prefetch).
+    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms; };
     auto issue_pf = [&](In& w, const Tok& t) {
-        const long long m_ = t.valid ? t.m : 0;
-        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = eok ? e0 : 0;
+        const int m_ = t.valid ? t.m : 0;
+        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = e0;         // PF: D == WPT * 256, every lane in range
         const long long tofs = ((long long)b_ * S * a.N + n_) * a.D + el;
+        issue_scalars(w, m_);
 #pragma unroll
         for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
         if (WIDTH) {
 #pragma unroll
             for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
             if (LNF) {
-                w.dxn = *reinterpret_cast<const uint2*>(a.dxn + m_ * a.lddxn + el);
+                w.dxn = *reinterpret_cast<const uint2*>(a.dxn + (long long)m_ * a.lddxn + el);
                 w.ex = make_uint2(0u, 0u);
-                if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + m_ * a.ldex + el);
+                if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + (long long)m_ * a.ldex + el);
             } else {
-                w.dx = ld4(a.dx + m_ * a.lddx + el);
+                w.dx = ld4(a.dx + (long long)m_ * a.lddx + el);
             }
         }
-        if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + m_ * a.ldy + el);
+        if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + (long long)m_ * a.ldy + el);
     };
     auto issue_plain = [&](In& w, const Tok& t) {
 #pragma unroll
         for (int t2 = 0; t2 < S; ++t2) { zraw(w.g[t2]); zraw(w.r[t2]); }
         w.gb = w.rb = w.dx = z4;
         w.dxn = w.ex = w.y = make_uint2(0u, 0u);
+        issue_scalars(w, t.valid ? t.m : 0);
         if (t.valid && eok) {
             const long long tofs = ((long long)t.b * S * a.N + t.n) * a.D + e0;
             if (a.bcast) {
-                w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + t.m * a.D + e0);
+                w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + (long long)t.m * a.D + e0);
             } else {
 #pragma unroll
                 for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
             }
             if (WIDTH) {
                 if (a.r_bcast) {
-                    w.rb = ld4(reinterpret_cast<const float*>(a.R) + t.m * a.D + e0);
+                    w.rb = ld4(reinterpret_cast<const float*>(a.R) + (long long)t.m * a.D + e0);
                 } else {
 #pragma unroll
                     for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
                 }
                 if (LNF) {
-                    w.dxn = *reinterpret_cast<const uint2*>(a.dxn + t.m * a.lddxn + e0);
-                    if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + t.m * a.ldex + e0);
+                    w.dxn = *reinterpret_cast<const uint2*>(a.dxn + (long long)t.m * a.lddxn + e0);
+                    if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + (long long)t.m * a.ldex + e0);
                 } else {
-                    w.dx = ld4(a.dx + t.m * a.lddx + e0);
+                    w.dx = ld4(a.dx + (long long)t.m * a.lddx + e0);
                 }
             }
-            if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + t.m * a.ldy + e0);
+            if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + (long long)t.m * a.ldy + e0);
         }
     };
     int par = 0;
     auto process = [&](const In& w, const Tok& t) {
-        const long long m = t.m;
+        const int m = t.m;
         const bool valid = t.valid;
         const int b = t.b, n = t.n;
         const bool ld_ok = valid && eok;
         float4 g[S], r_c[S];
         float4 dx_c = z4, yv = z4, ex_c = z4;
         if (PF) {
+            // a skipped token re-read token 0 (finite data): its results are never stored, its coefficient gradients are zeroed through `up`
+            // below, and the one running sum that takes the loaded data directly (dln) is protected by zeroing dxn
 #pragma unroll
-            for (int t2 = 0; t2 < S; ++t2) g[t2] = ld_ok ? unraw(w.g[t2]) : z4;
+            for (int t2 = 0; t2 < S; ++t2) g[t2] = unraw(w.g[t2]);
         } else if (a.bcast) {
 #pragma unroll
             for (int t2 = 0; t2 < S; ++t2) g[t2] = w.gb;
@@ -525,7 +652,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         if (WIDTH) {
             if (PF) {
 #pragma unroll
-                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = ld_ok ? unraw(w.r[s2]) : z4;
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = unraw(w.r[s2]);
             } else if (a.r_bcast) {
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2) r_c[s2] = w.rb;
@@ -534,22 +661,22 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 for (int s2 = 0; s2 < S; ++s2) r_c[s2] = unraw(w.r[s2]);
             }
             if (LNF) {
-                dx_c = (!PF || ld_ok) ? unraw(w.dxn) : z4;                       // dxn (bf16) travels in dx_c
-                ex_c = (!PF || ld_ok) ? unraw(w.ex) : z4;
+                dx_c = unraw((!PF || valid) ? w.dxn : make_uint2(0u, 0u));       // dxn (bf16) travels in dx_c
+                ex_c = unraw(w.ex);
             } else {
-                dx_c = (!PF || ld_ok) ? w.dx : z4;
+                dx_c = w.dx;
             }
         } else {
 #pragma unroll
             for (int s2 = 0; s2 < S; ++s2) r_c[s2] = z4;
         }
-        if (DEPTH) yv = (!PF || ld_ok) ? unraw(w.y) : z4;
+        if (DEPTH) yv = unraw(w.y);
         float4 out[S];
         if (WIDTH) {
             float4 r[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) r[s] = r_c[s];
-            const float* cp = a.coef + (valid ? m : 0) * C::W;
+            auto cpv = [&](int k) { return lane_bcast(w.cf, k); };             // entry k of the token's coefficient record (k: compile-time)
             float4 dxv = dx_c;
             float4 xh = z4, gg = z4;                                        // LNF: xhat and g = dxn * gamma of this thread's 4 elements
             float rs = 0.f;
@@ -557,12 +684,12 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) v[i] = 0.f;
             if (LNF) {
-                const float mu = valid ? a.mean[m] : 0.f;
-                rs = valid ? a.rstd[m] : 0.f;
+                const float mu = lane_bcast(w.ms, 0);
+                rs = lane_bcast(w.ms, 1);
                 float4 x = z4;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const float a0 = cp[C::A + s * (S + 1)];
+                    const float a0 = cpv(C::A + s * (S + 1));
                     x.x += a0 * r[s].x; x.y += a0 * r[s].y; x.z += a0 * r[s].z; x.w += a0 * r[s].w;
                 }
                 xh = eok ? make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs) : z4;
@@ -588,59 +715,55 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             if (LNF) {
                 // <dx, R_s> = <u, R_s> - rstd mean(g) sum R_s - rstd mean(g xhat) <xhat, R_s>; then the per-element dx itself
                 const float invD = 1.f / (float)a.D;
-                const float c1 = lane_bcast(da, O_C1) * invD, c2 = lane_bcast(da, O_C2) * invD;
-                const int sl0 = (lane < NB) ? lane / (S + 1) : 0;
-                const float sr = __shfl(da, O_SR + sl0, 64), xr = __shfl(da, O_XR + sl0, 64);
-                if (lane < NB && lane % (S + 1) == 0) da -= rs * (c1 * sr + c2 * xr);
+                const float c1 = lane_bcast(da, SM::lane_of(O_C1)) * invD, c2 = lane_bcast(da, SM::lane_of(O_C2)) * invD;
+                const float sr = __shfl(da, src_sr, 64), xr = __shfl(da, src_xr, 64);
+                if (is_dx) da -= rs * (c1 * sr + c2 * xr);
                 dxv = make_float4(rs * (gg.x - c1 - xh.x * c2) + ex_c.x, rs * (gg.y - c1 - xh.y * c2) + ex_c.y,
                                   rs * (gg.z - c1 - xh.z * c2) + ex_c.z, rs * (gg.w - c1 - xh.w * c2) + ex_c.w);
             }
-            // lane l < NB: slot (s, t) = (l / (S+1), l % (S+1)); lanes NB .. NB+S-1: the beta path of stream l - NB
-            const bool is_a = lane < NB, is_b = lane >= NB && lane < NB + S;
-            const int sl = is_a ? lane / (S + 1) : (is_b ? lane - NB : 0);
+            // slot (s, t) = (slot / (S+1), slot % (S+1)) for slot < NB; slots NB .. NB+S-1: the beta path of stream slot - NB  (roles: see above the loop)
             float pre = 0.f, up = 0.f;                                   // pre-activation and upstream gradient of this lane's coefficient
             if (valid) {
-                if (is_a) { pre = cp[C::AP + lane]; up = da; }
-                else if (is_b) { pre = cp[C::BP + sl]; up = a.dbeta[m * S + sl]; }
+                if (is_a) { pre = w.pre; up = da; }
+                else if (is_b) { pre = w.pre; up = w.upb; }
             }
-            const float th = tanhf(pre);
-            const float dpre = up * (is_a ? sa : sb) * (1.f - th * th);     // dap[s][t] (lanes < NB) | dbp[s] (lanes NB..)
+            const float th = tanh_fast(pre);
+            const float dpre = up * (is_a ? sa : sb) * (1.f - th * th);     // dap[s][t] (a slots) | dbp[s] (b slots)
             if (wv == 0) {
                 if (is_a) { accA += up; accsa += up * th; }
                 if (is_b) { accB += up; accsb += up * th; }
             }
-            float dap[S][S + 1], dbp[S], alpha[S][S + 1], rn[S], gdot[S];
+            // stream by stream: the 13 per-token scalars of stream s (alpha[s][.], dap[s][.], dbp, 1/|R_s|, <g_s, R_s>) are fetched right where they
+            // are used, so that only one stream's worth of SGPRs is live at a time (all 52 at once spill)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                rn[s] = cp[C::RN + s];
-                dbp[s] = lane_bcast(dpre, NB + s);
-                float gd = dbp[s] * cp[C::BP + s];
+                float dap[S + 1], alpha[S + 1];
+                const float rn = cpv(C::RN + s);
+                const float dbp = lane_bcast(dpre, SM::lane_of(NB + s));
+                float gd = dbp * cpv(C::BP + s);
 #pragma unroll
                 for (int t = 0; t < S + 1; ++t) {
-                    dap[s][t] = lane_bcast(dpre, s * (S + 1) + t);
-                    alpha[s][t] = cp[C::A + s * (S + 1) + t];
-                    gd += dap[s][t] * cp[C::AP + s * (S + 1) + t];
+                    dap[t] = lane_bcast(dpre, SM::lane_of(s * (S + 1) + t));
+                    alpha[t] = cpv(C::A + s * (S + 1) + t);
+                    gd += dap[t] * cpv(C::AP + s * (S + 1) + t);
                 }
-                gdot[s] = gd / rn[s];      // <g_s, R_s> = sum_t dap * apre / rn  (n_s . W = apre => sum_e W[e] (gamma+1) c R_s[e] = apre / rn)
-            }
+                // <g_s, R_s> = sum_t dap * apre / rn  (n_s . W = apre => sum_e W[e] (gamma+1) c R_s[e] = apre / rn); 1-ulp reciprocal of the uniform 1/|R_s|
+                const float gdot = gd * __builtin_amdgcn_rcpf(rn);
+                const float grr = gdot * rn * rn, rnc = rn * cD;
 #pragma unroll
-            for (int s = 0; s < S; ++s) out[s] = z4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
+                for (int c = 0; c < 4; ++c) {
                     const float rv = f4c(r[s], c);
-                    float dn = dbp[s] * wbv[c];
+                    float dn = dbp * wbv[c];
 #pragma unroll
-                    for (int t = 0; t < S + 1; ++t) dn += dap[s][t] * wa[t][c];
-                    const float nhat = rv * rn[s] * cD;                    // n_s / (gamma + 1)
+                    for (int t = 0; t < S + 1; ++t) dn += dap[t] * wa[t][c];
+                    const float nhat = rv * rnc;                           // n_s / (gamma + 1)
 #pragma unroll
-                    for (int t = 0; t < S + 1; ++t) rawa[t][c] += nhat * dap[s][t];
-                    rawb[c] += nhat * dbp[s];
+                    for (int t = 0; t < S + 1; ++t) rawa[t][c] += nhat * dap[t];
+                    rawb[c] += nhat * dbp;
                     const float gs = dn * g1[c] * cD;
-                    float o = alpha[s][0] * f4c(dxv, c) + rn[s] * (gs - gdot[s] * rn[s] * rn[s] * rv);
+                    float o = alpha[0] * f4c(dxv, c) + rn * (gs - grr * rv);
 #pragma unroll
-                    for (int t = 0; t < S; ++t) o += alpha[s][t + 1] * f4c(g[t], c);
+                    for (int t = 0; t < S; ++t) o += alpha[t + 1] * f4c(g[t], c);
                     f4(out[s], c) = o;
                 }
             }
@@ -653,7 +776,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                     float4 sm = out[0];
 #pragma unroll
                     for (int s = 1; s < S; ++s) { sm.x += out[s].x; sm.y += out[s].y; sm.z += out[s].z; sm.w += out[s].w; }
-                    *reinterpret_cast<float4*>(a.dsum + m * a.D + e0) = sm;
+                    *reinterpret_cast<float4*>(a.dsum + (long long)m * a.D + e0) = sm;
                 }
             }
         } else {
@@ -661,28 +784,29 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             for (int s = 0; s < S; ++s) out[s] = g[s];
         }
         if (DEPTH) {
-            const float* cq = a.coef_prev + (valid ? m : 0) * C::W;
             float4 o = z4;
             float v4[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) v4[t] = 0.f;
 #pragma unroll
             for (int t = 0; t < S; ++t) {
-                const float bt = cq[C::Bt + t];
+                const float bt = lane_bcast(w.cfp, C::Bt + t);
                 o.x += bt * out[t].x; o.y += bt * out[t].y; o.z += bt * out[t].z; o.w += bt * out[t].w;
                 v4[t] = out[t].x * yv.x + out[t].y * yv.y + out[t].z * yv.z + out[t].w * yv.w;
             }
-            if (ld_ok) st4bf(a.dy + m * a.lddy + e0, o);
-            float db = bfly<4>(v4, lane);
+            if (ld_ok) st4bf(a.dy + (long long)m * a.lddy + e0, o);
+            float db = bfly4(v4);                                           // every lane: total of slot bfly4_slot(lane)
             if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
                 float* rd = redd[par];
-                if (lane < 4) rd[(tok * WPT + wv) * 4 + lane] = db;
+                if ((lane & 15) == 0) rd[(tok * WPT + wv) * 4 + bfly4_slot(lane)] = db;
                 __syncthreads();
                 db = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < WPT; ++w2) db += rd[(tok * WPT + w2) * 4 + (lane & 3)];
+            } else {
+                db = __shfl(db, bfly4_lane_of(lane & 3), 64);
             }
-            if (valid && wv == 0 && lane < S) a.dbeta_out[m * S + lane] = db;
+            if (valid && wv == 0 && lane < S) a.dbeta_out[(long long)m * S + lane] = db;
         }
         par ^= 1;
     };
@@ -690,17 +814,17 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         In wa, wb2;
         Tok ta = next_tok(blockIdx.x), tb = ta;
         issue_pf(wa, ta);
-        for (long long it = blockIdx.x; it < niter; it += 2 * (long long)gridDim.x) {
+        for (int it = blockIdx.x; it < niter; it += 2 * (int)gridDim.x) {
             tb = next_tok(it + gridDim.x);
             issue_pf(wb2, tb);
             process(wa, ta);
             if (it + gridDim.x >= niter) break;
-            ta = next_tok(it + 2 * (long long)gridDim.x);
+            ta = next_tok(it + 2 * (int)gridDim.x);
             issue_pf(wa, ta);
             process(wb2, tb);
         }
     } else {
-        for (long long it = blockIdx.x; it < niter; it += gridDim.x) {
+        for (int it = blockIdx.x; it < niter; it += gridDim.x) {
             const Tok t = next_tok(it);
             In w;
             issue_plain(w, t);
@@ -720,8 +844,8 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     }
     if (wv == 0) {
         float* q = prow + (long long)a.D * (S + 3);
-        if (lane < NB) q[lane] = accA;
-        if (lane >= NB && lane < NB + S) q[lane] = accB;
+        if (is_a) q[slot] = accA;
+        if (is_b) q[slot] = accB;
         const float tsa = wave_sum(accsa), tsb = wave_sum(accsb);
         if (lane == 0) { q[NB + S] = tsa; q[NB + S + 1] = tsb; }
     }
@@ -839,7 +963,7 @@ void launch_fwd_p(const HcFwdArgs& a, hipStream_t st) {
 template <typename RT, int S, int WPT, bool DEPTH, bool WIDTH, bool FINAL>
 void launch_fwd_w(const HcFwdArgs& a, hipStream_t st) {
     if constexpr (sizeof(RT) == 2) {
-        if (!a.rin_bcast) return launch_fwd_p<RT, S, WPT, DEPTH, WIDTH, FINAL, true>(a, st);
+        if (!a.rin_bcast && a.D == WPT * 256) return launch_fwd_p<RT, S, WPT, DEPTH, WIDTH, FINAL, true>(a, st);      // PF assumes no out-of-range lanes
     }
     launch_fwd_p<RT, S, WPT, DEPTH, WIDTH, FINAL, false>(a, st);
 }
@@ -896,7 +1020,7 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
     const long long M = (long long)a.B * a.N;
     const int rows_alloc = (4 / WPT) * bwd_grid_w<RT, S, WPT, WIDTH, DEPTH, LNF>(M, a.D);     // what alm_hc_partial_rows reported
     bool pf = false;
-    if constexpr (sizeof(RT) == 2) pf = !a.bcast && !a.r_bcast;
+    if constexpr (sizeof(RT) == 2) pf = !a.bcast && !a.r_bcast && a.D == WPT * 256;                     // PF assumes no out-of-range lanes
     int grid;
     if constexpr (sizeof(RT) == 2) grid = pf ? bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true>(M, a.D) : bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
     else grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
@@ -977,8 +1101,9 @@ extern "C" int alm_hc_fwd(const void* R_in, int rin_bcast, int r_bf16, const voi
     if ((mode & 1) && (!y_prev || !coef_prev || (!(mode & 4) && !R_out))) return ALM_ERR_BAD_ARG;
     if ((mode & 2) && (!hc_gamma || !Wa || !sa || !Aa || !wb || !sb || !Bb || !ln_gamma || !xn_out || !mean || !rstd || !coef)) return ALM_ERR_BAD_ARG;
     if ((mode & 4) && (!ln_gamma || !(xn_out || xn32_out) || !mean || !rstd || !xs_out)) return ALM_ERR_BAD_ARG;
-    HcFwdArgs a{R_in, rin_bcast, (const bf16_t*)y_prev, ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
-                (bf16_t*)x_out, ldx, (bf16_t*)xn_out, ldxn, mean, rstd, coef, xs_out, xn32_out, B, N, D};
+    if (((ldx | ldxn | ldy) >> 31) || (long long)B * N >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;             // row strides / token index travel as int
+    HcFwdArgs a{R_in, rin_bcast, (const bf16_t*)y_prev, (int)ldy, coef_prev, R_out, HcParams{hc_gamma, Wa, sa, Aa, wb, sb, Bb}, ln_gamma,
+                (bf16_t*)x_out, (int)ldx, (bf16_t*)xn_out, (int)ldxn, mean, rstd, coef, xs_out, xn32_out, B, N, D};
     const int rc = r_bf16 ? dispatch_fwd_s<bf16_t>(a, S, mode, (hipStream_t)stream) : dispatch_fwd_s<float>(a, S, mode, (hipStream_t)stream);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
@@ -1001,8 +1126,9 @@ extern "C" int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const floa
     if ((mode & 1) && (mode & 2) && !dR) return ALM_ERR_BAD_ARG;
     if ((mode & 2) && (lnf ? (!mean || !rstd || !ln_gamma || dx != nullptr) : !dx)) return ALM_ERR_BAD_ARG;
     if ((mode & 1) && (!y_prev || !coef_prev || !dy || !dbeta_out)) return ALM_ERR_BAD_ARG;
-    HcBwdArgs a{dRn, dRn_bcast, dx, lddx, (const bf16_t*)dxn, lddxn, (const bf16_t*)extra, ldex, mean, rstd, ln_gamma, R, r_bcast, coef, dbeta,
-                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, partial, (const bf16_t*)y_prev, ldy, coef_prev, (bf16_t*)dy, lddy, dbeta_out,
+    if (((lddx | lddxn | ldex | ldy | lddy) >> 31) || (long long)B * N >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;   // row strides / token index travel as int
+    HcBwdArgs a{dRn, dRn_bcast, dx, (int)lddx, (const bf16_t*)dxn, (int)lddxn, (const bf16_t*)extra, (int)ldex, mean, rstd, ln_gamma, R, r_bcast, coef, dbeta,
+                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, partial, (const bf16_t*)y_prev, (int)ldy, coef_prev, (bf16_t*)dy, (int)lddy, dbeta_out,
                 B, N, D};
     const int rc = r_bf16 ? dispatch_bwd_s<bf16_t>(a, S, mode, lnf, (hipStream_t)stream) : dispatch_bwd_s<float>(a, S, mode, lnf, (hipStream_t)stream);
     if (rc) return rc;
