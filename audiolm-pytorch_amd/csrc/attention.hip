@@ -205,17 +205,28 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
     const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
 
-    auto stage = [&](int tile, int buf) {
+    // The key-mask byte of a tile is fetched ONE TILE AHEAD into a register (wave 0) and
+    // written to LDS when the tile's K / V DMA is issued: vector-memory results retire in order, so a load issued after the DMA and needed
+    // before the end of the step would make wave 0 wait for the whole DMA it has just started -- every step, with the other waves waiting for
+    // wave 0 at the barrier.
+    struct KeySide { int ok; };
+    auto load_side = [&](int tile) {
+        KeySide ks{1};
+        if (t < 64) {
+            const int key = tile * 64 + t;
+            ks.ok = key < p.N;
+            if (ks.ok && mrow) ks.ok = mrow[key] != 0;
+        }
+        return ks;
+    };
+    auto stage = [&](int tile, int buf, const KeySide& ks) {
         unsigned char* img = smem + buf * 16384;
         dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
         dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
         if (t < 64) {
-            const int key = tile * 64 + t;
-            bool ok = key < p.N;
-            if (ok && mrow) ok = mrow[key] != 0;
-            kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
-            if (BIAS) {
-                const int kc = min(key, p.N - 1);
+            kbias[buf * 64 + t] = ks.ok ? 0.f : -INFINITY;
+            if (BIAS) {                                                // (the biased variants are at their register limit: these stay at stage time)
+                const int kc = min(tile * 64 + t, p.N - 1);
                 kk4s[buf * 64 + t] = p.kkey4[kc];
                 const int ka = p.kattr[kc];
                 kas[buf * 64 + t] = ka;
@@ -261,12 +272,15 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     const TrOff troff = make_troff(lane);
     const int ntiles = qblk + 1;
 
-    stage(0, 0);
+    KeySide side = load_side(0);
+    stage(0, 0, side);
+    side = load_side(1);
     __syncthreads();
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1, side);
+        side = load_side(tile + 2);                                   // lands during this step; first needed by the next step's stage()
         if (active) {
             const unsigned char* Kt = smem + buf * 16384;
             const unsigned char* Vt = Kt + 8192;
@@ -459,17 +473,24 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
     const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
 
-    auto stage = [&](int tile, int buf) {
+    struct KeySide { int ok; };                                      // fetched one tile ahead: see mqa_fwd_kernel
+    auto load_side = [&](int tile) {
+        KeySide ks{1};
+        if (t < 64) {
+            const int key = tile * 64 + t;
+            ks.ok = key < p.N;
+            if (ks.ok && mrow) ks.ok = mrow[key] != 0;
+        }
+        return ks;
+    };
+    auto stage = [&](int tile, int buf, const KeySide& ks) {
         unsigned char* img = smem + buf * 16384;
         dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
         dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
         if (t < 64) {
-            const int key = tile * 64 + t;
-            bool ok = key < p.N;
-            if (ok && mrow) ok = mrow[key] != 0;
-            kbias[buf * 64 + t] = ok ? 0.f : -INFINITY;
-            if (BIAS) {
-                const int kc = min(key, p.N - 1);
+            kbias[buf * 64 + t] = ks.ok ? 0.f : -INFINITY;
+            if (BIAS) {                                                // (the biased variants are at their register limit: these stay at stage time)
+                const int kc = min(tile * 64 + t, p.N - 1);
                 const int kv = p.kkey4[kc];
                 kk4s[buf * 64 + t] = kv;
                 const int ka = p.kattr[kc];
@@ -540,12 +561,15 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     const TrOff troff = make_troff(lane);
     const int ntiles = qblk + 1;
 
-    stage(0, 0);
+    KeySide side = load_side(0);
+    stage(0, 0, side);
+    side = load_side(1);
     __syncthreads();
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1, side);
+        side = load_side(tile + 2);
         if (active) {
             const unsigned char* Kt = smem + buf * 16384;
             const unsigned char* Vt = Kt + 8192;
@@ -716,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 template <bool BIAS>
 __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB of Q / dO tiles + 4 KiB of row terms
     __shared__ int qor_s[BIAS ? 256 : 1];                                      // BIAS: OR of the query attributes of every 64-query tile
 
     const int nkb = (p.N + 63) / 64;
@@ -752,12 +776,24 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const bf16_t* dobase = p.dout + (long long)b * p.N * p.lddo;
     const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qbase), 0, (int)(((long long)(p.N - 1) * p.ldq + p.H * DH) * 2), 0x00020000);
     const auto rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dobase), 0, (int)(((long long)(p.N - 1) * p.lddo + p.H * DH) * 2), 0x00020000);
+    const int hclamp = active ? head : 0;
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
+    const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
+    constexpr int ROWT = 2 * 65536;                                            // row terms [2 buffers][4 heads][-lse/scale | -delta][64 queries] fp32
     auto stage = [&](int qt, int buf) {
-        // wave (hl, kh) fetches head hl's Q tile (kh == 0) or dO tile (kh == 1): 8 pieces each
+        // wave (hl, kh) fetches head hl's Q tile (kh == 0) or dO tile (kh == 1): 8 pieces each -- and, through the SAME DMA queue, the tile's 64
+        // row terms (-lse / scale for kh == 0, -delta for kh == 1: the accumulators' initial values).  They used to be 16 register loads per
+        // wave at the top of every step, issued right after the next tile's DMA: vector-memory results retire in order, so waiting for them
+        // meant waiting for that whole DMA -- the prefetch never overlapped the MFMAs.
         if (!active) return;
         unsigned char* img = smem + buf * 65536 + hl * 16384 + kh * 8192;
         if (kh == 0) dma_tile(rsQ, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.ldq * 2), (unsigned)(head * DH * 2));
         else dma_tile(rsD, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.lddo * 2), (unsigned)(head * DH * 2));
+        const int qi = qt * 64 + lane;
+        const unsigned vo = qi < p.N ? (unsigned)qi * 4u : OOB;               // rows >= N read 0 (harmless: their Q / dO rows are zero)
+        unsigned char* rt = smem + ROWT + buf * 2048 + hl * 512 + kh * 256;
+        if (kh == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void*)rt, 4, vo, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDl, (lds_void*)rt, 4, vo, 0, 0, 0);
     };
 
     f32x16 dkt[2], dvt[2];             // [db]: (d x 32 keys) blocks
@@ -769,9 +805,6 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const int frow = fsw(lr);
     const TrOff troff = make_troff(lane);
     const int nqt = (p.N + 63) / 64;
-    const int hclamp = active ? head : 0;
-    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
-    const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     const int key_eff = kvalid ? key : 0x7fffffff;                       // a masked / out-of-range key "follows" every query
     int kk4l = 0, kal = 0;
     __amdgpu_buffer_rsrc_t rsT = rsL, rsKQ = rsL, rsAQ = rsL;
@@ -802,18 +835,16 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             // Q / dO rows are zero so P only ever meets zeros).
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             f32x16 s[2], dp[2];
+            const float* rowt = reinterpret_cast<const float*>(smem + ROWT + buf * 2048 + hl * 512);      // [64] -lse/scale, [64] -delta (staged by DMA)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int qq0 = q0 + qb * 32 + 8 * g + 4 * lh;                      // 4 consecutive query rows
-                    const u32x4 lraw = __builtin_amdgcn_raw_buffer_load_b128(rsL, qq0 * 4, 0, 0);
-                    const u32x4 draw = __builtin_amdgcn_raw_buffer_load_b128(rsDl, qq0 * 4, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        s[qb][4 * g + c] = __uint_as_float(lraw[c]);
-                        dp[qb][4 * g + c] = __uint_as_float(draw[c]);
-                    }
+                    const int ql = qb * 32 + 8 * g + 4 * lh;                            // 4 consecutive query rows of the tile
+                    const float4 lraw = *reinterpret_cast<const float4*>(rowt + ql);
+                    const float4 draw = *reinterpret_cast<const float4*>(rowt + 64 + ql);
+                    s[qb][4 * g] = lraw.x; s[qb][4 * g + 1] = lraw.y; s[qb][4 * g + 2] = lraw.z; s[qb][4 * g + 3] = lraw.w;
+                    dp[qb][4 * g] = draw.x; dp[qb][4 * g + 1] = draw.y; dp[qb][4 * g + 2] = draw.z; dp[qb][4 * g + 3] = draw.w;
                 }
             if (BIAS) {                                                                 // rows >= N read offset 0 -> an out-of-table gather -> 0
                 auto add_bias = [&](auto spc) {
@@ -986,13 +1017,13 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
-    else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<false>, dim3(nqb * p.HG * B), dim3(512), 131072, st, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
+    else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<false>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }
