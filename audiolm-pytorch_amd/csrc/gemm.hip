@@ -684,6 +684,49 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs pj) {
     }
 }
 
+// the same with two elements per lane: 64 x 128 tiles, 8-byte fp32 loads, 4-byte bf16-pair stores both ways (needs even leading dimensions and
+// 8 / 4-byte aligned bases; the re-pack of a layer's weights is a pure HBM stream: 4 B read + 2 x 2 B written per parameter)
+struct PackJobs2 {
+    AlmPackJob job[8];
+    int tile_end[8];          // exclusive prefix sums of the per-job 64 x 128 tile counts
+    int njobs;
+};
+__global__ __launch_bounds__(256) void pack_weights_multi2_kernel(PackJobs2 pj) {
+    __shared__ uint32_t tile[64][65];                                   // [row][column pair], 65: the transposed reads spread over the banks
+    int j = 0;
+    while (j + 1 < pj.njobs && (int)blockIdx.x >= pj.tile_end[j]) ++j;
+    const AlmPackJob& q = pj.job[j];
+    const int local = blockIdx.x - (j ? pj.tile_end[j - 1] : 0);
+    const int tcols = (q.cols_pad + 127) / 128;
+    const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(q.dst);
+    bf16_t* dstT = reinterpret_cast<bf16_t*>(q.dstT);
+    const int c = c0 + 2 * tx;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i;
+        float2 v = make_float2(0.f, 0.f);
+        if (r < q.rows) {
+            if (c + 1 < q.cols) v = *reinterpret_cast<const float2*>(q.src + (long long)r * q.ld_src + c);
+            else if (c < q.cols) v.x = q.src[(long long)r * q.ld_src + c];
+        }
+        const uint32_t pk = pack_bf2(v.x, v.y);
+        tile[i][tx] = pk;
+        if (dst && r < q.rows_pad && c < q.cols_pad) *reinterpret_cast<uint32_t*>(dst + (long long)r * q.ld_dst + c) = pk;
+    }
+    if (!dstT) return;
+    __syncthreads();
+    // transposed rows: output row = source column cc, 64 source rows = 32 pairs; a half wave writes one 128-byte output row segment
+    const int rp = tx & 31, hw = tx >> 5;
+    for (int it = ty; it < 64; it += 4) {
+        const int cc = it * 2 + hw;                                     // source column within the tile
+        const int oc = c0 + cc, orow = r0 + 2 * rp;
+        const uint32_t a = tile[2 * rp][cc >> 1], b = tile[2 * rp + 1][cc >> 1];
+        const uint32_t pk = (cc & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        if (oc < q.cols_pad && orow < q.rows_pad) *reinterpret_cast<uint32_t*>(dstT + (long long)oc * q.ld_dstT + orow) = pk;
+    }
+}
+
 // ---- launch plumbing ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
 int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
@@ -897,12 +940,31 @@ extern "C" int alm_transpose_bf16(const void* src, void* dst, int rows, int cols
 extern "C" int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream) {
     if (njobs <= 0) return 0;
     if (njobs > 8 || !jobs) return ALM_ERR_BAD_ARG;
-    PackJobs pj{};
-    int total = 0;
+    bool vec = true;
     for (int j = 0; j < njobs; ++j) {
         const AlmPackJob& q = jobs[j];
         if (q.rows <= 0 || q.cols <= 0 || q.rows_pad < q.rows || q.cols_pad < q.cols) return ALM_ERR_BAD_ARG;
         if ((q.dst && q.ld_dst < q.cols_pad) || (q.dstT && q.ld_dstT < q.rows_pad)) return ALM_ERR_BAD_ARG;
+        vec = vec && !((q.ld_src | q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 1) && !((uintptr_t)q.src & 7) && !((uintptr_t)q.dst & 3) &&
+              !((uintptr_t)q.dstT & 3);
+    }
+    if (vec) {
+        PackJobs2 pj{};
+        int total = 0;
+        for (int j = 0; j < njobs; ++j) {
+            pj.job[j] = jobs[j];
+            total += ((jobs[j].cols_pad + 127) / 128) * ((jobs[j].rows_pad + 63) / 64);
+            pj.tile_end[j] = total;
+        }
+        pj.njobs = njobs;
+        hipLaunchKernelGGL(pack_weights_multi2_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pj);
+        ALM_LAUNCH_CHECK();
+        return 0;
+    }
+    PackJobs pj{};
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const AlmPackJob& q = jobs[j];
         pj.job[j] = q;
         total += ((q.cols_pad + 63) / 64) * ((q.rows_pad + 63) / 64);
         pj.tile_end[j] = total;

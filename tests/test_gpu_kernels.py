@@ -138,7 +138,7 @@ def test_transpose_and_pack(ops):
 
 def test_pack_weights_multi(ops):
     """several weights per launch == one alm_pack_weight launch each (incl. row-sliced sources and column-sliced destinations)"""
-    ws = [rnd(70, 130, seed=90), rnd(128, 64, seed=91), rnd(341, 96, seed=92)]
+    ws = [rnd(70, 130, seed=90), rnd(128, 64, seed=91), rnd(341, 96, seed=92), rnd(33, 129, seed=94), rnd(5460, 1024, seed=95)]   # odd rows / cols, a real W1
     jobs, singles = [], []
     for w in ws:
         rows, cols = w.shape
@@ -153,7 +153,7 @@ def test_pack_weights_multi(ops):
     jobs.append((big[:100], None, WT[:, :104], 104, 64))
     jobs.append((big[100:], None, WT[:, 104:], 104, 64))
     ops.pack_weights_multi(jobs)
-    for (w, d1, t1, rp, cp), (d2, t2) in zip(jobs[:3], singles):
+    for (w, d1, t1, rp, cp), (d2, t2) in zip(jobs[:5], singles):
         assert torch.equal(d1, d2) and torch.equal(t1, t2)
     assert torch.equal(WT[:, :100], big[:100].to(BF16).t()) and torch.equal(WT[:, 104:204], big[100:].to(BF16).t())
     assert float(WT[:, 100:104].float().abs().max()) == 0.0
