@@ -134,7 +134,7 @@ def load(build_if_missing: bool = True):
 
 class AlmOptTensor(ctypes.Structure):
     """mirror of AlmOptTensor in include/audiolm_hip.h"""
-    _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_longlong), ('wd', c_float), ('reserved', c_int)]
+    _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_longlong), ('wd', c_float), ('step', c_int)]
 
 
 class AlmPackJob(ctypes.Structure):

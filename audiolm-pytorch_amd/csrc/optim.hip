@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const AlmOptTensor* __restric
     float* v = reinterpret_cast<float*>(t.v);
     float clip = 1.f;
     if (a.sumsq) clip = fminf(1.f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));
+    if (t.step > 0) {
+        // this tensor's own step count (torch.optim.Adam keeps `step` per parameter: tensors whose gradients first appear later, or are None on
+        // some steps, have their own bias corrections)
+        const double bc1 = 1.0 - exp((double)t.step * log((double)a.beta1)), bc2 = 1.0 - exp((double)t.step * log((double)a.beta2));
+        a.step_size = (float)((double)a.lr / bc1);
+        a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     long long tail = beg;
     if (vec) {
@@ -102,7 +109,7 @@ extern "C" int alm_opt_grad_sumsq(const AlmOptTensor* tensors, const int* chunks
     return 0;
 }
 
-// step: 1-based count of THIS step (bias corrections 1 - beta^step).  sumsq: device scalar for the clip (NULL = no clipping).
+// step: 1-based count of THIS step (bias corrections 1 - beta^step) for tensors whose own AlmOptTensor.step is 0.  sumsq: device scalar for the clip (NULL = no clipping).
 extern "C" int alm_opt_adam_step(const AlmOptTensor* tensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
                                  int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream) {
     if (nchunks <= 0) return 0;

@@ -21,6 +21,10 @@ def _chk(t, dtype=None):
         raise _lib.AlmError('audiolm_pytorch_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback')
     if dtype is not None and t.dtype != dtype:
         raise _lib.AlmError(f'expected {dtype}, got {t.dtype}')
+    if t.device.index != torch.cuda.current_device():
+        # every launch goes to the CURRENT device's stream (_st): a tensor of another device would be dereferenced there
+        raise _lib.AlmError(f'tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: call '
+                            'torch.cuda.set_device(...) (one process per GPU) before using audiolm_pytorch_amd')
     return t
 
 

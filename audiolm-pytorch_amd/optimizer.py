@@ -47,6 +47,8 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad.dtype != F32 or not p.grad.is_contiguous():
                 p.grad = p.grad.to(F32).contiguous()
             st = self.state[p]
+            if len(st) != 0 and st['step'].is_cuda:              # a checkpoint loaded with map_location='cuda': keep the counter on the host
+                st['step'] = st['step'].cpu()
             if len(st) == 0:
                 st['step'] = torch.tensor(0., dtype=F32)         # torch.optim.Adam layout (host step counter, capturable=False)
                 st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
@@ -68,18 +70,31 @@ class FusedAdam(torch.optim.Optimizer):
         arr = (_lib.AlmOptTensor * len(flat))()
         i = 0
         for group, ps in zip(self.param_groups, groups):
-            for p in ps:
+            # the usual case -- every tensor of the launch at the same step -- takes the launch's `step` argument (bias corrections computed once
+            # on the host, in double); only a group with mixed counts stores them per tensor (the kernel then derives its own corrections)
+            steps = [int(self.state[p]['step']) for p in ps]
+            mixed = len(set(steps)) > 1
+            for p, st_count in zip(ps, steps):
                 st = self.state[p]
+                # step: THIS parameter's count for the coming update (torch.optim.Adam tracks it per parameter: one whose gradient first
+                # appears later, or is None on some steps, has its own bias corrections)
                 arr[i] = _lib.AlmOptTensor(p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel(),
-                                           float(group['weight_decay']), 0)
+                                           float(group['weight_decay']), st_count + 1 if mixed else 0)
                 i += 1
         nbytes = rec * len(flat)
         if self._pinned is None or self._pinned[0].numel() < nbytes:
             self._pinned = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        stage = self._pinned[self._turn & 1]
+            self._pinned_done = [None, None]
+        turn = self._turn & 1
+        stage = self._pinned[turn]
         self._turn += 1
+        if self._pinned_done[turn] is not None:
+            self._pinned_done[turn].synchronize()                # the asynchronous copy that last read this staging buffer has finished
         ctypes.memmove(stage.data_ptr(), ctypes.addressof(arr), nbytes)
         table = stage[:nbytes].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pinned_done[turn] = ev
         ckey = tuple(tuple(p.numel() for p in ps) for ps in groups)
         if self._chunks is None or self._chunks[0] != ckey:
             ch = _lib.query('alm_opt_chunk_elems')
@@ -133,7 +148,7 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             for p in ps:
                 self.state[p]['step'] += 1
-            step = int(self.state[ps[0]]['step'])
+            step = int(self.state[ps[0]]['step'])                # used by the tensors whose table entry carries no step of its own
             b1, b2 = group['betas']
             _lib.call('alm_opt_adam_step', table.data_ptr(), chunks.data_ptr(), chunks.shape[0], float(group['lr']), float(b1), float(b2),
                       float(group['eps']), step, int(bool(group['decoupled_weight_decay'])), clip[1].data_ptr() if clip else None,

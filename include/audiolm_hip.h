@@ -235,7 +235,7 @@ int alm_mqa_decode_attn(const void* q, long long ldq, void* cache, long long cac
 typedef struct AlmOptTensor {
     void* p; const void* g; void* m; void* v;   /* parameter, gradient, exp_avg, exp_avg_sq */
     long long n;                                /* elements */
-    float wd; int reserved;                     /* weight decay of this tensor */
+    float wd; int step;                         /* weight decay of this tensor; its own 1-based step count of THIS update (bias corrections), 0: the launch's `step` */
 } AlmOptTensor;
 int alm_opt_chunk_elems(void);
 int alm_opt_grad_sumsq(const AlmOptTensor* tensors, const int* chunks, int nchunks, float* partial, void* stream);

@@ -54,3 +54,28 @@ def test_fused_adam_skips_parameters_without_gradient():
     o.step()
     assert not torch.equal(ps[0].detach(), before[0])
     assert all(torch.equal(p.detach(), b) for p, b in zip(ps[1:], before[1:]))
+
+
+def test_fused_adam_keeps_a_step_count_per_parameter():
+    """torch.optim.Adam tracks `step` per parameter: a parameter whose gradient is None on some steps (a conditional head, a late-unfrozen
+    weight) gets its own bias corrections.  Three steps where the second parameter only has a gradient on steps 2 and 3."""
+    import audiolm_pytorch_amd as A
+    base = _params(3)[:3]
+    ours = [torch.nn.Parameter(p.clone()) for p in base]
+    ref = [torch.nn.Parameter(p.clone()) for p in base]
+    o = A.get_optimizer(ours, lr=3e-3, wd=0.)
+    r = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        for i, (p, q) in enumerate(zip(ours, ref)):
+            if i == 1 and step == 0:
+                p.grad = q.grad = None
+                continue
+            gr = torch.randn(p.shape, generator=g).to(p.device)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        o.step()
+        r.step()
+        for p, q in zip(ours, ref):
+            err = float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp(min=1e-30))
+            assert err <= 2e-6, (step, tuple(p.shape), err)
+    assert [float(o.state[p]['step']) for p in ours] == [float(r.state[q]['step']) for q in ref] == [3.0, 2.0, 3.0]
