@@ -14,6 +14,8 @@
 // D = 1024), every reduction (S norms, S*(S+2) dot products, LayerNorm statistics) is a wave shuffle butterfly: no LDS, no
 // block barrier.  Parameter gradients are accumulated in registers over a grid-stride token loop, reduced over the 4 waves
 // of a block through LDS and written as per-block partial rows (second stage: alm_colsum).
+#include <algorithm>
+
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -492,7 +494,9 @@ struct HcBwdArgs {
 //          separate LayerNorm-backward launch exist on the 4-stream path.
 // partial row (floats): raw_a[S+1][D] | raw_b[D] | dln[D] | dAa[S][S+1] | dBb[S] | dsa | dsb   with raw_* = sum over tokens, streams of
 // nhat * (dap | dbp): dWa = (gamma+1) raw_a, dwb = (gamma+1) raw_b, dgamma = sum_t Wa raw_a + wb raw_b  (alm_hc_param_grads).
-template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF>      // PF: see hc_fwd_kernel (needs no bcast / r_bcast)
+// PF: see hc_fwd_kernel.  BC (PF only): 0 = stream tensors everywhere, 1 = dRn is the broadcast fp32 [M][D] tensor (`bcast`: the last branch, behind
+// the final stream sum), 2 = R is (`r_bcast`: the first branch, right after the stream expansion) -- the two once-per-step launches prefetch too.
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
     const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
@@ -583,11 +587,19 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = e0;         // PF: D == WPT * 256, every lane in range
         const long long tofs = ((long long)b_ * S * a.N + n_) * a.D + el;
         issue_scalars(w, m_);
+        if constexpr (BC == 1) {
+            w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + (long long)m_ * a.D + el);
+        } else {
 #pragma unroll
-        for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
+            for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
+        }
         if (WIDTH) {
+            if constexpr (BC == 2) {
+                w.rb = ld4(reinterpret_cast<const float*>(a.R) + (long long)m_ * a.D + el);
+            } else {
 #pragma unroll
-            for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
+                for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
+            }
             if (LNF) {
                 w.dxn = *reinterpret_cast<const uint2*>(a.dxn + (long long)m_ * a.lddxn + el);
                 w.ex = make_uint2(0u, 0u);
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             // a skipped token re-read token 0 (finite data): its results are never stored, its coefficient gradients are zeroed through `up`
             // below, and the one running sum that takes the loaded data directly (dln) is protected by zeroing dxn
 #pragma unroll
-            for (int t2 = 0; t2 < S; ++t2) g[t2] = unraw(w.g[t2]);
+            for (int t2 = 0; t2 < S; ++t2) g[t2] = BC == 1 ? w.gb : unraw(w.g[t2]);
         } else if (a.bcast) {
 #pragma unroll
             for (int t2 = 0; t2 < S; ++t2) g[t2] = w.gb;
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         if (WIDTH) {
             if (PF) {
 #pragma unroll
-                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = unraw(w.r[s2]);
+                for (int s2 = 0; s2 < S; ++s2) r_c[s2] = BC == 2 ? w.rb : unraw(w.r[s2]);
             } else if (a.r_bcast) {
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2) r_c[s2] = w.rb;
@@ -991,10 +1003,10 @@ int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 256 * 4
 
 // the prefetching variant needs more registers and may be resident in fewer copies: the partial-row buffer is sized for the larger of the
 // two grids (a launch may then use fewer rows than alm_hc_partial_rows reported: the surplus rows are zeroed by the launch wrapper)
-template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF>
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
 int bwd_grid_p(long long M, int D) {
     static int resident = 0;
-    if (!resident) resident = resident_blocks(hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, PF>);
+    if (!resident) resident = resident_blocks(hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, PF, BC>);
     const int cap = hc_bwd_blocks(M, D);
     const int grid = hc_grid(M, 4 / WPT, resident);
     return grid > cap ? cap : grid;
@@ -1003,8 +1015,9 @@ template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
 int bwd_grid_w(long long M, int D) {
     int g = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, D);
     if constexpr (sizeof(RT) == 2) {
-        const int g2 = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true>(M, D);
-        g = g2 > g ? g2 : g;
+        g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>(M, D));
+        g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>(M, D));
+        if constexpr (WIDTH) g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>(M, D));
     }
     return g;
 }
@@ -1019,18 +1032,28 @@ template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF>
 void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
     const long long M = (long long)a.B * a.N;
     const int rows_alloc = (4 / WPT) * bwd_grid_w<RT, S, WPT, WIDTH, DEPTH, LNF>(M, a.D);     // what alm_hc_partial_rows reported
-    bool pf = false;
-    if constexpr (sizeof(RT) == 2) pf = !a.bcast && !a.r_bcast && a.D == WPT * 256;                     // PF assumes no out-of-range lanes
-    int grid;
-    if constexpr (sizeof(RT) == 2) grid = pf ? bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true>(M, a.D) : bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
-    else grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
+    // prefetching variants (bf16 streams, every lane in range): bc 0 plain, 1 broadcast dRn, 2 broadcast R; both broadcast: the plain kernel
+    int bc = -1;
+    if constexpr (sizeof(RT) == 2) {
+        if (a.D == WPT * 256 && !(a.bcast && a.r_bcast)) bc = a.bcast ? 1 : ((a.r_bcast && WIDTH) ? 2 : (a.r_bcast ? -1 : 0));
+    }
+    int grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
+    if constexpr (sizeof(RT) == 2) {
+        if (bc == 0) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>(M, a.D);
+        if (bc == 1) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>(M, a.D);
+        if constexpr (WIDTH) { if (bc == 2) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>(M, a.D); }
+    }
     if (WIDTH && a.partial) {
         const int rows_used = (4 / WPT) * grid;
         const long long P = (long long)a.D * (S + 3) + S * (S + 1) + S + 2;
         if (rows_used < rows_alloc) (void)hipMemsetAsync(a.partial + (long long)rows_used * P, 0, (size_t)(rows_alloc - rows_used) * P * sizeof(float), st);
     }
     if constexpr (sizeof(RT) == 2) {
-        if (pf) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (bc == 0) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>), dim3(grid), dim3(256), 0, st, a); return; }
+        if (bc == 1) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>), dim3(grid), dim3(256), 0, st, a); return; }
+        if constexpr (WIDTH) {
+            if (bc == 2) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>), dim3(grid), dim3(256), 0, st, a); return; }
+        }
     }
     hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, false>), dim3(grid), dim3(256), 0, st, a);
 }
