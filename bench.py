@@ -270,11 +270,13 @@ def main():
     # ---- schedule
     schedule, note, gstep = 'eager', None, None
     want = args.schedule
-    if want == 'auto':
-        # measured on MI355X (profiles/r2_schedules.log): eager 15.5 ms, graph 16.2 ms, graph2 17.1 ms per step -- the GPU, not the host, is the
-        # limit (host issue ~10-12 ms < 15.5 ms), a replayed graph adds a per-node gap to ~700 kernels and the two half-batches lose more to
-        # half-size GEMM tiles / the missing weight-gradient side stream than they win by co-residency (the 246-VGPR hyper-connection backward
-        # cannot share a SIMD with the 8-wave GEMM).  The captured schedules stay selectable; eager is the default.
+    probe = None
+    auto = want == 'auto'
+    if auto:
+        # measured on MI355X (profiles/r2_schedules.log) at the headline shape: eager 15.5 ms, graph 16.2 ms, graph2 17.1 ms per step -- there the
+        # GPU, not the host, is the limit (host issue ~11 ms < 14 ms) and a replayed graph only adds a per-node gap to ~900 kernels.  The smaller
+        # configurations are the other way round (coarse1024: 8.4 ms of GPU work against 8-9 ms of host issue), so `auto` PROBES: a few eager steps
+        # and a few replays of the captured step, and the timed region below runs whichever was faster (both probe figures are reported).
         want = 'eager'
     if want == 'eager2':                                        # diagnostic: the two-half-batch schedule without a graph (host-bound)
         model.transformer.micro_batches = 2
@@ -314,6 +316,26 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
         return dt
+
+    if auto and world == 1 and N <= 4096:
+        for _ in range(8):
+            eager_step()
+        te = timed(6, eager_step) / 6 * 1e3
+        probe = {'eager_ms': round(te, 3)}
+        try:
+            cand = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=1)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                cand(**inputs)
+            tg = timed(6, lambda: cand(**inputs)) / 6 * 1e3
+            probe['graph_ms'] = round(tg, 3)
+            if tg < 0.97 * te:                                  # a clear win only: the eager path keeps the weight-gradient side stream
+                gstep, schedule = cand, 'graph'
+            else:
+                del cand
+        except Exception as e:
+            probe['graph_error'] = f'{type(e).__name__}: {str(e)[:120]}'
+            torch.cuda.synchronize()
 
     # untimed priming in addition to --warmup: the first steps grow the caching allocator's pools (main + side stream) and run at ramping
     # clocks; measured on MI355X the step time only settles after ~10 steps (17.6 -> 16.4 ms).  The timed region below is exactly --steps steps.
@@ -462,6 +484,8 @@ def main():
         }
         if note:
             out['config']['schedule_note'] = note
+        if probe:
+            out['config']['schedule_probe'] = probe              # --schedule auto: ms/step of a few eager steps / graph replays; the faster one ran
         if roof:
             out['roofline'] = roof
         if opt_leg:
