@@ -12,7 +12,14 @@ from . import _lib
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _st():
+    """hipStream_t of torch's CURRENT stream on the current device (every alm_* launch goes there).  The raw-handle query is one C call; the
+    public torch.cuda.current_stream() builds a Stream object per call (~8 us: ~1.5 ms of host time per training step at ~180 launches)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
