@@ -36,6 +36,11 @@ def relmax(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
 
 
+def relfrob(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
 # ------------------------------------------------------------------------------------------------ GEMM / transpose / pack
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 128), (300, 200, 72), (1000, 520, 1024), (130, 1025, 64), (257, 129, 2736)])
@@ -255,7 +260,10 @@ def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
     ref = _attn_ref(qf, kf, vf, mask, B, N, H, d)                    # b h n d
     ref2 = ref.permute(0, 2, 1, 3).reshape(B * N, H * d)
     e = relmax(o, ref2)
-    assert e <= 1.2e-2, f'attention fwd rel-max err {e}'            # P and O rounded to bf16 once each (2 x 2^-8) + exp2 vs exp
+    ef = relfrob(o, ref2)
+    # P and O are rounded to bf16 once each (2^-9 relative per element): measured on MI355X rel-max 1.8-2.5e-3, rel-Frobenius 1.8-2.1e-3 over
+    # these shapes; the bounds leave a factor ~1.5-2 (round 1 allowed 1.2e-2 / 2e-2 rel-max)
+    assert e <= 5e-3 and ef <= 3e-3, f'attention fwd rel-max err {e}, rel-frob {ef}'
     do = rnd(B * N, H * d, seed=25, dtype=BF16)
     ref2.backward(do.float())
     dq, dkv_parts = ops.mqa_attn_bwd(q, k, v, mu8, o, lse, do, B, N, H, d)
@@ -263,7 +271,8 @@ def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
 
     for name, got, want in (('dq', dq, qf.grad), ('dk', dkv[:, :d], kf.grad), ('dv', dkv[:, d:], vf.grad)):
         e = relmax(got, want)
-        assert e <= 2e-2, f'attention bwd {name} rel-max err {e}'
+        ef = relfrob(got, want)                                     # measured: rel-max 0.8-5.4e-3, rel-Frobenius 1.3-2.9e-3
+        assert e <= 1e-2 and ef <= 4e-3, f'attention bwd {name} rel-max err {e}, rel-frob {ef}'
     # log-sum-exp statistic (fp32): lse = logsumexp(scale * q k^T over allowed keys)
     sim = torch.einsum('bhid,bjd->bhij', qf.detach().view(B, N, H, d).permute(0, 2, 1, 3), kf.detach().view(B, N, d)) * d ** -0.5
     allow = torch.ones(N, N, dtype=torch.bool, device=dev()).tril()
