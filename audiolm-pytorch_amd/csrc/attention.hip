@@ -50,6 +50,22 @@ typedef __attribute__((address_space(3))) void lds_void;
 // chunk swizzle of the 128-B-row LDS images
 __device__ __forceinline__ int fsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 
+// 16-byte LDS loads inside the DMA loops go through EXT-VECTOR types, never through HIP's float4 / int4 structs.  Why (found in the ISA, reproduced
+// in a 20-line kernel): after a `buffer_load ... lds` the compiler puts `s_waitcnt vmcnt(0)` in front of the next LDS load made through one of the
+// HIP_vector_type structs (an aggregate access it cannot tell apart from the DMA's destination), but not in front of ext_vector or scalar loads.
+// A single `*(const float4*)(kbias + ...)` at the top of a tile step therefore waited for the WHOLE DMA of the next tile that had just been issued:
+// the prefetch never overlapped the MFMAs in any of the three kernels.  The barrier at the end of every step is what orders DMA writes and reads.
+typedef __attribute__((ext_vector_type(4))) float lds_f4v;
+typedef __attribute__((ext_vector_type(4))) int lds_i4v;
+__device__ __forceinline__ float4 lds_ld_f4(const float* p) {
+    const lds_f4v v = *reinterpret_cast<const lds_f4v*>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ int4 lds_ld_i4(const int* p) {
+    const lds_i4v v = *reinterpret_cast<const lds_i4v*>(p);
+    return make_int4(v[0], v[1], v[2], v[3]);
+}
+
 // row fragment: lane (row, lh) gets dims ks*16 + lh*8 .. +7 of `row`
 __device__ __forceinline__ bf16x8 nat_frag(const unsigned char* tile, int row, int frow, int ks, int lh) {
     return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((((ks << 1) | lh) ^ frow) << 4));
@@ -179,9 +195,15 @@ __device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsig
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
+template <bool BIAS> constexpr int FWD_LDS = 2 * 16384 + 512 + (BIAS ? 1024 + 64 : 0);
+template <bool BIAS> constexpr int DQ_LDS = 2 * 16384 + 512 + (BIAS ? 1024 + 64 + HPB * WCAP * 4 : 0);
+
 template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 + 64 : 0)];
+    // DYNAMIC LDS on purpose: for a static __shared__ array the compiler knows the object every ds_read touches and, having no alias scopes for the
+    // LDS-DMA writes, waits (s_waitcnt vmcnt(0)) for ALL outstanding DMA before each batch of fragment reads -- the next tile's prefetch could never
+    // overlap this tile's MFMAs.  With extern __shared__ it leaves the ordering to the barriers below (as in gemm.hip and the dK/dV kernel).
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];       // FWD_LDS<BIAS> bytes
     float* kbias = reinterpret_cast<float*>(smem + 32768);          // [2][64]: 0 for attendable keys, -inf otherwise
     int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] key-side attributes
     int* kas = kk4s + 128;
@@ -294,12 +316,12 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                        const float4 bv = lds_ld_f4(kbs + kb * 32 + 8 * g + 4 * lh);
                         const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
                         if (BIAS) {
-                            const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            const int4 kk = lds_ld_i4(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                             int4 ka = make_int4(0, 0, 0, 0);
-                            if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                            if (SP) ka = lds_ld_i4(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                             const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
                             for (int qb = 0; qb < 2; ++qb)
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------------------------
 template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 16384 + 512 + (BIAS ? 1024 + 64 + HPB * WCAP * 4 : 0)];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];       // DQ_LDS<BIAS> bytes; dynamic LDS: see mqa_fwd_kernel
     float* kbias = reinterpret_cast<float*>(smem + 32768);
     int* kk4s = reinterpret_cast<int*>(smem + 32768 + 512);         // BIAS: [2][64] key-side table offsets, [2][64] attributes,
     int* kas = kk4s + 128;                                          //       [2][2] min / max offset of the staged key tile,
@@ -584,12 +606,12 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const float4 bv = *reinterpret_cast<const float4*>(kbs + kb * 32 + 8 * g + 4 * lh);
+                            const float4 bv = lds_ld_f4(kbs + kb * 32 + 8 * g + 4 * lh);
                             const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
                             if (BIAS) {
-                                const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                const int4 kk = lds_ld_i4(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                                 int4 ka = make_int4(0, 0, 0, 0);
-                                if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                if (SP) ka = lds_ld_i4(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                                 const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) st[kb][4 * g + c] = bvv[c] + bias_at<SP>(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
@@ -647,9 +669,9 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
-                                const int4 kk = *reinterpret_cast<const int4*>(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                const int4 kk = lds_ld_i4(kk4s + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                                 int4 ka = make_int4(0, 0, 0, 0);
-                                if (SP) ka = *reinterpret_cast<const int4*>(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
+                                if (SP) ka = lds_ld_i4(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                                 const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
@@ -841,8 +863,8 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ql = qb * 32 + 8 * g + 4 * lh;                            // 4 consecutive query rows of the tile
-                    const float4 lraw = *reinterpret_cast<const float4*>(rowt + ql);
-                    const float4 draw = *reinterpret_cast<const float4*>(rowt + 64 + ql);
+                    const float4 lraw = lds_ld_f4(rowt + ql);
+                    const float4 draw = lds_ld_f4(rowt + 64 + ql);
                     s[qb][4 * g] = lraw.x; s[qb][4 * g + 1] = lraw.y; s[qb][4 * g + 2] = lraw.z; s[qb][4 * g + 3] = lraw.w;
                     dp[qb][4 * g] = draw.x; dp[qb][4 * g + 1] = draw.y; dp[qb][4 * g + 2] = draw.z; dp[qb][4 * g + 3] = draw.w;
                 }
@@ -982,8 +1004,8 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     if (rc) return rc;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
     const int nqb = (N + 63) / 64;
-    if (p.tbl) hipLaunchKernelGGL(mqa_fwd_kernel<true>, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(mqa_fwd_kernel<false>, dim3(nqb * p.HG * B), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_fwd_kernel<true>, dim3(nqb * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(mqa_fwd_kernel<false>, dim3(nqb * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }
@@ -1013,8 +1035,8 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr; p.dtbl_part = ba.dtbl_part;
     const int nqb = (N + 63) / 64;
-    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), 0, st, p);
+    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
+    else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);

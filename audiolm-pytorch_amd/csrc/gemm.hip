@@ -282,8 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     const unsigned kstepA = TNMODE ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
     const unsigned kstepB = TNMODE ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
 
-    auto stage = [&](int kt, int buf) {
-        unsigned char* base = smem + buf * STAGE;
+    auto stage = [&](int kt, unsigned char* base) {
         const int kleft = Krem - kt * BK;
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
@@ -328,13 +327,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (Krem + BK - 1) / BK;
-    stage(0, 0);
+    stage(0, smem);
     __syncthreads();
 
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const unsigned char* sb = smem + buf * STAGE;
+    // One K-step: issue the next stage's DMA into `dst`, read this stage's fragments from `sb`.  The two are DISTINCT buffers, and they are
+    // `__restrict__` parameters on purpose: inlined, that becomes alias-scope metadata, without which the compiler makes every LDS read that has
+    // no type-based alias info of its own -- the `ds_read_b64_tr_b16` transpose reads of the TN mode are such -- wait (`s_waitcnt vmcnt(0)`) for
+    // ALL pending LDS-DMA: the DMA just issued.  The weight-gradient loops then ran DMA and MFMAs strictly one after the other.
+    auto kstep = [&](unsigned char* __restrict__ dst, const unsigned char* __restrict__ sb, int kt) {
+        if (kt + 1 < nk) stage(kt + 1, dst);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a[TM], b[TNB];
@@ -363,6 +364,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
                 for (int j = 0; j < TNB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
         }
+    };
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        kstep(smem + (buf ^ 1) * STAGE, smem + buf * STAGE, kt);
         __syncthreads();          // reads of `buf` done (lgkmcnt 0), next stage landed (vmcnt 0), all waves agree
         buf ^= 1;
     }
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 // the matrix pipe (measured: MFMA-only loop 601 us, DMA-only 716 us, both 886 us at 8192^3: they do not overlap).
 // Here the K-loop is a sequence of half-step SLOTS closed by one workgroup barrier each; in a slot one wave row issues the DMA of a later
 // stage (LOAD slot) while the other reads fragments and runs its 32 MFMAs (COMPUTE slot), then they swap:
-//     wave row g, slot s, q = s - g:   q even  -> LOAD stage q / 2          q odd -> COMPUTE stage (q - 3) / 2
+//     wave row g, slot s, q = s - g:   q even  -> LOAD stage q / 2          q odd -> COMPUTE stage (q - 1) / 2 - 1
 // so a stage is loaded 3 slots before the loading row computes on it, its DMA is waited for (vmcnt(0)) at the end of the row's next
 // COMPUTE slot -- a whole slot of MFMAs later -- and every wave executes exactly one barrier per slot (2 nk + 3 slots: no wave ever waits
 // on a barrier the others skip).
@@ -487,9 +492,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     const unsigned kstepB = TNMODE ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
     unsigned char* const myA = smem + wr * 2 * AH_BYTES;                    // this wave row's two A-half buffers
 
-    auto stage = [&](int j) {
-        unsigned char* ad = myA + (j & 1) * AH_BYTES;
-        unsigned char* bd = smem + B_BASE + (j % 3) * B_BYTES;
+    auto stage = [&](int j, unsigned char* ad, unsigned char* bd) {
         const int kleft = Krem - j * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -527,9 +530,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int c) {
-        const unsigned char* sa = myA + (c & 1) * AH_BYTES;
-        const unsigned char* sb = smem + B_BASE + (c % 3) * B_BYTES;
+    auto compute = [&](const unsigned char* sa, const unsigned char* sb) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a[TM], b[TNB];
@@ -559,22 +560,26 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     };
 
     const int nk = (Krem + BK - 1) / BK;
-    // slot pair i = slots 2 i, 2 i + 1 (written out per wave row: q = s - wr); nk + 2 pairs cover the 2 nk + 3 slots
-    if (wr == 0) {
-        for (int i = 0; i < nk + 2; ++i) {
-            if (i < nk) stage(i);
-            __builtin_amdgcn_s_barrier();                                   // raw: this slot's DMA stays in flight across it
-            if (i >= 1 && i <= nk) compute(i - 1);
-            __syncthreads();                                                // vmcnt(0): the DMA issued one slot ago has landed; lgkmcnt(0): reads done
-        }
-    } else {
-        for (int i = 0; i < nk + 2; ++i) {
-            if (i >= 2) compute(i - 2);
-            __syncthreads();
-            if (i < nk) stage(i);
-            __builtin_amdgcn_s_barrier();
-        }
-    }
+    // slot pair i = slots 2 i, 2 i + 1 (written out per wave row: q = s - wr); nk + 2 pairs cover the 2 nk + 3 slots.
+    // The buffers a pair writes by DMA (dA, dB) and the ones it reads (rA, rB) are distinct, and `__restrict__` parameters on purpose: see the
+    // lock-step kernel (without the alias scopes the TN mode's transpose reads wait for the DMA issued one slot earlier before they start).
+    auto Abuf = [&](int j) { return myA + (j & 1) * AH_BYTES; };
+    auto Bbuf = [&](int j) { return smem + B_BASE + (j % 3) * B_BYTES; };
+    // Both rows run the SAME slot pair -- LOAD stage i, COMPUTE stage i - 1 -- row 1 simply starts one slot later (it idles through slot 0 and
+    // the last slot).  The DMA pending while a pair computes is always the one the pair itself issued: the alias scopes of one (not unrolled)
+    // inlined body cover it.
+    auto pair = [&](unsigned char* __restrict__ dA, unsigned char* __restrict__ dB, const unsigned char* __restrict__ rA,
+                    const unsigned char* __restrict__ rB, int i) {
+        if (i < nk) stage(i, dA, dB);
+        __builtin_amdgcn_s_barrier();                                       // raw: this slot's DMA stays in flight across it
+        if (i >= 1) compute(rA, rB);                                        // stage i - 1: (i - 1) & 1 == (i + 1) & 1, (i - 1) % 3 == (i + 2) % 3
+        __syncthreads();                                                    // vmcnt(0): the DMA issued one slot ago has landed; lgkmcnt(0): reads done
+    };
+    if (wr == 1) __syncthreads();                                           // slot 0 of row 1
+#pragma unroll 1
+    for (int i = 0; i <= nk; ++i) pair(Abuf(i), Bbuf(i), Abuf(i + 1), Bbuf(i + 2), i);
+    if (wr == 0) __syncthreads();                                           // row 0: slots 2 nk + 2, 2 nk + 3;  row 1: slot 2 nk + 3
+    __builtin_amdgcn_s_barrier();
 
     const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
