@@ -925,7 +925,10 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         __syncthreads();
     }
 
-    // reduce over the 4 heads through LDS: red[wave][d][32 keys] fp32 (8 KiB per wave and pass)
+    // reduce over the 4 heads through LDS: red[wave][d][32 keys (+1 pad)] fp32.  The pad matters: the accumulators are written key-major (lane = key)
+    // and read dim-major (lane = d, for coalesced global stores) -- with a 32-float row every lane of the read hit ONE bank (32-way conflict,
+    // SQ_LDS_BANK_CONFLICT = 54 % of this kernel's LDS cycles, ~17 us per workgroup); 33 makes both directions conflict-free.
+    constexpr int RS = 33, RW = 64 * RS;
     float* red = reinterpret_cast<float*>(smem);
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave * 2048 + (db * 32 + drow(r, lh)) * 32 + lr] = acc[db][r];
+                for (int r = 0; r < 16; ++r) red[wave * RW + (db * 32 + drow(r, lh)) * RS + lr] = acc[db][r];
         }
         __syncthreads();
         float* outp = (pass == 0 ? p.dk : p.dv) + (long long)id.hg * p.part_stride;
@@ -944,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             const int kk = e >> 6, d = e & 63;          // output element (key kk of the block, dim d): coalesced along d
             const int half = kk >> 5, kl = kk & 31;
             float sum = 0.f;
-            for (int hh = 0; hh < nh; ++hh) sum += red[(hh * 2 + half) * 2048 + d * 32 + kl];
+            for (int hh = 0; hh < nh; ++hh) sum += red[(hh * 2 + half) * RW + d * RS + kl];
             if (kblk * 64 + kk < p.N) outp[((long long)b * p.N + kblk * 64 + kk) * p.lddk + d] = sum * sc;
         }
     }
