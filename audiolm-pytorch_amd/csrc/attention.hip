@@ -181,13 +181,21 @@ __device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, int B, 
 }
 
 // DMA of one [64 rows][64 dims] tile (rows row0 .. row0 + 63 of a row-major matrix with `ld_bytes` row pitch, dims at byte
-// offset col_bytes) into a swizzled LDS image: 8 pieces of 8 rows; this wave issues pieces first, first + step, ...
-__device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsigned char* img, int first, int step, int lane, int row0, int nrows,
-                                         unsigned ld_bytes, unsigned col_bytes) {
-    for (int piece = first; piece < 8; piece += step) {
+// offset col_bytes) into a swizzled LDS image: 8 pieces of 8 rows; this wave issues the NP pieces first, first + step, ...
+// STRAIGHT-LINE on purpose (compile-time piece count, no bounds predicate): as a run-time loop with a `row < nrows ? offset : OOB` test the
+// compiler emitted an exec-masked branch per piece, and every taken branch stalls the wave on an instruction fetch -- 150 cycles per piece in
+// isolation, ~260 in the kernels (8 waves fetching), against 25-35 for the unrolled form (scripts/ubench/dma_issue.hip; the forward kernel spent
+// ~1000 of its ~3800 cycles per tile step here).  Rows >= nrows need no test: their offsets lie beyond the buffer resource's num_records
+// (callers size it to end inside row nrows - 1), so the hardware bounds check returns zeros for them.
+template <int NP>
+__device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsigned char* img, int first, int step, int lane, int row0, unsigned ld_bytes,
+                                         unsigned col_bytes) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = first + i * step;
         const int row = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ fsw(row);
-        const unsigned vo = (row0 + row < nrows) ? (unsigned)(row0 + row) * ld_bytes + col_bytes + (unsigned)c * 16u : OOB;
+        const unsigned vo = (unsigned)(row0 + row) * ld_bytes + col_bytes + (unsigned)c * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(img + piece * 1024), 16, vo, 0, 0, 0);
     }
 }
@@ -198,8 +206,27 @@ __device__ __forceinline__ void dma_tile(const __amdgpu_buffer_rsrc_t& rs, unsig
 template <bool BIAS> constexpr int FWD_LDS = 2 * 16384 + 512 + (BIAS ? 1024 + 64 : 0);
 template <bool BIAS> constexpr int DQ_LDS = 2 * 16384 + 512 + (BIAS ? 1024 + 64 + HPB * WCAP * 4 : 0);
 
-template <bool BIAS>
+// Bench-only cycle probe (scripts/attn_probe.py builds attention.hip with -DALM_ATTN_PROBE into its own library; the product build has none of this):
+// per wave, s_memtime cycles spent in each segment of the forward tile loop.
+#ifdef ALM_ATTN_PROBE
+__device__ unsigned long long g_attn_probe[4096 * 8];
+#define PROBE_DECL unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long plast = __builtin_readcyclecounter();
+#define PROBE_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long pt_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); pacc[i] += pt_ - plast; plast = pt_; } while (0)
+#define PROBE_FLUSH(slot) do { if (lane == 0 && (slot) < 4096) for (int i_ = 0; i_ < 8; ++i_) g_attn_probe[(slot) * 8 + i_] = pacc[i_]; } while (0)
+#else
+#define PROBE_DECL
+#define PROBE_T(i)
+#define PROBE_FLUSH(slot)
+#endif
+
+// QB = 32-query sub-blocks per wave.  QB == 1 (the launcher's choice): a workgroup takes query blocks idx and nqb - 1 - idx back to back, so every
+// workgroup of the launch runs the SAME number of key tiles (nqb / 2 + 1).  With one 64-query block per workgroup and heavy / light blocks paired on
+// a CU (QB == 2 + decode_block's pairing, what this kernel did before) the CU that got blocks (31, 0) ran its heavy workgroup ALONE -- one wave per
+// SIMD, nothing to overlap the softmax VALU work with the other's MFMAs -- for the whole launch and was the long pole: 74 us, 23 % MFMA-busy, while a
+// (16, 15) CU was done long before (scripts/ubench/wg_placement.hip shows the placement).
+template <bool BIAS, int QB>
 __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
+    constexpr int QR = 32 * QB;                                       // query rows per block
     // DYNAMIC LDS on purpose: for a static __shared__ array the compiler knows the object every ds_read touches and, having no alias scopes for the
     // LDS-DMA writes, waits (s_waitcnt vmcnt(0)) for ALL outstanding DMA before each batch of fragment reads -- the next tile's prefetch could never
     // overlap this tile's MFMAs.  With extern __shared__ it leaves the ordering to the barriers below (as in gemm.hip and the dK/dV kernel).
@@ -209,10 +236,9 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     int* kas = kk4s + 128;
     int* kor = kas + 128;                                           //       [2] OR of the staged tile's key attributes
 
-    const int nqb = (p.N + 63) / 64;
-    const BlockId id = decode_block(blockIdx.x, nqb, p.HG, p.B, true, true);
-    const int qblk = id.blk, b = id.b;
-    const int q0 = qblk * 64;
+    const int nqb = (p.N + QR - 1) / QR;
+    const BlockId id = decode_block(blockIdx.x, QB == 1 ? (nqb + 1) / 2 : nqb, p.HG, p.B, true, QB != 1);
+    const int b = id.b;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -227,26 +253,35 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
     const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
 
-    // The key-mask byte of a tile is fetched ONE TILE AHEAD into a register (wave 0) and
-    // written to LDS when the tile's K / V DMA is issued: vector-memory results retire in order, so a load issued after the DMA and needed
-    // before the end of the step would make wave 0 wait for the whole DMA it has just started -- every step, with the other waves waiting for
-    // wave 0 at the barrier.
-    struct KeySide { int ok; };
+    // The key-mask byte of a tile is fetched ONE TILE AHEAD into a register (wave 0) and written to LDS when the tile's K / V DMA is issued:
+    // vector-memory results retire in order, so a load issued after the DMA and needed before the end of the step would make wave 0 wait for the
+    // whole DMA it has just started.  The register holds the RAW byte: with the `!= 0` test done at load time the compiler put the test -- and an
+    // `s_waitcnt vmcnt(0)` that EVERY wave executes, exec mask or not -- right behind the load, i.e. right behind the DMA issue (seen in the ISA,
+    // ~1300 cycles per step in scripts/attn_probe.py).
+    struct KeySide { int raw; };
     auto load_side = [&](int tile) {
         KeySide ks{1};
         if (t < 64) {
             const int key = tile * 64 + t;
-            ks.ok = key < p.N;
-            if (ks.ok && mrow) ks.ok = mrow[key] != 0;
+            ks.raw = key < p.N;
+            if (ks.raw && mrow) ks.raw = mrow[key];
         }
         return ks;
     };
-    auto stage = [&](int tile, int buf, const KeySide& ks) {
-        unsigned char* img = smem + buf * 16384;
-        dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
-        dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
+    auto stage = [&](unsigned char* __restrict__ img, int tile, int buf, const KeySide& ks) {
+#ifdef ALM_PROBE_TILE0
+        const int trow = 0;
+#else
+        const int trow = tile * 64;
+#endif
+        dma_tile<2>(rsK, img, wave, 4, lane, trow, (unsigned)(p.ldk * 2), 0);
+#ifndef ALM_PROBE_NOV
+        dma_tile<2>(rsV, img + 8192, wave, 4, lane, trow, (unsigned)(p.ldv * 2), 0);
+#endif
         if (t < 64) {
-            kbias[buf * 64 + t] = ks.ok ? 0.f : -INFINITY;
+            int raw = ks.raw;
+            asm volatile("" : "+v"(raw));                              // the test stays HERE (one step after the load)
+            kbias[buf * 64 + t] = raw ? 0.f : -INFINITY;
             if (BIAS) {                                                // (the biased variants are at their register limit: these stay at stage time)
                 const int kc = min(tile * 64 + t, p.N - 1);
                 kk4s[buf * 64 + t] = p.kkey4[kc];
@@ -258,58 +293,77 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
         }
     };
 
+    PROBE_DECL
+    const int npass = (QB == 1 && nqb - 1 - id.blk != id.blk) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qblk = pass ? nqb - 1 - id.blk : id.blk;
+    const int q0 = qblk * QR;
     // Q^T fragments (B operand): lane = query column, k = head dim
-    bf16x8 qf[2][4];
+    bf16x8 qf[QB][4];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 32 + lr;
         const bf16_t* qp = p.q + ((long long)b * p.N + qi) * p.ldq + head * DH;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = gload8(qp + ks * 16 + lh * 8, active && qi < p.N);
     }
 
-    int kq4[2] = {0, 0}, aq[2] = {0, 0};
+    int kq4[QB], aq[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { kq4[qb] = 0; aq[qb] = 0; }
     __amdgpu_buffer_rsrc_t rsT = rsK;
     if (BIAS) {
         rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.tbl + (long long)(active ? head : 0) * p.LT), 0, p.LT * 4, 0x00020000);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             const int qc = min(q0 + qb * 32 + lr, p.N - 1);
             kq4[qb] = p.qkey4[qc];
             aq[qb] = p.qattr[qc];
         }
     }
-    const int aq_or = BIAS ? wave_or(aq[0] | aq[1]) : 0;
+    int aq_all = 0;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) aq_all |= aq[qb];
+    const int aq_or = BIAS ? wave_or(aq_all) : 0;
 
-    f32x16 o[2][2];                    // [db][qb]: O^T blocks (rows = head dim, cols = queries)
+    f32x16 o[2][QB];                   // [db][qb]: O^T blocks (rows = head dim, cols = queries)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < QB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][j][r] = 0.f;
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m[qb] = -INFINITY; l[qb] = 0.f; }
 
     const int frow = fsw(lr);
     const TrOff troff = make_troff(lane);
-    const int ntiles = qblk + 1;
+    const int ntiles = (min(q0 + QR, p.N) - 1) / 64 + 1;
 
     KeySide side = load_side(0);
-    stage(0, 0, side);
+    stage(smem, 0, 0, side);
     side = load_side(1);
     __syncthreads();
 
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // One tile step.  The DMA destination (next tile's image) and the image being read are distinct __restrict__ parameters of ONE inlined body:
+    // that gives the compiler the alias scopes it needs to let the ds_read_b64_tr_b16 V^T reads go ahead of the in-flight DMA -- without them it
+    // put `s_waitcnt vmcnt(0)` in front of the first transposed read of every step (the builtin carries no alias information of its own).
+    auto step = [&](unsigned char* __restrict__ nimg, const unsigned char* __restrict__ Kt, int tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1, side);
+#if !defined(ALM_PROBE_NOSTAGE) && !defined(ALM_PROBE_LATE)
+        if (tile + 1 < ntiles) stage(nimg, tile + 1, buf ^ 1, side);
+#endif
+#ifndef ALM_PROBE_NOSIDE
         side = load_side(tile + 2);                                   // lands during this step; first needed by the next step's stage()
+#endif
+        PROBE_T(0);
         if (active) {
-            const unsigned char* Kt = smem + buf * 16384;
             const unsigned char* Vt = Kt + 8192;
             const float* kbs = kbias + buf * 64;
 
             // S^T = K Q^T (+ key bias): [kb][qb] 32x32 blocks
-            f32x16 st[2][2];
+            f32x16 st[2][QB];
             auto init_scores = [&](auto spc) {
                 constexpr bool SP = decltype(spc)::value;
 #pragma unroll
@@ -324,12 +378,12 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                             if (SP) ka = lds_ld_i4(kas + buf * 64 + kb * 32 + 8 * g + 4 * lh);
                             const int kkv[4] = {kk.x, kk.y, kk.z, kk.w}, kav[4] = {ka.x, ka.y, ka.z, ka.w};
 #pragma unroll
-                            for (int qb = 0; qb < 2; ++qb)
+                            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c] + bias_at<SP>(rsT, kq4[qb], kkv[c], aq[qb], kav[c]);
                         } else {
 #pragma unroll
-                            for (int qb = 0; qb < 2; ++qb)
+                            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) st[kb][qb][4 * g + c] = bvv[c];
                         }
@@ -343,21 +397,27 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                 for (int kb = 0; kb < 2; ++kb) {
                     const bf16x8 kf = nat_frag(Kt, kb * 32 + lr, frow, ks, lh);
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
+                    for (int qb = 0; qb < QB; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
                 }
-            if (tile == qblk) {                                    // diagonal tile: causal mask (key index > query index)
+            PROBE_T(1);
+#ifdef ALM_PROBE_LATE
+            if (tile + 1 < ntiles) stage(nimg, tile + 1, buf ^ 1, side);
+            PROBE_T(6);
+#endif
+            if (tile == ntiles - 1) {                              // diagonal tile: causal mask (key index > query index)
+                const int doff = tile * 64 - q0;                   // 0, or -32 for an odd 32-query block
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb)
+                    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            if (kb * 32 + drow(r, lh) > qb * 32 + lr) st[kb][qb][r] = -INFINITY;
+                            if (doff + kb * 32 + drow(r, lh) > qb * 32 + lr) st[kb][qb][r] = -INFINITY;
             }
             // online softmax, one lane = one query (its partner lane ^ 32 owns the other half of the keys)
-            float tm[2];
+            float tm[QB];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 float a = -INFINITY;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -366,10 +426,12 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                 a = fmaxf(a, __shfl_xor(a, 32, 64));
                 tm[qb] = a * c2;
             }
-            const bool need = (tm[0] > m[0] + RESCALE_THR) || (tm[1] > m[1] + RESCALE_THR);
+            bool need = false;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) need = need || (tm[qb] > m[qb] + RESCALE_THR);
             if (__any(need)) {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                for (int qb = 0; qb < QB; ++qb) {
                     const float mn = fmaxf(m[qb], tm[qb]);
                     const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qb] - mn);
                     m[qb] = mn;
@@ -380,8 +442,9 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                         for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
                 }
             }
+            PROBE_T(2);
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 const float ms = (m[qb] == -INFINITY) ? 0.f : m[qb];
                 float ps = 0.f;
 #pragma unroll
@@ -394,28 +457,35 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                     }
                 l[qb] += ps;
             }
+            PROBE_T(3);
             // O^T += V^T P^T
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    bf16x8 pf[2];
+                    bf16x8 pf[QB];
 #pragma unroll
-                    for (int qb = 0; qb < 2; ++qb) pf[qb] = pack8(st[kb][qb], s);
+                    for (int qb = 0; qb < QB; ++qb) pf[qb] = pack8(st[kb][qb], s);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const bf16x8 vf = tr_frag(Vt, kb * 32 + s * 16, troff, db);
 #pragma unroll
-                        for (int qb = 0; qb < 2; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
+                        for (int qb = 0; qb < QB; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
                     }
                 }
+            PROBE_T(4);
         }
+    };
+#pragma unroll 1
+    for (int tile = 0; tile < ntiles; ++tile) {
+        step(smem + ((tile & 1) ^ 1) * 16384, smem + (tile & 1) * 16384, tile);
         __syncthreads();
+        PROBE_T(5);
     }
 
-    if (!active) return;
+    if (active)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 32 + lr;
         const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
@@ -432,6 +502,9 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
             if (lh == 0) p.lse[((long long)b * p.H + head) * p.N + qi] = (lt > 0.f) ? (m[qb] / LOG2E + logf(lt)) : -INFINITY;
         }
     }
+    PROBE_T(6);
+    }
+    PROBE_FLUSH(blockIdx.x * 4 + wave);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -495,22 +568,23 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (int)(((long long)(p.N - 1) * p.ldv + DH) * 2), 0x00020000);
     const uint8_t* mrow = p.mask ? p.mask + (long long)b * p.N : nullptr;
 
-    struct KeySide { int ok; };                                      // fetched one tile ahead: see mqa_fwd_kernel
+    struct KeySide { int raw; };                                     // the RAW mask byte, fetched one tile ahead and tested one step later: see mqa_fwd_kernel
     auto load_side = [&](int tile) {
         KeySide ks{1};
         if (t < 64) {
             const int key = tile * 64 + t;
-            ks.ok = key < p.N;
-            if (ks.ok && mrow) ks.ok = mrow[key] != 0;
+            ks.raw = key < p.N;
+            if (ks.raw && mrow) ks.raw = mrow[key];
         }
         return ks;
     };
-    auto stage = [&](int tile, int buf, const KeySide& ks) {
-        unsigned char* img = smem + buf * 16384;
-        dma_tile(rsK, img, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldk * 2), 0);
-        dma_tile(rsV, img + 8192, wave, 4, lane, tile * 64, p.N, (unsigned)(p.ldv * 2), 0);
+    auto stage = [&](unsigned char* __restrict__ img, int tile, int buf, const KeySide& ks) {
+        dma_tile<2>(rsK, img, wave, 4, lane, tile * 64, (unsigned)(p.ldk * 2), 0);
+        dma_tile<2>(rsV, img + 8192, wave, 4, lane, tile * 64, (unsigned)(p.ldv * 2), 0);
         if (t < 64) {
-            kbias[buf * 64 + t] = ks.ok ? 0.f : -INFINITY;
+            int raw = ks.raw;
+            asm volatile("" : "+v"(raw));
+            kbias[buf * 64 + t] = raw ? 0.f : -INFINITY;
             if (BIAS) {                                                // (the biased variants are at their register limit: these stay at stage time)
                 const int kc = min(tile * 64 + t, p.N - 1);
                 const int kv = p.kkey4[kc];
@@ -584,16 +658,17 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     const int ntiles = qblk + 1;
 
     KeySide side = load_side(0);
-    stage(0, 0, side);
+    stage(smem, 0, 0, side);
     side = load_side(1);
     __syncthreads();
 
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // one tile step; DMA destination and the image being read are distinct __restrict__ parameters of one inlined body, so that the transposed
+    // K^T reads do not wait for the in-flight DMA (see mqa_fwd_kernel)
+    auto step = [&](unsigned char* __restrict__ nimg, const unsigned char* __restrict__ Kt, int tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1, side);
+        if (tile + 1 < ntiles) stage(nimg, tile + 1, buf ^ 1, side);
         side = load_side(tile + 2);
         if (active) {
-            const unsigned char* Kt = smem + buf * 16384;
             const unsigned char* Vt = Kt + 8192;
             const float* kbs = kbias + buf * 64;
 #pragma unroll
@@ -732,6 +807,10 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                     }
             }
         }
+    };
+#pragma unroll 1
+    for (int tile = 0; tile < ntiles; ++tile) {
+        step(smem + ((tile & 1) ^ 1) * 16384, smem + (tile & 1) * 16384, tile);
         __syncthreads();
     }
 
@@ -802,15 +881,15 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     constexpr int ROWT = 2 * 65536;                                            // row terms [2 buffers][4 heads][-lse/scale | -delta][64 queries] fp32
-    auto stage = [&](int qt, int buf) {
+    auto stage = [&](unsigned char* __restrict__ tiles, int qt, int buf) {                      // tiles = smem + buf * 65536
         // wave (hl, kh) fetches head hl's Q tile (kh == 0) or dO tile (kh == 1): 8 pieces each -- and, through the SAME DMA queue, the tile's 64
         // row terms (-lse / scale for kh == 0, -delta for kh == 1: the accumulators' initial values).  They used to be 16 register loads per
         // wave at the top of every step, issued right after the next tile's DMA: vector-memory results retire in order, so waiting for them
         // meant waiting for that whole DMA -- the prefetch never overlapped the MFMAs.
         if (!active) return;
-        unsigned char* img = smem + buf * 65536 + hl * 16384 + kh * 8192;
-        if (kh == 0) dma_tile(rsQ, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.ldq * 2), (unsigned)(head * DH * 2));
-        else dma_tile(rsD, img, 0, 1, lane, qt * 64, p.N, (unsigned)(p.lddo * 2), (unsigned)(head * DH * 2));
+        unsigned char* img = tiles + hl * 16384 + kh * 8192;
+        if (kh == 0) dma_tile<8>(rsQ, img, 0, 1, lane, qt * 64, (unsigned)(p.ldq * 2), (unsigned)(head * DH * 2));
+        else dma_tile<8>(rsD, img, 0, 1, lane, qt * 64, (unsigned)(p.lddo * 2), (unsigned)(head * DH * 2));
         const int qi = qt * 64 + lane;
         const unsigned vo = qi < p.N ? (unsigned)qi * 4u : OOB;               // rows >= N read 0 (harmless: their Q / dO rows are zero)
         unsigned char* rt = smem + ROWT + buf * 2048 + hl * 512 + kh * 256;
@@ -842,14 +921,16 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     }
     const int kal_or = BIAS ? wave_or(kal) : 0;
 
-    stage(kblk, 0);
+    stage(smem, kblk, 0);
     __syncthreads();
 
-    for (int qt = kblk; qt < nqt; ++qt) {
+    // one query-tile step; DMA destination and the images being read are distinct __restrict__ parameters of one inlined body, so that the transposed
+    // Q^T / dO^T reads do not wait for the in-flight DMA (see mqa_fwd_kernel)
+    auto step = [&](unsigned char* __restrict__ ntiles_img, const unsigned char* __restrict__ ctiles, int qt) {
         const int buf = (qt - kblk) & 1;
-        if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);
+        if (qt + 1 < nqt) stage(ntiles_img, qt + 1, buf ^ 1);
         if (active) {
-            const unsigned char* Qt = smem + buf * 65536 + hl * 16384;
+            const unsigned char* Qt = ctiles + hl * 16384;
             const unsigned char* Dt = Qt + 8192;
             const int q0 = qt * 64;
             // S' = Q K^T - lse / scale, dP' = dO V^T - delta : [qb] (32 queries x 32 keys) blocks; lane = key column, registers = query
@@ -922,6 +1003,11 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     }
                 }
         }
+    };
+#pragma unroll 1
+    for (int qt = kblk; qt < nqt; ++qt) {
+        const int buf = (qt - kblk) & 1;
+        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, qt);
         __syncthreads();
     }
 
@@ -1006,9 +1092,16 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     rc = check_bias(ba, false);
     if (rc) return rc;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
-    const int nqb = (N + 63) / 64;
-    if (p.tbl) hipLaunchKernelGGL(mqa_fwd_kernel<true>, dim3(nqb * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(mqa_fwd_kernel<false>, dim3(nqb * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
+    static const int qb_env = getenv("ALM_ATTN_QB") ? atoi(getenv("ALM_ATTN_QB")) : 1;
+    if (qb_env == 2) {
+        const int nqb = (N + 63) / 64;
+        if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 2>), dim3(nqb * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mqa_fwd_kernel<false, 2>), dim3(nqb * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
+    } else {
+        const int npair = ((N + 31) / 32 + 1) / 2;                       // 32-query blocks, taken two (idx, last - idx) per workgroup
+        if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
+    }
     ALM_LAUNCH_CHECK();
     return 0;
 }
@@ -1100,3 +1193,9 @@ extern "C" int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, in
     ALM_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef ALM_ATTN_PROBE
+extern "C" int alm_attn_probe_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_probe), sizeof(unsigned long long) * n);
+}
+#endif
