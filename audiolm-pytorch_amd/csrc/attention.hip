@@ -269,15 +269,8 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
         return ks;
     };
     auto stage = [&](unsigned char* __restrict__ img, int tile, int buf, const KeySide& ks) {
-#ifdef ALM_PROBE_TILE0
-        const int trow = 0;
-#else
-        const int trow = tile * 64;
-#endif
-        dma_tile<2>(rsK, img, wave, 4, lane, trow, (unsigned)(p.ldk * 2), 0);
-#ifndef ALM_PROBE_NOV
-        dma_tile<2>(rsV, img + 8192, wave, 4, lane, trow, (unsigned)(p.ldv * 2), 0);
-#endif
+        dma_tile<2>(rsK, img, wave, 4, lane, tile * 64, (unsigned)(p.ldk * 2), 0);
+        dma_tile<2>(rsV, img + 8192, wave, 4, lane, tile * 64, (unsigned)(p.ldv * 2), 0);
         if (t < 64) {
             int raw = ks.raw;
             asm volatile("" : "+v"(raw));                              // the test stays HERE (one step after the load)
@@ -351,12 +344,10 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     // put `s_waitcnt vmcnt(0)` in front of the first transposed read of every step (the builtin carries no alias information of its own).
     auto step = [&](unsigned char* __restrict__ nimg, const unsigned char* __restrict__ Kt, int tile) {
         const int buf = tile & 1;
-#if !defined(ALM_PROBE_NOSTAGE) && !defined(ALM_PROBE_LATE)
+#ifndef ALM_PROBE_NOSTAGE                                             // (probe builds can leave the DMA out: timing only, wrong results)
         if (tile + 1 < ntiles) stage(nimg, tile + 1, buf ^ 1, side);
 #endif
-#ifndef ALM_PROBE_NOSIDE
         side = load_side(tile + 2);                                   // lands during this step; first needed by the next step's stage()
-#endif
         PROBE_T(0);
         if (active) {
             const unsigned char* Vt = Kt + 8192;
@@ -400,10 +391,6 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
                     for (int qb = 0; qb < QB; ++qb) st[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], st[kb][qb], 0, 0, 0);
                 }
             PROBE_T(1);
-#ifdef ALM_PROBE_LATE
-            if (tile + 1 < ntiles) stage(nimg, tile + 1, buf ^ 1, side);
-            PROBE_T(6);
-#endif
             if (tile == ntiles - 1) {                              // diagonal tile: causal mask (key index > query index)
                 const int doff = tile * 64 - q0;                   // 0, or -32 for an odd 32-query block
 #pragma unroll
@@ -1092,16 +1079,9 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     rc = check_bias(ba, false);
     if (rc) return rc;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
-    static const int qb_env = getenv("ALM_ATTN_QB") ? atoi(getenv("ALM_ATTN_QB")) : 1;
-    if (qb_env == 2) {
-        const int nqb = (N + 63) / 64;
-        if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 2>), dim3(nqb * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((mqa_fwd_kernel<false, 2>), dim3(nqb * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
-    } else {
-        const int npair = ((N + 31) / 32 + 1) / 2;                       // 32-query blocks, taken two (idx, last - idx) per workgroup
-        if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
-    }
+    const int npair = ((N + 31) / 32 + 1) / 2;                           // 32-query blocks, taken two (idx, last - idx) per workgroup
+    if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -12,7 +12,6 @@ namespace {
 
 constexpr int MAX_TABLES = 8;
 struct Tables { const float* p[MAX_TABLES]; int rows[MAX_TABLES]; int n; };
-struct GradTables { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int n; };
 
 // source code: (table_id << 24) | row ; -1 = none (zero vector: padded position, get_embeds :176-181).  A code naming a table or a row that
 // does not exist (nn.Embedding would raise IndexError) is never dereferenced: it reads as zero / is skipped and raises the error flag.
@@ -45,16 +44,59 @@ __global__ __launch_bounds__(256) void embed_assemble_kernel(Tables tabs, const 
     }
 }
 
-__global__ __launch_bounds__(256) void embed_scatter_kernel(GradTables tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
+// Scatter-add backward of the assembly.  Workgroup = 128 token rows x 256 columns; thread = one column.
+//   * rows of LARGE tables (codebooks: thousands of destinations, a handful of tokens each): one L2 atomic per (token, element), as before;
+//   * rows of SMALL tables (<= SMALL_ROWS destinations in total: quantizer-position / start-token embeddings, 3-5 rows that EVERY token of the
+//     batch adds to): summed per workgroup in LDS first (a column belongs to one thread: plain read-modify-write), then one atomic per
+//     (workgroup, destination, element).  With one atomic per token the ~16k updates of each of those few floats were serialised in the L2
+//     (all of them on ~100 cache lines): 158 us for 67 MB of input; this form is bound by reading dout.
+constexpr int SMALL_ROWS = 32;          // LDS: 32 x 256 floats
+struct ScatterTabs { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int small_base[MAX_TABLES]; int n; int nsmall; };
+
+__global__ __launch_bounds__(256) void embed_scatter_kernel(ScatterTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
                                                             const float* __restrict__ dout, float alpha, long long rows, int D) {
-    const long long total = rows * D;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / D;
-        const int e = (int)(i % D);
-        const float g = dout[i] * alpha;
-        const int a = src_a[r], b = src_b[r];
-        if (a >= 0 && code_ok(tabs, a)) atomicAdd(tabs.p[a >> 24] + (long long)(a & 0xffffff) * D + e, g);
-        if (b >= 0 && code_ok(tabs, b)) atomicAdd(tabs.p[b >> 24] + (long long)(b & 0xffffff) * D + e, g);
+    __shared__ float acc[SMALL_ROWS][256];
+    __shared__ int used[SMALL_ROWS];
+    const int t = threadIdx.x;
+    const int c = blockIdx.y * 256 + t;
+    const long long r0 = (long long)blockIdx.x * 128;
+    const int nr = (int)min(128LL, rows - r0);
+    for (int g = 0; g < tabs.nsmall; ++g) acc[g][t] = 0.f;
+    if (t < SMALL_ROWS) used[t] = 0;
+    __syncthreads();
+    const bool cok = c < D;
+    for (int i0 = 0; i0 < nr; i0 += 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gv[u] = (cok && i0 + u < nr) ? dout[(r0 + i0 + u) * D + c] * alpha : 0.f;      // 8 loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= nr) break;
+            const long long r = r0 + i0 + u;
+            const float g = gv[u];
+            const int codes[2] = {src_a[r], src_b[r]};                   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int code = codes[k];
+                if (code < 0 || !code_ok(tabs, code)) continue;
+                const int tb = code >> 24, row = code & 0xffffff;
+                const int sb = tabs.small_base[tb];
+                if (sb >= 0) {
+                    acc[sb + row][t] += g;
+                    if (t == 0) used[sb + row] = 1;
+                } else if (cok) {
+                    atomicAdd(tabs.p[tb] + (long long)row * D + c, g);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!cok) return;
+    for (int tb = 0; tb < tabs.n; ++tb) {
+        const int sb = tabs.small_base[tb];
+        if (sb < 0) continue;
+        for (int row = 0; row < tabs.rows[tb]; ++row)
+            if (used[sb + row]) atomicAdd(tabs.p[tb] + (long long)row * D + c, acc[sb + row][t]);
     }
 }
 
@@ -224,10 +266,17 @@ extern "C" int alm_embed_assemble(const float* const* tables, const int* table_r
 extern "C" int alm_embed_scatter_add(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b,
                                      const float* dout, float alpha, long long rows, int D, void* stream) {
     if (ntables > MAX_TABLES || !table_rows) return ALM_ERR_BAD_ARG;
-    GradTables t{};
+    ScatterTabs t{};
     t.n = ntables;
-    for (int i = 0; i < ntables; ++i) { t.p[i] = grad_tables[i]; t.rows[i] = table_rows[i]; }
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, dout, alpha, rows, D);
+    for (int i = 0; i < ntables; ++i) {
+        t.p[i] = grad_tables[i];
+        t.rows[i] = table_rows[i];
+        t.small_base[i] = -1;
+        if (table_rows[i] > 0 && t.nsmall + table_rows[i] <= SMALL_ROWS) { t.small_base[i] = t.nsmall; t.nsmall += table_rows[i]; }
+    }
+    if (rows <= 0 || D <= 0) return 0;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)((rows + 127) / 128), (unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, dout,
+                       alpha, rows, D);
     ALM_LAUNCH_CHECK();
     return 0;
 }

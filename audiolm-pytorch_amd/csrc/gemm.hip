@@ -379,6 +379,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
 }
 
+// Bench-only cycle probe of the staggered kernel (scripts/gemm_probe.py builds gemm.hip with -DALM_GEMM_PROBE into its own library; the product build
+// has none of this): per wave, s_memtime cycles in the four parts of a slot pair + prologue / epilogue.
+#ifdef ALM_GEMM_PROBE
+__device__ unsigned long long g_gemm_probe[16384 * 8];
+#define GPROBE_DECL unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long plast = __builtin_readcyclecounter();
+#define GPROBE_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long pt_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); pacc[i] += pt_ - plast; plast = pt_; } while (0)
+#define GPROBE_FLUSH(slot) do { if (lane == 0 && (slot) < 16384) for (int i_ = 0; i_ < 8; ++i_) g_gemm_probe[(slot) * 8 + i_] = pacc[i_]; } while (0)
+#else
+#define GPROBE_DECL
+#define GPROBE_T(i)
+#define GPROBE_FLUSH(slot)
+#endif
+
 // ---- staggered 256 x 256 x 64 kernel (8 waves, NT and TN): the two wave rows (wr = 0 / 1: the two waves co-resident on each SIMD) run
 // HALF A K-STEP APART.  Why: in the lock-step kernel above every wave issues its 8 LDS-DMA instructions at the top of a K-step -- at
 // 60-185 issue cycles each (MI355X_MICROARCH: "LDS-DMA piece issue cost") that is ~1000 cycles during which neither wave of the SIMD feeds
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 template <bool TNMODE, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    GPROBE_DECL
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TNB = 2;
     constexpr int AH_BYTES = 128 * BK * 2, B_BYTES = BN * BK * 2;           // 16 KB, 32 KB
     constexpr int B_BASE = 4 * AH_BYTES;                                    // [A row 0: buf 0, 1][A row 1: buf 0, 1][B: buf 0, 1, 2]
@@ -530,33 +544,58 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](const unsigned char* sa, const unsigned char* sb) {
+    // The fragments of K sub-step ks + 1 are read while the 8 MFMAs of sub-step ks run (two register sets, explicit schedule groups): left to itself
+    // the compiler keeps ONE 16-register fragment set and issues each read right in front of the MFMA that needs it -- ~100 cycles of LDS latency
+    // exposed a dozen times per slot (probe: 1450 cycles per COMPUTE slot for 1024 cycles of MFMA; the other wave of the SIMD is in its LOAD slot
+    // and cannot fill the gaps).
+    auto load_frags = [&](const unsigned char* sa, const unsigned char* sb, int ks, bf16x8 (&a)[TM], bf16x8 (&b)[TNB]) {
+        if (!TNMODE) {
+            const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[TM], b[TNB];
-            if (!TNMODE) {
-                const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + fragA[i] + co);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sa + fragA[i] + co);
+            for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
+        } else {
 #pragma unroll
-                for (int j = 0; j < TNB; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned char* ad = sa + fragA[i] + ks * 4 * 8 * 128;
-                    a[i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + 8 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-                for (int j = 0; j < TNB; ++j) {
-                    const unsigned char* bd = sb + fragB[j] + ks * 4 * 16 * 128;
-                    b[j] = __builtin_shufflevector(lds_tr16(bd), lds_tr16(bd + 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
-                }
+            for (int i = 0; i < TM; ++i) {
+                const unsigned char* ad = sa + fragA[i] + ks * 4 * 8 * 128;
+                a[i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + 8 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TNB; ++j) {
+                const unsigned char* bd = sb + fragB[j] + ks * 4 * 16 * 128;
+                b[j] = __builtin_shufflevector(lds_tr16(bd), lds_tr16(bd + 16 * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         }
+    };
+    auto mfma_all = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TNB]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NRD = (TNMODE ? 2 : 1) * (TM + TNB);                     // LDS read instructions per sub-step
+    auto compute = [&](const unsigned char* sa, const unsigned char* sb) {
+        bf16x8 a0[TM], b0[TNB], a1[TM], b1[TNB];
+        load_frags(sa, sb, 0, a0, b0);
+        load_frags(sa, sb, 1, a1, b1);
+        mfma_all(a0, b0);
+        load_frags(sa, sb, 2, a0, b0);
+        mfma_all(a1, b1);
+        load_frags(sa, sb, 3, a1, b1);
+        mfma_all(a0, b0);
+        mfma_all(a1, b1);
+        // schedule: [reads 0][reads 1] | 8 MFMA (0) interleaved with reads 2 | 8 MFMA (1) interleaved with reads 3 | 8 MFMA | 8 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int q = 0; q < TM * TNB; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (NRD > TM * TNB) __builtin_amdgcn_sched_group_barrier(0x100, NRD - TM * TNB, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TNB, 0);
     };
 
     const int nk = (Krem + BK - 1) / BK;
@@ -571,10 +610,15 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     auto pair = [&](unsigned char* __restrict__ dA, unsigned char* __restrict__ dB, const unsigned char* __restrict__ rA,
                     const unsigned char* __restrict__ rB, int i) {
         if (i < nk) stage(i, dA, dB);
+        GPROBE_T(1);
         __builtin_amdgcn_s_barrier();                                       // raw: this slot's DMA stays in flight across it
+        GPROBE_T(2);
         if (i >= 1) compute(rA, rB);                                        // stage i - 1: (i - 1) & 1 == (i + 1) & 1, (i - 1) % 3 == (i + 2) % 3
+        GPROBE_T(3);
         __syncthreads();                                                    // vmcnt(0): the DMA issued one slot ago has landed; lgkmcnt(0): reads done
+        GPROBE_T(4);
     };
+    GPROBE_T(0);
     if (wr == 1) __syncthreads();                                           // slot 0 of row 1
 #pragma unroll 1
     for (int i = 0; i <= nk; ++i) pair(Abuf(i), Bbuf(i), Abuf(i + 1), Bbuf(i + 2), i);
@@ -582,7 +626,10 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
 
     const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
+    GPROBE_T(5);
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+    GPROBE_T(6);
+    GPROBE_FLUSH((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave);
 }
 
 // ---- split-K second stage: C[b][m][n] (+)= sum_z ws[z][b][m][n]   (blockIdx.y = b)
@@ -992,3 +1039,9 @@ extern "C" int alm_pack_weight(const float* src, int rows, int cols, long long l
     ALM_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef ALM_GEMM_PROBE
+extern "C" int alm_gemm_probe_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_probe), sizeof(unsigned long long) * n);
+}
+#endif

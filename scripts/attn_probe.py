@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'audiolm-pytorch_amd')
-VARIANT = os.environ.get('ALM_PROBE_VARIANT', '')                  # '', 'NOSTAGE', 'NOSIDE': leave a piece of the step out (wrong results, timing only)
+VARIANT = os.environ.get('ALM_PROBE_VARIANT', '')                  # '' or 'NOSTAGE' (leave the tile DMA out: wrong results, timing only)
 LIB = os.path.join(ROOT, 'scripts', 'ubench', 'bin', f'libalm_probe{VARIANT}.so')
 SEG = ['stage (DMA issue, key side)', 'score init + K reads + S MFMA issue', 'causal mask + row max (+ rescale)', 'exp2 + row sums', 'pack + V^T reads + PV MFMA issue',
        'barrier (vmcnt 0)', 'epilogue']
@@ -44,23 +44,14 @@ def run():
     buf = (ctypes.c_ulonglong * n)()
     rc = lib.alm_attn_probe_read(buf, n)
     assert rc == 0, rc
-    qb = int(os.environ.get('ALM_ATTN_QB', '1'))
-    nwg = (32 if qb == 1 else 32) * 2 * B
-    steps = 33 if qb == 1 else None
+    qb, nwg, steps = 1, 32 * 2 * B, 33
     import numpy as np
     a = np.array(buf, dtype=np.float64).reshape(4096, 8)[:nwg * 4]
     tot = a[:, :7].sum(1)
     print(f'QB={qb}: {nwg} workgroups; per-wave total cycles: min {tot.min():.0f}  mean {tot.mean():.0f}  max {tot.max():.0f}')
-    if steps:
-        print(f'  every workgroup runs {steps} tile steps; mean cycles per step and segment (all waves):')
-        for i, name in enumerate(SEG):
-            print(f'    {name:42s} {a[:, i].mean() / (steps if i < 6 else 1):9.0f}' + ('  (per pass pair)' if i == 6 else ''))
-    else:
-        heavy = a[:4]
-        print('  heaviest workgroup (32 steps), wave 0..3, cycles per step and segment:')
-        for i, name in enumerate(SEG):
-            print(f'    {name:42s} ' + ' '.join(f'{heavy[w, i] / (32 if i < 6 else 1):9.0f}' for w in range(4)))
-        print('  slowest wave:', int(tot.argmax()), 'of workgroup', int(tot.argmax()) // 4, [f'{x:.0f}' for x in a[tot.argmax()]])
+    print(f'  every workgroup runs {steps} tile steps; mean cycles per step and segment (all waves):')
+    for i, name in enumerate(SEG):
+        print(f'    {name:42s} {a[:, i].mean() / (steps if i < 6 else 1):9.0f}' + ('  (per pass pair)' if i == 6 else ''))
 
 
 if __name__ == '__main__':

@@ -609,6 +609,32 @@ def test_embed_assemble_and_scatter(ops):
         assert torch.allclose(a, b, atol=1e-5)
 
 
+def test_embed_scatter_large_and_small_tables(ops):
+    """codebook-sized tables take one atomic per (token, element); the few-row tables every token adds to are pre-summed per workgroup in LDS.
+    300 rows x 320 columns: more than one 128-row chunk, a ragged last chunk and a ragged 256-column block; includes out-of-range codes."""
+    D, rows = 320, 300
+    big, small, one = rnd(100, D, seed=60), rnd(3, D, seed=61), rnd(1, D, seed=62)
+    g = torch.Generator().manual_seed(63)
+    ia = torch.randint(-1, 100, (rows,), generator=g)
+    ib = torch.randint(-1, 3, (rows,), generator=g)
+    src_a = torch.where(ia >= 0, ia, torch.full_like(ia, -1)).to(torch.int32)
+    src_b = torch.where(ib >= 0, ib + (1 << 24), torch.full_like(ib, -1)).to(torch.int32)
+    src_a[5] = 2 << 24                       # the one-row table
+    src_a[6] = 100                           # out of range in the big table: skipped
+    src_b[7] = (1 << 24) | 3                 # out of range in the small table: skipped
+    src_a, src_b = src_a.to(dev()), src_b.to(dev())
+    dout = rnd(rows, D, seed=64)
+    grads = [torch.zeros_like(t) for t in (big, small, one)]
+    ops.embed_scatter_add(grads, src_a, src_b, dout, 0.5, rows, D)
+    refg = [torch.zeros_like(t, dtype=torch.float64) for t in (big, small, one)]
+    for r in range(rows):
+        for c in (int(src_a[r]), int(src_b[r])):
+            if c >= 0 and (c & 0xffffff) < refg[c >> 24].shape[0]:
+                refg[c >> 24][c & 0xffffff] += 0.5 * dout[r].double()
+    for a, b in zip(grads, refg):
+        assert torch.allclose(a.double(), b, atol=1e-4)
+
+
 def test_gather_scatter_rows(ops):
     x = rnd(50, 64, seed=55, dtype=BF16)
     idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32, device=dev())
