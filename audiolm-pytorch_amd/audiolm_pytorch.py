@@ -569,21 +569,54 @@ def _code(table_id, rows):
     return (rows.to(torch.int32) + (table_id << 24)).to(torch.int32)
 
 
+# Index tensors that depend only on shapes (never on token values) are built once per (shape, device) and re-used: every training step used to
+# launch ~30 aranges / fills / compares / wheres for them.  Callers treat them as read-only.  While a stream is being captured into a hipGraph
+# nothing is cached (a tensor born inside a capture has no contents until the graph is replayed) and nothing cached is created.
+def _shape_cached(fn):
+    cached = functools.lru_cache(maxsize=256)(fn)
+
+    @functools.wraps(fn)
+    def wrapper(*args):
+        device = args[-1]
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return fn(*args)
+        with torch.inference_mode(False), torch.no_grad():
+            return cached(*args)
+    wrapper.cache_clear = cached.cache_clear
+    return wrapper
+
+
+@_shape_cached
 def _const_code(table_id, b, device):
     return torch.full((b, 1), table_id << 24, dtype=torch.int32, device=device)
 
 
+@_shape_cached
 def _neg(b, n, device):
     return torch.full((b, n), -1, dtype=torch.int32, device=device)
 
 
+@_shape_cached
 def _quantizer_rows(n, Q, device):
     return (torch.arange(n, device=device) % Q).to(torch.int32)
 
 
+@_shape_cached
+def _quantizer_row_offsets(n, Q, stride, device):
+    """[1, n] int32: stride * (i mod Q) -- the per-quantizer offset of position i into a stacked codebook table"""
+    return (stride * _quantizer_rows(n, Q, device))[None].contiguous()
+
+
+@_shape_cached
+def _quantizer_codes(table_id, b, lead, n, Q, device):
+    """src_b of the assembly, [b, lead + n] int32: -1 for the `lead` leading positions, then the code of row (i mod Q) of table `table_id`"""
+    return torch.cat((_neg(b, lead, device), _code(table_id, _quantizer_rows(n, Q, device))[None].expand(b, -1)), dim=1).contiguous()
+
+
+@_shape_cached
 def _group_index(B, N, start, n, Q, device):
     """Rows of the flat hidden states [B*N, D] regrouped per quantizer: position i of the range uses head i mod Q
-    -> (idx int32 [Q, B*J] (-1 = pad), i_grid [Q, J], valid [Q, J])."""
+    -> (idx int32 [Q, B*J] (-1 = pad), i_grid [Q, J], valid [Q, J], i_clamped [Q*J])."""
     J = ceil_div(n, Q)
     i_grid = torch.arange(J, device=device)[None, :] * Q + torch.arange(Q, device=device)[:, None]     # [Q, J]
     valid = i_grid < n
@@ -592,12 +625,21 @@ def _group_index(B, N, start, n, Q, device):
     return idx.contiguous(), i_grid, valid
 
 
+@_shape_cached
+def _group_cols(n, Q, device):
+    """[Q * J] int64: label column read by slot (q, j) = min(j * Q + q, n - 1) (the clamp only touches slots that do not exist)"""
+    J = ceil_div(n, Q)
+    i_grid = torch.arange(J, device=device)[None, :] * Q + torch.arange(Q, device=device)[:, None]
+    return i_grid.clamp(max=n - 1).reshape(-1).contiguous()
+
+
 def _group_labels(labels, i_grid, valid, n):
     """labels [B, n] int64 -> [Q, B*J] (-1 where the slot does not exist)."""
     B = labels.shape[0]
     Q, J = i_grid.shape
-    g = labels[:, i_grid.clamp(max=n - 1).reshape(-1)].reshape(B, Q, J).permute(1, 0, 2)              # [Q, B, J]
-    g = torch.where(valid[:, None, :], g, torch.full_like(g, -1))
+    g = labels[:, _group_cols(n, Q, labels.device)].reshape(B, Q, J).permute(1, 0, 2)                 # [Q, B, J]
+    if J * Q != n:                                                                                    # ragged tail: mark the missing slots
+        g = g.masked_fill(~valid[:, None, :], -1)
     return g.reshape(Q, B * J).contiguous()
 
 
@@ -882,12 +924,10 @@ class CoarseTransformer(_TransformerBase):
         Q, C = self.num_coarse_quantizers, self.codebook_size
         coarse, sem = _flatten_ids(coarse_token_ids), _flatten_ids(semantic_token_ids)           # :894
         ns, nc = sem.shape[1], coarse.shape[1]
-        qrow = _quantizer_rows(nc, Q, dev)                                                       # i mod Q
-        coarse_rows = coarse.to(torch.int32) + C * qrow[None]                                    # :896-899 (stride C: eos aliasing kept)
-        sem32 = sem.to(torch.int32)
-        sem_code = torch.where(sem32 >= 0, sem32, torch.full_like(sem32, -1))                    # table 0; pad -> zero (:901)
+        coarse_rows = coarse.to(torch.int32) + _quantizer_row_offsets(nc, Q, C, dev)             # :896-899 (stride C: eos aliasing kept)
+        sem_code = sem.to(torch.int32).clamp(min=-1)                                             # table 0; pad (any negative id) -> zero (:901)
         src_a = torch.cat((_const_code(3, b, dev), sem_code, _const_code(4, b, dev), _code(1, coarse_rows)), dim=1).contiguous()
-        src_b = torch.cat((_neg(b, ns + 2, dev), _code(2, qrow)[None].expand(b, -1)), dim=1).contiguous()     # :904-906
+        src_b = _quantizer_codes(2, b, ns + 2, nc, Q, dev)                                       # :904-906
         N = ns + nc + 2
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.semantic_embedding.weight,
                                        self.coarse_embedding.weight, self.coarse_quantize_embedding.weight,
