@@ -248,13 +248,24 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     if (WIDTH || FINAL) { if (eok) lng = ld4(a.ln_gamma + e0); }
     if (WIDTH) {
         sa = *a.hp.sa; sb = *a.hp.sb;
+        // UNCONDITIONAL loads at a clamped index, selects afterwards: written as `eok ? p[e] * g1 : 0` each of the 28 parameter reads became its own
+        // exec-masked block with an `s_waitcnt vmcnt(0)` right behind the load -- 28 memory latencies one after the other at the top of every
+        // (persistent) workgroup, ~10 % of the kernel.  Now they are all in flight together.
+        const int eb = eok ? e0 : 0;
+        float gq[4], wa[4][S + 1], wbq[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int e = e0 + c;
-            const float g1 = eok ? a.hp.hc_gamma[e] + 1.f : 0.f;
+            gq[c] = a.hp.hc_gamma[eb + c];
+            wbq[c] = a.hp.wb[eb + c];
 #pragma unroll
-            for (int t = 0; t < S + 1; ++t) w[t][c] = eok ? a.hp.Wa[(long long)e * (S + 1) + t] * g1 : 0.f;
-            w[S + 1][c] = eok ? a.hp.wb[e] * g1 : 0.f;
+            for (int t = 0; t < S + 1; ++t) wa[c][t] = a.hp.Wa[(long long)(eb + c) * (S + 1) + t];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float g1 = eok ? gq[c] + 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < S + 1; ++t) w[t][c] = eok ? wa[c][t] * g1 : 0.f;
+            w[S + 1][c] = eok ? wbq[c] * g1 : 0.f;
         }
     }
 
@@ -525,14 +536,21 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     if (WIDTH) {
         sa = *a.hp.sa; sb = *a.hp.sb;
         if (LNF && eok) lng = ld4(a.ln_gamma + e0);
+        const int eb = eok ? e0 : 0;                             // unconditional loads at a clamped index, selects afterwards: see hc_fwd_kernel
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int e = e0 + c;
-            g1[c] = eok ? a.hp.hc_gamma[e] + 1.f : 0.f;
-            wbv[c] = eok ? a.hp.wb[e] : 0.f;
+            g1[c] = a.hp.hc_gamma[eb + c];
+            wbv[c] = a.hp.wb[eb + c];
+#pragma unroll
+            for (int t = 0; t < S + 1; ++t) wa[t][c] = a.hp.Wa[(long long)(eb + c) * (S + 1) + t];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            g1[c] = eok ? g1[c] + 1.f : 0.f;
+            wbv[c] = eok ? wbv[c] : 0.f;
             rawb[c] = 0.f;
 #pragma unroll
-            for (int t = 0; t < S + 1; ++t) { wa[t][c] = eok ? a.hp.Wa[(long long)e * (S + 1) + t] : 0.f; rawa[t][c] = 0.f; }
+            for (int t = 0; t < S + 1; ++t) { wa[t][c] = eok ? wa[t][c] : 0.f; rawa[t][c] = 0.f; }
         }
     }
 
