@@ -6,9 +6,10 @@
 // reference materialises never exist here: online softmax, fp32 statistics, bf16 MFMA operands.
 //
 // Mapping (wave64, MFMA 32x32x16 bf16):
-//   * forward / dQ: workgroup = 64 queries of one batch element x 4 heads, ONE WAVE PER HEAD, each wave owning a 64 x 64
-//     (queries x keys) score tile per step.  The 64-key K / V tile is fetched ONCE per workgroup by DMA
-//     (`buffer_load ... lds`, double buffered, one barrier per tile) and shared by the heads -- MQA makes K / V traffic ~free.
+//   * forward / dQ: workgroup = one query block of one batch element x 4 heads, ONE WAVE PER HEAD; dQ: 64 queries, a 64 x 64 (queries x keys)
+//     score tile per wave and step; forward: 32 queries (32 x 64 tile), and a workgroup takes TWO blocks (idx, last - idx) one after the other so
+//     that every workgroup of the launch walks the same number of key tiles (see mqa_fwd_kernel).  The 64-key K / V tile is fetched ONCE per
+//     workgroup by DMA (`buffer_load ... lds`, double buffered, one barrier per tile) and shared by the heads -- MQA makes K / V traffic ~free.
 //   * scores are computed transposed, S^T = K Q^T, so that one lane owns one query column: softmax statistics are lane-local
 //     (one cross-half exchange), and the fp32 S^T accumulator registers ARE the B operand (P^T) of the second MFMA
 //     (O^T = V^T P^T) after an in-register bf16 pack: no LDS round trip, no permutes.  The key-index permutation this implies
@@ -22,7 +23,8 @@
 //   * dK/dV: workgroup = 64 keys x 4 heads (8 waves = 4 heads x 2 key halves), loops over the 64-query tiles at/after the
 //     diagonal (Q / dO tiles by DMA, double buffered); per-head dK^T / dV^T accumulators are summed over the 4 heads through
 //     LDS; the two head groups write separate fp32 partials that alm_kv_grad_pack adds (deterministic, no atomics).
-//   * heavy (long-causal-span) workgroups are scheduled first and paired with light ones on a CU.
+//   * heavy (long-causal-span) workgroups are scheduled first and (dQ) paired with light ones on a CU; the DMA destination and the image being read
+//     are distinct `__restrict__` parameters of one inlined tile step in all three kernels (no compiler-inserted DMA wait before transposed reads).
 //   * STRUCTURED ATTENTION BIAS (the `flash_attn=False` models: reference RelativePositionBias audiolm_pytorch.py:202-242, the Coarse
 //     cross-attention override :924-936 and the Fine (frame, quantizer) table :1227-1298).  The reference gathers a (h, n, n) fp32
 //     tensor from a small per-head table and adds it to the scores; here the table is indexed INSIDE the kernels:
@@ -217,6 +219,16 @@ __device__ unsigned long long g_attn_probe[4096 * 8];
 #define PROBE_DECL
 #define PROBE_T(i)
 #define PROBE_FLUSH(slot)
+#endif
+#ifdef ALM_DKV_PROBE                                    // the same for the dK/dV kernel (slot 7 = number of query-tile steps of the workgroup)
+__device__ unsigned long long g_attn_probe[4096 * 8];
+#define DKV_PROBE_DECL unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long plast = __builtin_readcyclecounter();
+#define DKV_PROBE_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long pt_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); pacc[i] += pt_ - plast; plast = pt_; } while (0)
+#define DKV_PROBE_FLUSH(slot, steps) do { pacc[7] = (steps); if (lane == 0 && (slot) < 4096) for (int i_ = 0; i_ < 8; ++i_) g_attn_probe[(slot) * 8 + i_] = pacc[i_]; } while (0)
+#else
+#define DKV_PROBE_DECL
+#define DKV_PROBE_T(i)
+#define DKV_PROBE_FLUSH(slot, steps)
 #endif
 
 // QB = 32-query sub-blocks per wave.  QB == 1 (the launcher's choice): a workgroup takes query blocks idx and nqb - 1 - idx back to back, so every
@@ -910,12 +922,14 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
 
     stage(smem, kblk, 0);
     __syncthreads();
+    DKV_PROBE_DECL
 
     // one query-tile step; DMA destination and the images being read are distinct __restrict__ parameters of one inlined body, so that the transposed
     // Q^T / dO^T reads do not wait for the in-flight DMA (see mqa_fwd_kernel)
     auto step = [&](unsigned char* __restrict__ ntiles_img, const unsigned char* __restrict__ ctiles, int qt) {
         const int buf = (qt - kblk) & 1;
         if (qt + 1 < nqt) stage(ntiles_img, qt + 1, buf ^ 1);
+        DKV_PROBE_T(0);
         if (active) {
             const unsigned char* Qt = ctiles + hl * 16384;
             const unsigned char* Dt = Qt + 8192;
@@ -963,6 +977,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     const bf16x8 da = nat_frag(Dt, qb * 32 + lr, frow, ks, lh);
                     dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp[qb], 0, 0, 0);
                 }
+            DKV_PROBE_T(1);
             const int nodiag = (qt == kblk) ? 0 : 0x40000000;               // off the diagonal every key precedes every query
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
@@ -974,6 +989,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     s[qb][r] = pv;
                     dp[qb][r] *= pv;
                 }
+            DKV_PROBE_T(2);
             // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 64 queries of the tile: 4 steps of 16)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
@@ -989,6 +1005,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                         dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkt[db], 0, 0, 0);
                     }
                 }
+            DKV_PROBE_T(3);
         }
     };
 #pragma unroll 1
@@ -996,7 +1013,9 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         const int buf = (qt - kblk) & 1;
         step(smem + (buf ^ 1) * 65536, smem + buf * 65536, qt);
         __syncthreads();
+        DKV_PROBE_T(4);
     }
+    DKV_PROBE_FLUSH(blockIdx.x * 8 + wave, nqt - kblk);
 
     // reduce over the 4 heads through LDS: red[wave][d][32 keys (+1 pad)] fp32.  The pad matters: the accumulators are written key-major (lane = key)
     // and read dim-major (lane = d, for coalesced global stores) -- with a 32-float row every lane of the read hit ONE bank (32-way conflict,
@@ -1052,6 +1071,9 @@ static int check_attn(int B, int N, int H, long long ldq, long long ldk, long lo
     if (B <= 0 || N <= 0 || H <= 0 || H > 64) return ALM_ERR_UNSUPPORTED;
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return ALM_ERR_BAD_ARG;
     if ((long long)N * ldq * 2 >= 0x7fffffffLL || (long long)N * ldk * 2 >= 0x7fffffffLL || (long long)N * ldv * 2 >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
+    // the tile DMA relies on the buffer bounds check for rows N .. N + 63 of the last tile: their 32-bit byte offsets must not wrap
+    const long long ldmax = ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv);
+    if ((long long)(N + 64) * (ldmax > ldo ? ldmax : ldo) * 2 >= 0xffffffffLL) return ALM_ERR_UNSUPPORTED;
     return 0;
 }
 
@@ -1096,6 +1118,7 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
     if ((lddo & 7) || (lddq & 3) || (long long)N * lddo * 2 >= 0x7fffffffLL) return ALM_ERR_BAD_ARG;
+    if ((long long)(N + 64) * lddo * 2 >= 0xffffffffLL) return ALM_ERR_UNSUPPORTED;          // dO tile DMA: see check_attn
     rc = check_bias(ba, true);
     if (rc) return rc;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7)) return ALM_ERR_BAD_ARG;
@@ -1174,7 +1197,7 @@ extern "C" int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, in
     return 0;
 }
 
-#ifdef ALM_ATTN_PROBE
+#if defined(ALM_ATTN_PROBE) || defined(ALM_DKV_PROBE)
 extern "C" int alm_attn_probe_read(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_probe), sizeof(unsigned long long) * n);
 }
