@@ -422,3 +422,25 @@ def test_api_compat_helpers_get_embeds_and_grad_shrink():
     assert torch.allclose(y, x, atol=1e-7)
     y.sum().backward()
     assert torch.allclose(x.grad, torch.full_like(x, 0.1))
+
+
+def test_shape_derived_index_tensors_are_cached_and_plain():
+    """index tensors that depend only on shapes are built once per (shape, device): same object on the second call, never inference tensors (the first call
+    may happen under torch.inference_mode(), the next under autograd), and equal to the straightforward construction"""
+    dev = torch.device('cpu')
+    for fn in (AP._const_code, AP._neg, AP._quantizer_rows, AP._quantizer_row_offsets, AP._quantizer_codes, AP._group_index, AP._group_cols):
+        fn.cache_clear()
+    with torch.inference_mode():
+        a = AP._quantizer_codes(2, 3, 5, 7, 3, dev)
+        idx, ig, va = AP._group_index(2, 20, 4, 10, 3, dev)
+    b = AP._quantizer_codes(2, 3, 5, 7, 3, dev)
+    assert a is b and not a.is_inference() and not idx.is_inference()
+    assert AP._group_index(2, 20, 4, 10, 3, dev)[0] is idx
+    rows = torch.arange(7) % 3
+    ref = torch.cat((torch.full((3, 5), -1, dtype=torch.int32), ((2 << 24) + rows).to(torch.int32)[None].expand(3, -1)), dim=1)
+    assert torch.equal(a, ref) and a.dtype == torch.int32 and a.is_contiguous()
+    assert torch.equal(AP._quantizer_row_offsets(7, 3, 1024, dev), (1024 * rows).to(torch.int32)[None])
+    assert torch.equal(AP._group_cols(10, 3, dev), (torch.arange(4)[None, :] * 3 + torch.arange(3)[:, None]).clamp(max=9).reshape(-1))
+    assert torch.equal(AP._const_code(4, 2, dev), torch.full((2, 1), 4 << 24, dtype=torch.int32))
+    # a different shape is a different entry
+    assert AP._quantizer_codes(2, 3, 5, 8, 3, dev).shape == (3, 13)
