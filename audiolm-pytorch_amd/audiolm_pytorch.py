@@ -20,7 +20,7 @@ Conditioning (`has_condition=True`, reference :325-375, :450-455, :640-668, :818
 The reference's stacked kv_cache= / embed_cache= TENSOR protocol is accepted on forward() / forward_with_cond_scale()
 (Transformer.forward_kv_protocol: the one-new-token step runs the same single-position kernels); generate() drives the native cache directly.
 An arbitrary dense `attn_bias` tensor takes the reference's O(n^2) math path (relpos.DenseBias, xattn.py) instead of the flash kernels.
-Not accepted (NotImplementedError, nothing falls back silently): dropout > 0.
+Not accepted (NotImplementedError, nothing falls back silently): attn_dropout > 0 (ff_dropout > 0 is supported).
 Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
@@ -360,8 +360,11 @@ class Transformer(nn.Module):
         super().__init__()
         rel_pos_bias = rel_pos_bias and not flash_attn
         assert not (cross_attend and cond_as_self_attn_prefix)
-        if attn_dropout != 0. or ff_dropout != 0.:
-            raise NotImplementedError('dropout > 0 is not implemented in the fused stack (reference default is 0.)')
+        if attn_dropout != 0.:
+            raise NotImplementedError('attn_dropout > 0 (dropout of the attention probabilities and of the attention output) is not implemented in '
+                                      'the fused stack (reference default is 0.); ff_dropout > 0 is')
+        assert 0. <= ff_dropout < 1.
+        self.ff_dropout = float(ff_dropout)
         self.dim = dim
         self.depth = depth
         self.heads = heads
@@ -440,7 +443,8 @@ class Transformer(nn.Module):
         mask_u8 = None
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
-        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches, context_mask=context_mask)
+        opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches, context_mask=context_mask,
+                    ff_dropout=self.ff_dropout if self.training else 0.)
         hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
                                            attn_bias.tbl if exists(attn_bias) else None, context, *self.flat_params())
         if return_flat_hidden:

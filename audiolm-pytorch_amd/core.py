@@ -288,19 +288,32 @@ def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
     return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=cmixed, AO=AO, xs=xs)
 
 
-def _run_ff(cfg, W, prm, XN, M):
-    """feed-forward branch (audiolm_pytorch.py:246-260)"""
+def _dropout_keep(shape, p, device):
+    """0 / 1 keep mask (bf16) of an nn.Dropout(p).  A module-level function on purpose: the GPU parity test swaps it for a seeded generator and hands
+    the same masks to the oracle."""
+    return torch.empty(shape, dtype=BF16, device=device).bernoulli_(1. - p)
+
+
+def _run_ff(cfg, W, prm, XN, M, p_drop=0.):
+    """feed-forward branch (audiolm_pytorch.py:246-260).  p_drop > 0 (training only): the nn.Dropout(ff_dropout) between the inner LayerNorm and
+    the output projection (:258) -- the 0 / 1 mask is applied to HN in bf16 (exact), the 1 / (1 - p) factor rides on the fp32 alpha of the W2 GEMM
+    (and of its two backward GEMMs), so no rounded scale ever touches the activations."""
     I, Ip, dev = cfg.inner, cfg.inner_pad, XN.device
     (W1, _), (W2, _) = W['w1'], W['w2']
     U = _empty((M, 2 * Ip), BF16, dev)
     ops.gemm_nt(XN, W1, U)
     HN, mean3, rstd3 = ops.geglu_ln_fwd(U, prm['ln3'], I, Ip)
+    keep, alpha = None, 1.0
+    if p_drop > 0.:
+        keep = _dropout_keep((M, Ip), p_drop, dev)
+        HN = HN * keep
+        alpha = 1. / (1. - p_drop)
     Y = _empty((M, cfg.dim), BF16, dev)
-    ops.gemm_nt(HN, W2, Y)
-    return Y, dict(U=U, HN=HN, mean3=mean3, rstd3=rstd3)
+    ops.gemm_nt(HN, W2, Y, alpha=alpha)
+    return Y, dict(U=U, HN=HN, mean3=mean3, rstd3=rstd3, keep=keep, alpha=alpha)
 
 
-def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None):
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None, ff_dropout=0.):
     """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
     audiolm_pytorch.py:500-506 / :532) or None.  ctx: Context (cross-attention layers / self-attention prefix) or None.  Sampling: `kv_out`
     (DecodeCache) is filled with every layer's k / v of this (prefix) forward; `decode` (DecodeCache) means x holds ONE new position per
@@ -341,7 +354,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
             elif kind == 'cross':
                 Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx)
             else:
-                Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M)
+                Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M, ff_dropout)
             if need_grad:
                 sv.update(kind=kind, layer=l, first=l * ppl + first, R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Y=Y, r_bcast=r_bcast)
                 saved['branches'].append(sv)
@@ -489,10 +502,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         if kind == 'ff':
             (_, W1T), (_, W2T) = W['w1'], W['w2']
             dHN = _empty((M, Ip), BF16, dev)
-            ops.gemm_nt(dY, W2T, dHN)                                             # dHN = dY @ W2
+            fa = sv['alpha']                                                      # 1 / (1 - ff_dropout) (1.0 without dropout)
+            ops.gemm_nt(dY, W2T, dHN, alpha=fa)                                   # dHN = dY @ W2
+            if sv['keep'] is not None:
+                dHN.mul_(sv['keep'])                                              # through the dropout mask (HN below is the masked HN)
             dW2 = _empty((D, I), F32, dev)
             HNs, dYs = sv['HN'], dY
-            side.run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2), dYs, HNs, dW2)      # dW2 = dY^T @ HN
+            side.run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2, alpha=fa), dYs, HNs, dW2)      # dW2 = dY^T @ HN
             dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
             dXN = _empty((M, D), BF16, dev)
             ops.gemm_nt(dU, W1T, dXN)                                             # dXN = dU @ W1
@@ -650,7 +666,8 @@ class TransformerStackFn(torch.autograd.Function):
             micro = 1
         ctx.micro = micro
         if micro == 1:
-            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx)
+            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
+                                      ff_dropout=float(opts.get('ff_dropout', 0.)))
         else:
             S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
@@ -662,10 +679,10 @@ class TransformerStackFn(torch.autograd.Function):
                 (cma, cmb) = _halves(cx.mask, h)
                 ca, cb = Context(cx.x[:h * cx.m], cma, h, cx.m), Context(cx.x[h * cx.m:], cmb, B - h, cx.m)
             s2.wait_stream(cur)
-            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca)
+            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca, ff_dropout=float(opts.get('ff_dropout', 0.)))
             xb.record_stream(s2)
             with torch.cuda.stream(s2):
-                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb)
+                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb, ff_dropout=float(opts.get('ff_dropout', 0.)))
             cur.wait_stream(s2)
             hnb.record_stream(cur)
             hn = torch.cat((hna, hnb), dim=0)

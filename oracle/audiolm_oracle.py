@@ -98,12 +98,16 @@ def layer_norm(x, gamma):                        # audiolm_pytorch.py:191-198 (b
     return F.layer_norm(x, x.shape[-1:], gamma, torch.zeros_like(gamma))
 
 
-def feedforward(sd, p, x):                       # audiolm_pytorch.py:246-260
+def feedforward(sd, p, x, keep=None, p_drop=0.):  # audiolm_pytorch.py:246-260
+    """keep / p_drop: the nn.Dropout(ff_dropout) of :258 with its Bernoulli keep mask SUPPLIED (0 / 1, shape of the inner activation): x * keep / (1 - p)
+    is what F.dropout computes once the mask is drawn -- the parity test hands the masks of the device run to this restatement."""
     x = layer_norm(x, sd[p + '0.gamma'])
     x = F.linear(x, sd[p + '1.weight'])
     x, gate = x.chunk(2, dim=-1)                 # GEGLU: gate is the SECOND half (:246-249)
     x = F.gelu(gate) * x
     x = layer_norm(x, sd[p + '3.gamma'])
+    if keep is not None:
+        x = x * keep / (1. - p_drop)
     return F.linear(x, sd[p + '5.weight'])
 
 
@@ -185,7 +189,8 @@ def rel_pos_bias(sd, p, i, j):                    # audiolm_pytorch.py:202-242
 
 
 def transformer(sd, p, x, *, depth, heads, streams=4, self_attn_mask=None, attn_bias=None,
-                grad_shrink_alpha=0.1, add_value_residual=True, context=None, context_mask=None, cond_as_self_attn_prefix=False):
+                grad_shrink_alpha=0.1, add_value_residual=True, context=None, context_mask=None, cond_as_self_attn_prefix=False,
+                ff_keep=None, ff_dropout=0.):
     """audiolm_pytorch.py:461-560 (no kv-cache).  `p` is e.g. 'transformer.'.  A conditioning `context` goes to the cross-attention layers
     (present in `sd` as layers.{l}.1.*) or, with cond_as_self_attn_prefix, in front of the self-attention keys."""
     n = x.shape[1]
@@ -222,7 +227,7 @@ def transformer(sd, p, x, *, depth, heads, streams=4, self_attn_mask=None, attn_
                                                      value_residual=cross_value_residual, causal=False))
             if add_value_residual and cross_value_residual is None:
                 cross_value_residual = cvalues
-        branch(pf, lambda t: feedforward(sd, pf + 'branch.', t))
+        branch(pf, lambda t: feedforward(sd, pf + 'branch.', t, None if ff_keep is None else ff_keep[l], ff_dropout))   # ff_keep: one mask per layer
     if streams > 1:
         x = x.reshape(x.shape[0] // streams, streams, *x.shape[1:]).sum(dim=1)   # :551
     return layer_norm(x, sd[p + 'norm.gamma'])                             # :555

@@ -310,3 +310,57 @@ def test_transformer_with_dense_attn_bias_vs_oracle(streams):
     worst = max((fro(p.grad, sdr[k].grad), k) for k, p in tr.named_parameters()
                 if sdr[k].grad is not None and float(sdr[k].grad.norm()) > 1e-7 and not k.endswith(HC_SCALARS))
     assert worst[0] <= 8e-2, worst
+
+
+@pytest.mark.parametrize('streams', [1, 4])
+def test_transformer_ff_dropout_vs_oracle_with_the_same_masks(streams, monkeypatch):
+    """Transformer(ff_dropout = p) (reference FeedForward: nn.Dropout between the inner LayerNorm and the output projection, audiolm_pytorch.py:251-260).
+    The device run draws its keep masks through core._dropout_keep; the test swaps that for a seeded generator, records the masks and hands them to
+    the oracle: output and every gradient must agree as they do without dropout.  eval() must be the p = 0 model exactly."""
+    import audiolm_pytorch_amd as A
+    from audiolm_pytorch_amd import core
+    from common import synth_state_dict
+    dim, depth, heads, n, b, p = 128, 2, 4, 70, 2, 0.25
+    torch.manual_seed(0)
+    tr = A.audiolm_pytorch.Transformer(dim=dim, depth=depth, heads=heads, num_residual_streams=streams, rel_pos_bias=False, flash_attn=True, ff_dropout=p)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in tr.state_dict().items()}, 91)
+    tr.load_state_dict(sd)
+    tr.to(dev())
+    x = rnd(b, n, dim, seed=92).requires_grad_(True)
+    gm = torch.Generator().manual_seed(93)
+    mask = (torch.rand(b, n, generator=gm) > 0.15)
+    mask[:, 0] = True
+    masks = []
+
+    def seeded_keep(shape, p_, device):
+        k = (torch.rand(shape, generator=gm) >= p_).to(torch.bfloat16)
+        masks.append(k)
+        return k.to(device)
+    monkeypatch.setattr(core, '_dropout_keep', seeded_keep)
+    tr.train()
+    out = tr(x, self_attn_mask=mask.to(dev()))
+    go = rnd(b, n, dim, seed=94)
+    out.backward(go)
+    assert len(masks) == depth and 0.6 < float(torch.stack(masks).float().mean()) < 0.9
+    inner = int(dim * 8 / 3)
+    keep = [m[:, :inner].float().reshape(b, n, inner) for m in masks]
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    ref = O.transformer(sdr, '', xr, depth=depth, heads=heads, streams=streams, self_attn_mask=mask, ff_keep=keep, ff_dropout=p)
+    ref.backward(go.cpu())
+    fro = lambda a, w: float((a.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp(min=1e-30))
+    assert fro(out, ref) <= 1.5e-2, fro(out, ref)
+    assert fro(x.grad, xr.grad) <= 5e-2, fro(x.grad, xr.grad)
+    from test_gpu_parity import HC_SCALARS
+    worst = max((fro(q.grad, sdr[k].grad), k) for k, q in tr.named_parameters()
+                if sdr[k].grad is not None and float(sdr[k].grad.norm()) > 1e-7 and not k.endswith(HC_SCALARS))
+    assert worst[0] <= 8e-2, worst
+    # a run WITHOUT the masks must be clearly different (the masks really were applied) ...
+    ref0 = O.transformer({k: v.detach() for k, v in sd.items()}, '', x.detach().cpu(), depth=depth, heads=heads, streams=streams, self_attn_mask=mask)
+    assert fro(out, ref0) > 5e-2
+    # ... and eval() is the dropout-free model: no mask is drawn
+    tr.eval()
+    n_before = len(masks)
+    with torch.no_grad():
+        oe = tr(x.detach(), self_attn_mask=mask.to(dev()))
+    assert len(masks) == n_before and fro(oe, ref0) <= 1.5e-2
