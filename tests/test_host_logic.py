@@ -444,3 +444,23 @@ def test_shape_derived_index_tensors_are_cached_and_plain():
     assert torch.equal(AP._const_code(4, 2, dev), torch.full((2, 1), 4 << 24, dtype=torch.int32))
     # a different shape is a different entry
     assert AP._quantizer_codes(2, 3, 5, 8, 3, dev).shape == (3, 13)
+
+
+def test_oracle_feedforward_dropout_with_supplied_mask():
+    """the oracle's restated nn.Dropout (mask supplied): a ones-mask with p = 0 is the plain feed-forward, and a 0 / 1 mask with p scales the kept
+    activations of the inner LayerNorm output by 1 / (1 - p) -- checked against F.dropout's definition on the same tensor"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    d, inner = 24, int(24 * 8 / 3)
+    sd = {'f.0.gamma': torch.rand(d, generator=g) + 0.5, 'f.1.weight': torch.randn(2 * inner, d, generator=g) * 0.2,
+          'f.3.gamma': torch.rand(inner, generator=g) + 0.5, 'f.5.weight': torch.randn(d, inner, generator=g) * 0.2}
+    x = torch.randn(2, 7, d, generator=g)
+    plain = O.feedforward(sd, 'f.', x)
+    assert torch.equal(O.feedforward(sd, 'f.', x, torch.ones(2, 7, inner), 0.), plain)
+    p = 0.3
+    keep = (torch.rand(2, 7, inner, generator=g) >= p).float()
+    h = O.layer_norm(x, sd['f.0.gamma'])
+    a, gate = F.linear(h, sd['f.1.weight']).chunk(2, dim=-1)
+    hn = O.layer_norm(F.gelu(gate) * a, sd['f.3.gamma'])
+    want = F.linear(hn * keep / (1 - p), sd['f.5.weight'])
+    assert torch.allclose(O.feedforward(sd, 'f.', x, keep, p), want, atol=1e-6)
