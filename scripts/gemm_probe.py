@@ -53,14 +53,12 @@ def run():
         buf = (ctypes.c_ulonglong * n)()
         assert lib.alm_gemm_probe_read(buf, n) == 0
         a = np.array(buf, dtype=np.float64).reshape(16384, 8)
-        a = a[a[:, :7].sum(1) > 0]
-        nk = None
+        a = a[a[:, :7].sum(1) > 0]          # NOTE: a launch with fewer waves than an earlier one leaves the earlier one's slots in place (the means of the
+        #                                     later shapes then include stale rows): the first shape printed is the clean one
         print(f'{name}: M={M} N={N} K={K}: {e0.elapsed_time(e1) * 1e3:.1f} us (probed build), {len(a)} waves recorded; mean cycles per wave:')
         tot = a[:, :7].sum(1).mean()
         for i, s in enumerate(SEG):
             print(f'    {s:34s} {a[:, i].mean():9.0f}  ({100 * a[:, i].mean() / tot:4.1f} %)')
-        lib.alm_gemm_probe_read  # keep
-        # zero the buffer between shapes is not needed: every launch overwrites the slots it uses; larger earlier launches leave stale slots -> run big shapes last
 
 
 if __name__ == '__main__':

@@ -35,7 +35,6 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 
 agg = collections.defaultdict(lambda: [0, 0.0])
-pkg = os.path.join(ROOT, 'audiolm-pytorch_amd')
 for ev in prof.events():
     if not ev.name.startswith('aten::') or ev.device_time_total <= 0 or ev.cpu_children and any(c.name.startswith('aten::') and c.device_time_total > 0 for c in ev.cpu_children):
         continue
