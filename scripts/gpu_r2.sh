@@ -6,6 +6,7 @@ sections="$*"
 [[ -z $sections ]] && sections="kernels parity fullsize dp bench benchbf profbf rest smoke"
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+export ALM_BENCH_SUPERVISE=0      # rocprofv3 / timing scripts follow ONE process: bench.py measures in place (no re-launching child)
 has() { [[ " $sections " == *" $1 "* ]]; }
 python - > gpurun_out/${tag}_env.log 2>&1 <<'PY'
 import torch, os

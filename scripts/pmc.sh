@@ -4,6 +4,7 @@
 cnt="$1"; tag="$2"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export ALM_BENCH_SUPERVISE=0      # profilers follow ONE process: bench.py measures in place (no re-launching child)
 d=/tmp/pmc_$tag
 rm -rf $d
 timeout 600 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $d -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer-leg > gpurun_out/pmc_$tag.log 2>&1
