@@ -284,12 +284,27 @@ def semantic_forward(sd, cfg: Cfg, ids, self_attn_mask=None, text_embeds=None, c
                          self_attn_mask=self_attn_mask, grad_shrink_alpha=cfg.grad_shrink_alpha,
                          add_value_residual=cfg.add_value_residual, context=context, context_mask=context_mask,
                          cond_as_self_attn_prefix=cfg.cond_as_self_attn_prefix)
-    return F.linear(tokens, sd['to_logits.weight'], sd['to_logits.bias'])        # :719
+    return head_linear(tokens, sd['to_logits.weight'], sd['to_logits.bias'])     # :719
 
 
 # ----------------------------------------------------------------------------------------------
 # A9 CoarseTransformer.forward  (audiolm_pytorch.py:858-990)
 # ----------------------------------------------------------------------------------------------
+
+def head_linear(x, w, b=None):
+    """the nn.Linear logit heads (:621 / :798).  A module-level name on purpose: oracle/rounding_matched.py swaps the three head functions (this one,
+    _grouped_logits, _padded_logits) for split-bf16 restatements of the same contractions."""
+    return F.linear(x, w, b)
+
+
+def _padded_logits(weights, pred, Q):
+    """Fine-coarse logits: zero-pad to a multiple of Q, group, slice (:1325-1339)"""
+    b, n = pred.shape[:2]
+    padding = ceil_div(n, Q) * Q - n
+    pc = F.pad(pred, (0, 0, 0, padding), value=0.) if padding else pred
+    pc = pc.reshape(b, -1, Q, pc.shape[-1])
+    return torch.einsum('qcd,bnqd->bnqc', weights, pc).reshape(b, -1, weights.shape[1])[:, :n]
+
 
 def _grouped_logits(weights, pred, Q):
     """groupable part + remainder with W[:r]  (Coarse :965-983, Fine-fine :1343-1361)."""
@@ -335,7 +350,7 @@ def coarse_forward(sd, cfg: Cfg, semantic_token_ids, coarse_token_ids, self_attn
     pred_sem, pred_coarse = tokens[:, :semantic_seq_len], tokens[:, semantic_seq_len + 1:]   # :957
     semantic_logits = None
     if 'to_semantic_logits.weight' in sd:                                        # :961
-        semantic_logits = F.linear(pred_sem, sd['to_semantic_logits.weight'], sd['to_semantic_logits.bias'])
+        semantic_logits = head_linear(pred_sem, sd['to_semantic_logits.weight'], sd['to_semantic_logits.bias'])
     coarse_logits = _grouped_logits(sd['coarse_logit_weights'], pred_coarse, Q)  # :965-983
     return semantic_logits, coarse_logits
 
@@ -410,10 +425,7 @@ def fine_forward(sd, cfg: Cfg, coarse_token_ids, fine_token_ids, self_attn_mask=
     pred_coarse, pred_fine = tokens[:, :n], tokens[:, n + 1:]                    # :1319
     coarse_logits = None
     if 'coarse_logit_weights' in sd:                                             # :1325-1339 (zero-pad then slice)
-        padding = ceil_div(n, Qc) * Qc - n
-        pc = F.pad(pred_coarse, (0, 0, 0, padding), value=0.) if padding else pred_coarse
-        pc = pc.reshape(b, -1, Qc, pc.shape[-1])
-        coarse_logits = torch.einsum('qcd,bnqd->bnqc', sd['coarse_logit_weights'], pc).reshape(b, -1, C)[:, :n]
+        coarse_logits = _padded_logits(sd['coarse_logit_weights'], pred_coarse, Qc)
     fine_logits = _grouped_logits(sd['fine_logit_weights'], pred_fine, Qf)       # :1343-1361
     return coarse_logits, fine_logits
 

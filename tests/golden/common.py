@@ -49,7 +49,10 @@ def synth_state_dict(shapes: dict, seed: int, *, streams: int = 4, dtype=torch.f
         elif last == 'static_beta':
             v = 1.0 + 0.1 * r
         elif last in ('dynamic_alpha_fn', 'dynamic_beta_fn'):
-            v = 0.05 * r
+            # width-scaled (round 3): the pre-activation `normed @ fn` sums shape[0] = dim features of unit RMS, so a fixed 0.05 * randn gives a
+            # std of 0.05 * sqrt(dim) -- 0.4 at dim 64 (every small golden: unchanged) but 1.6 at dim 1024, where tanh saturates and every
+            # rounding difference is amplified until no bound on the 4-stream gradients discriminates (round-2 VERDICT).  Keep it at 0.4.
+            v = 0.05 * math.sqrt(64.0 / max(64, shape[0])) * r
         elif last in ('dynamic_alpha_scale', 'dynamic_beta_scale'):
             v = 0.1 + 0.02 * r
         elif last == 'bias':

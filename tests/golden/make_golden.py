@@ -167,6 +167,69 @@ def fine_case(name, *, ctor, coarse, fine, training=True, mask_prob=0., seed=3, 
                 outputs=dict(loss=loss, coarse_logits=cl.detach(), fine_logits=fl.detach(), grads=grad_digest(grads, full)))
 
 
+def logits_digest(t, n=32768):
+    """strided sample + norm of a big logits tensor (full-size fixtures stay small)"""
+    flat = t.detach().float().reshape(-1)
+    stride = max(1, flat.numel() // n)
+    if stride > 1 and stride % 2 == 0:
+        stride += 1                                           # odd stride: the sample walks through every class column
+    return dict(shape=tuple(t.shape), norm=float(flat.norm()), stride=stride, sample=flat[::stride].clone())
+
+
+def fullsize_case(name, kind, streams):
+    """BENCHMARK-SIZE fixtures of the REAL reference in digest form (round 3): CoarseTransformer dim=1024 depth=6 at N=2048 (BASELINE headline /
+    configs[3] shape, B=1) and FineTransformer 3 + 5 quantizers at N=2049 (configs[2]), reference forward :858-990 / :1136-1368 under the wrappers
+    :1742-1854 / :2041-2137, forgetful mask 0.15 injected.  Stored: loss, strided logits sample + norm, per-parameter gradient norm + strided
+    sample, and the reference's OWN bf16-autocast deviation (loss / logits / per-tensor gradients) on the same inputs.  The inputs are the ones
+    tests/test_gpu_fullsize.py::_case builds (same generator seed)."""
+    import audiolm_oracle as O
+    g = torch.Generator().manual_seed(1234)
+    extra = {} if streams == 4 else dict(num_residual_streams=streams)
+    if kind == 'coarse':
+        ctor = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True, **extra)
+        sem, coarse = torch.randint(0, 500, (1, 509), generator=g), torch.randint(0, 1024, (1, 512, 3), generator=g)
+        N = 1 + 510 + 1 + 1536
+        mask = O.generate_mask_with_prob((1, N), 0.15, 'cpu', generator=g)
+        K, seed = A.CoarseTransformer, 4242 + streams
+        inputs = dict(semantic_token_ids=sem, coarse_token_ids=coarse, forgetful_mask=mask)
+        options = dict(training=True, unique_consecutive=False, mask_prob=0.15)
+        mkw = lambda m: (A.CoarseTransformerWrapper(transformer=m, codec=_Codec(), unique_consecutive=False, mask_prob=0.15),
+                         dict(semantic_token_ids=sem, coarse_token_ids=coarse))
+        keys = ('semantic_logits', 'coarse_logits')
+    else:
+        ctor = dict(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True, **extra)
+        grid = torch.randint(0, 1024, (1, 256, 8), generator=g)
+        coarse, fine = grid[..., :3].contiguous(), grid[..., 3:].contiguous()
+        N = 1 + 768 + 1 + 1279
+        mask = O.generate_mask_with_prob((1, N), 0.15, 'cpu', generator=g)
+        K, seed = A.FineTransformer, 4242 + streams
+        inputs = dict(coarse_token_ids=coarse, fine_token_ids=fine, forgetful_mask=mask)
+        options = dict(training=True, mask_prob=0.15)
+        mkw = lambda m: (A.FineTransformerWrapper(transformer=m, codec=_Codec(8), mask_prob=0.15), dict(coarse_token_ids=coarse, fine_token_ids=fine))
+        keys = ('coarse_logits', 'fine_logits')
+    torch.manual_seed(0)
+    model = K(**ctor)
+    shapes = _shapes(model.state_dict())
+    model.load_state_dict(synth_state_dict(shapes, seed))
+    wrapper, kw = mkw(model)
+    import time
+    t0 = time.time()
+    loss, logits, grads = _run(model, wrapper, kw, True, mask)
+    t_ref = time.time() - t0
+    out = dict(loss=loss, grads=grad_digest(grads, False), ref_seconds=t_ref)
+    for k, t in zip(keys, logits):
+        out[k] = logits_digest(t)
+    g32 = {k: (v.detach().float().clone() if v is not None else None) for k, v in grads.items()}
+    l32 = [t.detach().float().clone() for t in logits]
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        nloss, nlogits, ngrads = _run(model, wrapper, kw, True, mask)
+    noise = dict(loss_abs=abs(float(nloss) - float(loss)),
+                 logits=[float((a.detach().float() - b).norm() / b.norm()) for a, b in zip(nlogits, l32)],
+                 grads={k: float((ngrads[k].float() - v).norm() / v.norm()) for k, v in g32.items() if v is not None and float(v.norm()) >= 1e-9})
+    return dict(name=name, kind=kind, ctor=ctor, shapes=shapes, seed=seed, restated=streams > 1, options=options, inputs=inputs, outputs=out,
+                noise=noise, N=N)
+
+
 def attend_case():
     g = torch.Generator().manual_seed(7)
     b, h, n, d = 2, 4, 37, 16
@@ -400,6 +463,23 @@ def main():
         c = soundstream_decode_case()
         torch.save(c, os.path.join(HERE, c['name'] + '.pt'))
         print(c['name'], tuple(c['outputs']['wave'].shape))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':                # benchmark-size digests of the REAL reference (added in round 3)
+        for name, kind, streams in (('full_coarse_s1', 'coarse', 1), ('full_coarse_s4', 'coarse', 4), ('full_fine_s4', 'fine', 4)):
+            c = fullsize_case(name, kind, streams)
+            path = os.path.join(HERE, c['name'] + '.pt')
+            torch.save(c, path)
+            nz = c['noise']
+            print(f'{name}: loss={float(c["outputs"]["loss"]):.6f} ref fwd+bwd {c["outputs"]["ref_seconds"]:.1f} s; reference bf16-autocast: loss |d| {nz["loss_abs"]:.2e}, '
+                  f'logits {["%.2e" % v for v in nz["logits"]]}, worst grads {sorted(((round(v, 3), k) for k, v in nz["grads"].items()), reverse=True)[:4]}; '
+                  f'{os.path.getsize(path) / 1024:.0f} KiB')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg0':                    # BASELINE configs[0] alone (its synthetic weights are width-scaled since round 3)
+        R0 = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
+        c = semantic_case('semantic_cfg0', ctor=dict(dim=256, depth=2, num_semantic_tokens=500), ids=R0(500, (8, 255), 0), unique_consecutive=False,
+                          mask_prob=0., full=False)
+        torch.save(c, os.path.join(HERE, c['name'] + '.pt'))
+        print(c['name'], float(c['outputs']['loss']))
         return
     R = lambda hi, shape, seed: torch.randint(0, hi, shape, generator=torch.Generator().manual_seed(seed))
     cases = []

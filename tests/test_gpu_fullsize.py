@@ -7,12 +7,19 @@ width, split-K weight gradients over K = B*N tokens, the multi-token-per-workgro
 non-degenerate synthetic values of tests/golden/common.py (every hyper-connection / LayerNorm / bias path carries signal); inputs are
 seeded uniform token ids; the forgetful mask is drawn once on the CPU and injected on both sides.
 
-Compared: the loss, EVERY logit, and the gradient of EVERY parameter.  Tolerances (bf16 GEMM operands vs an fp32 reference):
-  loss     |d| <= 1e-3 * |loss|                      (north_star: loss within 1e-3; no noise clause)
-  logits   rel Frobenius error <= max(1e-2, the oracle's own bf16-autocast deviation on the same inputs)  -- both numbers are reported
-  grads    per tensor rel Frobenius error <= max(3e-2, 2 x the oracle's bf16-autocast deviation of that tensor); hyper-connection scalar
-           statistics pooled (see tests/test_gpu_parity.py)
-Every run appends its numbers to gpurun_out/r2_fullsize_parity.jsonl (copied to profiles/ for the record).
+Compared: the loss, EVERY logit, and the gradient of EVERY parameter, against TWO oracles (round 3):
+  (A) the ROUNDING-MATCHED oracle (oracle/rounding_matched.py: the same restatement with bf16 rounding at the HIP path's storage / operand points,
+      fp32 accumulation) -- differs from the HIP path by summation order only, so this is where north_star's number is asserted:
+        logits   rel Frobenius error <= 1e-3
+        grads    per tensor rel Frobenius error <= 1e-2; the hyper-connection scalar statistics (heavily cancelling sums over all tokens) <= 0.1
+  (B) the fp32 oracle (pinned to the real reference at these sizes: tests/test_oracle_golden.py::test_oracle_matches_reference_at_benchmark_size):
+        loss     |d| <= 1e-3 * |loss|                      (north_star: loss within 1e-3; no noise clause)
+        logits   rel Frobenius error <= max(1e-2, the oracle's own bf16-autocast deviation on the same inputs)  -- both numbers are reported
+        grads    per tensor rel Frobenius error <= max(3e-2, 2 x the oracle's bf16-autocast deviation of that tensor); hyper-connection scalar
+                 statistics pooled (see tests/test_gpu_parity.py) -- a noise-relative bound, kept for the record; (A) is the one with teeth
+Synthetic hyper-connection weights are width-scaled (tests/golden/common.py): the dynamic pre-activations keep a std of ~0.4 at dim 1024.
+test_full_size_matches_real_reference_digest compares the HIP path DIRECTLY with digests of the REAL reference at these sizes (tests/golden/full_*.pt).
+Every run appends its numbers to gpurun_out/r3_fullsize_parity.jsonl (copied to profiles/ for the record).
 """
 import json
 import os
@@ -23,13 +30,14 @@ import torch
 
 import audiolm_oracle as O
 from common import synth_state_dict
-from test_gpu_parity import _frob, grad_report, ours_run
-from test_oracle_golden import oracle_run
+from test_gpu_parity import HC_SCALARS, _frob, grad_report, ours_run
+from test_oracle_golden import FULL_FIXTURES, _load, digest_errors, oracle_run
+import rounding_matched as RM
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r2_fullsize_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r3_fullsize_parity.jsonl')
 
 
 def _case(kind, streams, N_kind):
@@ -87,6 +95,11 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual):
     ologits = [t.detach() for t in ologits if t is not None]
     with torch.autocast('cpu', dtype=torch.bfloat16):                          # the oracle's own bf16-autocast deviation on these inputs
         nloss, nlogits, ngrads = oracle_run(fx)
+    t0 = time.time()
+    with RM.rounding_matched(residual_bf16=(residual == 'bf16' and streams > 1)):    # (A) the rounding-matched oracle, same storage type of the streams
+        rloss, rlogits, rgrads = oracle_run(fx)
+    t_rm = time.time() - t0
+    rlogits = [t.detach() for t in rlogits if t is not None]
     TG.synth_state_dict = orig_synth
     nlogits = [t.detach().float() for t in nlogits if t is not None]
     noise = dict(loss_rel=abs(float(nloss) - float(oloss)) / abs(float(oloss)),
@@ -116,12 +129,50 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual):
         assert grads.get(k) is not None, f'missing gradient for {k}'
         items.append((k, _frob(grads[k], g), float(g.norm()), noise['grads'].get(k, 0.0)))
     ok &= grad_report(items, rep)
+    # (A) against the rounding-matched oracle: north_star's 1e-3 on the logits, 1e-2 on every gradient tensor (0.1 on the cancelling scalar sums)
+    rm_l = [_frob(a, b) for a, b in zip(logits, rlogits)]
+    rep.append(f'  vs ROUNDING-MATCHED oracle ({t_rm:.1f} s): loss rel |d| {abs(loss - float(rloss)) / abs(float(rloss)):.2e}; logits rel-frob {["%.2e" % e for e in rm_l]} (bound 1e-3)')
+    ok &= max(rm_l) <= 1e-3
+    rm_g = {k: _frob(grads[k], g) for k, g in rgrads.items() if g is not None and float(g.norm()) >= 1e-7}
+    worst_t = max((e, k) for k, e in rm_g.items() if not k.endswith(HC_SCALARS))
+    hc = [(e, k) for k, e in rm_g.items() if k.endswith(HC_SCALARS)]
+    worst_s = max(hc) if hc else (0.0, '-')
+    rep.append(f'     grads: worst tensor {worst_t[0]:.2e} ({worst_t[1]}; bound 1e-2), worst hyper-connection scalar {worst_s[0]:.2e} ({worst_s[1]}; bound 1e-1)')
+    ok &= worst_t[0] <= 1e-2 and worst_s[0] <= 1e-1
     print('\n'.join(rep))
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
     with open(REPORT, 'a') as fh:
         fh.write(json.dumps(dict(kind=kind, init='default' if default_init else 'synthetic', streams=streams, N=N, B=B, residual_streams=residual, loss_ours=loss, loss_oracle=float(oloss),
                                  loss_rel=rel, loss_rel_oracle_bf16=noise['loss_rel'], logits_rel_frob=lerr, logits_rel_frob_oracle_bf16=noise['logits'],
-                                 worst_grad_rel_frob=max(e for _, e, _, _ in items), n_grad_tensors=len(items),
+                                 worst_grad_rel_frob=max(rm_g.values()), worst_grad_tensor_rel_frob=worst_t[0], worst_grad_hc_scalar_rel_frob=worst_s[0],
+                                 logits_rel_frob_vs_rounding_matched=rm_l, loss_rel_vs_rounding_matched=abs(loss - float(rloss)) / abs(float(rloss)),
+                                 worst_grad_rel_frob_vs_fp32_oracle=max(e for _, e, _, _ in items), n_grad_tensors=len(items),
                                  grads_over_3e2=sorted([(k, round(e, 4), round(nz, 4)) for k, e, _, nz in items if e > 3e-2], key=lambda t: -t[1])[:12],
                                  oracle_seconds=round(t_oracle, 1), ok=bool(ok))) + '\n')
+    assert ok, '\n'.join(rep)
+
+
+@pytest.mark.parametrize('name,residual', [(n, 'fp32') for n in FULL_FIXTURES] + [('full_coarse_s4', 'bf16'), ('full_fine_s4', 'bf16')])
+def test_full_size_matches_real_reference_digest(name, residual):
+    """The HIP path against the REAL reference at the benchmark sizes -- no oracle in between (round 3; fixtures: tests/golden/make_golden.py
+    fullsize, run in the build container on reference audiolm_pytorch.py:858-990 / :1136-1368 / :1742-1854 / :2041-2137).  The digests hold the loss, a
+    strided sample of every logits tensor, norm + strided sample of every parameter gradient and the reference's own bf16-autocast deviation.
+    Bounds: loss 1e-3; logits sample rel-Frobenius <= max(1e-2, the reference's bf16 deviation); gradients (sample and norm) per tensor
+    <= max(3e-2, 2 x the reference's bf16 deviation), hyper-connection scalars pooled."""
+    fx = _load(name)
+    loss, logits, grads = ours_run(fx, want_logits=True, residual_dtype=torch.bfloat16 if residual == 'bf16' else torch.float32)
+    logits = [t for t in (logits if isinstance(logits, (tuple, list)) else (logits,)) if t is not None]
+    lrel, lerr, gerr = digest_errors(fx, loss, logits, grads)
+    nz = fx['noise']
+    rep = [f'{name} [residual streams {residual}] vs the REAL reference: loss rel |d| {lrel:.2e} (bound 1e-3; reference bf16-autocast {nz["loss_abs"] / abs(float(fx["outputs"]["loss"])):.2e})']
+    ok = lrel <= 1e-3
+    for e, n_ in zip(lerr, nz['logits']):
+        rep.append(f'  logits sample rel-frob {e:.2e} (bound max(1e-2, reference bf16-autocast {n_:.2e}))')
+        ok &= e <= max(1e-2, n_)
+    items = [(k, max(en, es), fx['outputs']['grads'][k]['norm'], nz['grads'].get(k, 0.0)) for k, (en, es) in gerr.items()]
+    ok &= grad_report(items, rep)
+    print('\n'.join(rep))
+    with open(REPORT, 'a') as fh:
+        fh.write(json.dumps(dict(kind='real-reference digest ' + name, residual_streams=residual, loss_rel=lrel, logits_sample_rel_frob=lerr,
+                                 logits_rel_frob_reference_bf16=nz['logits'], worst_grad_sample_rel_frob=max(e for _, e, _, _ in items), ok=bool(ok))) + '\n')
     assert ok, '\n'.join(rep)
