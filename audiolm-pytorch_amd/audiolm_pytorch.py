@@ -451,8 +451,26 @@ class Transformer(nn.Module):
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)
         return hn.view(b, n, d)
 
-    @torch.no_grad()
     def forward_kv_protocol(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, kv_cache=None):
+        """see _forward_kv_protocol.  The outputs carry NO autograd graph, whereas the reference's Coarse / Fine forward requests the cache internally
+        and stays differentiable: code that passes return_kv_cache / return_cache while TRAINING would silently get detached logits, so a call in
+        training mode with autograd on is refused, and an eval-mode call with autograd on (inference without no_grad) warns once."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.training:
+                raise RuntimeError('audiolm_pytorch_amd: the kv_cache / return_kv_cache (return_cache) tensor protocol is inference-only -- its outputs are '
+                                   'detached from autograd.  Train without the cache arguments, or call it under torch.no_grad() / .eval()')
+            if not Transformer._warned_protocol_grad:
+                Transformer._warned_protocol_grad = True
+                import warnings
+                warnings.warn('audiolm_pytorch_amd: kv_cache / return_kv_cache outputs are detached from autograd (inference-only protocol); wrap '
+                              'sampling code in torch.no_grad() to silence this', stacklevel=3)
+        return self._forward_kv_protocol(x, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask, attn_bias=attn_bias,
+                                         kv_cache=kv_cache)
+
+    _warned_protocol_grad = False
+
+    @torch.no_grad()
+    def _forward_kv_protocol(self, x, self_attn_mask=None, context=None, context_mask=None, attn_bias=None, kv_cache=None):
         """The reference's kv-cache TENSOR protocol (audiolm_pytorch.py:360-370 store / concat, :487-496 `x = x[:, cache_len:]`, :560 stack):
         x fp32 [b, n, d] = embeddings of the WHOLE sequence, kv_cache [depth, 2 (k | v), b, cache_len, dim_head] | None
         -> (final-norm hidden states of the positions cache_len .. n-1, fp32 [b, n - cache_len, d];  new kv_cache fp32 [depth, 2, b, n, dim_head]).

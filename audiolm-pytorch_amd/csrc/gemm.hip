@@ -989,6 +989,17 @@ extern "C" int alm_transpose_bf16(const void* src, void* dst, int rows, int cols
     return 0;
 }
 
+extern "C" int alm_transpose_bf16_batched(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, int nb,
+                                          long long bs_src, long long bs_dst, void* stream) {
+    if (rows <= 0 || cols <= 0 || nb <= 0) return 0;
+    if (rows_pad < rows || ld_dst < rows_pad || nb > 65535) return ALM_ERR_BAD_ARG;
+    dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64, nb);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src,
+                       ld_dst, rows_pad, bs_src, bs_dst);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream) {
     if (njobs <= 0) return 0;
     if (njobs > 8 || !jobs) return ALM_ERR_BAD_ARG;

@@ -70,6 +70,12 @@ class GraphedTrainStep:
         with torch.cuda.graph(g):
             self.loss, self.grads = self._issue()
         self.graph = g
+        # The capture only RECORDED the step: the bf16 weight packs it re-created were keyed into the WeightCaches with the masters' current
+        # (data_ptr, version), but their contents -- like self.loss and self.grads -- do not exist until the graph has run once.  An eager forward
+        # (eval, generate, a parity check) between construction and the first replay would hit those cache entries and read uninitialised packs.
+        # One replay makes every captured buffer real.
+        g.replay()
+        torch.cuda.synchronize(self.dev)
 
     def __call__(self, **inputs):
         for k, v in inputs.items():

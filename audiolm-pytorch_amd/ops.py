@@ -547,8 +547,43 @@ def check_device_errors(device=None):
             continue
         if int(flag.item()) != 0:
             flag.zero_()
+            _err_poll.pop(key, None)
             raise IndexError('token id out of range of its embedding table (audiolm_pytorch_amd embed_assemble): the offending positions were '
                              'embedded as zero vectors')
+
+
+_err_poll = {}
+CHECK_IDS = __import__('os').environ.get('ALM_CHECK_IDS', '1') != '0'
+
+
+def poll_device_errors(device):
+    """Non-blocking form of check_device_errors(), called by every embedding lookup (ALM_CHECK_IDS=0 turns it off): the error word is copied to
+    pinned host memory asynchronously and the copy issued by an EARLIER call is examined once it has landed -- an out-of-range token id therefore
+    raises IndexError (what the reference's nn.Embedding does at once) one or two lookups late, without a host-device synchronisation anywhere.
+    Skipped while a hipGraph is being captured (events cannot be queried there)."""
+    if not CHECK_IDS or device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+        return
+    key = (device.type, device.index)
+    flag = _err_flags.get(key)
+    if flag is None:
+        return
+    st = _err_poll.get(key)
+    if st is None:
+        st = _err_poll[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    host, ev = st
+    if ev is not None:
+        if not ev.query():
+            return                                            # the previous copy is still in flight: look again at the next lookup
+        st[1] = None
+        if int(host[0]) != 0:
+            flag.zero_()
+            host.zero_()
+            raise IndexError('token id out of range of its embedding table (audiolm_pytorch_amd embed_assemble, an earlier step): the offending '
+                             'positions were embedded as zero vectors')
+    host.copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st[1] = ev
 
 
 def _table_rows(tables):
@@ -559,6 +594,7 @@ def embed_assemble(tables, src_a, src_b, rows, D):
     """tables: fp32 [rows_t, D] each.  Ids outside a table never touch memory: zero vector + device error flag (see device_error_flag)."""
     out = torch.empty((rows, D), dtype=F32, device=src_a.device)
     arr = _ptr_array(tables)
+    poll_device_errors(src_a.device)
     _lib.call('alm_embed_assemble', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_table_rows(tables), ctypes.c_void_p), len(tables), src_a.data_ptr(),
               src_b.data_ptr(), out.data_ptr(), rows, D, device_error_flag(src_a.device).data_ptr(), _st())
     return out

@@ -18,13 +18,20 @@ backward.  It is not a general DDP replacement.
     without no_sync(), or `zero_grad(set_to_none=False)`), autograd ADDS this backward's share to it -- the overlapped buckets only carry the
     fresh share, so that backward is exchanged like an accumulated one (p.grad itself is reduced in `finish()`, per layer, not overlapped).
     `zero_grad()` with torch's default set_to_none=True keeps the overlap.
-  * `bucket_dtype=torch.bfloat16` halves the bytes on the xGMI links (the reduction then runs in bf16; fp32 is the default, like DDP)
+  * `bucket_dtype=torch.bfloat16` halves the bytes on the xGMI links (the reduction then runs in bf16; fp32 is the default, like DDP;
+    bench.py uses bf16 for N > 1: a ring over 7 x ~153 GB/s xGMI links is per-link bound, 131 instead of 262 MB per step)
+  * `force_collectives=True` issues the collectives even in a 1-rank group (they are the identity there): the way the RCCL hand-off -- bucket copy
+    and asynchronous all-reduce issued from the backward's side stream, `work.wait()` ordering the main stream in `finish()` -- is executed on a
+    1-GPU box (tests/test_gpu_dp.py)
+  * `stats` (per step, reset by `finish()`): bucket count, bytes put on the wire, host time from the last bucket launch to the return of `finish()`
+    (what the step still waited for: the tail that did not overlap)
 
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
 """
 from __future__ import annotations
 
 import contextlib
+import time
 
 import torch
 
@@ -37,10 +44,13 @@ class _Bucket:
 
 
 class DataParallelEngine:
-    def __init__(self, model, dist, process_group=None, broadcast_parameters=True, bucket_dtype=torch.float32):
+    def __init__(self, model, dist, process_group=None, broadcast_parameters=True, bucket_dtype=torch.float32, force_collectives=False):
         assert bucket_dtype in (torch.float32, torch.bfloat16), bucket_dtype
         self.model, self.dist, self.pg, self.bucket_dtype = model, dist, process_group, bucket_dtype
         self.world = dist.get_world_size(process_group)
+        self.force = bool(force_collectives)
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_stream=None)
+        self._t_last_launch = None
         self._avg_ok = str(dist.get_backend(process_group)).lower() == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
         if broadcast_parameters and self.world > 1:
@@ -67,6 +77,7 @@ class DataParallelEngine:
         self._dirty = False                   # p.grad holds local, not yet reduced micro-step gradients
         self._bw_started = False              # a backward is in progress (first gradient callback seen, finish() not yet called)
         self._stale = False                   # that backward started with gradients already present: exchange p.grad itself afterwards
+        self.last_stats = None                # stats of the last synchronising step (see the module docstring)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -88,7 +99,7 @@ class DataParallelEngine:
 
     # ---- bucket launch -------------------------------------------------------------------------------------------
     def _launch(self, key, params, grads):
-        if self.world == 1 or not params:
+        if (self.world == 1 and not self.force) or not params:
             return
         n = sum(g.numel() for g in grads)
         flat = self._flat_cache.get(key)
@@ -98,6 +109,11 @@ class DataParallelEngine:
         torch.cat([g.reshape(-1).to(self.bucket_dtype) for g in grads], out=flat)
         op = self.dist.ReduceOp.AVG if self._avg_ok else self.dist.ReduceOp.SUM       # gloo has no AVG: sum, divide in finish()
         work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
+        self.stats['buckets'] += 1
+        self.stats['bytes'] += flat.numel() * flat.element_size()
+        if flat.is_cuda:
+            self.stats['launch_stream'] = int(torch.cuda.current_stream(flat.device).cuda_stream)
+        self._t_last_launch = time.perf_counter()
         b = _Bucket()
         b.params, b.flat, b.work = list(params), flat, work
         b.grads = [tuple(g.shape) for g in grads]
@@ -161,7 +177,11 @@ class DataParallelEngine:
                 torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
             for p, v in zip(b.params, views):
                 if p.grad is None:
-                    p.grad = v.clone()
+                    p.grad = v.to(p.dtype, copy=True)                  # a bf16 bucket must not become the .grad of an fp32 parameter
+        if self._inflight and self._t_last_launch is not None:
+            self.last_stats = dict(self.stats, tail_ms=round((time.perf_counter() - self._t_last_launch) * 1e3, 3))
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_stream=None)
+        self._t_last_launch = None
         self._inflight = []
 
     def remove(self):

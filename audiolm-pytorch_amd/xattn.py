@@ -28,8 +28,8 @@ def _transpose_pad(t, Mp):
     """bf16 [B, Me, dh] -> [B, dh, Mp] (zero-filled pad columns): the K-contiguous operand of `P @ V` / `dS @ K`"""
     B, Me, dh = t.shape
     out = torch.empty((B, dh, Mp), dtype=BF16, device=t.device)
-    for b in range(B):
-        _lib.call('alm_transpose_bf16', t[b].data_ptr(), out[b].data_ptr(), Me, dh, t.stride(1), Mp, Mp, ops._st())
+    assert t.stride(2) == 1
+    _lib.call('alm_transpose_bf16_batched', t.data_ptr(), out.data_ptr(), Me, dh, t.stride(1), Mp, Mp, B, t.stride(0), dh * Mp, ops._st())   # one launch for the batch
     return out
 
 

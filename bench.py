@@ -198,7 +198,7 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 per the MI355X guide's gfx950
     correction + WRITE_SIZE) -- read from profiles/, NOT measured in this run (counters cannot be collected inside this process;
     scripts/pmc.sh regenerates them) -- or None when no summary is present."""
-    for name in ('r2_pmc_summary.json', 'r1_pmc_summary.json'):
+    for name in ('r3_pmc_summary.json', 'r2_pmc_summary.json', 'r1_pmc_summary.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 return json.load(fh)['hbm_bytes_per_launch'], name
@@ -216,6 +216,8 @@ def main():
     ap.add_argument('--schedule', default='auto', choices=['auto', 'eager', 'eager2', 'graph', 'graph2'])
     ap.add_argument('--residual', default='bf16', choices=['bf16', 'fp32'],
                     help='HBM storage of the 4 hyper-connection residual streams: bf16 = what trainer.py:1241 autocast gives the reference (default), fp32')
+    ap.add_argument('--bucket-dtype', default='auto', choices=['auto', 'bf16', 'fp32'],
+                    help='wire format of the gradient all-reduce buckets for N > 1 (auto = bf16: a ring over xGMI is per-link bound, 131 instead of 262 MB/step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer-leg', action='store_true')
     args = ap.parse_args()
@@ -247,7 +249,8 @@ def main():
 
     W = build(args.config, dev, rank, torch.bfloat16 if args.residual == 'bf16' else torch.float32)
     model, wrapper, inputs, N = W['model'], W['wrapper'], W['inputs'], W['N']
-    engine = parallel.DataParallelEngine(model, dist) if world > 1 else None
+    bucket_dtype = torch.float32 if args.bucket_dtype == 'fp32' else torch.bfloat16
+    engine = parallel.DataParallelEngine(model, dist, bucket_dtype=bucket_dtype) if world > 1 else None
     cache = model.transformer._cache
 
     def eager_step(opt=None):
@@ -347,6 +350,14 @@ def main():
     dt = timed(args.steps, step)
     ms = dt / args.steps * 1e3
     tokens_per_s = world * W['B'] * N / (dt / args.steps)
+    dp_stats = None
+    if engine is not None:
+        # one line per rank on stderr, so that a driver SCALE run is diagnosable from its tail: what went on the wire and how much of the exchange
+        # did NOT hide under backward (host time from the launch of the last bucket to the return of finish())
+        dp_stats = dict(engine.last_stats or {}, bucket_dtype=str(bucket_dtype).replace('torch.', ''), ms_per_step=round(ms, 3))
+        print(f'[bench rank {rank}/{world}] dp: {dp_stats["buckets"]} buckets, {dp_stats["bytes"] / 1e6:.1f} MB/step on the wire ({dp_stats["bucket_dtype"]}), '
+              f'tail after the last bucket launch {dp_stats["tail_ms"]} ms, step {ms:.3f} ms, launch stream != main: '
+              f'{dp_stats.get("launch_stream") != int(torch.cuda.current_stream(dev).cuda_stream)}', file=sys.stderr, flush=True)
 
     # host time to ISSUE one step (no synchronisation inside): eager launches vs one graph replay
     host = {}
@@ -370,62 +381,135 @@ def main():
     # EVERY rank runs the instrumented step (with N > 1 it contains the gradient all-reduces: a step on rank 0 alone would dead-lock the
     # collectives); only rank 0's numbers are reported.
     roof = None
-    events = []
-    orig_nt, orig_tn = ops.gemm_nt, ops.gemm_tn_splitk
+    events = []                                                  # (start event, end event, algorithmic work, unit, kernel key)
+    timed_names = ('gemm_nt', 'gemm_tn_splitk', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
+                   'layernorm_bwd')
+    originals = {n: getattr(ops, n) for n in timed_names}
 
     def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
         return M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) * nb >= 192
 
-    def timed_nt(Am, Bm, Cm, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_nt(Am, Bm, Cm, **kw)
-        e1.record()
-        nb = 1
-        for d in Am.shape[:-2]:
-            nb *= d
-        Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
-        events.append((e0, e1, 2.0 * nb * Mm * Nn * Kk, 'nt256' if big_tile(Mm, Nn, nb) else 'nt128'))
-        return out
+    def esz(t):
+        return 0 if t is None else t.element_size()
 
-    def timed_tn(At, Bt, Cm, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_tn(At, Bt, Cm, **kw)
-        e1.record()
-        nb = At.shape[0] if At.dim() == 3 else 1
-        events.append((e0, e1, 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2], 'tn'))
-        return out
-    ops.gemm_nt, ops.gemm_tn_splitk = timed_nt, timed_tn
+    def work_of(name, a, kw, out):
+        """(algorithmic work of ONE launch, unit, kernel key): FLOPs for the MFMA kernels, HBM bytes (every operand read once, every result written
+        once: DESIGN.md section 4) for the row kernels"""
+        if name == 'gemm_nt':
+            Am, Bm = a[0], a[1]
+            nb = 1
+            for d in Am.shape[:-2]:
+                nb *= d
+            Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
+            return 2.0 * nb * Mm * Nn * Kk, 'flop', ('nt256' if big_tile(Mm, Nn, nb) else 'nt128')
+        if name == 'gemm_tn_splitk':
+            At, Bt = a[0], a[1]
+            nb = At.shape[0] if At.dim() == 3 else 1
+            fl = 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2]
+            return fl, 'flop', ('tn256' if big_tile(At.shape[-1], Bt.shape[-1], nb) else 'tn128')
+        if name in ('mqa_attn_fwd', 'mqa_attn_bwd'):
+            Bq, Nq, Hq, dh = (a[4], a[5], a[6], a[7] if len(a) > 7 else 64) if name == 'mqa_attn_fwd' else (a[7], a[8], a[9], a[10] if len(a) > 10 else 64)
+            fwd = 4.0 * Hq * dh * Nq * (Nq + 1) / 2 * Bq                            # causal: QK^T + PV over the lower triangle
+            return (fwd, 'flop', 'mqa_fwd') if name == 'mqa_attn_fwd' else (2.5 * fwd, 'flop', 'mqa_bwd')
+        if name == 'hc_fwd':
+            R_in, Bq, Sq, Nq, Dq = a[0], a[1], a[2], a[3], a[4]
+            M_ = Bq * Nq
+            rsz = 2 if kw.get('r_dtype') == torch.bfloat16 else 4
+            by = (4 * Dq if kw.get('rin_bcast') else Sq * Dq * rsz)
+            if kw.get('y_prev') is not None:
+                by += 2 * Dq + (0 if kw.get('final') else Sq * Dq * rsz)
+            if kw.get('hc') is not None:
+                by += 2 * Dq + (2 * Dq if kw.get('want_x', True) else 0) + 4 * 52
+            if kw.get('final'):
+                by += 4 * Dq + (4 * Dq if kw.get('final_f32') else 2 * Dq)
+            return float(by) * M_, 'byte', 'hc_fwd'
+        if name == 'hc_bwd':
+            Bq, Sq, Nq, Dq = a[1], a[2], a[3], a[4]
+            M_ = Bq * Nq
+            rsz = 2 if kw.get('r_dtype') == torch.bfloat16 else 4
+            by = 4 * Dq if kw.get('bcast') else Sq * Dq * rsz
+            if kw.get('hc') is not None:
+                by += (4 * Dq if kw.get('r_bcast') else Sq * Dq * rsz) + 2 * Dq + (2 * Dq if kw.get('extra') is not None else 0)
+                by += 4 * Dq if kw.get('sum_only') else Sq * Dq * rsz
+            if kw.get('y_prev') is not None:
+                by += 2 * Dq + 2 * Dq
+            return float(by) * M_, 'byte', 'hc_bwd'
+        if name == 'geglu_ln_fwd':
+            return 6.0 * a[3] * a[0].shape[0], 'byte', 'geglu_ln_fwd'              # read U (x | gate), write HN
+        if name == 'geglu_ln_bwd':
+            return 10.0 * a[6] * a[1].shape[0], 'byte', 'geglu_ln_bwd'             # read dHN, U; write dU
+        if name == 'layernorm_fwd':
+            x = a[0]
+            return float(x.numel()) * (esz(x) + (4 if kw.get('out_f32') else 2) + (2 if kw.get('want_copy') else 0)), 'byte', 'layernorm_fwd'
+        x = a[1]
+        return float(x.numel()) * (esz(a[0]) + esz(x) + (2 if kw.get('extra') is not None else 0) + (2 if kw.get('dx_dtype') == torch.bfloat16 else 4)), 'byte', 'layernorm_bwd'
+
+    def make_timed(name):
+        fn = originals[name]
+
+        def timed_fn(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            events.append((e0, e1) + work_of(name, a, kw, out))
+            return out
+        return timed_fn
+    for n in timed_names:
+        setattr(ops, n, make_timed(n))
     was_async, core.ASYNC_WGRAD = core.ASYNC_WGRAD, False      # per-kernel durations: no concurrent side-stream GEMMs in this step
     try:
         eager_step()
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
+        for n in timed_names:
+            setattr(ops, n, originals[n])
         core.ASYNC_WGRAD = was_async
     agg = {}
-    for e0, e1, fl, kind in events:
-        a = agg.setdefault(kind, [0.0, 0.0, 0])
+    for e0, e1, wk, unit, key in events:
+        a = agg.setdefault(key, [0.0, 0.0, 0, unit])
         a[0] += e0.elapsed_time(e1)
-        a[1] += fl
+        a[1] += wk
         a[2] += 1
-    tot_ms = sum(a[0] for a in agg.values())
-    tot_fl = sum(a[1] for a in agg.values())
-    d_ms, d_fl, d_n = agg.get('nt256', [0.0, 0.0, 0])
+    gem = {k: v for k, v in agg.items() if v[3] == 'flop' and k[:2] in ('nt', 'tn')}
+    tot_ms = sum(a[0] for a in gem.values())
+    tot_fl = sum(a[1] for a in gem.values())
+    d_ms, d_fl, d_n, _ = agg.get('nt256', [0.0, 0.0, 0, 'flop'])
+    PEAK_HBM_GBS = 8000.0
+    desc = {'nt256': 'gemm_stag_kernel<NT> 256x256 / gemm_kernel<384,256,NT>: forward + dgrad GEMMs on the big tiles (dominant)',
+            'nt128': 'NT GEMMs on the 128x128 tile or grouped launches (attention projections, logit heads)',
+            'tn256': 'gemm_stag_kernel<TN>: weight gradients on the big tile (split-K)', 'tn128': 'weight gradients on the 128x128 tile / grouped (split-K)',
+            'mqa_fwd': 'mqa_fwd_kernel (causal flash attention forward)', 'mqa_bwd': 'attn_delta + mqa_bwd_dq + mqa_bwd_dkv (flash attention backward)',
+            'hc_fwd': 'hc_fwd_kernel (depth + width connection + pre-LayerNorm, fused)', 'hc_bwd': 'hc_bwd_kernel (+ its colsum / param-grad launches)',
+            'geglu_ln_fwd': 'geglu_ln_fwd_kernel', 'geglu_ln_bwd': 'geglu_ln_bwd_kernel (+ colsum)', 'layernorm_fwd': 'ln_fwd_kernel', 'layernorm_bwd': 'ln_bwd_kernel (+ colsum)'}
+    kernels = []
+    for key, (k_ms, k_w, k_n, unit) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        if k_ms <= 0:
+            continue
+        mf = unit == 'flop'
+        ach = k_w / (k_ms * 1e-3) / (1e12 if mf else 1e9)
+        peak = PEAK_BF16_TFLOPS if mf else PEAK_HBM_GBS
+        kernels.append({'kernel': key, 'what': desc.get(key, key), 'bound': 'mfma' if mf else 'hbm', 'launches_per_step': k_n,
+                        'avg_launch_us': round(k_ms * 1e3 / k_n, 2), 'ms_per_step': round(k_ms, 3),
+                        ('flop_per_launch' if mf else 'bytes_per_launch'): round(k_w / k_n, 0), 'achieved': round(ach, 1), 'peak': peak,
+                        'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': round(ach / peak, 4)})
     if d_n:
         ach = d_fl / (d_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
         roof = {'bound': 'mfma', 'kernel': 'gemm_stag_kernel<NT> 256x256x64 + gemm_kernel<384,256,2,4,NT> (8-wave bf16 MFMA 32x32x16 big tiles; FFN / projection forward + dgrad GEMMs)',
                 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
                 'traffic': traffic if args.config == 'coarse2048' else None,
-                'traffic_source': (f'profiles/{traffic_src} (committed rocprofv3 PMC passes of this workload; not re-measured in this run)'
+                'traffic_source': (f'profiles/{traffic_src} (committed rocprofv3 PMC passes of this workload; not re-measured in this run; regenerate on the GPU box: '
+                                   f'`bash scripts/gpu_r3.sh <tag> pmc` = scripts/pmc.sh "FETCH_SIZE" / "WRITE_SIZE" in separate passes, FETCH x 2 per the MI355X guide)'
                                    if traffic is not None and args.config == 'coarse2048' else None),
                 'launches_per_step': d_n, 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
                 'flop_per_launch_avg': round(d_fl / d_n, 0),
-                'measured_in': 'one instrumented eager step, weight-gradient side stream off (kernels do not overlap)',
-                'all_gemm_launches': {'launches_per_step': len(events), 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
-                                      'by_kind_ms': {k: round(v[0], 3) for k, v in agg.items()}},
+                'measured_in': 'one instrumented eager step, weight-gradient side stream off (kernels do not overlap); HIP events on the launch stream bracket each '
+                               'host-level op (its launch gap and, for the row kernels, their small second-stage reductions included)',
+                'all_gemm_launches': {'launches_per_step': sum(v[2] for v in gem.values()), 'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                      'by_kind_ms': {k: round(v[0], 3) for k, v in gem.items()}},
+                'kernels': kernels,
+                'instrumented_ms_per_step': round(sum(v[0] for v in agg.values()), 3),
                 'model_flops_frac': round(tokens_per_s / world * flops_per_token(W['kind'], N, W['ctor'].get('codebook_size', 1024)) / (PEAK_BF16_TFLOPS * 1e12), 4)}
     if dist is not None:
         dist.barrier()
@@ -488,6 +572,9 @@ def main():
             out['config']['schedule_probe'] = probe              # --schedule auto: ms/step of a few eager steps / graph replays; the faster one ran
         if roof:
             out['roofline'] = roof
+            out['model_flops_frac'] = roof['model_flops_frac']     # whole step: algorithmic model FLOPs / s over the dense bf16 MFMA peak
+        if dp_stats:
+            out['config']['dp'] = dp_stats
         if opt_leg:
             out['with_optimizer'] = opt_leg
         if world == 1 and not args.no_cpu_baseline:
@@ -521,6 +608,8 @@ def _supervised(cmd, env=None, retries=1):
 
 
 if __name__ == '__main__':
+    import faulthandler
+    faulthandler.enable()                 # a SIGSEGV / SIGABRT inside a native call prints the Python stack of every thread: WHICH launch died
     # single-process runs are measured in a child process that is re-launched once if it is killed by a signal; under torch.distributed.run
     # (one rank per GPU, rendezvous owned by the launcher) every rank measures in place
     if os.environ.get('ALM_BENCH_CHILD') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('ALM_BENCH_SUPERVISE', '1') == '0':

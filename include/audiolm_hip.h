@@ -49,6 +49,9 @@ int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 /* dst[c][r] = src[r][c]; columns [rows, rows_pad) of dst are zero-filled (K-padding of a transposed GEMM operand). */
 int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, void* stream);
+/* nb matrices (element strides bs_src / bs_dst) in ONE launch: the per-sequence key / value sets of a conditioning context (xattn.py). */
+int alm_transpose_bf16_batched(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, int nb,
+                               long long bs_src, long long bs_dst, void* stream);
 /* fp32 master weight -> zero-padded bf16 copy (dst, may be NULL) and zero-padded bf16 transpose (dstT, may be NULL).
  * This is the autocast weight cast of trainer.py:1241 (accelerator.autocast), done once per optimiser step. */
 int alm_pack_weight(const float* src, int rows, int cols, long long ld_src, void* dst, long long ld_dst, int rows_pad, int cols_pad,

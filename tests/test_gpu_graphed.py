@@ -83,3 +83,18 @@ def test_graphed_step_matches_eager(micro):
     assert abs(float(loss) - l3) <= 1e-6 * abs(l3)
     bad = [(k, _frob(got[k], g3[k])) for k in g3 if _frob(got[k], g3[k]) > 2e-3]
     assert not bad, bad[:6]
+
+
+def test_eager_forward_right_after_capture_uses_real_weight_packs():
+    """ADVICE (round 2): the capture only RECORDS the weight re-pack kernels, yet keys the packs into the WeightCache -- an eager forward between
+    construction and the first replay would read uninitialised bf16 weights.  GraphedTrainStep now replays once before returning."""
+    from audiolm_pytorch_amd.graphed import GraphedTrainStep
+    model, w, inputs = _setup(torch.bfloat16)
+    with torch.no_grad():
+        before = float(w(**inputs, return_loss=True))
+    step = GraphedTrainStep(w, inputs, micro_batches=1)
+    with torch.no_grad():
+        after = float(w(**inputs, return_loss=True))               # hits the cache entries the capture created
+    assert abs(after - before) <= 1e-6 * abs(before), (before, after)
+    assert step.loss is not None and abs(float(step.loss) - before) <= 1e-6 * abs(before)
+    assert all(g is None or bool(torch.isfinite(g).all()) for g in step.grads)

@@ -145,3 +145,49 @@ def test_dp_engine_world2_matches_big_batch(tmp_path):
             assert r['grads'][k] is None
             continue
         assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
+
+
+def _worker_bf16_none_grad(rank, world, port, out):
+    """bf16 buckets + parameters whose .grad is None when finish() runs (the fused stack hands fresh gradient tensors to the callback BEFORE autograd
+    has assigned p.grad): finish() must create fp32 .grad tensors from the bf16 bucket (`p.grad = v.clone()` made them bf16)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(5)
+    model = Model()
+    eng = DataParallelEngine(model, dist, bucket_dtype=torch.bfloat16)
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    _loss(model, ids_all[rank:rank + 1]).backward()
+    flat = model.transformer.flat_params()
+    fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(model.transformer.depth)]
+    for p in flat[:-1]:
+        p.grad = None                                              # as inside the fused backward: the stack's .grad does not exist yet
+    for l in reversed(range(model.transformer.depth)):
+        eng._on_layer_grads(l, fresh[l])
+    eng.finish()
+    st = eng.last_stats
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    dtypes = {k: (str(p.grad.dtype) if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().clone() for k, v in model.state_dict().items()}, grads=grads, dtypes=dtypes, ids=ids_all, stats=st), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_bf16_buckets_with_missing_grads(tmp_path):
+    out = str(tmp_path / 'bf.pt')
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_worker_bf16_none_grad, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    (sum(_loss(model, r['ids'][i:i + 1]) for i in range(2)) / 2).backward()
+    for k, p in model.named_parameters():
+        if k == 'unused':
+            assert r['grads'][k] is None
+            continue
+        assert r['dtypes'][k] == 'torch.float32', (k, r['dtypes'][k])
+        assert torch.allclose(r['grads'][k], p.grad, atol=2e-2 * float(p.grad.abs().max()) + 1e-6), k          # bf16 wire format
+    assert r['stats']['buckets'] >= 3 and r['stats']['bytes'] > 0 and r['stats']['tail_ms'] >= 0.0, r['stats']
