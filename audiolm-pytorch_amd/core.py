@@ -440,6 +440,11 @@ MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weig
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
 
+# Test hook (tests/test_gpu_opwise.py): a list that stack_backward appends one record per branch to -- the gradient tensors flowing between its
+# launches (references, nothing is copied), so that every backward op can be checked on its own against the oracle given the SAME inputs.
+TRACE = None
+
+
 def _vgrad_mode(acc, mixed):
     """alm_kv_grad_pack mode: 0 no value residual, 1 this layer's v was mixed (half of dv goes to layer 0's accumulator), 2 layer 0 (receives it)"""
     return 0 if acc is None else (1 if mixed else 2)
@@ -516,6 +521,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             XNs = sv['XN']
             side.run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
             grads[ip + 1], grads[ip + 2], grads[ip + 3] = dW1, dg3, dW2
+            rec = dict(dY=dY, dHN=dHN, dU=dU, dXN=dXN, dW1=dW1, dg3=dg3, dW2=dW2) if TRACE is not None else None
         elif kind == 'cross':
             (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
             m = ctx.m
@@ -542,6 +548,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             dc, dgc = ops.layernorm_bwd(dCN, ctx.x, sv['cmean'], sv['crstd'], prm['ctx_ln'])      # context_norm backward -> d(context)
             add_ctx(dc)
             grads[ip + 1], grads[ip + 2], grads[ip + 3], grads[ip + 4], grads[ip + 5] = dgc, dnull, dWq, dWkv, dWo
+            rec = dict(dY=dY) if TRACE is not None else None
         else:
             (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
             dAO = _empty((M, H * dh), BF16, dev)
@@ -587,6 +594,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                     ops.gemm_tn_splitk(dKVp, cx, dWkv, accumulate=True)
             side.run(wkv_grad, *[t for t in (dKV, Xs, dWkv, dKVp, cx) if t is not None])
             grads[ip + 1], grads[ip + 2], grads[ip + 3] = dWq, dWkv, dWo
+            rec = dict(dY=dY, dAO=dAO, dQ=dQ, dkv32=dkv32, dKV=dKV, dXN=dXN, extra=extra, dWq=dWq, dWkv=dWkv, dWo=dWo) if TRACE is not None else None
 
         # ---- this branch's pre-LayerNorm backward + width-connection backward + the depth-connection backward of the previous branch: ONE pass
         prev = brs[bi - 1] if bi > 0 else None
@@ -595,12 +603,19 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN, extra=extra, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=prm['ln'], R=sv['R'],
                            coef=sv['coef'], dbeta=dbeta, hc=prm['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=prev is None,
                            r_dtype=rdt)
+            if rec is not None:
+                rec.update(kind=kind, layer=l, dR_in=dR, dR_in_bcast=bcast, dbeta_in=dbeta, dR_out=h['dsum'] if prev is None else h['dR'], sum_only=prev is None,
+                           dY_prev=h['dy'], dbeta_prev=h['dbeta'], hc_grads=dict(h['grads']))
+                TRACE.append(rec)
             dR, dY, dbeta, bcast = (h['dsum'] if prev is None else h['dR']), h['dy'], h['dbeta'], False     # first branch: summed over the streams (:524)
             for j, k in enumerate(HC_KEYS):
                 grads[first + j] = h['grads'][k]
             grads[ip] = h['grads']['ln']
         else:
             dX, dgl = ops.layernorm_bwd(dXN, sv['R'], sv['mean'], sv['rstd'], prm['ln'], extra=extra)
+            if rec is not None:
+                rec.update(kind=kind, layer=l, dR_in=dR, dX=dX, dln=dgl)
+                TRACE.append(rec)
             dR = ops.add_f32(dR, dX)
             grads[ip] = dgl
         sv.clear()

@@ -632,6 +632,283 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     GPROBE_FLUSH((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave);
 }
 
+
+// counted wait on the vector-memory queue: at most N operations (here: LDS-DMA pieces, which retire in order) may still be in flight
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 16, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+// ---- 256 x 256 x 64, FOUR waves (one per SIMD), wave tile 128 x 128 (tile id 14; NT and TN) -----------------------------------------------
+// Why another main loop (round 3): the 8-wave tiles above read (4 + 2) 16-byte fragments per 8 MFMAs -- 48 ds_read_b128 per CU for every 512
+// matrix-pipe cycles = 75 % of the LDS port (128 B / clk / CU), which is why their MFMAs issue every ~45 instead of 32 cycles (slot probe, DESIGN.md
+// section 8.1 (e)) -- and while one wave of a SIMD computes, the other one loads or waits, so nothing fills a wave's own gaps.  A 128 x 128 wave tile
+// reads (4 + 4) fragments per 16 MFMAs: 50 % of the LDS port, and its 256 accumulator registers (AGPRs) leave one wave per SIMD with the whole
+// 512-entry file.  With ONE wave per SIMD every stall is exposed, so the loop is software-pipelined by hand, in the order the vendor's Tensile kernels
+// for this chip use (read off their ISA: MT256x256x64, 4 waves, wave tile 128 x 128, direct-to-LDS, prefetch 2, local-read prefetch 1):
+//     K-step t (stage buffer cur = t & 1), sub-steps S0 .. S3 of 16 MFMAs, fragment register sets F0 .. F3 (F0 was read during step t - 1):
+//       S0 (F0) || read F1 <- cur          S1 (F1) || read F2, F3 <- cur          -> lgkmcnt(0), barrier: cur is consumed by every wave
+//       S2 (F2) || DMA tile t + 2 -> cur, one 1-KiB piece per MFMA (no burst of DMA issues in front of the matrix pipe)
+//       vmcnt(16), barrier: tile t + 1 (issued one step ago) has landed in nxt; the 16 pieces just issued stay in flight
+//       S3 (F3) || read F0 <- nxt (sub-step 0 of tile t + 1)
+// so the operand fetch runs ~1.5 K-steps ahead out of two 64-KB stages, and neither a DMA burst nor a fragment-read latency ever sits between two
+// MFMAs.  The compiler cannot see the DMA -> LDS -> ds_read dependency through `__restrict__` (it must not: it would wait for ALL pending DMA, see
+// gemm_kernel); the two counted waits + barriers above are what orders them.
+template <bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NW = 4, TM = 4, TNB = 4;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;       // 32 KB + 32 KB
+    constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;                                          // 8 + 8 one-KiB DMA pieces per wave and stage
+    static_assert(NIA + NIB == 16, "the counted waits below assume 16 pieces per wave and stage");
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn, zb, zs;
+    if (p.raster == 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const bool m_major = tiles_m >= tiles_n;
+        const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
+        const int P = tmaj * p.nb2;
+        const int PL = (P + 7) / 8;
+        zs = j / (PL * Q);
+        const int rem = j % (PL * Q);
+        const int panel = (rem / Q) * 8 + xcd;
+        const int minor = rem % Q;
+        if (panel >= P || zs >= p.nsl) return;
+        zb = panel / tmaj;
+        const int tmajor = panel % tmaj;
+        tm = m_major ? tmajor : minor;
+        tn = m_major ? minor : tmajor;
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        tm = first_m + (bid % per_group) % gsz;
+        tn = (bid % per_group) / gsz;
+        zb = blockIdx.y;
+        zs = blockIdx.z;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z1 = zb / p.nb2, z2 = zb % p.nb2;
+    int kbeg = 0, Krem = p.K;
+    const long long zoffA = z1 * p.sA1 + z2 * p.sA2, zoffB = z1 * p.sB1 + z2 * p.sB2;
+    if (p.ksplit > 0) {
+        kbeg = zs * p.ksplit;
+        Krem = min(p.K - kbeg, p.ksplit);
+    }
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const bf16_t* Ab;
+    const bf16_t* Bb;
+    long long extA, extB;
+    if (!TNMODE) {
+        Ab = p.A + zoffA + (long long)m0 * p.lda + kbeg;
+        Bb = p.B + zoffB + (long long)n0 * p.ldb + kbeg;
+        extA = ((long long)(min(p.M - m0, BM) - 1) * p.lda + Krem) * 2;
+        extB = ((long long)(min(p.N - n0, BN) - 1) * p.ldb + Krem) * 2;
+    } else {
+        Ab = p.A + zoffA + (long long)kbeg * p.lda + m0;
+        Bb = p.B + zoffB + (long long)kbeg * p.ldb + n0;
+        extA = ((long long)(Krem - 1) * p.lda + ((min(p.M - m0, BM) + 7) & ~7)) * 2;
+        extB = ((long long)(Krem - 1) * p.ldb + ((min(p.N - n0, BN) + 7) & ~7)) * 2;
+    }
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Ab), 0, (int)min(extA, 0x7fffffffLL), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Bb), 0, (int)min(extB, 0x7fffffffLL), 0x00020000);
+
+    unsigned offA[NIA], offB[NIB];
+    int kcA[NIA], kcB[NIB];
+    if (!TNMODE) {
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offA[j] = (unsigned)(row * p.lda * 2 + c * 16);
+            kcA[j] = c * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            offB[j] = (unsigned)(row * p.ldb * 2 + c * 16);
+            kcB[j] = c * 8;
+        }
+    } else {
+        const int st = lane >> 3, kin = (lane >> 1) & 3, half = lane & 1;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const int q = j * NW + wave;
+            const int kg = q / (BM / 128), part = q % (BM / 128);
+            const int k = kg * 4 + kin, i = part * 128 + st * 16 + half * 8;
+            offA[j] = (unsigned)(k * p.lda * 2 + i * 2);
+            kcA[j] = k;
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const int q = j * NW + wave;
+            const int kg = q / (BN / 128), part = q % (BN / 128);
+            const int k = kg * 4 + kin, i = part * 128 + st * 16 + half * 8;
+            offB[j] = (unsigned)(k * p.ldb * 2 + i * 2);
+            kcB[j] = k;
+        }
+    }
+    const unsigned kstepA = TNMODE ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+    const unsigned kstepB = TNMODE ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+
+    auto stage = [&](int kt, unsigned char* base) {
+        const int kleft = Krem - kt * BK;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
+        }
+    };
+
+    unsigned fragA[TM], fragB[TNB];
+    if (!TNMODE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((wr * 128 + i * 32 + lr) * 128);
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) fragB[j] = (unsigned)(A_BYTES + (wc * 128 + j * 32 + lr) * 128);
+    } else {
+        const int g = lane >> 4, s = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fragA[i] = (unsigned)((((g >> 1) * 2) * (BM / 16) + (wr * 128 + i * 32) / 16 + (g & 1)) * 128 + s * 8);
+#pragma unroll
+        for (int j = 0; j < TNB; ++j) fragB[j] = (unsigned)(A_BYTES + (((g >> 1) * 2) * (BN / 16) + (wc * 128 + j * 32) / 16 + (g & 1)) * 128 + s * 8);
+    }
+    const unsigned sw = (unsigned)((lr >> 1) & 7);
+
+    f32x16 acc[TM][TNB];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Frags { bf16x8 a[TM], b[TNB]; };
+    auto load_frags = [&](const unsigned char* sb, int ks, Frags& f) {
+        if (!TNMODE) {
+            const unsigned co = (((unsigned)(ks * 2 + lh)) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(sb + fragA[i] + co);
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(sb + fragB[j] + co);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned char* ad = sb + fragA[i] + ks * 4 * (BM / 16) * 128;
+                f.a[i] = __builtin_shufflevector(lds_tr16(ad), lds_tr16(ad + (BM / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) {
+                const unsigned char* bd = sb + fragB[j] + ks * 4 * (BN / 16) * 128;
+                f.b[j] = __builtin_shufflevector(lds_tr16(bd), lds_tr16(bd + (BN / 16) * 128), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+    auto mfma_all = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j], f.a[i], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NMF = TM * TNB;                                           // 16 MFMAs per sub-step
+    constexpr int NRD = (TNMODE ? 2 : 1) * (TM + TNB);                      // LDS read instructions per fragment set (8 b128 | 16 b64)
+
+    const int nk = (Krem + BK - 1) / BK;
+    Frags F0, F1, F2, F3;
+
+    stage(0, smem);
+    if (nk > 1) { stage(1, smem + STAGE); wait_vmcnt<16>(); } else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(smem, 0, F0);
+
+    // one K-step; `cur` (read, then overwritten by the DMA of tile kt + 2) and `nxt` (read: sub-step 0 of tile kt + 1) are distinct buffers.
+    // MORE2 / MORE1 (tile kt + 2 / kt + 1 exists) are COMPILE-TIME: the steady-state body must be one basic block, or the schedule groups below
+    // (which only order instructions inside a block) cannot interleave the DMA pieces and the fragment reads with the MFMAs.
+    auto kstep = [&](unsigned char* __restrict__ cur, const unsigned char* __restrict__ nxt, int kt, auto m2c, auto m1c) {
+        constexpr bool MORE2 = decltype(m2c)::value, MORE1 = decltype(m1c)::value;
+        // ---- S0, S1: the rest of this tile's fragments come in under the first 32 MFMAs
+        load_frags(cur, 1, F1);
+        mfma_all(F0);
+        load_frags(cur, 2, F2);
+        load_frags(cur, 3, F3);
+        mfma_all(F1);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (2 * NRD + NMF - 1) / NMF, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's reads of `cur` have returned
+            __builtin_amdgcn_s_barrier();                                   // ... and everybody else's: `cur` may be overwritten
+            __builtin_amdgcn_sched_barrier(0);
+            stage(kt + 2, cur);
+        }
+        mfma_all(F2);
+        if (MORE2) {
+#pragma unroll
+            for (int q = 0; q < NMF; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         // one DMA piece behind every MFMA
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE1) {
+            if (MORE2) wait_vmcnt<16>(); else wait_vmcnt<0>();              // tile kt + 1 has landed in `nxt` (this wave's pieces)
+            __builtin_amdgcn_s_barrier();                                   // ... and every other wave's
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(nxt, 0, F0);
+        }
+        mfma_all(F3);
+        if (MORE1) {
+#pragma unroll
+            for (int q = 0; q < NMF; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 2 < nk; ++kt) kstep(smem + (kt & 1) * STAGE, smem + ((kt & 1) ^ 1) * STAGE, kt, T{}, T{});
+    if (kt + 1 < nk) { kstep(smem + (kt & 1) * STAGE, smem + ((kt & 1) ^ 1) * STAGE, kt, F{}, T{}); ++kt; }
+    kstep(smem + (kt & 1) * STAGE, smem + ((kt & 1) ^ 1) * STAGE, kt, F{}, F{});
+    __syncthreads();                                                        // every wave is done with the stage buffers: the epilogue slabs reuse them
+
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    static_assert(NW * 32 * (32 * TNB * ES) <= 2 * STAGE, "epilogue slab");
+    const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
+    gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+}
+
 // ---- split-K second stage: C[b][m][n] (+)= sum_z ws[z][b][m][n]   (blockIdx.y = b)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, long long slice_stride, int N,
                                                             float* __restrict__ C, long long ldc, long long sC, int accumulate) {
@@ -822,13 +1099,35 @@ int launch_stag(const GemmParams& p, int ny, int nz, hipStream_t st) {
     return 0;
 }
 
+
+template <bool TNMODE, bool OUT_F32>
+int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
+    constexpr int smem = 131072;
+    static bool attr_done = false;
+    auto kfn = gemm_w4_kernel<TNMODE, OUT_F32>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    if (p.raster == 1) {
+        const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
+        const int PL = (tmaj * ny + 7) / 8;
+        hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(256), smem, st, p);
+        return 0;
+    }
+    hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n, ny, nz), dim3(256), smem, st, p);
+    return 0;
+}
+
 // Tile ids (alm_gemm_bf16_nt_tile): 1 = 128 x 128 (4 waves, two workgroups per CU), 2 = 256 x 256 lock-step (8 waves), 13 = 256 x 256 with
 // staggered wave rows (the production big tile), 11 = 384 x 256 (8 waves, wave tile 192 x 64: 17 % fewer L2 -> LDS bytes per flop).
 // Automatic choice (tile 0): small problems -> 1; otherwise 13, except that an NT problem takes 11 when the coarser tiling needs so many
 // fewer rounds of 256 resident workgroups that it wins despite its 1.5x longer tile (measured per-tile cost ratio 1.41: W1 forward
 // 16384 x 5472: 6 rounds -> 4, +6 %; with N = 1024 it is 172 tiles on 256 CUs, -15 %).
 int pick_tile(int M, int N, int ny, int tile, bool tn) {
-    if (tile == 1 || tile == 2 || tile == 11 || tile == 13) return tile;
+    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14) return tile;
     if (tile != 0) return -1;
     if (M < 256 || N < 256) return 1;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
@@ -845,7 +1144,8 @@ int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipS
     static const int big_tile = [] { const char* e = getenv("ALM_GEMM_BIG_TILE"); return e ? atoi(e) : 0; }();   // A/B hook: 2 / 11 / 13 for every big launch
     int tl = pick_tile(p.M, p.N, ny * nz, tile, TNMODE);
     if (tl < 0) return ALM_ERR_UNSUPPORTED;
-    if (hook && tl != 1 && (big_tile == 2 || big_tile == 11 || big_tile == 13)) tl = big_tile;
+    if (hook && tl != 1 && (big_tile == 2 || big_tile == 11 || big_tile == 13 || big_tile == 14)) tl = big_tile;
+    if (tl == 14) return out_f32 ? launch_w4<TNMODE, true>(p, ny, nz, st) : launch_w4<TNMODE, false>(p, ny, nz, st);
     if (tl == 13) return out_f32 ? launch_stag<TNMODE, true>(p, ny, nz, st) : launch_stag<TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
@@ -923,6 +1223,9 @@ extern "C" int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, cons
 // strides sA / sB / sC between them).  ws: fp32 workspace of alm_gemm_splitk_ws_floats(M, N, K, nb) floats (unused when that is 0).
 // Deterministic (no atomics): the slices are reduced in a fixed order by a second kernel.
 extern "C" int alm_gemm_splitk_slices(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).slices; }
+
+// block tile the split-K plan picks for this problem: 1 = 128 x 128, otherwise a 256 x 256 tile (bench.py files its per-kernel timings by it)
+extern "C" int alm_gemm_splitk_tile(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).tile; }
 
 // fp32 workspace floats alm_gemm_bf16_{nt,tn}_splitk need for this problem (0: none)
 extern "C" int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb) {

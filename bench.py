@@ -406,7 +406,8 @@ def main():
             At, Bt = a[0], a[1]
             nb = At.shape[0] if At.dim() == 3 else 1
             fl = 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2]
-            return fl, 'flop', ('tn256' if big_tile(At.shape[-1], Bt.shape[-1], nb) else 'tn128')
+            from audiolm_pytorch_amd import _lib as _L
+            return fl, 'flop', ('tn128' if _L.query('alm_gemm_splitk_tile', At.shape[-1], Bt.shape[-1], At.shape[-2], nb) == 1 else 'tn256')
         if name in ('mqa_attn_fwd', 'mqa_attn_bwd'):
             Bq, Nq, Hq, dh = (a[4], a[5], a[6], a[7] if len(a) > 7 else 64) if name == 'mqa_attn_fwd' else (a[7], a[8], a[9], a[10] if len(a) > 10 else 64)
             fwd = 4.0 * Hq * dh * Nq * (Nq + 1) / 2 * Bq                            # causal: QK^T + PV over the lower triangle

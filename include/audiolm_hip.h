@@ -43,6 +43,8 @@ int alm_gemm_bf16_nt_tile(const void* A, const void* B, void* C, const float* bi
  *         (autograd of audiolm_pytorch.py:255-259, :351, :395, :961, :972) with no transposed copies; lda/ldb % 8 == 0. */
 int alm_gemm_splitk_slices(int M, int N, int K, int nb);
 int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb);
+/* block tile of the split-K plan for this problem: 1 = 128 x 128 (4 waves), otherwise a 256 x 256 tile */
+int alm_gemm_splitk_tile(int M, int N, int K, int nb);
 int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,

@@ -64,45 +64,77 @@ rst = _RoundST.apply
 rf = _RoundFwd.apply
 
 
-class _FlashEmul(torch.autograd.Function):
-    """csrc/attention.hip mqa_fwd_kernel / mqa_bwd_dq_kernel / mqa_bwd_dkv_kernel, arithmetic only (reference attend.py:98-146).
-    q (b h n d), k / v (b n d): fp32 tensors holding bf16 values; mask bool (b n) | None.  -> o (b h n d) fp32 (un-rounded O / l)."""
+def _c2(dh):
+    return float(torch.tensor(float(dh) ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))     # the kernel's fp32 constant
 
+
+def flash_fwd_emul(q, k, v, mask):
+    """csrc/attention.hip mqa_fwd_kernel, arithmetic only (reference attend.py:98-146).  q (b h n d), k / v (b n d): fp32 tensors holding bf16 values;
+    mask bool (b n) | None -> (o (b h n d) fp32 = un-rounded O / l, lse (b h n))."""
+    B, H, N, dh = q.shape
+    c2 = _c2(dh)
+    ninf = float('-inf')
+    m = torch.full((B, H, N), ninf)
+    l = torch.zeros((B, H, N))
+    o = torch.zeros((B, H, N, dh))
+    qi = torch.arange(N)
+    for t in range((N + 63) // 64):
+        k0, k1 = t * 64, min(N, t * 64 + 64)
+        qs = k0                                                     # queries before the tile see none of its keys (and their waves skip it)
+        s = torch.einsum('bhid,bjd->bhij', q[:, :, qs:], k[:, k0:k1])
+        dead = (torch.arange(k0, k1)[None, :] > qi[qs:, None])[None, None]
+        if mask is not None:
+            dead = dead | ~mask[:, None, None, k0:k1]
+        s = s.masked_fill(dead, ninf)
+        tm = s.amax(dim=-1) * c2
+        mc, lc, oc = m[:, :, qs:], l[:, :, qs:], o[:, :, qs:]
+        nq = N - qs
+        pad = (-nq) % 32
+        need = F.pad(tm > mc + RESCALE_THR, (0, pad)).reshape(B, H, -1, 32).any(dim=-1, keepdim=True)
+        need = need.expand(-1, -1, -1, 32).reshape(B, H, -1)[:, :, :nq]                                   # __any over the 32-query wave
+        mn = torch.where(need, torch.maximum(mc, tm), mc)
+        alpha = torch.where(mn == ninf, torch.ones_like(mn), torch.exp2(mc - mn))
+        alpha = torch.where(need, alpha, torch.ones_like(alpha))
+        ms = torch.where(mn == ninf, torch.zeros_like(mn), mn)
+        p = torch.exp2((s.double() * c2 - ms.double()[..., None]).float())                                # fma(s, c2, -m) in the kernel
+        m[:, :, qs:] = mn
+        l[:, :, qs:] = lc * alpha + p.sum(dim=-1)
+        o[:, :, qs:] = oc * alpha[..., None] + torch.einsum('bhij,bjd->bhid', _bf(p), v[:, k0:k1])
+    inv = torch.where(l > 0, 1.0 / l, torch.zeros_like(l))
+    lse = torch.where(l > 0, m / LOG2E + torch.log(l), torch.full_like(l, ninf))
+    return o * inv[..., None], lse
+
+
+def flash_bwd_emul(q, k, v, o, lse, do, mask):
+    """attn_delta_kernel + mqa_bwd_dq_kernel + mqa_bwd_dkv_kernel, arithmetic only.  o: the bf16 forward output (as fp32), do: bf16 dO (as fp32)
+    -> (dq (b h n d), dk (b n d), dv (b n d)), fp32, un-rounded"""
+    B, H, N, dh = q.shape
+    scale = float(dh) ** -0.5
+    c2 = _c2(dh)
+    delta = (do * o).sum(dim=-1)                                      # attn_delta_kernel: from the bf16 O and dO
+    dq = torch.empty_like(q)
+    dk = torch.zeros_like(k)
+    dv = torch.zeros_like(v)
+    ii = torch.arange(N)
+    causal = (ii[None, :] > ii[:, None])[None]
+    for b in range(B):
+        s = torch.einsum('hid,jd->hij', q[b], k[b])
+        dead = causal if mask is None else (causal | ~mask[b][None, None, :])
+        lse2 = torch.where(lse[b] == float('-inf'), torch.full_like(lse[b], float('inf')), lse[b]).double() * LOG2E
+        p = torch.exp2((s.double() * c2 - lse2[..., None]).float()).masked_fill(dead, 0.)
+        dp = torch.einsum('hid,jd->hij', do[b], v[b])
+        ds = p * (dp - delta[b][..., None])
+        dv[b] = torch.einsum('hij,hid->jd', _bf(p), do[b])
+        dsr = _bf(ds)
+        dk[b] = scale * torch.einsum('hij,hid->jd', dsr, q[b])
+        dq[b] = scale * torch.einsum('hij,jd->hid', dsr, k[b])
+    return dq, dk, dv
+
+
+class _FlashEmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask):
-        B, H, N, dh = q.shape
-        scale = float(dh) ** -0.5
-        c2 = float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))     # the kernel's fp32 constant
-        ninf = float('-inf')
-        m = torch.full((B, H, N), ninf)
-        l = torch.zeros((B, H, N))
-        o = torch.zeros((B, H, N, dh))
-        qi = torch.arange(N)
-        for t in range((N + 63) // 64):
-            k0, k1 = t * 64, min(N, t * 64 + 64)
-            qs = k0                                                     # queries before the tile see none of its keys (and their waves skip it)
-            s = torch.einsum('bhid,bjd->bhij', q[:, :, qs:], k[:, k0:k1])
-            dead = (torch.arange(k0, k1)[None, :] > qi[qs:, None])[None, None]
-            if mask is not None:
-                dead = dead | ~mask[:, None, None, k0:k1]
-            s = s.masked_fill(dead, ninf)
-            tm = s.amax(dim=-1) * c2
-            mc, lc, oc = m[:, :, qs:], l[:, :, qs:], o[:, :, qs:]
-            nq = N - qs
-            pad = (-nq) % 32
-            need = F.pad(tm > mc + RESCALE_THR, (0, pad)).reshape(B, H, -1, 32).any(dim=-1, keepdim=True)
-            need = need.expand(-1, -1, -1, 32).reshape(B, H, -1)[:, :, :nq]                                   # __any over the 32-query wave
-            mn = torch.where(need, torch.maximum(mc, tm), mc)
-            alpha = torch.where(mn == ninf, torch.ones_like(mn), torch.exp2(mc - mn))
-            alpha = torch.where(need, alpha, torch.ones_like(alpha))
-            ms = torch.where(mn == ninf, torch.zeros_like(mn), mn)
-            p = torch.exp2((s.double() * c2 - ms.double()[..., None]).float())                                # fma(s, c2, -m) in the kernel
-            m[:, :, qs:] = mn
-            l[:, :, qs:] = lc * alpha + p.sum(dim=-1)
-            o[:, :, qs:] = oc * alpha[..., None] + torch.einsum('bhij,bjd->bhid', _bf(p), v[:, k0:k1])
-        inv = torch.where(l > 0, 1.0 / l, torch.zeros_like(l))
-        out = o * inv[..., None]
-        lse = torch.where(l > 0, m / LOG2E + torch.log(l), torch.full_like(l, ninf))
+        out, lse = flash_fwd_emul(q, k, v, mask)
         ctx.save_for_backward(q, k, v, _bf(out), lse)
         ctx.mask = mask
         return out
@@ -110,27 +142,7 @@ class _FlashEmul(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        mask = ctx.mask
-        B, H, N, dh = q.shape
-        scale = float(dh) ** -0.5
-        c2 = float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
-        do = _bf(do)                                                      # dAO is a bf16 GEMM output
-        delta = (do * o).sum(dim=-1)                                      # attn_delta_kernel: from the bf16 O and dO
-        dq = torch.empty_like(q)
-        dk = torch.zeros_like(k)
-        dv = torch.zeros_like(v)
-        ii = torch.arange(N)
-        causal = (ii[None, :] > ii[:, None])[None]
-        for b in range(B):
-            s = torch.einsum('hid,jd->hij', q[b], k[b])
-            dead = causal if mask is None else (causal | ~mask[b][None, None, :])
-            p = torch.exp2((s.double() * c2 - (lse[b].double() * LOG2E)[..., None]).float()).masked_fill(dead, 0.)
-            dp = torch.einsum('hid,jd->hij', do[b], v[b])
-            ds = p * (dp - delta[b][..., None])
-            dv[b] = torch.einsum('hij,hid->jd', _bf(p), do[b])
-            dsr = _bf(ds)
-            dk[b] = scale * torch.einsum('hij,hid->jd', dsr, q[b])
-            dq[b] = scale * torch.einsum('hij,jd->hid', dsr, k[b])
+        dq, dk, dv = flash_bwd_emul(q, k, v, o, lse, _bf(do), ctx.mask)       # dAO is a bf16 GEMM output
         return dq, dk, dv, None
 
 

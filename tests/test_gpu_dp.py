@@ -107,7 +107,7 @@ def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype):
     assert not bad, bad[:8]
 
 
-def _nccl_one_rank(port, out, bucket_dtype):
+def _nccl_one_rank(rank, port, out, bucket_dtype):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import datetime
