@@ -7,12 +7,12 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_longlong, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ALM_LIB_PATH') or os.path.join(_HERE, 'libaudiolm_hip.so')      # ALM_LIB_PATH: A/B runs of an alternative build
 
-_P, _I, _L, _F = c_void_p, c_int, c_longlong, c_float
+_P, _I, _L, _F, _U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 
 # name -> argtypes (all return int).  Kept in sync with include/audiolm_hip.h (tests/test_cabi.py checks both directions).
 SIGNATURES = {
@@ -32,14 +32,16 @@ SIGNATURES = {
     'alm_layernorm_bwd': [_P, _I, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
     'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P, _P],
     'alm_colsum_chunks': [_I],
+    'alm_geglu_fwd': [_P, _P, _L, _I, _P],
+    'alm_geglu_bwd': [_P, _P, _P, _L, _I, _P],
     'alm_geglu_partial_blocks': [_I],
     'alm_geglu_ln_fwd': [_P, _L, _I, _P, _P, _L, _P, _P, _I, _I, _I, _P],
     'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P],
-    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _P],
-    'alm_mqa_attn_bias_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P],
+    'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P],
+    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P],
+    'alm_mqa_attn_bias_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _F, _U, _P],
     'alm_mqa_attn_bias_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F,
-                              _P, _I, _P, _P, _P, _P, _P, _P],
+                              _P, _I, _P, _P, _P, _P, _P, _F, _U, _P],
     'alm_attn_bias_part_rows': [_I, _I, _I],
     'alm_attn_bias_grad_reduce': [_P, _P, _I, _I, _I, _I, _F, _P],
     'alm_posmlp_in_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],

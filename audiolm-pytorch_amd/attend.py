@@ -4,7 +4,9 @@ forward(q (b h n d), k (b n d), v (b n d), mask (b n) bool | None, attn_bias) ->
 d == 64.  The math path's attn_bias (attend.py:118-121) in its STRUCTURED form (relpos.AttnBias: per-head table + index vectors, what
 RelativePositionBias / the Coarse and Fine transformers build) runs on the flash kernels: no (b, h, n, n) tensor is ever materialised.
 An arbitrary DENSE attn_bias tensor ((h, i, j) or broadcastable to it), and non-causal attention, take the reference's math path as three MFMA
-GEMMs + the row-softmax kernels of csrc/xattn.hip (AttendMathFn: O(n^2) memory, like the reference).  Dropout must be 0.  No CPU fallback.
+GEMMs + the row-softmax kernels of csrc/xattn.hip (AttendMathFn: O(n^2) memory, like the reference).  dropout > 0 (training mode, attend.py:92 / :140):
+the flash kernels decide keep / drop per (batch, head, query, key) with a stateless hash of a per-call seed (the same decision in forward, dQ and
+dK/dV); the math path multiplies its probabilities with a drawn 0 / 1 mask.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -16,14 +18,15 @@ from . import ops, relpos, xattn
 
 class AttendFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask_u8, bias, tbl):
+    def forward(ctx, q, k, v, mask_u8, bias, tbl, dropout_p=0., seed=0):
         # bias: relpos.AttnBias | None; tbl = bias.tbl passed separately so that autograd routes the table gradient
         b, h, n, d = q.shape
         q2 = q.detach().permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
         k2 = k.detach().reshape(b * n, d).to(torch.bfloat16).contiguous()
         v2 = v.detach().reshape(b * n, d).to(torch.bfloat16).contiguous()
         bias = bias.detached() if bias is not None else None
-        o, lse = ops.mqa_attn_fwd(q2, k2, v2, mask_u8, b, n, h, d, bias=bias)
+        o, lse = ops.mqa_attn_fwd(q2, k2, v2, mask_u8, b, n, h, d, bias=bias, dropout_p=dropout_p, seed=seed)
+        ctx.drop = (float(dropout_p), int(seed))
         ctx.save_for_backward(q2, k2, v2, o, lse)
         ctx.mask, ctx.shape, ctx.dtypes, ctx.bias = mask_u8, (b, h, n, d), (q.dtype, k.dtype, v.dtype), bias
         return o.view(b, n, h, d).permute(0, 2, 1, 3).to(q.dtype)
@@ -34,13 +37,13 @@ class AttendFn(torch.autograd.Function):
         b, h, n, d = ctx.shape
         do = dout.permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
         part = ops.attn_bias_part(b, n, h, ctx.bias.tbl.shape[1], do.device) if ctx.bias is not None else None
-        dq, dkv = ops.mqa_attn_bwd(q2, k2, v2, ctx.mask, o, lse, do, b, n, h, d, bias=ctx.bias, dtbl_part=part)
+        dq, dkv = ops.mqa_attn_bwd(q2, k2, v2, ctx.mask, o, lse, do, b, n, h, d, bias=ctx.bias, dtbl_part=part, dropout_p=ctx.drop[0], seed=ctx.drop[1])
         dtbl = ops.attn_bias_grad_reduce(part, b, n, h, d) if ctx.bias is not None else None
         dkv = dkv.sum(0)                                   # per-head-group partials (summed by alm_kv_grad_pack on the fused path)
         dq = dq.view(b, n, h, d).permute(0, 2, 1, 3).to(ctx.dtypes[0])
         dk = dkv[:, :d].reshape(b, n, d).to(ctx.dtypes[1])
         dv = dkv[:, d:].reshape(b, n, d).to(ctx.dtypes[2])
-        return dq, dk, dv, None, None, dtbl
+        return dq, dk, dv, None, None, dtbl, None, None
 
 
 class AttendMathFn(torch.autograd.Function):
@@ -48,14 +51,14 @@ class AttendMathFn(torch.autograd.Function):
     (k / v (b j d) shared by the heads).  q (b h i d), dense bias fp32 (h, i, j) | None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask_u8, bias, causal):
+    def forward(ctx, q, k, v, mask_u8, bias, causal, dropout_p=0.):
         b, h, n, d = q.shape
         m = k.shape[1]
         q2 = q.detach().permute(0, 2, 1, 3).reshape(b * n, h * d).to(torch.bfloat16).contiguous()
         k2 = k.detach().to(torch.bfloat16).contiguous()
         v2 = v.detach().to(torch.bfloat16).contiguous()
         bd = None if bias is None else bias.detach().to(torch.float32).expand(h, n, m).contiguous()
-        o, lse, saved = xattn.extra_attn_fwd(q2, k2, v2, mask_u8, b, n, h, d, float(d) ** -0.5, bias=bd, causal=causal)
+        o, lse, saved = xattn.extra_attn_fwd(q2, k2, v2, mask_u8, b, n, h, d, float(d) ** -0.5, bias=bd, causal=causal, dropout_p=float(dropout_p))
         ctx.save_for_backward(q2, o)
         ctx.saved, ctx.shape, ctx.dtypes, ctx.m = saved, (b, h, n, d), (q.dtype, k.dtype, v.dtype), m
         ctx.bias_meta = None if bias is None else (bias.shape, bias.dtype, bias.requires_grad)
@@ -75,7 +78,7 @@ class AttendMathFn(torch.autograd.Function):
             shape, dtype, _ = ctx.bias_meta
             dbias = dbias.sum_to_size(shape) if tuple(shape) != (h, n, ctx.m) else dbias
             dbias = dbias.to(dtype)
-        return dq.view(b, n, h, d).permute(0, 2, 1, 3).to(ctx.dtypes[0]), dke.to(ctx.dtypes[1]), dve.to(ctx.dtypes[2]), None, dbias, None
+        return dq.view(b, n, h, d).permute(0, 2, 1, 3).to(ctx.dtypes[0]), dke.to(ctx.dtypes[1]), dve.to(ctx.dtypes[2]), None, dbias, None, None
 
 
 class Attend(nn.Module):
@@ -88,8 +91,7 @@ class Attend(nn.Module):
         self.flash = flash
 
     def forward(self, q, k, v, mask=None, attn_bias=None):
-        if self.dropout != 0. and self.training:
-            raise NotImplementedError('attention dropout > 0 is not implemented (reference default 0.)')
+        pd = float(self.dropout) if self.training else 0.
         if not q.is_cuda:
             raise RuntimeError('audiolm_pytorch_amd.Attend runs on the MI355X only (no CPU fallback)')
         mask_u8 = None if mask is None else mask.to(torch.bool).contiguous().view(torch.uint8)
@@ -101,5 +103,6 @@ class Attend(nn.Module):
                 while attn_bias.dim() > 3:                          # (1, h, i, j)
                     assert attn_bias.shape[0] == 1, 'one (h, i, j) bias for every sample (attend.py:118-121)'
                     attn_bias = attn_bias[0]
-            return AttendMathFn.apply(q, k, v, mask_u8, attn_bias if dense else None, self.causal)
-        return AttendFn.apply(q, k, v, mask_u8, attn_bias, attn_bias.tbl if attn_bias is not None else None)
+            return AttendMathFn.apply(q, k, v, mask_u8, attn_bias if dense else None, self.causal, pd)
+        from . import core
+        return AttendFn.apply(q, k, v, mask_u8, attn_bias, attn_bias.tbl if attn_bias is not None else None, pd, core._attn_seed() if pd > 0. else 0)

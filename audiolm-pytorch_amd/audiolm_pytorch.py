@@ -20,7 +20,8 @@ Conditioning (`has_condition=True`, reference :325-375, :450-455, :640-668, :818
 The reference's stacked kv_cache= / embed_cache= TENSOR protocol is accepted on forward() / forward_with_cond_scale()
 (Transformer.forward_kv_protocol: the one-new-token step runs the same single-position kernels); generate() drives the native cache directly.
 An arbitrary dense `attn_bias` tensor takes the reference's O(n^2) math path (relpos.DenseBias, xattn.py) instead of the flash kernels.
-Not accepted (NotImplementedError, nothing falls back silently): attn_dropout > 0 (ff_dropout > 0 is supported).
+attn_dropout > 0 and ff_dropout > 0 are supported (training mode; in-kernel keep decisions for the flash attention, drawn 0 / 1 masks elsewhere).
+Attention / FeedForward / GEGLU also run STANDALONE (outside Transformer) on the same kernels, un-fused.
 Waveform reconstruction (SoundStream decoder) is native: soundstream.py.
 There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refused.
 """
@@ -267,14 +268,79 @@ class RelativePositionBias(nn.Module):                        # audiolm_pytorch.
         return relpos.AttnBias(tbl, *relpos.toeplitz_index(j, dev, num_leading))
 
 
-class GEGLU(nn.Module):                                       # audiolm_pytorch.py:246-249 (fused into alm_geglu_ln_*)
+class GEGLUFn(torch.autograd.Function):
+    """x, gate = chunk(2, dim=-1); gelu(gate) * x  (audiolm_pytorch.py:246-249), fp32 in / out, exact-erf GELU: csrc/norm_act.hip alm_geglu_fwd / bwd"""
+
+    @staticmethod
+    def forward(ctx, x):
+        shape = x.shape
+        x2 = x.detach().reshape(-1, shape[-1]).float().contiguous()
+        ctx.save_for_backward(x2)
+        ctx.shape, ctx.dtype = shape, x.dtype
+        return ops.geglu_fwd(x2).view(*shape[:-1], shape[-1] // 2).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).float().contiguous()
+        return ops.geglu_bwd(dy2, x2).view(ctx.shape).to(ctx.dtype)
+
+
+class GEGLU(nn.Module):                                       # audiolm_pytorch.py:246-249 (inside Transformer it is fused into alm_geglu_ln_*)
     def forward(self, x):
-        raise NotImplementedError('GEGLU runs fused inside the transformer stack (alm_geglu_ln_fwd)')
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only (no CPU fallback)')
+        return GEGLUFn.apply(x)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """FeedForward.forward OUTSIDE the fused stack (audiolm_pytorch.py:251-260): LayerNorm -> W1 -> GEGLU + LayerNorm -> Dropout -> W2 on the same
+    kernels and launch sequence the stack uses (core._run_ff / core.ff_backward), fp32 in / out."""
+
+    @staticmethod
+    def forward(ctx, x, seq, p_drop, g0, w1, g3, w2):
+        shape = x.shape
+        D = shape[-1]
+        x2 = x.detach().reshape(-1, D).float().contiguous()
+        I = w2.shape[1]
+        cfg = core.StackCfg(dim=D, depth=1, heads=1, dim_head=64, streams=1, inner=I, add_value_residual=False, grad_shrink_alpha=1.)
+        Ip = cfg.inner_pad
+        W = dict(w1=seq._cache.get('w1', w1, lambda w: core._pack_w1(w, I, Ip)), w2=seq._cache.get('w2', w2, lambda w: core._pack_w2(w, I, Ip)))
+        XN, _, mean, rstd = ops.layernorm_fwd(x2, g0.detach())
+        prm = dict(ln3=g3.detach())
+        Y, sv = core._run_ff(cfg, W, prm, XN, x2.shape[0], float(p_drop))
+        ctx.cfg, ctx.W, ctx.prm, ctx.sv = cfg, W, prm, dict(sv, XN=XN)
+        ctx.save_for_backward(x2, mean, rstd, g0)
+        ctx.shape, ctx.dtype = shape, x.dtype
+        return Y.float().view(shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, g0 = ctx.saved_tensors
+        dY = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        dXN, dW1, dg3, dW2 = core.ff_backward(ctx.cfg, ctx.W, ctx.prm, ctx.sv, dY, None)
+        dx, dg0 = ops.layernorm_bwd(dXN, x2, mean, rstd, g0.detach())
+        return dx.view(ctx.shape).to(ctx.dtype), None, None, dg0, dW1, dg3, dW2
+
+
+class FeedForwardSeq(nn.Sequential):
+    """the reference's nn.Sequential(LayerNorm, Linear, GEGLU, LayerNorm, Dropout, Linear) -- same children, same state_dict keys -- whose forward
+    runs the fused kernels instead of walking the children through ATen"""
+
+    def __init__(self, *mods):
+        super().__init__(*mods)
+        self._cache = core.WeightCache()
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only (no CPU fallback)')
+        p = self[4].p if self.training else 0.
+        return FeedForwardFn.apply(x, self, p, self[0].gamma, self[1].weight, self[3].gamma, self[5].weight)
 
 
 def FeedForward(dim, mult=4, dropout=0.1):                    # audiolm_pytorch.py:251-260
     inner_dim = int(dim * 2 * mult / 3)
-    return nn.Sequential(
+    return FeedForwardSeq(
         LayerNorm(dim),
         nn.Linear(dim, inner_dim * 2, bias=False),
         GEGLU(),
@@ -284,7 +350,27 @@ def FeedForward(dim, mult=4, dropout=0.1):                    # audiolm_pytorch.
     )
 
 
-class Attention(nn.Module):                                   # audiolm_pytorch.py:264-305 (parameters; compute fused in the stack)
+class _MaskMulFn(torch.autograd.Function):
+    """y = x * keep / (1 - p): nn.Dropout with the mask drawn by core._dropout_keep (so that tests can pin it)"""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        keep = core._dropout_keep(x.shape, p, x.device).to(x.dtype)
+        ctx.save_for_backward(keep)
+        ctx.s = 1. / (1. - p)
+        return x * keep * ctx.s
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep, = ctx.saved_tensors
+        return dy * keep * ctx.s, None
+
+
+class Attention(nn.Module):                                   # audiolm_pytorch.py:264-406
+    """Parameter container of the fused stack (Transformer reads to_q / to_kv / to_out / norm from here) AND a working module of its own: forward()
+    below is the reference's Attention.forward (:307-406) composed, un-fused, from the same kernels -- LayerNorm (alm_layernorm_*), the bias-free
+    projections (bf16 MFMA GEMMs, LinearNoBiasFn), Attend (flash-MQA kernels / the math path of csrc/xattn.hip) -- with torch only gluing views."""
+
     def __init__(self, dim, causal=False, dim_head=64, dim_context=None, heads=8, norm_context=False, num_null_kv=0,
                  dropout=0.1, scale=8, flash=False):
         super().__init__()
@@ -302,10 +388,56 @@ class Attention(nn.Module):                                   # audiolm_pytorch.
         self.to_kv = nn.Linear(dim_context, dim_head * 2, bias=False)
         self.attend = Attend(flash=flash, dropout=dropout, causal=causal)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim, bias=False), nn.Dropout(dropout))
+        self._cache = core.WeightCache()
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('Attention runs fused inside Transformer.forward (core.TransformerStackFn); '
-                                  'standalone use / kv-cache / cross-attention are out of scope this round')
+    def forward(self, x, context=None, mask=None, attn_bias=None, prefix_context=None, prefix_context_mask=None, return_kv_cache=False,
+                return_values=False, value_residual=None, kv_cache=None):
+        if not x.is_cuda:
+            raise RuntimeError('audiolm_pytorch_amd runs on the MI355X only (no CPU fallback)')
+        b, n, _ = x.shape
+        device = x.device
+        if exists(context):
+            context = self.context_norm(context)                                                   # :322-323
+        kv_input = default(context, x)                                                             # :325 (bound BEFORE the pre-norm)
+        if exists(prefix_context):                                                                 # :330-345
+            kv_input = torch.cat((prefix_context, kv_input), dim=-2)
+            m = prefix_context.shape[-2]
+            if not exists(mask):
+                mask = torch.ones((b, n), device=device, dtype=torch.bool)
+            mask = torch.cat((prefix_context_mask, mask), dim=-1) if exists(prefix_context_mask) else F.pad(mask, (m, 0), value=True)
+            if exists(attn_bias):
+                attn_bias = F.pad(attn_bias, (m, 0), value=0.)
+        xn = self.norm(x)                                                                          # :347
+        q = LinearNoBiasFn.apply(xn, self.to_q.weight, self._cache, 'to_q')                        # :351
+        k, v = LinearNoBiasFn.apply(kv_input, self.to_kv.weight, self._cache, 'to_kv').chunk(2, dim=-1)
+        orig_v = v
+        if exists(value_residual):                                                                 # :357-358
+            v = 0.5 * (v + value_residual)
+        if exists(kv_cache):                                                                       # :362-366
+            ck, cv = kv_cache
+            k, v = torch.cat((ck, k), dim=-2), torch.cat((cv, v), dim=-2)
+        if return_kv_cache:
+            kv_cache = torch.stack((k, v))                                                         # :370
+        if self.num_null_kv > 0:                                                                   # :372-376
+            nk, nv = self.null_kv[0], self.null_kv[1]
+            k = torch.cat((nk.expand(b, -1, -1).to(k.dtype), k), dim=-2)
+            v = torch.cat((nv.expand(b, -1, -1).to(v.dtype), v), dim=-2)
+        q = q.reshape(b, n, self.heads, -1).transpose(1, 2)                                        # 'b n (h d) -> b h n d'
+        if exists(mask):
+            mask = F.pad(mask, (self.num_null_kv, 0), value=True)                                  # :384-385
+        out = self.attend(q, k, v, attn_bias=attn_bias, mask=mask)                                 # :389
+        out = out.transpose(1, 2).reshape(b, n, -1)                                                # 'b h n d -> b n (h d)'
+        out = LinearNoBiasFn.apply(out, self.to_out[0].weight, self._cache, 'to_out')
+        pd = self.to_out[1].p
+        if self.training and pd > 0.:
+            out = _MaskMulFn.apply(out, pd)                                                        # the nn.Dropout behind to_out (:304)
+        if not return_kv_cache and not return_values:
+            return out
+        if return_kv_cache and not return_values:
+            return out, kv_cache
+        if return_values and not return_kv_cache:
+            return out, orig_v
+        return out, (kv_cache, orig_v)
 
 
 class RMSNorm(nn.Module):                                     # hyper-connections stream norm (gamma init 0)
@@ -360,11 +492,9 @@ class Transformer(nn.Module):
         super().__init__()
         rel_pos_bias = rel_pos_bias and not flash_attn
         assert not (cross_attend and cond_as_self_attn_prefix)
-        if attn_dropout != 0.:
-            raise NotImplementedError('attn_dropout > 0 (dropout of the attention probabilities and of the attention output) is not implemented in '
-                                      'the fused stack (reference default is 0.); ff_dropout > 0 is')
-        assert 0. <= ff_dropout < 1.
+        assert 0. <= ff_dropout < 1. and 0. <= attn_dropout < 1.
         self.ff_dropout = float(ff_dropout)
+        self.attn_dropout = float(attn_dropout)          # Attention(dropout=): attention probabilities (attend.py:92 / :140) + the Dropout behind to_out (:304)
         self.dim = dim
         self.depth = depth
         self.heads = heads
@@ -444,7 +574,7 @@ class Transformer(nn.Module):
         if exists(self_attn_mask):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
         opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches, context_mask=context_mask,
-                    ff_dropout=self.ff_dropout if self.training else 0.)
+                    ff_dropout=self.ff_dropout if self.training else 0., attn_dropout=self.attn_dropout if self.training else 0.)
         hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
                                            attn_bias.tbl if exists(attn_bias) else None, context, *self.flat_params())
         if return_flat_hidden:

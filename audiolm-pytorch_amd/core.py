@@ -205,8 +205,17 @@ class Context:
         self.x, self.mask, self.B, self.m = x, mask_u8, B, m
 
 
-def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx):
-    """self-attention branch (audiolm_pytorch.py:307-406): -> (Y bf16 [M, D], saved dict)."""
+def _attn_seed():
+    """64-bit seed of one forward's attention-dropout streams, drawn from torch's CPU generator (torch.manual_seed reproduces it; no device sync).
+    A module-level function on purpose: the GPU parity test pins it and restates the keep masks for the oracle."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, drop=(0., 0)):
+    """self-attention branch (audiolm_pytorch.py:307-406): -> (Y bf16 [M, D], saved dict).  drop = (p, seed): Attention(dropout=p) in training mode --
+    dropout on the attention probabilities (attend.py:92 / :140; in-kernel for the flash part, a drawn 0 / 1 mask for a prefix / dense-bias part) and
+    the nn.Dropout(p) behind to_out (:304): a 0 / 1 mask on the bf16 output with the 1 / (1 - p) factor on the fp32 alpha of the GEMMs."""
+    pd, seed = drop
     M, D, H, dh, dev = B * N, cfg.dim, cfg.heads, cfg.dim_head, X.device
     (Wq, _), (Wkv, _), (Wo, _) = W['wq'], W['wkv'], W['wo']
     Q = _empty((M, H * dh), BF16, dev)
@@ -244,22 +253,27 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
     elif dense:
         # an arbitrary dense attn_bias (reference math path, attend.py:98-146): GEMM scores + bias + causal / key mask + softmax + GEMM values
         AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, K.reshape(B, N, dh), V.reshape(B, N, dh), mask_u8, B, N, H, dh, float(dh) ** -0.5,
-                                                    bias=bias.tbl, causal=True)
+                                                    bias=bias.tbl, causal=True, dropout_p=pd)
     else:
-        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias)
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed)
         if pre is not None:
-            AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE)
+            AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE, dropout_p=pd)
             pre['xs'] = xs
         if kv_out is not None:
             kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
             kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
     Y = _empty((M, D), BF16, dev)
-    ops.gemm_nt(AO, Wo, Y)
-    sv.update(AO=AO, LSE=LSE, pre=pre)
+    okeep, oalpha = None, 1.0
+    if pd > 0.:
+        okeep, oalpha = _dropout_keep((M, D), pd, dev), 1. / (1. - pd)
+    ops.gemm_nt(AO, Wo, Y, alpha=oalpha)
+    if okeep is not None:
+        Y = Y * okeep
+    sv.update(AO=AO, LSE=LSE, pre=pre, drop=(pd, seed), okeep=okeep, oalpha=oalpha)
     return Y, sv
 
 
-def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
+def _run_cross(cfg, W, prm, XN, B, N, st, ctx, pd=0.):
     """cross-attention branch (Attention(dim_context, num_null_kv=1, norm_context=True, causal=False), :450; forward :307-406 with `context`):
     q from the pre-LayerNorm'd stream, k / v from context_norm(context), value residual across the cross-attention layers (:541-544), one
     learned null key / value in front (:372-376) which the context mask never hides (:384-385)."""
@@ -282,10 +296,15 @@ def _run_cross(cfg, W, prm, XN, B, N, st, ctx):
     emask = None
     if ctx.mask is not None:
         emask = torch.cat((torch.ones((B, 1), dtype=torch.uint8, device=dev), ctx.mask), dim=1).contiguous()
-    AO, LSE, xs = xattn.extra_attn_fwd(Q, ke, ve, emask, B, N, H, dh, float(dh) ** -0.5)
+    AO, LSE, xs = xattn.extra_attn_fwd(Q, ke, ve, emask, B, N, H, dh, float(dh) ** -0.5, dropout_p=pd)
     Y = _empty((M, D), BF16, dev)
-    ops.gemm_nt(AO, Wo, Y)
-    return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=cmixed, AO=AO, xs=xs)
+    okeep, oalpha = None, 1.0
+    if pd > 0.:
+        okeep, oalpha = _dropout_keep((M, D), pd, dev), 1. / (1. - pd)
+    ops.gemm_nt(AO, Wo, Y, alpha=oalpha)
+    if okeep is not None:
+        Y = Y * okeep
+    return Y, dict(Q=Q, CN=CN, cmean=cmean, crstd=crstd, KVc=KVc, cmixed=cmixed, AO=AO, xs=xs, okeep=okeep, oalpha=oalpha)
 
 
 def _dropout_keep(shape, p, device):
@@ -313,7 +332,8 @@ def _run_ff(cfg, W, prm, XN, M, p_drop=0.):
     return Y, dict(U=U, HN=HN, mean3=mean3, rstd3=rstd3, keep=keep, alpha=alpha)
 
 
-def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None, ff_dropout=0.):
+def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None, ff_dropout=0.,
+                  attn_dropout=0.):
     """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
     audiolm_pytorch.py:500-506 / :532) or None.  ctx: Context (cross-attention layers / self-attention prefix) or None.  Sampling: `kv_out`
     (DecodeCache) is filled with every layer's k / v of this (prefix) forward; `decode` (DecodeCache) means x holds ONE new position per
@@ -334,6 +354,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     rb = S > 1
     rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
     st = dict(kv0=None, kvp0=None, kvc0=None)
+    drop_seed = _attn_seed() if attn_dropout > 0. else 0           # one draw per forward; layer l's self-attention uses stream drop_seed + l
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
         branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
@@ -350,9 +371,9 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
                 XN, X, mean, rstd = ops.layernorm_fwd(R, prm['ln'], want_copy=want_x)
                 coef, r_bcast = None, False
             if kind == 'attn':
-                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx)
+                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, (float(attn_dropout), drop_seed + l))
             elif kind == 'cross':
-                Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx)
+                Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx, float(attn_dropout))
             else:
                 Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M, ff_dropout)
             if need_grad:
@@ -450,6 +471,30 @@ def _vgrad_mode(acc, mixed):
     return 0 if acc is None else (1 if mixed else 2)
 
 
+def ff_backward(cfg, W, prm, sv, dY, side, want_trace=False):
+    """backward of the feed-forward branch (the launches of _run_ff in reverse): dY bf16 [M, D] -> (dXN bf16 [M, D], dW1 fp32 [2 I, D], d gamma3 [I],
+    dW2 fp32 [D, I]).  The two weight gradients go to `side` (a _SideStream) when one is given."""
+    M, D = dY.shape
+    I, Ip, dev = cfg.inner, cfg.inner_pad, dY.device
+    (_, W1T), (_, W2T) = W['w1'], W['w2']
+    run = side.run if side is not None else (lambda fn, *t: fn())
+    dHN = _empty((M, Ip), BF16, dev)
+    fa = sv['alpha']                                                      # 1 / (1 - ff_dropout) (1.0 without dropout)
+    ops.gemm_nt(dY, W2T, dHN, alpha=fa)                                   # dHN = dY @ W2
+    if sv['keep'] is not None:
+        dHN.mul_(sv['keep'])                                              # through the dropout mask (HN below is the masked HN)
+    dW2 = _empty((D, I), F32, dev)
+    HNs, dYs = sv['HN'], dY
+    run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2, alpha=fa), dYs, HNs, dW2)      # dW2 = dY^T @ HN
+    dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
+    dXN = _empty((M, D), BF16, dev)
+    ops.gemm_nt(dU, W1T, dXN)                                             # dXN = dU @ W1
+    dW1 = _empty((2 * I, D), F32, dev)
+    XNs = sv['XN']
+    run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
+    return (dXN, dW1, dg3, dW2, dHN, dU) if want_trace else (dXN, dW1, dg3, dW2)
+
+
 def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None, async_wgrad=True):
     """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None,
     d(loss)/d(context) fp32 [B*m, Dc] | None)."""
@@ -505,31 +550,19 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         extra = None
         W = LW[kind]
         if kind == 'ff':
-            (_, W1T), (_, W2T) = W['w1'], W['w2']
-            dHN = _empty((M, Ip), BF16, dev)
-            fa = sv['alpha']                                                      # 1 / (1 - ff_dropout) (1.0 without dropout)
-            ops.gemm_nt(dY, W2T, dHN, alpha=fa)                                   # dHN = dY @ W2
-            if sv['keep'] is not None:
-                dHN.mul_(sv['keep'])                                              # through the dropout mask (HN below is the masked HN)
-            dW2 = _empty((D, I), F32, dev)
-            HNs, dYs = sv['HN'], dY
-            side.run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2, alpha=fa), dYs, HNs, dW2)      # dW2 = dY^T @ HN
-            dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
-            dXN = _empty((M, D), BF16, dev)
-            ops.gemm_nt(dU, W1T, dXN)                                             # dXN = dU @ W1
-            dW1 = _empty((2 * I, D), F32, dev)
-            XNs = sv['XN']
-            side.run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
+            dXN, dW1, dg3, dW2, dHN, dU = ff_backward(cfg, W, prm, sv, dY, side, want_trace=True)
             grads[ip + 1], grads[ip + 2], grads[ip + 3] = dW1, dg3, dW2
             rec = dict(dY=dY, dHN=dHN, dU=dU, dXN=dXN, dW1=dW1, dg3=dg3, dW2=dW2) if TRACE is not None else None
         elif kind == 'cross':
             (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
             m = ctx.m
             dAO = _empty((M, H * dh), BF16, dev)
-            ops.gemm_nt(dY, WoT, dAO)
+            oa = sv['oalpha']
+            dYs = dY if sv['okeep'] is None else dY * sv['okeep']                  # through the to_out dropout mask (:304)
+            ops.gemm_nt(dYs, WoT, dAO, alpha=oa)
             dWo = _empty((D, H * dh), F32, dev)
-            AOs, dYs = sv['AO'], dY
-            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo), dYs, AOs, dWo)
+            AOs = sv['AO']
+            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo, alpha=oa), dYs, AOs, dWo)
             nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
             dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, sv['xs'], nd, B, N, H, dh, scale)
             dnull = torch.stack((dke[:, 0].sum(0), dve[:, 0].sum(0))).reshape(2, 1, dh)           # null_kv is shared by the batch (:373)
@@ -552,10 +585,13 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         else:
             (_, WqT), (_, WkvT), (_, WoT) = W['wq'], W['wkv'], W['wo']
             dAO = _empty((M, H * dh), BF16, dev)
-            ops.gemm_nt(dY, WoT, dAO)
+            oa = sv['oalpha']
+            dYs = dY if sv['okeep'] is None else dY * sv['okeep']                  # through the to_out dropout mask (:304)
+            ops.gemm_nt(dYs, WoT, dAO, alpha=oa)
             dWo = _empty((D, H * dh), F32, dev)
-            AOs, dYs = sv['AO'], dY
-            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo), dYs, AOs, dWo)
+            AOs = sv['AO']
+            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo, alpha=oa), dYs, AOs, dWo)
+            pd, dseed = sv['drop']
             KV = sv['KV']
             # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
             if dense:
@@ -565,7 +601,8 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 ddense += dbl
                 dkv32 = torch.cat((dke.reshape(M, dh), dve.reshape(M, dh)), dim=1).contiguous()
             else:
-                dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part)
+                dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part,
+                                             dropout_p=pd, seed=dseed)
             dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh)
             dKVp = None
             pre = sv['pre']
@@ -682,7 +719,7 @@ class TransformerStackFn(torch.autograd.Function):
         ctx.micro = micro
         if micro == 1:
             hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
-                                      ff_dropout=float(opts.get('ff_dropout', 0.)))
+                                      ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)))
         else:
             S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
@@ -694,10 +731,11 @@ class TransformerStackFn(torch.autograd.Function):
                 (cma, cmb) = _halves(cx.mask, h)
                 ca, cb = Context(cx.x[:h * cx.m], cma, h, cx.m), Context(cx.x[h * cx.m:], cmb, B - h, cx.m)
             s2.wait_stream(cur)
-            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca, ff_dropout=float(opts.get('ff_dropout', 0.)))
+            adp = float(opts.get('attn_dropout', 0.))
+            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp)
             xb.record_stream(s2)
             with torch.cuda.stream(s2):
-                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb, ff_dropout=float(opts.get('ff_dropout', 0.)))
+                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp)
             cur.wait_stream(s2)
             hnb.record_stream(cur)
             hn = torch.cat((hna, hnb), dim=0)

@@ -127,7 +127,25 @@ struct AttnParams {
     // structured bias (null tbl = none)
     const float* tbl; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part;
     int LT;
+    // attention dropout (DROP instantiations only): keep iff hash >= drop_thr (= p * 2^32), kept probabilities x drop_scale = 1 / (1 - p)
+    unsigned drop_thr; float drop_scale; unsigned seed_lo, seed_hi;
 };
+
+// ---- attention dropout (reference attend.py:92 `dropout_p` / :140 `attn_dropout(attn)`, training only) ----------------------------------------
+// The keep decision of pair (query i, key j) of (batch element b, head h) must be the SAME in the forward, the dQ and the dK/dV kernels, which hold
+// the pair in different lanes / registers: it is a stateless function of (seed, b, h, i, j) -- a 32-bit integer finaliser (two multiply-xorshift
+// rounds, "lowbias32") over the pair index i * N + j, salted per (seed, b, h).  tests/test_gpu_dropout.py restates it in numpy and hands the
+// resulting masks to the oracle.  Dropped probabilities still count in the softmax normalisation (the reference drops AFTER the softmax).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_salt(const AttnParams& p, int b, int head) {
+    return mix32(p.seed_lo ^ mix32(p.seed_hi + (unsigned)(b * p.H + head) * 0x9E3779B9u));
+}
+__device__ __forceinline__ bool drop_keep(unsigned salt, int qi, int kj, int N, unsigned thr) {
+    return mix32(((unsigned)qi * (unsigned)N + (unsigned)kj) ^ salt) >= thr;
+}
 
 constexpr int WCAP = 1024;                          // floats per wave in the dQ kernel's table-gradient window (slot 0 = special pairs)
 
@@ -236,7 +254,7 @@ __device__ unsigned long long g_attn_probe[4096 * 8];
 // a CU (QB == 2 + decode_block's pairing, what this kernel did before) the CU that got blocks (31, 0) ran its heavy workgroup ALONE -- one wave per
 // SIMD, nothing to overlap the softmax VALU work with the other's MFMAs -- for the whole launch and was the long pole: 74 us, 23 % MFMA-busy, while a
 // (16, 15) CU was done long before (scripts/ubench/wg_placement.hip shows the placement).
-template <bool BIAS, int QB>
+template <bool BIAS, int QB, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     constexpr int QR = 32 * QB;                                       // query rows per block
     // DYNAMIC LDS on purpose: for a static __shared__ array the compiler knows the object every ds_read touches and, having no alias scopes for the
@@ -258,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
     const float c2 = p.scale * LOG2E;
+    const unsigned dsalt = DROP ? drop_salt(p, b, active ? head : 0) : 0u;
 
     const bf16_t* kbase = p.k + (long long)b * p.N * p.ldk;
     const bf16_t* vbase = p.v + (long long)b * p.N * p.ldv;
@@ -451,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][qb][r], c2, -ms));
-                        st[kb][qb][r] = pv;
-                        ps += pv;
+                        ps += pv;                                  // the row sum counts dropped pairs too: dropout acts on the softmax OUTPUT
+                        st[kb][qb][r] = (!DROP || drop_keep(dsalt, q0 + qb * 32 + lr, tile * 64 + kb * 32 + drow(r, lh), p.N, p.drop_thr)) ? pv : 0.f;
                     }
                 l[qb] += ps;
             }
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void mqa_fwd_kernel(AttnParams p) {
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 32 + lr;
         const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const float inv = (lt > 0.f ? 1.f / lt : 0.f) * (DROP ? p.drop_scale : 1.f);
         if (qi < p.N) {
             bf16_t* op = p.o + ((long long)b * p.N + qi) * p.ldo + head * DH;
 #pragma unroll
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward dQ: same decomposition as forward.  dQ^T = scale * K^T dS^T,  dS^T = P^T o (dP^T - delta),  dP^T = V dO^T.
 // The two 32-query blocks of a wave are processed one after the other inside a tile (register budget).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool BIAS>
+template <bool BIAS, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];       // DQ_LDS<BIAS> bytes; dynamic LDS: see mqa_fwd_kernel
     float* kbias = reinterpret_cast<float*>(smem + 32768);
@@ -560,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
     const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
     const float c2 = p.scale * LOG2E;
+    const unsigned dsalt = DROP ? drop_salt(p, b, active ? head : 0) : 0u;
 
     const bf16_t* kbase = p.k + (long long)b * p.N * p.ldk;
     const bf16_t* vbase = p.v + (long long)b * p.N * p.ldv;
@@ -715,7 +735,9 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
                     for (int r = 0; r < 16; ++r) {
                         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c2, -lse2[qb]));      // masked keys: exp2(-inf) = 0
                         if (diag && kb * 32 + drow(r, lh) > qb * 32 + lr) pv = 0.f;
-                        st[kb][r] = pv * (dpt[kb][r] + dlt[qb]);                                           // dS^T (unscaled)
+                        float dpe = dpt[kb][r];
+                        if (DROP) dpe = drop_keep(dsalt, q0 + qb * 32 + lr, tile * 64 + kb * 32 + drow(r, lh), p.N, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+                        st[kb][r] = pv * (dpe + dlt[qb]);                                                  // dS^T (unscaled)
                     }
                 if (BIAS) {
                     // table gradient: every pair adds its dS to the slot it read.  wlo .. whi = byte offsets this pass can touch.
@@ -838,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 //   dV^T (d x keys) += dO^T P ;  dK^T (d x keys) += Q^T dS  (x scale at the end); then summed over the heads through LDS.
 // LDS stage: per head Q tile [64 q][64 d] + dO tile (16 KB) -> 64 KB / stage, 2 stages.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool BIAS>
+template <bool BIAS, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB of Q / dO tiles + 4 KiB of row terms
     __shared__ int qor_s[BIAS ? 256 : 1];                                      // BIAS: OR of the query attributes of every 64-query tile
@@ -854,6 +876,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
     const float c2 = p.scale * LOG2E;
+    const unsigned dsalt = DROP ? drop_salt(p, b, active ? head : 0) : 0u;
     const int key = kblk * 64 + kh * 32 + lr;
 
     bool kvalid = key < p.N;
@@ -948,7 +971,11 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     const float4 lraw = lds_ld_f4(rowt + ql);
                     const float4 draw = lds_ld_f4(rowt + 64 + ql);
                     s[qb][4 * g] = lraw.x; s[qb][4 * g + 1] = lraw.y; s[qb][4 * g + 2] = lraw.z; s[qb][4 * g + 3] = lraw.w;
-                    dp[qb][4 * g] = draw.x; dp[qb][4 * g + 1] = draw.y; dp[qb][4 * g + 2] = draw.z; dp[qb][4 * g + 3] = draw.w;
+                    if (DROP) {                                                             // -delta joins AFTER the keep mask (below): dS = P (keep dP / (1 - p) - delta)
+                        dp[qb][4 * g] = 0.f; dp[qb][4 * g + 1] = 0.f; dp[qb][4 * g + 2] = 0.f; dp[qb][4 * g + 3] = 0.f;
+                    } else {
+                        dp[qb][4 * g] = draw.x; dp[qb][4 * g + 1] = draw.y; dp[qb][4 * g + 2] = draw.z; dp[qb][4 * g + 3] = draw.w;
+                    }
                 }
             if (BIAS) {                                                                 // rows >= N read offset 0 -> an out-of-table gather -> 0
                 auto add_bias = [&](auto spc) {
@@ -986,8 +1013,15 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     const int qq = q0 + qb * 32 + drow(r, lh);
                     float pv = __builtin_amdgcn_exp2f(s[qb][r] * c2);
                     if (key_eff > qq + nodiag) pv = 0.f;                            // masked key | causal (diagonal tile only)
-                    s[qb][r] = pv;
-                    dp[qb][r] *= pv;
+                    if (DROP) {
+                        const bool kp = drop_keep(dsalt, qq, key, p.N, p.drop_thr);
+                        const float nd = rowt[64 + qb * 32 + drow(r, lh)];           // -delta of this query row
+                        dp[qb][r] = pv * ((kp ? dp[qb][r] * p.drop_scale : 0.f) + nd);
+                        s[qb][r] = kp ? pv : 0.f;                                   // dV takes the dropped probabilities (x 1 / (1 - p) at the end)
+                    } else {
+                        s[qb][r] = pv;
+                        dp[qb][r] *= pv;
+                    }
                 }
             DKV_PROBE_T(2);
             // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 64 queries of the tile: 4 steps of 16)
@@ -1033,7 +1067,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         }
         __syncthreads();
         float* outp = (pass == 0 ? p.dk : p.dv) + (long long)id.hg * p.part_stride;
-        const float sc = pass == 0 ? p.scale : 1.f;
+        const float sc = pass == 0 ? p.scale : (DROP ? p.drop_scale : 1.f);
         const int nh = min(HPB, p.H - id.hg * HPB);
         for (int e = t; e < 64 * 64; e += 512) {
             const int kk = e >> 6, d = e & 63;          // output element (key kk of the block, dim d): coalesced along d
@@ -1088,9 +1122,21 @@ static int check_bias(const BiasArgs& ba, bool bwd) {
     return 0;
 }
 
+// dropout_p in [0, 1): > 0 selects the DROP instantiations (training-mode attention dropout), `seed` picks the mask stream
+static bool set_dropout(AttnParams& p, float dropout_p, unsigned long long seed) {
+    if (!(dropout_p > 0.f)) return false;
+    const double thr = (double)dropout_p * 4294967296.0;
+    p.drop_thr = thr >= 4294967295.0 ? 4294967295u : (unsigned)thr;
+    p.drop_scale = 1.f / (1.f - dropout_p);
+    p.seed_lo = (unsigned)(seed & 0xffffffffu);
+    p.seed_hi = (unsigned)(seed >> 32);
+    return true;
+}
+
 static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
-                         float scale, const BiasArgs& ba, void* stream) {
+                         float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, void* stream) {
+    if (dropout_p < 0.f || dropout_p >= 1.f) return ALM_ERR_BAD_ARG;
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
@@ -1102,7 +1148,11 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     if (rc) return rc;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
     const int npair = ((N + 31) / 32 + 1) / 2;                           // 32-query blocks, taken two (idx, last - idx) per workgroup
-    if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+    const bool drop = set_dropout(p, dropout_p, seed);
+    if (drop) {
+        if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
+    } else if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
     ALM_LAUNCH_CHECK();
     return 0;
@@ -1113,8 +1163,9 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
 static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
                          void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
-                         int N, int H, int dim_head, float scale, const BiasArgs& ba, void* stream) {
+                         int N, int H, int dim_head, float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, void* stream) {
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return ALM_ERR_BAD_ARG;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
     if (rc) return rc;
     if ((lddo & 7) || (lddq & 3) || (long long)N * lddo * 2 >= 0x7fffffffLL) return ALM_ERR_BAD_ARG;
@@ -1134,16 +1185,25 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr; p.dtbl_part = ba.dtbl_part;
     const int nqb = (N + 63) / 64;
-    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
+    const bool drop = set_dropout(p, dropout_p, seed);
+    if (drop) {
+        if (p.tbl) hipLaunchKernelGGL((mqa_bwd_dq_kernel<true, true>), dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
+        else hipLaunchKernelGGL((mqa_bwd_dq_kernel<false, true>), dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
+    } else if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
     else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
+    if (drop) {
+        if (p.tbl) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<true, true>), dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
+        else hipLaunchKernelGGL((mqa_bwd_dkv_kernel<false, true>), dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
+    } else if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
     else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<false>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
     ALM_LAUNCH_CHECK();
     return 0;
@@ -1151,16 +1211,16 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
 
 extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
-                                float scale, void* stream) {
-    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{}, stream);
+                                float scale, float dropout_p, unsigned long long seed, void* stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{}, dropout_p, seed, stream);
 }
 
 extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
                                 void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
-                                int N, int H, int dim_head, float scale, void* stream) {
+                                int N, int H, int dim_head, float scale, float dropout_p, unsigned long long seed, void* stream) {
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
-                         scale, BiasArgs{}, stream);
+                         scale, BiasArgs{}, dropout_p, seed, stream);
 }
 
 // Same contractions with the structured score bias described at the top of this file.  tbl: fp32 [H][LT] in raw-score units (bias /
@@ -1168,10 +1228,10 @@ extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, lon
 extern "C" int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                      const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
                                      float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr,
-                                     const int* kattr, void* stream) {
+                                     const int* kattr, float dropout_p, unsigned long long seed, void* stream) {
     if (!tbl) return ALM_ERR_BAD_ARG;
     return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, nullptr},
-                         stream);
+                         dropout_p, seed, stream);
 }
 
 // dtbl_part: fp32 [alm_attn_bias_part_rows(B, N, H)][LT] per-workgroup partial table gradients, ACCUMULATED into (zero it before the
@@ -1180,10 +1240,11 @@ extern "C" int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k
                                      const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout,
                                      long long lddo, void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride,
                                      float* delta, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT, const int* qkey4,
-                                     const int* kkey4, const int* qattr, const int* kattr, float* dtbl_part, void* stream) {
+                                     const int* kkey4, const int* qattr, const int* kattr, float* dtbl_part, float dropout_p,
+                                     unsigned long long seed, void* stream) {
     if (!tbl) return ALM_ERR_BAD_ARG;
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
-                         scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, dtbl_part}, stream);
+                         scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, dtbl_part}, dropout_p, seed, stream);
 }
 
 extern "C" int alm_attn_bias_part_rows(int B, int N, int H) { return B * alm_mqa_head_groups(H) * ((N + 63) / 64) * HPB; }

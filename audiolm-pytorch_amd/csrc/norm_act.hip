@@ -363,6 +363,30 @@ int launch_ln_bwd(const TDY* dy, long long lddy, const TX* x, long long ldx, con
     return 0;
 }
 
+
+// ---- standalone GEGLU (reference audiolm_pytorch.py:246-249: x, gate = chunk(2, dim=-1); gelu(gate) * x) on fp32 rows [rows][2 I]: the module form
+// used outside the fused stack (inside it the gate is fused with the inner LayerNorm: geglu_ln_*).  Exact-erf GELU (F.gelu default).
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int I) {
+    const long long n = rows * I;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long r = e / I;
+        const int c = (int)(e % I);
+        const float xv = x[r * 2 * I + c], g = x[r * 2 * I + I + c];
+        y[e] = gelu_f(g) * xv;
+    }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long rows,
+                                                        int I) {
+    const long long n = rows * I;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long r = e / I;
+        const int c = (int)(e % I);
+        const float xv = x[r * 2 * I + c], g = x[r * 2 * I + I + c], d = dy[e];
+        dx[r * 2 * I + c] = d * gelu_f(g);
+        dx[r * 2 * I + I + c] = d * xv * gelu_grad_f(g);
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_ln_partial_blocks(int rows) { return min((rows + 3) / 4, 512); }
@@ -451,6 +475,22 @@ extern "C" int alm_geglu_ln_bwd(const void* dhn, long long lddh, const void* u, 
     if (inner <= 0 || inner_pad < inner || inner_pad > GE_MAX * 1024 || (inner_pad & 7) || (ldu & 7) || (gate_offset & 7)) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(geglu_ln_bwd_kernel, dim3(alm_geglu_partial_blocks(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dhn, lddh,
                        (const bf16_t*)u, ldu, gate_offset, gamma, mean, rstd, (bf16_t*)du, dgamma_part, rows, inner, inner_pad);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_geglu_fwd(const float* x, float* y, long long rows, int inner, void* stream) {
+    if (rows <= 0 || inner <= 0) return 0;
+    const long long n = rows * inner;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)min((n + 255) / 256, (long long)8192)), dim3(256), 0, (hipStream_t)stream, x, y, rows, inner);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int alm_geglu_bwd(const float* dy, const float* x, float* dx, long long rows, int inner, void* stream) {
+    if (rows <= 0 || inner <= 0) return 0;
+    const long long n = rows * inner;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)min((n + 255) / 256, (long long)8192)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, rows, inner);
     ALM_LAUNCH_CHECK();
     return 0;
 }

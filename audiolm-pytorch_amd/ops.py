@@ -183,6 +183,25 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, extra=None, dx_dtype=F32, want_dg
     return dx, (colsum(part) if want_dgamma else None)
 
 
+def geglu_fwd(x):
+    """fp32 [rows, 2 I] -> [rows, I]: x_half * gelu(gate_half) (the standalone GEGLU module)"""
+    _chk(x, F32)
+    rows, two_i, ld = _rows_ld(x)
+    assert ld == two_i and two_i % 2 == 0
+    y = torch.empty((rows, two_i // 2), dtype=F32, device=x.device)
+    _lib.call('alm_geglu_fwd', x.data_ptr(), y.data_ptr(), rows, two_i // 2, _st())
+    return y
+
+
+def geglu_bwd(dy, x):
+    _chk(dy, F32), _chk(x, F32)
+    rows, two_i, ld = _rows_ld(x)
+    assert ld == two_i and dy.shape == (rows, two_i // 2) and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.call('alm_geglu_bwd', dy.data_ptr(), x.data_ptr(), dx.data_ptr(), rows, two_i // 2, _st())
+    return dx
+
+
 def geglu_ln_fwd(u, gamma, inner, inner_pad):
     """u bf16 [rows, 2 * inner_pad] (x | gate halves) -> (hn bf16 [rows, inner_pad], mean, rstd)."""
     _chk(u, BF16)
@@ -230,22 +249,23 @@ def attn_bias_grad_reduce(part, B, N, H, dim_head=64):
     return dtbl
 
 
-def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None):
+def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., seed=0):
     """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse).
-    bias: structured score bias (see alm_mqa_attn_bias_fwd) or None."""
+    bias: structured score bias (see alm_mqa_attn_bias_fwd) or None.  dropout_p > 0: attention dropout with the mask stream `seed` (the
+    backward must get the same pair)."""
     _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
     o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, N), dtype=F32, device=q.device)
     if bias is not None:
         _lib.call('alm_mqa_attn_bias_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
-                  o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), _st())
+                  o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), float(dropout_p), int(seed), _st())
         return o, lse
     _lib.call('alm_mqa_attn_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
-              o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
+              o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, float(dropout_p), int(seed), _st())
     return o, lse
 
 
-def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None):
+def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None, dropout_p=0., seed=0):
     """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them).
     With `bias`, the table gradient is accumulated into dtbl_part (attn_bias_part)."""
     _chk(dout, BF16)
@@ -258,11 +278,12 @@ def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, d
         _lib.call('alm_mqa_attn_bias_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask),
                   o.data_ptr(), o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
                   dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5,
-                  *_bias_args(bias, N, H), dtbl_part.data_ptr(), _st())
+                  *_bias_args(bias, N, H), dtbl_part.data_ptr(), float(dropout_p), int(seed), _st())
         return dq, dkv
     _lib.call('alm_mqa_attn_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
               o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
-              dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, _st())
+              dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5,
+              float(dropout_p), int(seed), _st())
     return dq, dkv
 
 

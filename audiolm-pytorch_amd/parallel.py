@@ -23,7 +23,8 @@ backward.  It is not a general DDP replacement.
   * `force_collectives=True` issues the collectives even in a 1-rank group (they are the identity there): the way the RCCL hand-off -- bucket copy
     and asynchronous all-reduce issued from the backward's side stream, `work.wait()` ordering the main stream in `finish()` -- is executed on a
     1-GPU box (tests/test_gpu_dp.py)
-  * `stats` (per step, reset by `finish()`): bucket count, bytes put on the wire, host time from the last bucket launch to the return of `finish()`
+  * `stats` (per step, reset by `finish()`; the finished step's copy is `last_stats`): bucket count, bytes put on the wire, the HIP streams the
+    collectives were issued from, host time from the last bucket launch to the return of `finish()`
     (what the step still waited for: the tail that did not overlap)
 
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
@@ -49,7 +50,7 @@ class DataParallelEngine:
         self.model, self.dist, self.pg, self.bucket_dtype = model, dist, process_group, bucket_dtype
         self.world = dist.get_world_size(process_group)
         self.force = bool(force_collectives)
-        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_stream=None)
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[])
         self._t_last_launch = None
         self._avg_ok = str(dist.get_backend(process_group)).lower() == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -112,7 +113,9 @@ class DataParallelEngine:
         self.stats['buckets'] += 1
         self.stats['bytes'] += flat.numel() * flat.element_size()
         if flat.is_cuda:
-            self.stats['launch_stream'] = int(torch.cuda.current_stream(flat.device).cuda_stream)
+            sid = int(torch.cuda.current_stream(flat.device).cuda_stream)
+            if sid not in self.stats['launch_streams']:
+                self.stats['launch_streams'].append(sid)
         self._t_last_launch = time.perf_counter()
         b = _Bucket()
         b.params, b.flat, b.work = list(params), flat, work
@@ -180,7 +183,7 @@ class DataParallelEngine:
                     p.grad = v.to(p.dtype, copy=True)                  # a bf16 bucket must not become the .grad of an fp32 parameter
         if self._inflight and self._t_last_launch is not None:
             self.last_stats = dict(self.stats, tail_ms=round((time.perf_counter() - self._t_last_launch) * 1e3, 3))
-        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_stream=None)
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[])
         self._t_last_launch = None
         self._inflight = []
 

@@ -36,9 +36,16 @@ def _transpose_pad(t, Mp):
 NOT_CAUSAL = 0x7fffffff
 
 
-def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=None, bias=None, causal=False):
+def _keep_mask(shape, p, device):
+    """0 / 1 keep mask (bf16) of the attention dropout on this key set's probabilities (attend.py:140).  Module-level: the parity test pins it."""
+    return torch.empty(shape, dtype=BF16, device=device).bernoulli_(1. - p)
+
+
+def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=None, bias=None, causal=False, dropout_p=0.):
     """-> (o bf16 [B*N, H*dh], lse_tot fp32 [B, H, N], saved) ; emask uint8 [B, Me] (1 = attend) | None; bias fp32 [H, N, >= Me] contiguous | None
-    (dense attn_bias, added to the scaled scores); causal: key e visible to query n iff e <= n + (Me - N) (attend.py:131-134)."""
+    (dense attn_bias, added to the scaled scores); causal: key e visible to query n iff e <= n + (Me - N) (attend.py:131-134).
+    dropout_p > 0 (training): the probabilities of this key set are multiplied by a drawn 0 / 1 mask, the 1 / (1 - p) factor rides on the fp32 alpha
+    of the value GEMM (and of its two backward GEMMs); the softmax normalisation (lse) is untouched, as in the reference (dropout AFTER softmax)."""
     dev = q.device
     Me = ke.shape[1]
     Mp = _pad8(Me)
@@ -54,11 +61,15 @@ def extra_attn_fwd(q, ke, ve, emask, B, N, H, dh, scale, o_self=None, lse_self=N
               ops._p(bias), bias.shape[2] if bias is not None else 0, (Me - N) if causal else NOT_CAUSAL, B, N, H, Me, ops._st())
     veT = _transpose_pad(ve, Mp)
     Oe = torch.empty((B, N * H, dh), dtype=F32, device=dev)
-    ops.gemm_nt(P.view(B, N * H, Mp), veT, Oe)
+    keep, da, Pd = None, 1.0, P
+    if dropout_p > 0.:
+        keep, da = _keep_mask(P.shape, dropout_p, dev), 1. / (1. - dropout_p)
+        Pd = P * keep
+    ops.gemm_nt(Pd.view(B, N * H, Mp), veT, Oe, alpha=da)
     o = torch.empty((B * N, H * dh), dtype=BF16, device=dev)
     _lib.call('alm_xattn_combine', ops._p(o_self), o_self.stride(0) if o_self is not None else 0, ops._p(fself), Oe.data_ptr(), o.data_ptr(), H * dh,
               B * N, H, dh, ops._st())
-    return o, lse, dict(P=P, ke=ke, ve=ve, Me=Me, Mp=Mp)
+    return o, lse, dict(P=P, ke=ke, ve=ve, Me=Me, Mp=Mp, keep=keep, da=da, Pd=Pd)
 
 
 def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None, dbias=None):
@@ -67,8 +78,11 @@ def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None, dbias=No
     attn_bias (sum over the batch of the un-scaled dS).  -> (dq bf16, dke fp32 [B, Me, dh], dve fp32 [B, Me, dh])."""
     dev = q.device
     P, ke, ve, Me, Mp = saved['P'], saved['ke'], saved['ve'], saved['Me'], saved['Mp']
+    keep, da, Pd = saved.get('keep'), saved.get('da', 1.0), saved.get('Pd', P)
     dP = torch.empty((B, N * H, Mp), dtype=F32, device=dev)
-    ops.gemm_nt(dout.view(B, N * H, dh), ve, dP[:, :, :Me])
+    ops.gemm_nt(dout.view(B, N * H, dh), ve, dP[:, :, :Me], alpha=da)
+    if keep is not None:
+        dP.mul_(keep.view(B, N * H, Mp))                              # d(loss)/dP through the dropout: keep / (1 - p)
     dS = torch.empty((B * N * H, Mp), dtype=BF16, device=dev)
     _lib.call('alm_xattn_softmax_bwd', P.data_ptr(), Mp, dP.data_ptr(), Mp, ndelta.data_ptr(), float(scale), dS.data_ptr(), Mp, Me, B, N, H, ops._st())
     if dbias is not None:
@@ -83,7 +97,7 @@ def extra_attn_bwd(q, dout, saved, ndelta, B, N, H, dh, scale, dq=None, dbias=No
     dke = torch.empty((B, Mp, dh), dtype=F32, device=dev)
     dve = torch.empty((B, Mp, dh), dtype=F32, device=dev)
     ops._splitk('alm_gemm_bf16_tn_splitk', dS.view(B, K, Mp), q.view(B, K, dh), dke, Mp, dh, K, B, K * Mp, K * dh, Mp * dh, 1.0, False)
-    ops._splitk('alm_gemm_bf16_tn_splitk', P.view(B, K, Mp), dout.view(B, K, dh), dve, Mp, dh, K, B, K * Mp, K * dh, Mp * dh, 1.0, False)
+    ops._splitk('alm_gemm_bf16_tn_splitk', Pd.view(B, K, Mp), dout.view(B, K, dh), dve, Mp, dh, K, B, K * Mp, K * dh, Mp * dh, da, False)
     return dq, dke[:, :Me], dve[:, :Me]
 
 

@@ -80,6 +80,9 @@ int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols,
 int alm_colsum_chunks(int rows);
 
 /* ---- GEGLU + inner LayerNorm: audiolm_pytorch.py:246-260 (gate = second half, exact-erf GELU, LN over int(dim*8/3)) -------- */
+/* standalone GEGLU module (audiolm_pytorch.py:246-249) on fp32 rows [rows][2 inner] -> [rows][inner]: y = x * gelu(gate), gate = the second half */
+int alm_geglu_fwd(const float* x, float* y, long long rows, int inner, void* stream);
+int alm_geglu_bwd(const float* dy, const float* x, float* dx, long long rows, int inner, void* stream);
 int alm_geglu_partial_blocks(int rows);
 int alm_geglu_ln_fwd(const void* u_bf16, long long ldu, int gate_offset, const float* gamma, void* out_bf16, long long ldo, float* mean,
                      float* rstd, int rows, int inner, int inner_pad, void* stream);
@@ -90,13 +93,17 @@ int alm_geglu_ln_bwd(const void* dhn_bf16, long long lddh, const void* u_bf16, l
 /* ---- causal multi-query flash attention: attend.py:69-146 as called from audiolm_pytorch.py:381-394 ------------------------
  * q (B,N,H*64) bf16, k/v (B,N,64) bf16 single shared head, mask (B,N) uint8 (1 = attend) or NULL, scale = 64^-0.5.
  * lse fp32 [B][H][N].  Backward: dq bf16; dk/dv fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 columns each, `part_stride`
- * floats between partials; summed by alm_kv_grad_pack: deterministic, no atomics); delta = fp32 workspace [2][B][H][N]. */
+ * floats between partials; summed by alm_kv_grad_pack: deterministic, no atomics); delta = fp32 workspace [2][B][H][N].
+ * dropout_p in [0, 1) / seed: training-mode attention dropout (attend.py:92 `dropout_p`, :140 `attn_dropout(attn)`): the softmax OUTPUT of pair
+ * (b, h, i, j) is kept iff hash(seed, b, h, i * N + j) >= dropout_p * 2^32 (a stateless 32-bit finaliser, the same in forward, dQ and dK/dV) and
+ * scaled by 1 / (1 - dropout_p); 0 = off (the default path, no cost).  Pass the forward's (dropout_p, seed) to the backward. */
 int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
-                     void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, void* stream);
+                     void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, float dropout_p,
+                     unsigned long long seed, void* stream);
 int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                      const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq, float* dk,
                      float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head, float scale,
-                     void* stream);
+                     float dropout_p, unsigned long long seed, void* stream);
 /* number of head groups (4 heads each) = number of dk / dv partials the backward writes */
 int alm_mqa_head_groups(int H);
 /* The same attention with the STRUCTURED SCORE BIAS of the `flash_attn=False` models -- Attend.forward's `sim + attn_bias` (attend.py:118-
@@ -109,12 +116,13 @@ int alm_mqa_head_groups(int H);
  * zero before the first layer, alm_attn_bias_grad_reduce after the last -- all layers of a stack share one table). */
 int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                           void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT,
-                          const int* qkey4, const int* kkey4, const int* qattr, const int* kattr, void* stream);
+                          const int* qkey4, const int* kkey4, const int* qattr, const int* kattr, float dropout_p, unsigned long long seed,
+                          void* stream);
 int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                           const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq,
                           float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head,
                           float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr, const int* kattr,
-                          float* dtbl_part, void* stream);
+                          float* dtbl_part, float dropout_p, unsigned long long seed, void* stream);
 int alm_attn_bias_part_rows(int B, int N, int H);
 int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, int B, int N, int H, int LT, float scale, void* stream);
 /* The small MLPs that produce `tbl` (RelativePositionBias.net audiolm_pytorch.py:214-221, FineTransformer.pos_bias_mlp :1065-1071): first

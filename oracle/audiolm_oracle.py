@@ -73,8 +73,10 @@ def get_embeds(weight, codes, pad_id=-1):        # audiolm_pytorch.py:168-186
 # A1/A2  Attend   (attend.py:98-146; the flash path attend.py:69-96 is the same maths)
 # ----------------------------------------------------------------------------------------------
 
-def attend(q, k, v, mask=None, attn_bias=None, causal=True):
-    """q (b h i d), k/v (b j d) single shared head (MQA).  attend.py:115-146."""
+def attend(q, k, v, mask=None, attn_bias=None, causal=True, keep=None, p_drop=0.):
+    """q (b h i d), k/v (b j d) single shared head (MQA).  attend.py:115-146.  keep / p_drop: the nn.Dropout on the attention probabilities
+    (attend.py:140; the flash path's dropout_p, :92) with its Bernoulli keep mask SUPPLIED (0 / 1, (b h i j)): attn * keep / (1 - p) is what
+    F.dropout computes once the mask is drawn."""
     scale = q.shape[-1] ** -0.5
     sim = torch.einsum('bhid,bjd->bhij', q, k) * scale
     if attn_bias is not None:
@@ -87,6 +89,8 @@ def attend(q, k, v, mask=None, attn_bias=None, causal=True):
         causal_mask = torch.ones((i, j), device=sim.device, dtype=torch.bool).triu(j - i + 1)
         sim = sim.masked_fill(causal_mask, neg)
     attn = sim.softmax(dim=-1)
+    if keep is not None:
+        attn = attn * keep / (1. - p_drop)
     return torch.einsum('bhij,bjd->bhid', attn, v)
 
 
@@ -112,10 +116,12 @@ def feedforward(sd, p, x, keep=None, p_drop=0.):  # audiolm_pytorch.py:246-260
 
 
 def attention(sd, p, x, heads, mask=None, attn_bias=None, value_residual=None, context=None, prefix_context=None,
-              prefix_context_mask=None, causal=True):
+              prefix_context_mask=None, causal=True, attn_keep=None, out_keep=None, p_drop=0.):
     """Attention.forward, audiolm_pytorch.py:307-406 (no kv-cache).  Self-attention: context None.  Cross-attention (:450: dim_context,
     num_null_kv=1, norm_context=True, causal=False): `context` (b m dc), `mask` = context mask.  cond_as_self_attn_prefix: `prefix_context`
-    (b m d) is prepended to the self-attention key / value inputs (:330-345).  Returns (out, orig_v)."""
+    (b m d) is prepended to the self-attention key / value inputs (:330-345).  Returns (out, orig_v).
+    attn_keep (b h i j) / out_keep (b n dim) / p_drop: Attention(dropout = p) in training mode with both Bernoulli masks supplied -- the dropout on the
+    attention probabilities (Attend, :299-303) and the nn.Dropout behind to_out (:304)."""
     b, n, _ = x.shape
     if context is not None and (p + 'context_norm.gamma') in sd:
         context = layer_norm(context, sd[p + 'context_norm.gamma'])      # :322-323
@@ -144,9 +150,12 @@ def attention(sd, p, x, heads, mask=None, attn_bias=None, value_residual=None, c
         if mask is not None:                      # :384-385
             mask = F.pad(mask, (nk.shape[0], 0), value=True)
     q = q.reshape(b, n, heads, -1).transpose(1, 2)            # 'b n (h d) -> b h n d'
-    out = attend(q, k, v, mask=mask, attn_bias=attn_bias, causal=causal)
+    out = attend(q, k, v, mask=mask, attn_bias=attn_bias, causal=causal, keep=attn_keep, p_drop=p_drop)
     out = out.transpose(1, 2).reshape(b, n, -1)               # 'b h n d -> b n (h d)'
-    return F.linear(out, sd[p + 'to_out.0.weight']), orig_v
+    out = F.linear(out, sd[p + 'to_out.0.weight'])
+    if out_keep is not None:
+        out = out * out_keep / (1. - p_drop)
+    return out, orig_v
 
 
 # ----------------------------------------------------------------------------------------------
@@ -190,7 +199,7 @@ def rel_pos_bias(sd, p, i, j):                    # audiolm_pytorch.py:202-242
 
 def transformer(sd, p, x, *, depth, heads, streams=4, self_attn_mask=None, attn_bias=None,
                 grad_shrink_alpha=0.1, add_value_residual=True, context=None, context_mask=None, cond_as_self_attn_prefix=False,
-                ff_keep=None, ff_dropout=0.):
+                ff_keep=None, ff_dropout=0., attn_keep=None, out_keep=None, attn_dropout=0.):
     """audiolm_pytorch.py:461-560 (no kv-cache).  `p` is e.g. 'transformer.'.  A conditioning `context` goes to the cross-attention layers
     (present in `sd` as layers.{l}.1.*) or, with cond_as_self_attn_prefix, in front of the self-attention keys."""
     n = x.shape[1]
@@ -217,8 +226,9 @@ def transformer(sd, p, x, *, depth, heads, streams=4, self_attn_mask=None, attn_
 
     for l in range(depth):
         pa, pc, pf = f'{p}layers.{l}.0.', f'{p}layers.{l}.1.', f'{p}layers.{l}.2.'
+        akw = {} if attn_keep is None else dict(attn_keep=attn_keep[l], out_keep=out_keep[l], p_drop=attn_dropout)     # one mask pair per layer
         values = branch(pa, lambda t: attention(sd, pa + 'branch.', t, heads, mask=self_attn_mask, attn_bias=attn_bias,
-                                                value_residual=value_residual, **self_kw))
+                                                value_residual=value_residual, **self_kw, **akw))
         if add_value_residual and value_residual is None:                  # :534-535
             value_residual = values
         if (pc + 'branch.to_q.weight') in sd:                              # :539-544 cross attention

@@ -139,7 +139,7 @@ def _nccl_one_rank(rank, port, out, bucket_dtype):
         res['stages'][tag] = dict(loss=float(lo), stats=eng.last_stats,
                                   grads={k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()})
     run('overlapped')                                              # fresh gradients: per-layer buckets from the side stream
-    res['launched_off_main_stream'] = eng.last_stats['launch_stream'] != main
+    res['launched_off_main_stream'] = any(sid != main for sid in eng.last_stats['launch_streams'])
     with eng.no_sync():                                            # accumulation micro-step: nothing exchanged
         run('micro')
     run('accumulated', zero=False)                                 # synchronising step on top: p.grad itself is reduced in finish()

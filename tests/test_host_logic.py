@@ -139,8 +139,12 @@ def test_product_refuses_cpu_and_out_of_scope_features():
     m = A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, flash_attn=True)
     with pytest.raises(RuntimeError):
         m(ids=torch.randint(0, 10, (2, 5)))
-    with pytest.raises(NotImplementedError):
-        A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, attn_dropout=0.1)
+    md = A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, attn_dropout=0.1)        # round 3: attention dropout is built
+    assert md.transformer.attn_dropout == 0.1 and md.transformer.layers[0][0].branch.attend.dropout == 0.1
+    with pytest.raises(RuntimeError):                                                            # standalone modules: MI355X only, like everything else
+        md.transformer.layers[0][0].branch(torch.zeros(1, 4, 64))
+    with pytest.raises(RuntimeError):
+        md.transformer.layers[0][2].branch(torch.zeros(1, 4, 64))
     # conditioning is native from pre-computed text embeddings; the T5 text encoder itself is out of scope
     mc = A.SemanticTransformer(dim=64, depth=1, num_semantic_tokens=10, has_condition=True)
     assert 'transformer.layers.0.1.branch.null_kv' in mc.state_dict()
