@@ -14,7 +14,7 @@ Compared END TO END: the loss, EVERY logit, and the gradient of EVERY parameter,
         grads    per tensor rel Frobenius error <= max(3e-2, 2 x the oracle's bf16-autocast deviation of that tensor); hyper-connection scalar
                  statistics pooled (see tests/test_gpu_parity.py)
   (A) the ROUNDING-MATCHED oracle (oracle/rounding_matched.py: bf16 rounding at the HIP path's storage / operand points).  MEASURED (round 3,
-      profiles/r3_run_a_fullsize_parity.jsonl): end to end it is NO closer than (B) -- logits 0.7-3e-2 -- although the very same oracle reproduces the
+      profiles/r3_runC_fullsize_parity.jsonl, profiles/r3_runA_golden_parity.log): end to end it is NO closer than (B) -- logits 0.7-3e-2 -- although the very same oracle reproduces the
       small goldens to 4e-7 when no rounding flips and every single op of THIS stack to <= 7e-5 given the same inputs (tests/test_gpu_opwise.py).  A
       6-layer dim-1024 stack amplifies the ~1e-3 of bf16 roundings that a different fp32 summation order flips until the two runs' rounding errors are
       independent draws: an end-to-end 1e-3 does not exist for this model at this size, for any implementation.  (A) is therefore reported and held
