@@ -211,8 +211,25 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
         const int e = (t + 256 * j) * 4;
         gam[j] = make_float4(e < I ? gamma[e] : 0.f, e + 1 < I ? gamma[e + 1] : 0.f, e + 2 < I ? gamma[e + 2] : 0.f, e + 3 < I ? gamma[e + 3] : 0.f);
     }
-    int par = 0;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 2) {
+    // SOFTWARE PREFETCH (round 3): a row costs a load phase, two block reductions and a store phase that depend on each other; with one row in
+    // flight per block the kernel was latency-bound (4.5 TB/s, ~7 us per row and block).  The NEXT row's raw bf16 vectors are requested before the
+    // current row is processed (two register sets, loop unrolled by two), as in the hyper-connection kernels.
+    struct Raw { uint2 x[GE_MAX], g[GE_MAX]; };
+    auto issue = [&](Raw& r, int row) {
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = (t + 256 * j) * 4;
+            r.x[j] = r.g[j] = make_uint2(0u, 0u);
+            if (e < Ipad && row < rows) {
+                r.x[j] = *reinterpret_cast<const uint2*>(u + (long long)row * ldu + e);
+                r.g[j] = *reinterpret_cast<const uint2*>(u + (long long)row * ldu + goff + e);
+            }
+        }
+    };
+    auto cvt = [](uint2 v) {
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    };
+    auto process = [&](const Raw& r, int row, int par) {
         float4 h[GE_MAX];
         float s = 0.f;
 #pragma unroll
@@ -220,8 +237,8 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
             const int e = (t + 256 * j) * 4;
             h[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < Ipad) {
-                const float4 xv = load4(u + (long long)row * ldu + e);
-                const float4 gv = load4(u + (long long)row * ldu + goff + e);
+                const float4 xv = cvt(r.x[j]);
+                const float4 gv = cvt(r.g[j]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float cdf, pdf;
@@ -258,6 +275,16 @@ __global__ __launch_bounds__(256) void geglu_ln_fwd_kernel(const bf16_t* __restr
             mean_out[row] = mean;
             rstd_out[row] = rstd;
         }
+    };
+    Raw ra, rb;
+    const int stride = gridDim.x;
+    issue(ra, blockIdx.x);
+    for (int row = blockIdx.x; row < rows; row += 2 * stride) {
+        issue(rb, row + stride);
+        process(ra, row, 0);
+        if (row + stride >= rows) break;
+        issue(ra, row + 2 * stride);
+        process(rb, row + stride, 2);
     }
 }
 
@@ -277,36 +304,56 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
         dgam[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         gam[j] = make_float4(e < I ? gamma[e] : 0.f, e + 1 < I ? gamma[e + 1] : 0.f, e + 2 < I ? gamma[e + 2] : 0.f, e + 3 < I ? gamma[e + 3] : 0.f);
     }
-    int par = 0;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float4 ga[GE_MAX], gb[GE_MAX], xh[GE_MAX], g[GE_MAX];        // ga = d h / d x = gelu(gate); gb = d h / d gate = x * gelu'(gate)
+    // software prefetch of the next row (see geglu_ln_fwd_kernel): its raw vectors and its two LayerNorm statistics travel together
+    struct Raw { uint2 x[GE_MAX], g[GE_MAX], d[GE_MAX]; float mean, rstd; };
+    auto issue = [&](Raw& r, int row) {
+        const int rr = row < rows ? row : 0;
+        r.mean = mean_in[rr];
+        r.rstd = rstd_in[rr];
+#pragma unroll
+        for (int j = 0; j < GE_MAX; ++j) {
+            const int e = (t + 256 * j) * 4;
+            r.x[j] = r.g[j] = r.d[j] = make_uint2(0u, 0u);
+            if (e < Ipad && row < rows) {
+                r.x[j] = *reinterpret_cast<const uint2*>(u + (long long)row * ldu + e);
+                r.g[j] = *reinterpret_cast<const uint2*>(u + (long long)row * ldu + goff + e);
+                r.d[j] = *reinterpret_cast<const uint2*>(dhn + (long long)row * lddh + e);
+            }
+        }
+    };
+    auto cvt = [](uint2 v) {
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    };
+    auto process = [&](const Raw& r, int row, int par) {
+        const float mean = r.mean, rstd = r.rstd;
+        float4 ga[GE_MAX], gb[GE_MAX], g[GE_MAX];                    // ga = d h / d x = gelu(gate); gb = d h / d gate = x * gelu'(gate)
+                                                                      // (xhat is recomputed in the second pass: 12 registers that decide 4 vs 3 waves per SIMD)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < GE_MAX; ++j) {
             const int e = (t + 256 * j) * 4;
-            ga[j] = gb[j] = xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ga[j] = gb[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < Ipad) {
-                const float4 xv = load4(u + (long long)row * ldu + e);
-                const float4 gv = load4(u + (long long)row * ldu + goff + e);
-                const float4 d = load4(dhn + (long long)row * lddh + e);
+                const float4 xv = cvt(r.x[j]);
+                const float4 gv = cvt(r.g[j]);
+                const float4 d = cvt(r.d[j]);
+                // BRANCH-FREE over the 4 elements (round 3): as `if (e + c < I) { ... }` every element became its own exec-masked block -- ~60 taken
+                // branches per row.  The pad columns [I, Ipad) need no test: gamma is 0 there, so g = 0 and the two row sums see nothing; the
+                // dgamma accumulators of pad columns are never stored; the outputs are zeroed by a select at the store.
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (e + c < I) {
-                        const float gt = f4e(gv, c), xx = f4e(xv, c);
-                        float cdf, pdf;
-                        gauss_cdf_pdf(gt, cdf, pdf);
-                        const float gl = gt * cdf;
-                        const float xhat = (gl * xx - mean) * rstd;
-                        const float gg = f4e(d, c) * f4e(gam[j], c);
-                        f4e(ga[j], c) = gl;
-                        f4e(gb[j], c) = xx * fmaf(gt, pdf, cdf);
-                        f4e(xh[j], c) = xhat;
-                        f4e(g[j], c) = gg;
-                        f4e(dgam[j], c) += f4e(d, c) * xhat;
-                        s1 += gg;
-                        s2 += gg * xhat;
-                    }
+                    const float gt = f4e(gv, c), xx = f4e(xv, c);
+                    float cdf, pdf;
+                    gauss_cdf_pdf(gt, cdf, pdf);
+                    const float gl = gt * cdf;
+                    const float xhat = (gl * xx - mean) * rstd;
+                    const float gg = f4e(d, c) * f4e(gam[j], c);
+                    f4e(ga[j], c) = gl;
+                    f4e(gb[j], c) = xx * fmaf(gt, pdf, cdf);
+                    f4e(g[j], c) = gg;
+                    f4e(dgam[j], c) += f4e(d, c) * xhat;
+                    s1 += gg;
+                    s2 += gg * xhat;
                 }
             }
         }
@@ -317,9 +364,11 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
             const int e = (t + 256 * j) * 4;
             if (e < Ipad) {
                 float4 dxh, dgh;
+                const float4 xv = cvt(r.x[j]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float dh = rstd * (f4e(g[j], c) - c1 - f4e(xh[j], c) * c2);
+                    const float xhat = (f4e(ga[j], c) * f4e(xv, c) - mean) * rstd;
+                    const float dh = rstd * (f4e(g[j], c) - c1 - xhat * c2);
                     f4e(dxh, c) = (e + c < I) ? dh * f4e(ga[j], c) : 0.f;
                     f4e(dgh, c) = (e + c < I) ? dh * f4e(gb[j], c) : 0.f;
                 }
@@ -327,6 +376,16 @@ __global__ __launch_bounds__(256) void geglu_ln_bwd_kernel(const bf16_t* __restr
                 store4(du + (long long)row * ldu + goff + e, dgh);
             }
         }
+    };
+    Raw ra, rb;
+    const int stride = gridDim.x;
+    issue(ra, blockIdx.x);
+    for (int row = blockIdx.x; row < rows; row += 2 * stride) {
+        issue(rb, row + stride);
+        process(ra, row, 0);
+        if (row + stride >= rows) break;
+        issue(ra, row + 2 * stride);
+        process(rb, row + stride, 1);
     }
     if (!dgamma_part) return;
 #pragma unroll
@@ -461,7 +520,7 @@ extern "C" int alm_geglu_ln_fwd(const void* u, long long ldu, int gate_offset, c
                                 float* rstd, int rows, int inner, int inner_pad, void* stream) {
     if (rows <= 0) return 0;
     if (inner <= 0 || inner_pad < inner || inner_pad > GE_MAX * 1024 || (inner_pad & 7) || (ldu & 7) || (gate_offset & 7)) return ALM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(geglu_ln_fwd_kernel, dim3(min(rows, 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, ldu, gate_offset, gamma,
+    hipLaunchKernelGGL(geglu_ln_fwd_kernel, dim3(min(rows, 2048)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)u, ldu, gate_offset, gamma,
                        (bf16_t*)out, ldo, mean, rstd, rows, inner, inner_pad);
     ALM_LAUNCH_CHECK();
     return 0;
