@@ -636,8 +636,9 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
 // counted wait on the vector-memory queue: at most N operations (here: LDS-DMA pieces, which retire in order) may still be in flight
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 16, "add the literal");
+    static_assert(N == 0 || N == 8 || N == 16, "add the literal");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
@@ -648,17 +649,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // reads (4 + 4) fragments per 16 MFMAs: 50 % of the LDS port, and its 256 accumulator registers (AGPRs) leave one wave per SIMD with the whole
 // 512-entry file.  With ONE wave per SIMD every stall is exposed, so the loop is software-pipelined by hand, in the order the vendor's Tensile kernels
 // for this chip use (read off their ISA: MT256x256x64, 4 waves, wave tile 128 x 128, direct-to-LDS, prefetch 2, local-read prefetch 1):
-//     K-step t (stage buffer cur = t & 1), sub-steps S0 .. S3 of 16 MFMAs, fragment register sets F0 .. F3 (F0 was read during step t - 1):
-//       S0 (F0) || read F1 <- cur          S1 (F1) || read F2, F3 <- cur          -> lgkmcnt(0), barrier: cur is consumed by every wave
-//       S2 (F2) || DMA tile t + 2 -> cur, one 1-KiB piece per MFMA (no burst of DMA issues in front of the matrix pipe)
-//       vmcnt(16), barrier: tile t + 1 (issued one step ago) has landed in nxt; the 16 pieces just issued stay in flight
-//       S3 (F3) || read F0 <- nxt (sub-step 0 of tile t + 1)
-// so the operand fetch runs ~1.5 K-steps ahead out of two 64-KB stages, and neither a DMA burst nor a fragment-read latency ever sits between two
-// MFMAs.  The compiler cannot see the DMA -> LDS -> ds_read dependency through `__restrict__` (it must not: it would wait for ALL pending DMA, see
-// gemm_kernel); the two counted waits + barriers above are what orders them.
+//     K-step t (stage buffers cur = t & 1, nxt = the other), sub-steps S0 .. S3 of 16 MFMAs, fragment register sets F0 .. F3 (F0 read during step t - 1):
+//       S0 (F0) || read F1 <- cur || DMA of the B half of tile t + 1 -> nxt      (one 1-KiB piece per TWO MFMAs)
+//       S1 (F1) || read F2 <- cur          S2 (F2) || read F3 <- cur
+//       vmcnt(0) lgkmcnt(0), barrier: cur is consumed by every wave and tile t + 1 has landed in nxt -- the ONLY barrier of the K-step
+//       S3 (F3) || read F0 <- nxt (sub-step 0 of tile t + 1) || DMA of the A half of tile t + 2 -> cur
+// so 8 fragment reads ride under every 16 MFMAs, the 16 DMA pieces of a wave are spread over two sub-steps, and the operand fetch runs 1 - 1.75
+// K-steps ahead out of two 64-KB stages.  How this schedule was found (in-kernel s_memtime probe, scripts/gemm_probe.py, ALM_PROBE_TILE=14): with all
+// 16 pieces issued under S2, one per MFMA, S2 took 1316 cycles for 512 cycles of MFMA -- the CU's vector-memory path moves 64 B / clk, so the 4
+// waves' 64 one-KiB pieces occupy it for ~1024 cycles however they are issued; they must be spread over at least that many MFMA cycles (spread over
+// S2 + S3: 8192^3 1301 -> 1418 TFLOP/s).  The compiler cannot see the DMA -> LDS -> ds_read dependency through `__restrict__` (it must not: it
+// would wait for ALL pending DMA, see gemm_kernel); the counted wait + barrier above is what orders them.
 template <bool TNMODE, bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    GPROBE_DECL
     constexpr int BM = 256, BN = 256, WM = 2, WN = 2, NW = 4, TM = 4, TNB = 4;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;       // 32 KB + 32 KB
     constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;                                          // 8 + 8 one-KiB DMA pieces per wave and stage
@@ -764,19 +769,23 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     const unsigned kstepA = TNMODE ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
     const unsigned kstepB = TNMODE ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
 
-    auto stage = [&](int kt, unsigned char* base) {
+    auto stage_a = [&](int kt, unsigned char* base) {
         const int kleft = Krem - kt * BK;
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
         }
+    };
+    auto stage_b = [&](int kt, unsigned char* base) {
+        const int kleft = Krem - kt * BK;
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
         }
     };
+    auto stage = [&](int kt, unsigned char* base) { stage_a(kt, base); stage_b(kt, base); };
 
     unsigned fragA[TM], fragB[TNB];
     if (!TNMODE) {
@@ -835,64 +844,62 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     Frags F0, F1, F2, F3;
 
     stage(0, smem);
-    if (nk > 1) { stage(1, smem + STAGE); wait_vmcnt<16>(); } else wait_vmcnt<0>();
+    if (nk > 1) { stage_a(1, smem + STAGE); wait_vmcnt<8>(); } else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, F0);
+    GPROBE_T(0);
 
-    // one K-step; `cur` (read, then overwritten by the DMA of tile kt + 2) and `nxt` (read: sub-step 0 of tile kt + 1) are distinct buffers.
-    // MORE2 / MORE1 (tile kt + 2 / kt + 1 exists) are COMPILE-TIME: the steady-state body must be one basic block, or the schedule groups below
-    // (which only order instructions inside a block) cannot interleave the DMA pieces and the fragment reads with the MFMAs.
-    auto kstep = [&](unsigned char* __restrict__ cur, const unsigned char* __restrict__ nxt, int kt, auto m2c, auto m1c) {
+    // one K-step; `cur` (read, then overwritten by the A half of tile kt + 2) and `nxt` (receives the B half of tile kt + 1, then read: sub-step 0 of
+    // tile kt + 1) are distinct buffers.  MORE2 / MORE1 (tile kt + 2 / kt + 1 exists) are COMPILE-TIME: the steady-state body must be straight-line
+    // code, or the schedule groups below (which only order instructions inside a basic block) cannot interleave DMA pieces and fragment reads with
+    // the MFMAs.
+    auto kstep = [&](unsigned char* __restrict__ cur, unsigned char* __restrict__ nxt, int kt, auto m2c, auto m1c) {
         constexpr bool MORE2 = decltype(m2c)::value, MORE1 = decltype(m1c)::value;
-        // ---- S0, S1: the rest of this tile's fragments come in under the first 32 MFMAs
+        // ---- S0: MFMA(F0) || read F1 <- cur || DMA of the B half of tile kt + 1 -> nxt (consumed one step ago: the barrier below ordered that)
+        if (MORE1) stage_b(kt + 1, nxt);
         load_frags(cur, 1, F1);
         mfma_all(F0);
+#pragma unroll
+        for (int q = 0; q < NMF / 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (MORE1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // ONE DMA piece per two MFMAs (64 cycles): the CU's vector-memory path moves
+            __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NMF / 2 - 1) / (NMF / 2), 0);   // 64 B / clk: 4 waves x 1 KiB = 64 cycles per round
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GPROBE_T(1);
+        // ---- S1, S2: MFMA(F1) || read F2 ; MFMA(F2) || read F3
         load_frags(cur, 2, F2);
-        load_frags(cur, 3, F3);
         mfma_all(F1);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, (2 * NRD + NMF - 1) / NMF, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (MORE2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's reads of `cur` have returned
-            __builtin_amdgcn_s_barrier();                                   // ... and everybody else's: `cur` may be overwritten
-            __builtin_amdgcn_sched_barrier(0);
-            stage(kt + 2, cur);
-        }
+        load_frags(cur, 3, F3);
         mfma_all(F2);
-        if (MORE2) {
 #pragma unroll
-            for (int q = 0; q < NMF; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);         // one DMA piece behind every MFMA
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int q = 0; q < NMF / 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NMF / 2 - 1) / (NMF / 2), 0);
             }
-        }
         __builtin_amdgcn_sched_barrier(0);
+        GPROBE_T(2);
+        // ---- ONE barrier per K-step: this wave's reads of `cur` have returned and its pieces of tile kt + 1 have landed -- and everybody else's
         if (MORE1) {
-            if (MORE2) wait_vmcnt<16>(); else wait_vmcnt<0>();              // tile kt + 1 has landed in `nxt` (this wave's pieces)
-            __builtin_amdgcn_s_barrier();                                   // ... and every other wave's
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(nxt, 0, F0);
         }
+        GPROBE_T(3);
+        // ---- S3: MFMA(F3) || read F0 <- nxt (sub-step 0 of tile kt + 1) || DMA of the A half of tile kt + 2 -> cur
+        if (MORE2) stage_a(kt + 2, cur);
+        if (MORE1) load_frags(nxt, 0, F0);
         mfma_all(F3);
-        if (MORE1) {
 #pragma unroll
-            for (int q = 0; q < NMF; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
+        for (int q = 0; q < NMF / 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (MORE2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            if (MORE1) __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NMF / 2 - 1) / (NMF / 2), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        GPROBE_T(4);
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -907,6 +914,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     static_assert(NW * 32 * (32 * TNB * ES) <= 2 * STAGE, "epilogue slab");
     const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
+    GPROBE_T(6);
+    GPROBE_FLUSH((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave);
 }
 
 // ---- split-K second stage: C[b][m][n] (+)= sum_z ws[z][b][m][n]   (blockIdx.y = b)
@@ -1145,6 +1154,13 @@ int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipS
     int tl = pick_tile(p.M, p.N, ny * nz, tile, TNMODE);
     if (tl < 0) return ALM_ERR_UNSUPPORTED;
     if (hook && tl != 1 && (big_tile == 2 || big_tile == 11 || big_tile == 13 || big_tile == 14)) tl = big_tile;
+    // The 4-wave tile (gemm_w4_kernel, id 14) is OPT-IN: stand-alone its main loop is 4-9 % faster per K-step than the staggered tile on long
+    // contractions (K = 1024 -1 %, 2736 +-0, 5472 +4 %, 8192 +6-9 %), but INSIDE the training step it measured slower on alternating runs
+    // (ALM_GEMM_W4_MINK = 4096: NT big-tile time 3.94 -> 4.05 ms / step; 2048: 4.13 ms; TN unchanged) -- one wave per SIMD has nothing to cover a
+    // late operand fetch with when the inputs come from HBM instead of a warm L2.  ALM_GEMM_W4_MINK=<K> routes the
+    // automatic 256 x 256 choices with at least that many K elements per slice to it (A/B runs).
+    static const int w4_mink = [] { const char* e = getenv("ALM_GEMM_W4_MINK"); return e ? atoi(e) : 0; }();
+    if (hook && w4_mink > 0 && tl == 13 && tile == 0 && (p.ksplit > 0 ? p.ksplit : p.K) >= w4_mink) tl = 14;
     if (tl == 14) return out_f32 ? launch_w4<TNMODE, true>(p, ny, nz, st) : launch_w4<TNMODE, false>(p, ny, nz, st);
     if (tl == 13) return out_f32 ? launch_stag<TNMODE, true>(p, ny, nz, st) : launch_stag<TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'audiolm-pytorch_amd')
 LIB = os.path.join(ROOT, 'scripts', 'ubench', 'bin', 'libalm_gprobe.so')
 SEG = ['prologue', 'DMA issue (8 pieces)', 'raw barrier', 'fragment reads + 32 MFMA', 'barrier (vmcnt 0, lgkmcnt 0)', 'tail barriers', 'epilogue']
+SEG14 = ['prologue (1.5 stages + first fragments)', 'S0: 16 MFMA || 8 reads || 8 DMA pieces', 'S1 + S2: 32 MFMA || 16 reads', 'vmcnt(0) lgkmcnt(0) + barrier', 'S3: 16 MFMA || 8 reads || 8 DMA pieces', '-', 'epilogue']
+TILE = int(os.environ.get('ALM_PROBE_TILE', '13'))
 
 
 def build():
@@ -31,8 +33,11 @@ def run():
     dev, BF16 = torch.device('cuda'), torch.bfloat16
     lib = ctypes.CDLL(LIB)
     T = 16384
-    for name, M, N, K, tn in [('W1 fwd  NT', T, 5472, 1024, False), ('dXN2 dgrad NT', T, 1024, 5472, False), ('square 8192 NT', 8192, 8192, 8192, False),
-                              ('dW1 wgrad TN (split-K)', 5472, 1024, T, True)]:
+    shapes = [('W1 fwd  NT', T, 5472, 1024, False), ('dXN2 dgrad NT', T, 1024, 5472, False), ('square 8192 NT', 8192, 8192, 8192, False),
+              ('dW1 wgrad TN (split-K)', 5472, 1024, T, True)]
+    if os.environ.get('ALM_PROBE_SHAPE'):
+        shapes = [sh for sh in shapes if os.environ['ALM_PROBE_SHAPE'] in sh[0]]
+    for name, M, N, K, tn in shapes:
         if tn:
             At, Bt = torch.randn(K, M, device=dev).to(BF16), torch.randn(K, N, device=dev).to(BF16)
             C = torch.empty(M, N, dtype=torch.float32, device=dev)
@@ -40,7 +45,7 @@ def run():
         else:
             A, B = torch.randn(M, K, device=dev).to(BF16), torch.randn(N, K, device=dev).to(BF16)
             C = torch.empty(M, N, dtype=BF16, device=dev)
-            fn = lambda: ops.gemm_nt_tile(A, B, C, 13)
+            fn = lambda: ops.gemm_nt_tile(A, B, C, TILE)
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -57,7 +62,7 @@ def run():
         #                                     later shapes then include stale rows): the first shape printed is the clean one
         print(f'{name}: M={M} N={N} K={K}: {e0.elapsed_time(e1) * 1e3:.1f} us (probed build), {len(a)} waves recorded; mean cycles per wave:')
         tot = a[:, :7].sum(1).mean()
-        for i, s in enumerate(SEG):
+        for i, s in enumerate(SEG14 if TILE == 14 else SEG):
             print(f'    {s:34s} {a[:, i].mean():9.0f}  ({100 * a[:, i].mean() / tot:4.1f} %)')
 
 
