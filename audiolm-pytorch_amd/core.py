@@ -244,16 +244,25 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
             st['kvp0'] = KVp
         pre = dict(KVp=KVp, ke=KVp[:, :dh].reshape(B, m, dh), ve=Vp.reshape(B, m, dh), pmixed=pmixed)
     dense = isinstance(bias, relpos.DenseBias)
-    if dense and (pre is not None or decode is not None):
-        raise NotImplementedError('a dense attn_bias tensor with prefix conditioning or a kv cache is not implemented (the structured relpos.AttnBias is)')
+    if dense and decode is not None:
+        raise NotImplementedError('a dense attn_bias tensor with the native kv cache is not implemented (the structured relpos.AttnBias is; the tensor '
+                                  'protocol recomputes dense-bias models without a cache)')
     if decode is not None:
         assert pre is None, 'the reference turns the kv cache off for prefix conditioning (audiolm_pytorch.py:481-482)'
         kv_new = KV if V is Vown else torch.cat((K, V), dim=1)       # k | value-residual-mixed v of the new position
         AO, LSE = ops.mqa_decode_attn(Q, decode.kv[l], kv_new, decode.length, mask_u8, H, dh, bias=bias, pos_dev=decode.pos_dev), None
     elif dense:
-        # an arbitrary dense attn_bias (reference math path, attend.py:98-146): GEMM scores + bias + causal / key mask + softmax + GEMM values
-        AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, K.reshape(B, N, dh), V.reshape(B, N, dh), mask_u8, B, N, H, dh, float(dh) ** -0.5,
-                                                    bias=bias.tbl, causal=True, dropout_p=pd)
+        # an arbitrary dense attn_bias (reference math path, attend.py:98-146): GEMM scores + bias + causal / key mask + softmax + GEMM values.
+        # With a conditioning prefix the key set is [prefix | sequence] (audiolm_pytorch.py:330-345): the bias gets zero columns for the prefix keys
+        # (F.pad(attn_bias, (m, 0)), :345), the key mask the prefix mask in front, and "causal" means key e <= query n + m (attend.py:131-134)
+        kd, vd, md, bd = K.reshape(B, N, dh), V.reshape(B, N, dh), mask_u8, bias.tbl
+        if pre is not None:
+            m = ctx.m
+            kd, vd = torch.cat((pre['ke'], kd), dim=1), torch.cat((pre['ve'], vd), dim=1)
+            ones = lambda n_: torch.ones((B, n_), dtype=torch.uint8, device=dev)
+            md = None if (mask_u8 is None and ctx.mask is None) else torch.cat((ones(m) if ctx.mask is None else ctx.mask, ones(N) if mask_u8 is None else mask_u8), dim=1).contiguous()
+            bd = torch.cat((torch.zeros((H, N, m), dtype=F32, device=dev), bd), dim=2).contiguous()
+        AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, kd, vd, md, B, N, H, dh, float(dh) ** -0.5, bias=bd, causal=True, dropout_p=pd)
     else:
         AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed)
         if pre is not None:
@@ -594,11 +603,16 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             pd, dseed = sv['drop']
             KV = sv['KV']
             # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
+            dense_pre = None
             if dense:
                 nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
-                dbl = torch.empty_like(ddense)
+                mpre = ctx.m if sv['pre'] is not None else 0
+                dbl = torch.empty((H, N, mpre + N), dtype=F32, device=dev)
                 dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, sv['dense'], nd, B, N, H, dh, scale, dbias=dbl)
-                ddense += dbl
+                ddense += dbl[:, :, mpre:]                                        # the prefix columns of the padded bias are constants (:345)
+                if mpre:
+                    dense_pre = (dke[:, :mpre], dve[:, :mpre])
+                    dke, dve = dke[:, mpre:], dve[:, mpre:]
                 dkv32 = torch.cat((dke.reshape(M, dh), dve.reshape(M, dh)), dim=1).contiguous()
             else:
                 dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part,
@@ -608,8 +622,11 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             pre = sv['pre']
             if pre is not None:
                 m = ctx.m
-                nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
-                dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, pre['xs'], nd, B, N, H, dh, scale, dq=dQ)
+                if dense_pre is not None:
+                    dke, dve = dense_pre                                          # the dense path already covered the prefix keys
+                else:
+                    nd = xattn.attn_delta(sv['AO'], dAO, B, N, H, dh)
+                    dQ, dke, dve = xattn.extra_attn_bwd(sv['Q'], dAO, pre['xs'], nd, B, N, H, dh, scale, dq=dQ)
                 dkvp32 = torch.cat((dke.reshape(B * m, dh), dve.reshape(B * m, dh)), dim=1).contiguous()
                 dKVp = ops.kv_grad_pack(dkvp32, acc_vp0, _vgrad_mode(acc_vp0, pre['pmixed']), dh)
                 dcp = _empty((B * m, D), F32, dev)

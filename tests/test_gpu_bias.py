@@ -312,6 +312,43 @@ def test_transformer_with_dense_attn_bias_vs_oracle(streams):
     assert worst[0] <= 8e-2, worst
 
 
+def test_transformer_dense_attn_bias_with_a_conditioning_prefix_vs_oracle():
+    """attn_bias=<dense tensor> together with cond_as_self_attn_prefix (reference audiolm_pytorch.py:330-345: the prefix keys get zero bias columns,
+    F.pad(attn_bias, (m, 0)); :510-515): the math path runs over the concatenated [prefix | sequence] key set.  Output, d(context), d(bias) and
+    the parameter gradients vs the fp32 oracle (round 3: this combination used to be refused)."""
+    import audiolm_pytorch_amd as A
+    from common import synth_state_dict
+    from test_gpu_parity import HC_SCALARS
+    dim, depth, heads, n, b, m = 128, 2, 4, 60, 2, 7
+    torch.manual_seed(0)
+    tr = A.audiolm_pytorch.Transformer(dim=dim, depth=depth, heads=heads, num_residual_streams=4, rel_pos_bias=False, cond_as_self_attn_prefix=True)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in tr.state_dict().items()}, 177)
+    tr.load_state_dict(sd)
+    tr.to(dev())
+    x = rnd(b, n, dim, seed=178).requires_grad_(True)
+    ctxt = rnd(b, m, dim, seed=182).requires_grad_(True)
+    bias = rnd(heads, n, n, seed=179, scale=1.5).requires_grad_(True)
+    g = torch.Generator().manual_seed(180)
+    mask = (torch.rand(b, n, generator=g) > 0.15)
+    mask[:, 0] = True
+    cmask = torch.rand(b, m, generator=g) > 0.3
+    cmask[:, 0] = True
+    out = tr(x, self_attn_mask=mask.to(dev()), attn_bias=bias, context=ctxt, context_mask=cmask.to(dev()))
+    go = rnd(b, n, dim, seed=181)
+    out.backward(go)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, br, cr = (t.detach().cpu().clone().requires_grad_(True) for t in (x, bias, ctxt))
+    ref = O.transformer(sdr, '', xr, depth=depth, heads=heads, streams=4, self_attn_mask=mask, attn_bias=br, context=cr, context_mask=cmask,
+                        cond_as_self_attn_prefix=True)
+    ref.backward(go.cpu())
+    fro = lambda a, w: float((a.detach().cpu().double() - w.double()).norm() / w.double().norm().clamp(min=1e-30))
+    assert fro(out, ref) <= 1.5e-2, fro(out, ref)
+    assert fro(bias.grad, br.grad) <= 5e-2 and fro(x.grad, xr.grad) <= 5e-2 and fro(ctxt.grad, cr.grad) <= 5e-2, (fro(bias.grad, br.grad), fro(x.grad, xr.grad), fro(ctxt.grad, cr.grad))
+    worst = max((fro(p.grad, sdr[k].grad), k) for k, p in tr.named_parameters()
+                if sdr[k].grad is not None and float(sdr[k].grad.norm()) > 1e-7 and not k.endswith(HC_SCALARS))
+    assert worst[0] <= 8e-2, worst
+
+
 @pytest.mark.parametrize('streams', [1, 4])
 def test_transformer_ff_dropout_vs_oracle_with_the_same_masks(streams, monkeypatch):
     """Transformer(ff_dropout = p) (reference FeedForward: nn.Dropout between the inner LayerNorm and the output projection, audiolm_pytorch.py:251-260).
