@@ -620,15 +620,18 @@ class Transformer(nn.Module):
                 f'kv_cache must be [depth={cfg.depth}, 2, b={b}, cached positions, dim_head={dh}], got {tuple(kv_cache.shape)}'
             cache_len = kv_cache.shape[-2]
             assert cache_len <= n
-        if exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias):
-            raise NotImplementedError('the kv-cache protocol takes the structured relpos.AttnBias only (a dense attn_bias runs through forward())')
+        dense = exists(attn_bias) and not isinstance(attn_bias, relpos.AttnBias)
+        if dense:
+            # an arbitrary dense attn_bias (h, n, n): the math path has no single-position kernel, so the sequence is recomputed from scratch on
+            # every call (`cache_len` only selects the positions that are returned) -- the same numbers the reference's cached step gives
+            attn_bias = attn_bias if isinstance(attn_bias, relpos.DenseBias) else relpos.DenseBias.wrap(attn_bias, cfg.heads, n)
         if not exists(attn_bias) and exists(self.rel_pos_bias):
             attn_bias = self.rel_pos_bias(n, n)
         tbl = attn_bias.tbl if exists(attn_bias) else None
         mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8) if exists(self_attn_mask) else None
         state = core.DecodeCache(cfg, b, n, x.device)
         flat = self.flat_params()
-        if cache_len > 0 and n - cache_len == 1:
+        if cache_len > 0 and n - cache_len == 1 and not dense:
             for l in range(cfg.depth):
                 state.kv[l][:, :cache_len, :dh] = kv_cache[l, 0]
                 state.kv[l][:, :cache_len, dh:] = kv_cache[l, 1]

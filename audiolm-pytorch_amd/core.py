@@ -268,9 +268,9 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
         if pre is not None:
             AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE, dropout_p=pd)
             pre['xs'] = xs
-        if kv_out is not None:
-            kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
-            kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
+    if kv_out is not None and decode is None:                # a (prefix) forward of a sampling run / of the cache protocol: keep every layer's k | v
+        kv_out.kv[l][:, :N, :dh] = K.reshape(B, N, dh)
+        kv_out.kv[l][:, :N, dh:] = V.reshape(B, N, dh)
     Y = _empty((M, D), BF16, dev)
     okeep, oalpha = None, 1.0
     if pd > 0.:

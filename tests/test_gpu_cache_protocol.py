@@ -86,3 +86,26 @@ def test_fine_guided_stacked_cache_protocol():
         # without caches the guided logits are the same numbers
         cl0, fl0 = model.forward_with_cond_scale(coarse, fine[:, :m['calls'][-1]['n']], text_embeds=te, cond_scale=m['cond_scale'])
         assert _frob(fl0, fl) <= 2e-2 and _frob(cl0, cl) <= 2e-2
+
+
+def test_dense_attn_bias_through_the_cache_protocol_equals_the_uncached_forward():
+    """Transformer.forward(attn_bias=<dense tensor>, kv_cache=..., return_kv_cache=True) (reference :487-506 with any bias tensor): the math path has no
+    single-position kernel, so the protocol recomputes the sequence; the positions it returns and the cache it hands back must equal the uncached
+    forward / a structured run of the same model (round 3: this combination used to be refused)."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    dim, depth, heads, n, b = 128, 2, 4, 40, 2
+    torch.manual_seed(0)
+    tr = A.audiolm_pytorch.Transformer(dim=dim, depth=depth, heads=heads, num_residual_streams=4, rel_pos_bias=False)
+    tr.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in tr.state_dict().items()}, 401))
+    tr.to(dev).eval()
+    g = torch.Generator().manual_seed(402)
+    x = torch.randn(b, n, dim, generator=g).to(dev)
+    bias = (torch.randn(heads, n, n, generator=g) * 1.5).to(dev)
+    with torch.no_grad():
+        full = tr(x, attn_bias=bias)
+        h0, kv0 = tr(x[:, :n - 1], attn_bias=bias[:, :n - 1, :n - 1], return_kv_cache=True)
+        h1, kv1 = tr(x, attn_bias=bias, kv_cache=kv0, return_kv_cache=True)
+    assert tuple(kv0.shape) == (depth, 2, b, n - 1, 64) and tuple(kv1.shape) == (depth, 2, b, n, 64) and tuple(h1.shape) == (b, 1, dim)
+    assert _frob(h0, full[:, :n - 1]) <= 2e-3 and _frob(h1, full[:, -1:]) <= 2e-3, (_frob(h0, full[:, :n - 1]), _frob(h1, full[:, -1:]))
+    assert _frob(kv1[..., :n - 1, :], kv0) <= 2e-3
