@@ -22,6 +22,7 @@ SIGNATURES = {
     'alm_gemm_splitk_tile': [_I, _I, _I, _I],
     'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
+    'alm_gemm_bf16_tn_batched': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_nt_tile': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _I, _I, _P],
     'alm_transpose_bf16': [_P, _P, _I, _I, _L, _L, _I, _P],
     'alm_transpose_bf16_batched': [_P, _P, _I, _I, _L, _L, _I, _I, _L, _L, _P],
@@ -32,6 +33,7 @@ SIGNATURES = {
     'alm_layernorm_bwd': [_P, _I, _L, _P, _I, _L, _P, _P, _P, _P, _L, _P, _I, _L, _P, _I, _I, _P],
     'alm_colsum': [_P, _I, _L, _I, _I, _P, _F, _I, _P, _P],
     'alm_colsum_chunks': [_I],
+    'alm_colsum_partial': [_P, _L, _I, _I, _P, _P],
     'alm_geglu_fwd': [_P, _P, _L, _I, _P],
     'alm_geglu_bwd': [_P, _P, _P, _L, _I, _P],
     'alm_geglu_partial_blocks': [_I],
@@ -64,13 +66,13 @@ SIGNATURES = {
     'alm_hc_grads_width': [_I, _I],
     'alm_hc_partial_rows': [_I, _I, _I, _I, _L, _I],
     'alm_hc_fwd': [_P, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'alm_hc_bwd': [_P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
-    'alm_hc_param_grads': [_P, _P, _P, _P, _P, _I, _I, _P],
+    'alm_hc_bwd': [_P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    'alm_hc_param_grads': [_P, _I, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
     'alm_residual_add': [_P, _P, _L, _P, _L, _I, _P],
     'alm_f32_to_bf16': [_P, _P, _P, _L, _L, _I, _P],
-    'alm_add_f32': [_P, _P, _P, _L, _P],
+    'alm_add_f32': [_P, _P, _P, _L, _F, _P],
     'alm_embed_assemble': [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P],
     'alm_embed_scatter_add': [_P, _P, _I, _P, _P, _P, _F, _L, _I, _P],
     'alm_gather_split_bf16': [_P, _L, _L, _P, _P, _P, _L, _L, _I, _P],

@@ -211,7 +211,7 @@ def _attn_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
-def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, drop=(0., 0)):
+def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, drop=(0., 0), ao_out=None):
     """self-attention branch (audiolm_pytorch.py:307-406): -> (Y bf16 [M, D], saved dict).  drop = (p, seed): Attention(dropout=p) in training mode --
     dropout on the attention probabilities (attend.py:92 / :140; in-kernel for the flash part, a drawn 0 / 1 mask for a prefix / dense-bias part) and
     the nn.Dropout(p) behind to_out (:304): a 0 / 1 mask on the bf16 output with the 1 / (1 - p) factor on the fp32 alpha of the GEMMs."""
@@ -219,9 +219,16 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
     M, D, H, dh, dev = B * N, cfg.dim, cfg.heads, cfg.dim_head, X.device
     (Wq, _), (Wkv, _), (Wo, _) = W['wq'], W['wkv'], W['wo']
     Q = _empty((M, H * dh), BF16, dev)
-    ops.gemm_nt(XN, Wq, Q)
     KV = _empty((M, 2 * dh), BF16, dev)
-    ops.gemm_nt(X, Wkv, KV)                              # k / v from the UN-normalised branch input (:325 vs :347)
+    fside = st.get('fside')
+    if fside is not None:
+        # to_kv (N = 128: a quarter of the chip for ~17 us) runs on a side stream UNDER to_q: both only read the branch input
+        fside.run(lambda: ops.gemm_nt(X, Wkv, KV), X, KV)
+        ops.gemm_nt(XN, Wq, Q)
+        fside.join()
+    else:
+        ops.gemm_nt(XN, Wq, Q)
+        ops.gemm_nt(X, Wkv, KV)                          # k / v from the UN-normalised branch input (:325 vs :347)
     K, Vown = KV[:, :dh], KV[:, dh:]
     if cfg.add_value_residual and st['kv0'] is not None:
         V = ops.value_residual_mix(Vown, st['kv0'][:, dh:])  # :357-358
@@ -264,7 +271,7 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
             bd = torch.cat((torch.zeros((H, N, m), dtype=F32, device=dev), bd), dim=2).contiguous()
         AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, kd, vd, md, B, N, H, dh, float(dh) ** -0.5, bias=bd, causal=True, dropout_p=pd)
     else:
-        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed)
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed, o=ao_out if pre is None else None)
         if pre is not None:
             AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE, dropout_p=pd)
             pre['xs'] = xs
@@ -322,7 +329,7 @@ def _dropout_keep(shape, p, device):
     return torch.empty(shape, dtype=BF16, device=device).bernoulli_(1. - p)
 
 
-def _run_ff(cfg, W, prm, XN, M, p_drop=0.):
+def _run_ff(cfg, W, prm, XN, M, p_drop=0., hn_out=None):
     """feed-forward branch (audiolm_pytorch.py:246-260).  p_drop > 0 (training only): the nn.Dropout(ff_dropout) between the inner LayerNorm and
     the output projection (:258) -- the 0 / 1 mask is applied to HN in bf16 (exact), the 1 / (1 - p) factor rides on the fp32 alpha of the W2 GEMM
     (and of its two backward GEMMs), so no rounded scale ever touches the activations."""
@@ -330,7 +337,7 @@ def _run_ff(cfg, W, prm, XN, M, p_drop=0.):
     (W1, _), (W2, _) = W['w1'], W['w2']
     U = _empty((M, 2 * Ip), BF16, dev)
     ops.gemm_nt(XN, W1, U)
-    HN, mean3, rstd3 = ops.geglu_ln_fwd(U, prm['ln3'], I, Ip)
+    HN, mean3, rstd3 = ops.geglu_ln_fwd(U, prm['ln3'], I, Ip, out=hn_out)
     keep, alpha = None, 1.0
     if p_drop > 0.:
         keep = _dropout_keep((M, Ip), p_drop, dev)
@@ -342,7 +349,7 @@ def _run_ff(cfg, W, prm, XN, M, p_drop=0.):
 
 
 def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None, ff_dropout=0.,
-                  attn_dropout=0.):
+                  attn_dropout=0., defer_wgrad=False):
     """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
     audiolm_pytorch.py:500-506 / :532) or None.  ctx: Context (cross-attention layers / self-attention prefix) or None.  Sampling: `kv_out`
     (DecodeCache) is filled with every layer's k / v of this (prefix) forward; `decode` (DecodeCache) means x holds ONE new position per
@@ -363,6 +370,14 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     rb = S > 1
     rdt = BF16 if (cfg.residual_bf16 and S > 1) else F32
     st = dict(kv0=None, kvp0=None, kvc0=None)
+    stk = None
+    if (defer_wgrad and need_grad and ctx is None and decode is None and kv_out is None and ff_dropout == 0. and attn_dropout == 0.
+            and not isinstance(bias, relpos.DenseBias)):
+        L, dev = cfg.depth, x.device                     # operands of the deferred weight-gradient GEMMs, stacked over the layers (see DEFER_WGRAD)
+        stk = dict(XNat=_empty((L, M, D), BF16, dev), Xat=_empty((L, M, D), BF16, dev), AO=_empty((L, M, cfg.heads * cfg.dim_head), BF16, dev),
+                   XNff=_empty((L, M, D), BF16, dev), HN=_empty((L, M, Ip), BF16, dev))
+    if ASYNC_KV and decode is None and kv_out is None and M >= 4096 and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        st['fside'] = _SideStream(x.device, True)
     drop_seed = _attn_seed() if attn_dropout > 0. else 0           # one draw per forward; layer l's self-attention uses stream drop_seed + l
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
@@ -370,21 +385,25 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         LW = layer_weights(cache, l, branches, I, Ip)
         for kind, prm, first in branches:
             want_x = kind == 'attn'                  # only to_kv reads the un-normalised branch input
+            xo = xno = None
+            if stk is not None:
+                xo, xno = (stk['Xat'][l], stk['XNat'][l]) if kind == 'attn' else (None, stk['XNff'][l])
             if S > 1:
                 h = ops.hc_fwd(R, B, S, N, D, y_prev=pend_y, coef_prev=pend_coef, hc=prm['hc'], ln_gamma=prm['ln'], rin_bcast=rb, r_dtype=rdt,
-                               want_x=want_x)
+                               want_x=want_x, x_out=xo, xn_out=xno)
                 r_bcast = pend_y is None                 # R is still the un-expanded x (first branch only)
                 R, X, XN, mean, rstd, coef = h['R'], h['x'], h['xn'], h['mean'], h['rstd'], h['coef']
                 rb = rb and pend_y is None               # still the un-expanded x after a width-only call
             else:
-                XN, X, mean, rstd = ops.layernorm_fwd(R, prm['ln'], want_copy=want_x)
+                XN, X, mean, rstd = ops.layernorm_fwd(R, prm['ln'], want_copy=want_x, y_out=xno, xc_out=xo)
                 coef, r_bcast = None, False
             if kind == 'attn':
-                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, (float(attn_dropout), drop_seed + l))
+                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, (float(attn_dropout), drop_seed + l),
+                                  ao_out=stk['AO'][l] if stk is not None else None)
             elif kind == 'cross':
                 Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx, float(attn_dropout))
             else:
-                Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M, ff_dropout)
+                Y, sv = _run_ff(cfg, LW['ff'], prm, XN, M, ff_dropout, hn_out=stk['HN'][l] if stk is not None else None)
             if need_grad:
                 sv.update(kind=kind, layer=l, first=l * ppl + first, R=R, X=X, XN=XN, mean=mean, rstd=rstd, coef=coef, Y=Y, r_bcast=r_bcast)
                 saved['branches'].append(sv)
@@ -401,7 +420,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
         xs = R
         hn, _, fmean, frstd = ops.layernorm_fwd(xs, flat[-1], out_f32=True)  # :555 (fp32 out: F.layer_norm autocasts to fp32; the logit heads split it)
     if need_grad:
-        saved.update(xs=xs, fmean=fmean, frstd=frstd, st=st, ctx=ctx)
+        saved.update(xs=xs, fmean=fmean, frstd=frstd, st=st, ctx=ctx, stk=stk)
     if decode is not None and not decode.frozen:
         decode.length += 1
     if kv_out is not None:
@@ -466,6 +485,13 @@ class _SideStream:
 
 
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
+ASYNC_KV = os.environ.get('ALM_ASYNC_KV', '0') != '0'                # forward: to_kv on a side stream under to_q (A/B switch; measured +-0: off)
+# Deferred weight gradients (round 3): instead of one split-K GEMM + reduce per weight and layer as the backward walks down, the activations the
+# weight gradients need (dU, dY, dQ, dKV; XN, X, AO, HN from the forward) are written into buffers STACKED over the layers, and each weight kind is
+# computed for all layers at once at the end of the backward pass (ops.gemm_tn_batched: 5 launches instead of 30 + 30 reduces, long K slices, the
+# chip full).  Used when nothing needs a layer's gradients early (no data-parallel hook) and no dropout mask sits on the operands.
+DEFER_WGRAD = os.environ.get('ALM_DEFER_WGRAD', '1') != '0'
+DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '2')))
 MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
@@ -480,7 +506,7 @@ def _vgrad_mode(acc, mixed):
     return 0 if acc is None else (1 if mixed else 2)
 
 
-def ff_backward(cfg, W, prm, sv, dY, side, want_trace=False):
+def ff_backward(cfg, W, prm, sv, dY, side, want_trace=False, du_out=None):
     """backward of the feed-forward branch (the launches of _run_ff in reverse): dY bf16 [M, D] -> (dXN bf16 [M, D], dW1 fp32 [2 I, D], d gamma3 [I],
     dW2 fp32 [D, I]).  The two weight gradients go to `side` (a _SideStream) when one is given."""
     M, D = dY.shape
@@ -492,21 +518,27 @@ def ff_backward(cfg, W, prm, sv, dY, side, want_trace=False):
     ops.gemm_nt(dY, W2T, dHN, alpha=fa)                                   # dHN = dY @ W2
     if sv['keep'] is not None:
         dHN.mul_(sv['keep'])                                              # through the dropout mask (HN below is the masked HN)
-    dW2 = _empty((D, I), F32, dev)
-    HNs, dYs = sv['HN'], dY
-    run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2, alpha=fa), dYs, HNs, dW2)      # dW2 = dY^T @ HN
-    dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip)
+    deferred = du_out is not None                                         # the two weight gradients are computed for all layers at the end
+    dW2 = None
+    if not deferred:
+        dW2 = _empty((D, I), F32, dev)
+        HNs, dYs = sv['HN'], dY
+        run(lambda: ops.gemm_tn_splitk(dYs, HNs[:, :I], dW2, alpha=fa), dYs, HNs, dW2)      # dW2 = dY^T @ HN
+    dU, dg3 = ops.geglu_ln_bwd(dHN, sv['U'], prm['ln3'], sv['mean3'], sv['rstd3'], I, Ip, du_out=du_out)
     dXN = _empty((M, D), BF16, dev)
     ops.gemm_nt(dU, W1T, dXN)                                             # dXN = dU @ W1
-    dW1 = _empty((2 * I, D), F32, dev)
-    XNs = sv['XN']
-    run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
+    dW1 = None
+    if not deferred:
+        dW1 = _empty((2 * I, D), F32, dev)
+        XNs = sv['XN']
+        run(lambda: ops.gemm_tn_splitk(dU.view(M, 2, Ip).permute(1, 0, 2)[:, :, :I], XNs, dW1.view(2, I, D)), dU, XNs, dW1)   # dW1 = dU^T @ XN
     return (dXN, dW1, dg3, dW2, dHN, dU) if want_trace else (dXN, dW1, dg3, dW2)
 
 
-def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None, async_wgrad=True):
-    """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D], list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None,
-    d(loss)/d(context) fp32 [B*m, Dc] | None)."""
+def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved, on_layer_grads=None, bias=None, async_wgrad=True, dx_scale=1.0):
+    """dhn fp32 | bf16 [M, D] -> (dx fp32 [B, N, D] x dx_scale, list of parameter grads aligned with `flat`, d(loss)/d(bias.tbl) | None,
+    d(loss)/d(context) fp32 [B*m, Dc] | None).  dx_scale: grad_shrink's alpha (audiolm_pytorch.py:93-94) -- applied by the kernel that produces dx (the
+    first branch's stream-sum / residual add) instead of a separate pass over the [B, N, D] gradient."""
     B, N = saved['B'], saved['N']
     D, S, H, dh = cfg.dim, cfg.streams, cfg.heads, cfg.dim_head
     M = B * N
@@ -535,9 +567,44 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     # fused kernels.
     dR, bcast = dxs, S > 1
     dY = dbeta = None
+    stk = saved.get('stk') if on_layer_grads is None else None                 # deferred weight gradients (see DEFER_WGRAD): operands stacked over the layers
+    bst = None
+    if stk is not None:
+        L = cfg.depth
+        bst = dict(dYat=_empty((L, M, D), BF16, dev), dYff=_empty((L, M, D), BF16, dev), dU=_empty((L, M, 2 * Ip), BF16, dev),
+                   dQ=_empty((L, M, H * dh), BF16, dev), dKV=_empty((L, M, 2 * dh), BF16, dev))
+
+    def dy_slot(br):
+        """where the gradient wrt branch `br`'s output goes: its slot of the stacked buffers in deferred mode"""
+        return None if bst is None else bst['dYat' if br['kind'] == 'attn' else 'dYff'][br['layer']]
     if S > 1:
-        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=brs[-1]['Y'], coef_prev=brs[-1]['coef'], r_dtype=rdt)
+        h = ops.hc_bwd(dxs, B, S, N, D, bcast=True, y_prev=brs[-1]['Y'], coef_prev=brs[-1]['coef'], r_dtype=rdt, dy_out=dy_slot(brs[-1]))
         dY, dbeta = h['dy'], h['dbeta']
+
+    wg = None
+    if bst is not None:
+        # the weight gradients of a GROUP of layers, one launch per weight kind (ops.gemm_tn_batched: C[l] = At[l]^T @ Bt[l], K = all tokens), issued on
+        # the side stream as soon as the backward has passed the group's lowest layer: the upper groups run under the remaining layers' kernels,
+        # only the last group is exposed.  ALM_DEFER_GROUPS = number of groups (1: everything at the end).
+        L = cfg.depth
+        gsz = (L + DEFER_GROUPS - 1) // DEFER_GROUPS
+        wg = dict(dW1=_empty((L, 2, I, D), F32, dev), dW2=_empty((L, 1, D, I), F32, dev), dWo=_empty((L, 1, D, H * dh), F32, dev),
+                  dWq=_empty((L, 1, H * dh, D), F32, dev), dWkv=_empty((L, 1, 2 * dh, D), F32, dev))
+
+        def launch_group(l0):
+            l1 = min(L, l0 + gsz)
+            jobs = [(bst['dU'][l0:l1].view(l1 - l0, M, 2, Ip).permute(0, 2, 1, 3)[..., :I], stk['XNff'][l0:l1].unsqueeze(1), wg['dW1'][l0:l1]),   # dW1 = dU^T @ XN (x | gate)
+                    (bst['dYff'][l0:l1].unsqueeze(1), stk['HN'][l0:l1][..., :I].unsqueeze(1), wg['dW2'][l0:l1]),                                  # dW2 = dY^T @ HN
+                    (bst['dYat'][l0:l1].unsqueeze(1), stk['AO'][l0:l1].unsqueeze(1), wg['dWo'][l0:l1]),                                           # dWo = dY^T @ AO
+                    (bst['dQ'][l0:l1].unsqueeze(1), stk['XNat'][l0:l1].unsqueeze(1), wg['dWq'][l0:l1]),                                           # dWq = dQ^T @ XN
+                    (bst['dKV'][l0:l1].unsqueeze(1), stk['Xat'][l0:l1].unsqueeze(1), wg['dWkv'][l0:l1])]                                          # dWkv = dKV^T @ X
+            for At, Bt, C in jobs:
+                side.run(lambda At=At, Bt=Bt, C=C: ops.gemm_tn_batched(At, Bt, C), At, Bt, C)
+            hc_n = 7 if S > 1 else 0
+            for l in range(l0, l1):
+                fa, ff_ = l * ppl + hc_n, l * ppl + (hc_n + 4) + hc_n           # first non-hyper-connection parameter of the attention / feed-forward branch
+                grads[fa + 1], grads[fa + 2], grads[fa + 3] = wg['dWq'][l, 0], wg['dWkv'][l, 0], wg['dWo'][l, 0]
+                grads[ff_ + 1], grads[ff_ + 3] = wg['dW1'][l].view(2 * I, D), wg['dW2'][l, 0]
 
     def add_ctx(g):
         nonlocal dctx
@@ -555,11 +622,11 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         hc_n = 7 if S > 1 else 0
         ip = first + hc_n                                                      # index of this branch's first non-hyper-connection parameter
         if S == 1:
-            dY = ops.f32_to_bf16(dR)
+            dY = ops.f32_to_bf16(dR, out=dy_slot(sv))
         extra = None
         W = LW[kind]
         if kind == 'ff':
-            dXN, dW1, dg3, dW2, dHN, dU = ff_backward(cfg, W, prm, sv, dY, side, want_trace=True)
+            dXN, dW1, dg3, dW2, dHN, dU = ff_backward(cfg, W, prm, sv, dY, side, want_trace=True, du_out=bst['dU'][l] if bst is not None else None)
             grads[ip + 1], grads[ip + 2], grads[ip + 3] = dW1, dg3, dW2
             rec = dict(dY=dY, dHN=dHN, dU=dU, dXN=dXN, dW1=dW1, dg3=dg3, dW2=dW2) if TRACE is not None else None
         elif kind == 'cross':
@@ -597,9 +664,11 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             oa = sv['oalpha']
             dYs = dY if sv['okeep'] is None else dY * sv['okeep']                  # through the to_out dropout mask (:304)
             ops.gemm_nt(dYs, WoT, dAO, alpha=oa)
-            dWo = _empty((D, H * dh), F32, dev)
-            AOs = sv['AO']
-            side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo, alpha=oa), dYs, AOs, dWo)
+            dWo = dWq = dWkv = None
+            if bst is None:
+                dWo = _empty((D, H * dh), F32, dev)
+                AOs = sv['AO']
+                side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo, alpha=oa), dYs, AOs, dWo)
             pd, dseed = sv['drop']
             KV = sv['KV']
             # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
@@ -616,8 +685,8 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 dkv32 = torch.cat((dke.reshape(M, dh), dve.reshape(M, dh)), dim=1).contiguous()
             else:
                 dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part,
-                                             dropout_p=pd, seed=dseed)
-            dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh)
+                                             dropout_p=pd, seed=dseed, dq_out=bst['dQ'][l] if bst is not None else None)
+            dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh, out=bst['dKV'][l] if bst is not None else None)
             dKVp = None
             pre = sv['pre']
             if pre is not None:
@@ -634,19 +703,20 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 add_ctx(dcp)
             dXN = _empty((M, D), BF16, dev)
             ops.gemm_nt(dQ, WqT, dXN)
-            dWq = _empty((H * dh, D), F32, dev)
-            XNs = sv['XN']
-            side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
             extra = _empty((M, D), BF16, dev)
             ops.gemm_nt(dKV, WkvT, extra)                                         # K/V-path gradient: reaches the un-normalised branch input directly
-            dWkv = _empty((2 * dh, D), F32, dev)
-            Xs, cx = sv['X'], (ctx.x if dKVp is not None else None)
+            if bst is None:
+                dWq = _empty((H * dh, D), F32, dev)
+                XNs = sv['XN']
+                side.run(lambda: ops.gemm_tn_splitk(dQ, XNs, dWq), dQ, XNs, dWq)
+                dWkv = _empty((2 * dh, D), F32, dev)
+                Xs, cx = sv['X'], (ctx.x if dKVp is not None else None)
 
-            def wkv_grad():
-                ops.gemm_tn_splitk(dKV, Xs, dWkv)
-                if dKVp is not None:
-                    ops.gemm_tn_splitk(dKVp, cx, dWkv, accumulate=True)
-            side.run(wkv_grad, *[t for t in (dKV, Xs, dWkv, dKVp, cx) if t is not None])
+                def wkv_grad():
+                    ops.gemm_tn_splitk(dKV, Xs, dWkv)
+                    if dKVp is not None:
+                        ops.gemm_tn_splitk(dKVp, cx, dWkv, accumulate=True)
+                side.run(wkv_grad, *[t for t in (dKV, Xs, dWkv, dKVp, cx) if t is not None])
             grads[ip + 1], grads[ip + 2], grads[ip + 3] = dWq, dWkv, dWo
             rec = dict(dY=dY, dAO=dAO, dQ=dQ, dkv32=dkv32, dKV=dKV, dXN=dXN, extra=extra, dWq=dWq, dWkv=dWkv, dWo=dWo) if TRACE is not None else None
 
@@ -656,7 +726,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             py, pc = (prev['Y'], prev['coef']) if prev is not None else (None, None)
             h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN, extra=extra, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=prm['ln'], R=sv['R'],
                            coef=sv['coef'], dbeta=dbeta, hc=prm['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=prev is None,
-                           r_dtype=rdt)
+                           r_dtype=rdt, dsum_scale=dx_scale if prev is None else 1.0, dy_out=dy_slot(prev) if prev is not None else None)
             if rec is not None:
                 rec.update(kind=kind, layer=l, dR_in=dR, dR_in_bcast=bcast, dbeta_in=dbeta, dR_out=h['dsum'] if prev is None else h['dR'], sum_only=prev is None,
                            dY_prev=h['dy'], dbeta_prev=h['dbeta'], hc_grads=dict(h['grads']))
@@ -670,9 +740,11 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             if rec is not None:
                 rec.update(kind=kind, layer=l, dR_in=dR, dX=dX, dln=dgl)
                 TRACE.append(rec)
-            dR = ops.add_f32(dR, dX)
+            dR = ops.add_f32(dR, dX, dx_scale if prev is None else 1.0)
             grads[ip] = dgl
         sv.clear()
+        if wg is not None and (prev is None or prev['layer'] != l) and l % gsz == 0:
+            launch_group(l)                                    # this layer closes a group: its operands (and the layers' above it) are complete
         if on_layer_grads is not None and (prev is None or prev['layer'] != l):
             # the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the critical
             # path never waits for them
@@ -736,7 +808,8 @@ class TransformerStackFn(torch.autograd.Function):
         ctx.micro = micro
         if micro == 1:
             hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
-                                      ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)))
+                                      ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)),
+                                      defer_wgrad=DEFER_WGRAD and hooks is None)
         else:
             S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
@@ -769,7 +842,7 @@ class TransformerStackFn(torch.autograd.Function):
         if dhn.dtype not in (BF16, F32):
             dhn = dhn.to(F32)
         if ctx.micro == 1:
-            dx, grads, dtbl, dctx = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias)
+            dx, grads, dtbl, dctx = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias, dx_scale=cfg.grad_shrink_alpha)
         else:
             sva, svb = ctx.saved
             h = sva['B']
@@ -780,10 +853,10 @@ class TransformerStackFn(torch.autograd.Function):
             s2.wait_stream(cur)
             # no weight-gradient side streams here: the other half already fills the idle CUs, and nested stream forks do not survive
             # hipStreamEndCapture on ROCm 7.0 (segmentation fault)
-            dxa, ga, ta, ca = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
+            dxa, ga, ta, ca = stack_backward(da, ma, flat, cfg, ctx.cache, sva, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD, dx_scale=cfg.grad_shrink_alpha)
             db.record_stream(s2)
             with torch.cuda.stream(s2):
-                dxb, gb, tb, cb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD)
+                dxb, gb, tb, cb = stack_backward(db, mb, flat, cfg, ctx.cache, svb, None, ctx.bias, async_wgrad=MICRO_ASYNC_WGRAD, dx_scale=cfg.grad_shrink_alpha)
             cur.wait_stream(s2)
             for t in [dxb, tb, cb] + gb:
                 if t is not None:
@@ -796,8 +869,7 @@ class TransformerStackFn(torch.autograd.Function):
             grads = [a if a is not None else b for a, b in zip(ga, gb)]
             dtbl = None if ta is None else ta + tb
             dctx = None if ca is None else torch.cat((ca, cb), dim=0)
-        ctx.saved = None
-        dx = dx * cfg.grad_shrink_alpha                                       # grad_shrink, audiolm_pytorch.py:93-94, :478
+        ctx.saved = None                                                      # (grad_shrink, audiolm_pytorch.py:93-94, :478: applied inside stack_backward)
         out = []
         for p, g in zip(ctx.flat, grads):
             out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)

@@ -56,6 +56,7 @@ struct GemmParams {
     long long sCk;
     int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel)
     int nsl;           // number of K slices (raster 1)
+    int nbt = 0;       // total number of batched problems nb1 * nb2 (0: nb2 -- the one-level callers); raster 1 enumerates panels over all of them
 };
 
 // ---- epilogue (shared by every GEMM kernel) --------------------------------------------------------------------------------------------
@@ -107,7 +108,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     const int row = it * RPI + lane / LPR, ch = lane % LPR;
                     const uint4 val = *reinterpret_cast<const uint4*>(slab + row * ROWB + ((ch ^ (row & (NCH - 1))) << 4));
                     const int gm = mrow0 + row, gn = ncol0 + ch * (16 / ES);
+#if defined(ALM_GEMM_WHATIF_NOSTORE)                                   // diagnostic build (scripts/gemm_probe.py nostore): WRONG results, timing only
+                    if (gm < p.M && gn < p.N && val.x == 0x7fc12345u) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
+#else
                     if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
+#endif
                 }
             }
             return;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * p.nb2;
+        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * p.nb2;
+        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * p.nb2;
+        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -920,9 +925,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 
 // ---- split-K second stage: C[b][m][n] (+)= sum_z ws[z][b][m][n]   (blockIdx.y = b)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, long long slice_stride, int N,
-                                                            float* __restrict__ C, long long ldc, long long sC, int accumulate) {
+                                                            float* __restrict__ C, long long ldc, long long sC, int accumulate,
+                                                            int nb2 = 0x40000000, long long sC1 = 0) {   // defaults: one batch level (index y, stride sC)
     ws += (long long)blockIdx.y * mn;
-    C += (long long)blockIdx.y * sC;
+    C += (long long)(blockIdx.y / nb2) * sC1 + (long long)(blockIdx.y % nb2) * sC;
     const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (mn & 3) == 0 && (slice_stride & 3) == 0;
     if (vec) {
         const long long mn4 = mn >> 2;
@@ -1292,6 +1298,42 @@ extern "C" int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C,
     if (K <= 0 || (lda & 7) || (ldb & 7) || ((sA | sB) & 7) || ((uintptr_t)At & 15) || ((uintptr_t)Bt & 15)) return ALM_ERR_BAD_ARG;
     if (view_too_big(K, lda) || view_too_big(K, ldb)) return ALM_ERR_UNSUPPORTED;
     int rc = splitk_common(true, At, Bt, C, ws, M, N, K, lda, ldb, ldc, nb, sA, sB, sC, alpha, accumulate, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Two-level batched weight gradients (round 3): C[z1][z2][M][N] fp32 (+)= alpha * At[z1][z2][K][M]^T . Bt[z1][z2][K][N] for nb1 x nb2 same-shape problems
+// with element strides (sA1, sA2) / (sB1, sB2) / (sC1, sC2) -- the form in which ALL LAYERS' gradients of one weight kind are computed in one launch at
+// the end of the backward pass from stacked activation buffers (core.stack_backward, deferred mode): enough tiles to fill the chip with long K slices,
+// i.e. few or no split-K partials and one reduce launch per kind instead of one per layer.  ws: alm_gemm_splitk_ws_floats(M, N, K, nb1 * nb2) floats.
+extern "C" int alm_gemm_bf16_tn_batched(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
+                                        long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
+                                        long long sC2, float alpha, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return 0;
+    if (K <= 0 || (lda & 7) || (ldb & 7) || ((sA1 | sA2 | sB1 | sB2) & 7) || ((uintptr_t)At & 15) || ((uintptr_t)Bt & 15)) return ALM_ERR_BAD_ARG;
+    if (view_too_big(K, lda) || view_too_big(K, ldb)) return ALM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = nb1 * nb2;
+    const SplitPlan pl = splitk_plan(M, N, K, nb);
+    int rc;
+    if (pl.slices <= 1) {
+        GemmParams p{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0,
+                     pick_raster(M, N, nb, pl.tile), 1, nb};
+        rc = launch_gemm<true>(p, nb, 1, 1, pl.tile, st);
+    } else {
+        if (!ws) return ALM_ERR_BAD_ARG;
+        int kc = (K + pl.slices - 1) / pl.slices;
+        kc = (kc + BK - 1) / BK * BK;
+        const int nsl = (K + kc - 1) / kc;
+        const long long mn = (long long)M * N;
+        GemmParams p{(const bf16_t*)At, (const bf16_t*)Bt, ws, nullptr, M, N, K, lda, ldb, (long long)N, nb2, sA1, sA2, sB1, sB2, mn * nb2, mn, alpha, 0, kc, mn * nb,
+                     pick_raster(M, N, nb, pl.tile), nsl, nb};
+        rc = launch_gemm<true>(p, nb, nsl, 1, pl.tile, st);
+        if (rc) return rc;
+        const int grid = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid, nb), dim3(256), 0, st, (const float*)ws, nsl, mn, mn * nb, N, C, ldc, sC2, accumulate, nb2, sC1);
+    }
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;

@@ -489,7 +489,8 @@ struct HcBwdArgs {
     const void* R; int r_bcast;                          // residual input of the width connection (RT [B][S][N][D], or one fp32 [B*N][D] tensor for all streams)
     const float* coef; const float* dbeta;
     HcParams hp;
-    void* dR; float* dsum;                               // dR RT [B][S][N][D] and / or dsum fp32 [B*N][D] = sum over streams of dR (gradient of the :524 expand)
+    void* dR; float* dsum; float dsum_scale;             // dR RT [B][S][N][D] and / or dsum fp32 [B*N][D] = dsum_scale * sum over streams of dR (gradient of the :524 expand; the scale
+                                                         // is grad_shrink's alpha, audiolm_pytorch.py:93-94: folded in here instead of a separate pass over dx)
     float* partial;
     const bf16_t* y; int ldy; const float* coef_prev; bf16_t* dy; int lddy; float* dbeta_out;
     int B, N, D;
@@ -806,7 +807,8 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                     float4 sm = out[0];
 #pragma unroll
                     for (int s = 1; s < S; ++s) { sm.x += out[s].x; sm.y += out[s].y; sm.z += out[s].z; sm.w += out[s].w; }
-                    *reinterpret_cast<float4*>(a.dsum + (long long)m * a.D + e0) = sm;
+                    const float ds = a.dsum_scale;
+                    *reinterpret_cast<float4*>(a.dsum + (long long)m * a.D + e0) = make_float4(sm.x * ds, sm.y * ds, sm.z * ds, sm.w * ds);
                 }
             }
         } else {
@@ -884,23 +886,30 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
 // second stage of the hyper-connection parameter gradients: column sums of the partial rows (alm_colsum) -> the gradients,
 // out layout (floats): dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D] (LayerNorm weight, fused-LN mode)
 template <int S>
-__global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __restrict__ sums, HcParams hp, float* __restrict__ out, int D) {
+__global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __restrict__ ws, int chunks, HcParams hp, float* __restrict__ out, int D) {
     constexpr int NB = S * (S + 1);
+    const long long P = (long long)D * (S + 3) + NB + S + 2;              // floats per chunk row (alm_hc_partial_width)
+    // `ws` holds `chunks` partial column sums (stage 1 of alm_colsum): summed here, in a fixed order -- the former colsum_finish launch
+    auto sums_at = [&](long long i) {
+        float v = 0.f;
+        for (int k = 0; k < chunks; ++k) v += ws[k * P + i];
+        return v;
+    };
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < D) {
         const float g1 = hp.hc_gamma[e] + 1.f;
-        float dg = hp.wb[e] * sums[(long long)(S + 1) * D + e];
+        float dg = hp.wb[e] * sums_at((long long)(S + 1) * D + e);
 #pragma unroll
         for (int t = 0; t < S + 1; ++t) {
-            const float ra = sums[(long long)t * D + e];
+            const float ra = sums_at((long long)t * D + e);
             out[(long long)e * (S + 1) + t] = g1 * ra;
             dg += hp.Wa[(long long)e * (S + 1) + t] * ra;
         }
-        out[(long long)D * (S + 1) + e] = g1 * sums[(long long)(S + 1) * D + e];
+        out[(long long)D * (S + 1) + e] = g1 * sums_at((long long)(S + 1) * D + e);
         out[(long long)D * (S + 2) + e] = dg;
-        out[(long long)D * (S + 3) + NB + S + 2 + e] = sums[(long long)(S + 2) * D + e];
+        out[(long long)D * (S + 3) + NB + S + 2 + e] = sums_at((long long)(S + 2) * D + e);
     }
-    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums[(long long)D * (S + 3) + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums_at((long long)D * (S + 3) + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -957,10 +966,11 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 }
 
 // out (fp32) = a (fp32) + b (fp32)
-__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n4) {
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n4,
+                                                      float scale) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
-        reinterpret_cast<float4*>(out)[i] = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w);
+        reinterpret_cast<float4*>(out)[i] = make_float4((v.x + w.x) * scale, (v.y + w.y) * scale, (v.z + w.z) * scale, (v.w + w.w) * scale);
     }
 }
 
@@ -1159,8 +1169,8 @@ extern "C" int alm_hc_fwd(const void* R_in, int rin_bcast, int r_bf16, const voi
 extern "C" int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const float* dx, long long lddx, const void* dxn, long long lddxn, const void* extra,
                           long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const void* R, int r_bcast,
                           const float* coef, const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb,
-                          const float* sb, void* dR, float* dsum, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy, long long lddy,
-                          float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
+                          const float* sb, void* dR, float* dsum, float dsum_scale, float* partial, const void* y_prev, long long ldy, const float* coef_prev, void* dy,
+                          long long lddy, float* dbeta_out, int mode, int B, int S, int N, int D, void* stream) {
     if ((D & 3) || D > 1024 || (lddx & 3) || (lddxn & 3) || (ldex & 3) || (ldy & 3) || (lddy & 3) || !dRn) return ALM_ERR_BAD_ARG;
     const bool lnf = dxn != nullptr;
     if ((mode & 2) && (!R || !coef || !dbeta || !hc_gamma || !Wa || !sa || !wb || !sb || !(dR || dsum) || !partial)) return ALM_ERR_BAD_ARG;
@@ -1169,7 +1179,7 @@ extern "C" int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const floa
     if ((mode & 1) && (!y_prev || !coef_prev || !dy || !dbeta_out)) return ALM_ERR_BAD_ARG;
     if (((lddx | lddxn | ldex | ldy | lddy) >> 31) || (long long)B * N >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;   // row strides / token index travel as int
     HcBwdArgs a{dRn, dRn_bcast, dx, (int)lddx, (const bf16_t*)dxn, (int)lddxn, (const bf16_t*)extra, (int)ldex, mean, rstd, ln_gamma, R, r_bcast, coef, dbeta,
-                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, partial, (const bf16_t*)y_prev, (int)ldy, coef_prev, (bf16_t*)dy, (int)lddy, dbeta_out,
+                HcParams{hc_gamma, Wa, sa, nullptr, wb, sb, nullptr}, dR, dsum, dsum_scale, partial, (const bf16_t*)y_prev, (int)ldy, coef_prev, (bf16_t*)dy, (int)lddy, dbeta_out,
                 B, N, D};
     const int rc = r_bf16 ? dispatch_bwd_s<bf16_t>(a, S, mode, lnf, (hipStream_t)stream) : dispatch_bwd_s<float>(a, S, mode, lnf, (hipStream_t)stream);
     if (rc) return rc;
@@ -1179,13 +1189,14 @@ extern "C" int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const floa
 
 // sums: column sums (alm_colsum) of the partial rows.  out: alm_hc_grads_width(S, D) floats:
 // dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]
-extern "C" int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D,
+extern "C" int alm_hc_param_grads(const float* sums, int chunks, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D,
                                   void* stream) {
+    if (chunks < 1) return ALM_ERR_BAD_ARG;
     HcParams hp{hc_gamma, Wa, nullptr, nullptr, wb, nullptr, nullptr};
     const int grid = (D + 255) / 256;
-    if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
-    else if (S == 3) hipLaunchKernelGGL(hc_param_grads_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
-    else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, hp, out, D);
+    if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
+    else if (S == 3) hipLaunchKernelGGL(hc_param_grads_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
+    else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
     else return ALM_ERR_UNSUPPORTED;
     ALM_LAUNCH_CHECK();
     return 0;
@@ -1227,11 +1238,11 @@ extern "C" int alm_f32_to_bf16(const float* a, const float* b, void* out, long l
     return 0;
 }
 
-extern "C" int alm_add_f32(const float* a, const float* b, float* out, long long n, void* stream) {
+extern "C" int alm_add_f32(const float* a, const float* b, float* out, long long n, float scale, void* stream) {
     if (n & 3) return ALM_ERR_BAD_ARG;
     const long long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(add_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n4);
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n4, scale);
     ALM_LAUNCH_CHECK();
     return 0;
 }

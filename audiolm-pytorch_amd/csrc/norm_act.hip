@@ -493,6 +493,18 @@ extern "C" int alm_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, 
     return 0;
 }
 
+// stage 1 alone: ws[alm_colsum_chunks(rows)][cols] partial column sums (fp32 input); a consumer that sums the chunk rows itself (alm_hc_param_grads)
+// saves the finish launch
+extern "C" int alm_colsum_chunks(int rows);
+extern "C" int alm_colsum_partial(const float* in, long long ld, int rows, int cols, float* ws, void* stream) {
+    if (cols <= 0 || rows <= 0 || !ws) return ALM_ERR_BAD_ARG;
+    const int chunks = alm_colsum_chunks(rows);
+    const int rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, in, ld, rows, cols, ws, 1.f, 0, rpc, 0);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
 // number of row chunks stage 1 uses; the caller provides `ws` = alm_colsum_chunks(rows) * cols floats when that is > 1
 extern "C" int alm_colsum_chunks(int rows) { return rows <= 128 ? 1 : min(16, (rows + 63) / 64); }
 

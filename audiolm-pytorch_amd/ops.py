@@ -101,6 +101,24 @@ def gemm_tn_splitk(At, Bt, C, *, alpha=1.0, accumulate=False):
     return _splitk('alm_gemm_bf16_tn_splitk', At, Bt, C, M, N, K, nb, sA, 0, sC, alpha, accumulate)
 
 
+def gemm_tn_batched(At, Bt, C, *, alpha=1.0, accumulate=False):
+    """fp32 C[n1, n2, M, N] (+)= alpha * At[n1, n2, K, M]^T @ Bt[n1, n2, K, N]: 4-D strided views (last dim contiguous; a size-1 / stride-0 leading dim of Bt
+    broadcasts), e.g. every layer's gradient of one weight kind from stacked activation buffers in ONE launch."""
+    _chk(At, BF16), _chk(Bt, BF16), _chk(C, F32)
+    assert At.dim() == 4 and Bt.dim() == 4 and C.dim() == 4 and At.stride(-1) == 1 and Bt.stride(-1) == 1 and C.stride(-1) == 1
+    n1, n2, K, M = At.shape
+    N = Bt.shape[-1]
+    assert Bt.shape[-2] == K and tuple(C.shape) == (n1, n2, M, N), (At.shape, Bt.shape, C.shape)
+    sb = [Bt.stride(0) if Bt.shape[0] != 1 else 0, Bt.stride(1) if Bt.shape[1] != 1 else 0]
+    nws = _lib.query('alm_gemm_splitk_ws_floats', M, N, K, n1 * n2)
+    if nws < 0:
+        raise _lib.AlmError('split-K workspace exceeds 2^31 floats')
+    ws = torch.empty(nws, dtype=F32, device=At.device) if nws > 0 else None
+    _lib.call('alm_gemm_bf16_tn_batched', At.data_ptr(), Bt.data_ptr(), C.data_ptr(), _p(ws), M, N, K, At.stride(-2), Bt.stride(-2), C.stride(-2), n1, n2,
+              At.stride(0), At.stride(1), sb[0], sb[1], C.stride(0), C.stride(1), float(alpha), int(accumulate), _st())
+    return C
+
+
 def gemm_nt_tile(A, B, C, tile, *, bias=None, alpha=1.0, accumulate=False):
     """un-batched gemm_nt with an explicit tile configuration (0 auto, 1 = 128x128, 2 = 256x256): tuning / benchmarks."""
     _chk(A, BF16), _chk(B, BF16), _chk(C)
@@ -143,12 +161,13 @@ def pack_weights_multi(jobs):
 
 # ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
 
-def layernorm_fwd(x, gamma, *, want_copy=False, out_f32=False):
+def layernorm_fwd(x, gamma, *, want_copy=False, out_f32=False, y_out=None, xc_out=None):
     """x [rows, D] fp32|bf16 -> (y bf16 (fp32 with out_f32: the final LayerNorm feeding the logit heads), xcopy bf16|None, mean, rstd)."""
     _chk(x)
     rows, D, ld = _rows_ld(x)
-    y = torch.empty((rows, D), dtype=F32 if out_f32 else BF16, device=x.device)
-    xc = torch.empty((rows, D), dtype=BF16, device=x.device) if want_copy else None
+    y = torch.empty((rows, D), dtype=F32 if out_f32 else BF16, device=x.device) if y_out is None else y_out
+    xc = (torch.empty((rows, D), dtype=BF16, device=x.device) if xc_out is None else xc_out) if want_copy else None
+    assert y.shape == (rows, D) and y.is_contiguous() and (xc is None or (xc.shape == (rows, D) and xc.is_contiguous()))
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
     _lib.call('alm_layernorm_fwd', x.data_ptr(), int(x.dtype == BF16), ld, gamma.data_ptr(), y.data_ptr(), int(out_f32), D, _p(xc), D, mean.data_ptr(),
@@ -202,11 +221,13 @@ def geglu_bwd(dy, x):
     return dx
 
 
-def geglu_ln_fwd(u, gamma, inner, inner_pad):
-    """u bf16 [rows, 2 * inner_pad] (x | gate halves) -> (hn bf16 [rows, inner_pad], mean, rstd)."""
+def geglu_ln_fwd(u, gamma, inner, inner_pad, out=None):
+    """u bf16 [rows, 2 * inner_pad] (x | gate halves) -> (hn bf16 [rows, inner_pad] (written into `out` when given), mean, rstd)."""
     _chk(u, BF16)
     rows, _, ldu = _rows_ld(u)
-    out = torch.empty((rows, inner_pad), dtype=BF16, device=u.device)
+    if out is None:
+        out = torch.empty((rows, inner_pad), dtype=BF16, device=u.device)
+    assert out.shape == (rows, inner_pad) and out.dtype == BF16 and out.stride(1) == 1 and out.stride(0) == inner_pad
     mean = torch.empty(rows, dtype=F32, device=u.device)
     rstd = torch.empty(rows, dtype=F32, device=u.device)
     _lib.call('alm_geglu_ln_fwd', u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), out.data_ptr(), inner_pad, mean.data_ptr(), rstd.data_ptr(),
@@ -214,10 +235,11 @@ def geglu_ln_fwd(u, gamma, inner, inner_pad):
     return out, mean, rstd
 
 
-def geglu_ln_bwd(dhn, u, gamma, mean, rstd, inner, inner_pad):
-    """-> (du bf16 [rows, 2 * inner_pad], dgamma [inner])."""
+def geglu_ln_bwd(dhn, u, gamma, mean, rstd, inner, inner_pad, du_out=None):
+    """-> (du bf16 [rows, 2 * inner_pad] (written into `du_out` when given: same shape and row stride as u), dgamma [inner])."""
     rows, _, ldu = _rows_ld(u)
-    du = torch.empty_like(u)
+    du = torch.empty_like(u) if du_out is None else du_out
+    assert du.shape == u.shape and du.stride(0) == ldu and du.stride(1) == 1 and du.dtype == BF16
     nblk = _lib.query('alm_geglu_partial_blocks', rows)
     part = torch.empty((nblk, inner), dtype=F32, device=u.device)
     _lib.call('alm_geglu_ln_bwd', dhn.data_ptr(), dhn.stride(0), u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
@@ -249,12 +271,14 @@ def attn_bias_grad_reduce(part, B, N, H, dim_head=64):
     return dtbl
 
 
-def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., seed=0):
+def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., seed=0, o=None):
     """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse).
     bias: structured score bias (see alm_mqa_attn_bias_fwd) or None.  dropout_p > 0: attention dropout with the mask stream `seed` (the
     backward must get the same pair)."""
     _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
-    o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
+    if o is None:
+        o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
+    assert o.shape == (B * N, H * dim_head) and o.dtype == BF16 and o.stride(1) == 1
     lse = torch.empty((B, H, N), dtype=F32, device=q.device)
     if bias is not None:
         _lib.call('alm_mqa_attn_bias_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
@@ -265,11 +289,12 @@ def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., s
     return o, lse
 
 
-def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None, dropout_p=0., seed=0):
+def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None, dropout_p=0., seed=0, dq_out=None):
     """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them).
     With `bias`, the table gradient is accumulated into dtbl_part (attn_bias_part)."""
     _chk(dout, BF16)
-    dq = torch.empty_like(q)
+    dq = torch.empty_like(q) if dq_out is None else dq_out
+    assert dq.shape == q.shape and dq.dtype == BF16 and dq.stride(1) == 1
     hg = _lib.query('alm_mqa_head_groups', H)
     dkv = torch.empty((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
     delta = torch.empty((2, B, H, N), dtype=F32, device=q.device)
@@ -319,12 +344,14 @@ def value_residual_mix(v, v0):
     return out
 
 
-def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64):
+def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64, out=None):
     """dkv_f32: [rows, 2*dh] or per-head-group partials [HG, rows, 2*dh] (summed here) -> bf16 [rows, 2*dh]."""
     if dkv_f32.dim() == 2:
         dkv_f32 = dkv_f32.unsqueeze(0)
     nparts, rows = dkv_f32.shape[0], dkv_f32.shape[1]
-    out = torch.empty((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
+    if out is None:
+        out = torch.empty((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
+    assert out.shape == (rows, 2 * dim_head) and out.dtype == BF16 and out.stride(1) == 1
     _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(1), nparts, dkv_f32.stride(0),
               _p(acc_v0), out.data_ptr(), out.stride(0), rows, dim_head, mode, _st())
     return out
@@ -401,7 +428,7 @@ _HC_KEYS7 = ('gamma', 'Wa', 'sa', 'Aa', 'wb', 'sb', 'Bb')
 
 
 def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=None, final=False, want_x=True, rin_bcast=False, r_dtype=F32,
-           final_f32=False):
+           final_f32=False, x_out=None, xn_out=None):
     """Hyper-connection forward pass over the residual streams R_in [B, S, N, D] (C ABI: alm_hc_fwd).
       y_prev / coef_prev given : depth connection of the previous branch (R = mix(R_in) + beta * y_prev)
       hc given                 : width connection + pre-LayerNorm of the next branch on that R
@@ -420,11 +447,13 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
         if final and final_f32:
             xn32 = torch.empty((M, D), dtype=F32, device=dev)
         else:
-            xn = torch.empty((M, D), dtype=BF16, device=dev)
+            xn = torch.empty((M, D), dtype=BF16, device=dev) if xn_out is None else xn_out
+            assert xn.shape == (M, D) and xn.dtype == BF16 and xn.is_contiguous()
         mean = torch.empty(M, dtype=F32, device=dev)
         rstd = torch.empty(M, dtype=F32, device=dev)
     if width:
-        x = torch.empty((M, D), dtype=BF16, device=dev) if want_x else None
+        x = (torch.empty((M, D), dtype=BF16, device=dev) if x_out is None else x_out) if want_x else None
+        assert x is None or (x.shape == (M, D) and x.dtype == BF16 and x.is_contiguous())
         coef = torch.empty((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
     if final:
         xs = torch.empty((M, D), dtype=F32, device=dev)
@@ -436,14 +465,14 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
 
 
 def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=None, rstd=None, ln_gamma=None, R=None, coef=None, dbeta=None,
-           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False, r_dtype=F32):
+           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False, r_dtype=F32, dsum_scale=1.0, dy_out=None):
     """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D] (r_dtype), or with
     bcast fp32 [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
     gradient wrt the branch input is either `dx` (fp32, LayerNorm backward already applied) or `dxn` (bf16, wrt the LayerNorm output) +
     optional `extra` (bf16, added to dx) + mean / rstd / ln_gamma: then the LayerNorm backward is fused (grads['ln'] = its weight gradient).
     y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
     r_bcast: R is one fp32 [B*N, D] tensor for all streams; sum_only: return dsum fp32 [B*N, D] = sum over streams of dR instead of dR.
-    r_dtype: storage type of dRn / R / dR (the non-bcast forms).
+    r_dtype: storage type of dRn / R / dR (the non-bcast forms).  dsum_scale: factor on dsum (grad_shrink's alpha rides here).
     -> dict(dR, dsum, grads, dy, dbeta)."""
     width, depth = hc is not None, y_prev is not None
     mode = (2 if width else 0) | (1 if depth else 0)
@@ -463,18 +492,24 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
         P = _lib.query('alm_hc_partial_width', S, D)
         part = torch.empty((rows, P), dtype=F32, device=dev)
     if depth:
-        dy = torch.empty((M, D), dtype=BF16, device=dev)
+        dy = torch.empty((M, D), dtype=BF16, device=dev) if dy_out is None else dy_out
+        assert dy.shape == (M, D) and dy.dtype == BF16 and dy.is_contiguous()
         dbo = torch.empty((M, S), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
     _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), rbf, _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
               dxn.stride(0) if dxn is not None else 0, _p(extra), extra.stride(0) if extra is not None else 0, _p(mean), _p(rstd), _p(ln_gamma),
-              _p(R), int(r_bcast), _p(coef), _p(dbeta), *hp, _p(dR), _p(dsum), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
+              _p(R), int(r_bcast), _p(coef), _p(dbeta), *hp, _p(dR), _p(dsum), float(dsum_scale), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
               mode, B, S, N, D, _st())
     grads = None
     if width:
-        sums = colsum(part)
+        chunks = _lib.query('alm_colsum_chunks', rows)
+        if chunks > 1:                                       # stage 1 of the column sums; the chunk rows are summed inside alm_hc_param_grads
+            ws = torch.empty((chunks, P), dtype=F32, device=dev)
+            _lib.call('alm_colsum_partial', part.data_ptr(), P, rows, P, ws.data_ptr(), _st())
+        else:
+            ws = colsum(part)
         g = torch.empty(_lib.query('alm_hc_grads_width', S, D), dtype=F32, device=dev)
-        _lib.call('alm_hc_param_grads', sums.data_ptr(), hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['wb'].data_ptr(), g.data_ptr(), S, D, _st())
+        _lib.call('alm_hc_param_grads', ws.data_ptr(), chunks, hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['wb'].data_ptr(), g.data_ptr(), S, D, _st())
         o = 0
         grads = {}
         for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ()), ('ln', (D,))):
@@ -529,16 +564,19 @@ def residual_add(x, y):
     return out
 
 
-def f32_to_bf16(a, b=None):
+def f32_to_bf16(a, b=None, out=None):
     rows, D = a.shape
-    out = torch.empty((rows, D), dtype=BF16, device=a.device)
+    if out is None:
+        out = torch.empty((rows, D), dtype=BF16, device=a.device)
+    assert out.shape == (rows, D) and out.dtype == BF16 and out.is_contiguous()
     _lib.call('alm_f32_to_bf16', a.data_ptr(), _p(b), out.data_ptr(), D, rows, D, _st())
     return out
 
 
-def add_f32(a, b):
+def add_f32(a, b, scale=1.0):
+    """(a + b) * scale, fp32"""
     out = torch.empty_like(a)
-    _lib.call('alm_add_f32', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st())
+    _lib.call('alm_add_f32', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), float(scale), _st())
     return out
 
 

@@ -382,7 +382,7 @@ def main():
     # collectives); only rank 0's numbers are reported.
     roof = None
     events = []                                                  # (start event, end event, algorithmic work, unit, kernel key)
-    timed_names = ('gemm_nt', 'gemm_tn_splitk', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
+    timed_names = ('gemm_nt', 'gemm_tn_splitk', 'gemm_tn_batched', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
                    'layernorm_bwd')
     originals = {n: getattr(ops, n) for n in timed_names}
 
@@ -408,6 +408,11 @@ def main():
             fl = 2.0 * nb * At.shape[-1] * Bt.shape[-1] * At.shape[-2]
             from audiolm_pytorch_amd import _lib as _L
             return fl, 'flop', ('tn128' if _L.query('alm_gemm_splitk_tile', At.shape[-1], Bt.shape[-1], At.shape[-2], nb) == 1 else 'tn256')
+        if name == 'gemm_tn_batched':                                            # every layer's gradient of one weight kind in one launch
+            At, Bt = a[0], a[1]
+            n1, n2, Kk, Mm = At.shape
+            from audiolm_pytorch_amd import _lib as _L
+            return 2.0 * n1 * n2 * Mm * Bt.shape[-1] * Kk, 'flop', ('tn128' if _L.query('alm_gemm_splitk_tile', Mm, Bt.shape[-1], Kk, n1 * n2) == 1 else 'tn256')
         if name in ('mqa_attn_fwd', 'mqa_attn_bwd'):
             Bq, Nq, Hq, dh = (a[4], a[5], a[6], a[7] if len(a) > 7 else 64) if name == 'mqa_attn_fwd' else (a[7], a[8], a[9], a[10] if len(a) > 10 else 64)
             fwd = 4.0 * Hq * dh * Nq * (Nq + 1) / 2 * Bq                            # causal: QK^T + PV over the lower triangle
@@ -479,7 +484,7 @@ def main():
     PEAK_HBM_GBS = 8000.0
     desc = {'nt256': 'gemm_stag_kernel<NT> 256x256 / gemm_kernel<384,256,NT>: forward + dgrad GEMMs on the big tiles (dominant)',
             'nt128': 'NT GEMMs on the 128x128 tile or grouped launches (attention projections, logit heads)',
-            'tn256': 'gemm_stag_kernel<TN>: weight gradients on the big tile (split-K)', 'tn128': 'weight gradients on the 128x128 tile / grouped (split-K)',
+            'tn256': 'gemm_stag_kernel<TN>: weight gradients on the big tile, all layers of a weight kind per launch (deferred mode) or split-K per layer', 'tn128': 'weight gradients on the 128x128 tile (split-K)',
             'mqa_fwd': 'mqa_fwd_kernel (causal flash attention forward)', 'mqa_bwd': 'attn_delta + mqa_bwd_dq + mqa_bwd_dkv (flash attention backward)',
             'hc_fwd': 'hc_fwd_kernel (depth + width connection + pre-LayerNorm, fused)', 'hc_bwd': 'hc_bwd_kernel (+ its colsum / param-grad launches)',
             'geglu_ln_fwd': 'geglu_ln_fwd_kernel', 'geglu_ln_bwd': 'geglu_ln_bwd_kernel (+ colsum)', 'layernorm_fwd': 'ln_fwd_kernel', 'layernorm_bwd': 'ln_bwd_kernel (+ colsum)'}

@@ -49,6 +49,12 @@ int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, i
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
+/* two-level batched _tn_ form: C[z1][z2] (+)= alpha * At[z1][z2]^T . Bt[z1][z2] for nb1 x nb2 same-shape problems (element strides per level): every
+ * layer's gradient of one weight kind in ONE launch from stacked activation buffers (the deferred weight-gradient mode of the fused backward).
+ * ws: alm_gemm_splitk_ws_floats(M, N, K, nb1 * nb2) floats (NULL when that is 0). */
+int alm_gemm_bf16_tn_batched(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                             int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2, float alpha,
+                             int accumulate, void* stream);
 /* dst[c][r] = src[r][c]; columns [rows, rows_pad) of dst are zero-filled (K-padding of a transposed GEMM operand). */
 int alm_transpose_bf16(const void* src, void* dst, int rows, int cols, long long ld_src, long long ld_dst, int rows_pad, void* stream);
 /* nb matrices (element strides bs_src / bs_dst) in ONE launch: the per-sequence key / value sets of a conditioning context (xattn.py). */
@@ -78,6 +84,8 @@ int alm_layernorm_bwd(const void* dy, int dy_is_f32, long long lddy, const void*
 int alm_colsum(const void* in, int in_is_bf16, long long ld, int rows, int cols, float* out, float scale, int accumulate, float* ws,
                void* stream);          /* ws: alm_colsum_chunks(rows) * cols floats (two-stage reduction of tall inputs) or NULL */
 int alm_colsum_chunks(int rows);
+/* stage 1 alone: ws[alm_colsum_chunks(rows)][cols] partial column sums of an fp32 matrix (the consumer sums the chunk rows: alm_hc_param_grads) */
+int alm_colsum_partial(const float* in, long long ld, int rows, int cols, float* ws, void* stream);
 
 /* ---- GEGLU + inner LayerNorm: audiolm_pytorch.py:246-260 (gate = second half, exact-erf GELU, LN over int(dim*8/3)) -------- */
 /* standalone GEGLU module (audiolm_pytorch.py:246-249) on fp32 rows [rows][2 inner] -> [rows][inner]: y = x * gelu(gate), gate = the second half */
@@ -193,19 +201,19 @@ int alm_hc_fwd(const void* R_in, int rin_bcast, int r_bf16, const void* y_prev_b
  * mode, dx == NULL -- as dxn (bf16, gradient wrt the LayerNorm OUTPUT) + optional extra (bf16, added to dx directly: the K/V path of
  * the attention branch) + the LayerNorm statistics / weight: the LayerNorm backward (audiolm_pytorch.py:191-198 autograd) then happens
  * inside this kernel and its weight gradient joins the outputs.
- * partial: [alm_hc_partial_rows(mode, dx == NULL, r_bf16, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum -> alm_hc_param_grads, whose
+ * partial: [alm_hc_partial_rows(mode, dx == NULL, r_bf16, S, B*N, D)][alm_hc_partial_width(S, D)] floats -> alm_colsum_partial (`chunks` partial sums) -> alm_hc_param_grads(sums, chunks, ...), whose
  * output is dWa[D][S+1] | dwb[D] | dgamma[D] | dAa[S][S+1] | dBb[S] | dsa | dsb | dln[D]  (alm_hc_grads_width(S, D) floats). */
 int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const float* dx, long long lddx, const void* dxn_bf16, long long lddxn,
                const void* extra_bf16, long long ldex, const float* mean, const float* rstd, const float* ln_gamma, const void* R, int r_bcast,
                const float* coef, const float* dbeta, const float* hc_gamma, const float* Wa, const float* sa, const float* wb, const float* sb,
-               void* dR, float* dsum, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy,
+               void* dR, float* dsum, float dsum_scale, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy,
                float* dbeta_out, int mode, int B, int S, int N, int D, void* stream);
-int alm_hc_param_grads(const float* sums, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
+int alm_hc_param_grads(const float* sums, int chunks, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
 int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */
 int alm_residual_add(const float* x, const void* y_bf16, long long ldy, float* out, long long rows, int D, void* stream);
 int alm_f32_to_bf16(const float* a, const float* b_or_null, void* out_bf16, long long ldo, long long rows, int D, void* stream);
-int alm_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
+int alm_add_f32(const float* a, const float* b, float* out, long long n, float scale, void* stream);   /* out = (a + b) * scale */
 
 /* ---- token-id side: embedding assembly (:709-713, :894-918, :1186-1223), logit-head regrouping (:965-983, :1325-1361),
  *      cross-entropy (:1561-1565, :1839-1849, :2122-2132) -------------------------------------------------------------------- */

@@ -676,3 +676,30 @@ def test_package_import_before_torch():
             "torch.cuda.synchronize()\nassert torch.isfinite(out[0].float()).all()\nprint('import-order-ok')\n")
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'import-order-ok' in r.stdout, (r.stdout[-300:], r.stderr[-800:])
+
+
+def test_gemm_tn_batched_two_level_strided(ops):
+    """alm_gemm_bf16_tn_batched: C[l][h] = At[l][h]^T @ Bt[l][(h)] over strided 4-D views -- the stacked-buffer form of the deferred weight gradients
+    (dW1: the x / gate halves of dU against the layer's XN, Bt broadcast over the halves; dW2: padded HN columns sliced off)."""
+    L, M, I, Ip, D = 3, 1000, 170, 176, 128
+    dU = rnd(L, M, 2 * Ip, seed=501, dtype=BF16)
+    XN = rnd(L, M, D, seed=502, dtype=BF16)
+    C = torch.empty((L, 2, I, D), dtype=torch.float32, device=dev())
+    At = dU.view(L, M, 2, Ip).permute(0, 2, 1, 3)[..., :I]
+    ops.gemm_tn_batched(At, XN.unsqueeze(1), C)
+    ref = torch.einsum('lhki,lkd->lhid', At.float(), XN.float())
+    assert relmax(C, ref) <= 2e-5, relmax(C, ref)
+    HN = rnd(L, M, Ip, seed=503, dtype=BF16)
+    dY = rnd(L, M, D, seed=504, dtype=BF16)
+    C2 = torch.empty((L, 1, D, I), dtype=torch.float32, device=dev())
+    ops.gemm_tn_batched(dY.unsqueeze(1), HN[..., :I].unsqueeze(1), C2)
+    ref2 = torch.einsum('lkd,lki->ldi', dY.float(), HN[..., :I].float())
+    assert relmax(C2[:, 0], ref2) <= 2e-5
+    # a long contraction that takes the split-K path, accumulate on top
+    K = 9000
+    A3, B3 = rnd(2, 1, K, 64, seed=505, dtype=BF16), rnd(2, 1, K, 256, seed=506, dtype=BF16)
+    C3 = rnd(2, 1, 64, 256, seed=507)
+    base = C3.clone()
+    ops.gemm_tn_batched(A3, B3, C3, alpha=0.5, accumulate=True)
+    ref3 = base.double() + 0.5 * torch.einsum('lhkm,lhkn->lhmn', A3.double(), B3.double())
+    assert relmax(C3, ref3) <= 2e-5
