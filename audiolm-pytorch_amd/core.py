@@ -492,6 +492,7 @@ ASYNC_KV = os.environ.get('ALM_ASYNC_KV', '0') != '0'                # forward: 
 # chip full).  Used when nothing needs a layer's gradients early (no data-parallel hook) and no dropout mask sits on the operands.
 DEFER_WGRAD = os.environ.get('ALM_DEFER_WGRAD', '1') != '0'
 DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '2')))
+DEFER_GROUPS_CAPTURE = max(1, int(os.environ.get('ALM_DEFER_GROUPS_CAPTURE', '1')))      # see stack_backward
 MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
@@ -586,8 +587,14 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         # the weight gradients of a GROUP of layers, one launch per weight kind (ops.gemm_tn_batched: C[l] = At[l]^T @ Bt[l], K = all tokens), issued on
         # the side stream as soon as the backward has passed the group's lowest layer: the upper groups run under the remaining layers' kernels,
         # only the last group is exposed.  ALM_DEFER_GROUPS = number of groups (1: everything at the end).
+        # Inside a hipGraph capture ONE group at the end: with the first group forked in the middle of the backward pass (any kernel node on the side
+        # branch while the capturing stream goes on, even one that only zeroes an unrelated buffer) the replays of the captured step came out corrupted on
+        # ROCm 7.2 (NaN gradients, sometimes a wrong loss; scripts/debug/graph_defer_groups.py with ALM_DEFER_GROUPS_CAPTURE=2 reproduces; a join right after
+        # the group, or no side stream, cures it; the same fork-twice pattern in pure torch, scripts/ubench/capture_fork_twice.py, replays correctly).
+        # Not root-caused.  A replay has no host issue to hide, so the early start is worth nothing there anyway.
         L = cfg.depth
-        gsz = (L + DEFER_GROUPS - 1) // DEFER_GROUPS
+        ngroups = DEFER_GROUPS_CAPTURE if (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()) else DEFER_GROUPS
+        gsz = (L + ngroups - 1) // ngroups
         wg = dict(dW1=_empty((L, 2, I, D), F32, dev), dW2=_empty((L, 1, D, I), F32, dev), dWo=_empty((L, 1, D, H * dh), F32, dev),
                   dWq=_empty((L, 1, H * dh, D), F32, dev), dWkv=_empty((L, 1, 2 * dh, D), F32, dev))
 
