@@ -490,8 +490,13 @@ ASYNC_KV = os.environ.get('ALM_ASYNC_KV', '0') != '0'                # forward: 
 # weight gradients need (dU, dY, dQ, dKV; XN, X, AO, HN from the forward) are written into buffers STACKED over the layers, and each weight kind is
 # computed for all layers at once at the end of the backward pass (ops.gemm_tn_batched: 5 launches instead of 30 + 30 reduces, long K slices, the
 # chip full).  Used when nothing needs a layer's gradients early (no data-parallel hook) and no dropout mask sits on the operands.
+# ALM_DEFER_GROUPS: the layers can be cut into groups whose GEMMs start as soon as the backward has passed them (2 groups measured 0.04 ms better than 1
+# with the uniform split-K plan; with the hybrid plan of alm_gemm_bf16_tn_batched all 6 layers in one group are 0.27 ms / step better: 528 and 264 tiles
+# are whole waves of the chip plus a small tail, 3 layers of dW2 are 132 tiles and fall back to the uniform plan).
+# Tried and dropped: re-packing every layer's bf16 weight copies on a side stream at the start of the step (so that the 35-us packs of layers 1..5 run
+# under layer 0's kernels): +0.26 ms / step on three interleaved runs -- the HBM-bound packs slow the critical kernels more than they hide.
 DEFER_WGRAD = os.environ.get('ALM_DEFER_WGRAD', '1') != '0'
-DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '2')))
+DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '1')))
 DEFER_GROUPS_CAPTURE = max(1, int(os.environ.get('ALM_DEFER_GROUPS_CAPTURE', '1')))      # see stack_backward
 MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over

@@ -57,6 +57,7 @@ struct GemmParams {
     int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel)
     int nsl;           // number of K slices (raster 1)
     int nbt = 0;       // total number of batched problems nb1 * nb2 (0: nb2 -- the one-level callers); raster 1 enumerates panels over all of them
+    int plimit = 0;    // raster 1: > 0 = launch only the first `plimit` panels (alm_gemm_bf16_tn_batched: whole waves at full K, the tail separately)
 };
 
 // ---- epilogue (shared by every GEMM kernel) --------------------------------------------------------------------------------------------
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
+        const int P = p.plimit > 0 ? p.plimit : tmaj * (p.nbt > 0 ? p.nbt : p.nb2);   // plimit: only the first panels (hybrid full-K + tail launch)
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
+        const int P = p.plimit > 0 ? p.plimit : tmaj * (p.nbt > 0 ? p.nbt : p.nb2);   // plimit: only the first panels (hybrid full-K + tail launch)
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
-        const int P = tmaj * (p.nbt > 0 ? p.nbt : p.nb2);
+        const int P = p.plimit > 0 ? p.plimit : tmaj * (p.nbt > 0 ? p.nbt : p.nb2);   // plimit: only the first panels (hybrid full-K + tail launch)
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
@@ -1085,7 +1086,7 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     if (p.raster == 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
-        const int PL = (tmaj * ny + 7) / 8;
+        const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(WM * WN * 64), smem, st, p);
         return 0;
     }
@@ -1106,7 +1107,7 @@ int launch_stag(const GemmParams& p, int ny, int nz, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
     if (p.raster == 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
-        const int PL = (tmaj * ny + 7) / 8;
+        const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(512), smem, st, p);
         return 0;
     }
@@ -1128,7 +1129,7 @@ int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
     if (p.raster == 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
-        const int PL = (tmaj * ny + 7) / 8;
+        const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(256), smem, st, p);
         return 0;
     }
@@ -1212,6 +1213,46 @@ SplitPlan splitk_plan(int M, int N, int K, int nb) {
     return best;
 }
 
+// Hybrid plan of the layer-batched weight gradients (alm_gemm_bf16_tn_batched): when the 256 x 256 tiles of all problems fill the chip's 256 CUs a
+// whole number of times plus a SMALL remainder (dW1 of 3 layers: 264 tiles), the uniform split-K plan pays for the remainder with partials of
+// EVERYTHING (4 slices: 5 waves of K/4 + 270 MB of fp32 partials).  Instead: the first panels_a panels (whole waves) run at full K straight into C,
+// and the remaining row (column) blocks -- they all lie in the LAST problem -- are one ordinary split-K launch, sliced deep enough to occupy the chip
+// once.  panels_a == 0: not applicable (use the uniform plan).
+struct HybridPlan { int panels_a, m_major, off, slices_b; };
+HybridPlan hybrid_plan(int M, int N, int K, int nb) {
+    static const int off_switch = [] { const char* e = getenv("ALM_GEMM_HYBRID"); return e ? atoi(e) : 1; }();    // A/B switch (0: uniform plan)
+    HybridPlan none{0, 0, 0, 0};
+    if (!off_switch || M < 256 || N < 256 || K < 4096) return none;
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+    const int m_major = tm >= tn, tmaj = m_major ? tm : tn, Q = m_major ? tn : tm;
+    const int P = tmaj * nb, total = P * Q;
+    if (total <= 256) return none;
+    const int panels_a = (total / 256) * 256 / Q;                 // whole waves of 256 tiles (Q tiles per panel)
+    const int rem = P - panels_a;
+    if (panels_a * Q % 256 != 0 || rem <= 0 || rem >= tmaj || rem * Q > 64) return none;    // the tail must be small and inside the last problem
+    const int off = (tmaj - rem) * 256;
+    int s = 256 / (rem * Q);                                      // tail tiles x slices ~ one wave of the chip
+    const int ksteps = (K + BK - 1) / BK;
+    while (s > 1 && ksteps / s < 8) --s;                          // at least 8 K-steps per slice
+    if (s < 2) return none;
+    return HybridPlan{panels_a, m_major, off, s};
+}
+
+// one TN split-K problem with a GIVEN number of slices (the tail of the hybrid plan): partials into ws [slices][M][N], then the fixed-order reduce
+int splitk_fixed(const bf16_t* At, const bf16_t* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb, long long ldc, int slices,
+                 float alpha, int accumulate, hipStream_t st) {
+    int kc = (K + slices - 1) / slices;
+    kc = (kc + BK - 1) / BK * BK;
+    const int nsl = (K + kc - 1) / kc;
+    const long long mn = (long long)M * N;
+    GemmParams p{At, Bt, ws, nullptr, M, N, K, lda, ldb, (long long)N, 1, 0, 0, 0, 0, 0, mn, alpha, 0, kc, mn, 0, nsl, 1};
+    int rc = launch_gemm<true>(p, 1, nsl, 1, 13, st);
+    if (rc) return rc;
+    const int grid = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid, 1), dim3(256), 0, st, (const float*)ws, nsl, mn, mn, N, C, ldc, 0LL, accumulate);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda,
@@ -1253,7 +1294,13 @@ extern "C" int alm_gemm_splitk_tile(int M, int N, int K, int nb) { return splitk
 extern "C" int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb) {
     nb = nb < 1 ? 1 : nb;
     const SplitPlan pl = splitk_plan(M, N, K, nb);
-    const long long fl = pl.slices > 1 ? (long long)pl.slices * nb * M * N : 0;
+    long long fl = pl.slices > 1 ? (long long)pl.slices * nb * M * N : 0;
+    const HybridPlan hy = hybrid_plan(M, N, K, nb);               // alm_gemm_bf16_tn_batched: the tail's partials (the larger of the two covers both callers)
+    if (hy.panels_a > 0) {
+        const long long m2 = hy.m_major ? M - hy.off : M, n2 = hy.m_major ? N : N - hy.off;
+        const long long f2 = (long long)hy.slices_b * m2 * n2;
+        if (f2 > fl) fl = f2;
+    }
     return fl > 0x7fffffffLL ? -1 : (int)fl;
 }
 
@@ -1317,6 +1364,26 @@ extern "C" int alm_gemm_bf16_tn_batched(const void* At, const void* Bt, float* C
     const int nb = nb1 * nb2;
     const SplitPlan pl = splitk_plan(M, N, K, nb);
     int rc;
+    const HybridPlan hy = hybrid_plan(M, N, K, nb);
+    if (hy.panels_a > 0) {
+        // (a) the panels that fill whole waves of the chip: full K, straight into C -- no partials, no reduce
+        GemmParams pa{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0, 1, 1, nb,
+                      hy.panels_a};
+        rc = launch_gemm<true>(pa, nb, 1, 1, 13, st);
+        if (rc) return rc;
+        // (b) the last problem's remaining row (column) blocks: an ordinary split-K problem on the sub-matrix, deep enough to fill the chip once
+        const long long zA = (long long)(nb1 - 1) * sA1 + (long long)(nb2 - 1) * sA2, zB = (long long)(nb1 - 1) * sB1 + (long long)(nb2 - 1) * sB2;
+        const long long zC = (long long)(nb1 - 1) * sC1 + (long long)(nb2 - 1) * sC2;
+        const bf16_t* A2 = (const bf16_t*)At + zA + (hy.m_major ? hy.off : 0);
+        const bf16_t* B2 = (const bf16_t*)Bt + zB + (hy.m_major ? 0 : hy.off);
+        float* C2 = C + zC + (hy.m_major ? (long long)hy.off * ldc : hy.off);
+        const int M2 = hy.m_major ? M - hy.off : M, N2 = hy.m_major ? N : N - hy.off;
+        if (!ws) return ALM_ERR_BAD_ARG;
+        rc = splitk_fixed(A2, B2, C2, ws, M2, N2, K, lda, ldb, ldc, hy.slices_b, alpha, accumulate, st);
+        if (rc) return rc;
+        ALM_LAUNCH_CHECK();
+        return 0;
+    }
     if (pl.slices <= 1) {
         GemmParams p{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0,
                      pick_raster(M, N, nb, pl.tile), 1, nb};

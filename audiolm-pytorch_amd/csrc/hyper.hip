@@ -889,27 +889,44 @@ template <int S>
 __global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __restrict__ ws, int chunks, HcParams hp, float* __restrict__ out, int D) {
     constexpr int NB = S * (S + 1);
     const long long P = (long long)D * (S + 3) + NB + S + 2;              // floats per chunk row (alm_hc_partial_width)
-    // `ws` holds `chunks` partial column sums (stage 1 of alm_colsum): summed here, in a fixed order -- the former colsum_finish launch
-    auto sums_at = [&](long long i) {
-        float v = 0.f;
-        for (int k = 0; k < chunks; ++k) v += ws[k * P + i];
-        return v;
-    };
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    // `ws` holds `chunks` partial column sums (stage 1 of alm_colsum): summed here -- the former colsum_finish launch.  A workgroup owns 64 elements;
+    // its 4 waves take the chunk rows k = wave, wave + 4, ... of all S + 3 columns (independent loads, all in flight together: the one-thread-per-
+    // element form of this kernel was a 4-workgroup chain of dependent loads, 18 us for 0.5 MB) and meet in LDS.  Fixed order: deterministic.
+    __shared__ float red[S + 3][4][64];
+    const int el = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float part[S + 3];
+#pragma unroll
+    for (int c = 0; c < S + 3; ++c) part[c] = 0.f;
     if (e < D) {
+        for (int k = kq; k < chunks; k += 4) {
+#pragma unroll
+            for (int c = 0; c < S + 3; ++c) part[c] += ws[k * P + (long long)c * D + e];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < S + 3; ++c) red[c][kq][el] = part[c];
+    __syncthreads();
+    if (kq == 0 && e < D) {
+        float col[S + 3];
+#pragma unroll
+        for (int c = 0; c < S + 3; ++c) col[c] = (red[c][0][el] + red[c][1][el]) + (red[c][2][el] + red[c][3][el]);
         const float g1 = hp.hc_gamma[e] + 1.f;
-        float dg = hp.wb[e] * sums_at((long long)(S + 1) * D + e);
+        float dg = hp.wb[e] * col[S + 1];
 #pragma unroll
         for (int t = 0; t < S + 1; ++t) {
-            const float ra = sums_at((long long)t * D + e);
-            out[(long long)e * (S + 1) + t] = g1 * ra;
-            dg += hp.Wa[(long long)e * (S + 1) + t] * ra;
+            out[(long long)e * (S + 1) + t] = g1 * col[t];
+            dg += hp.Wa[(long long)e * (S + 1) + t] * col[t];
         }
-        out[(long long)D * (S + 1) + e] = g1 * sums_at((long long)(S + 1) * D + e);
+        out[(long long)D * (S + 1) + e] = g1 * col[S + 1];
         out[(long long)D * (S + 2) + e] = dg;
-        out[(long long)D * (S + 3) + NB + S + 2 + e] = sums_at((long long)(S + 2) * D + e);
+        out[(long long)D * (S + 3) + NB + S + 2 + e] = col[S + 2];
     }
-    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) out[(long long)D * (S + 3) + threadIdx.x] = sums_at((long long)D * (S + 3) + threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) {
+        float v = 0.f;
+        for (int k = 0; k < chunks; ++k) v += ws[k * P + (long long)D * (S + 3) + threadIdx.x];
+        out[(long long)D * (S + 3) + threadIdx.x] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1193,7 +1210,7 @@ extern "C" int alm_hc_param_grads(const float* sums, int chunks, const float* hc
                                   void* stream) {
     if (chunks < 1) return ALM_ERR_BAD_ARG;
     HcParams hp{hc_gamma, Wa, nullptr, nullptr, wb, nullptr, nullptr};
-    const int grid = (D + 255) / 256;
+    const int grid = (D + 63) / 64;
     if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
     else if (S == 3) hipLaunchKernelGGL(hc_param_grads_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
     else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);

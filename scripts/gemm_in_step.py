@@ -1,6 +1,8 @@
 """Per-shape GEMM time INSIDE the headline training step (side stream off, HIP events around every launch), next to the same shape timed
 back-to-back stand-alone: shows which launches lose time to their neighbours (cold operands, clock, launch gaps) rather than to the kernel.
-Usage: python scripts/gemm_in_step.py
+With --vendor a second pass substitutes torch.mm (hipBLASLt / rocBLAS) for every plain 2-D NT launch (no bias, alpha 1, no accumulation) INSIDE the
+same step -- a yardstick only: is the vendor kernel faster than ours in the step, or does it lose the same 10-15 % to the step's conditions?
+Usage: python scripts/gemm_in_step.py [--vendor]
 """
 import os
 import sys
@@ -12,19 +14,19 @@ sys.path.insert(0, ROOT)
 import audiolm_pytorch_amd as A  # noqa: E402
 import audiolm_pytorch_amd.core as core_mod  # noqa: E402
 from audiolm_pytorch_amd import ops  # noqa: E402
-from bench import B_PER_GPU, MODEL, N_FRAMES, N_SEM, Codec  # noqa: E402
+from bench import build  # noqa: E402
 
 dev = torch.device('cuda')
 
 
+def fl_of(nb, M, N, K):
+    return 2.0 * nb * M * N * K
+
+
 def main():
-    torch.manual_seed(0)
-    model = A.CoarseTransformer(**MODEL).to(dev)
-    wrapper = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
-    wrapper.train()
-    g = torch.Generator().manual_seed(1000)
-    sem = torch.randint(0, 500, (B_PER_GPU, N_SEM), generator=g).to(dev)
-    coarse = torch.randint(0, 1024, (B_PER_GPU, N_FRAMES, 3), generator=g).to(dev)
+    W = build('coarse2048', dev, 0, torch.bfloat16)
+    model, wrapper = W['model'], W['wrapper']
+    sem, coarse = W['inputs']['semantic_token_ids'], W['inputs']['coarse_token_ids']
     cache = model.transformer._cache
 
     def step():
@@ -64,12 +66,41 @@ def main():
         step()
     torch.cuda.synchronize()
     ops.gemm_nt, ops.gemm_tn_splitk = orig_nt, orig_tn
+    vend = {}
+    if '--vendor' in sys.argv:
+        vev = []
+
+        def vendor_nt(Am, Bm, Cm, **kw):
+            plain = Am.dim() == 2 and kw.get('bias') is None and kw.get('alpha', 1.0) == 1.0 and not kw.get('accumulate', False) and Cm.is_contiguous() and Am.is_contiguous() and Bm.is_contiguous()
+            if not plain:
+                return orig_nt(Am, Bm, Cm, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if Cm.dtype == torch.bfloat16:
+                torch.mm(Am, Bm.t(), out=Cm)
+            else:
+                Cm.copy_(torch.mm(Am, Bm.t()))                               # fp32 result: the vendor path pays a cast (shown, not hidden)
+            e1.record()
+            vev.append((e0, e1, ('nt', 1, Am.shape[0], Bm.shape[0], Am.shape[1], str(Cm.dtype)[6:], '')))
+            return Cm
+        ops.gemm_nt = vendor_nt
+        for _ in range(3):
+            step()
+        vev.clear()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        ops.gemm_nt = orig_nt
+        for e0, e1, key in vev:
+            a = vend.setdefault(key, [0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
     agg = {}
     for e0, e1, key in events:
         a = agg.setdefault(key, [0.0, 0])
         a[0] += e0.elapsed_time(e1)
         a[1] += 1
-    print(f'{"kind nb M N K out":44s} launches/step   in-step us   stand-alone us   TF in-step')
+    print(f'{"kind nb M N K out":44s} launches/step   in-step us   stand-alone us   TF in-step   vendor in-step us   vendor stand-alone us')
     tot = 0.0
     for key, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         kind, nb, M, N, K, dt, bias = key
@@ -90,8 +121,21 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             sa = e0.elapsed_time(e1) / 20 * 1e3
+        vtxt = ''
+        if key in vend:
+            vus = vend[key][0] / vend[key][1] * 1e3
+            Cv = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            for _ in range(3):
+                torch.mm(Am, Bm.t(), out=Cv)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                torch.mm(Am, Bm.t(), out=Cv)
+            e1.record()
+            torch.cuda.synchronize()
+            vtxt = f'      {vus:8.1f} ({fl_of(nb, M, N, K) / vus / 1e6:5.0f} TF)   {e0.elapsed_time(e1) / 20 * 1e3:8.1f}'
         fl = 2.0 * nb * M * N * K
-        print(f'{kind} nb={nb:<2d} {M:6d} x {N:5d} x {K:6d} {dt:8s} {bias:4s}   {n / reps:5.1f}        {us:8.1f}      {sa:8.1f}        {fl / us / 1e6:7.0f}')
+        print(f'{kind} nb={nb:<2d} {M:6d} x {N:5d} x {K:6d} {dt:8s} {bias:4s}   {n / reps:5.1f}        {us:8.1f}      {sa:8.1f}        {fl / us / 1e6:7.0f}{vtxt}')
     print(f'total GEMM time per step {tot:.3f} ms')
 
 

@@ -703,3 +703,29 @@ def test_gemm_tn_batched_two_level_strided(ops):
     ops.gemm_tn_batched(A3, B3, C3, alpha=0.5, accumulate=True)
     ref3 = base.double() + 0.5 * torch.einsum('lhkm,lhkn->lhmn', A3.double(), B3.double())
     assert relmax(C3, ref3) <= 2e-5
+
+
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_gemm_tn_batched_hybrid_plan(ops, accumulate):
+    """alm_gemm_bf16_tn_batched, hybrid plan: the panels that fill whole waves of the 256 CUs run at full K straight into C, the last problem's
+    remaining row (m-major: dW1) or column (n-major: dW2) blocks are a deep split-K launch on the sub-matrix.  Shapes of the benchmark's weight
+    gradients (inner width 2730, padded 2736, 3 layers x 2 halves / 6 layers), a shorter contraction."""
+    from audiolm_pytorch_amd import _lib
+    L, K, I, Ip, D = 3, 4160, 2730, 2736, 1024
+    assert _lib.query('alm_gemm_splitk_ws_floats', I, D, K, 2 * L) > 0
+    dU = rnd(L, K, 2 * Ip, seed=601, dtype=BF16)
+    XN = rnd(L, K, D, seed=602, dtype=BF16)
+    At = dU.view(L, K, 2, Ip).permute(0, 2, 1, 3)[..., :I]                     # 2 * 3 problems x 11 x 4 tiles = 264: 64 panels + a 2-panel tail
+    C = rnd(L, 2, I, D, seed=603) if accumulate else torch.empty((L, 2, I, D), dtype=torch.float32, device=dev())
+    base = C.clone()
+    ops.gemm_tn_batched(At, XN.unsqueeze(1), C, alpha=0.5, accumulate=accumulate)
+    ref = 0.5 * torch.einsum('lhki,lkd->lhid', At.float(), XN.float()) + (base if accumulate else 0.)
+    assert relmax(C, ref) <= 3e-5, relmax(C, ref)
+    L2 = 6                                                                     # n-major: 6 problems x 4 x 11 tiles = 264
+    HN = rnd(L2, K, Ip, seed=604, dtype=BF16)
+    dY = rnd(L2, K, D, seed=605, dtype=BF16)
+    C2 = rnd(L2, 1, D, I, seed=606) if accumulate else torch.empty((L2, 1, D, I), dtype=torch.float32, device=dev())
+    base2 = C2.clone()
+    ops.gemm_tn_batched(dY.unsqueeze(1), HN[..., :I].unsqueeze(1), C2, accumulate=accumulate)
+    ref2 = torch.einsum('lkd,lki->ldi', dY.float(), HN[..., :I].float()) + (base2[:, 0] if accumulate else 0.)
+    assert relmax(C2[:, 0], ref2) <= 3e-5, relmax(C2[:, 0], ref2)
