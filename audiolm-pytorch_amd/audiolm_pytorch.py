@@ -70,18 +70,35 @@ def round_down_nearest_multiple(val, mult):
     return (val // mult) * mult
 
 
-def generate_mask_with_prob(shape, mask_prob, device):
-    """Forgetful causal mask (reference audiolm_pytorch.py:82-89): True = key kept.  Per row, the int(n * mask_prob) keys (at most n - 1) with
-    the largest Gaussian draw are dropped; key 0 (the start token) is never dropped.  ONE randn(shape) draw on `device`, like the reference,
-    so a seeded run masks the same keys."""
-    n = shape[-1]
+def _forgetful_drop_(keep, mask_prob):
+    """keep (bool [..., n]) &= forgetful mask: per row, the int(n * mask_prob) keys (at most n - 1) with the largest Gaussian draw are dropped; key 0
+    (the start token) never.  ONE randn(shape) draw on keep's device, like the reference (audiolm_pytorch.py:82-89), so a seeded run masks the same
+    keys.  On the GPU the selection is one kernel (alm_forgetful_mask) instead of ATen's topk + sort + scatter + fills."""
+    n = keep.shape[-1]
     drop_count = min(int(n * mask_prob), n - 1)
-    score = torch.randn(shape, device=device)
-    score[:, 0] = -torch.finfo(score.dtype).max                  # never among the top draws
-    keep = torch.ones(shape, dtype=torch.bool, device=device)
-    if drop_count > 0:
-        keep.scatter_(1, score.topk(drop_count, dim=-1).indices, False)
-    return keep
+    score = torch.randn(keep.shape, device=keep.device)
+    if drop_count <= 0:
+        return keep
+    if keep.is_cuda and keep.dim() == 2 and keep.is_contiguous() and n <= ops.FORGETFUL_MAX_N:
+        return ops.forgetful_mask_(keep, score, drop_count)
+    score[..., 0] = -torch.finfo(score.dtype).max                # never among the top draws
+    return keep.scatter_(-1, score.topk(drop_count, dim=-1).indices, False)
+
+
+def _forgetful_and_(mask, mask_prob):
+    """mask & generate_mask_with_prob(mask.shape, mask_prob, mask.device) without the ones / and passes (tests swap generate_mask_with_prob for a
+    recorded mask: honoured)"""
+    if generate_mask_with_prob is not _GENERATE_MASK:
+        return mask & generate_mask_with_prob(mask.shape, mask_prob, mask.device)
+    return _forgetful_drop_(mask, mask_prob)
+
+
+def generate_mask_with_prob(shape, mask_prob, device):
+    """Forgetful causal mask (reference audiolm_pytorch.py:82-89): True = key kept."""
+    return _forgetful_drop_(torch.ones(shape, dtype=torch.bool, device=device), mask_prob)
+
+
+_GENERATE_MASK = generate_mask_with_prob
 
 
 def grad_shrink(t, alpha=0.1):
@@ -1528,7 +1545,7 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         coarse_token_len = coarse_token_ids.shape[-1]
         self_attn_mask = F.pad(self_attn_mask, (1, coarse_token_len + 1), value=True)             # :1805
         if self.mask_prob > 0 and self.training:                                                  # forgetful causal mask, :1809-1810
-            self_attn_mask &= generate_mask_with_prob(self_attn_mask.shape, self.mask_prob, device=self_attn_mask.device)
+            self_attn_mask = _forgetful_and_(self_attn_mask, self.mask_prob)
         if not return_loss:
             return self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids,
                                     self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds, **kwargs)

@@ -249,6 +249,76 @@ __global__ __launch_bounds__(256) void kv_grad_pack_kernel(const float* __restri
 
 int grid_for(long long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 
+// ------------------------------------------------------------------------------------------------------------------
+// forgetful causal mask (reference audiolm_pytorch.py:82-89: `rand[:, 0] = -max; idx = rand.topk(k).indices; mask = ~zeros.scatter(1, idx, 1)`):
+// per row, the k keys with the largest Gaussian draw are dropped, key 0 never.  ONE workgroup per row replaces ATen's topk (radix select + sort) +
+// scatter + fills + and: the k-th largest score is found by bisection over the order-preserving integer image of the floats (32 rounds of
+// count-and-compare; a thread owns a contiguous run of the row), equal scores at the threshold go in index order.  keep[b][i] &= !dropped.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FM_MAX_PER_THREAD = 64;                                          // rows up to 256 * 64 = 16384 keys
+
+__device__ __forceinline__ uint32_t fm_key(float f) {                          // monotone float -> uint32 (larger float <=> larger key); NaN sorts high
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int PER>                                                             // keys per thread (compile-time: the row lives in registers)
+__global__ __launch_bounds__(256) void forgetful_mask_kernel(const float* __restrict__ score, long long ld_score, unsigned char* __restrict__ keep,
+                                                             long long ld_keep, int N, int drop) {
+    __shared__ int wsum[2][4];
+    __shared__ int tcnt[256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = t * PER;
+    const float* row = score + (long long)blockIdx.x * ld_score;
+    unsigned char* krow = keep + (long long)blockIdx.x * ld_keep;
+    uint32_t key[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = i0 + j;
+        key[j] = (i < N && i > 0) ? fm_key(row[i]) : 0u;                       // key 0 = "never dropped" (below every real score): column 0 and the padding
+    }
+    int par = 0;
+    auto block_count = [&](int c) {
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) wsum[par][wave] = c;
+        __syncthreads();
+        const int tot = wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
+        par ^= 1;                                                              // double-buffered: one barrier per count
+        return tot;
+    };
+    uint32_t prefix = 0u;                                                      // largest value v with  #(key >= v) >= drop  = the drop-th largest key
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += key[j] >= cand;
+        if (block_count(c) >= drop) prefix = cand;
+    }
+    if (prefix == 0u) return;                                                  // fewer real keys than `drop` cannot happen (drop <= N - 1); defensive
+    // everything above the threshold goes; of the keys EQUAL to it, the first (drop - #above) in index order (one key unless two draws coincide)
+    int above = 0, equal = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { above += key[j] > prefix; equal += key[j] == prefix; }
+    const int n_above = block_count(above), n_equal = block_count(equal);
+    int quota = equal;
+    if (n_above + n_equal > drop) {                                            // a tie at the threshold: a thread owns a contiguous run -> thread order = index order
+        tcnt[t] = equal;
+        __syncthreads();
+        int before = 0;
+        for (int u = 0; u < t; ++u) before += tcnt[u];
+        quota = drop - n_above - before;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = i0 + j;
+        if (i < N) {
+            bool gone = key[j] > prefix;
+            if (key[j] == prefix && quota > 0) { gone = true; --quota; }
+            if (gone) krow[i] = 0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
@@ -351,6 +421,20 @@ extern "C" int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, 
     if (mode < 0 || mode > 2 || (mode && !acc_v0) || nparts < 1) return ALM_ERR_BAD_ARG;
     hipLaunchKernelGGL(kv_grad_pack_kernel, dim3(grid_for(rows * dim_head)), dim3(256), 0, (hipStream_t)stream, dk, dv, ld, nparts, part_stride,
                        acc_v0, (bf16_t*)dkv, ldo, rows, dim_head, mode);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// keep [B][N] (bytes: torch.bool storage) &= forgetful mask of score [B][N]: see forgetful_mask_kernel.  drop = min(int(N * mask_prob), N - 1).
+extern "C" int alm_forgetful_mask(const float* score, long long ld_score, void* keep, long long ld_keep, int B, int N, int drop, void* stream) {
+    if (B <= 0 || N <= 0 || drop <= 0) return 0;
+    if (drop > N - 1 || N > 256 * FM_MAX_PER_THREAD) return ALM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* kp = (unsigned char*)keep;
+    if (N <= 256 * 8) hipLaunchKernelGGL(forgetful_mask_kernel<8>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
+    else if (N <= 256 * 16) hipLaunchKernelGGL(forgetful_mask_kernel<16>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
+    else if (N <= 256 * 32) hipLaunchKernelGGL(forgetful_mask_kernel<32>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
+    else hipLaunchKernelGGL(forgetful_mask_kernel<64>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -344,6 +344,18 @@ def value_residual_mix(v, v0):
     return out
 
 
+FORGETFUL_MAX_N = 16384
+
+
+def forgetful_mask_(keep, score, drop):
+    """keep (bool [B, N]) &= NOT(one of the `drop` largest entries of its row of score (fp32 [B, N])); column 0 is never dropped (audiolm_pytorch.py:82-89)."""
+    _chk(score, F32)
+    assert keep.dtype == torch.bool and keep.dim() == 2 and score.shape == keep.shape and keep.stride(1) == 1 and score.stride(1) == 1
+    B, N = keep.shape
+    _lib.call('alm_forgetful_mask', score.data_ptr(), score.stride(0), keep.data_ptr(), keep.stride(0), B, N, int(drop), _st())
+    return keep
+
+
 def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64, out=None):
     """dkv_f32: [rows, 2*dh] or per-head-group partials [HG, rows, 2*dh] (summed here) -> bf16 [rows, 2*dh]."""
     if dkv_f32.dim() == 2:

@@ -174,6 +174,11 @@ int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long lo
 int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts, long long part_stride, float* acc_v0, void* dkv_bf16,
                      long long ldo, long long rows, int dim_head, int mode, void* stream);
 
+/* forgetful causal mask, audiolm_pytorch.py:82-89 (`rand[:, 0] = -max; mask = ~zeros.scatter(1, rand.topk(k).indices, 1)`): keep [B][N] bytes (torch.bool
+ * storage) &= NOT(one of the `drop` largest scores of its row); column 0 is never dropped; equal scores at the threshold go in index order.
+ * drop <= N - 1, N <= 16384. */
+int alm_forgetful_mask(const float* score, long long ld_score, void* keep, long long ld_keep, int B, int N, int drop, void* stream);
+
 /* ---- hyper-connection residual streams: third-party `hyper_connections` used at audiolm_pytorch.py:24, 446-454, 524, 551 ----
  * R [B][S][N][D], stored fp32 or (r_bf16) bf16 -- under trainer.py:1241's autocast the reference's streams are bf16 tensors; the arithmetic is
  * fp32 in registers either way.  Tensors standing for all streams at once (the `*_bcast` forms) are always fp32 [B*N][D].

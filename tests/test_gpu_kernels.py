@@ -729,3 +729,44 @@ def test_gemm_tn_batched_hybrid_plan(ops, accumulate):
     ops.gemm_tn_batched(dY.unsqueeze(1), HN[..., :I].unsqueeze(1), C2, accumulate=accumulate)
     ref2 = torch.einsum('lkd,lki->ldi', dY.float(), HN[..., :I].float()) + (base2[:, 0] if accumulate else 0.)
     assert relmax(C2[:, 0], ref2) <= 3e-5, relmax(C2[:, 0], ref2)
+
+
+@pytest.mark.parametrize('N', [2, 7, 100, 2048, 2049, 5000, 16384])
+def test_forgetful_mask_kernel_matches_topk(ops, N):
+    """alm_forgetful_mask vs the reference's own formulation (audiolm_pytorch.py:82-89: rand[:, 0] = -max; topk; scatter): same keys dropped."""
+    B = 5
+    g = torch.Generator().manual_seed(700 + N)
+    score = torch.randn(B, N, generator=g).to(dev())
+    for prob in (0.15, 0.5, 1.0):
+        k = min(int(N * prob), N - 1)
+        if k <= 0:
+            continue
+        pre = (torch.rand(B, N, generator=g) > 0.1).to(dev())                   # the key-padding mask it is ANDed into
+        keep = pre.clone()
+        ops.forgetful_mask_(keep, score, k)
+        s2 = score.clone()
+        s2[:, 0] = -torch.finfo(s2.dtype).max
+        ref = torch.ones(B, N, dtype=torch.bool, device=dev()).scatter_(1, s2.topk(k, dim=-1).indices, False) & pre
+        assert torch.equal(keep, ref), (N, prob, int((keep != ref).sum()))
+
+
+def test_forgetful_mask_kernel_ties_and_seeded_run(ops):
+    """equal scores at the threshold: exactly k keys go, none of them column 0, and no kept key beats a dropped one; a seeded run of the host function
+    masks the same keys as the ATen formulation of the reference"""
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    B, N, k = 3, 300, 45
+    g = torch.Generator().manual_seed(77)
+    score = torch.randint(0, 20, (B, N), generator=g).float().to(dev())          # heavy ties
+    keep = torch.ones(B, N, dtype=torch.bool, device=dev())
+    ops.forgetful_mask_(keep, score, k)
+    assert bool(keep[:, 0].all()) and torch.equal((~keep).sum(1), torch.full((B,), k, device=dev()))
+    for b in range(B):
+        dropped, kept = score[b][~keep[b]], score[b][1:][keep[b][1:]]
+        assert float(dropped.min()) >= float(kept.max())
+    torch.manual_seed(5)
+    m1 = AP.generate_mask_with_prob((4, 777), 0.15, dev())
+    torch.manual_seed(5)
+    s = torch.randn((4, 777), device=dev())
+    s[:, 0] = -torch.finfo(s.dtype).max
+    m2 = torch.ones((4, 777), dtype=torch.bool, device=dev()).scatter_(1, s.topk(min(int(777 * 0.15), 776), dim=-1).indices, False)
+    assert torch.equal(m1, m2)
