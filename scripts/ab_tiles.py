@@ -12,7 +12,11 @@ from audiolm_pytorch_amd import ops  # noqa: E402
 dev, BF16 = torch.device('cuda'), torch.bfloat16
 tiles = [int(a) for a in sys.argv[1:]] or [13, 14]
 T = 16384
+if os.environ.get('ALM_AB_SMALL'):
+    shapes_small = [('Wq fwd / dAO', T, 512, 1024), ('Wo fwd / dXN', T, 1024, 512), ('Wkv fwd', T, 128, 1024), ('dKV.WkvT', T, 1024, 128), ('N=768', T, 768, 1024)]
 shapes = [('W1 fwd', T, 5472, 1024), ('W2 fwd', T, 1024, 2736), ('dHN dgrad', T, 2736, 1024), ('dXN2 dgrad', T, 1024, 5472), ('Wo fwd', T, 1024, 512), ('square 8192', 8192, 8192, 8192)]
+if os.environ.get('ALM_AB_SMALL'):
+    shapes = shapes_small
 for name, M, N, K in shapes:
     A, B = torch.randn(M, K, device=dev).to(BF16), torch.randn(N, K, device=dev).to(BF16)
     C = torch.empty(M, N, dtype=BF16, device=dev)
