@@ -508,6 +508,23 @@ struct HcBwdArgs {
 // nhat * (dap | dbp): dWa = (gamma+1) raw_a, dwb = (gamma+1) raw_b, dgamma = sum_t Wa raw_a + wb raw_b  (alm_hc_param_grads).
 // PF: see hc_fwd_kernel.  BC (PF only): 0 = stream tensors everywhere, 1 = dRn is the broadcast fp32 [M][D] tensor (`bcast`: the last branch, behind
 // the final stream sum), 2 = R is (`r_bcast`: the first branch, right after the stream expansion) -- the two once-per-step launches prefetch too.
+// The kernel arguments re-read from the kernarg segment (scalar loads: free for the VALU) instead of held in SGPRs across the token loop: hc_bwd keeps
+// ~25 pointers / strides alive next to 2 x 13 per-stream scalars, more than the 102 SGPRs -- the compiler parked the surplus in VGPR lanes and fetched it
+// back with v_readlane INSIDE the loop (56 of the ~1190 VALU instructions per token and wave).  The empty asm makes every call a fresh base the loads
+// cannot be hoisted over.
+// base + a 32-bit BYTE offset: the form the global_load / global_store "SGPR base + 32-bit VGPR offset" addressing takes (an element index would be
+// widened to 64 bits before the scale, i.e. a v_lshl_add_u64 per access)
+template <typename T> __device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
+    typedef __attribute__((address_space(1))) char gchar;                      // every tensor of the C ABI is device (global) memory
+    return (T*)((gchar*)(base) + byte_off);
+}
+typedef const __attribute__((address_space(4))) HcBwdArgs* HcBwdKArgs;
+__device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
+    HcBwdKArgs p = (HcBwdKArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
 __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
@@ -525,7 +542,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = wave / WPT, wv = wave % WPT;
     const int e0 = (wv * 64 + lane) * 4;
-    const bool eok = e0 < a.D;
+    const bool eok = PF || e0 < a.D;                                        // PF: D == WPT * 256, every lane in range (no selects in the loop)
     const long long M = (long long)a.B * a.N;
     const float cD = sqrtf((float)a.D);
 
@@ -576,15 +593,15 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     const int src_sr = SM::lane_of_dyn(O_SR + sl0), src_xr = SM::lane_of_dyn(O_XR + sl0);
     const int cl = lane < C::W ? lane : 0;                                   // this lane's entry of a coefficient record
     const int pre_idx = is_a ? C::AP + slot : C::BP + sl;
-    auto issue_scalars = [&](auto& w, long long m_) {
+    auto issue_scalars = [&](auto& w, unsigned m_, const auto& a) {
         w.cf = w.cfp = w.pre = w.upb = w.ms = 0.f;
         if (WIDTH) {
-            w.cf = a.coef[(long long)m_ * C::W + cl];
-            w.pre = a.coef[(long long)m_ * C::W + pre_idx];
-            w.upb = a.dbeta[(long long)m_ * S + sl];
-            if (LNF) w.ms = (lane & 1) ? a.rstd[m_] : a.mean[m_];
+            w.cf = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)cl) * 4u);       // 32-bit byte offsets (the launcher checks the sizes): SGPR base + VGPR offset
+            w.pre = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)pre_idx) * 4u);
+            w.upb = *at_bytes(a.dbeta, (m_ * (unsigned)S + (unsigned)sl) * 4u);
+            if (LNF) w.ms = (lane & 1) ? *at_bytes(a.rstd, m_ * 4u) : *at_bytes(a.mean, m_ * 4u);
         }
-        if (DEPTH) w.cfp = a.coef_prev[(long long)m_ * C::W + cl];
+        if (DEPTH) w.cfp = *at_bytes(a.coef_prev, (m_ * (unsigned)C::W + (unsigned)cl) * 4u);
     };
     struct Tok { int m; int b, n; bool valid; };                             // m = b * N + n < 2^31 (checked by the launcher)
     auto next_tok = [&](int it_) {
@@ -602,39 +619,44 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     // retires in order: a late scalar load would force a wait for everything issued before it, i.e. for the whole prefetch).
     struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms; };
     auto issue_pf = [&](In& w, const Tok& t) {
-        const int m_ = t.valid ? t.m : 0;
-        const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0, el = e0;         // PF: D == WPT * 256, every lane in range
-        const long long tofs = ((long long)b_ * S * a.N + n_) * a.D + el;
-        issue_scalars(w, m_);
+        const auto& a = *hc_bwd_kargs();                                           // (shadows the by-value parameter: see hc_bwd_kargs)
+        const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
+        const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
+        const unsigned m_ = t.valid ? (unsigned)t.m : 0u;
+        const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u, el = (unsigned)e0;         // PF: D == WPT * 256, every lane in range
+        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
+        constexpr unsigned RB = sizeof(RT);
+        const unsigned tofs = ((b_ * (unsigned)S * uN + n_) * uD + el) * RB;       // 32-bit BYTE offsets: the launcher takes this path only when every tensor is < 4 GB
+        issue_scalars(w, m_, a);
         if constexpr (BC == 1) {
-            w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + (long long)m_ * a.D + el);
+            w.gb = ld4(at_bytes(reinterpret_cast<const float*>(a.dRn), (m_ * uD + el) * 4u));
         } else {
 #pragma unroll
-            for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], dRn + tofs + t2 * sND);
+            for (int t2 = 0; t2 < S; ++t2) ldraw(w.g[t2], at_bytes(dRn, tofs + (unsigned)t2 * sND32 * RB));
         }
         if (WIDTH) {
             if constexpr (BC == 2) {
-                w.rb = ld4(reinterpret_cast<const float*>(a.R) + (long long)m_ * a.D + el);
+                w.rb = ld4(at_bytes(reinterpret_cast<const float*>(a.R), (m_ * uD + el) * 4u));
             } else {
 #pragma unroll
-                for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], Rsv + tofs + s2 * sND);
+                for (int s2 = 0; s2 < S; ++s2) ldraw(w.r[s2], at_bytes(Rsv, tofs + (unsigned)s2 * sND32 * RB));
             }
             if (LNF) {
-                w.dxn = *reinterpret_cast<const uint2*>(a.dxn + (long long)m_ * a.lddxn + el);
+                w.dxn = *reinterpret_cast<const uint2*>(at_bytes(a.dxn, (m_ * (unsigned)a.lddxn + el) * 2u));
                 w.ex = make_uint2(0u, 0u);
-                if (a.extra) w.ex = *reinterpret_cast<const uint2*>(a.extra + (long long)m_ * a.ldex + el);
+                if (a.extra) w.ex = *reinterpret_cast<const uint2*>(at_bytes(a.extra, (m_ * (unsigned)a.ldex + el) * 2u));
             } else {
-                w.dx = ld4(a.dx + (long long)m_ * a.lddx + el);
+                w.dx = ld4(at_bytes(a.dx, (m_ * (unsigned)a.lddx + el) * 4u));
             }
         }
-        if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + (long long)m_ * a.ldy + el);
+        if (DEPTH) w.y = *reinterpret_cast<const uint2*>(at_bytes(a.y, (m_ * (unsigned)a.ldy + el) * 2u));
     };
     auto issue_plain = [&](In& w, const Tok& t) {
 #pragma unroll
         for (int t2 = 0; t2 < S; ++t2) { zraw(w.g[t2]); zraw(w.r[t2]); }
         w.gb = w.rb = w.dx = z4;
         w.dxn = w.ex = w.y = make_uint2(0u, 0u);
-        issue_scalars(w, t.valid ? t.m : 0);
+        issue_scalars(w, t.valid ? (unsigned)t.m : 0u, a);
         if (t.valid && eok) {
             const long long tofs = ((long long)t.b * S * a.N + t.n) * a.D + e0;
             if (a.bcast) {
@@ -661,7 +683,8 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         }
     };
     int par = 0;
-    auto process = [&](const In& w, const Tok& t) {
+    auto process_impl = [&](const In& w, const Tok& t, const auto& a) {
+        RT* const dRo = reinterpret_cast<RT*>(a.dR);
         const int m = t.m;
         const bool valid = t.valid;
         const int b = t.b, n = t.n;
@@ -801,14 +824,18 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             if (ld_ok) {
                 if (a.dR) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) stR(dRo + (((long long)b * S + s) * a.N + n) * a.D + e0, out[s]);
+                    for (int s = 0; s < S; ++s) {
+                        if constexpr (PF) stR(at_bytes(dRo, ((((unsigned)b * (unsigned)S + (unsigned)s) * (unsigned)a.N + (unsigned)n) * (unsigned)a.D + (unsigned)e0) * (unsigned)sizeof(RT)), out[s]);
+                        else stR(dRo + (((long long)b * S + s) * a.N + n) * a.D + e0, out[s]);
+                    }
                 }
                 if (a.dsum) {
                     float4 sm = out[0];
 #pragma unroll
                     for (int s = 1; s < S; ++s) { sm.x += out[s].x; sm.y += out[s].y; sm.z += out[s].z; sm.w += out[s].w; }
                     const float ds = a.dsum_scale;
-                    *reinterpret_cast<float4*>(a.dsum + (long long)m * a.D + e0) = make_float4(sm.x * ds, sm.y * ds, sm.z * ds, sm.w * ds);
+                    float* dsp = PF ? at_bytes(a.dsum, ((unsigned)m * (unsigned)a.D + (unsigned)e0) * 4u) : a.dsum + (long long)m * a.D + e0;
+                    *reinterpret_cast<float4*>(dsp) = make_float4(sm.x * ds, sm.y * ds, sm.z * ds, sm.w * ds);
                 }
             }
         } else {
@@ -826,7 +853,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 o.x += bt * out[t].x; o.y += bt * out[t].y; o.z += bt * out[t].z; o.w += bt * out[t].w;
                 v4[t] = out[t].x * yv.x + out[t].y * yv.y + out[t].z * yv.z + out[t].w * yv.w;
             }
-            if (ld_ok) st4bf(a.dy + (long long)m * a.lddy + e0, o);
+            if (ld_ok) st4bf(PF ? at_bytes(a.dy, ((unsigned)m * (unsigned)a.lddy + (unsigned)e0) * 2u) : a.dy + (long long)m * a.lddy + e0, o);
             float db = bfly4(v4);                                           // every lane: total of slot bfly4_slot(lane)
             if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
                 float* rd = redd[par];
@@ -838,9 +865,13 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             } else {
                 db = __shfl(db, bfly4_lane_of(lane & 3), 64);
             }
-            if (valid && wv == 0 && lane < S) a.dbeta_out[(long long)m * S + lane] = db;
+            if (valid && wv == 0 && lane < S) *(PF ? at_bytes(a.dbeta_out, ((unsigned)m * (unsigned)S + (unsigned)lane) * 4u) : a.dbeta_out + ((long long)m * S + lane)) = db;
         }
         par ^= 1;
+    };
+    auto process = [&](const In& w, const Tok& t) {
+        if constexpr (PF) process_impl(w, t, *hc_bwd_kargs());
+        else process_impl(w, t, a);
     };
     if constexpr (PF) {
         In wa, wb2;
@@ -1080,7 +1111,9 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
     // prefetching variants (bf16 streams, every lane in range): bc 0 plain, 1 broadcast dRn, 2 broadcast R; both broadcast: the plain kernel
     int bc = -1;
     if constexpr (sizeof(RT) == 2) {
-        if (a.D == WPT * 256 && !(a.bcast && a.r_bcast)) bc = a.bcast ? 1 : ((a.r_bcast && WIDTH) ? 2 : (a.r_bcast ? -1 : 0));
+        // the prefetching kernels address with 32-bit byte offsets: every tensor below 4 GB (the largest: fp32 [M][D] / RT [B][S][N][D] / the coefficient records)
+        const bool small = (long long)a.B * S * a.N * a.D * 4 < 0xffffffffLL && M * 64 * 4 < 0xffffffffLL && M * (long long)std::max(std::max(std::max(a.lddxn, a.ldex), std::max(a.ldy, a.lddy)), a.lddx) * 4 < 0xffffffffLL;
+        if (small && a.D == WPT * 256 && !(a.bcast && a.r_bcast)) bc = a.bcast ? 1 : ((a.r_bcast && WIDTH) ? 2 : (a.r_bcast ? -1 : 0));
     }
     int grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
     if constexpr (sizeof(RT) == 2) {
