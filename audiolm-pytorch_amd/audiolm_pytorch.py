@@ -732,7 +732,12 @@ class EmbedAssembleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous().to(torch.float32)
-        grads = [torch.zeros_like(t, dtype=torch.float32) for t in ctx.tables]
+        sizes = [t.numel() for t in ctx.tables]                                                   # one zero fill for all tables (the scatter adds atomically)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dout.device)
+        grads, o = [], 0
+        for t, n in zip(ctx.tables, sizes):
+            grads.append(flat[o:o + n].view(t.shape))
+            o += n
         ops.embed_scatter_add([g.view(-1, ctx.dim) for g in grads], ctx.src[0], ctx.src[1], dout.view(-1, ctx.dim), 1.0, ctx.rows, ctx.dim)
         return (None, None, None, None, *grads)
 
@@ -1050,7 +1055,7 @@ class SemanticTransformer(_TransformerBase):
         if exists(labels):                                                                   # fused loss path (wrapper)
             grp = heads.HeadGroup('semantic', self.to_logits.weight, self.to_logits.bias, idx, _group_labels(labels, i_grid, valid, N))
             (loss_sum,) = heads.HeadsLossFn.apply(hn, [grp], self._heads_cache(), self.to_logits.weight, self.to_logits.bias)
-            return loss_sum / (labels != -1).sum().clamp(min=1)
+            return heads.combine_losses([loss_sum], [labels], [1.0])                               # CE mean over the non-pad labels
         C = self.num_semantic_tokens + 1
         _, lg = heads.head_logits(hn, self.to_logits.weight.detach().unsqueeze(0), self.to_logits.bias.detach(), idx,
                                   self._heads_cache(), ('head', 'semantic'))
@@ -1153,7 +1158,7 @@ class CoarseTransformer(_TransformerBase):
         return groups, params
 
     def forward(self, *, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text=None, text_embeds=None, cond_drop_prob=None,
-                return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None):
+                return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None, loss_weights=None):
         context, context_mask = self._condition(semantic_token_ids.shape[0], semantic_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=True)
         caches = (None, None)
         if exists(kv_cache) or exists(embed_cache) or return_cache:                               # the reference's cache protocol (:938-953): inference only
@@ -1169,9 +1174,10 @@ class CoarseTransformer(_TransformerBase):
             sem_labels, coarse_labels = labels
             groups, params = self._groups(b, N, ns, nc, dev, sem_labels, coarse_labels)
             sums = heads.HeadsLossFn.apply(hn, groups, self._heads_cache(), *params)
-            out = []
-            for s, lab in zip(sums, ([sem_labels] if len(sums) == 2 else []) + [coarse_labels]):
-                out.append(s / (lab != -1).sum().clamp(min=1))
+            labs = ([sem_labels] if len(sums) == 2 else []) + [coarse_labels]
+            if exists(loss_weights):                                                              # the wrapper's weighted combination, fused with the means
+                return heads.combine_losses(sums, labs, loss_weights[-len(sums):])
+            out = [heads.combine_losses([s], [lab], [1.0]) for s, lab in zip(sums, labs)]
             return (out[0] if len(out) == 2 else None), out[-1]
         groups, _ = self._groups(b, N, ns, nc, dev, only_coarse=return_only_coarse_logits)
         outs = []
@@ -1275,7 +1281,7 @@ class FineTransformer(_TransformerBase):
         return self._last_logits(h, self.fine_logit_weights, None, 'fine', nf % self.num_fine_quantizers), state
 
     def forward(self, coarse_token_ids, fine_token_ids, text=None, text_embeds=None, cond_drop_prob=None, self_attn_mask=None,
-                kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None):
+                kv_cache=None, embed_cache=None, return_cache=False, return_only_fine_logits=False, labels=None, loss_weights=None):
         context, context_mask = self._condition(coarse_token_ids.shape[0], coarse_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
         tokens, self_attn_mask, b, n, nf, N = self._assemble(coarse_token_ids, fine_token_ids, self_attn_mask)
         dev = tokens.device
@@ -1304,7 +1310,9 @@ class FineTransformer(_TransformerBase):
         if exists(labels):
             sums = heads.HeadsLossFn.apply(hn, groups, self._heads_cache(), *params)
             labs = ([labels[0]] if want_coarse else []) + [labels[1]]
-            out = [s / (l != -1).sum().clamp(min=1) for s, l in zip(sums, labs)]
+            if exists(loss_weights):                                                              # the wrapper's weighted combination, fused with the means
+                return heads.combine_losses(sums, labs, loss_weights[-len(sums):])
+            out = [heads.combine_losses([s], [l], [1.0]) for s, l in zip(sums, labs)]
             return (out[0] if want_coarse else None), out[-1]
         outs = []
         for gi, g in enumerate(groups):
@@ -1550,6 +1558,12 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
             return self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids,
                                     self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds, **kwargs)
         use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(self.transformer.to_semantic_logits)
+        if not self.unique_consecutive:
+            # the logit counts are plain integers here: the reference's weighted combination (:1826-1854) rides in the same kernel as the CE means
+            n_c, n_s = coarse_labels.shape[-1], (semantic_labels.shape[-1] if use_sem else 0)
+            w = (n_s * self.semantic_cross_entropy_loss_weight / (n_s + n_c), n_c / (n_s + n_c))
+            return self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids, self_attn_mask=self_attn_mask, text=text,
+                                    text_embeds=text_embeds, labels=(semantic_labels, coarse_labels), loss_weights=w, **kwargs)
         semantic_loss, coarse_loss = self.transformer(semantic_token_ids=semantic_token_ids, coarse_token_ids=coarse_token_ids,
                                                       self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds,
                                                       labels=(semantic_labels, coarse_labels), **kwargs)
@@ -1668,17 +1682,11 @@ class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.
             return self.transformer(coarse_token_ids=coarse_token_ids, fine_token_ids=fine_token_ids, self_attn_mask=self_attn_mask,
                                     text=text, text_embeds=text_embeds, **kwargs)
         use_coarse = self.coarse_cross_entropy_loss_weight > 0 and exists(self.transformer.coarse_logit_weights)
-        coarse_loss, fine_loss = self.transformer(coarse_token_ids=coarse_token_ids, fine_token_ids=fine_token_ids,
-                                                  self_attn_mask=self_attn_mask, text=text, text_embeds=text_embeds,
-                                                  labels=(coarse_labels, fine_labels), return_only_fine_logits=not use_coarse, **kwargs)
-        num_fine_logits = fine_labels.shape[-1]                                                   # :2114
-        num_coarse_logits = 0
-        if use_coarse and exists(coarse_loss):
-            num_coarse_logits = coarse_labels.shape[-1]
-        else:
-            coarse_loss = 0.
-        return (coarse_loss * num_coarse_logits * self.coarse_cross_entropy_loss_weight +
-                fine_loss * num_fine_logits) / (num_coarse_logits + num_fine_logits)               # :2134-2137
+        # (coarse_loss * n_coarse * weight + fine_loss * n_fine) / (n_coarse + n_fine)  (:2112-2137): integers, folded into the kernel that takes the CE means
+        n_f, n_c = fine_labels.shape[-1], (coarse_labels.shape[-1] if use_coarse else 0)
+        w = (n_c * self.coarse_cross_entropy_loss_weight / (n_c + n_f), n_f / (n_c + n_f))
+        return self.transformer(coarse_token_ids=coarse_token_ids, fine_token_ids=fine_token_ids, self_attn_mask=self_attn_mask, text=text,
+                                text_embeds=text_embeds, labels=(coarse_labels, fine_labels), return_only_fine_logits=not use_coarse, loss_weights=w, **kwargs)
 
 
 class AudioLM(nn.Module):                                     # audiolm_pytorch.py:2141-2254

@@ -319,6 +319,36 @@ __global__ __launch_bounds__(256) void forgetful_mask_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// loss = sum_g w_g * sum_g / max(#(labels_g != ignore), 1): the cross-entropy means of up to 4 head groups and the wrappers' weighted combination
+// (audiolm_pytorch.py:1561-1565, :1826-1854, :2112-2137) in ONE launch instead of ne / sum / clamp / div per group + mul / add / div.
+// scale_g = w_g / max(count_g, 1) is kept for the backward (d sum_g = d loss * scale_g).
+// ------------------------------------------------------------------------------------------------------------------
+struct LossGroups { const float* sum[4]; const long long* labels[4]; long long n[4]; float w[4]; int G; long long ignore; };
+
+__global__ __launch_bounds__(1024) void loss_combine_kernel(LossGroups g, float* __restrict__ loss, float* __restrict__ scales) {
+    __shared__ int red[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < g.G; ++k) {
+        int c = 0;
+        for (long long i = threadIdx.x; i < g.n[k]; i += 1024) c += g.labels[k][i] != g.ignore;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) red[k][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < g.G; ++k) {
+            int c = 0;
+            for (int w2 = 0; w2 < 16; ++w2) c += red[k][w2];
+            const float sc = g.w[k] / (float)(c > 1 ? c : 1);
+            scales[k] = sc;
+            tot += sc * g.sum[k][0];
+        }
+        loss[0] = tot;
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
@@ -435,6 +465,19 @@ extern "C" int alm_forgetful_mask(const float* score, long long ld_score, void* 
     else if (N <= 256 * 16) hipLaunchKernelGGL(forgetful_mask_kernel<16>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
     else if (N <= 256 * 32) hipLaunchKernelGGL(forgetful_mask_kernel<32>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
     else hipLaunchKernelGGL(forgetful_mask_kernel<64>, dim3(B), dim3(256), 0, st, score, ld_score, kp, ld_keep, N, drop);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss[0] = sum_g w_g * sum_g[0] / max(#(labels_g != ignore), 1), scales[g] = w_g / max(count_g, 1); G <= 4 groups (unused slots: NULL / 0)
+extern "C" int alm_loss_combine(const float* s0, const float* s1, const float* s2, const float* s3, const long long* l0, const long long* l1,
+                                const long long* l2, const long long* l3, long long n0, long long n1, long long n2, long long n3, float w0, float w1,
+                                float w2, float w3, int G, long long ignore_index, float* loss, float* scales, void* stream) {
+    if (G < 1 || G > 4 || !loss || !scales) return ALM_ERR_BAD_ARG;
+    LossGroups g{{s0, s1, s2, s3}, {l0, l1, l2, l3}, {n0, n1, n2, n3}, {w0, w1, w2, w3}, G, ignore_index};
+    for (int k = 0; k < G; ++k)
+        if (!g.sum[k] || (g.n[k] > 0 && !g.labels[k]) || g.n[k] < 0) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, loss, scales);
     ALM_LAUNCH_CHECK();
     return 0;
 }

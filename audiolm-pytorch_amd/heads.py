@@ -121,3 +121,26 @@ class HeadsLossFn(torch.autograd.Function):
                 grads.append(ops.colsum(dl[:, :C]))
         ctx.saved = None
         return (dhn, None, None, *grads)
+
+
+class CombineLossFn(torch.autograd.Function):
+    """(per-group cross-entropy SUMS, their label tensors, weights) -> loss = sum_g w_g * sum_g / max(#valid labels_g, 1): the means of F.cross_entropy
+    (ignore_index) per head and the wrappers' weighted combination (audiolm_pytorch.py:1561-1565, :1826-1854, :2112-2137) as one kernel, one more in
+    the backward -- instead of ne / sum / clamp / div per group and mul / add / div on top, each with its autograd twin."""
+
+    @staticmethod
+    def forward(ctx, labels, weights, ignore_index, *sums):
+        loss, scales = ops.loss_combine([s.detach() for s in sums], labels, weights, ignore_index)
+        ctx.save_for_backward(scales)
+        ctx.G = len(sums)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (scales,) = ctx.saved_tensors
+        d = scales * go.to(F32)
+        return (None, None, None, *[d[g] for g in range(ctx.G)])
+
+
+def combine_losses(sums, labels, weights, ignore_index=-1):
+    return CombineLossFn.apply(list(labels), tuple(float(w) for w in weights), ignore_index, *sums)

@@ -344,6 +344,24 @@ def value_residual_mix(v, v0):
     return out
 
 
+def loss_combine(sums, labels, weights, ignore_index=-1):
+    """sums: G <= 4 fp32 scalars (per-group cross-entropy SUMS), labels: G int64 tensors, weights: G floats ->
+    (loss fp32 [1] = sum_g w_g * sum_g / max(#(labels_g != ignore), 1), scales fp32 [G] = w_g / max(count_g, 1))."""
+    G = len(sums)
+    assert 1 <= G <= 4 and len(labels) == G and len(weights) == G
+    dev = sums[0].device
+    labels = [l if l.is_contiguous() else l.contiguous() for l in labels]
+    for t, l in zip(sums, labels):
+        _chk(t, F32)
+        _chk(l, torch.int64)
+    loss = torch.empty(1, dtype=F32, device=dev)
+    scales = torch.empty(G, dtype=F32, device=dev)
+    pad = [None] * (4 - G)
+    _lib.call('alm_loss_combine', *[t.data_ptr() for t in sums], *pad, *[l.data_ptr() for l in labels], *pad, *[l.numel() for l in labels], *([0] * (4 - G)),
+              *[float(w) for w in weights], *([0.0] * (4 - G)), G, int(ignore_index), loss.data_ptr(), scales.data_ptr(), _st())
+    return loss, scales
+
+
 FORGETFUL_MAX_N = 16384
 
 

@@ -174,6 +174,13 @@ int alm_value_residual_mix(const void* v, long long ldv, const void* v0, long lo
 int alm_kv_grad_pack(const float* dk, const float* dv, long long ld, int nparts, long long part_stride, float* acc_v0, void* dkv_bf16,
                      long long ldo, long long rows, int dim_head, int mode, void* stream);
 
+/* cross-entropy means + the wrappers' weighted combination (audiolm_pytorch.py:1561-1565, :1826-1854, :2112-2137: F.cross_entropy(..., ignore_index) per
+ * head, then (loss_a * n_a * w + loss_b * n_b) / (n_a + n_b)) from the per-group loss SUMS: loss[0] = sum_g w_g * sum_g[0] / max(#(labels_g != ignore), 1);
+ * scales[g] = w_g / max(count_g, 1) (the backward's factor).  G <= 4 groups; unused slots NULL / 0. */
+int alm_loss_combine(const float* s0, const float* s1, const float* s2, const float* s3, const long long* l0, const long long* l1, const long long* l2,
+                     const long long* l3, long long n0, long long n1, long long n2, long long n3, float w0, float w1, float w2, float w3, int G,
+                     long long ignore_index, float* loss, float* scales, void* stream);
+
 /* forgetful causal mask, audiolm_pytorch.py:82-89 (`rand[:, 0] = -max; mask = ~zeros.scatter(1, rand.topk(k).indices, 1)`): keep [B][N] bytes (torch.bool
  * storage) &= NOT(one of the `drop` largest scores of its row); column 0 is never dropped; equal scores at the threshold go in index order.
  * drop <= N - 1, N <= 16384. */
