@@ -108,7 +108,9 @@ def grad_shrink(t, alpha=0.1):
 
 
 def append_eos_id(ids, eos_id):                               # semantics of audiolm_pytorch.py:155-160
-    """(b, n) int64 -> (b, n + 1): one eos column on the right"""
+    """(b, n) int64 -> (b, n + 1): one eos column on the right (one cat with a cached column: F.pad is a fill + a copy)"""
+    if ids.dim() == 2 and ids.dtype == torch.int64:
+        return torch.cat((ids, _const_ids(int(eos_id), ids.shape[0], ids.device)), dim=1)
     return F.pad(ids, (0, 1), value=eos_id)
 
 
@@ -766,6 +768,11 @@ def _shape_cached(fn):
 @_shape_cached
 def _const_code(table_id, b, device):
     return torch.full((b, 1), table_id << 24, dtype=torch.int32, device=device)
+
+
+@_shape_cached
+def _const_ids(value, b, device):
+    return torch.full((b, 1), value, dtype=torch.int64, device=device)
 
 
 @_shape_cached
@@ -1546,7 +1553,7 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         if self.unique_consecutive:
             semantic_token_ids = batch_unique_consecutive(semantic_token_ids, pad_value=self.pad_id)
         if return_loss:
-            semantic_labels, coarse_labels = semantic_token_ids, coarse_token_ids.clone()
+            semantic_labels, coarse_labels = semantic_token_ids, coarse_token_ids                  # (nothing below writes into the ids: no copy)
             coarse_token_ids = coarse_token_ids[:, :-1]
         self_attn_mask = (semantic_token_ids != self.pad_id) & (semantic_token_ids != self.semantic_eos_id)   # :1801
         semantic_token_ids = semantic_token_ids.masked_fill(~self_attn_mask, 0)

@@ -770,3 +770,21 @@ def test_forgetful_mask_kernel_ties_and_seeded_run(ops):
     s[:, 0] = -torch.finfo(s.dtype).max
     m2 = torch.ones((4, 777), dtype=torch.bool, device=dev()).scatter_(1, s.topk(min(int(777 * 0.15), 776), dim=-1).indices, False)
     assert torch.equal(m1, m2)
+
+
+def test_loss_combine_kernel_and_its_backward(ops):
+    """alm_loss_combine vs the formulation it replaces: per head `sum / (labels != -1).sum().clamp(min=1)`, then the wrappers' weighted sum; the
+    autograd Function's backward is the scale per group"""
+    from audiolm_pytorch_amd import heads
+    g = torch.Generator().manual_seed(9)
+    labels = [torch.randint(-1, 50, (7, 33), generator=g).to(dev()), torch.randint(-1, 3, (5, 1000), generator=g).to(dev()),
+              torch.full((2, 9), -1, dtype=torch.int64, device=dev())]                                     # the last one: no valid label at all
+    sums = [(torch.rand((), generator=g) * 100).to(dev()).requires_grad_() for _ in labels]
+    w = (0.3, 1.7, 0.5)
+    loss = heads.combine_losses(sums, labels, w)
+    ref = sum(wi * s.detach().double() / (l != -1).sum().clamp(min=1) for wi, s, l in zip(w, sums, labels))
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    (loss * 2.5).backward()
+    for wi, s, l in zip(w, sums, labels):
+        want = 2.5 * wi / max(int((l != -1).sum()), 1)
+        assert abs(float(s.grad) - want) <= 1e-6 * want
