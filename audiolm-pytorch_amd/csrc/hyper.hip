@@ -15,6 +15,7 @@
 // block barrier.  Parameter gradients are accumulated in registers over a grid-stride token loop, reduced over the 4 waves
 // of a block through LDS and written as per-block partial rows (second stage: alm_colsum).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
@@ -35,7 +36,15 @@ __device__ __forceinline__ void st4bf(bf16_t* p, float4 v) { *reinterpret_cast<u
 __device__ __forceinline__ float4 ldR(const float* p) { return ld4(p); }
 __device__ __forceinline__ float4 ldR(const bf16_t* p) { return ld4bf(p); }
 __device__ __forceinline__ void stR(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void stR(bf16_t* p, float4 v) { st4bf(p, v); }
+// bf16 stream stores are NON-TEMPORAL: R' / dR' (134 MB per launch) are next read several kernels later, while the X / XN / dY rows written beside them
+// (st4bf, cached) feed the GEMM that follows immediately -- hc_fwd 84 -> 80 us stand-alone, -0.05 ms per training step (three interleaved runs)
+typedef unsigned int nt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stR(bf16_t* p, float4 v) {
+    nt_u2 w;
+    w.x = pack_bf2(v.x, v.y);
+    w.y = pack_bf2(v.z, v.w);
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_u2*>(p));
+}
 // 4 consecutive residual elements exactly as they sit in HBM (fp32: 4 registers, bf16: 2): what a software-prefetched token keeps in
 // registers while the previous token is being processed
 template <typename RT> struct Raw4;
@@ -511,7 +520,7 @@ struct HcBwdArgs {
 // The kernel arguments re-read from the kernarg segment (scalar loads: free for the VALU) instead of held in SGPRs across the token loop: hc_bwd keeps
 // ~25 pointers / strides alive next to 2 x 13 per-stream scalars, more than the 102 SGPRs -- the compiler parked the surplus in VGPR lanes and fetched it
 // back with v_readlane INSIDE the loop (56 of the ~1190 VALU instructions per token and wave).  The empty asm makes every call a fresh base the loads
-// cannot be hoisted over.
+// cannot be hoisted over.  HcBwdArgs is the kernel's first and only parameter: it sits at offset 0 of the kernarg segment (static_assert below).
 // base + a 32-bit BYTE offset: the form the global_load / global_store "SGPR base + 32-bit VGPR offset" addressing takes (an element index would be
 // widened to 64 bits before the scale, i.e. a v_lshl_add_u64 per access)
 template <typename T> __device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
@@ -519,6 +528,7 @@ template <typename T> __device__ __forceinline__ T* at_bytes(T* base, unsigned b
     return (T*)((gchar*)(base) + byte_off);
 }
 typedef const __attribute__((address_space(4))) HcBwdArgs* HcBwdKArgs;
+static_assert(std::is_trivially_copyable<HcBwdArgs>::value && alignof(HcBwdArgs) <= 8, "passed by value in the kernarg segment, read back in place");
 __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
     HcBwdKArgs p = (HcBwdKArgs)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
