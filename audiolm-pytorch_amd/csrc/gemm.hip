@@ -1168,6 +1168,10 @@ int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipS
     // automatic 256 x 256 choices with at least that many K elements per slice to it (A/B runs).
     static const int w4_mink = [] { const char* e = getenv("ALM_GEMM_W4_MINK"); return e ? atoi(e) : 0; }();
     if (hook && w4_mink > 0 && tl == 13 && tile == 0 && (p.ksplit > 0 ? p.ksplit : p.K) >= w4_mink) tl = 14;
+    // ... except the full-K weight-gradient launches of the hybrid plan (TN, K = all tokens of the batch, no slices): there the 4-wave tile is ON by
+    // default -- its longer uninterrupted main loop is what it was built for: -0.05 ms / step on three interleaved runs (ALM_GEMM_W4_TN_MINK=0: off)
+    static const int w4_tn_mink = [] { const char* e = getenv("ALM_GEMM_W4_TN_MINK"); return e ? atoi(e) : 8192; }();
+    if (TNMODE && hook && w4_tn_mink > 0 && tl == 13 && (p.ksplit > 0 ? p.ksplit : p.K) >= w4_tn_mink) tl = 14;
     if (tl == 14) return out_f32 ? launch_w4<TNMODE, true>(p, ny, nz, st) : launch_w4<TNMODE, false>(p, ny, nz, st);
     if (tl == 13) return out_f32 ? launch_stag<TNMODE, true>(p, ny, nz, st) : launch_stag<TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);

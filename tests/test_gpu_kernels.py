@@ -705,13 +705,14 @@ def test_gemm_tn_batched_two_level_strided(ops):
     assert relmax(C3, ref3) <= 2e-5
 
 
+@pytest.mark.parametrize('K', [4160, 8256])                                        # 8256: the full-K launch takes the 4-wave tile (>= 8192 per slice)
 @pytest.mark.parametrize('accumulate', [False, True])
-def test_gemm_tn_batched_hybrid_plan(ops, accumulate):
+def test_gemm_tn_batched_hybrid_plan(ops, accumulate, K):
     """alm_gemm_bf16_tn_batched, hybrid plan: the panels that fill whole waves of the 256 CUs run at full K straight into C, the last problem's
     remaining row (m-major: dW1) or column (n-major: dW2) blocks are a deep split-K launch on the sub-matrix.  Shapes of the benchmark's weight
     gradients (inner width 2730, padded 2736, 3 layers x 2 halves / 6 layers), a shorter contraction."""
     from audiolm_pytorch_amd import _lib
-    L, K, I, Ip, D = 3, 4160, 2730, 2736, 1024
+    L, I, Ip, D = 3, 2730, 2736, 1024
     assert _lib.query('alm_gemm_splitk_ws_floats', I, D, K, 2 * L) > 0
     dU = rnd(L, K, 2 * Ip, seed=601, dtype=BF16)
     XN = rnd(L, K, D, seed=602, dtype=BF16)
