@@ -54,7 +54,9 @@ struct GemmParams {
     int ksplit;        // > 0: split-K -- blockIdx.z is the K-slice index, slice s covers k in [s*ksplit, min(K, (s+1)*ksplit)) and
                        // writes its fp32 partial tile to C + s * sCk (reduced afterwards by splitk_reduce_kernel)
     long long sCk;
-    int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel)
+    int raster;        // 1: split-K launches -- 1-D grid, XCD-panel rasterisation (see kernel): panel q on XCD q % 8.  2: the same with panel q on
+                       // XCD q / (P / 8) -- consecutive panels are the row blocks of ONE problem, so an XCD then needs the small operand of 2-3
+                       // problems instead of every problem's (batched weight gradients: the small operand was fetched by all 8 XCD L2s)
     int nsl;           // number of K slices (raster 1)
     int nbt = 0;       // total number of batched problems nb1 * nb2 (0: nb2 -- the one-level callers); raster 1 enumerates panels over all of them
     int plimit = 0;    // raster 1: > 0 = launch only the first `plimit` panels (alm_gemm_bf16_tn_batched: whole waves at full K, the tail separately)
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn, zb, zs;
-    if (p.raster == 1) {
+    if (p.raster >= 1) {
         // split-K weight gradients: the operand with MANY tile panels (e.g. dU: 22 panels of 256 columns) is the big one.  Panel q
         // (its K slices and the few tiles along the other dimension) is pinned to XCD q % 8 (workgroup L runs on XCD L % 8 -- observed
         // dispatch order; a wrong guess only costs speed), so each of its K slices is fetched from HBM once and shared through that
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
-        const int panel = (rem / Q) * 8 + xcd;
+        const int panel = p.raster == 2 ? xcd * PL + rem / Q : (rem / Q) * 8 + xcd;       // raster 2: a contiguous block of panels per XCD (see GemmParams)
         const int minor = rem % Q;
         if (panel >= P || zs >= p.nsl) return;
         zb = panel / tmaj;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn, zb, zs;
-    if (p.raster == 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
+    if (p.raster >= 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
-        const int panel = (rem / Q) * 8 + xcd;
+        const int panel = p.raster == 2 ? xcd * PL + rem / Q : (rem / Q) * 8 + xcd;       // raster 2: a contiguous block of panels per XCD (see GemmParams)
         const int minor = rem % Q;
         if (panel >= P || zs >= p.nsl) return;                              // whole workgroup: no barrier is skipped by a subset
         zb = panel / tmaj;
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn, zb, zs;
-    if (p.raster == 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
+    if (p.raster >= 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
         const int PL = (P + 7) / 8;
         zs = j / (PL * Q);
         const int rem = j % (PL * Q);
-        const int panel = (rem / Q) * 8 + xcd;
+        const int panel = p.raster == 2 ? xcd * PL + rem / Q : (rem / Q) * 8 + xcd;       // raster 2: a contiguous block of panels per XCD (see GemmParams)
         const int minor = rem % Q;
         if (panel >= P || zs >= p.nsl) return;
         zb = panel / tmaj;
@@ -1084,7 +1086,7 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
         attr_done = true;
     }
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    if (p.raster == 1) {
+    if (p.raster >= 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
         const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(WM * WN * 64), smem, st, p);
@@ -1105,7 +1107,7 @@ int launch_stag(const GemmParams& p, int ny, int nz, hipStream_t st) {
         attr_done = true;
     }
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-    if (p.raster == 1) {
+    if (p.raster >= 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
         const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(512), smem, st, p);
@@ -1127,7 +1129,7 @@ int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
         attr_done = true;
     }
     const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-    if (p.raster == 1) {
+    if (p.raster >= 1) {
         const int tmaj = tiles_m >= tiles_n ? tiles_m : tiles_n, Q = tiles_m >= tiles_n ? tiles_n : tiles_m;
         const int PL = ((p.plimit > 0 ? p.plimit : tmaj * ny) + 7) / 8;
         hipLaunchKernelGGL(kfn, dim3(8 * PL * Q * nz), dim3(256), smem, st, p);
@@ -1371,8 +1373,9 @@ extern "C" int alm_gemm_bf16_tn_batched(const void* At, const void* Bt, float* C
     const HybridPlan hy = hybrid_plan(M, N, K, nb);
     if (hy.panels_a > 0) {
         // (a) the panels that fill whole waves of the chip: full K, straight into C -- no partials, no reduce
-        GemmParams pa{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0, 1, 1, nb,
-                      hy.panels_a};
+        static const int raster_a = [] { const char* e = getenv("ALM_GEMM_HYBRID_RASTER"); return e ? atoi(e) : 2; }();    // A/B switch: 1 = round-robin panels
+        GemmParams pa{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0,
+                      (hy.panels_a % 8 == 0 && raster_a == 2) ? 2 : 1, 1, nb, hy.panels_a};
         rc = launch_gemm<true>(pa, nb, 1, 1, 13, st);
         if (rc) return rc;
         // (b) the last problem's remaining row (column) blocks: an ordinary split-K problem on the sub-matrix, deep enough to fill the chip once
