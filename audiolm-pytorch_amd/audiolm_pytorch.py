@@ -41,6 +41,7 @@ from .attend import Attend
 from .version import __version__
 
 DEFAULT_T5_NAME = 'google/t5-v1_1-base'
+FUSED_PREPARE = os.environ.get('ALM_FUSED_PREPARE', '1') != '0'      # CoarseTransformerWrapper: training-step id bookkeeping as one kernel (A/B switch, tests)
 DECODE_GRAPH = os.environ.get('ALM_DECODE_GRAPH', '1') != '0'        # capture the single-position sampling step into a hipGraph
 _T5_DIMS = {'google/t5-v1_1-small': 512, 'google/t5-v1_1-base': 768, 'google/t5-v1_1-large': 1024,
             'google/t5-v1_1-xl': 2048, 'google/t5-v1_1-xxl': 4096, 't5-small': 512, 't5-base': 768, 't5-large': 1024}
@@ -1103,14 +1104,17 @@ class CoarseTransformer(_TransformerBase):
         self.coarse_logit_weights = nn.Parameter(torch.randn(num_coarse_quantizers, codebook_size_with_eos, dim))
         self.dim = dim
 
-    def _assemble(self, semantic_token_ids, coarse_token_ids):
+    def _assemble(self, semantic_token_ids, coarse_token_ids, prepared=None):
         b, dev = semantic_token_ids.shape[0], semantic_token_ids.device
         Q, C = self.num_coarse_quantizers, self.codebook_size
-        coarse, sem = _flatten_ids(coarse_token_ids), _flatten_ids(semantic_token_ids)           # :894
-        ns, nc = sem.shape[1], coarse.shape[1]
-        coarse_rows = coarse.to(torch.int32) + _quantizer_row_offsets(nc, Q, C, dev)             # :896-899 (stride C: eos aliasing kept)
-        sem_code = sem.to(torch.int32).clamp(min=-1)                                             # table 0; pad (any negative id) -> zero (:901)
-        src_a = torch.cat((_const_code(3, b, dev), sem_code, _const_code(4, b, dev), _code(1, coarse_rows)), dim=1).contiguous()
+        if prepared is not None:                                                                 # (src_a, ns, nc) from ops.coarse_prepare: the codes below, one kernel
+            src_a, ns, nc = prepared
+        else:
+            coarse, sem = _flatten_ids(coarse_token_ids), _flatten_ids(semantic_token_ids)       # :894
+            ns, nc = sem.shape[1], coarse.shape[1]
+            coarse_rows = coarse.to(torch.int32) + _quantizer_row_offsets(nc, Q, C, dev)         # :896-899 (stride C: eos aliasing kept)
+            sem_code = sem.to(torch.int32).clamp(min=-1)                                         # table 0; pad (any negative id) -> zero (:901)
+            src_a = torch.cat((_const_code(3, b, dev), sem_code, _const_code(4, b, dev), _code(1, coarse_rows)), dim=1).contiguous()
         src_b = _quantizer_codes(2, b, ns + 2, nc, Q, dev)                                       # :904-906
         N = ns + nc + 2
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.semantic_embedding.weight,
@@ -1138,8 +1142,8 @@ class CoarseTransformer(_TransformerBase):
         h = self.transformer._sample(tokens, None, state, context, cmask)
         return self._last_logits(h, self.coarse_logit_weights, None, 'coarse', nc % self.num_coarse_quantizers), state
 
-    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask, context=None, context_mask=None):
-        tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids)
+    def _hidden(self, semantic_token_ids, coarse_token_ids, self_attn_mask, context=None, context_mask=None, prepared=None):
+        tokens, b, N, ns, nc = self._assemble(semantic_token_ids, coarse_token_ids, prepared)
         attn_bias = None
         if exists(self.transformer.rel_pos_bias):
             # :924-936 -- relative positions everywhere except across the semantic / coarse boundary, where every pair gets the learned
@@ -1165,7 +1169,7 @@ class CoarseTransformer(_TransformerBase):
         return groups, params
 
     def forward(self, *, semantic_token_ids, coarse_token_ids, self_attn_mask=None, text=None, text_embeds=None, cond_drop_prob=None,
-                return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None, loss_weights=None):
+                return_only_coarse_logits=False, return_cache=False, kv_cache=None, embed_cache=None, labels=None, loss_weights=None, _prepared=None):
         context, context_mask = self._condition(semantic_token_ids.shape[0], semantic_token_ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=True)
         caches = (None, None)
         if exists(kv_cache) or exists(embed_cache) or return_cache:                               # the reference's cache protocol (:938-953): inference only
@@ -1175,7 +1179,7 @@ class CoarseTransformer(_TransformerBase):
             hn, new_kv, new_em = self._protocol_hidden(tokens, self_attn_mask, attn_bias, context, context_mask, kv_cache, embed_cache)
             caches = (new_kv, new_em)
         else:
-            hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask, context, context_mask)
+            hn, b, N, ns, nc = self._hidden(semantic_token_ids, coarse_token_ids, self_attn_mask, context, context_mask, _prepared)
         dev = hn.device
         if exists(labels):                                                                        # fused loss path: (sem_labels, coarse_labels)
             sem_labels, coarse_labels = labels
@@ -1547,6 +1551,9 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
             coarse_token_ids = coarse_token_ids.clone()
         semantic_token_ids = _flatten_ids(semantic_token_ids)
         coarse_token_ids = _flatten_ids(coarse_token_ids)
+        if (FUSED_PREPARE and self.training and return_loss and not self.unique_consecutive and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64
+                and coarse_token_ids.dtype == torch.int64 and 'kv_cache' not in kwargs and 'embed_cache' not in kwargs and 'return_cache' not in kwargs):
+            return self._forward_train_fused(semantic_token_ids, coarse_token_ids, text, text_embeds, kwargs)
         if self.training:                                                                         # :1788-1790
             semantic_token_ids = append_eos_id(semantic_token_ids, self.transformer.semantic_eos_id)
             coarse_token_ids = append_eos_id(coarse_token_ids, self.transformer.coarse_eos_id)
@@ -1585,6 +1592,22 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
             num_semantic_logits = _num_semantic_logits
         return (semantic_loss * num_semantic_logits * self.semantic_cross_entropy_loss_weight +
                 coarse_loss * num_coarse_logits) / (num_semantic_logits + num_coarse_logits)        # :1851-1854
+
+
+    def _forward_train_fused(self, sem, coarse, text, text_embeds, kwargs):
+        """The training step of forward() (:1785-1854) with its id bookkeeping as ONE kernel (ops.coarse_prepare: eos appended, key mask, zeroed masked ids,
+        padded mask, embedding source codes, labels) instead of ~18 small ATen launches; same arithmetic, same RNG consumption (one randn for the
+        forgetful mask).  Taken when the ids are given, unique_consecutive is off and the wrapper is in training mode; everything else runs forward()."""
+        tr = self.transformer
+        sem_labels, coarse_labels, src_a, keep = ops.coarse_prepare(sem if sem.stride(1) == 1 else sem.contiguous(), coarse if coarse.stride(1) == 1 else coarse.contiguous(),
+                                                                    self.pad_id, tr.semantic_eos_id, tr.coarse_eos_id, tr.num_coarse_quantizers, tr.codebook_size)
+        if self.mask_prob > 0:                                                                    # forgetful causal mask, :1809-1810
+            keep = _forgetful_and_(keep, self.mask_prob)
+        use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(tr.to_semantic_logits)
+        n_c, n_s = coarse_labels.shape[-1], (sem_labels.shape[-1] if use_sem else 0)
+        w = (n_s * self.semantic_cross_entropy_loss_weight / (n_s + n_c), n_c / (n_s + n_c))    # :1826-1854 with integer logit counts
+        return tr(semantic_token_ids=sem, coarse_token_ids=coarse, self_attn_mask=keep, text=text, text_embeds=text_embeds,
+                  labels=(sem_labels, coarse_labels), loss_weights=w, _prepared=(src_a, sem.shape[1] + 1, coarse.shape[1]), **kwargs)
 
 
 class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.py:1856-2137

@@ -349,6 +349,45 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(LossGroups g, float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// CoarseTransformerWrapper.forward's id bookkeeping for a training step (audiolm_pytorch.py:1785-1810 + the code arithmetic of :894-918) in ONE launch:
+// append the eos ids, key mask of the semantic ids (pad / eos keys are masked and their ids zeroed), padded mask over the whole sequence, embedding
+// source codes (start tokens, semantic ids, per-quantizer offset coarse rows) and the two label tensors -- ~18 ATen launches of <= 5 us otherwise.
+//   N = 1 + (ns0 + 1) + 1 + nc0:  [start | semantic ids + eos | coarse start | coarse ids]      (the appended coarse eos is a label only)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_prepare_kernel(const long long* __restrict__ sem, long long ld_sem, const long long* __restrict__ coarse,
+                                                             long long ld_coarse, int B, int ns0, int nc0, long long pad_id, long long sem_eos,
+                                                             long long coarse_eos, int Q, int C, long long* __restrict__ sem_labels,
+                                                             long long* __restrict__ coarse_labels, int* __restrict__ src_a,
+                                                             unsigned char* __restrict__ keep) {
+    const int ns = ns0 + 1, N = ns + nc0 + 2, W = max(N, nc0 + 1);
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)B * W; t += (long long)gridDim.x * 256) {
+        const int b = (int)(t / W), i = (int)(t % W);
+        if (i < N) {
+            int code;
+            bool k = true;
+            if (i == 0) {
+                code = 3 << 24;                                                // semantic_start_token (table 3)
+            } else if (i <= ns) {
+                const int j = i - 1;
+                const long long v = j < ns0 ? sem[(long long)b * ld_sem + j] : sem_eos;
+                sem_labels[(long long)b * ns + j] = v;
+                k = v != pad_id && v != sem_eos;                               // :1801
+                const long long c = k ? v : 0;                                 // masked_fill(~mask, 0)
+                code = c < -1 ? -1 : (int)c;                                   // table 0; a negative id is the zero vector (:901)
+            } else if (i == ns + 1) {
+                code = 4 << 24;                                                // coarse_start_token (table 4)
+            } else {
+                const int kx = i - (ns + 2);
+                code = (int)coarse[(long long)b * ld_coarse + kx] + (kx % Q) * C + (1 << 24);      // :896-899 (stride C: eos aliasing kept)
+            }
+            src_a[(long long)b * N + i] = code;
+            keep[(long long)b * N + i] = k ? 1 : 0;
+        }
+        if (i <= nc0) coarse_labels[(long long)b * (nc0 + 1) + i] = i < nc0 ? coarse[(long long)b * ld_coarse + i] : coarse_eos;
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
@@ -478,6 +517,20 @@ extern "C" int alm_loss_combine(const float* s0, const float* s1, const float* s
     for (int k = 0; k < G; ++k)
         if (!g.sum[k] || (g.n[k] > 0 && !g.labels[k]) || g.n[k] < 0) return ALM_ERR_BAD_ARG;
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, loss, scales);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// sem [B][ns0] / coarse [B][nc0] int64 ids (row strides ld_*) -> sem_labels [B][ns0 + 1], coarse_labels [B][nc0 + 1] (eos appended), src_a int32 [B][N]
+// (embedding source codes, table << 24 | row), keep bytes [B][N] (torch.bool storage; the forgetful mask is ANDed in afterwards), N = ns0 + nc0 + 3.
+extern "C" int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0,
+                                  long long pad_id, long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels,
+                                  long long* coarse_labels, int* src_a, void* keep, void* stream) {
+    if (B <= 0 || ns0 < 0 || nc0 < 0 || Q < 1) return ALM_ERR_BAD_ARG;
+    const long long N = (long long)ns0 + nc0 + 3, W = N > nc0 + 1 ? N : nc0 + 1;
+    if ((long long)(Q - 1) * C + C + 1 >= (1 << 24) || B * W >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(coarse_prepare_kernel, dim3(grid_for(B * W)), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, coarse, ld_coarse, B, ns0, nc0, pad_id,
+                       sem_eos, coarse_eos, Q, C, sem_labels, coarse_labels, src_a, (unsigned char*)keep);
     ALM_LAUNCH_CHECK();
     return 0;
 }

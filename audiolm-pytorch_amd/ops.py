@@ -362,6 +362,23 @@ def loss_combine(sums, labels, weights, ignore_index=-1):
     return loss, scales
 
 
+def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C):
+    """sem int64 [B, ns0], coarse int64 [B, nc0] (flattened (n q)) -> (sem_labels [B, ns0+1], coarse_labels [B, nc0+1], src_a int32 [B, N],
+    keep bool [B, N]) with N = ns0 + nc0 + 3: CoarseTransformerWrapper's training-step id bookkeeping (C ABI: alm_coarse_prepare)."""
+    _chk(sem, torch.int64), _chk(coarse, torch.int64)
+    assert sem.dim() == 2 and coarse.dim() == 2 and sem.stride(1) == 1 and coarse.stride(1) == 1 and sem.shape[0] == coarse.shape[0]
+    B, ns0 = sem.shape
+    nc0 = coarse.shape[1]
+    N, dev = ns0 + nc0 + 3, sem.device
+    sl = torch.empty((B, ns0 + 1), dtype=torch.int64, device=dev)
+    cl = torch.empty((B, nc0 + 1), dtype=torch.int64, device=dev)
+    src_a = torch.empty((B, N), dtype=torch.int32, device=dev)
+    keep = torch.empty((B, N), dtype=torch.bool, device=dev)
+    _lib.call('alm_coarse_prepare', sem.data_ptr(), sem.stride(0), coarse.data_ptr(), coarse.stride(0), B, ns0, nc0, int(pad_id), int(sem_eos), int(coarse_eos),
+              int(Q), int(C), sl.data_ptr(), cl.data_ptr(), src_a.data_ptr(), keep.data_ptr(), _st())
+    return sl, cl, src_a, keep
+
+
 FORGETFUL_MAX_N = 16384
 
 

@@ -181,6 +181,13 @@ int alm_loss_combine(const float* s0, const float* s1, const float* s2, const fl
                      const long long* l3, long long n0, long long n1, long long n2, long long n3, float w0, float w1, float w2, float w3, int G,
                      long long ignore_index, float* loss, float* scales, void* stream);
 
+/* CoarseTransformerWrapper.forward's id bookkeeping of a training step, audiolm_pytorch.py:1785-1810 (append eos, key mask of pad / eos semantic keys,
+ * their ids zeroed, mask padded over [start | semantic | coarse start | coarse]) + the embedding source codes of :894-918 (start tokens, semantic ids,
+ * coarse rows id + (i mod Q) * codebook_size) + the label tensors (ids with the eos appended), in one launch.  N = ns0 + nc0 + 3. */
+int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0, long long pad_id,
+                       long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels, long long* coarse_labels, int* src_a, void* keep,
+                       void* stream);
+
 /* forgetful causal mask, audiolm_pytorch.py:82-89 (`rand[:, 0] = -max; mask = ~zeros.scatter(1, rand.topk(k).indices, 1)`): keep [B][N] bytes (torch.bool
  * storage) &= NOT(one of the `drop` largest scores of its row); column 0 is never dropped; equal scores at the threshold go in index order.
  * drop <= N - 1, N <= 16384. */

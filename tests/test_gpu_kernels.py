@@ -789,3 +789,29 @@ def test_loss_combine_kernel_and_its_backward(ops):
     for wi, s, l in zip(w, sums, labels):
         want = 2.5 * wi / max(int((l != -1).sum()), 1)
         assert abs(float(s.grad) - want) <= 1e-6 * want
+
+
+@pytest.mark.parametrize('B,ns0,nf,Q', [(3, 17, 5, 3), (1, 1, 1, 1), (4, 100, 33, 4), (2, 509, 512, 3)])
+def test_coarse_prepare_kernel_matches_the_wrapper_bookkeeping(ops, B, ns0, nf, Q):
+    """alm_coarse_prepare vs the ATen formulation it replaces (CoarseTransformerWrapper.forward + CoarseTransformer._assemble): labels with the eos
+    appended, key mask, source codes -- with pad ids (-1) and stray eos ids inside the semantic rows"""
+    import torch.nn.functional as F
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    g = torch.Generator().manual_seed(31 * B + ns0)
+    C, n_sem, pad = 64, 50, -1
+    sem_eos, coarse_eos = n_sem, C
+    sem = torch.randint(0, n_sem, (B, ns0), generator=g)
+    sem[torch.rand(B, ns0, generator=g) < 0.15] = pad
+    sem[torch.rand(B, ns0, generator=g) < 0.05] = sem_eos
+    coarse = torch.randint(0, C, (B, nf * Q), generator=g)
+    sem, coarse = sem.to(dev()), coarse.to(dev())
+    sl, cl, src_a, keep = ops.coarse_prepare(sem, coarse, pad, sem_eos, coarse_eos, Q, C)
+    sem1, coarse1 = F.pad(sem, (0, 1), value=sem_eos), F.pad(coarse, (0, 1), value=coarse_eos)
+    assert torch.equal(sl, sem1) and torch.equal(cl, coarse1)
+    m = (sem1 != pad) & (sem1 != sem_eos)
+    sem_clean = sem1.masked_fill(~m, 0)
+    nc = coarse.shape[1]
+    assert torch.equal(keep, F.pad(m, (1, nc + 1), value=True))
+    rows = coarse.to(torch.int32) + AP._quantizer_row_offsets(nc, Q, C, coarse.device)
+    ref = torch.cat((AP._const_code(3, B, coarse.device), sem_clean.to(torch.int32).clamp(min=-1), AP._const_code(4, B, coarse.device), AP._code(1, rows)), dim=1)
+    assert torch.equal(src_a, ref)

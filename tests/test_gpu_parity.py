@@ -455,3 +455,42 @@ def test_classifier_free_guidance_matches_reference():
     print(f'classifier-free guidance (cond_scale {out["cfg_scale"]}): rel-frob semantic {es:.2e} coarse {ec:.2e}')
     bound = 1e-2 * (2 * out['cfg_scale'] - 1)
     assert es <= bound and ec <= bound, (es, ec, bound)
+
+
+def test_coarse_wrapper_fused_training_bookkeeping_equals_the_unfused_path():
+    """CoarseTransformerWrapper._forward_train_fused (ids -> labels / mask / source codes in one kernel) computes the same loss, bit for bit, as the
+    ATen bookkeeping of forward() -- pads and eos ids inside the semantic rows, the forgetful mask recorded and replayed"""
+    import audiolm_pytorch_amd as A
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    model = A.CoarseTransformer(dim=128, depth=2, num_semantic_tokens=50, codebook_size=64, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15, semantic_cross_entropy_loss_weight=0.7)
+    w.train()
+    g = torch.Generator().manual_seed(4)
+    sem = torch.randint(0, 50, (3, 40), generator=g)
+    sem[0, 30:] = -1
+    sem[1, 7] = model.semantic_eos_id
+    coarse = torch.randint(0, 64, (3, 20, 3), generator=g)
+    sem, coarse = sem.to(dev), coarse.to(dev)
+    losses = []
+    for fused in (True, False):
+        AP.FUSED_PREPARE = fused
+        try:
+            torch.manual_seed(123)                                            # the same forgetful draw
+            for p in model.parameters():
+                p.grad = None
+            loss = w(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True)
+            loss.backward()
+            losses.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            AP.FUSED_PREPARE = True
+    assert losses[0][0] == losses[1][0], (losses[0][0], losses[1][0])
+    assert losses[0][1].keys() == losses[1][1].keys()
+    for k in losses[0][1]:
+        a, b = losses[0][1][k], losses[1][1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max().clamp(min=1e-30)), k      # (the embedding scatter adds atomically: order-dependent last bits)
