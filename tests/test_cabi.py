@@ -70,3 +70,43 @@ def test_product_modules_do_not_import_the_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
+
+
+def test_splitk_workspace_covers_the_hybrid_tail():
+    """alm_gemm_bf16_tn_batched's hybrid plan (whole waves of 256 tiles at full K + the last problem's remaining blocks as one deep split-K launch)
+    writes slices x M2 x N2 partial floats: alm_gemm_splitk_ws_floats, which sizes the caller's workspace, must cover them for every shape the plan
+    accepts (host arithmetic only: no GPU).  The plan is restated here from its definition (csrc/gemm.hip hybrid_plan)."""
+    import importlib
+    L = importlib.import_module('audiolm_pytorch_amd._lib')
+
+    def tail_floats(M, N, K, nb):
+        if M < 256 or N < 256 or K < 4096:
+            return 0
+        tm, tn = -(-M // 256), -(-N // 256)
+        m_major = tm >= tn
+        tmaj, Q = (tm, tn) if m_major else (tn, tm)
+        P, total = tmaj * nb, tmaj * nb * Q
+        if total <= 256:
+            return 0
+        pa = (total // 256) * 256 // Q
+        rem = P - pa
+        if pa * Q % 256 or rem <= 0 or rem >= tmaj or rem * Q > 64:
+            return 0
+        off = (tmaj - rem) * 256
+        s = 256 // (rem * Q)
+        ksteps = -(-K // 64)
+        while s > 1 and ksteps // s < 8:
+            s -= 1
+        if s < 2:
+            return 0
+        m2, n2 = (M - off, N) if m_major else (M, N - off)
+        return s * m2 * n2
+    hit = 0
+    for M, N in ((2730, 1024), (1024, 2730), (2736, 1024), (4096, 1024), (1024, 512), (3000, 768), (700, 2050)):
+        for K in (4096, 8192, 16384, 131072):
+            for nb in (1, 2, 3, 6, 12, 24):
+                need = tail_floats(M, N, K, nb)
+                got = L.query('alm_gemm_splitk_ws_floats', M, N, K, nb)
+                assert got == -1 or got >= need, (M, N, K, nb, got, need)
+                hit += need > 0
+    assert hit >= 10                                            # the benchmark's dW1 / dW2 shapes (6 and 12 problems) are among them
