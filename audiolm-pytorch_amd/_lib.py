@@ -20,6 +20,8 @@ SIGNATURES = {
     'alm_gemm_splitk_slices': [_I, _I, _I, _I],
     'alm_gemm_splitk_ws_floats': [_I, _I, _I, _I],
     'alm_gemm_splitk_tile': [_I, _I, _I, _I],
+    'alm_gemm_nt_tile_choice': [_I, _I, _I],
+    'alm_gemm_tn_batched_plan': [_I, _I, _I, _I, _P],
     'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_batched': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _P],

@@ -1158,11 +1158,13 @@ int pick_tile(int M, int N, int ny, int tile, bool tn) {
 }
 
 template <bool TNMODE>
-int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st, bool hook = true) {
+int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st, bool hook = true, bool only256 = false) {
     static const int big_tile = [] { const char* e = getenv("ALM_GEMM_BIG_TILE"); return e ? atoi(e) : 0; }();   // A/B hook: 2 / 11 / 13 for every big launch
     int tl = pick_tile(p.M, p.N, ny * nz, tile, TNMODE);
     if (tl < 0) return ALM_ERR_UNSUPPORTED;
-    if (hook && tl != 1 && (big_tile == 2 || big_tile == 11 || big_tile == 13 || big_tile == 14)) tl = big_tile;
+    // only256: the caller's panel arithmetic (GemmParams.plimit and the tail offset of the hybrid weight-gradient plan) is in units of 256 x 256 tiles --
+    // the hook may swap the 256 x 256 kernels for one another there, never re-tile the launch (a 384 x 256 grid would cover the wrong set of C tiles)
+    if (hook && tl != 1 && (big_tile == 2 || big_tile == 13 || big_tile == 14 || (big_tile == 11 && !only256))) tl = big_tile;
     // The 4-wave tile (gemm_w4_kernel, id 14) is OPT-IN: stand-alone its main loop is 4-9 % faster per K-step than the staggered tile on long
     // contractions (K = 1024 -1 %, 2736 +-0, 5472 +4 %, 8192 +6-9 %), but INSIDE the training step it measured slower on alternating runs
     // (ALM_GEMM_W4_MINK = 4096: NT big-tile time 3.94 -> 4.05 ms / step; 2048: 4.13 ms; TN unchanged) -- one wave per SIMD has nothing to cover a
@@ -1296,6 +1298,27 @@ extern "C" int alm_gemm_splitk_slices(int M, int N, int K, int nb) { return spli
 // block tile the split-K plan picks for this problem: 1 = 128 x 128, otherwise a 256 x 256 tile (bench.py files its per-kernel timings by it)
 extern "C" int alm_gemm_splitk_tile(int M, int N, int K, int nb) { return splitk_plan(M, N, K, nb < 1 ? 1 : nb).tile; }
 
+// Host-side plan queries (no launch, no GPU): which kernel a given launch WILL take.  Tests assert with them that the shapes of the benchmarked step
+// (B = 8: M = 16384) run on the big tiles the roofline is quoted on, bench.py files its per-kernel timings by them.
+//   alm_gemm_nt_tile_choice: block tile of alm_gemm_bf16_nt(M, N, nb = nb1 * nb2 problems): 1 = 128 x 128, 13 = 256 x 256 staggered, 11 = 384 x 256
+//   (the ALM_GEMM_BIG_TILE / ALM_GEMM_W4_MINK A/B environment hooks are NOT applied: this is the shipped choice)
+extern "C" int alm_gemm_nt_tile_choice(int M, int N, int nb) { return pick_tile(M, N, nb < 1 ? 1 : nb, 0, false); }
+
+//   alm_gemm_tn_batched_plan: alm_gemm_bf16_tn_batched(M, N, K, nb problems) -> 0 = one launch at full K (no partials), 1 = uniform split-K
+//   (plan[0] = tile, plan[1] = slices), 2 = hybrid (plan[0] = panels at full K on the 4-wave 256 x 256 tile when K >= 8192, else the staggered
+//   tile; plan[1] = slices of the tail; plan[2] = first row / column of the tail inside the last problem; plan[3] = 1 when the tail is cut along M)
+extern "C" int alm_gemm_tn_batched_plan(int M, int N, int K, int nb, int* plan) {
+    nb = nb < 1 ? 1 : nb;
+    const HybridPlan hy = hybrid_plan(M, N, K, nb);
+    if (hy.panels_a > 0) {
+        if (plan) { plan[0] = hy.panels_a; plan[1] = hy.slices_b; plan[2] = hy.off; plan[3] = hy.m_major; }
+        return 2;
+    }
+    const SplitPlan pl = splitk_plan(M, N, K, nb);
+    if (plan) { plan[0] = pl.tile; plan[1] = pl.slices; plan[2] = 0; plan[3] = 0; }
+    return pl.slices > 1 ? 1 : 0;
+}
+
 // fp32 workspace floats alm_gemm_bf16_{nt,tn}_splitk need for this problem (0: none)
 extern "C" int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb) {
     nb = nb < 1 ? 1 : nb;
@@ -1376,7 +1399,7 @@ extern "C" int alm_gemm_bf16_tn_batched(const void* At, const void* Bt, float* C
         static const int raster_a = [] { const char* e = getenv("ALM_GEMM_HYBRID_RASTER"); return e ? atoi(e) : 2; }();    // A/B switch: 1 = round-robin panels
         GemmParams pa{(const bf16_t*)At, (const bf16_t*)Bt, C, nullptr, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0,
                       (hy.panels_a % 8 == 0 && raster_a == 2) ? 2 : 1, 1, nb, hy.panels_a};
-        rc = launch_gemm<true>(pa, nb, 1, 1, 13, st);
+        rc = launch_gemm<true>(pa, nb, 1, 1, 13, st, true, true);
         if (rc) return rc;
         // (b) the last problem's remaining row (column) blocks: an ordinary split-K problem on the sub-matrix, deep enough to fill the chip once
         const long long zA = (long long)(nb1 - 1) * sA1 + (long long)(nb2 - 1) * sA2, zB = (long long)(nb1 - 1) * sB1 + (long long)(nb2 - 1) * sB2;

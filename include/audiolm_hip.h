@@ -45,6 +45,13 @@ int alm_gemm_splitk_slices(int M, int N, int K, int nb);
 int alm_gemm_splitk_ws_floats(int M, int N, int K, int nb);
 /* block tile of the split-K plan for this problem: 1 = 128 x 128 (4 waves), otherwise a 256 x 256 tile */
 int alm_gemm_splitk_tile(int M, int N, int K, int nb);
+/* host-side plan queries (no launch): the kernel a launch WILL take.
+ *   alm_gemm_nt_tile_choice: block tile of alm_gemm_bf16_nt(M, N) with nb = nb1 * nb2 problems: 1 = 128 x 128 (4 waves), 13 = 256 x 256 with staggered
+ *     wave rows, 11 = 384 x 256 (the shipped choice; A/B environment hooks not applied)
+ *   alm_gemm_tn_batched_plan: alm_gemm_bf16_tn_batched(M, N, K) over nb problems -> 0 = one full-K launch, 1 = uniform split-K (plan = {tile, slices, 0, 0}),
+ *     2 = hybrid: plan = {panels at full K, slices of the tail, first row / column of the tail in the last problem, tail cut along M}; plan: int[4] | NULL */
+int alm_gemm_nt_tile_choice(int M, int N, int nb);
+int alm_gemm_tn_batched_plan(int M, int N, int K, int nb, int* plan);
 int alm_gemm_bf16_nt_splitk(const void* A, const void* B, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,
                             long long ldc, int nb, long long sA, long long sB, long long sC, float alpha, int accumulate, void* stream);
 int alm_gemm_bf16_tn_splitk(const void* At, const void* Bt, float* C, float* ws, int M, int N, int K, long long lda, long long ldb,

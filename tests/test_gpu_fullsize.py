@@ -2,8 +2,14 @@
 dim=1024 depth=6, N=1024), the headline (same model, N=2048) and configs[2] (FineTransformer dim=1024 depth=6, 3 + 5 quantizers, N=2049),
 each with 4 residual streams (restated hyper-connections) and with 1 stream (every op first-party reference code).
 
-This is where the production kernels actually run: the 256x256 GEMM tile, attention across many 64-key tiles, the 2730 -> 2736 padded FFN
-width, split-K weight gradients over K = B*N tokens, the multi-token-per-workgroup hyper-connection loops.  Parameters are the
+WHICH kernels run depends on the batch (tests/test_plan_queries.py pins the selection on the CPU):
+  * B = 1 / 2 (M = 2048 rows; the round 2-3 cases): attention across many 64-key tiles, the 2730 -> 2736 padded FFN width, split-K weight gradients
+    over K = B*N tokens, the multi-token-per-workgroup hyper-connection loops -- but every NT GEMM of the step is on the 128 x 128 tile (too few 256 x 256
+    tiles for 256 CUs) and the weight gradients on the uniform split-K plan;
+  * B = 8 (M = 16 384 rows = EXACTLY what bench.py times; round 4): `gemm_kernel<384,256>` (W1 forward, dHN), `gemm_stag_kernel<NT>` (to_out, W2, the dXN
+    dgrads, the coarse logit head), the layer-batched weight gradients on the hybrid plan (`gemm_w4_kernel<TN>` at full K = 16 384 + split-K tail), the
+    stacked `out=` buffers of the deferred mode.  The oracle runs the 8 sequences in one CPU pass (~8x the B = 1 time).
+Parameters are the
 non-degenerate synthetic values of tests/golden/common.py (every hyper-connection / LayerNorm / bias path carries signal); inputs are
 seeded uniform token ids; the forgetful mask is drawn once on the CPU and injected on both sides.
 
@@ -12,7 +18,11 @@ Compared END TO END: the loss, EVERY logit, and the gradient of EVERY parameter,
         loss     |d| <= 1e-3 * |loss|                      (north_star: loss within 1e-3; no noise clause)
         logits   rel Frobenius error <= max(1e-2, the oracle's own bf16-autocast deviation on the same inputs)  -- both numbers are reported
         grads    per tensor rel Frobenius error <= max(3e-2, 2 x the oracle's bf16-autocast deviation of that tensor); hyper-connection scalar
-                 statistics pooled (see tests/test_gpu_parity.py)
+                 statistics pooled (see tests/test_gpu_parity.py).  HONEST SCOPE: for the hyper-connection SCALARS (static_alpha / static_beta /
+                 dynamic_*_scale: sums over all tokens of terms that cancel) this end-to-end bound does not discriminate -- e.g.
+                 layers.0.0.dynamic_beta_scale passes at a rel error of 5.8 because the reference's own bf16-autocast run moves it by 6.1
+                 (profiles/r3_runZ_fullsize_parity.jsonl); those gradients are checked with teeth only op by op (tests/test_gpu_opwise.py: 1e-2
+                 given the same inputs, measured <= 1e-4 with fp32 streams)
   (A) the ROUNDING-MATCHED oracle (oracle/rounding_matched.py: bf16 rounding at the HIP path's storage / operand points).  MEASURED (round 3,
       profiles/r3_runC_fullsize_parity.jsonl, profiles/r3_runA_golden_parity.log): end to end it is NO closer than (B) -- logits 0.7-3e-2 -- although the very same oracle reproduces the
       small goldens to 4e-7 when no rounding flips and every single op of THIS stack to <= 7e-5 given the same inputs (tests/test_gpu_opwise.py).  A
@@ -22,7 +32,7 @@ Compared END TO END: the loss, EVERY logit, and the gradient of EVERY parameter,
       forward <= 1e-3, measured <= 7e-5; backward <= 3e-3; cancelling hyper-connection scalar gradients <= 1e-2).
 Synthetic hyper-connection weights are width-scaled (tests/golden/common.py): the dynamic pre-activations keep a std of ~0.4 at dim 1024.
 test_full_size_matches_real_reference_digest compares the HIP path DIRECTLY with digests of the REAL reference at these sizes (tests/golden/full_*.pt).
-Every run appends its numbers to gpurun_out/r3_fullsize_parity.jsonl (copied to profiles/ for the record).
+Every run appends its numbers to gpurun_out/r4_fullsize_parity.jsonl (copied to profiles/ for the record).
 """
 import json
 import os
@@ -40,23 +50,23 @@ import rounding_matched as RM
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r3_fullsize_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r4_fullsize_parity.jsonl')
 
 
-def _case(kind, streams, N_kind):
+def _case(kind, streams, N_kind, batch=None):
     g = torch.Generator().manual_seed(1234)
     extra = {} if streams == 4 else dict(num_residual_streams=streams)
     if kind == 'coarse':
         ctor = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True, **extra)
         ns, nf = (253, 256) if N_kind == 1024 else (509, 512)
-        B = 2 if N_kind == 1024 else 1
+        B = batch or (2 if N_kind == 1024 else 1)
         inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, ns), generator=g), coarse_token_ids=torch.randint(0, 1024, (B, nf, 3), generator=g))
         N = 1 + (ns + 1) + 1 + nf * 3
         inputs['forgetful_mask'] = O.generate_mask_with_prob((B, N), 0.15, 'cpu', generator=g)
         options = dict(training=True, unique_consecutive=False, mask_prob=0.15)
     else:
         ctor = dict(dim=1024, depth=6, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=1024, flash_attn=True, **extra)
-        B = 1
+        B = batch or 1
         grid = torch.randint(0, 1024, (B, 256, 8), generator=g)
         inputs = dict(coarse_token_ids=grid[..., :3].contiguous(), fine_token_ids=grid[..., 3:].contiguous())
         N = 1 + 768 + 1 + 1279
@@ -65,20 +75,34 @@ def _case(kind, streams, N_kind):
     return ctor, inputs, options, N, B
 
 
-@pytest.mark.parametrize('kind,streams,N_kind,residual', [('coarse', 4, 2048, 'fp32'), ('coarse', 4, 2048, 'bf16'), ('coarse', 1, 2048, 'fp32'),
-                                                          ('coarse', 4, 1024, 'fp32'), ('coarse', 4, 1024, 'bf16'), ('coarse', 1, 1024, 'fp32'),
-                                                          ('fine', 4, 2049, 'fp32'), ('fine', 4, 2049, 'bf16'), ('fine', 1, 2049, 'fp32'),
-                                                          ('coarse-default-init', 4, 2048, 'bf16')])
-def test_full_size_matches_oracle(kind, streams, N_kind, residual):
+@pytest.mark.parametrize('kind,streams,N_kind,residual,batch',
+                         [('coarse', 4, 2048, 'fp32', None), ('coarse', 4, 2048, 'bf16', None), ('coarse', 1, 2048, 'fp32', None),
+                          ('coarse', 4, 1024, 'fp32', None), ('coarse', 4, 1024, 'bf16', None), ('coarse', 1, 1024, 'fp32', None),
+                          ('fine', 4, 2049, 'fp32', None), ('fine', 4, 2049, 'bf16', None), ('fine', 1, 2049, 'fp32', None),
+                          ('coarse-default-init', 4, 2048, 'bf16', None),
+                          # round 4: the BENCHMARKED shape itself -- B = 8 x N = 2048, bf16 streams, synthetic and default (= bench.py's) initialisation
+                          ('coarse', 4, 2048, 'bf16', 8), ('coarse-default-init', 4, 2048, 'bf16', 8)])
+def test_full_size_matches_oracle(kind, streams, N_kind, residual, batch):
     """residual: HBM storage of the 4 residual streams (bf16 = the benchmark's setting = what autocast gives the reference).
+    batch = 8: M = 16 384 rows, the shape bench.py times -- the big-tile NT GEMMs, the hybrid-plan batched weight gradients and the stacked buffers of the
+    deferred mode run inside this comparison (asserted below through the library's plan queries).  The rounding-matched oracle pass is skipped there
+    (it would triple the CPU time and is reported-only: see (A) in the module docstring); every gradient tensor listed is held to max(3e-2, 2 x the
+    oracle's own bf16-autocast deviation), the hyper-connection SCALAR gradients pooled -- their per-tensor errors are dominated by cancellation noise
+    (a scalar passes at rel error > 1 when the reference's own bf16 run moves it as much): the discriminating bound for them is the op-wise one (1e-2).
     'coarse-default-init': the reference's DEFAULT initialisation instead of the synthetic values (hyper-connection dynamic weights zero,
     randn logit weights: the weights bench.py times) -- the synthetic hyper-connection weights (0.05 randn over 1024 features: saturating tanh
     gates) amplify every rounding difference, the reference's own bf16 run moves its logits by 7-19 % there."""
     import audiolm_pytorch_amd as A
     default_init = kind.endswith('-default-init')
     kind = kind.split('-')[0]
-    ctor, inputs, options, N, B = _case(kind, streams, N_kind)
+    ctor, inputs, options, N, B = _case(kind, streams, N_kind, batch)
     assert N == N_kind
+    if batch == 8:                                                             # the kernels the roofline is quoted on really run in this case
+        import ctypes
+        from audiolm_pytorch_amd import _lib
+        plan = (ctypes.c_int * 4)()
+        assert _lib.query('alm_gemm_nt_tile_choice', B * N, 2 * 2736, 1) == 11 and _lib.query('alm_gemm_nt_tile_choice', B * N, 1024, 1) == 13
+        assert _lib.query('alm_gemm_tn_batched_plan', 2730, 1024, B * N, 12, ctypes.cast(plan, ctypes.c_void_p)) == 2
     K = dict(coarse=A.CoarseTransformer, fine=A.FineTransformer)[kind]
     torch.manual_seed(7)
     m0 = K(**ctor)
@@ -99,10 +123,12 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual):
     with torch.autocast('cpu', dtype=torch.bfloat16):                          # the oracle's own bf16-autocast deviation on these inputs
         nloss, nlogits, ngrads = oracle_run(fx)
     t0 = time.time()
-    with RM.rounding_matched(residual_bf16=(residual == 'bf16' and streams > 1)):    # (A) the rounding-matched oracle, same storage type of the streams
-        rloss, rlogits, rgrads = oracle_run(fx)
+    rloss = rlogits = rgrads = None
+    if batch is None:
+        with RM.rounding_matched(residual_bf16=(residual == 'bf16' and streams > 1)):    # (A) the rounding-matched oracle, same storage type of the streams
+            rloss, rlogits, rgrads = oracle_run(fx)
+        rlogits = [t.detach() for t in rlogits if t is not None]
     t_rm = time.time() - t0
-    rlogits = [t.detach() for t in rlogits if t is not None]
     TG.synth_state_dict = orig_synth
     nlogits = [t.detach().float() for t in nlogits if t is not None]
     noise = dict(loss_rel=abs(float(nloss) - float(oloss)) / abs(float(oloss)),
@@ -134,21 +160,24 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual):
     ok &= grad_report(items, rep)
     # (A) against the rounding-matched oracle, end to end: reported, held to the same bound as (B) (see the module docstring: a deep stack decorrelates
     # the rounding errors of ANY two runs; the tight per-op bounds are in tests/test_gpu_opwise.py)
-    rm_l = [_frob(a, b) for a, b in zip(logits, rlogits)]
-    rep.append(f'  vs ROUNDING-MATCHED oracle ({t_rm:.1f} s): loss rel |d| {abs(loss - float(rloss)) / abs(float(rloss)):.2e}; logits rel-frob {["%.2e" % e for e in rm_l]}')
-    ok &= all(e <= max(1e-2, nz) for e, nz in zip(rm_l, noise['logits']))
-    rm_g = {k: _frob(grads[k], g) for k, g in rgrads.items() if g is not None and float(g.norm()) >= 1e-7}
-    worst_t = max((e, k) for k, e in rm_g.items() if not k.endswith(HC_SCALARS))
-    hc = [(e, k) for k, e in rm_g.items() if k.endswith(HC_SCALARS)]
-    worst_s = max(hc) if hc else (0.0, '-')
-    rep.append(f'     grads: worst tensor {worst_t[0]:.2e} ({worst_t[1]}), worst hyper-connection scalar {worst_s[0]:.2e} ({worst_s[1]})')
+    rm_l, worst_t, worst_s, rm_loss = None, (None, '-'), (None, '-'), None
+    if rloss is not None:
+        rm_l = [_frob(a, b) for a, b in zip(logits, rlogits)]
+        rm_loss = abs(loss - float(rloss)) / abs(float(rloss))
+        rep.append(f'  vs ROUNDING-MATCHED oracle ({t_rm:.1f} s): loss rel |d| {rm_loss:.2e}; logits rel-frob {["%.2e" % e for e in rm_l]}')
+        ok &= all(e <= max(1e-2, nz) for e, nz in zip(rm_l, noise['logits']))
+        rm_g = {k: _frob(grads[k], g) for k, g in rgrads.items() if g is not None and float(g.norm()) >= 1e-7}
+        worst_t = max((e, k) for k, e in rm_g.items() if not k.endswith(HC_SCALARS))
+        hc = [(e, k) for k, e in rm_g.items() if k.endswith(HC_SCALARS)]
+        worst_s = max(hc) if hc else (0.0, '-')
+        rep.append(f'     grads: worst tensor {worst_t[0]:.2e} ({worst_t[1]}), worst hyper-connection scalar {worst_s[0]:.2e} ({worst_s[1]})')
     print('\n'.join(rep))
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
     with open(REPORT, 'a') as fh:
         fh.write(json.dumps(dict(kind=kind, init='default' if default_init else 'synthetic', streams=streams, N=N, B=B, residual_streams=residual, loss_ours=loss, loss_oracle=float(oloss),
                                  loss_rel=rel, loss_rel_oracle_bf16=noise['loss_rel'], logits_rel_frob=lerr, logits_rel_frob_oracle_bf16=noise['logits'],
                                  worst_grad_tensor_rel_frob_vs_rounding_matched=worst_t[0], worst_grad_hc_scalar_rel_frob_vs_rounding_matched=worst_s[0],
-                                 logits_rel_frob_vs_rounding_matched=rm_l, loss_rel_vs_rounding_matched=abs(loss - float(rloss)) / abs(float(rloss)),
+                                 logits_rel_frob_vs_rounding_matched=rm_l, loss_rel_vs_rounding_matched=rm_loss,
                                  worst_grad_rel_frob_vs_fp32_oracle=max(e for _, e, _, _ in items), n_grad_tensors=len(items),
                                  grads_over_3e2=sorted([(k, round(e, 4), round(nz, 4)) for k, e, _, nz in items if e > 3e-2], key=lambda t: -t[1])[:12],
                                  oracle_seconds=round(t_oracle, 1), ok=bool(ok))) + '\n')
