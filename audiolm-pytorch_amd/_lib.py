@@ -41,11 +41,11 @@ SIGNATURES = {
     'alm_geglu_partial_blocks': [_I],
     'alm_geglu_ln_fwd': [_P, _L, _I, _P, _P, _L, _P, _P, _I, _I, _I, _P],
     'alm_geglu_ln_bwd': [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P],
-    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P],
-    'alm_mqa_attn_bias_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _F, _U, _P],
+    'alm_mqa_attn_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P],
+    'alm_mqa_attn_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P],
+    'alm_mqa_attn_bias_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _F, _U, _P, _P],
     'alm_mqa_attn_bias_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _F,
-                              _P, _I, _P, _P, _P, _P, _P, _F, _U, _P],
+                              _P, _I, _P, _P, _P, _P, _P, _F, _U, _P, _P],
     'alm_attn_bias_part_rows': [_I, _I, _I],
     'alm_attn_bias_grad_reduce': [_P, _P, _I, _I, _I, _I, _F, _P],
     'alm_posmlp_in_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],

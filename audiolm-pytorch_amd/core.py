@@ -211,11 +211,31 @@ def _attn_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
-def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, drop=(0., 0), ao_out=None):
+_GRAPH_SEEDS = {}
+
+
+def graph_seed_state(dev, create=False):
+    """Device-side counter (int64 [1]) of the attention-dropout mask streams of CAPTURED steps (graphed.GraphedTrainStep).  A host seed passed by
+    value is baked into a captured launch, so every replay of the graph would repeat one and the same keep mask; inside a capture the flash kernels
+    therefore take `seed + counter[0]`, read when they run, and the captured step advances the counter (an in-place add that is itself part of the
+    graph): each replay draws fresh masks, forward and backward of one replay see the same value.  The tensor must exist BEFORE the capture starts
+    (memory allocated inside a capture belongs to the graph's pool and has no contents until a replay): GraphedTrainStep creates it (create=True),
+    initialised from torch's CPU generator like the eager seeds (`torch.manual_seed` reproduces a run)."""
+    key = (dev.type, dev.index)
+    st = _GRAPH_SEEDS.get(key)
+    if st is None:
+        if not create or (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            raise RuntimeError('attention dropout inside a hipGraph capture needs core.graph_seed_state(device, create=True) BEFORE the capture '
+                               '(graphed.GraphedTrainStep does it): the mask-stream counter must be a live device tensor')
+        st = _GRAPH_SEEDS[key] = torch.tensor([_attn_seed()], dtype=torch.int64, device=dev)
+    return st
+
+
+def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, drop=(0., 0, None), ao_out=None):
     """self-attention branch (audiolm_pytorch.py:307-406): -> (Y bf16 [M, D], saved dict).  drop = (p, seed): Attention(dropout=p) in training mode --
     dropout on the attention probabilities (attend.py:92 / :140; in-kernel for the flash part, a drawn 0 / 1 mask for a prefix / dense-bias part) and
     the nn.Dropout(p) behind to_out (:304): a 0 / 1 mask on the bf16 output with the 1 / (1 - p) factor on the fp32 alpha of the GEMMs."""
-    pd, seed = drop
+    pd, seed, seed_dev = drop
     M, D, H, dh, dev = B * N, cfg.dim, cfg.heads, cfg.dim_head, X.device
     (Wq, _), (Wkv, _), (Wo, _) = W['wq'], W['wkv'], W['wo']
     Q = _empty((M, H * dh), BF16, dev)
@@ -271,7 +291,7 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
             bd = torch.cat((torch.zeros((H, N, m), dtype=F32, device=dev), bd), dim=2).contiguous()
         AO, LSE, sv['dense'] = xattn.extra_attn_fwd(Q, kd, vd, md, B, N, H, dh, float(dh) ** -0.5, bias=bd, causal=True, dropout_p=pd)
     else:
-        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed, o=ao_out if pre is None else None)
+        AO, LSE = ops.mqa_attn_fwd(Q, K, V, mask_u8, B, N, H, dh, bias=bias, dropout_p=pd, seed=seed, o=ao_out if pre is None else None, seed_dev=seed_dev)
         if pre is not None:
             AO, LSE, xs = xattn.extra_attn_fwd(Q, pre['ke'], pre['ve'], ctx.mask, B, N, H, dh, float(dh) ** -0.5, o_self=AO, lse_self=LSE, dropout_p=pd)
             pre['xs'] = xs
@@ -285,7 +305,7 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
     ops.gemm_nt(AO, Wo, Y, alpha=oalpha)
     if okeep is not None:
         Y = Y * okeep
-    sv.update(AO=AO, LSE=LSE, pre=pre, drop=(pd, seed), okeep=okeep, oalpha=oalpha)
+    sv.update(AO=AO, LSE=LSE, pre=pre, drop=(pd, seed, seed_dev), okeep=okeep, oalpha=oalpha)
     return Y, sv
 
 
@@ -349,7 +369,7 @@ def _run_ff(cfg, W, prm, XN, M, p_drop=0., hn_out=None):
 
 
 def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad: bool, bias=None, kv_out=None, decode=None, ctx=None, ff_dropout=0.,
-                  attn_dropout=0., defer_wgrad=False):
+                  attn_dropout=0., defer_wgrad=False, drop_seed=None):
     """x fp32 [B, N, D] -> (hn fp32 [B*N, D], saved-for-backward | None).  bias: relpos.AttnBias (structured score bias shared by every layer,
     audiolm_pytorch.py:500-506 / :532) or None.  ctx: Context (cross-attention layers / self-attention prefix) or None.  Sampling: `kv_out`
     (DecodeCache) is filled with every layer's k / v of this (prefix) forward; `decode` (DecodeCache) means x holds ONE new position per
@@ -372,13 +392,19 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     st = dict(kv0=None, kvp0=None, kvc0=None)
     stk = None
     if (defer_wgrad and need_grad and ctx is None and decode is None and kv_out is None and ff_dropout == 0. and attn_dropout == 0.
-            and not isinstance(bias, relpos.DenseBias)):
+            and not isinstance(bias, relpos.DenseBias) and deferred_bytes(cfg, M) <= DEFER_MAX_BYTES):
         L, dev = cfg.depth, x.device                     # operands of the deferred weight-gradient GEMMs, stacked over the layers (see DEFER_WGRAD)
         stk = dict(XNat=_empty((L, M, D), BF16, dev), Xat=_empty((L, M, D), BF16, dev), AO=_empty((L, M, cfg.heads * cfg.dim_head), BF16, dev),
                    XNff=_empty((L, M, D), BF16, dev), HN=_empty((L, M, Ip), BF16, dev))
     if ASYNC_KV and decode is None and kv_out is None and M >= 4096 and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         st['fside'] = _SideStream(x.device, True)
-    drop_seed = _attn_seed() if attn_dropout > 0. else 0           # one draw per forward; layer l's self-attention uses stream drop_seed + l
+    # attention-dropout mask streams: one host draw per forward, layer l's self-attention uses stream seed + l; inside a hipGraph capture the
+    # caller hands (offset, device counter) instead (TransformerStackFn.forward / graph_seed_state: a by-value seed would freeze the masks of every replay)
+    drop_dev = None
+    if drop_seed is not None:
+        drop_seed, drop_dev = drop_seed
+    else:
+        drop_seed = _attn_seed() if attn_dropout > 0. else 0
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
     for l in range(cfg.depth):
         branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
@@ -398,7 +424,7 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
                 XN, X, mean, rstd = ops.layernorm_fwd(R, prm['ln'], want_copy=want_x, y_out=xno, xc_out=xo)
                 coef, r_bcast = None, False
             if kind == 'attn':
-                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, (float(attn_dropout), drop_seed + l),
+                Y, sv = _run_attn(cfg, LW['attn'], prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ctx, (float(attn_dropout), drop_seed + l, drop_dev),
                                   ao_out=stk['AO'][l] if stk is not None else None)
             elif kind == 'cross':
                 Y, sv = _run_cross(cfg, LW['cross'], prm, XN, B, N, st, ctx, float(attn_dropout))
@@ -496,8 +522,26 @@ ASYNC_KV = os.environ.get('ALM_ASYNC_KV', '0') != '0'                # forward: 
 # Tried and dropped: re-packing every layer's bf16 weight copies on a side stream at the start of the step (so that the 35-us packs of layers 1..5 run
 # under layer 0's kernels): +0.26 ms / step on three interleaved runs -- the HBM-bound packs slow the critical kernels more than they hide.
 DEFER_WGRAD = os.environ.get('ALM_DEFER_WGRAD', '1') != '0'
+# Memory cost of the deferred mode: the gradient-side operands (dY of both branches, dU, dQ, dKV) of EVERY layer stay alive until the batched launches
+# at the end of the backward pass, where the per-layer path frees them layer by layer -- L * M * (2 D + 2 Ipad + H dh + 2 dh) * 2 bytes more at the peak
+# (1.6 GB at the headline shape: nothing against 288 GB, but it grows with batch x sequence).  Above ALM_DEFER_MAX_GB (default 24) the stack falls back to
+# the per-layer split-K path instead of failing an allocation.
+DEFER_MAX_BYTES = int(float(os.environ.get('ALM_DEFER_MAX_GB', '24')) * (1 << 30))
+
+
+def deferred_bytes(cfg, M):
+    """extra peak bytes of the deferred weight-gradient mode for M = B * N rows (see DEFER_MAX_BYTES)"""
+    return cfg.depth * M * (2 * cfg.dim + 2 * cfg.inner_pad + cfg.heads * cfg.dim_head + 2 * cfg.dim_head) * 2
 DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '1')))
-DEFER_GROUPS_CAPTURE = max(1, int(os.environ.get('ALM_DEFER_GROUPS_CAPTURE', '1')))      # see stack_backward
+# Data-parallel runs (a per-layer gradient hook is attached: parallel.DataParallelEngine) take the SAME deferred path since round 4, cut into
+# ALM_DP_DEFER_GROUPS layer groups (default 2): each group's batched weight-gradient launches go to the side stream as soon as the backward has passed the
+# group, followed by ONE gradient bucket for the whole group (fewer, larger collectives: a ring over xGMI is per-link bound), so the upper group's
+# all-reduce runs under the lower layers' backward and only the last group's is exposed.  Until round 3 the hook forced the per-layer split-K path
+# (30 + 30 launches, +0.8 ms/step per GPU against the single-GPU step).  0 = that per-layer path (one bucket per layer, maximal overlap, slower GEMMs).
+DP_DEFER_GROUPS = max(0, int(os.environ.get('ALM_DP_DEFER_GROUPS', '2')))
+# Inside a hipGraph capture ALWAYS one group (see stack_backward): more than one corrupts the replays on ROCm 7.2, not root-caused.  The reproducer
+# (scripts/debug/graph_defer_groups.py) sets core._DEBUG_DEFER_GROUPS_CAPTURE itself; there is deliberately no environment switch for it.
+_DEBUG_DEFER_GROUPS_CAPTURE = 1
 MICRO_ASYNC_WGRAD = os.environ.get('ALM_MICRO_ASYNC_WGRAD', '0') != '0'   # weight-gradient side streams inside the two-half-batch schedule
 SIDE_STREAMS = max(1, int(os.environ.get('ALM_SIDE_STREAMS', '1')))    # number of side streams the weight-gradient GEMMs are dealt over
 
@@ -573,7 +617,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     # fused kernels.
     dR, bcast = dxs, S > 1
     dY = dbeta = None
-    stk = saved.get('stk') if on_layer_grads is None else None                 # deferred weight gradients (see DEFER_WGRAD): operands stacked over the layers
+    stk = saved.get('stk')                                                     # deferred weight gradients (see DEFER_WGRAD): operands stacked over the layers
     bst = None
     if stk is not None:
         L = cfg.depth
@@ -594,12 +638,15 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         # only the last group is exposed.  ALM_DEFER_GROUPS = number of groups (1: everything at the end).
         # Inside a hipGraph capture ONE group at the end: with the first group forked in the middle of the backward pass (any kernel node on the side
         # branch while the capturing stream goes on, even one that only zeroes an unrelated buffer) the replays of the captured step came out corrupted on
-        # ROCm 7.2 (NaN gradients, sometimes a wrong loss; scripts/debug/graph_defer_groups.py with ALM_DEFER_GROUPS_CAPTURE=2 reproduces; a join right after
+        # ROCm 7.2 (NaN gradients, sometimes a wrong loss; scripts/debug/graph_defer_groups.py reproduces; a join right after
         # the group, or no side stream, cures it; the same fork-twice pattern in pure torch, scripts/ubench/capture_fork_twice.py, replays correctly).
         # Not root-caused.  A replay has no host issue to hide, so the early start is worth nothing there anyway.
         L = cfg.depth
-        ngroups = DEFER_GROUPS_CAPTURE if (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()) else DEFER_GROUPS
+        ngroups = _DEBUG_DEFER_GROUPS_CAPTURE if (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()) else (
+            DEFER_GROUPS if on_layer_grads is None else max(1, DP_DEFER_GROUPS))
+        ngroups = min(ngroups, L)
         gsz = (L + ngroups - 1) // ngroups
+        on_group = getattr(on_layer_grads, 'on_group', None)                   # parallel.DataParallelEngine: one bucket per layer GROUP
         wg = dict(dW1=_empty((L, 2, I, D), F32, dev), dW2=_empty((L, 1, D, I), F32, dev), dWo=_empty((L, 1, D, H * dh), F32, dev),
                   dWq=_empty((L, 1, H * dh, D), F32, dev), dWkv=_empty((L, 1, 2 * dh, D), F32, dev))
 
@@ -611,7 +658,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                     (bst['dQ'][l0:l1].unsqueeze(1), stk['XNat'][l0:l1].unsqueeze(1), wg['dWq'][l0:l1]),                                           # dWq = dQ^T @ XN
                     (bst['dKV'][l0:l1].unsqueeze(1), stk['Xat'][l0:l1].unsqueeze(1), wg['dWkv'][l0:l1])]                                          # dWkv = dKV^T @ X
             for At, Bt, C in jobs:
-                if ngroups > 1:
+                if ngroups > 1 or on_layer_grads is not None:  # (with a gradient hook even a single group goes to the side stream: its bucket follows it there)
                     side.run(lambda At=At, Bt=Bt, C=C: ops.gemm_tn_batched(At, Bt, C), At, Bt, C)
                 else:                                          # one group at the end: nothing left to run beside it -- the main stream, no fork / join
                     ops.gemm_tn_batched(At, Bt, C)             # (interleaved A/B: 13.11 -> 12.97 ms/step)
@@ -620,6 +667,19 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 fa, ff_ = l * ppl + hc_n, l * ppl + (hc_n + 4) + hc_n           # first non-hyper-connection parameter of the attention / feed-forward branch
                 grads[fa + 1], grads[fa + 2], grads[fa + 3] = wg['dWq'][l, 0], wg['dWkv'][l, 0], wg['dWo'][l, 0]
                 grads[ff_ + 1], grads[ff_ + 3] = wg['dW1'][l].view(2 * I, D), wg['dW2'][l, 0]
+            if on_layer_grads is not None:
+                # the gradient hand-off of the GROUP, ordered after its weight-gradient launches ON THE SIDE STREAM (the critical path never waits):
+                # one call for the whole group when the hook takes groups (one bucket, one collective), else layer by layer in backward order
+                layers = list(range(l1 - 1, l0 - 1, -1))
+                per_layer = [grads[l * ppl:(l + 1) * ppl] for l in layers]
+                live = [g for gl in per_layer for g in gl if g is not None]
+                if on_group is not None:
+                    side.run_after_all(lambda: on_group(layers, per_layer), *live)
+                else:
+                    def hand_off():
+                        for l, gl in zip(layers, per_layer):
+                            on_layer_grads(l, gl)
+                    side.run_after_all(hand_off, *live)
 
     def add_ctx(g):
         nonlocal dctx
@@ -684,7 +744,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 dWo = _empty((D, H * dh), F32, dev)
                 AOs = sv['AO']
                 side.run(lambda: ops.gemm_tn_splitk(dYs, AOs, dWo, alpha=oa), dYs, AOs, dWo)
-            pd, dseed = sv['drop']
+            pd, dseed, dseed_dev = sv['drop']
             KV = sv['KV']
             # with a prefix the joint softmax statistics (LSE) and the joint output (AO) make the flash backward exact for the sequence's own keys
             dense_pre = None
@@ -700,7 +760,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 dkv32 = torch.cat((dke.reshape(M, dh), dve.reshape(M, dh)), dim=1).contiguous()
             else:
                 dQ, dkv32 = ops.mqa_attn_bwd(sv['Q'], KV[:, :dh], sv['V'], mask_u8, sv['AO'], sv['LSE'], dAO, B, N, H, dh, bias=bias, dtbl_part=dtbl_part,
-                                             dropout_p=pd, seed=dseed, dq_out=bst['dQ'][l] if bst is not None else None)
+                                             dropout_p=pd, seed=dseed, dq_out=bst['dQ'][l] if bst is not None else None, seed_dev=dseed_dev)
             dKV = ops.kv_grad_pack(dkv32, acc_v0, _vgrad_mode(acc_v0, sv['mixed']), dh, out=bst['dKV'][l] if bst is not None else None)
             dKVp = None
             pre = sv['pre']
@@ -760,9 +820,9 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         sv.clear()
         if wg is not None and (prev is None or prev['layer'] != l) and l % gsz == 0:
             launch_group(l)                                    # this layer closes a group: its operands (and the layers' above it) are complete
-        if on_layer_grads is not None and (prev is None or prev['layer'] != l):
-            # the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the critical
-            # path never waits for them
+        if on_layer_grads is not None and wg is None and (prev is None or prev['layer'] != l):
+            # (per-layer path) the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the
+            # critical path never waits for them
             base = l * ppl
             side.run_after_all(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
@@ -821,10 +881,15 @@ class TransformerStackFn(torch.autograd.Function):
         if micro == 2 and (B % 2 or B < 2 or opts.get('kv_out') is not None or opts.get('decode') is not None or hooks is not None):
             micro = 1
         ctx.micro = micro
+        dseed = None
+        if float(opts.get('attn_dropout', 0.)) > 0. and xin.is_cuda and torch.cuda.is_current_stream_capturing():
+            seed_state = graph_seed_state(xin.device)
+            seed_state.add_(2 * cfg.depth)                            # part of the capture: every replay moves on to unused mask streams
+            dseed = (0, seed_state)                                   # (second half-batch: offset cfg.depth)
         if micro == 1:
             hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
                                       ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)),
-                                      defer_wgrad=DEFER_WGRAD and hooks is None)
+                                      defer_wgrad=DEFER_WGRAD and (hooks is None or DP_DEFER_GROUPS > 0), drop_seed=dseed)
         else:
             S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
@@ -837,10 +902,11 @@ class TransformerStackFn(torch.autograd.Function):
                 ca, cb = Context(cx.x[:h * cx.m], cma, h, cx.m), Context(cx.x[h * cx.m:], cmb, B - h, cx.m)
             s2.wait_stream(cur)
             adp = float(opts.get('attn_dropout', 0.))
-            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp)
+            hna, sva = stack_forward(xa, ma, flat_d, cfg, cache, need, bias, ctx=ca, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp, drop_seed=dseed)
             xb.record_stream(s2)
             with torch.cuda.stream(s2):
-                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp)
+                hnb, svb = stack_forward(xb, mb, flat_d, cfg, cache, need, bias, ctx=cb, ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=adp,
+                                         drop_seed=None if dseed is None else (cfg.depth, dseed[1]))
             cur.wait_stream(s2)
             hnb.record_stream(cur)
             hn = torch.cat((hna, hnb), dim=0)

@@ -129,6 +129,7 @@ struct AttnParams {
     int LT;
     // attention dropout (DROP instantiations only): keep iff hash >= drop_thr (= p * 2^32), kept probabilities x drop_scale = 1 / (1 - p)
     unsigned drop_thr; float drop_scale; unsigned seed_lo, seed_hi;
+    const unsigned long long* seed_dev;     // non-NULL: the mask stream is seed + *seed_dev, read at RUN time (a hipGraph replay re-draws: see set_dropout)
 };
 
 // ---- attention dropout (reference attend.py:92 `dropout_p` / :140 `attn_dropout(attn)`, training only) ----------------------------------------
@@ -141,7 +142,13 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
     return x;
 }
 __device__ __forceinline__ unsigned drop_salt(const AttnParams& p, int b, int head) {
-    return mix32(p.seed_lo ^ mix32(p.seed_hi + (unsigned)(b * p.H + head) * 0x9E3779B9u));
+    unsigned lo = p.seed_lo, hi = p.seed_hi;
+    if (p.seed_dev) {                                                    // wave-uniform scalar load; the three kernels of a layer read the same value
+        const unsigned long long s = (((unsigned long long)hi << 32) | lo) + *p.seed_dev;
+        lo = (unsigned)(s & 0xffffffffu);
+        hi = (unsigned)(s >> 32);
+    }
+    return mix32(lo ^ mix32(hi + (unsigned)(b * p.H + head) * 0x9E3779B9u));
 }
 __device__ __forceinline__ bool drop_keep(unsigned salt, int qi, int kj, int N, unsigned thr) {
     return mix32(((unsigned)qi * (unsigned)N + (unsigned)kj) ^ salt) >= thr;
@@ -1122,9 +1129,13 @@ static int check_bias(const BiasArgs& ba, bool bwd) {
     return 0;
 }
 
-// dropout_p in [0, 1): > 0 selects the DROP instantiations (training-mode attention dropout), `seed` picks the mask stream
-static bool set_dropout(AttnParams& p, float dropout_p, unsigned long long seed) {
+// dropout_p in [0, 1): > 0 selects the DROP instantiations (training-mode attention dropout), `seed` picks the mask stream.  seed_dev (device
+// uint64, may be NULL): the stream is seed + *seed_dev, read by the kernels when they RUN -- a by-value seed is baked into a captured hipGraph and every
+// replay would repeat the same keep mask; with the counter on the device a small captured kernel advances it and each replay draws a new mask.
+static bool set_dropout(AttnParams& p, float dropout_p, unsigned long long seed, const void* seed_dev) {
+    p.seed_dev = nullptr;
     if (!(dropout_p > 0.f)) return false;
+    p.seed_dev = reinterpret_cast<const unsigned long long*>(seed_dev);
     const double thr = (double)dropout_p * 4294967296.0;
     p.drop_thr = thr >= 4294967295.0 ? 4294967295u : (unsigned)thr;
     p.drop_scale = 1.f / (1.f - dropout_p);
@@ -1135,7 +1146,7 @@ static bool set_dropout(AttnParams& p, float dropout_p, unsigned long long seed)
 
 static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
-                         float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, void* stream) {
+                         float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream) {
     if (dropout_p < 0.f || dropout_p >= 1.f) return ALM_ERR_BAD_ARG;
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
@@ -1148,7 +1159,7 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     if (rc) return rc;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
     const int npair = ((N + 31) / 32 + 1) / 2;                           // 32-query blocks, taken two (idx, last - idx) per workgroup
-    const bool drop = set_dropout(p, dropout_p, seed);
+    const bool drop = set_dropout(p, dropout_p, seed, seed_dev);
     if (drop) {
         if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
@@ -1163,7 +1174,7 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
 static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
                          void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
-                         int N, int H, int dim_head, float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, void* stream) {
+                         int N, int H, int dim_head, float scale, const BiasArgs& ba, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream) {
     if (dim_head != DH) return ALM_ERR_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return ALM_ERR_BAD_ARG;
     int rc = check_attn(B, N, H, ldq, ldk, ldv, ldo);
@@ -1185,7 +1196,7 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     p.B = B; p.N = N; p.H = H; p.HG = alm_mqa_head_groups(H); p.scale = scale;
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr; p.dtbl_part = ba.dtbl_part;
     const int nqb = (N + 63) / 64;
-    const bool drop = set_dropout(p, dropout_p, seed);
+    const bool drop = set_dropout(p, dropout_p, seed, seed_dev);
     if (drop) {
         if (p.tbl) hipLaunchKernelGGL((mqa_bwd_dq_kernel<true, true>), dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
         else hipLaunchKernelGGL((mqa_bwd_dq_kernel<false, true>), dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
@@ -1211,16 +1222,16 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
 
 extern "C" int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
-                                float scale, float dropout_p, unsigned long long seed, void* stream) {
-    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{}, dropout_p, seed, stream);
+                                float scale, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{}, dropout_p, seed, seed_dev, stream);
 }
 
 extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                 const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
                                 void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B,
-                                int N, int H, int dim_head, float scale, float dropout_p, unsigned long long seed, void* stream) {
+                                int N, int H, int dim_head, float scale, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream) {
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
-                         scale, BiasArgs{}, dropout_p, seed, stream);
+                         scale, BiasArgs{}, dropout_p, seed, seed_dev, stream);
 }
 
 // Same contractions with the structured score bias described at the top of this file.  tbl: fp32 [H][LT] in raw-score units (bias /
@@ -1228,10 +1239,10 @@ extern "C" int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, lon
 extern "C" int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                      const unsigned char* mask, void* o, long long ldo, float* lse, int B, int N, int H, int dim_head,
                                      float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr,
-                                     const int* kattr, float dropout_p, unsigned long long seed, void* stream) {
+                                     const int* kattr, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream) {
     if (!tbl) return ALM_ERR_BAD_ARG;
     return attn_fwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, B, N, H, dim_head, scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, nullptr},
-                         dropout_p, seed, stream);
+                         dropout_p, seed, seed_dev, stream);
 }
 
 // dtbl_part: fp32 [alm_attn_bias_part_rows(B, N, H)][LT] per-workgroup partial table gradients, ACCUMULATED into (zero it before the
@@ -1241,10 +1252,10 @@ extern "C" int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k
                                      long long lddo, void* dq, long long lddq, float* dk, float* dv, long long lddk, long long part_stride,
                                      float* delta, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT, const int* qkey4,
                                      const int* kkey4, const int* qattr, const int* kattr, float* dtbl_part, float dropout_p,
-                                     unsigned long long seed, void* stream) {
+                                     unsigned long long seed, const void* seed_dev, void* stream) {
     if (!tbl) return ALM_ERR_BAD_ARG;
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, mask, o, ldo, lse, dout, lddo, dq, lddq, dk, dv, lddk, part_stride, delta, B, N, H, dim_head,
-                         scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, dtbl_part}, dropout_p, seed, stream);
+                         scale, BiasArgs{tbl, LT, qkey4, kkey4, qattr, kattr, dtbl_part}, dropout_p, seed, seed_dev, stream);
 }
 
 extern "C" int alm_attn_bias_part_rows(int B, int N, int H) { return B * alm_mqa_head_groups(H) * ((N + 63) / 64) * HPB; }

@@ -16,6 +16,10 @@ the arithmetic is unchanged; the weight gradients of the two halves are summed.
     loss = step(semantic_token_ids=sem, coarse_token_ids=coarse)      # p.grad of every parameter holds this step's gradient
     optimizer.step()
 
+Dropout inside a captured step: the feed-forward / to_out masks are drawn by torch's graph-safe generator (re-drawn per replay); the in-kernel
+attention dropout of the flash kernels reads its mask-stream counter from the device (core.graph_seed_state), advanced by the captured step, so every
+replay draws new masks as well (tests/test_gpu_graphed.py::test_graph_replays_redraw_the_attention_dropout_masks).
+
 Restrictions (checked or documented): fixed shapes; no data-dependent host control flow inside the step (`unique_consecutive=True` is one:
 its output length depends on the data); the gradient exchange of parallel.DataParallelEngine is not captured -- call the engine's
 `reduce_grads()` style hooks outside, or use the eager path for multi-GPU runs.
@@ -42,6 +46,12 @@ class GraphedTrainStep:
         self.loss = None
         self.grads = None
         self._stacks = [m for m in module.modules() if hasattr(m, 'micro_batches') and hasattr(m, 'flat_params')]
+        if any(getattr(m, 'attn_dropout', 0.) > 0. for m in self._stacks):
+            # attention dropout inside a captured step: the mask-stream counter lives on the device and is advanced by the captured step itself
+            # (core.graph_seed_state) -- a host seed would be baked into the graph and every replay would drop the same pairs.  It has to exist
+            # before the capture begins.
+            from . import core
+            core.graph_seed_state(self.dev, create=True)
         self._capture(warmup)
 
     # the work of one step, issued on the current stream (with micro_batches == 2 the fused stack forks its second stream itself)

@@ -271,10 +271,10 @@ def attn_bias_grad_reduce(part, B, N, H, dim_head=64):
     return dtbl
 
 
-def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., seed=0, o=None):
+def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., seed=0, o=None, seed_dev=None):
     """q bf16 [B*N, H*dh]; k, v bf16 [B*N, dh] views (row stride arbitrary); mask uint8 [B, N] | None -> (o, lse).
     bias: structured score bias (see alm_mqa_attn_bias_fwd) or None.  dropout_p > 0: attention dropout with the mask stream `seed` (the
-    backward must get the same pair)."""
+    backward must get the same pair); seed_dev (int64 [1] device tensor | None): the stream is seed + seed_dev[0], read when the kernel runs."""
     _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
     if o is None:
         o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
@@ -282,14 +282,14 @@ def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., s
     lse = torch.empty((B, H, N), dtype=F32, device=q.device)
     if bias is not None:
         _lib.call('alm_mqa_attn_bias_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
-                  o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), float(dropout_p), int(seed), _st())
+                  o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), float(dropout_p), int(seed), _p(seed_dev), _st())
         return o, lse
     _lib.call('alm_mqa_attn_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
-              o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, float(dropout_p), int(seed), _st())
+              o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, float(dropout_p), int(seed), _p(seed_dev), _st())
     return o, lse
 
 
-def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None, dropout_p=0., seed=0, dq_out=None):
+def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, dtbl_part=None, dropout_p=0., seed=0, dq_out=None, seed_dev=None):
     """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them).
     With `bias`, the table gradient is accumulated into dtbl_part (attn_bias_part)."""
     _chk(dout, BF16)
@@ -303,12 +303,12 @@ def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, d
         _lib.call('alm_mqa_attn_bias_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask),
                   o.data_ptr(), o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
                   dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5,
-                  *_bias_args(bias, N, H), dtbl_part.data_ptr(), float(dropout_p), int(seed), _st())
+                  *_bias_args(bias, N, H), dtbl_part.data_ptr(), float(dropout_p), int(seed), _p(seed_dev), _st())
         return dq, dkv
     _lib.call('alm_mqa_attn_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
               o.stride(0), lse.data_ptr(), dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dkv.data_ptr(),
               dkv.data_ptr() + 4 * dim_head, dkv.stride(1), dkv.stride(0), delta.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5,
-              float(dropout_p), int(seed), _st())
+              float(dropout_p), int(seed), _p(seed_dev), _st())
     return dq, dkv
 
 

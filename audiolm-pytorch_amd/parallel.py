@@ -5,9 +5,12 @@ SURVEY.md §2 row 8 / §8(e)) for THIS path only: pure data parallelism, one gra
 backward.  It is not a general DDP replacement.
 
   * the path shards over batch rows (independent sequences); the only exchange step is the gradient mean
-  * buckets follow the backward order of the fused stack: [logit heads] -> layer depth-1 ... layer 0 -> [embeddings / start tokens];
-    a layer's bucket is launched by core.stack_backward's per-layer callback the moment that layer's weight gradients exist
-    (38 MB fp32 per layer at dim 1024), so RCCL traffic on the xGMI links runs under the remaining layers' backward GEMMs
+  * buckets follow the backward order of the fused stack: [logit heads] -> layer groups from the top down -> [embeddings / start tokens].
+    Round 4: the stack computes its weight gradients per GROUP of layers (core.DP_DEFER_GROUPS, default 2 groups of 3 layers: the layer-batched TN
+    launches of the single-GPU step) and hands the whole group over at once (`on_group`): ONE bucket and ONE collective per group (115 MB fp32 at
+    dim 1024 depth 6 -- a ring over xGMI is per-link bound, few large collectives beat many small ones), issued from the side stream right behind the
+    group's GEMMs, so the upper group's RCCL traffic runs under the lower layers' backward and only the last group's is exposed.
+    ALM_DP_DEFER_GROUPS=0 restores the round-3 behaviour: per-layer split-K weight gradients and one 38 MB bucket per layer
   * parameters that never receive a gradient (proj_text_embed -- the reason the reference needs find_unused_parameters=True,
     trainer.py:75) are simply never bucketed; DDP's per-forward buffer broadcast is skipped (only constant zero `beta` buffers exist)
   * `finish()` must be called after backward(): it waits for the collectives and writes the averaged gradients back into p.grad
@@ -19,7 +22,8 @@ backward.  It is not a general DDP replacement.
     fresh share, so that backward is exchanged like an accumulated one (p.grad itself is reduced in `finish()`, per layer, not overlapped).
     `zero_grad()` with torch's default set_to_none=True keeps the overlap.
   * `bucket_dtype=torch.bfloat16` halves the bytes on the xGMI links (the reduction then runs in bf16; fp32 is the default, like DDP;
-    bench.py uses bf16 for N > 1: a ring over 7 x ~153 GB/s xGMI links is per-link bound, 131 instead of 262 MB per step)
+    bench.py --bucket-dtype bf16 selects it as a labelled variant: a ring over 7 x ~153 GB/s xGMI links is per-link bound, 131 instead of
+    262 MB per step -- the default scaling run reduces fp32 like the reference)
   * `force_collectives=True` issues the collectives even in a 1-rank group (they are the identity there): the way the RCCL hand-off -- bucket copy
     and asynchronous all-reduce issued from the backward's side stream, `work.wait()` ordering the main stream in `finish()` -- is executed on a
     1-GPU box (tests/test_gpu_dp.py)
@@ -65,7 +69,7 @@ class DataParallelEngine:
         tr = getattr(model, 'transformer', None)
         self._stack = tr if (tr is not None and hasattr(tr, '_layer_grad_hook')) else None
         if self._stack is not None:
-            self._stack._layer_grad_hook = self._on_layer_grads
+            self._stack._layer_grad_hook = self                      # callable per layer (__call__) and per layer group (on_group): see core.stack_backward
             self._stack_flat = self._stack.flat_params()
             self._stack_param_ids = {id(p) for p in self._stack_flat}
             self._ppl = (len(self._stack_flat) - 1) // self._stack.depth
@@ -131,6 +135,23 @@ class DataParallelEngine:
         params = self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl]
         pg = [(p, g) for p, g in zip(params, grads) if g is not None and p.requires_grad]
         self._launch(('layer', layer), [p for p, _ in pg], [g for _, g in pg])
+
+    __call__ = _on_layer_grads
+
+    def on_group(self, layers, grads_per_layer):
+        """core.stack_backward callback of the deferred (layer-batched) weight-gradient mode: the fresh gradients of a GROUP of layers, `layers` in
+        backward order -- one bucket, one collective for the whole group."""
+        self._begin_backward()
+        if not self._overlapped():
+            return
+        self._flush_loose(('loose', 'pre', layers[0]))
+        params, grads = [], []
+        for layer, gl in zip(layers, grads_per_layer):
+            for p, g in zip(self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl], gl):
+                if g is not None and p.requires_grad:
+                    params.append(p)
+                    grads.append(g)
+        self._launch(('group', layers[0], len(layers)), params, grads)
 
     def _on_loose_grad(self, p):
         self._begin_backward(skip=p)

@@ -225,7 +225,9 @@ def main():
     ap.add_argument('--residual', default='bf16', choices=['bf16', 'fp32'],
                     help='HBM storage of the 4 hyper-connection residual streams: bf16 = what trainer.py:1241 autocast gives the reference (default), fp32')
     ap.add_argument('--bucket-dtype', default='auto', choices=['auto', 'bf16', 'fp32'],
-                    help='wire format of the gradient all-reduce buckets for N > 1 (auto = bf16: a ring over xGMI is per-link bound, 131 instead of 262 MB/step)')
+                    help='wire format of the gradient all-reduce buckets for N > 1.  auto = fp32: what the reference reduces (DDP / accelerate all-reduce fp32 '
+                         'gradients), so the scaling numbers are like for like; bf16 halves the bytes on the xGMI ring (131 instead of 262 MB/step) at the price of a '
+                         'bf16 reduction across ranks -- an explicitly labelled variant (config.dp.bucket_dtype)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer-leg', action='store_true')
     args = ap.parse_args()
@@ -257,7 +259,7 @@ def main():
 
     W = build(args.config, dev, rank, torch.bfloat16 if args.residual == 'bf16' else torch.float32)
     model, wrapper, inputs, N = W['model'], W['wrapper'], W['inputs'], W['N']
-    bucket_dtype = torch.float32 if args.bucket_dtype == 'fp32' else torch.bfloat16
+    bucket_dtype = torch.bfloat16 if args.bucket_dtype == 'bf16' else torch.float32
     engine = parallel.DataParallelEngine(model, dist, bucket_dtype=bucket_dtype) if world > 1 else None
     cache = model.transformer._cache
 
@@ -576,7 +578,11 @@ def main():
                                     'graph': 'one hipGraph replay per step (captured fwd + bwd)',
                                     'graph2': 'one hipGraph replay per step: two half-batches of 4 sequences on two HIP streams (row kernels of one half under the GEMMs '
                                               'of the other), gradients summed'}[schedule],
-                       'residual_stream_storage': 'bf16 (what autocast gives the reference)' if model.transformer.cfg.residual_bf16 else 'fp32'},
+                       'residual_stream_storage': 'bf16 (what autocast gives the reference)' if model.transformer.cfg.residual_bf16 else 'fp32',
+                       # which weight-gradient path the timed step took: the N = 1 line and the N > 1 lines of a scaling run are comparable because both
+                       # are the deferred, layer-batched path (N > 1: cut into layer groups, one gradient bucket per group)
+                       'wgrad_path': ('per-layer' if (not core.DEFER_WGRAD or (world > 1 and core.DP_DEFER_GROUPS == 0)) else
+                                      f'deferred-g{core.DEFER_GROUPS if world == 1 else core.DP_DEFER_GROUPS}')},
             'loss': round(float(loss), 4),
             'host': host,
         }

@@ -111,14 +111,16 @@ int alm_geglu_ln_bwd(const void* dhn_bf16, long long lddh, const void* u_bf16, l
  * floats between partials; summed by alm_kv_grad_pack: deterministic, no atomics); delta = fp32 workspace [2][B][H][N].
  * dropout_p in [0, 1) / seed: training-mode attention dropout (attend.py:92 `dropout_p`, :140 `attn_dropout(attn)`): the softmax OUTPUT of pair
  * (b, h, i, j) is kept iff hash(seed, b, h, i * N + j) >= dropout_p * 2^32 (a stateless 32-bit finaliser, the same in forward, dQ and dK/dV) and
- * scaled by 1 / (1 - dropout_p); 0 = off (the default path, no cost).  Pass the forward's (dropout_p, seed) to the backward. */
+ * scaled by 1 / (1 - dropout_p); 0 = off (the default path, no cost).  Pass the forward's (dropout_p, seed, seed_dev) to the backward.
+ * seed_dev (device uint64 | NULL): when given, the stream is seed + *seed_dev with the counter read when the kernel RUNS -- a hipGraph replay then
+ * draws a new mask each time (a by-value seed is baked into the captured launch); the caller advances the counter on the device between steps. */
 int alm_mqa_attn_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                      void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, float dropout_p,
-                     unsigned long long seed, void* stream);
+                     unsigned long long seed, const void* seed_dev, void* stream);
 int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                      const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq, float* dk,
                      float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head, float scale,
-                     float dropout_p, unsigned long long seed, void* stream);
+                     float dropout_p, unsigned long long seed, const void* seed_dev, void* stream);
 /* number of head groups (4 heads each) = number of dk / dv partials the backward writes */
 int alm_mqa_head_groups(int H);
 /* The same attention with the STRUCTURED SCORE BIAS of the `flash_attn=False` models -- Attend.forward's `sim + attn_bias` (attend.py:118-
@@ -132,12 +134,12 @@ int alm_mqa_head_groups(int H);
 int alm_mqa_attn_bias_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                           void* o, long long ldo, float* lse, int B, int N, int H, int dim_head, float scale, const float* tbl, int LT,
                           const int* qkey4, const int* kkey4, const int* qattr, const int* kattr, float dropout_p, unsigned long long seed,
-                          void* stream);
+                          const void* seed_dev, void* stream);
 int alm_mqa_attn_bias_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv, const unsigned char* mask,
                           const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq,
                           float* dk, float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head,
                           float scale, const float* tbl, int LT, const int* qkey4, const int* kkey4, const int* qattr, const int* kattr,
-                          float* dtbl_part, float dropout_p, unsigned long long seed, void* stream);
+                          float* dtbl_part, float dropout_p, unsigned long long seed, const void* seed_dev, void* stream);
 int alm_attn_bias_part_rows(int B, int N, int H);
 int alm_attn_bias_grad_reduce(const float* dtbl_part, float* dtbl, int B, int N, int H, int LT, float scale, void* stream);
 /* The small MLPs that produce `tbl` (RelativePositionBias.net audiolm_pytorch.py:214-221, FineTransformer.pos_bias_mlp :1065-1071): first

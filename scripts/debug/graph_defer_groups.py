@@ -1,5 +1,7 @@
-"""Repro: the captured training step with the deferred weight gradients forked in more than one group (ALM_DEFER_GROUPS_CAPTURE=2) replays with NaN /
-wrong gradients; with the default (one group at the end of the backward pass) every gradient matches the eager step.  See core.stack_backward."""
+"""Repro: the captured training step with the deferred weight gradients forked in more than one group (`python scripts/debug/graph_defer_groups.py 2`)
+replays with NaN / wrong gradients; with one group at the end of the backward pass (argument 1, what the product always does inside a capture) every
+gradient matches the eager step.  See core.stack_backward.  The group count is set HERE (core._DEBUG_DEFER_GROUPS_CAPTURE): the product has no
+environment switch for the known-corrupting configuration."""
 import os, sys, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
@@ -7,7 +9,8 @@ import audiolm_pytorch_amd
 from audiolm_pytorch_amd import core
 from audiolm_pytorch_amd.graphed import GraphedTrainStep
 from test_gpu_graphed import _setup, _eager
-print('env', {k: v for k, v in os.environ.items() if k.startswith('ALM_')}, 'groups in capture', core.DEFER_GROUPS_CAPTURE, 'side streams', core.SIDE_STREAMS, core.ASYNC_WGRAD)
+core._DEBUG_DEFER_GROUPS_CAPTURE = max(1, int(sys.argv[1])) if len(sys.argv) > 1 else 2
+print('env', {k: v for k, v in os.environ.items() if k.startswith('ALM_')}, 'groups in capture', core._DEBUG_DEFER_GROUPS_CAPTURE, 'side streams', core.SIDE_STREAMS, core.ASYNC_WGRAD)
 model, w, inputs = _setup(torch.bfloat16)
 l1, g1 = _eager(model, w, inputs)
 for p in model.parameters():

@@ -1,6 +1,8 @@
 """Data parallelism through the REAL fused stack on a 1-GPU box: two ranks share cuda:0 and exchange gradients over gloo (RCCL refuses two
-ranks on one device), so the whole production control flow runs -- core.stack_backward's per-layer callback on the side stream ->
-parallel.DataParallelEngine._on_layer_grads -> bucket copy -> asynchronous all-reduce -> finish() -- with the real CoarseTransformer.
+ranks on one device), so the whole production control flow runs -- core.stack_backward's gradient hand-off on the side stream ->
+parallel.DataParallelEngine.on_group / _on_layer_grads -> bucket copy -> asynchronous all-reduce -> finish() -- with the real CoarseTransformer.
+Round 4: the data-parallel step takes the same deferred, layer-batched weight-gradient path as the single-GPU step, cut into layer groups with one
+bucket per group (core.DP_DEFER_GROUPS); the tests run 2 groups (the default), 1 group and 0 = the round-3 per-layer path.
 
 Asserted (pure data parallelism, the only exchange is the gradient mean):
   * DP-2 averaged gradients == the gradients of ONE process that sees both shards as one batch (same weights, same ids)
@@ -42,12 +44,14 @@ def _build(dev, seed=0):
     return model, w
 
 
-def _worker(rank, world, port, out, bucket_dtype):
+def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ALM_DP_DEFER_GROUPS=str(dp_groups))
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from audiolm_pytorch_amd import core
     from audiolm_pytorch_amd.parallel import DataParallelEngine
+    assert core.DP_DEFER_GROUPS == dp_groups
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     model, w = _build(dev, seed=100 + rank)                       # different init per rank: the engine must broadcast rank 0's weights
@@ -58,6 +62,7 @@ def _worker(rank, world, port, out, bucket_dtype):
     loss.backward()
     eng.finish()
     torch.cuda.synchronize()
+    nbuckets = eng.last_stats['buckets']
     g1 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     # second synchronising backward WITHOUT clearing the gradients: DDP semantics = previous (already averaged) + mean of the new shares
     loss2 = w(semantic_token_ids=sem[sl].flip(0).to(dev), coarse_token_ids=coarse[sl].flip(0).to(dev), return_loss=True)
@@ -66,7 +71,7 @@ def _worker(rank, world, port, out, bucket_dtype):
     torch.cuda.synchronize()
     g2 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     if rank == 0:
-        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss)), out)
+        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss), buckets=nbuckets), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,13 +81,16 @@ def _frob(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize('bucket_dtype', ['float32', 'bfloat16'])
-def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype):
+@pytest.mark.parametrize('bucket_dtype,dp_groups', [('float32', 2), ('bfloat16', 2), ('float32', 1), ('float32', 0)])
+def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype, dp_groups):
+    """dp_groups: layer groups of the deferred weight gradients in the data-parallel step (2 = default: groups {2}, {0, 1} of this depth-3 model, one
+    bucket each; 1 = everything at the end; 0 = the per-layer path of rounds 1-3) -- all must give the big-batch gradients"""
     import torch.multiprocessing as mp
     out = str(tmp_path / 'dp.pt')
-    port = 33500 + (os.getpid() % 2000) + (7 if bucket_dtype == 'bfloat16' else 0)
-    mp.spawn(_worker, args=(2, port, out, bucket_dtype), nprocs=2, join=True)
+    port = 33500 + (os.getpid() % 2000) + (7 if bucket_dtype == 'bfloat16' else 0) + 13 * dp_groups
+    mp.spawn(_worker, args=(2, port, out, bucket_dtype, dp_groups), nprocs=2, join=True)
     r = torch.load(out, weights_only=False)
+    assert r['buckets'] == (CTOR['depth'] if dp_groups == 0 else dp_groups) + 2, r['buckets']      # stack buckets + [heads, final norm] + [embeddings]
     dev = torch.device('cuda:0')
     model, w = _build(dev)
     model.load_state_dict(r['sd'])
@@ -157,8 +165,8 @@ def test_rccl_one_rank_group_drives_the_engine(tmp_path, bucket_dtype):
     r = torch.load(out, weights_only=False)
     assert r['backend'] == 'nccl'
     st = r['stages']['overlapped']['stats']
-    assert st['buckets'] >= CTOR['depth'] + 1 and st['bytes'] > 0, st        # one bucket per layer + the loose parameters
-    assert r['launched_off_main_stream'], 'the per-layer buckets are issued from the weight-gradient side stream'
+    assert st['buckets'] >= 2 + 1 and st['bytes'] > 0, st                    # one bucket per layer group (2 by default) + the loose parameters
+    assert r['launched_off_main_stream'], 'the stack\'s buckets are issued from the weight-gradient side stream'
     tol = 1e-6 if bucket_dtype == 'float32' else 1e-2
     n = 0
     for k, g in r['ref'].items():

@@ -98,3 +98,63 @@ def test_eager_forward_right_after_capture_uses_real_weight_packs():
     assert abs(after - before) <= 1e-6 * abs(before), (before, after)
     assert step.loss is not None and abs(float(step.loss) - before) <= 1e-6 * abs(before)
     assert all(g is None or bool(torch.isfinite(g).all()) for g in step.grads)
+
+
+def test_graph_replays_redraw_the_attention_dropout_masks(monkeypatch):
+    """ADVICE (round 3, medium): the attention-dropout seed was a host integer passed by value -- baked into the captured launches, so every replay of a
+    graphed step dropped the SAME (query, key) pairs.  Inside a capture the flash kernels now read `seed + counter` from a device counter that the
+    captured step advances (core.graph_seed_state): (1) two replays on identical inputs give different losses; (2) the counter moves by 2 x depth per
+    replay; (3) forward and backward of ONE replay use the same masks: the replay's loss and gradients equal an EAGER step whose host seed is set to the
+    counter value that replay used (the to_out dropout masks, drawn by torch's generator, are pinned to all-ones on both sides for this comparison)."""
+    from audiolm_pytorch_amd import core
+    from audiolm_pytorch_amd.graphed import GraphedTrainStep
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = A.CoarseTransformer(dim=256, depth=3, num_semantic_tokens=100, codebook_size=64, num_coarse_quantizers=3, flash_attn=True, attn_dropout=0.25,
+                                residual_dtype=torch.bfloat16).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.)
+    w.train()
+    g = torch.Generator().manual_seed(3)
+    inputs = dict(semantic_token_ids=torch.randint(0, 100, (4, 50), generator=g).to(dev), coarse_token_ids=torch.randint(0, 64, (4, 40, 3), generator=g).to(dev))
+    monkeypatch.setattr(core, '_dropout_keep', lambda shape, p, device: torch.ones(shape, dtype=torch.bfloat16, device=device))
+    step = GraphedTrainStep(w, inputs, micro_batches=1)
+    counter = core.graph_seed_state(dev)
+    c0 = int(counter.item())
+    la = float(step(**inputs))
+    torch.cuda.synchronize()
+    c1 = int(counter.item())
+    ga = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    lb = float(step(**inputs))
+    torch.cuda.synchronize()
+    c2 = int(counter.item())
+    assert c1 - c0 == 2 * model.transformer.cfg.depth and c2 - c1 == 2 * model.transformer.cfg.depth, (c0, c1, c2)
+    assert abs(la - lb) > 1e-5 * abs(la), f'two replays dropped the same pairs: {la} == {lb}'
+    monkeypatch.setattr(core, '_attn_seed', lambda: c1)            # the eager path: host seed = the counter value the first replay's kernels read
+    le, ge = _eager(model, w, inputs)
+    assert abs(le - la) <= 1e-6 * abs(la), (le, la)
+    bad = [(k, _frob(ga[k], ge[k])) for k in ge if _frob(ga[k], ge[k]) > 2e-3]
+    assert not bad, bad[:6]
+    # eval(): no dropout, replays of an eval-mode capture are repeatable
+    w.eval()
+    with torch.no_grad():
+        assert float(w(**inputs, return_loss=True)) == float(w(**inputs, return_loss=True))
+
+
+@pytest.mark.parametrize('groups', [2, 3])
+def test_eager_deferred_weight_gradient_groups_match_one_group_and_the_per_layer_path(monkeypatch, groups):
+    """ADVICE (round 3): the eager ALM_DEFER_GROUPS > 1 path (the upper layer groups' batched weight-gradient launches forked to the side stream in the
+    middle of the backward pass) had no test.  Gradients of 2 / 3 groups vs one group at the end vs the per-layer split-K path: the same sums over
+    tokens in a different order (the split-K plan depends on how many problems a launch holds) -- equal to fp32 summation noise."""
+    from audiolm_pytorch_amd import core
+    model, w, inputs = _setup(torch.bfloat16)
+    monkeypatch.setattr(core, 'DEFER_GROUPS', 1)
+    l1, g1 = _eager(model, w, inputs)
+    monkeypatch.setattr(core, 'DEFER_GROUPS', groups)
+    l2, g2 = _eager(model, w, inputs)
+    monkeypatch.setattr(core, 'DEFER_WGRAD', False)
+    l3, g3 = _eager(model, w, inputs)
+    assert l1 == l2 == l3
+    assert g1.keys() == g2.keys() == g3.keys()
+    bad = [(k, _frob(g2[k], g1[k]), _frob(g3[k], g1[k])) for k in g1 if _frob(g2[k], g1[k]) > 2e-5 or _frob(g3[k], g1[k]) > 2e-5]
+    assert not bad, bad[:6]

@@ -191,3 +191,61 @@ def test_dp_engine_bf16_buckets_with_missing_grads(tmp_path):
         assert r['dtypes'][k] == 'torch.float32', (k, r['dtypes'][k])
         assert torch.allclose(r['grads'][k], p.grad, atol=2e-2 * float(p.grad.abs().max()) + 1e-6), k          # bf16 wire format
     assert r['stats']['buckets'] >= 3 and r['stats']['bytes'] > 0 and r['stats']['tail_ms'] >= 0.0, r['stats']
+
+
+def _worker_groups(rank, world, port, out):
+    """round 4: the fused stack hands over whole LAYER GROUPS (core.stack_backward's deferred weight-gradient mode: `on_group(layers, grads per layer)`,
+    layers in backward order) -- one bucket per group; the hook object the engine installs is callable per layer too (`engine(layer, grads)`)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(77 + rank)
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    hook = model.transformer._layer_grad_hook
+    assert hook is eng and callable(hook) and callable(getattr(hook, 'on_group', None))
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    _loss(model, ids_all[rank:rank + 1]).backward()
+    flat = model.transformer.flat_params()
+    fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(model.transformer.depth)]
+    for p in flat[:-1]:
+        p.grad = None                                              # as inside the fused backward: the stack's .grad does not exist yet
+    hook.on_group([2], [fresh[2]])                                  # depth 3, two groups: {2}, then {1, 0}
+    hook.on_group([1, 0], [fresh[1], fresh[0]])
+    eng.finish()
+    st = eng.last_stats
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    # a second step through the per-layer entry of the same hook object
+    for p in model.parameters():
+        p.grad = None
+    _loss(model, ids_all[rank:rank + 1]).backward()
+    fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(model.transformer.depth)]
+    for p in flat[:-1]:
+        p.grad = None
+    for l in reversed(range(model.transformer.depth)):
+        hook(l, fresh[l])
+    eng.finish()
+    grads2 = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().clone() for k, v in model.state_dict().items()}, grads=grads, grads2=grads2, ids=ids_all, stats=st), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_layer_group_buckets_match_big_batch(tmp_path):
+    out = str(tmp_path / 'grp.pt')
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_worker_groups, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    (sum(_loss(model, r['ids'][i:i + 1]) for i in range(2)) / 2).backward()
+    for k, p in model.named_parameters():
+        if k == 'unused':
+            assert r['grads'][k] is None and r['grads2'][k] is None
+            continue
+        assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
+        assert torch.allclose(r['grads2'][k], p.grad, atol=1e-6), k
+    assert r['stats']['buckets'] == 1 + 2, r['stats']               # [every loose parameter: here the whole backward ran before the hand-off] + 2 layer groups
