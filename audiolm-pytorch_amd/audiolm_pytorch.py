@@ -27,6 +27,7 @@ There is NO CPU or eager-PyTorch fallback for the hot path: CPU tensors are refu
 """
 from __future__ import annotations
 
+import dataclasses
 import functools
 import os
 from functools import partial
@@ -506,9 +507,10 @@ class Transformer(nn.Module):
     def __init__(self, *, dim, depth, heads, dim_context=None, cross_attend=False, attn_dropout=0., ff_dropout=0.,
                  grad_shrink_alpha=0.1, cond_as_self_attn_prefix=False, rel_pos_bias=True, flash_attn=False,
                  add_value_residual=True, num_residual_streams=4, residual_dtype=None, **kwargs):
-        # residual_dtype (extension; default: ALM_RESIDUAL_DTYPE or fp32): HBM storage of the hyper-connection residual streams and their
-        # gradients, torch.float32 | torch.bfloat16.  bf16 is what trainer.py:1241's autocast gives the reference (its streams are bf16 tensors
-        # from the first width connection on) and halves the traffic of the HBM-bound hyper-connection kernels; arithmetic is fp32 either way.
+        # residual_dtype (extension): HBM storage of the hyper-connection residual streams and their gradients, torch.float32 | torch.bfloat16 | None.
+        # bf16 is what trainer.py:1241's autocast gives the reference (its streams are bf16 tensors from the first width connection on) and halves the
+        # traffic of the HBM-bound hyper-connection kernels; arithmetic is fp32 either way.  None (default) = ALM_RESIDUAL_DTYPE, whose default `auto`
+        # follows the caller like the reference does: bf16 inside torch.autocast(bfloat16), fp32 outside (core.default_residual_bf16).
         super().__init__()
         rel_pos_bias = rel_pos_bias and not flash_attn
         assert not (cross_attend and cond_as_self_attn_prefix)
@@ -539,8 +541,9 @@ class Transformer(nn.Module):
         self.cfg = core.StackCfg(dim=dim, depth=depth, heads=heads, dim_head=attn0.dim_head, streams=num_residual_streams,
                                  inner=int(dim * 2 * 4 / 3), add_value_residual=add_value_residual,
                                  grad_shrink_alpha=grad_shrink_alpha,
-                                 residual_bf16=(core.default_residual_bf16() if residual_dtype is None else residual_dtype == torch.bfloat16),
+                                 residual_bf16=bool(core.default_residual_bf16() if residual_dtype is None else residual_dtype == torch.bfloat16),
                                  cross_attend=cross_attend, prefix=cond_as_self_attn_prefix, dim_context=self.dim_context)
+        self._residual_auto = residual_dtype is None and core.default_residual_bf16() is None      # storage follows the caller's autocast state
         self.cross_attend = cross_attend
         if cond_as_self_attn_prefix:
             assert self.dim_context == dim, 'cond_as_self_attn_prefix feeds the context through the self-attention to_kv: dim_context must equal dim'
@@ -595,7 +598,10 @@ class Transformer(nn.Module):
             mask_u8 = self_attn_mask.to(torch.bool).contiguous().view(torch.uint8)
         opts = dict(hook=self._layer_grad_hook, grad=torch.is_grad_enabled(), micro=self.micro_batches, context_mask=context_mask,
                     ff_dropout=self.ff_dropout if self.training else 0., attn_dropout=self.attn_dropout if self.training else 0.)
-        hn = core.TransformerStackFn.apply(x, mask_u8, self.cfg, self._cache, opts, attn_bias,
+        cfg = self.cfg
+        if self._residual_auto and cfg.streams > 1 and cfg.residual_bf16 != core.autocast_bf16():
+            cfg = dataclasses.replace(cfg, residual_bf16=not cfg.residual_bf16)
+        hn = core.TransformerStackFn.apply(x, mask_u8, cfg, self._cache, opts, attn_bias,
                                            attn_bias.tbl if exists(attn_bias) else None, context, *self.flat_params())
         if return_flat_hidden:
             return hn                                           # bf16 [b*n, d] (feeds heads.HeadsLossFn)

@@ -171,11 +171,24 @@ def layer_weights(cache: WeightCache, l, branches, I, Ip):
 
 
 def default_residual_bf16():
-    """ALM_RESIDUAL_DTYPE = fp32 | bf16: storage of the hyper-connection residual streams (see StackCfg.residual_bf16)"""
-    v = os.environ.get('ALM_RESIDUAL_DTYPE', 'fp32').lower()
-    if v not in ('fp32', 'float32', 'bf16', 'bfloat16'):
-        raise ValueError(f'ALM_RESIDUAL_DTYPE={v!r}: expected fp32 or bf16')
-    return v in ('bf16', 'bfloat16')
+    """ALM_RESIDUAL_DTYPE = auto | fp32 | bf16: storage of the hyper-connection residual streams (see StackCfg.residual_bf16) of a Transformer built
+    without `residual_dtype=`.  -> True / False, or None for `auto` (the default since round 4): decided per forward by `autocast_bf16()` -- bf16 when
+    the call runs under `torch.autocast(bfloat16)`, which is how the reference trainer runs the model (trainer.py:1241 `accelerator.autocast()`: the
+    reference's own streams are bf16 tensors there), fp32 otherwise (a plain fp32 call of the reference keeps fp32 streams).  A drop-in user of trainer.py
+    therefore gets the storage bench.py measures without setting anything."""
+    v = os.environ.get('ALM_RESIDUAL_DTYPE', 'auto').lower()
+    if v not in ('auto', 'fp32', 'float32', 'bf16', 'bfloat16'):
+        raise ValueError(f'ALM_RESIDUAL_DTYPE={v!r}: expected auto, fp32 or bf16')
+    return None if v == 'auto' else v in ('bf16', 'bfloat16')
+
+
+def autocast_bf16():
+    """is the caller inside torch.autocast(device_type='cuda', dtype=torch.bfloat16)?  (the HIP kernels themselves always feed bf16 operands to the
+    matrix cores; this only selects the residual-stream storage of `residual_dtype=None` models)"""
+    try:
+        return bool(torch.is_autocast_enabled('cuda')) and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    except TypeError:                                                # older torch: no device argument
+        return bool(torch.is_autocast_enabled()) and torch.get_autocast_gpu_dtype() == torch.bfloat16
 
 
 def _empty(shape, dtype, dev):

@@ -195,7 +195,12 @@ __device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, int B, 
     } else {
         idx = L % nblk;
         combo = L / nblk;
-        flip = pair_on_cu && ((L >> 8) & 1);
+        // the flip must be constant WITHIN a combo, or idx -> blk stops being a bijection.  Until round 4 this read `(L >> 8) & 1` ("the second
+        // co-resident round"): in a launch of more than 256 workgroups whose combo count is not a multiple of 8 (B = 1, N > 8192; B = 3, N > 2730) the
+        // combo straddling workgroup 256 mapped two idx values onto blocks it had already produced and never computed two others -- dQ rows left
+        // uninitialised.  Found by tests/test_gpu_kernels.py::test_mqa_attention_long_sequences_vs_chunked_fp64; the benchmark shapes (combos % 8 == 0)
+        // always took the branch above.
+        flip = pair_on_cu && (combo & 1);
     }
     r.hg = combo % HG;
     r.b = combo / HG;

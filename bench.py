@@ -173,7 +173,7 @@ def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
     orig = AP.generate_mask_with_prob
     AP.generate_mask_with_prob = lambda shape, prob, device: mask.to(device).clone()
     try:
-        with torch.no_grad():
+        with torch.no_grad(), W['amp']():
             lh = float(W['wrapper'](**{k: v.to(dev) for k, v in ids.items()}, return_loss=True))
     finally:
         AP.generate_mask_with_prob = orig
@@ -222,8 +222,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='coarse2048', choices=['coarse2048', 'coarse1024', 'fine2049', 'fine_t2048_q8', 'e2e_config5'])
     ap.add_argument('--schedule', default='auto', choices=['auto', 'eager', 'eager2', 'graph', 'graph2'])
-    ap.add_argument('--residual', default='bf16', choices=['bf16', 'fp32'],
-                    help='HBM storage of the 4 hyper-connection residual streams: bf16 = what trainer.py:1241 autocast gives the reference (default), fp32')
+    ap.add_argument('--residual', default='auto', choices=['auto', 'bf16', 'fp32'],
+                    help='HBM storage of the 4 hyper-connection residual streams.  auto (default) = the SHIPPED default: the model is built without '
+                         'residual_dtype and the forward runs inside torch.autocast(bfloat16) like reference trainer.py:1241 -> bf16 streams (what autocast '
+                         'gives the reference); bf16 / fp32 = built with that storage explicitly, no autocast context')
     ap.add_argument('--bucket-dtype', default='auto', choices=['auto', 'bf16', 'fp32'],
                     help='wire format of the gradient all-reduce buckets for N > 1.  auto = fp32: what the reference reduces (DDP / accelerate all-reduce fp32 '
                          'gradients), so the scaling numbers are like for like; bf16 halves the bytes on the xGMI ring (131 instead of 262 MB/step) at the price of a '
@@ -257,7 +259,12 @@ def main():
     from audiolm_pytorch_amd import core, graphed, ops, parallel
     import audiolm_pytorch_amd as A
 
-    W = build(args.config, dev, rank, torch.bfloat16 if args.residual == 'bf16' else torch.float32)
+    W = build(args.config, dev, rank, {'bf16': torch.bfloat16, 'fp32': torch.float32, 'auto': None}[args.residual])
+    # --residual auto: the training call runs under autocast exactly as trainer.py:1241 (`with self.accelerator.autocast(): loss = train_wrapper(...)`);
+    # it changes nothing in the HIP launches (they take raw pointers) except that the default-constructed model then stores bf16 residual streams
+    import contextlib
+    amp = (lambda: torch.autocast('cuda', dtype=torch.bfloat16)) if args.residual == 'auto' else contextlib.nullcontext
+    W['amp'] = amp
     model, wrapper, inputs, N = W['model'], W['wrapper'], W['inputs'], W['N']
     bucket_dtype = torch.bfloat16 if args.bucket_dtype == 'bf16' else torch.float32
     engine = parallel.DataParallelEngine(model, dist, bucket_dtype=bucket_dtype) if world > 1 else None
@@ -267,7 +274,8 @@ def main():
         cache.store.clear()                                     # weights "changed": re-pack bf16 copies like after an optimiser step
         for p in model.parameters():
             p.grad = None
-        loss = wrapper(**inputs, return_loss=True)
+        with amp():
+            loss = wrapper(**inputs, return_loss=True)
         loss.backward()
         if engine is not None:
             engine.finish()                                     # waits for the overlapped RCCL all-reduces, grads averaged in place
@@ -298,7 +306,8 @@ def main():
         eager_step()
     if want in ('graph', 'graph2') and world == 1:
         try:
-            gstep = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=2 if want == 'graph2' else 1)
+            with amp():
+                gstep = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=2 if want == 'graph2' else 1)
             torch.cuda.synchronize()
             schedule = want
         except Exception as e:                                  # capture is an optimisation: report why it was not used, run eager
@@ -336,7 +345,8 @@ def main():
         te = timed(6, eager_step) / 6 * 1e3
         probe = {'eager_ms': round(te, 3)}
         try:
-            cand = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=1)
+            with amp():
+                cand = graphed.GraphedTrainStep(wrapper, inputs, micro_batches=1)
             torch.cuda.synchronize()
             for _ in range(3):
                 cand(**inputs)
@@ -578,7 +588,8 @@ def main():
                                     'graph': 'one hipGraph replay per step (captured fwd + bwd)',
                                     'graph2': 'one hipGraph replay per step: two half-batches of 4 sequences on two HIP streams (row kernels of one half under the GEMMs '
                                               'of the other), gradients summed'}[schedule],
-                       'residual_stream_storage': 'bf16 (what autocast gives the reference)' if model.transformer.cfg.residual_bf16 else 'fp32',
+                       'residual_stream_storage': ('bf16 (shipped default: model built without residual_dtype, forward inside torch.autocast(bfloat16) like trainer.py:1241)'
+                                                   if args.residual == 'auto' else 'bf16 (what autocast gives the reference)' if model.transformer.cfg.residual_bf16 else 'fp32'),
                        # which weight-gradient path the timed step took: the N = 1 line and the N > 1 lines of a scaling run are comparable because both
                        # are the deferred, layer-batched path (N > 1: cut into layer groups, one gradient bucket per group)
                        'wgrad_path': ('per-layer' if (not core.DEFER_WGRAD or (world > 1 and core.DP_DEFER_GROUPS == 0)) else

@@ -92,7 +92,7 @@ def test_embeddings_heads_and_cross_entropy_match_the_oracle_given_the_same_hidd
         tr.forward = capture
         with torch.no_grad():
             w(**kw, return_loss=True)
-        tokens_real, hn_real = seen['tokens'].float().cpu(), seen['hn'].float().reshape(B * N, -1)
+        tokens_real, hn_real = seen['tokens'].float().cpu(), seen['hn'].float().reshape(B * N, -1).cpu()
         D = hn_real.shape[1]
 
         # ---- 2. HIP heads + CE + loss combination on the supplied hidden states (stack stubbed out), forward + backward
