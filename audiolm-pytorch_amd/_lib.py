@@ -88,8 +88,8 @@ SIGNATURES = {
     'alm_reduce_sum': [_P, _L, _P, _F, _P],
     'alm_mqa_decode_attn': [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     'alm_opt_chunk_elems': [],
-    'alm_opt_grad_sumsq': [_P, _P, _I, _P, _P],
-    'alm_opt_adam_step': [_P, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
+    'alm_opt_grad_sumsq': [_P, _I, _P, _I, _P, _P],
+    'alm_opt_adam_step': [_P, _I, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
     'alm_conv1d_packed_floats': [_I, _I, _I],
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
     'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

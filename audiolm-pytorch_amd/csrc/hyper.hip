@@ -20,8 +20,16 @@
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
+// A/B switch of the backward kernel's per-stream element loop (round 4): 1 = the token's per-stream scalars travel through a
+// per-wave LDS record as broadcast splat pairs + folded weights (24 % fewer VALU instructions, but 256 VGPRs + scratch spills whose reloads drain the
+// vector-memory queue); 0 = v_readlane broadcasts from lane-distributed registers (215 VGPRs, no spill).
+#ifndef ALM_HC_LDSREC
+#define ALM_HC_LDSREC 0
+#endif
+
 namespace {
 
+constexpr bool HC_LDSREC = ALM_HC_LDSREC != 0;
 constexpr float LN_EPS = 1e-5f;
 constexpr float NORM_EPS = 1e-12f;
 
@@ -202,6 +210,15 @@ __device__ __forceinline__ float inv_norm(float ss) { return fminf(__builtin_amd
 
 __device__ __forceinline__ float lane_bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
+typedef float hc_f2 __attribute__((ext_vector_type(2)));            // element pair: the operand shape of v_pk_fma_f32
+typedef float hc_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hc_f2 f2fma(hc_f2 a, hc_f2 b, hc_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// <a, b> of two packed bf16 pairs + c on the raw HBM image (v_dot2_f32_bf16: products of bf16 values are exact in fp32)
+typedef __attribute__((ext_vector_type(2))) __bf16 hc_bf2;
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hc_bf2, a), __builtin_bit_cast(hc_bf2, b), c, false);
+}
+
 // combine the per-wave totals of the WPT waves of a token through LDS (one block barrier); every lane gets slot (lane & (NV-1))
 template <int WPT, int NV>
 __device__ __forceinline__ float token_combine(float tot, float* red, int tok, int wv, int lane) {
@@ -340,7 +357,11 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     };
     auto process = [&](const In& in, const Tok& t) {
         const int m = t.m;
-        const bool valid = t.valid;
+        // STRAIGHT: see hc_bwd_kernel -- with one token per workgroup pass the prefetching loop only processes valid tokens, and every store of the
+        // token is made unconditional (all waves / lanes write; duplicates carry the same value to the same address), so that the compiler can count
+        // the vector-memory operations between a prefetch and its first use instead of draining the queue (s_waitcnt vmcnt(0)) once per token pair
+        constexpr bool STRAIGHT = PF && TPB == 1;
+        const bool valid = STRAIGHT ? true : t.valid;
         const int b = t.b, n = t.n;
         const bool ld_ok = valid && eok;
         float4 r[S];
@@ -409,7 +430,18 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
             const float pre = tot * rn_l * cD;
             const float th = tanh_fast(pre);
             const float coefv = th * (is_beta ? sb : sa) + stat;             // alpha[ds][dt] or beta[ds]
-            if (valid && wv == 0 && SM::primary(lane)) {
+            if constexpr (STRAIGHT) {
+                // the coefficient record, two stores by EVERY lane of every wave of the token: a (stream, coefficient) slot writes its coefficient and its
+                // pre-activation, every other lane 1 / |R_(l mod S)| twice; all four waves hold identical totals (same LDS sums in the same order)
+                float* cp = a.coef + (long long)m * C::W;
+                float rn_k = rn[0];
+#pragma unroll
+                for (int s = 1; s < S; ++s) rn_k = (l % S == s) ? rn[s] : rn_k;
+                const int i1 = is_dot ? (is_beta ? C::Bt + ds : C::A + ds * (S + 1) + dt) : C::RN + l % S;
+                const int i2 = is_dot ? (is_beta ? C::BP + ds : C::AP + ds * (S + 1) + dt) : C::RN + l % S;
+                cp[i1] = is_dot ? coefv : rn_k;
+                cp[i2] = is_dot ? pre : rn_k;
+            } else if (valid && wv == 0 && SM::primary(lane)) {
                 float* cp = a.coef + (long long)m * C::W;
                 if (is_dot) {
                     if (is_beta) { cp[C::Bt + ds] = coefv; cp[C::BP + ds] = pre; }
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
                 else st4bf(a.xn_out + (long long)m * a.ldxn + e0, xnv);
                 if (WIDTH && a.x_out) st4bf(a.x_out + (long long)m * a.ldx + e0, x);
             }
-            if (valid && wv == 0 && lane == 0) { a.mean_out[m] = mean; a.rstd_out[m] = rstd; }
+            if (STRAIGHT || (valid && wv == 0 && lane == 0)) { a.mean_out[m] = mean; a.rstd_out[m] = rstd; }      // (STRAIGHT: every lane, same value)
         }
     };
     if constexpr (PF) {
@@ -536,7 +568,7 @@ __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
 }
 
 template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
-__global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
     const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
     const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
@@ -548,6 +580,15 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     static_assert(O_C2 < NV, "slot budget");
     __shared__ float red[2][TPB * WPT * NV];                     // parity-double-buffered: possibly the only barrier of an iteration
     __shared__ float redd[2][TPB * WPT * 4];
+    // Per-WAVE record of the token's per-stream scalars (round 4).  The element loop needs 12 token-wide scalars per stream (the five dap, dbp, the
+    // normalisation term, five alpha); they used to be fetched one by one with v_readlane from lane-distributed registers -- 74 VALU instructions per
+    // token and wave, a fifth of that loop, plus the moves that build the {x, x} register pairs v_pk_fma_f32 wants.  Now the lanes that own a value
+    // write it ONCE to LDS as a splat pair and every lane reads the pairs back with broadcast ds_read_b128 (same address in all lanes: conflict-free,
+    // issued on the LDS pipe, not the VALU).  Written and read by the same wave: LDS operations of a wave execute in order -- no barrier.
+    // Layout per stream (floats): S + 2 slots of [dR, dR, q, q] (dR = dpre / |R_s| for the S + 1 alpha slots and the beta slot, q = dR pre / |R_s|),
+    // then the S + 1 alpha pairs, padded to 16 bytes; 4 dump floats at the end take the writes of the lanes that own nothing.
+    constexpr int AF = ((2 * (S + 1) + 3) / 4) * 4, RS = 4 * (S + 2) + AF, RECW = S * RS + 4;
+    __shared__ __attribute__((aligned(16))) float hcrec[4][RECW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = wave / WPT, wv = wave % WPT;
@@ -574,11 +615,13 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            // LDSREC: (gamma + 1) sqrt(D) is folded into the weights once: the element loop's dn * g1 * cD becomes part of the dot with dap / dbp
             g1[c] = eok ? g1[c] + 1.f : 0.f;
-            wbv[c] = eok ? wbv[c] : 0.f;
+            const float gc = HC_LDSREC ? g1[c] * cD : (eok ? 1.f : 0.f);
+            wbv[c] = wbv[c] * gc;
             rawb[c] = 0.f;
 #pragma unroll
-            for (int t = 0; t < S + 1; ++t) { wa[t][c] = eok ? wa[t][c] : 0.f; rawa[t][c] = 0.f; }
+            for (int t = 0; t < S + 1; ++t) { wa[t][c] = wa[t][c] * gc; rawa[t][c] = 0.f; }
         }
     }
 
@@ -603,9 +646,14 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     const int src_sr = SM::lane_of_dyn(O_SR + sl0), src_xr = SM::lane_of_dyn(O_XR + sl0);
     const int cl = lane < C::W ? lane : 0;                                   // this lane's entry of a coefficient record
     const int pre_idx = is_a ? C::AP + slot : C::BP + sl;
+    // record addresses of this lane (see hcrec): its slot [dR, dR, q, q], its alpha pair; lanes that own neither write to the dump floats
+    float* const recw = hcrec[wave];
+    float* const rec_slot = recw + ((is_a || is_b) ? sl * RS + 4 * (is_a ? slot % (S + 1) : S + 1) : S * RS);
+    float* const rec_alpha = recw + (lane < NB ? (lane / (S + 1)) * RS + 4 * (S + 2) + 2 * (lane % (S + 1)) : S * RS);
     auto issue_scalars = [&](auto& w, unsigned m_, const auto& a) {
-        w.cf = w.cfp = w.pre = w.upb = w.ms = 0.f;
+        w.cf = w.cfp = w.pre = w.upb = w.ms = w.rnl = 0.f;
         if (WIDTH) {
+            if constexpr (HC_LDSREC) w.rnl = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)(C::RN + sl)) * 4u);         // 1 / |R_s| of this lane's stream
             w.cf = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)cl) * 4u);       // 32-bit byte offsets (the launcher checks the sizes): SGPR base + VGPR offset
             w.pre = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)pre_idx) * 4u);
             w.upb = *at_bytes(a.dbeta, (m_ * (unsigned)S + (unsigned)sl) * 4u);
@@ -627,7 +675,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     // scalar is then a v_readlane away); pre / upb: this lane's pre-activation and (beta slots) upstream gradient; ms: lane 0 mean, lane 1 rstd.
     // With them NO load sits between the prefetch of the next token and the end of this one: the prefetch really stays in flight (vmcnt
     // retires in order: a late scalar load would force a wait for everything issued before it, i.e. for the whole prefetch).
-    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms; };
+    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms, rnl; };
     auto issue_pf = [&](In& w, const Tok& t) {
         const auto& a = *hc_bwd_kargs();                                           // (shadows the by-value parameter: see hc_bwd_kargs)
         const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
@@ -696,12 +744,23 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     auto process_impl = [&](const In& w, const Tok& t, const auto& a) {
         RT* const dRo = reinterpret_cast<RT*>(a.dR);
         const int m = t.m;
-        const bool valid = t.valid;
+        // STRAIGHT (round 4): in the prefetching loop with one token per workgroup pass, process() only ever sees valid tokens (skipped ones are
+        // prefetched, never processed) and every lane is in range, so every store of the token is UNCONDITIONAL.  That is not cosmetic: a store
+        // inside a branch makes the number of vector-memory operations issued since a prefetch unknowable at compile time, the compiler then waits
+        // with s_waitcnt vmcnt(0) -- i.e. for every store the wave has just issued -- before the first use of the next token's prefetched data,
+        // once per loop iteration: the write latency of HBM in the critical path of every wave (found in the ISA after a 24 % cut of the VALU
+        // instructions of this kernel changed nothing: DESIGN.md section 8.9).
+        constexpr bool STRAIGHT = PF && TPB == 1;
+        const bool valid = STRAIGHT ? true : t.valid;
         const int b = t.b, n = t.n;
         const bool ld_ok = valid && eok;
         float4 g[S], r_c[S];
         float4 dx_c = z4, yv = z4, ex_c = z4;
-        if (PF) {
+        // DOT2: the <dRn_t, R_s> products are taken from the packed bf16 images (v_dot2_f32_bf16); dRn is then unpacked only in front of the element
+        // loop that mixes it -- 8 raw registers live through the reduction instead of 16 unpacked ones
+        constexpr bool DOT2 = WIDTH && PF && BC == 0 && sizeof(RT) == 2;
+        if (DOT2) {
+        } else if (PF) {
             // a skipped token re-read token 0 (finite data): its results are never stored, its coefficient gradients are zeroed through `up`
             // below, and the one running sum that takes the loaded data directly (dln) is protected by zeroing dxn
 #pragma unroll
@@ -735,7 +794,25 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             for (int s2 = 0; s2 < S; ++s2) r_c[s2] = z4;
         }
         if (DEPTH) yv = unraw(w.y);
-        float4 out[S];
+        // consumers of one stream's gradient dR_s -- the store (stream tensor and / or the stream sum of the first branch) and the depth-connection
+        // backward of the previous branch (dy += beta_p[s] dR_s, dbeta_p[s] = <dR_s, y>) -- run as soon as the stream is computed: only ONE stream's
+        // output is live at a time (16 registers less than holding all S of them: the difference between two workgroups per CU and one)
+        float4 dsum_acc = z4, dy_acc = z4;
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+        auto emit = [&](int s_, const float4& o_) {
+            if (WIDTH && ld_ok) {
+                if ((STRAIGHT && BC != 2) || a.dR) {                 // (the launcher takes the prefetching kernels with BC != 2 only when dR is given)
+                    if constexpr (PF) stR(at_bytes(dRo, ((((unsigned)b * (unsigned)S + (unsigned)s_) * (unsigned)a.N + (unsigned)n) * (unsigned)a.D + (unsigned)e0) * (unsigned)sizeof(RT)), o_);
+                    else stR(dRo + (((long long)b * S + s_) * a.N + n) * a.D + e0, o_);
+                }
+            }
+            if (WIDTH) { dsum_acc.x += o_.x; dsum_acc.y += o_.y; dsum_acc.z += o_.z; dsum_acc.w += o_.w; }
+            if (DEPTH) {
+                const float bt = lane_bcast(w.cfp, C::Bt + s_);
+                dy_acc.x += bt * o_.x; dy_acc.y += bt * o_.y; dy_acc.z += bt * o_.z; dy_acc.w += bt * o_.w;
+                v4[s_] = o_.x * yv.x + o_.y * yv.y + o_.z * yv.z + o_.w * yv.w;
+            }
+        };
         if (WIDTH) {
             float4 r[S];
 #pragma unroll
@@ -772,7 +849,14 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             for (int s = 0; s < S; ++s) {
                 v[s * (S + 1)] = dxv.x * r[s].x + dxv.y * r[s].y + dxv.z * r[s].z + dxv.w * r[s].w;
 #pragma unroll
-                for (int t = 0; t < S; ++t) v[s * (S + 1) + t + 1] = g[t].x * r[s].x + g[t].y * r[s].y + g[t].z * r[s].z + g[t].w * r[s].w;
+                for (int t = 0; t < S; ++t) {
+                    if constexpr (DOT2) {
+                        // <dRn_t, R_s> straight from the packed bf16 images: two v_dot2_f32_bf16 instead of a multiply + three FMAs (or their packed forms)
+                        v[s * (S + 1) + t + 1] = dot2bf(w.g[t].v.y, w.r[s].v.y, dot2bf(w.g[t].v.x, w.r[s].v.x, 0.f));
+                    } else {
+                        v[s * (S + 1) + t + 1] = g[t].x * r[s].x + g[t].y * r[s].y + g[t].z * r[s].z + g[t].w * r[s].w;
+                    }
+                }
             }
             float da = bfly<NV>(v, lane);
             da = token_combine<WPT, NV>(da, red[par], tok, wv, lane);
@@ -797,6 +881,68 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 if (is_a) { accA += up; accsa += up * th; }
                 if (is_b) { accB += up; accsb += up * th; }
             }
+            if constexpr (DOT2) {
+                __builtin_amdgcn_sched_barrier(0);                        // (keeps the unpack HERE: see DOT2)
+#pragma unroll
+                for (int t2 = 0; t2 < S; ++t2) g[t2] = unraw(w.g[t2]);
+            }
+            if constexpr (HC_LDSREC) {
+            // ---- the token's per-stream scalars -> this wave's LDS record (see hcrec), read back as broadcast splat pairs
+            {
+                const float dR = dpre * w.rnl;                             // dap[s][t] / |R_s|  (a slots) | dbp[s] / |R_s|  (b slots); 0 in lanes that own no slot
+                const float q = dR * w.rnl * pre;                          // its share of <g_s, R_s> / |R_s|^2 = sum_t dap apre + dbp bpre, over |R_s|^2
+                *reinterpret_cast<hc_f4*>(rec_slot) = hc_f4{dR, dR, q, q};
+                *reinterpret_cast<hc_f2*>(rec_alpha) = hc_f2{w.cf, w.cf};   // lane l < NB holds alpha entry l of the coefficient record
+            }
+            hc_f2 dxv2[2] = {hc_f2{dxv.x, dxv.y}, hc_f2{dxv.z, dxv.w}};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float* rs_ = recw + s * RS;
+                hc_f2 dRp[S + 2], qs = hc_f2{0.f, 0.f}, al[S + 1];
+#pragma unroll
+                for (int k = 0; k < S + 2; ++k) {
+                    const hc_f4 t4 = *reinterpret_cast<const hc_f4*>(rs_ + 4 * k);
+                    dRp[k] = hc_f2{t4[0], t4[1]};
+                    qs += hc_f2{t4[2], t4[3]};
+                }
+#pragma unroll
+                for (int k = 0; k < AF / 4; ++k) {
+                    const hc_f4 a4 = *reinterpret_cast<const hc_f4*>(rs_ + 4 * (S + 2) + 4 * k);
+                    al[2 * k] = hc_f2{a4[0], a4[1]};
+                    if (2 * k + 1 < S + 1) al[2 * k + 1] = hc_f2{a4[2], a4[3]};
+                }
+                // dR_s = alpha[s][0] dx + (1 / |R_s|) (gs - <gs, R_s> R_s / |R_s|^2) + sum_t alpha[s][t+1] dRn_t   with gs = (sum_t dap W_t + dbp wb) (gamma + 1) sqrt(D):
+                // the factors (gamma + 1) sqrt(D) sit in wa / wbv, 1 / |R_s| in dRp, <gs, R_s> / |R_s|^2 = qs (n_s . W = apre |R_s| ... see the forward)
+                float4 out_s;
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const hc_f2 rv = cp ? hc_f2{r[s].z, r[s].w} : hc_f2{r[s].x, r[s].y};
+                    hc_f2 o = al[0] * dxv2[cp];
+                    o = f2fma(dRp[S + 1], hc_f2{wbv[2 * cp], wbv[2 * cp + 1]}, o);
+#pragma unroll
+                    for (int t = 0; t < S + 1; ++t) o = f2fma(dRp[t], hc_f2{wa[t][2 * cp], wa[t][2 * cp + 1]}, o);
+                    o = f2fma(-qs, rv, o);
+#pragma unroll
+                    for (int t = 0; t < S; ++t) o = f2fma(al[t + 1], cp ? hc_f2{g[t].z, g[t].w} : hc_f2{g[t].x, g[t].y}, o);
+                    f4(out_s, 2 * cp) = o[0];
+                    f4(out_s, 2 * cp + 1) = o[1];
+                    // parameter-gradient sums: raw_a[t] += nhat dap[t], nhat = R_s sqrt(D) / |R_s| -- the sqrt(D) is applied once, when the partial row is written
+#pragma unroll
+                    for (int t = 0; t < S + 1; ++t) {
+                        const hc_f2 acc = f2fma(rv, dRp[t], hc_f2{rawa[t][2 * cp], rawa[t][2 * cp + 1]});
+                        rawa[t][2 * cp] = acc[0];
+                        rawa[t][2 * cp + 1] = acc[1];
+                    }
+                    const hc_f2 accb = f2fma(rv, dRp[S + 1], hc_f2{rawb[2 * cp], rawb[2 * cp + 1]});
+                    rawb[2 * cp] = accb[0];
+                    rawb[2 * cp + 1] = accb[1];
+                }
+                emit(s, out_s);
+                // one stream's record live at a time: left alone the scheduler hoists all S x 9 broadcast reads to the top (another 100 VGPRs: one
+                // workgroup per CU instead of two)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            } else {
             // stream by stream: the 13 per-token scalars of stream s (alpha[s][.], dap[s][.], dbp, 1/|R_s|, <g_s, R_s>) are fetched right where they
             // are used, so that only one stream's worth of SGPRs is live at a time (all 52 at once spill)
 #pragma unroll
@@ -814,6 +960,7 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                 // <g_s, R_s> = sum_t dap * apre / rn  (n_s . W = apre => sum_e W[e] (gamma+1) c R_s[e] = apre / rn); 1-ulp reciprocal of the uniform 1/|R_s|
                 const float gdot = gd * __builtin_amdgcn_rcpf(rn);
                 const float grr = gdot * rn * rn, rnc = rn * cD;
+                float4 out_s;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float rv = f4c(r[s], c);
@@ -828,41 +975,22 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
                     float o = alpha[0] * f4c(dxv, c) + rn * (gs - grr * rv);
 #pragma unroll
                     for (int t = 0; t < S; ++t) o += alpha[t + 1] * f4c(g[t], c);
-                    f4(out[s], c) = o;
+                    f4(out_s, c) = o;
                 }
+                emit(s, out_s);
             }
-            if (ld_ok) {
-                if (a.dR) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if constexpr (PF) stR(at_bytes(dRo, ((((unsigned)b * (unsigned)S + (unsigned)s) * (unsigned)a.N + (unsigned)n) * (unsigned)a.D + (unsigned)e0) * (unsigned)sizeof(RT)), out[s]);
-                        else stR(dRo + (((long long)b * S + s) * a.N + n) * a.D + e0, out[s]);
-                    }
-                }
-                if (a.dsum) {
-                    float4 sm = out[0];
-#pragma unroll
-                    for (int s = 1; s < S; ++s) { sm.x += out[s].x; sm.y += out[s].y; sm.z += out[s].z; sm.w += out[s].w; }
-                    const float ds = a.dsum_scale;
-                    float* dsp = PF ? at_bytes(a.dsum, ((unsigned)m * (unsigned)a.D + (unsigned)e0) * 4u) : a.dsum + (long long)m * a.D + e0;
-                    *reinterpret_cast<float4*>(dsp) = make_float4(sm.x * ds, sm.y * ds, sm.z * ds, sm.w * ds);
-                }
+            }
+            if (ld_ok && !(STRAIGHT && BC != 2) && a.dsum) {           // (... and no stream sum is asked for)
+                const float ds = a.dsum_scale;
+                float* dsp = PF ? at_bytes(a.dsum, ((unsigned)m * (unsigned)a.D + (unsigned)e0) * 4u) : a.dsum + (long long)m * a.D + e0;
+                *reinterpret_cast<float4*>(dsp) = make_float4(dsum_acc.x * ds, dsum_acc.y * ds, dsum_acc.z * ds, dsum_acc.w * ds);
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < S; ++s) out[s] = g[s];
+            for (int s = 0; s < S; ++s) emit(s, g[s]);
         }
         if (DEPTH) {
-            float4 o = z4;
-            float v4[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v4[t] = 0.f;
-#pragma unroll
-            for (int t = 0; t < S; ++t) {
-                const float bt = lane_bcast(w.cfp, C::Bt + t);
-                o.x += bt * out[t].x; o.y += bt * out[t].y; o.z += bt * out[t].z; o.w += bt * out[t].w;
-                v4[t] = out[t].x * yv.x + out[t].y * yv.y + out[t].z * yv.z + out[t].w * yv.w;
-            }
+            const float4 o = dy_acc;
             if (ld_ok) st4bf(PF ? at_bytes(a.dy, ((unsigned)m * (unsigned)a.lddy + (unsigned)e0) * 2u) : a.dy + (long long)m * a.lddy + e0, o);
             float db = bfly4(v4);                                           // every lane: total of slot bfly4_slot(lane)
             if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
@@ -875,7 +1003,12 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
             } else {
                 db = __shfl(db, bfly4_lane_of(lane & 3), 64);
             }
-            if (valid && wv == 0 && lane < S) *(PF ? at_bytes(a.dbeta_out, ((unsigned)m * (unsigned)S + (unsigned)lane) * 4u) : a.dbeta_out + ((long long)m * S + lane)) = db;
+            if constexpr (STRAIGHT && S == 4) {
+                // every lane of every wave holds the total of slot (lane & 3): all of them write it (same value, same address) -- an unconditional store
+                *at_bytes(a.dbeta_out, ((unsigned)m * 4u + (unsigned)(lane & 3)) * 4u) = db;
+            } else {
+                if (valid && wv == 0 && lane < S) *(PF ? at_bytes(a.dbeta_out, ((unsigned)m * (unsigned)S + (unsigned)lane) * 4u) : a.dbeta_out + ((long long)m * S + lane)) = db;
+            }
         }
         par ^= 1;
     };
@@ -909,10 +1042,11 @@ __global__ __launch_bounds__(256) void hc_bwd_kernel(HcBwdArgs a) {
     // per-(block, token slot) partial rows; the token's WPT waves own disjoint element ranges
     const int P = a.D * (S + 3) + NB + S + 2;
     float* prow = a.partial + ((long long)blockIdx.x * TPB + tok) * P;
+    const float rsc = HC_LDSREC ? cD : 1.f;                          // LDSREC accumulates R dap / |R| and applies the sqrt(D) of nhat here
     if (eok) {
 #pragma unroll
-        for (int t = 0; t < S + 1; ++t) *reinterpret_cast<float4*>(prow + (long long)t * a.D + e0) = make_float4(rawa[t][0], rawa[t][1], rawa[t][2], rawa[t][3]);
-        *reinterpret_cast<float4*>(prow + (long long)(S + 1) * a.D + e0) = make_float4(rawb[0], rawb[1], rawb[2], rawb[3]);
+        for (int t = 0; t < S + 1; ++t) *reinterpret_cast<float4*>(prow + (long long)t * a.D + e0) = make_float4(rawa[t][0] * rsc, rawa[t][1] * rsc, rawa[t][2] * rsc, rawa[t][3] * rsc);
+        *reinterpret_cast<float4*>(prow + (long long)(S + 1) * a.D + e0) = make_float4(rawb[0] * rsc, rawb[1] * rsc, rawb[2] * rsc, rawb[3] * rsc);
         *reinterpret_cast<float4*>(prow + (long long)(S + 2) * a.D + e0) = make_float4(dln[0], dln[1], dln[2], dln[3]);
     }
     if (wv == 0) {
@@ -1124,6 +1258,8 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
         // the prefetching kernels address with 32-bit byte offsets: every tensor below 4 GB (the largest: fp32 [M][D] / RT [B][S][N][D] / the coefficient records)
         const bool small = (long long)a.B * S * a.N * a.D * 4 < 0xffffffffLL && M * 64 * 4 < 0xffffffffLL && M * (long long)std::max(std::max(std::max(a.lddxn, a.ldex), std::max(a.ldy, a.lddy)), a.lddx) * 4 < 0xffffffffLL;
         if (small && a.D == WPT * 256 && !(a.bcast && a.r_bcast)) bc = a.bcast ? 1 : ((a.r_bcast && WIDTH) ? 2 : (a.r_bcast ? -1 : 0));
+        // the prefetching kernels with stream-tensor R store dR unconditionally and never the stream sum (see STRAIGHT): any other request -> plain kernel
+        if (WIDTH && (bc == 0 || bc == 1) && (!a.dR || a.dsum)) bc = -1;
     }
     int grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
     if constexpr (sizeof(RT) == 2) {

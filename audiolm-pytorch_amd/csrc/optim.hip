@@ -4,9 +4,14 @@
 //     self.optim.step()   with optimizer.py:get_optimizer -> torch.optim.Adam / AdamW
 // spend.  HBM-bound: 16 B read + 12 B written per parameter (p, g, m, v fp32).  SURVEY.md §8(f) item 4.
 //
-// Multi-tensor layout: a device table of AlmOptTensor (pointers + length + weight decay) and a device table of chunks (tensor index,
-// chunk index): workgroup b processes 16 Ki elements of one tensor.  The clip coefficient is derived on the device from the sum of
-// squares (no host round trip): coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_).
+// Multi-tensor layout: a table of AlmOptTensor (pointers + length + weight decay) and a device table of chunks (tensor index, chunk index):
+// workgroup b processes 16 Ki elements of one tensor.  The clip coefficient is derived on the device from the sum of squares (no host round
+// trip): coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_).
+// Round 4: the tensor table travels IN THE KERNEL ARGUMENTS (64 tensors = 3 KB per launch; the ~150 tensors of a model = 3 launches per kernel), not
+// through a pinned staging buffer + an asynchronous host-to-device copy per step.  The gradient storage moves every step (autograd allocates fresh
+// .grad tensors), so the table cannot be cached on the device; the staged copy was the one thing in the fused step that could make the host wait for
+// the stream (a small H2D copy is not guaranteed to be asynchronous on every box): the suspected cause of the +1.9 ms "slow mode" of the
+// `with_optimizer` leg seen on some boxes and not on others (profiles/README.md).  The chunk tables depend on shapes only and stay on the device.
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
@@ -14,10 +19,16 @@ namespace {
 
 constexpr int CHUNK = 16384;
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const AlmOptTensor* __restrict__ tensors, const int2* __restrict__ chunks, float* __restrict__ partial) {
+constexpr int OPT_BATCH = 64;                                   // tensors per launch: 64 x 48 B of kernel arguments
+struct OptBatch {
+    AlmOptTensor t[OPT_BATCH];
+    int t0;                                                     // index of t[0] in the caller's table (the chunk table holds global tensor indices)
+};
+
+__global__ __launch_bounds__(256) void sumsq_kernel(OptBatch tb, const int2* __restrict__ chunks, float* __restrict__ partial) {
     __shared__ float red[4];
     const int2 c = chunks[blockIdx.x];
-    const AlmOptTensor t = tensors[c.x];
+    const AlmOptTensor t = tb.t[c.x - tb.t0];
     const long long beg = (long long)c.y * CHUNK, end = beg + CHUNK < t.n ? beg + CHUNK : t.n;
     const float* g = reinterpret_cast<const float*>(t.g);
     float s = 0.f;
@@ -55,9 +66,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p -= a.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AlmOptTensor* __restrict__ tensors, const int2* __restrict__ chunks, AdamArgs a) {
+__global__ __launch_bounds__(256) void adam_kernel(OptBatch tb, const int2* __restrict__ chunks, AdamArgs a) {
     const int2 c = chunks[blockIdx.x];
-    const AlmOptTensor t = tensors[c.x];
+    const AlmOptTensor t = tb.t[c.x - tb.t0];
     const long long beg = (long long)c.y * CHUNK, end = beg + CHUNK < t.n ? beg + CHUNK : t.n;
     float* p = reinterpret_cast<float*>(t.p);
     const float* g = reinterpret_cast<const float*>(t.g);
@@ -96,27 +107,57 @@ __global__ __launch_bounds__(256) void adam_kernel(const AlmOptTensor* __restric
     }
 }
 
+// walks the HOST table in batches of OPT_BATCH tensors; the chunk table is tensor-major (all chunks of tensor 0, then tensor 1, ...), so a batch owns a
+// contiguous chunk range.  launch(batch, first chunk, chunk count) issues one kernel.
+template <typename F>
+int for_each_batch(const AlmOptTensor* tensors, int ntensors, int nchunks, F launch) {
+    int c0 = 0;
+    for (int t0 = 0; t0 < ntensors; t0 += OPT_BATCH) {
+        OptBatch tb;
+        tb.t0 = t0;
+        const int nt = ntensors - t0 < OPT_BATCH ? ntensors - t0 : OPT_BATCH;
+        long long nc = 0;
+        for (int i = 0; i < nt; ++i) {
+            tb.t[i] = tensors[t0 + i];
+            if (tb.t[i].n < 0) return ALM_ERR_BAD_ARG;
+            nc += (tb.t[i].n + CHUNK - 1) / CHUNK;
+        }
+        for (int i = nt; i < OPT_BATCH; ++i) tb.t[i] = AlmOptTensor{nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0};
+        if (c0 + nc > nchunks) return ALM_ERR_BAD_ARG;             // the chunk table does not belong to this tensor table
+        if (nc > 0) launch(tb, c0, (int)nc);
+        c0 += (int)nc;
+    }
+    return c0 == nchunks ? 0 : ALM_ERR_BAD_ARG;
+}
+
 }  // namespace
 
 extern "C" int alm_opt_chunk_elems(void) { return CHUNK; }
 
+// tensors: HOST array of ntensors AlmOptTensor (device pointers inside); chunks: DEVICE int32 pairs (tensor index, chunk index), tensor-major.
 // partial: fp32 [nchunks] (sum of squares of each chunk's gradients; alm_reduce_sum over it gives the squared global norm)
-extern "C" int alm_opt_grad_sumsq(const AlmOptTensor* tensors, const int* chunks, int nchunks, float* partial, void* stream) {
-    if (nchunks <= 0) return 0;
+extern "C" int alm_opt_grad_sumsq(const AlmOptTensor* tensors, int ntensors, const int* chunks, int nchunks, float* partial, void* stream) {
+    if (nchunks <= 0 || ntensors <= 0) return 0;
     if (!tensors || !chunks || !partial) return ALM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors, reinterpret_cast<const int2*>(chunks), partial);
+    const int rc = for_each_batch(tensors, ntensors, nchunks, [&](const OptBatch& tb, int c0, int nc) {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nc), dim3(256), 0, (hipStream_t)stream, tb, reinterpret_cast<const int2*>(chunks) + c0, partial + c0);
+    });
+    if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
 // step: 1-based count of THIS step (bias corrections 1 - beta^step) for tensors whose own AlmOptTensor.step is 0.  sumsq: device scalar for the clip (NULL = no clipping).
-extern "C" int alm_opt_adam_step(const AlmOptTensor* tensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
-                                 int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream) {
-    if (nchunks <= 0) return 0;
+extern "C" int alm_opt_adam_step(const AlmOptTensor* tensors, int ntensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                                 int step, int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream) {
+    if (nchunks <= 0 || ntensors <= 0) return 0;
     if (!tensors || !chunks || step < 1) return ALM_ERR_BAD_ARG;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     AdamArgs a{lr, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), max_norm, decoupled_weight_decay, sumsq};
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, tensors, reinterpret_cast<const int2*>(chunks), a);
+    const int rc = for_each_batch(tensors, ntensors, nchunks, [&](const OptBatch& tb, int c0, int nc) {
+        hipLaunchKernelGGL(adam_kernel, dim3(nc), dim3(256), 0, (hipStream_t)stream, tb, reinterpret_cast<const int2*>(chunks) + c0, a);
+    });
+    if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;
 }

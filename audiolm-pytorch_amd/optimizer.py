@@ -33,9 +33,7 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled_weight_decay=decoupled_weight_decay)
         super().__init__(params, defaults)
         self._chunks = None             # (key, [per group: device chunk table], partial buffer, [offsets])
-        self._pinned = None             # two pinned staging buffers for the AlmOptTensor tables (alternating)
-        self._turn = 0
-        self._prepared = None           # (key of gradient pointers, [per group: (ps, device table view)])
+        self._prepared = None           # (key of gradient pointers, [per group: (ps, host AlmOptTensor array, ...)], the arrays' owner)
         self._pending_clip = None       # (max_norm, device scalar sum of squares)
 
     # ------------------------------------------------------------------------------------------------------------------ tables
@@ -56,8 +54,9 @@ class FusedAdam(torch.optim.Optimizer):
         return ps
 
     def _prepare(self):
-        """Per iteration: one device table of AlmOptTensor for all groups (ONE async copy from pinned memory: gradient storage changes every
-        step) + the cached chunk tables.  clip_grad_norm_() and step() of the same iteration share it."""
+        """Per iteration: one HOST table of AlmOptTensor per group (the C side hands it to the kernels in their arguments, 64 tensors per launch:
+        gradient storage changes every step, and a staged host-to-device copy per step is exactly what could stall the host behind the stream)
+        + the cached device chunk tables.  clip_grad_norm_() and step() of the same iteration share it."""
         groups = [self._group_tensors(g) for g in self.param_groups]
         flat = [p for ps in groups for p in ps]
         if not flat:
@@ -81,20 +80,6 @@ class FusedAdam(torch.optim.Optimizer):
                 arr[i] = _lib.AlmOptTensor(p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel(),
                                            float(group['weight_decay']), st_count + 1 if mixed else 0)
                 i += 1
-        nbytes = rec * len(flat)
-        if self._pinned is None or self._pinned[0].numel() < nbytes:
-            self._pinned = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-            self._pinned_done = [None, None]
-        turn = self._turn & 1
-        stage = self._pinned[turn]
-        self._turn += 1
-        if self._pinned_done[turn] is not None:
-            self._pinned_done[turn].synchronize()                # the asynchronous copy that last read this staging buffer has finished
-        ctypes.memmove(stage.data_ptr(), ctypes.addressof(arr), nbytes)
-        table = stage[:nbytes].to(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pinned_done[turn] = ev
         ckey = tuple(tuple(p.numel() for p in ps) for ps in groups)
         if self._chunks is None or self._chunks[0] != ckey:
             ch = _lib.query('alm_opt_chunk_elems')
@@ -107,9 +92,9 @@ class FusedAdam(torch.optim.Optimizer):
             self._chunks = (ckey, tabs, torch.empty(max(off, 1), dtype=F32, device=dev), offs)
         out, start = [], 0
         for gi, ps in enumerate(groups):
-            out.append((ps, table[start * rec:(start + len(ps)) * rec], self._chunks[1][gi], self._chunks[3][gi]))
+            out.append((ps, (ctypes.addressof(arr) + start * rec, len(ps)), self._chunks[1][gi], self._chunks[3][gi]))
             start += len(ps)
-        self._prepared = (gkey, out)
+        self._prepared = (gkey, out, arr)                         # `arr` owns the memory the addresses above point into
         return out
 
     # ------------------------------------------------------------------------------------------------------------------ API
@@ -125,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         for ps, table, chunks, off in prep:
             if chunks is None:
                 continue
-            _lib.call('alm_opt_grad_sumsq', table.data_ptr(), chunks.data_ptr(), chunks.shape[0], partial.data_ptr() + 4 * off, ops._st())
+            _lib.call('alm_opt_grad_sumsq', table[0], table[1], chunks.data_ptr(), chunks.shape[0], partial.data_ptr() + 4 * off, ops._st())
             n = off + chunks.shape[0]
         total = ops.reduce_sum(partial[:n])
         self._pending_clip = (float(max_norm), total)
@@ -140,6 +125,7 @@ class FusedAdam(torch.optim.Optimizer):
         clip = self._pending_clip
         self._pending_clip = None
         prep = self._prepare()
+        keep = self._prepared                                     # (holds the host table alive until the launches below have copied it)
         self._prepared = None
         if prep is None:
             return loss
@@ -150,10 +136,11 @@ class FusedAdam(torch.optim.Optimizer):
                 self.state[p]['step'] += 1
             step = int(self.state[ps[0]]['step'])                # used by the tensors whose table entry carries no step of its own
             b1, b2 = group['betas']
-            _lib.call('alm_opt_adam_step', table.data_ptr(), chunks.data_ptr(), chunks.shape[0], float(group['lr']), float(b1), float(b2),
+            _lib.call('alm_opt_adam_step', table[0], table[1], chunks.data_ptr(), chunks.shape[0], float(group['lr']), float(b1), float(b2),
                       float(group['eps']), step, int(bool(group['decoupled_weight_decay'])), clip[1].data_ptr() if clip else None,
                       clip[0] if clip else 0.0, ops._st())
             _mark_updated(ps)
+        del keep
         return loss
 
 

@@ -202,17 +202,37 @@ def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
     return out
 
 
+def csrc_digest():
+    """digest of the kernel sources + the C-ABI header (audiolm-pytorch_amd/build.py: what decides whether the library is rebuilt)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_alm_build', os.path.join(ROOT, 'audiolm-pytorch_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._digest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x 2 per the MI355X guide's gfx950
     correction + WRITE_SIZE) -- read from profiles/, NOT measured in this run (counters cannot be collected inside this process;
-    scripts/pmc.sh regenerates them) -- or None when no summary is present."""
-    for name in ('r3_pmc_summary.json', 'r2_pmc_summary.json', 'r1_pmc_summary.json'):
+    scripts/pmc.sh regenerates them).  -> (bytes | None, file name | None, provenance text).  Since round 4 the summary records the commit and the
+    digest of the kernel sources it was measured on; a summary whose digest differs from the sources of THIS run is refused (traffic: null) --
+    the numbers would describe other kernels."""
+    for name in ('r4_pmc_summary.json', 'r3_pmc_summary.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
-                return json.load(fh)['hbm_bytes_per_launch'], name
+                d = json.load(fh)
         except Exception:
             continue
-    return None, None
+        dig, commit = d.get('csrc_digest'), d.get('commit')
+        if dig is None:
+            return None, name, f'profiles/{name} carries no source digest (generated before round 4): refused, traffic not reported'
+        if dig != csrc_digest():
+            return None, name, (f'profiles/{name} was measured at commit {commit} on kernel sources with digest {dig}; this run\'s sources have digest '
+                                f'{csrc_digest()}: refused (regenerate: bash scripts/gpu_r4_final.sh <tag> <commit>)')
+        return d['hbm_bytes_per_launch'], name, (f'profiles/{name}: rocprofv3 PMC passes of this workload at commit {commit} (kernel-source digest {dig} == this '
+                                                 f'run\'s), FETCH_SIZE x 2 + WRITE_SIZE per the MI355X guide, one counter group per run; not re-measured in this run')
+    return None, None, 'no PMC summary under profiles/'
+
 
 
 def main():
@@ -403,7 +423,7 @@ def main():
     roof = None
     events = []                                                  # (start event, end event, algorithmic work, unit, kernel key)
     timed_names = ('gemm_nt', 'gemm_tn_splitk', 'gemm_tn_batched', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
-                   'layernorm_bwd')
+                   'layernorm_bwd', 'conv1d_causal', 'rvq_encode')       # (the last two: the SoundStream tokenize kernels of --config e2e_config5)
     originals = {n: getattr(ops, n) for n in timed_names}
 
     def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
@@ -433,6 +453,14 @@ def main():
             n1, n2, Kk, Mm = At.shape
             from audiolm_pytorch_amd import _lib as _L
             return 2.0 * n1 * n2 * Mm * Bt.shape[-1] * Kk, 'flop', ('tn128' if _L.query('alm_gemm_splitk_tile', Mm, Bt.shape[-1], Kk, n1 * n2) == 1 else 'tn256')
+        if name == 'conv1d_causal':                                              # implicit GEMM on the exact-fp32 MFMA: 2 B Cout Cin k Tout
+            x = a[0]
+            Bc, Cin, T = x.shape
+            st_ = kw.get('stride', 1)
+            return 2.0 * Bc * a[3] * Cin * a[4] * ((T - st_) // st_ + 1), 'flop32', 'conv1d_causal'
+        if name == 'rvq_encode':                                                 # distance GEMM of every quantizer stage: 2 T C d Q
+            x, E = a[0], a[1]
+            return 2.0 * x.shape[0] * E.shape[1] * E.shape[2] * E.shape[0], 'flop32', 'rvq_encode'
         if name in ('mqa_attn_fwd', 'mqa_attn_bwd'):
             Bq, Nq, Hq, dh = (a[4], a[5], a[6], a[7] if len(a) > 7 else 64) if name == 'mqa_attn_fwd' else (a[7], a[8], a[9], a[10] if len(a) > 10 else 64)
             fwd = 4.0 * Hq * dh * Nq * (Nq + 1) / 2 * Bq                            # causal: QK^T + PV over the lower triangle
@@ -497,6 +525,7 @@ def main():
         a[0] += e0.elapsed_time(e1)
         a[1] += wk
         a[2] += 1
+    PEAK_F32_MFMA_TFLOPS = 157.0                       # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32; MI355X_MICROARCH.md)
     gem = {k: v for k, v in agg.items() if v[3] == 'flop' and k[:2] in ('nt', 'tn')}
     tot_ms = sum(a[0] for a in gem.values())
     tot_fl = sum(a[1] for a in gem.values())
@@ -507,27 +536,28 @@ def main():
             'tn256': 'gemm_stag_kernel<TN>: weight gradients on the big tile, all layers of a weight kind per launch (deferred mode) or split-K per layer', 'tn128': 'weight gradients on the 128x128 tile (split-K)',
             'mqa_fwd': 'mqa_fwd_kernel (causal flash attention forward)', 'mqa_bwd': 'attn_delta + mqa_bwd_dq + mqa_bwd_dkv (flash attention backward)',
             'hc_fwd': 'hc_fwd_kernel (depth + width connection + pre-LayerNorm, fused)', 'hc_bwd': 'hc_bwd_kernel (+ its colsum / param-grad launches)',
-            'geglu_ln_fwd': 'geglu_ln_fwd_kernel', 'geglu_ln_bwd': 'geglu_ln_bwd_kernel (+ colsum)', 'layernorm_fwd': 'ln_fwd_kernel', 'layernorm_bwd': 'ln_bwd_kernel (+ colsum)'}
+            'geglu_ln_fwd': 'geglu_ln_fwd_kernel', 'geglu_ln_bwd': 'geglu_ln_bwd_kernel (+ colsum)', 'layernorm_fwd': 'ln_fwd_kernel', 'layernorm_bwd': 'ln_bwd_kernel (+ colsum)',
+            'conv1d_causal': 'conv1d_causal_kernel (SoundStream encoder: causal conv as implicit GEMM on the exact-fp32 MFMA; the 32-channel k = 1 convs are HBM-bound)',
+            'rvq_encode': 'rvq_encode_kernel (residual VQ: fp32-MFMA distance GEMM + first-index argmin over 8 quantizers)'}
     kernels = []
     for key, (k_ms, k_w, k_n, unit) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         if k_ms <= 0:
             continue
-        mf = unit == 'flop'
+        mf = unit in ('flop', 'flop32')
         ach = k_w / (k_ms * 1e-3) / (1e12 if mf else 1e9)
-        peak = PEAK_BF16_TFLOPS if mf else PEAK_HBM_GBS
+        peak = PEAK_BF16_TFLOPS if unit == 'flop' else PEAK_F32_MFMA_TFLOPS if unit == 'flop32' else PEAK_HBM_GBS
         kernels.append({'kernel': key, 'what': desc.get(key, key), 'bound': 'mfma' if mf else 'hbm', 'launches_per_step': k_n,
+                        **({'mfma_dtype': 'fp32'} if unit == 'flop32' else {}),
                         'avg_launch_us': round(k_ms * 1e3 / k_n, 2), 'ms_per_step': round(k_ms, 3),
                         ('flop_per_launch' if mf else 'bytes_per_launch'): round(k_w / k_n, 0), 'achieved': round(ach, 1), 'peak': peak,
                         'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': round(ach / peak, 4)})
     if d_n:
         ach = d_fl / (d_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src, traffic_note = pmc_traffic()
         roof = {'bound': 'mfma', 'kernel': 'gemm_stag_kernel<NT> 256x256x64 + gemm_kernel<384,256,2,4,NT> (8-wave bf16 MFMA 32x32x16 big tiles; FFN / projection forward + dgrad GEMMs)',
                 'achieved': round(ach, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
                 'traffic': traffic if args.config == 'coarse2048' else None,
-                'traffic_source': (f'profiles/{traffic_src} (committed rocprofv3 PMC passes of this workload; not re-measured in this run; regenerate on the GPU box: '
-                                   f'`bash scripts/gpu_r3.sh <tag> pmc` = scripts/pmc.sh "FETCH_SIZE" / "WRITE_SIZE" in separate passes, FETCH x 2 per the MI355X guide)'
-                                   if traffic is not None and args.config == 'coarse2048' else None),
+                'traffic_source': traffic_note if args.config == 'coarse2048' else None,
                 'launches_per_step': d_n, 'avg_launch_us': round(d_ms * 1e3 / d_n, 2),
                 'flop_per_launch_avg': round(d_fl / d_n, 0),
                 'measured_in': 'one instrumented eager step, weight-gradient side stream off (kernels do not overlap); HIP events on the launch stream bracket each '
@@ -547,26 +577,45 @@ def main():
         # same step with torch.optim.Adam + torch.nn.utils.clip_grad_norm_ as the stock baseline.
         nst = max(3, args.steps // 2)
 
+        opt_events = []
+
         def opt_step(opt, clip):
             step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             clip(opt)
             opt.step()
+            e1.record()
+            opt_events.append((e0, e1))
 
         def timed_opt(opt, clip):
+            """-> (seconds for nst steps, diagnostics): GPU time of the clip + update kernels alone (HIP events) and the caching allocator's device-level
+            traffic during the timed steps -- the `with_optimizer` figure has been bimodal between processes on one box (12.96 vs 14.75 ms for the same
+            library in one visit, profiles/r4_*): these numbers say whether the optimiser kernels or the rest of the step move"""
             opt_step(opt, clip)
-            return timed(nst, lambda: opt_step(opt, clip))
+            opt_events.clear()
+            ms0 = torch.cuda.memory_stats(dev)
+            dt_ = timed(nst, lambda: opt_step(opt, clip))
+            ms1 = torch.cuda.memory_stats(dev)
+            gpu_ms = sorted(a.elapsed_time(b) for a, b in opt_events)
+            diag = dict(optimizer_gpu_ms_median=round(gpu_ms[len(gpu_ms) // 2], 3), optimizer_gpu_ms_max=round(gpu_ms[-1], 3),
+                        device_mallocs=int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
+                        device_frees=int(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)),
+                        alloc_retries=int(ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)),
+                        reserved_gb=round(ms1.get('reserved_bytes.all.current', 0) / 2 ** 30, 2))
+            return dt_, diag
         state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
         fused = A.get_optimizer(model.parameters(), lr=1e-5, wd=0.)
-        dto = timed_opt(fused, lambda o: o.clip_grad_norm_(0.5))
+        dto, diag_f = timed_opt(fused, lambda o: o.clip_grad_norm_(0.5))
         del fused
         model.load_state_dict(state0)
         stock = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(0.9, 0.99))
-        dts = timed_opt(stock, lambda o: torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5))
+        dts, diag_s = timed_opt(stock, lambda o: torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5))
         del stock
         model.load_state_dict(state0)
         opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * W['B'] * N / (dto / nst), 1),
                        optimizer='FusedAdam (alm_opt_grad_sumsq + alm_opt_adam_step): clip_grad_norm_(0.5) + Adam',
-                       torch_adam_ms_per_step=round(dts / nst * 1e3, 3))
+                       torch_adam_ms_per_step=round(dts / nst * 1e3, 3), diagnostics=dict(fused=diag_f, torch_adam=diag_s, steps=nst))
 
     if rank == 0:
         out = {

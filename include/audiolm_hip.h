@@ -277,8 +277,9 @@ int alm_mqa_decode_attn(const void* q, long long ldq, void* cache, long long cac
                         const int* qkey4_vec, const int* qattr_vec, void* stream);
 
 /* ---- fused optimiser step: global-norm clip (trainer.py:953-954 accelerator.clip_grad_norm_) + Adam / AdamW (optimizer.py:get_optimizer) over
- * every parameter in two launches.  `tensors`: DEVICE array of AlmOptTensor; `chunks`: DEVICE int32 pairs (tensor index, chunk index), one
- * per alm_opt_chunk_elems() elements of each tensor.  alm_opt_grad_sumsq writes one partial sum of squares per chunk (alm_reduce_sum over it =
+ * every parameter in two kernels.  `tensors`: HOST array of `ntensors` AlmOptTensor (device pointers inside): it travels in the kernel arguments, 64
+ * tensors per launch -- no staged host-to-device copy per step (the gradient storage moves every step, so the table cannot live on the device);
+ * `chunks`: DEVICE int32 pairs (tensor index, chunk index), tensor-major, one per alm_opt_chunk_elems() elements of each tensor (shape-dependent: cached).  alm_opt_grad_sumsq writes one partial sum of squares per chunk (alm_reduce_sum over it =
  * the squared global gradient norm, kept on the device); alm_opt_adam_step applies coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) to the
  * gradients on the fly (sumsq NULL: no clipping), then torch.optim.Adam's update (decoupled_weight_decay 1: AdamW).  All fp32. */
 typedef struct AlmOptTensor {
@@ -287,8 +288,8 @@ typedef struct AlmOptTensor {
     float wd; int step;                         /* weight decay of this tensor; its own 1-based step count of THIS update (bias corrections), 0: the launch's `step` */
 } AlmOptTensor;
 int alm_opt_chunk_elems(void);
-int alm_opt_grad_sumsq(const AlmOptTensor* tensors, const int* chunks, int nchunks, float* partial, void* stream);
-int alm_opt_adam_step(const AlmOptTensor* tensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
+int alm_opt_grad_sumsq(const AlmOptTensor* tensors, int ntensors, const int* chunks, int nchunks, float* partial, void* stream);
+int alm_opt_adam_step(const AlmOptTensor* tensors, int ntensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
                       int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream);
 
 /* ---- SoundStream tokenize path (encode only): soundstream.py:332-345, 362-380, 519-531 (causal conv encoder), :592-607 / :840 ----
