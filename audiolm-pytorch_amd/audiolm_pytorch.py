@@ -42,7 +42,7 @@ from .attend import Attend
 from .version import __version__
 
 DEFAULT_T5_NAME = 'google/t5-v1_1-base'
-FUSED_PREPARE = os.environ.get('ALM_FUSED_PREPARE', '1') != '0'      # CoarseTransformerWrapper: training-step id bookkeeping as one kernel (A/B switch, tests)
+FUSED_PREPARE = os.environ.get('ALM_FUSED_PREPARE', '1') != '0'      # Coarse wrapper's training step / FineTransformer's assembly: id bookkeeping as one kernel (A/B switch, tests)
 DECODE_GRAPH = os.environ.get('ALM_DECODE_GRAPH', '1') != '0'        # capture the single-position sampling step into a hipGraph
 _T5_DIMS = {'google/t5-v1_1-small': 512, 'google/t5-v1_1-base': 768, 'google/t5-v1_1-large': 1024,
             'google/t5-v1_1-xl': 2048, 'google/t5-v1_1-xxl': 4096, 't5-small': 512, 't5-base': 768, 't5-large': 1024}
@@ -805,6 +805,13 @@ def _quantizer_codes(table_id, b, lead, n, Q, device):
 
 
 @_shape_cached
+def _fine_quantizer_codes(b, n, nf, Qc, Qf, device):
+    """src_b of FineTransformer's assembly, [b, n + nf + 2] int32: -1 at the two start positions, the quantizer-embedding codes (tables 2 / 3) elsewhere"""
+    qc, qf = _quantizer_rows(n, Qc, device), _quantizer_rows(nf, Qf, device)
+    return torch.cat((_neg(b, 1, device), _code(2, qc)[None].expand(b, -1), _neg(b, 1, device), _code(3, qf)[None].expand(b, -1)), dim=1).contiguous()
+
+
+@_shape_cached
 def _group_index(B, N, start, n, Q, device):
     """Rows of the flat hidden states [B*N, D] regrouped per quantizer: position i of the range uses head i mod Q
     -> (idx int32 [Q, B*J] (-1 = pad), i_grid [Q, J], valid [Q, J], i_clamped [Q*J])."""
@@ -1249,19 +1256,24 @@ class FineTransformer(_TransformerBase):
         b, dev = coarse_token_ids.shape[0], coarse_token_ids.device
         Qc, Qf, C = self.num_coarse_quantizers, self.num_fine_quantizers, self.codebook_size
         coarse, fine = _flatten_ids(coarse_token_ids), _flatten_ids(fine_token_ids)               # :1171
-        coarse_mask = (coarse != self.pad_id) & (coarse != self.eos_id)                           # :1175
-        coarse = coarse.masked_fill(~coarse_mask, 0)
         n, nf = coarse.shape[1], fine.shape[1]
-        coarse_mask = F.pad(coarse_mask, (1, nf + 1), value=True)                                 # :1179
+        if (FUSED_PREPARE and coarse.is_cuda and coarse.dtype == torch.int64 and fine.dtype == torch.int64 and coarse.stride(1) == 1 and fine.stride(1) == 1
+                and max(Qc, Qf) * C < (1 << 24)):
+            # the id bookkeeping below as ONE kernel (ops.fine_prepare; round 4: the Coarse wrapper got its own in round 3): ~12 ATen launches fewer
+            src_a, coarse_mask = ops.fine_prepare(coarse, fine, nf, self.pad_id, self.eos_id, Qc, Qf, C)
+        else:
+            coarse_mask = (coarse != self.pad_id) & (coarse != self.eos_id)                       # :1175
+            coarse = coarse.masked_fill(~coarse_mask, 0)
+            coarse_mask = F.pad(coarse_mask, (1, nf + 1), value=True)                             # :1179
+            qc, qf = _quantizer_rows(n, Qc, dev), _quantizer_rows(nf, Qf, dev)
+            coarse_rows = coarse.to(torch.int32) + qc[None] * C                                   # :1195
+            fine_rows = fine.to(torch.int32) + qf[None] * C                                       # :1202
+            src_a = torch.cat((_const_code(4, b, dev), _code(0, coarse_rows), _const_code(5, b, dev), _code(1, fine_rows)), dim=1).contiguous()
         if exists(self_attn_mask):
             self_attn_mask &= coarse_mask                                                         # in place, like the reference (:1182)
         else:
             self_attn_mask = coarse_mask
-        qc, qf = _quantizer_rows(n, Qc, dev), _quantizer_rows(nf, Qf, dev)
-        coarse_rows = coarse.to(torch.int32) + qc[None] * C                                       # :1195
-        fine_rows = fine.to(torch.int32) + qf[None] * C                                           # :1202
-        src_a = torch.cat((_const_code(4, b, dev), _code(0, coarse_rows), _const_code(5, b, dev), _code(1, fine_rows)), dim=1).contiguous()
-        src_b = torch.cat((_neg(b, 1, dev), _code(2, qc)[None].expand(b, -1), _neg(b, 1, dev), _code(3, qf)[None].expand(b, -1)), dim=1).contiguous()
+        src_b = _fine_quantizer_codes(b, n, nf, Qc, Qf, dev)
         N = n + nf + 2
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * N, self.dim, self.coarse_embedding.weight,
                                        self.fine_embedding.weight, self.coarse_quantize_embedding.weight,

@@ -388,6 +388,35 @@ __global__ __launch_bounds__(256) void coarse_prepare_kernel(const long long* __
     }
 }
 
+// FineTransformer.forward's id bookkeeping (audiolm_pytorch.py:1171-1223) in ONE launch: key mask of the coarse ids (pad / eos keys are masked and their ids
+// zeroed, :1175-1177), the mask padded over [coarse start | coarse | fine start | fine] (:1179) and the embedding source codes (start tokens, per-quantizer
+// offset rows id + (i mod Q) * codebook_size of the two tables, :1186-1223) -- ~12 ATen launches otherwise.  N = 1 + n + 1 + nf.
+__global__ __launch_bounds__(256) void fine_prepare_kernel(const long long* __restrict__ coarse, long long ld_coarse, const long long* __restrict__ fine,
+                                                           long long ld_fine, int B, int n, int nf, long long pad_id, long long eos_id, int Qc, int Qf, int C,
+                                                           int* __restrict__ src_a, unsigned char* __restrict__ keep) {
+    const int N = n + nf + 2;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)B * N; t += (long long)gridDim.x * 256) {
+        const int b = (int)(t / N), i = (int)(t % N);
+        int code;
+        bool k = true;
+        if (i == 0) {
+            code = 4 << 24;                                                    // coarse_start_token (table 4)
+        } else if (i <= n) {
+            const int j = i - 1;
+            const long long v = coarse[(long long)b * ld_coarse + j];
+            k = v != pad_id && v != eos_id;                                    // :1175
+            code = (int)(k ? v : 0) + (j % Qc) * C;                            // masked_fill(~mask, 0) + quantizer offset, table 0
+        } else if (i == n + 1) {
+            code = 5 << 24;                                                    // fine_start_token (table 5)
+        } else {
+            const int j = i - (n + 2);
+            code = (int)fine[(long long)b * ld_fine + j] + (j % Qf) * C + (1 << 24);       // table 1
+        }
+        src_a[t] = code;
+        keep[t] = k ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_embed_assemble(const float* const* tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, float* out,
@@ -531,6 +560,18 @@ extern "C" int alm_coarse_prepare(const long long* sem, long long ld_sem, const 
     if ((long long)(Q - 1) * C + C + 1 >= (1 << 24) || B * W >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(coarse_prepare_kernel, dim3(grid_for(B * W)), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, coarse, ld_coarse, B, ns0, nc0, pad_id,
                        sem_eos, coarse_eos, Q, C, sem_labels, coarse_labels, src_a, (unsigned char*)keep);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+/* see fine_prepare_kernel.  coarse int64 [B][n], fine int64 [B][>= nf] (the first nf ids of each row are used: the wrapper drops the last fine id). */
+extern "C" int alm_fine_prepare(const long long* coarse, long long ld_coarse, const long long* fine, long long ld_fine, int B, int n, int nf, long long pad_id,
+                                long long eos_id, int Qc, int Qf, int C, int* src_a, void* keep, void* stream) {
+    if (B <= 0 || n < 0 || nf < 0 || Qc < 1 || Qf < 1) return ALM_ERR_BAD_ARG;
+    const long long N = (long long)n + nf + 2;
+    if ((long long)(Qc > Qf ? Qc : Qf) * C >= (1 << 24) || B * N >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fine_prepare_kernel, dim3(grid_for(B * N)), dim3(256), 0, (hipStream_t)stream, coarse, ld_coarse, fine, ld_fine, B, n, nf, pad_id, eos_id,
+                       Qc, Qf, C, src_a, (unsigned char*)keep);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -379,6 +379,20 @@ def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C):
     return sl, cl, src_a, keep
 
 
+def fine_prepare(coarse, fine, nf, pad_id, eos_id, Qc, Qf, C):
+    """coarse int64 [B, n], fine int64 [B, >= nf] (flattened (n q)) -> (src_a int32 [B, N], keep bool [B, N]), N = n + nf + 2: FineTransformer.forward's
+    id bookkeeping (C ABI: alm_fine_prepare)."""
+    _chk(coarse, torch.int64), _chk(fine, torch.int64)
+    assert coarse.dim() == 2 and fine.dim() == 2 and coarse.stride(1) == 1 and fine.stride(1) == 1 and coarse.shape[0] == fine.shape[0] and fine.shape[1] >= nf
+    B, n = coarse.shape
+    N, dev = n + nf + 2, coarse.device
+    src_a = torch.empty((B, N), dtype=torch.int32, device=dev)
+    keep = torch.empty((B, N), dtype=torch.bool, device=dev)
+    _lib.call('alm_fine_prepare', coarse.data_ptr(), coarse.stride(0), fine.data_ptr(), fine.stride(0), B, n, nf, int(pad_id), int(eos_id), int(Qc), int(Qf),
+              int(C), src_a.data_ptr(), keep.data_ptr(), _st())
+    return src_a, keep
+
+
 FORGETFUL_MAX_N = 16384
 
 

@@ -196,6 +196,11 @@ int alm_loss_combine(const float* s0, const float* s1, const float* s2, const fl
 int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0, long long pad_id,
                        long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels, long long* coarse_labels, int* src_a, void* keep,
                        void* stream);
+/* FineTransformer.forward's id bookkeeping, audiolm_pytorch.py:1171-1223 (key mask of pad / eos coarse keys, their ids zeroed, mask padded over
+ * [coarse start | coarse | fine start | fine], embedding source codes id + (i mod Q) * codebook_size per table) in one launch.  fine: the first nf ids of
+ * each row (the training wrapper drops the last one, :2086).  src_a int32 [B][n + nf + 2], keep bool [B][n + nf + 2]. */
+int alm_fine_prepare(const long long* coarse, long long ld_coarse, const long long* fine, long long ld_fine, int B, int n, int nf, long long pad_id,
+                     long long eos_id, int Qc, int Qf, int C, int* src_a, void* keep, void* stream);
 
 /* forgetful causal mask, audiolm_pytorch.py:82-89 (`rand[:, 0] = -max; mask = ~zeros.scatter(1, rand.topk(k).indices, 1)`): keep [B][N] bytes (torch.bool
  * storage) &= NOT(one of the `drop` largest scores of its row); column 0 is never dropped; equal scores at the threshold go in index order.

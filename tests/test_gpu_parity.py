@@ -494,3 +494,47 @@ def test_coarse_wrapper_fused_training_bookkeeping_equals_the_unfused_path():
     for k in losses[0][1]:
         a, b = losses[0][1][k], losses[1][1][k]
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max().clamp(min=1e-30)), k      # (the embedding scatter adds atomically: order-dependent last bits)
+
+
+def test_fine_fused_id_bookkeeping_equals_the_unfused_path():
+    """FineTransformer._assemble with ops.fine_prepare (key mask of pad / eos coarse ids, zeroed ids, padded mask, embedding source codes: one kernel,
+    round 4) vs the ATen formulation: identical source codes and key mask, identical loss -- pad and eos ids inside the coarse rows, a caller-supplied
+    mask and-ed in place, the training wrapper's `fine[:, :-1]` view (row stride != row length)."""
+    import audiolm_pytorch_amd as A
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = A.FineTransformer(dim=128, depth=2, num_coarse_quantizers=3, num_fine_quantizers=5, codebook_size=64, flash_attn=True).to(dev)
+    w = A.FineTransformerWrapper(transformer=model, codec=Codec(8), mask_prob=0.15)
+    w.train()
+    g = torch.Generator().manual_seed(4)
+    grid = torch.randint(0, 64, (3, 11, 8), generator=g)
+    coarse, fine = grid[..., :3].contiguous(), grid[..., 3:].contiguous()
+    coarse[0, 4:] = -1                                                    # padded frames
+    coarse[1, 2, 1] = model.eos_id                                        # an eos id among the coarse keys
+    coarse, fine = coarse.to(dev), fine.to(dev)
+    seen = {}
+    orig = AP.EmbedAssembleFn.apply
+    outs = []
+    for fused in (True, False):
+        AP.FUSED_PREPARE = fused
+        try:
+            with torch.no_grad():
+                cf, ff = coarse.reshape(3, -1), fine.reshape(3, -1)[:, :-1]
+                user_mask = torch.ones((3, cf.shape[1] + ff.shape[1] + 2), dtype=torch.bool, device=dev)
+                user_mask[2, 5] = False
+                tokens, mask, b, n, nf, N = model._assemble(cf, ff, user_mask)
+            torch.manual_seed(123)                                        # the same forgetful draw
+            for p in model.parameters():
+                p.grad = None
+            loss = w(coarse_token_ids=coarse, fine_token_ids=fine, return_loss=True)
+            loss.backward()
+            outs.append((tokens.clone(), mask.clone(), float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            AP.FUSED_PREPARE = True
+    (t1, m1, l1, g1), (t0, m0, l0, g0) = outs
+    assert torch.equal(t1, t0) and torch.equal(m1, m0)
+    assert not bool(m1[0, 1 + 12:1 + 33].any()) and not bool(m1[1, 1 + 7]) and not bool(m1[2, 5])      # pads, the eos key, the caller's masked key
+    assert l1 == l0, (l1, l0)
+    for k in g1:
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max().clamp(min=1e-30)), k
