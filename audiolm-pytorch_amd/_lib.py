@@ -74,6 +74,7 @@ SIGNATURES = {
     'alm_hc_fwd': [_P, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'alm_hc_bwd': [_P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     'alm_hc_param_grads': [_P, _I, _P, _P, _P, _P, _I, _I, _P],
+    'alm_hc_param_grads_batched': [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     'alm_streams_expand': [_P, _P, _I, _I, _L, _P],
     'alm_streams_reduce': [_P, _P, _I, _I, _L, _P],
     'alm_residual_add': [_P, _P, _L, _P, _L, _I, _P],

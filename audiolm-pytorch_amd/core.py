@@ -694,6 +694,20 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                             on_layer_grads(l, gl)
                     side.run_after_all(hand_off, *live)
 
+    hc_pending = []                                    # deferred mode: (first, ip, partial rows, trace record) of the branches whose parameter gradients wait
+
+    def finish_hc():
+        """the hyper-connection parameter gradients of every branch processed since the last call, in two launches (ops.hc_param_grads_batched)"""
+        if not hc_pending:
+            return
+        for (first_, ip_, _, rec_), g_ in zip(hc_pending, ops.hc_param_grads_batched([t[2] for t in hc_pending], S, D)):
+            for j, k in enumerate(HC_KEYS):
+                grads[first_ + j] = g_[k]
+            grads[ip_] = g_['ln']
+            if rec_ is not None:
+                rec_['hc_grads'] = dict(g_)
+        hc_pending.clear()
+
     def add_ctx(g):
         nonlocal dctx
         dctx = g if dctx is None else ops.add_f32(dctx, g)
@@ -814,15 +828,19 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             py, pc = (prev['Y'], prev['coef']) if prev is not None else (None, None)
             h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN, extra=extra, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=prm['ln'], R=sv['R'],
                            coef=sv['coef'], dbeta=dbeta, hc=prm['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=prev is None,
-                           r_dtype=rdt, dsum_scale=dx_scale if prev is None else 1.0, dy_out=dy_slot(prev) if prev is not None else None)
+                           r_dtype=rdt, dsum_scale=dx_scale if prev is None else 1.0, dy_out=dy_slot(prev) if prev is not None else None,
+                           defer_grads=wg is not None)
             if rec is not None:
                 rec.update(kind=kind, layer=l, dR_in=dR, dR_in_bcast=bcast, dbeta_in=dbeta, dR_out=h['dsum'] if prev is None else h['dR'], sum_only=prev is None,
-                           dY_prev=h['dy'], dbeta_prev=h['dbeta'], hc_grads=dict(h['grads']))
+                           dY_prev=h['dy'], dbeta_prev=h['dbeta'], hc_grads=dict(h['grads']) if h['grads'] is not None else None)
                 TRACE.append(rec)
             dR, dY, dbeta, bcast = (h['dsum'] if prev is None else h['dR']), h['dy'], h['dbeta'], False     # first branch: summed over the streams (:524)
-            for j, k in enumerate(HC_KEYS):
-                grads[first + j] = h['grads'][k]
-            grads[ip] = h['grads']['ln']
+            if h['grads'] is None:
+                hc_pending.append((first, ip, h['part'], rec))     # deferred mode: finished with the other branches (finish_hc)
+            else:
+                for j, k in enumerate(HC_KEYS):
+                    grads[first + j] = h['grads'][k]
+                grads[ip] = h['grads']['ln']
         else:
             dX, dgl = ops.layernorm_bwd(dXN, sv['R'], sv['mean'], sv['rstd'], prm['ln'], extra=extra)
             if rec is not None:
@@ -832,6 +850,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             grads[ip] = dgl
         sv.clear()
         if wg is not None and (prev is None or prev['layer'] != l) and l % gsz == 0:
+            finish_hc()                                        # (before the group's hand-off: a gradient hook wants the whole group's gradients)
             launch_group(l)                                    # this layer closes a group: its operands (and the layers' above it) are complete
         if on_layer_grads is not None and wg is None and (prev is None or prev['layer'] != l):
             # (per-layer path) the bucket copy + all-reduce launch of this layer is ordered after its weight gradients ON THE SIDE STREAM: the
@@ -839,6 +858,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             base = l * ppl
             side.run_after_all(lambda: on_layer_grads(l, grads[base:base + ppl]), *[g for g in grads[base:base + ppl] if g is not None])
 
+    finish_hc()
     dx = dR.view(B, N, D)
     dtbl = ddense if dense else (ops.attn_bias_grad_reduce(dtbl_part, B, N, H) if bias is not None else None)
     side.join()                                    # autograd hands the gradients to consumers on the main stream

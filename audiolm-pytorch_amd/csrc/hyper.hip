@@ -1104,6 +1104,84 @@ __global__ __launch_bounds__(256) void hc_param_grads_kernel(const float* __rest
     }
 }
 
+// ---- the same for SEVERAL width connections in two launches (round 4): the fused backward of a 6-layer stack finishes 12 hyper-connection branches,
+// each with a column-sum launch + a parameter-gradient launch of ~5 us -- 24 launches and as many dispatch gaps per step for 0.1 ms of work.  The
+// deferred mode of core.stack_backward keeps the partial rows of every branch and finishes them together: stage 1 = the column sums of every
+// problem's partial rows in HC_CHUNKS row chunks (grid.z = problem), stage 2 = hc_param_grads_kernel over (element block, problem).
+constexpr int HC_FINISH_MAX = 16, HC_CHUNKS = 16;
+struct HcFinish {
+    const float* part[HC_FINISH_MAX];      // partial rows of problem z: [rows[z]][P]
+    const float* gamma[HC_FINISH_MAX];
+    const float* Wa[HC_FINISH_MAX];
+    const float* wb[HC_FINISH_MAX];
+    float* out[HC_FINISH_MAX];             // alm_hc_grads_width(S, D) floats each
+    int rows[HC_FINISH_MAX];
+    int nb;
+};
+__global__ __launch_bounds__(256) void hc_colsum_batched_kernel(HcFinish f, float* __restrict__ ws, int P) {
+    __shared__ float red[4][64];
+    const int z = blockIdx.z;
+    const float* __restrict__ in = f.part[z];
+    const int rows = f.rows[z], rpc = (rows + HC_CHUNKS - 1) / HC_CHUNKS;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < P) {
+        int r = r0 + ry;
+        for (; r + 12 < r1; r += 16) {
+            s0 += in[(long long)r * P + c]; s1 += in[(long long)(r + 4) * P + c]; s2 += in[(long long)(r + 8) * P + c]; s3 += in[(long long)(r + 12) * P + c];
+        }
+        for (; r < r1; r += 4) s0 += in[(long long)r * P + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < P) ws[((long long)z * HC_CHUNKS + blockIdx.y) * P + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+template <int S>
+__global__ __launch_bounds__(256) void hc_param_grads_batched_kernel(HcFinish f, const float* __restrict__ ws, int D) {
+    constexpr int NB = S * (S + 1);
+    const long long P = (long long)D * (S + 3) + NB + S + 2;
+    const int z = blockIdx.y;
+    ws += (long long)z * HC_CHUNKS * P;
+    float* __restrict__ out = f.out[z];
+    __shared__ float red[S + 3][4][64];
+    const int el = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float part[S + 3];
+#pragma unroll
+    for (int c = 0; c < S + 3; ++c) part[c] = 0.f;
+    if (e < D) {
+        for (int k = kq; k < HC_CHUNKS; k += 4) {
+#pragma unroll
+            for (int c = 0; c < S + 3; ++c) part[c] += ws[k * P + (long long)c * D + e];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < S + 3; ++c) red[c][kq][el] = part[c];
+    __syncthreads();
+    if (kq == 0 && e < D) {
+        float col[S + 3];
+#pragma unroll
+        for (int c = 0; c < S + 3; ++c) col[c] = (red[c][0][el] + red[c][1][el]) + (red[c][2][el] + red[c][3][el]);
+        const float g1 = f.gamma[z][e] + 1.f;
+        float dg = f.wb[z][e] * col[S + 1];
+#pragma unroll
+        for (int t = 0; t < S + 1; ++t) {
+            out[(long long)e * (S + 1) + t] = g1 * col[t];
+            dg += f.Wa[z][(long long)e * (S + 1) + t] * col[t];
+        }
+        out[(long long)D * (S + 1) + e] = g1 * col[S + 1];
+        out[(long long)D * (S + 2) + e] = dg;
+        out[(long long)D * (S + 3) + NB + S + 2 + e] = col[S + 2];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < NB + S + 2) {
+        float v = 0.f;
+        for (int k = 0; k < HC_CHUNKS; ++k) v += ws[k * P + (long long)D * (S + 3) + threadIdx.x];
+        out[(long long)D * (S + 3) + threadIdx.x] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // stream expand / reduce  (reference audiolm_pytorch.py:524 / :551): R[b][s] = x[b]  ;  x[b] = sum_s R[b][s]
 // ------------------------------------------------------------------------------------------------------------------
@@ -1393,6 +1471,30 @@ extern "C" int alm_hc_param_grads(const float* sums, int chunks, const float* hc
     if (S == 2) hipLaunchKernelGGL(hc_param_grads_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
     else if (S == 3) hipLaunchKernelGGL(hc_param_grads_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
     else if (S == 4) hipLaunchKernelGGL(hc_param_grads_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, chunks, hp, out, D);
+    else return ALM_ERR_UNSUPPORTED;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the finish of nb <= 16 width connections in two launches (see hc_colsum_batched_kernel): parts[z] = the partial rows alm_hc_bwd wrote for problem z
+ * ([rows[z]][alm_hc_partial_width]), gammas / Was / wbs its hyper-connection parameters, outs[z] = alm_hc_grads_width(S, D) floats (layout as
+ * alm_hc_param_grads); ws: nb * 16 * alm_hc_partial_width(S, D) floats of scratch.  The pointer arrays are HOST arrays (they travel in the kernel arguments). */
+extern "C" int alm_hc_param_grads_batched(const float* const* parts, const int* rows, int nb, const float* const* gammas, const float* const* Was,
+                                          const float* const* wbs, float* ws, float* const* outs, int S, int D, void* stream) {
+    if (nb <= 0) return 0;
+    if (nb > HC_FINISH_MAX || !parts || !rows || !gammas || !Was || !wbs || !ws || !outs) return ALM_ERR_BAD_ARG;
+    HcFinish f{};
+    f.nb = nb;
+    for (int z = 0; z < nb; ++z) {
+        if (rows[z] < 1 || !parts[z] || !outs[z]) return ALM_ERR_BAD_ARG;
+        f.part[z] = parts[z]; f.rows[z] = rows[z]; f.gamma[z] = gammas[z]; f.Wa[z] = Was[z]; f.wb[z] = wbs[z]; f.out[z] = outs[z];
+    }
+    const int P = alm_hc_partial_width(S, D);
+    hipLaunchKernelGGL(hc_colsum_batched_kernel, dim3((P + 63) / 64, HC_CHUNKS, nb), dim3(256), 0, (hipStream_t)stream, f, ws, P);
+    const dim3 grid((D + 63) / 64, nb);
+    if (S == 2) hipLaunchKernelGGL(hc_param_grads_batched_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, f, (const float*)ws, D);
+    else if (S == 3) hipLaunchKernelGGL(hc_param_grads_batched_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, f, (const float*)ws, D);
+    else if (S == 4) hipLaunchKernelGGL(hc_param_grads_batched_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, f, (const float*)ws, D);
     else return ALM_ERR_UNSUPPORTED;
     ALM_LAUNCH_CHECK();
     return 0;

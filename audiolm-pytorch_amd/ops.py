@@ -526,7 +526,7 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
 
 
 def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=None, rstd=None, ln_gamma=None, R=None, coef=None, dbeta=None,
-           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False, r_dtype=F32, dsum_scale=1.0, dy_out=None):
+           hc=None, y_prev=None, coef_prev=None, r_bcast=False, sum_only=False, r_dtype=F32, dsum_scale=1.0, dy_out=None, defer_grads=False):
     """Hyper-connection backward (C ABI: alm_hc_bwd).  dRn: gradient wrt the residual output of a width connection, [B, S, N, D] (r_dtype), or with
     bcast fp32 [B*N, D] shared by all streams.  hc / R / coef / dbeta given: width-connection backward -> dR + the 7 parameter gradients; the
     gradient wrt the branch input is either `dx` (fp32, LayerNorm backward already applied) or `dxn` (bf16, wrt the LayerNorm output) +
@@ -534,7 +534,9 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
     y_prev / coef_prev given: depth-connection backward of the previous branch on that dR (or on dRn) -> dy (bf16), dbeta_prev.
     r_bcast: R is one fp32 [B*N, D] tensor for all streams; sum_only: return dsum fp32 [B*N, D] = sum over streams of dR instead of dR.
     r_dtype: storage type of dRn / R / dR (the non-bcast forms).  dsum_scale: factor on dsum (grad_shrink's alpha rides here).
-    -> dict(dR, dsum, grads, dy, dbeta)."""
+    defer_grads: the parameter gradients are NOT finished here -- `grads` is None and `part` = (partial rows, row count, hc) goes to
+    hc_param_grads_batched together with the other branches' (two launches for all of them instead of two per branch).
+    -> dict(dR, dsum, grads, dy, dbeta, part)."""
     width, depth = hc is not None, y_prev is not None
     mode = (2 if width else 0) | (1 if depth else 0)
     dev, M = dRn.device, B * N
@@ -562,6 +564,8 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
               _p(R), int(r_bcast), _p(coef), _p(dbeta), *hp, _p(dR), _p(dsum), float(dsum_scale), _p(part), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(dy), D, _p(dbo),
               mode, B, S, N, D, _st())
     grads = None
+    if width and defer_grads:
+        return dict(dR=dR, dsum=dsum, grads=None, dy=dy, dbeta=dbo, part=(part, rows, hc))
     if width:
         chunks = _lib.query('alm_colsum_chunks', rows)
         if chunks > 1:                                       # stage 1 of the column sums; the chunk rows are summed inside alm_hc_param_grads
@@ -579,7 +583,39 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
                 n *= d
             grads[name] = g[o:o + n].view(shape)
             o += n
-    return dict(dR=dR, dsum=dsum, grads=grads, dy=dy, dbeta=dbo)
+    return dict(dR=dR, dsum=dsum, grads=grads, dy=dy, dbeta=dbo, part=None)
+
+
+def _hc_grad_views(g, S, D):
+    o, grads = 0, {}
+    for name, shape in (('Wa', (D, S + 1)), ('wb', (D,)), ('gamma', (D,)), ('Aa', (S, S + 1)), ('Bb', (S,)), ('sa', ()), ('sb', ()), ('ln', (D,))):
+        n = 1
+        for d in shape:
+            n *= d
+        grads[name] = g[o:o + n].view(shape)
+        o += n
+    return grads
+
+
+def hc_param_grads_batched(parts, S, D):
+    """parts: list of hc_bwd(..., defer_grads=True)['part'] = (partial rows, row count, hc) -> list of gradient dicts (keys as hc_bwd's `grads`), finished
+    in two launches per 16 branches (C ABI: alm_hc_param_grads_batched)."""
+    out = []
+    for i0 in range(0, len(parts), 16):
+        grp = parts[i0:i0 + 16]
+        nb, dev = len(grp), grp[0][0].device
+        P, GW = _lib.query('alm_hc_partial_width', S, D), _lib.query('alm_hc_grads_width', S, D)
+        g = torch.empty((nb, GW), dtype=F32, device=dev)
+        ws = torch.empty((nb, 16, P), dtype=F32, device=dev)
+        arr_p = (ctypes.c_void_p * nb)(*[t[0].data_ptr() for t in grp])
+        arr_r = (ctypes.c_int * nb)(*[int(t[1]) for t in grp])
+        arr_g = (ctypes.c_void_p * nb)(*[t[2]['gamma'].data_ptr() for t in grp])
+        arr_wa = (ctypes.c_void_p * nb)(*[t[2]['Wa'].data_ptr() for t in grp])
+        arr_wb = (ctypes.c_void_p * nb)(*[t[2]['wb'].data_ptr() for t in grp])
+        arr_o = (ctypes.c_void_p * nb)(*[g[z].data_ptr() for z in range(nb)])
+        _lib.call('alm_hc_param_grads_batched', arr_p, arr_r, nb, arr_g, arr_wa, arr_wb, ws.data_ptr(), arr_o, S, D, _st())
+        out += [_hc_grad_views(g[z], S, D) for z in range(nb)]
+    return out
 
 
 # un-fused single-connection forms (kernel tests; the product path uses the fused modes)

@@ -592,11 +592,28 @@ def main():
             """-> (seconds for nst steps, diagnostics): GPU time of the clip + update kernels alone (HIP events) and the caching allocator's device-level
             traffic during the timed steps -- the `with_optimizer` figure has been bimodal between processes on one box (12.96 vs 14.75 ms for the same
             library in one visit, profiles/r4_*): these numbers say whether the optimiser kernels or the rest of the step move"""
-            opt_step(opt, clip)
+            # untimed priming, like the main loop's: the first optimiser steps allocate the Adam state and re-shape the caching allocator's pools (the
+            # step's working set now competes with 0.8 GB of state + the saved parameters for cached blocks).  With ONE priming step the timed region
+            # still saw a device-level malloc per step (`diagnostics.device_mallocs`: 10 in 10 steps, each a millisecond-class synchronising call) in
+            # whichever optimiser leg ran FIRST -- the "slow mode" of this figure in rounds 2-3 (+1.9 instead of +0.5 ms); the second leg, on settled
+            # pools, never did.  Four priming steps settle them.
+            for _ in range(4):
+                opt_step(opt, clip)
             opt_events.clear()
+            trace = os.environ.get('ALM_BENCH_ALLOC_TRACE') == '1'      # debugging aid: which Python frames make the caching allocator go to the device
+            if trace:
+                torch.cuda.memory._record_memory_history(max_entries=200000)
             ms0 = torch.cuda.memory_stats(dev)
             dt_ = timed(nst, lambda: opt_step(opt, clip))
             ms1 = torch.cuda.memory_stats(dev)
+            if trace:
+                snap = torch.cuda.memory._snapshot()
+                torch.cuda.memory._record_memory_history(enabled=None)
+                for tr_ in snap.get('device_traces', []):
+                    for ev in tr_:
+                        if ev.get('action') in ('segment_alloc', 'segment_free', 'segment_map', 'segment_unmap', 'oom'):
+                            fr = [f"{os.path.basename(f['filename'])}:{f['line']}:{f['name']}" for f in ev.get('frames', []) if 'site-packages' not in f['filename']][:8]
+                            print('[alloc-trace]', type(opt).__name__, ev['action'], ev.get('size'), fr, file=sys.stderr, flush=True)
             gpu_ms = sorted(a.elapsed_time(b) for a, b in opt_events)
             diag = dict(optimizer_gpu_ms_median=round(gpu_ms[len(gpu_ms) // 2], 3), optimizer_gpu_ms_max=round(gpu_ms[-1], 3),
                         device_mallocs=int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),

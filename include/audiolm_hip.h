@@ -242,6 +242,11 @@ int alm_hc_bwd(const void* dRn, int dRn_bcast, int r_bf16, const float* dx, long
                void* dR, float* dsum, float dsum_scale, float* partial, const void* y_prev_bf16, long long ldy, const float* coef_prev, void* dy_bf16, long long lddy,
                float* dbeta_out, int mode, int B, int S, int N, int D, void* stream);
 int alm_hc_param_grads(const float* sums, int chunks, const float* hc_gamma, const float* Wa, const float* wb, float* out, int S, int D, void* stream);
+/* the same finish for nb <= 16 width connections in two launches (column sums of every problem's partial rows, then the parameter gradients): the deferred
+ * mode of the fused backward keeps the partial rows of all 12 branches of a 6-layer stack and finishes them together (24 small launches -> 2).  HOST pointer
+ * arrays; ws: nb * 16 * alm_hc_partial_width(S, D) floats; outs[z]: alm_hc_grads_width(S, D) floats. */
+int alm_hc_param_grads_batched(const float* const* parts, const int* rows, int nb, const float* const* gammas, const float* const* Was,
+                               const float* const* wbs, float* ws, float* const* outs, int S, int D, void* stream);
 int alm_streams_expand(const float* x, float* R, int B, int S, long long nd, void* stream);   /* :524 */
 int alm_streams_reduce(const float* R, float* x, int B, int S, long long nd, void* stream);   /* :551 */
 int alm_residual_add(const float* x, const void* y_bf16, long long ldy, float* out, long long rows, int D, void* stream);

@@ -550,6 +550,43 @@ def test_hyper_connections_bf16_streams(ops, S, D, N):
     assert relmax(s1['dsum'], s0['dsum']) <= 1e-6
 
 
+@pytest.mark.parametrize('S,D,N', [(4, 1024, 700), (2, 512, 333)])
+def test_hyper_connection_param_grads_batched_finish(ops, S, D, N):
+    """round 4: the parameter-gradient finish of several width connections in two launches (alm_hc_param_grads_batched: column sums of every branch's
+    partial rows + the gradient kernel over (element block, branch)) against the per-branch finish (alm_colsum_partial + alm_hc_param_grads): the same
+    sums in another chunking -- equal to fp32 summation noise.  Three branches with different parameters and different row counts (first-branch
+    broadcast variant, plain, fused-LayerNorm + depth)."""
+    B = 2
+    M = B * N
+    hcs = [{k: v.contiguous() for k, v in _hc_params(S, D, 300 + 10 * i).items()} for i in range(3)]
+    gs = [(1 + 0.1 * rnd(D, seed=340 + i)).contiguous() for i in range(3)]
+    Rb = rnd(B, S, N, D, seed=350, dtype=BF16)
+    y = rnd(M, D, seed=351, dtype=BF16)
+    w = [ops.hc_fwd(Rb, B, S, N, D, hc=hcs[i], ln_gamma=gs[i], r_dtype=BF16) for i in range(3)]
+    Gb = rnd(B, S, N, D, seed=352, dtype=BF16)
+    dxn = rnd(M, D, seed=353, dtype=BF16)
+    dx = rnd(M, D, seed=354)
+    dbeta = rnd(M, S, seed=355)
+    xb = rnd(M, D, seed=356)
+    _, _, _, _, coefx = ops.hc_width_fwd(ops.streams_expand(xb.view(B, N, D), B, S), hcs[2], gs[2], B, S, N, D)
+    calls = [dict(dRn=Gb, kw=dict(dxn=dxn, mean=w[0]['mean'], rstd=w[0]['rstd'], ln_gamma=gs[0], R=Rb, coef=w[0]['coef'], dbeta=dbeta, hc=hcs[0], y_prev=y,
+                                  coef_prev=w[1]['coef'], r_dtype=BF16)),
+             dict(dRn=Gb, kw=dict(dx=dx, R=Rb, coef=w[1]['coef'], dbeta=dbeta, hc=hcs[1], r_dtype=BF16)),
+             dict(dRn=Gb, kw=dict(dx=dx, R=xb, coef=coefx, dbeta=dbeta, hc=hcs[2], r_bcast=True, sum_only=True, r_dtype=BF16))]
+    ref = [ops.hc_bwd(c['dRn'], B, S, N, D, **c['kw']) for c in calls]
+    dfr = [ops.hc_bwd(c['dRn'], B, S, N, D, defer_grads=True, **c['kw']) for c in calls]
+    assert all(d['grads'] is None and d['part'] is not None for d in dfr)
+    got = ops.hc_param_grads_batched([d['part'] for d in dfr], S, D)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert r['grads'].keys() == g.keys()
+        for k in g:
+            assert relmax(g[k], r['grads'][k]) <= 2e-5, (i, k, relmax(g[k], r['grads'][k]))
+        for k in ('dR', 'dsum', 'dy', 'dbeta'):
+            assert (r[k] is None) == (dfr[i][k] is None)
+            if r[k] is not None:
+                assert torch.equal(r[k], dfr[i][k]), (i, k)
+
+
 def test_layernorm_fp32_output_and_fp32_upstream_gradient(ops):
     """the final LayerNorm of the stack writes fp32 hidden states (logit heads) and receives an fp32 gradient from them"""
     rows, D = 37, 1024
