@@ -552,6 +552,9 @@ DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '1')))
 # all-reduce runs under the lower layers' backward and only the last group's is exposed.  Until round 3 the hook forced the per-layer split-K path
 # (30 + 30 launches, +0.8 ms/step per GPU against the single-GPU step).  0 = that per-layer path (one bucket per layer, maximal overlap, slower GEMMs).
 DP_DEFER_GROUPS = max(0, int(os.environ.get('ALM_DP_DEFER_GROUPS', '2')))
+# deferred mode: the hyper-connection parameter gradients of all branches of a layer group finished together in two launches (ops.hc_param_grads_batched)
+# instead of two small launches behind every hc_bwd (A/B switch)
+HC_BATCH_FINISH = os.environ.get('ALM_HC_BATCH_FINISH', '1') != '0'
 # Inside a hipGraph capture ALWAYS one group (see stack_backward): more than one corrupts the replays on ROCm 7.2, not root-caused.  The reproducer
 # (scripts/debug/graph_defer_groups.py) sets core._DEBUG_DEFER_GROUPS_CAPTURE itself; there is deliberately no environment switch for it.
 _DEBUG_DEFER_GROUPS_CAPTURE = 1
@@ -829,7 +832,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             h = ops.hc_bwd(dR, B, S, N, D, bcast=bcast, dxn=dXN, extra=extra, mean=sv['mean'], rstd=sv['rstd'], ln_gamma=prm['ln'], R=sv['R'],
                            coef=sv['coef'], dbeta=dbeta, hc=prm['hc'], y_prev=py, coef_prev=pc, r_bcast=sv['r_bcast'], sum_only=prev is None,
                            r_dtype=rdt, dsum_scale=dx_scale if prev is None else 1.0, dy_out=dy_slot(prev) if prev is not None else None,
-                           defer_grads=wg is not None)
+                           defer_grads=wg is not None and HC_BATCH_FINISH)
             if rec is not None:
                 rec.update(kind=kind, layer=l, dR_in=dR, dR_in_bcast=bcast, dbeta_in=dbeta, dR_out=h['dsum'] if prev is None else h['dR'], sum_only=prev is None,
                            dY_prev=h['dy'], dbeta_prev=h['dbeta'], hc_grads=dict(h['grads']) if h['grads'] is not None else None)
