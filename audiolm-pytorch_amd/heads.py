@@ -32,17 +32,38 @@ class HeadGroup:
         self.labels = labels                           # int64 [G, Rg] (-1 = ignore)  | None for logits-only use
 
 
+_PAD_IDX = {}
+
+
+def _pad_index(G, C, Cp, device):
+    """int32 [G * Cp]: row g * Cp + c of the padded head image <- row g * C + c of the flat [G * C, D] weight, -1 (zero row) for c >= C (shape-only: cached)"""
+    key = (G, C, Cp, device.type, device.index)
+    if key not in _PAD_IDX:
+        c = torch.arange(Cp, device=device)
+        idx = torch.where(c[None, :] < C, torch.arange(G, device=device)[:, None] * C + c[None, :], torch.full((1, 1), -1, device=device))
+        _PAD_IDX[key] = idx.reshape(-1).to(torch.int32).contiguous()
+    return _PAD_IDX[key]
+
+
 def _pack_head(w):
-    """fp32 [G, C, D] -> (Whi bf16 [G, C, D], Wlo bf16 [G, C, D] (w ~= Whi + Wlo), WT bf16 [G, D, Cpad] = Whi^T zero padded)."""
+    """fp32 [G, C, D] -> (Whi bf16 [G, C, D], Wlo bf16 [G, C, D] (w ~= Whi + Wlo), WT bf16 [G, D, Cpad] = Whi^T zero padded).  Two launches for all G
+    quantizers (round 4; it was 2 G + 2: the packs are redone after every optimiser step): one split-gather into the row-padded [G, Cpad, D] images,
+    one multi-weight transpose pack."""
     G, C, D = w.shape
     Cp = (C + 7) // 8 * 8
+    w = w.contiguous()
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    idx = _pad_index(G, C, Cp, w.device) if not capturing else None
+    if idx is not None:
+        hi, lo = ops.gather_split(w.view(G * C, D), idx)                       # rows C .. Cp-1 of every quantizer are zero
+        hi, lo = hi.view(G, Cp, D), lo.view(G, Cp, D)
+    else:                                                                      # (index tensors are not created inside a hipGraph capture)
+        his, los = zip(*[ops.gather_split(w[g], None, rows_out=Cp) for g in range(G)])
+        hi, lo = torch.stack(his), torch.stack(los)
     WT = torch.empty((G, D, Cp), dtype=BF16, device=w.device)
-    his, los = [], []
-    for g in range(G):
-        hi, lo = ops.gather_split(w[g], None, rows_out=Cp)                  # rows C .. Cp-1 are zero
-        his.append(hi), los.append(lo)
-        ops.pack_weight(w[g], None, WT[g], rows_pad=Cp, cols_pad=D)
-    return torch.stack(his)[:, :C], torch.stack(los)[:, :C], WT
+    for g0 in range(0, G, 8):
+        ops.pack_weights_multi([(w[g], None, WT[g], Cp, D) for g in range(g0, min(G, g0 + 8))])
+    return hi[:, :C], lo[:, :C], WT
 
 
 def head_logits(hn, w3, bias, idx, cache, key):
