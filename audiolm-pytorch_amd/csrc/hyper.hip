@@ -15,6 +15,7 @@
 // block barrier.  Parameter gradients are accumulated in registers over a grid-stride token loop, reduced over the 4 waves
 // of a block through LDS and written as per-block partial rows (second stage: alm_colsum).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -567,8 +568,17 @@ __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
     return p;
 }
 
+// ALM_HC_PROBE (measurement builds only, never the shipped library: scripts/build_variant.sh): where does hc_bwd's time go?
+//   1 = memory pattern only (same loads, same stores, trivial arithmetic, no reductions / barriers)     2 = full arithmetic, stores to L2-resident rows
+//   3 = full arithmetic, loads from L2-resident rows                                                    4 = both (no HBM traffic: arithmetic + latency chains alone)
+#ifndef ALM_HC_PROBE
+#define ALM_HC_PROBE 0
+#endif
+#ifndef ALM_HC_BWD_OCC
+#define ALM_HC_BWD_OCC 2                  // workgroups per CU the register allocation is bounded for (3 was tried: see DESIGN.md section 8.9)
+#endif
 template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
-__global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
+__global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a) {
     using C = Coef<S>;
     const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
     const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
@@ -680,8 +690,12 @@ __global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
         const auto& a = *hc_bwd_kargs();                                           // (shadows the by-value parameter: see hc_bwd_kargs)
         const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
         const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
+#if ALM_HC_PROBE == 3 || ALM_HC_PROBE == 4
+        const unsigned m_ = blockIdx.x, b_ = 0u, n_ = blockIdx.x, el = (unsigned)e0;
+#else
         const unsigned m_ = t.valid ? (unsigned)t.m : 0u;
         const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u, el = (unsigned)e0;         // PF: D == WPT * 256, every lane in range
+#endif
         const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
         constexpr unsigned RB = sizeof(RT);
         const unsigned tofs = ((b_ * (unsigned)S * uN + n_) * uD + el) * RB;       // 32-bit BYTE offsets: the launcher takes this path only when every tensor is < 4 GB
@@ -743,7 +757,11 @@ __global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
     int par = 0;
     auto process_impl = [&](const In& w, const Tok& t, const auto& a) {
         RT* const dRo = reinterpret_cast<RT*>(a.dR);
+#if ALM_HC_PROBE == 2 || ALM_HC_PROBE == 4
+        const int m = PF ? (int)blockIdx.x : t.m;
+#else
         const int m = t.m;
+#endif
         // STRAIGHT (round 4): in the prefetching loop with one token per workgroup pass, process() only ever sees valid tokens (skipped ones are
         // prefetched, never processed) and every lane is in range, so every store of the token is UNCONDITIONAL.  That is not cosmetic: a store
         // inside a branch makes the number of vector-memory operations issued since a prefetch unknowable at compile time, the compiler then waits
@@ -752,7 +770,11 @@ __global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
         // instructions of this kernel changed nothing: DESIGN.md section 8.9).
         constexpr bool STRAIGHT = PF && TPB == 1;
         const bool valid = STRAIGHT ? true : t.valid;
+#if ALM_HC_PROBE == 2 || ALM_HC_PROBE == 4
+        const int b = PF ? 0 : t.b, n = PF ? (int)blockIdx.x : t.n;
+#else
         const int b = t.b, n = t.n;
+#endif
         const bool ld_ok = valid && eok;
         float4 g[S], r_c[S];
         float4 dx_c = z4, yv = z4, ex_c = z4;
@@ -813,6 +835,21 @@ __global__ __launch_bounds__(256, 2) void hc_bwd_kernel(HcBwdArgs a) {
                 v4[s_] = o_.x * yv.x + o_.y * yv.y + o_.z * yv.z + o_.w * yv.w;
             }
         };
+#if ALM_HC_PROBE == 1
+        if (PF && WIDTH && DEPTH) {
+            const float sc = w.cf + w.cfp + w.pre + w.upb + w.ms;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float4 gs_ = DOT2 ? unraw(w.g[s]) : g[s];
+                const float4 o_ = make_float4(gs_.x + r_c[s].x * sc + dx_c.x, gs_.y + r_c[s].y * sc + ex_c.y, gs_.z + r_c[s].z + yv.z, gs_.w + r_c[s].w);
+                stR(at_bytes(dRo, ((((unsigned)b * (unsigned)S + (unsigned)s) * (unsigned)a.N + (unsigned)n) * (unsigned)a.D + (unsigned)e0) * (unsigned)sizeof(RT)), o_);
+                dy_acc.x += o_.x; dy_acc.y += o_.y; dy_acc.z += o_.z; dy_acc.w += o_.w;
+            }
+            st4bf(at_bytes(a.dy, ((unsigned)m * (unsigned)a.lddy + (unsigned)e0) * 2u), dy_acc);
+            *at_bytes(a.dbeta_out, ((unsigned)m * 4u + (unsigned)(lane & 3)) * 4u) = sc;
+            return;
+        }
+#endif
         if (WIDTH) {
             float4 r[S];
 #pragma unroll
@@ -1250,6 +1287,9 @@ template <typename K>
 int resident_blocks(K kernel) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 2;
+#if ALM_HC_PROBE
+    if (const char* e = getenv("ALM_HC_PROBE_OCC")) occ = atoi(e) < occ ? atoi(e) : occ;      // (probe builds: fewer resident workgroups than the registers allow)
+#endif
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
