@@ -92,6 +92,7 @@ SIGNATURES = {
     'alm_opt_chunk_elems': [],
     'alm_opt_grad_sumsq': [_P, _I, _P, _I, _P, _P],
     'alm_opt_adam_step': [_P, _I, _P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
+    'alm_opt_adam_pack_step': [_P, _I, _F, _F, _F, _F, _I, _I, _P, _F, _P],
     'alm_conv1d_packed_floats': [_I, _I, _I],
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
     'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -148,6 +149,13 @@ def load(build_if_missing: bool = True):
 class AlmOptTensor(ctypes.Structure):
     """mirror of AlmOptTensor in include/audiolm_hip.h"""
     _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_longlong), ('wd', c_float), ('step', c_int)]
+
+
+class AlmOptPackJob(ctypes.Structure):
+    """mirror of AlmOptPackJob in include/audiolm_hip.h"""
+    _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('rows', c_int), ('cols', c_int), ('ld', c_longlong),
+                ('dst', c_void_p), ('ld_dst', c_longlong), ('rows_pad', c_int), ('cols_pad', c_int), ('dstT', c_void_p), ('ld_dstT', c_longlong),
+                ('wd', c_float), ('step', c_int)]
 
 
 class AlmPackJob(ctypes.Structure):

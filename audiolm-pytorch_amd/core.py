@@ -80,6 +80,46 @@ def tensor_version(t):
         return 0
 
 
+# ---- optimiser <-> packed weights (round 4).  FusedAdam (optimizer.py) can write the bf16 images of a dense weight while it updates the fp32 master
+# (alm_opt_adam_pack_step): layer_weights() registers, per master weight, where its current images live; the optimiser asks pack_target(p) and, after
+# the fused update, calls stamp_packed() so that the next forward finds the cache entry current and skips the re-pack.  Keyed by the master's data
+# pointer and validated by its (pointer, version, shape) stamp: an entry whose stamp no longer matches the tensor (any other in-place update, a cleared
+# or re-packed cache, another tensor at a recycled address) is simply not used.
+FUSED_ADAM_PACK = os.environ.get('ALM_FUSED_ADAM_PACK', '1') != '0'
+_PACK_REGISTRY = {}      # data_ptr -> dict(stamp, cache (weakref), key, out (the cache entry's packed pair), jobs [(row0, rows, cols, dst, dstT, rows_pad, cols_pad)])
+
+
+def _register_pack(w, stamp, cache, key, out, jobs):
+    import weakref
+    if len(_PACK_REGISTRY) > 4096:                                   # models come and go (tests): drop entries whose cache is gone
+        for k in [k for k, e in _PACK_REGISTRY.items() if e['cache']() is None]:
+            del _PACK_REGISTRY[k]
+    _PACK_REGISTRY[w.data_ptr()] = dict(stamp=stamp, cache=weakref.ref(cache), key=key, out=out, jobs=jobs)
+
+
+def pack_target(p):
+    """-> the registry entry of master weight `p` when its packed images are CURRENT (then updating p and the images together keeps them so), else None"""
+    if not FUSED_ADAM_PACK:
+        return None
+    e = _PACK_REGISTRY.get(p.data_ptr())
+    if e is None or e['stamp'] != (p.data_ptr(), tensor_version(p), tuple(p.shape)):
+        return None
+    cache = e['cache']()
+    hit = cache.store.get(e['key']) if cache is not None else None
+    if hit is None or hit[1] is not e['out'] or hit[0] != e['stamp']:
+        return None
+    return e
+
+
+def stamp_packed(p, e):
+    """after alm_opt_adam_pack_step wrote p and its images (and p's version counter advanced): the cache entry now describes the NEW value"""
+    stamp = (p.data_ptr(), tensor_version(p), tuple(p.shape))
+    e['stamp'] = stamp
+    cache = e['cache']()
+    if cache is not None:
+        cache.store[e['key']] = (stamp, e['out'])
+
+
 class WeightCache:
     """bf16 packed copies (W and W^T, zero padded) of the fp32 master weights; refreshed when a master's version changes
     (i.e. once per optimiser step) -- this is what `accelerator.autocast()` (trainer.py:1241) does per call, amortised."""
@@ -135,7 +175,7 @@ def layer_weights(cache: WeightCache, l, branches, I, Ip):
     vers = {k: (w.data_ptr(), tensor_version(w), tuple(w.shape)) for k, w in ws}
     hits = {k: cache.store.get((l,) + k) for k, _ in ws}
     if not all(h is not None and h[0] == vers[k] for k, h in hits.items()):
-        out, jobs = {}, []
+        out, jobs, targets = {}, [], {}
         with torch.no_grad():
             for k, w in ws:
                 w = w.detach()
@@ -146,12 +186,14 @@ def layer_weights(cache: WeightCache, l, branches, I, Ip):
                     jobs.append((w[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
                     jobs.append((w[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
                     out[k] = (W1, W1T)
+                    targets[k] = [(0, I, D, W1[:Ip], W1T[:, :Ip], Ip, D), (I, w.shape[0] - I, D, W1[Ip:], W1T[:, Ip:], Ip, D)]
                 elif k[1] == 'w2':
                     D = w.shape[0]
                     W2 = torch.empty((D, Ip), dtype=BF16, device=w.device)
                     W2T = torch.empty((Ip, D), dtype=BF16, device=w.device)
                     jobs.append((w, W2, W2T, D, Ip))
                     out[k] = (W2, W2T)
+                    targets[k] = [(0, D, w.shape[1], W2, W2T, D, Ip)]
                 else:
                     rows, cols = w.shape
                     rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
@@ -159,10 +201,13 @@ def layer_weights(cache: WeightCache, l, branches, I, Ip):
                     WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
                     jobs.append((w, W, WT, rp, cp))
                     out[k] = (W[:rows], WT[:cols])
+                    targets[k] = [(0, rows, cols, W, WT, rp, cp)]
             for j in range(0, len(jobs), 8):
                 ops.pack_weights_multi(jobs[j:j + 8])
-        for k, _ in ws:
+        for k, w in ws:
             cache.store[(l,) + k] = (vers[k], out[k])
+            if FUSED_ADAM_PACK and w.is_contiguous():
+                _register_pack(w, vers[k], cache, (l,) + k, out[k], targets[k])
         hits = {k: cache.store[(l,) + k] for k, _ in ws}
     res = {}
     for (kind, name), h in hits.items():

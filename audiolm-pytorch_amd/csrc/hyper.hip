@@ -221,13 +221,18 @@ __device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
 }
 
 // combine the per-wave totals of the WPT waves of a token through LDS (one block barrier); every lane gets slot (lane & (NV-1))
-template <int WPT, int NV>
+// RAWBAR: the kernel has LDS-DMA loads in flight (hc_bwd's GL variant).  __syncthreads() is a fence + barrier, and the fence waits for every pending
+// vector-memory operation -- the DMA prefetch of the NEXT token included.  The partial sums only need this wave's LDS writes to be done before the barrier:
+// s_waitcnt lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void lds_barrier_raw() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int WPT, int NV, bool RAWBAR = false>
 __device__ __forceinline__ float token_combine(float tot, float* red, int tok, int wv, int lane) {
     if (WPT == 1) return tot;
     using SM = SlotMap<NV>;
     const int sl = SM::slot(lane);
     if (SM::primary(lane)) red[(tok * WPT + wv) * NV + sl] = tot;
-    __syncthreads();
+    if constexpr (RAWBAR) lds_barrier_raw();
+    else __syncthreads();
     float r = 0.f;
 #pragma unroll
     for (int w = 0; w < WPT; ++w) r += red[(tok * WPT + w) * NV + sl];
@@ -577,8 +582,19 @@ __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
 #ifndef ALM_HC_BWD_OCC
 #define ALM_HC_BWD_OCC 2                  // workgroups per CU the register allocation is bounded for (3 was tried: see DESIGN.md section 8.9)
 #endif
-template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
-__global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a) {
+// GL (round 4; PF, BC == 0, bf16 streams, WIDTH + DEPTH + LNF, WPT == 4 only): the token's inputs travel HBM -> LDS by DMA (global_load_lds) instead of
+// through a second register set.  Each wave fetches exactly the 5.5 KB it consumes -- its 256-element segment of the 2 x S stream rows and of dxn / extra / y
+// (six 16-byte instructions: lanes 0-31 one segment, lanes 32-63 the next, LDS image lane-linear) and the token's scalar records (three 4-byte instructions:
+// coefficient record, previous branch's record, [dbeta | mean | rstd]) -- into its own slice of one of two LDS buffers, and reads it back with ds_read_b64 /
+// b32 when the token's turn comes: no cross-wave hand-over, hence no barrier for the data.  EVERY load of the loop is on the DMA path (a VGPR-destination
+// load next to an LDS-DMA makes the compiler drain vmcnt(0)), the kernel has ONE __shared__ object (a second one does the same), the reduction barriers
+// are raw (see token_combine), and the two buffers reach the step lambda as __restrict__ parameters so that the reads of the current buffer wait for THEIR
+// DMA only (counted vmcnt) and not for the one just issued.  The 56 registers of the two prefetch sets are gone: three workgroups per CU (<= 168 VGPRs,
+// 52 KB of LDS each) with the prefetch intact -- the probes of DESIGN.md section 8.9 (b) say that is what the kernel is short of.
+constexpr int GL_WAVE = 11 * 512 + 3 * 256, GL_BUF = 4 * GL_WAVE;        // per wave: 2 S + 3 row segments of 512 B, three 256-byte scalar records (S == 4)
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0, bool GL = false>
+__global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a) {
+    static_assert(!GL || (PF && BC == 0 && WIDTH && DEPTH && LNF && WPT == 4 && sizeof(RT) == 2 && !HC_LDSREC), "GL: the production variant of the inner branches only");
     using C = Coef<S>;
     const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
     const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
@@ -588,8 +604,12 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
     constexpr int NB = S * (S + 1);
     constexpr int O_SR = NB, O_XR = NB + S, O_C1 = NB + 2 * S, O_C2 = NB + 2 * S + 1;
     static_assert(O_C2 < NV, "slot budget");
-    __shared__ float red[2][TPB * WPT * NV];                     // parity-double-buffered: possibly the only barrier of an iteration
-    __shared__ float redd[2][TPB * WPT * 4];
+    __shared__ float red_[GL ? 1 : 2][GL ? 1 : TPB * WPT * NV];  // parity-double-buffered: possibly the only barrier of an iteration
+    __shared__ float redd_[GL ? 1 : 2][GL ? 1 : TPB * WPT * 4];
+    constexpr int RED_F = TPB * WPT * NV, REDD_F = TPB * WPT * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char glsm[GL ? 2 * GL_BUF + (2 * RED_F + 2 * REDD_F) * 4 : 16];     // GL: the kernel's ONLY LDS object
+    float* const red_base = GL ? reinterpret_cast<float*>(glsm + 2 * GL_BUF) : &red_[0][0];
+    float* const redd_base = GL ? reinterpret_cast<float*>(glsm + 2 * GL_BUF) + 2 * RED_F : &redd_[0][0];
     // Per-WAVE record of the token's per-stream scalars (round 4).  The element loop needs 12 token-wide scalars per stream (the five dap, dbp, the
     // normalisation term, five alpha); they used to be fetched one by one with v_readlane from lane-distributed registers -- 74 VALU instructions per
     // token and wave, a fifth of that loop, plus the moves that build the {x, x} register pairs v_pk_fma_f32 wants.  Now the lanes that own a value
@@ -625,9 +645,10 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            // LDSREC: (gamma + 1) sqrt(D) is folded into the weights once: the element loop's dn * g1 * cD becomes part of the dot with dap / dbp
+            // (gamma + 1) sqrt(D) is folded into the weights once: the element loop's dn * g1 * cD becomes part of the dot with dap / dbp (4 registers and 4
+            // multiplies per stream less; out-of-range lanes: zero weights)
             g1[c] = eok ? g1[c] + 1.f : 0.f;
-            const float gc = HC_LDSREC ? g1[c] * cD : (eok ? 1.f : 0.f);
+            const float gc = g1[c] * cD;
             wbv[c] = wbv[c] * gc;
             rawb[c] = 0.f;
 #pragma unroll
@@ -685,7 +706,7 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
     // scalar is then a v_readlane away); pre / upb: this lane's pre-activation and (beta slots) upstream gradient; ms: lane 0 mean, lane 1 rstd.
     // With them NO load sits between the prefetch of the next token and the end of this one: the prefetch really stays in flight (vmcnt
     // retires in order: a late scalar load would force a wait for everything issued before it, i.e. for the whole prefetch).
-    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms, rnl; };
+    struct In { Raw4<RT> g[S], r[S]; float4 gb, rb, dx; uint2 dxn, ex, y; float cf, cfp, pre, upb, ms, rnl; const unsigned char* lds; };       // lds: GL only (this wave's slice of the current buffer)
     auto issue_pf = [&](In& w, const Tok& t) {
         const auto& a = *hc_bwd_kargs();                                           // (shadows the by-value parameter: see hc_bwd_kargs)
         const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
@@ -754,6 +775,74 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
             if (DEPTH) w.y = *reinterpret_cast<const uint2*>(a.y + (long long)t.m * a.ldy + e0);
         }
     };
+    typedef __attribute__((address_space(1))) const char gcchar;
+    typedef __attribute__((address_space(3))) void lds_void;
+    // GL: DMA of one token's inputs into this wave's slice of an LDS buffer (`dstw`: wave-uniform).  Segment order: dRn_0..3 | R_0..3 | dxn | extra | y | (y)
+    auto issue_gl = [&](unsigned char* dstw, const Tok& t) {
+        const auto& a = *hc_bwd_kargs();
+        const unsigned m_ = t.valid ? (unsigned)t.m : 0u;
+        const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u;
+        const unsigned half = (unsigned)lane >> 5, l32 = (unsigned)lane & 31u;
+        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
+        const unsigned el = (unsigned)(wv * 256) + l32 * 8u;                                        // 8 bf16 = 16 bytes per lane
+        const unsigned tofs = ((b_ * (unsigned)S * uN + n_) * uD + el) * 2u + half * sND32 * 2u;    // lanes 32-63: the next stream's row
+        gcchar* const gd = (gcchar*)a.dRn;
+        gcchar* const gr = (gcchar*)a.R;
+#pragma unroll
+        for (int j = 0; j < S / 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gd + (tofs + (unsigned)(2 * j) * sND32 * 2u)), (lds_void*)(dstw + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < S / 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gr + (tofs + (unsigned)(2 * j) * sND32 * 2u)), (lds_void*)(dstw + (S / 2 + j) * 1024), 16, 0, 0);
+        }
+        // every base pointer is fetched (scalar loads) BEFORE the per-lane selects and pinned: left to itself the compiler moves each load into the arm of the
+        // select that uses it and branches around it -- with branches between the DMA instructions
+        auto pin = [](const void* q) { unsigned long long v = (unsigned long long)q; asm volatile("" : "+s"(v)); return v; };
+        {
+            const unsigned long long bx = pin(a.dxn), bex = pin(a.extra), by = pin(a.y);
+            const unsigned ox = (m_ * (unsigned)a.lddxn + el) * 2u, oe = (m_ * (unsigned)a.ldex + el) * 2u;
+            const bool hx = half != 0u && bex != 0ull;
+            const unsigned long long px = (hx ? bex : bx) + (unsigned long long)(hx ? oe : ox);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px, (lds_void*)(dstw + S * 1024), 16, 0, 0);
+            // y is the 11th and last 512-byte segment: lanes 0-31 only (an LDS-DMA writes M0 + 16 * lane for the ACTIVE lanes; the upper half would land in
+            // the scalar records behind it)
+            const unsigned long long py = by + (unsigned long long)((m_ * (unsigned)a.ldy + el) * 2u);
+            if (half == 0u) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py, (lds_void*)(dstw + (S + 1) * 1024), 16, 0, 0);
+        }
+        {
+            const unsigned lc = (unsigned)lane < (unsigned)C::W ? (unsigned)lane : (unsigned)C::W - 1u;
+            unsigned char* const sc = dstw + (2 * S + 3) * 512;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((gcchar*)a.coef + (m_ * (unsigned)C::W + lc) * 4u), (lds_void*)sc, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((gcchar*)a.coef_prev + (m_ * (unsigned)C::W + lc) * 4u), (lds_void*)(sc + 256), 4, 0, 0);
+            const unsigned long long bdb = pin(a.dbeta), bmu = pin(a.mean), brs = pin(a.rstd);
+            const unsigned long long pm = (lane < S ? bdb : (lane == S ? bmu : brs)) + (unsigned long long)(lane < S ? (m_ * (unsigned)S + (unsigned)lane) * 4u : m_ * 4u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pm, (lds_void*)(sc + 512), 4, 0, 0);
+        }
+    };
+    // ... and its read-back into the In record process() consumes
+    auto fetch_gl = [&](In& w, const unsigned char* curw) {
+        const unsigned lo = (unsigned)lane * 8u;
+        if constexpr (sizeof(RT) == 2) {
+#pragma unroll
+            for (int t2 = 0; t2 < S; ++t2) {
+                w.g[t2].v = *reinterpret_cast<const uint2*>(curw + t2 * 512 + lo);
+                w.r[t2].v = *reinterpret_cast<const uint2*>(curw + (S + t2) * 512 + lo);
+            }
+        }
+        w.dxn = *reinterpret_cast<const uint2*>(curw + 2 * S * 512 + lo);
+        w.ex = *reinterpret_cast<const uint2*>(curw + (2 * S + 1) * 512 + lo);
+        w.y = *reinterpret_cast<const uint2*>(curw + (2 * S + 2) * 512 + lo);
+        const float* sc = reinterpret_cast<const float*>(curw + (2 * S + 3) * 512);
+        w.cf = sc[cl];
+        w.pre = sc[pre_idx];
+        w.cfp = sc[64 + cl];
+        w.upb = sc[128 + sl];
+        w.ms = sc[128 + S + (lane & 1)];
+        w.rnl = 0.f;
+        w.gb = w.rb = w.dx = z4;
+        w.lds = curw;
+    };
     int par = 0;
     auto process_impl = [&](const In& w, const Tok& t, const auto& a) {
         RT* const dRo = reinterpret_cast<RT*>(a.dR);
@@ -807,7 +896,7 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
             }
             if (LNF) {
                 dx_c = unraw((!PF || valid) ? w.dxn : make_uint2(0u, 0u));       // dxn (bf16) travels in dx_c
-                ex_c = unraw(w.ex);
+                ex_c = unraw((GL && !a.extra) ? make_uint2(0u, 0u) : w.ex);      // (GL fetched dxn in extra's place when there is no extra)
             } else {
                 dx_c = w.dx;
             }
@@ -896,7 +985,7 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
                 }
             }
             float da = bfly<NV>(v, lane);
-            da = token_combine<WPT, NV>(da, red[par], tok, wv, lane);
+            da = token_combine<WPT, NV, GL>(da, red_base + par * RED_F, tok, wv, lane);
             if (LNF) {
                 // <dx, R_s> = <u, R_s> - rstd mean(g) sum R_s - rstd mean(g xhat) <xhat, R_s>; then the per-element dx itself
                 const float invD = 1.f / (float)a.D;
@@ -921,7 +1010,11 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
             if constexpr (DOT2) {
                 __builtin_amdgcn_sched_barrier(0);                        // (keeps the unpack HERE: see DOT2)
 #pragma unroll
-                for (int t2 = 0; t2 < S; ++t2) g[t2] = unraw(w.g[t2]);
+                for (int t2 = 0; t2 < S; ++t2) {
+                    // GL: the packed image is read again from the LDS buffer -- no register carries dRn across the reduction
+                    if constexpr (GL) g[t2] = unraw(*reinterpret_cast<const uint2*>(w.lds + t2 * 512 + lane * 8));
+                    else g[t2] = unraw(w.g[t2]);
+                }
             }
             if constexpr (HC_LDSREC) {
             // ---- the token's per-stream scalars -> this wave's LDS record (see hcrec), read back as broadcast splat pairs
@@ -998,9 +1091,12 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
                 const float gdot = gd * __builtin_amdgcn_rcpf(rn);
                 const float grr = gdot * rn * rn, rnc = rn * cD;
                 float4 out_s;
+                // GL: R_s comes back from the LDS buffer right here (2 registers, unpacked for this stream only) instead of living unpacked through the token
+                float4 r_s = r[s];
+                if constexpr (GL) r_s = unraw(*reinterpret_cast<const uint2*>(w.lds + (S + s) * 512 + lane * 8));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float rv = f4c(r[s], c);
+                    const float rv = f4c(r_s, c);
                     float dn = dbp * wbv[c];
 #pragma unroll
                     for (int t = 0; t < S + 1; ++t) dn += dap[t] * wa[t][c];
@@ -1008,7 +1104,7 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
 #pragma unroll
                     for (int t = 0; t < S + 1; ++t) rawa[t][c] += nhat * dap[t];
                     rawb[c] += nhat * dbp;
-                    const float gs = dn * g1[c] * cD;
+                    const float gs = dn;                                   // ((gamma + 1) sqrt(D) sits in wa / wbv)
                     float o = alpha[0] * f4c(dxv, c) + rn * (gs - grr * rv);
 #pragma unroll
                     for (int t = 0; t < S; ++t) o += alpha[t + 1] * f4c(g[t], c);
@@ -1031,9 +1127,10 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
             if (ld_ok) st4bf(PF ? at_bytes(a.dy, ((unsigned)m * (unsigned)a.lddy + (unsigned)e0) * 2u) : a.dy + (long long)m * a.lddy + e0, o);
             float db = bfly4(v4);                                           // every lane: total of slot bfly4_slot(lane)
             if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
-                float* rd = redd[par];
+                float* rd = redd_base + par * REDD_F;
                 if ((lane & 15) == 0) rd[(tok * WPT + wv) * 4 + bfly4_slot(lane)] = db;
-                __syncthreads();
+                if constexpr (GL) lds_barrier_raw();
+                else __syncthreads();
                 db = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < WPT; ++w2) db += rd[(tok * WPT + w2) * 4 + (lane & 3)];
@@ -1053,7 +1150,34 @@ __global__ __launch_bounds__(256, ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a
         if constexpr (PF) process_impl(w, t, *hc_bwd_kargs());
         else process_impl(w, t, a);
     };
-    if constexpr (PF) {
+    if constexpr (GL) {
+        unsigned char* const b0 = glsm + wave * GL_WAVE;
+        unsigned char* const b1 = glsm + GL_BUF + wave * GL_WAVE;
+        // one token: DMA of the NEXT token into `dst`, then the current one out of `cur` (distinct buffers; __restrict__ parameters -> alias scopes once inlined)
+        // The compiler does not order these ds_reads behind the DMA that filled `cur` (it was issued in the previous call of this lambda), so the wait is
+        // explicit and COUNTED: since that DMA group the wave has issued the previous token's 6 stores (S x dR, dy, dbeta: all unconditional, see
+        // STRAIGHT) and the 9 DMA instructions of the group just issued = 15 younger operations; vmcnt retires in order, so "at most 15 outstanding" means
+        // the older group has landed while the stores and the new prefetch stay in flight.  (More younger operations than counted would only make the wait
+        // longer than needed, never too short; the first token is waited for in full before the loop.)
+        static_assert(S == 4, "the counted wait below assumes S + 2 stores per token and 9 DMA instructions per group");
+        auto gstep = [&](unsigned char* __restrict__ dst, const unsigned char* __restrict__ cur, const Tok& tn, const Tok& tc) {
+            issue_gl(dst, tn);
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            In w;
+            fetch_gl(w, cur);
+            process(w, tc);
+        };
+        Tok ta = next_tok(blockIdx.x), tb = ta;
+        issue_gl(b0, ta);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int it = blockIdx.x; it < niter; it += 2 * (int)gridDim.x) {
+            tb = next_tok(it + gridDim.x);
+            gstep(b1, b0, tb, ta);
+            if (it + gridDim.x >= niter) break;
+            ta = next_tok(it + 2 * (int)gridDim.x);
+            gstep(b0, b1, ta, tb);
+        }
+    } else if constexpr (PF) {
         In wa, wb2;
         Tok ta = next_tok(blockIdx.x), tb = ta;
         issue_pf(wa, ta);
@@ -1341,10 +1465,10 @@ int hc_bwd_blocks(long long M, int D) { return hc_grid(M, 4 / hc_wpt(D), 256 * 4
 
 // the prefetching variant needs more registers and may be resident in fewer copies: the partial-row buffer is sized for the larger of the
 // two grids (a launch may then use fewer rows than alm_hc_partial_rows reported: the surplus rows are zeroed by the launch wrapper)
-template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0>
+template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0, bool GL = false>
 int bwd_grid_p(long long M, int D) {
     static int resident = 0;
-    if (!resident) resident = resident_blocks(hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, PF, BC>);
+    if (!resident) resident = resident_blocks(hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, PF, BC, GL>);
     const int cap = hc_bwd_blocks(M, D);
     const int grid = hc_grid(M, 4 / WPT, resident);
     return grid > cap ? cap : grid;
@@ -1356,8 +1480,19 @@ int bwd_grid_w(long long M, int D) {
         g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>(M, D));
         g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>(M, D));
         if constexpr (WIDTH) g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>(M, D));
+        if constexpr (WIDTH && DEPTH && LNF && WPT == 4 && S == 4) g = std::max(g, bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0, true>(M, D));
     }
     return g;
+}
+// ALM_HC_GL (default: see hc_gl_default): the LDS-DMA variant of the inner-branch backward (hc_bwd_kernel<..., GL = true>)
+constexpr int hc_gl_default = 1;
+int hc_gl_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ALM_HC_GL");
+        v = e ? (atoi(e) != 0) : hc_gl_default;
+    }
+    return v;
 }
 template <typename RT, int S, bool WIDTH, bool DEPTH, bool LNF>
 int bwd_grid(long long M, int D) {
@@ -1378,12 +1513,16 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
         if (small && a.D == WPT * 256 && !(a.bcast && a.r_bcast)) bc = a.bcast ? 1 : ((a.r_bcast && WIDTH) ? 2 : (a.r_bcast ? -1 : 0));
         // the prefetching kernels with stream-tensor R store dR unconditionally and never the stream sum (see STRAIGHT): any other request -> plain kernel
         if (WIDTH && (bc == 0 || bc == 1) && (!a.dR || a.dsum)) bc = -1;
+        if constexpr (WIDTH && DEPTH && LNF && WPT == 4 && S == 4) {
+            if (bc == 0 && hc_gl_enabled()) bc = 3;
+        }
     }
     int grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
     if constexpr (sizeof(RT) == 2) {
         if (bc == 0) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>(M, a.D);
         if (bc == 1) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>(M, a.D);
         if constexpr (WIDTH) { if (bc == 2) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>(M, a.D); }
+        if constexpr (WIDTH && DEPTH && LNF && WPT == 4 && S == 4) { if (bc == 3) grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0, true>(M, a.D); }
     }
     if (WIDTH && a.partial) {
         const int rows_used = (4 / WPT) * grid;
@@ -1395,6 +1534,9 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
         if (bc == 1) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 1>), dim3(grid), dim3(256), 0, st, a); return; }
         if constexpr (WIDTH) {
             if (bc == 2) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 2>), dim3(grid), dim3(256), 0, st, a); return; }
+        }
+        if constexpr (WIDTH && DEPTH && LNF && WPT == 4 && S == 4) {
+            if (bc == 3) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0, true>), dim3(grid), dim3(256), 0, st, a); return; }
         }
     }
     hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, false>), dim3(grid), dim3(256), 0, st, a);

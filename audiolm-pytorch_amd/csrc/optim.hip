@@ -130,6 +130,77 @@ int for_each_batch(const AlmOptTensor* tensors, int ntensors, int nchunks, F lau
     return c0 == nchunks ? 0 : ALM_ERR_BAD_ARG;
 }
 
+// ---- Adam + the bf16 re-pack of the GEMM weights in one pass (round 4).  The dense weights of the stack are consumed as packed bf16 copies (W and W^T,
+// zero-padded: alm_pack_weights_multi); after every optimiser step they used to be re-packed from the fp32 masters by the next forward: one more read
+// of every weight (4 B) + 2 x 2 B written, 30 us per layer.  Here the update kernel walks a weight matrix in the pack kernel's 64 x 128 tiles and writes the
+// new fp32 parameter, both moments AND both bf16 images: the re-pack's read disappears and its launches with it.  Same arithmetic as adam_kernel
+// (adam_one), same packed bits as pack_weights_multi2_kernel (pack_bf2 of the updated fp32 value).
+constexpr int PACK_BATCH = 12;
+struct OptPackBatch {
+    AlmOptPackJob job[PACK_BATCH];
+    int tile_end[PACK_BATCH];                                   // exclusive prefix sums of the per-job 64 x 128 tile counts
+    int njobs;
+};
+__global__ __launch_bounds__(256) void adam_pack_kernel(OptPackBatch pb, AdamArgs a) {
+    __shared__ uint32_t tile[64][65];                                   // [row][column pair]: see pack_weights_multi2_kernel
+    int j = 0;
+    while (j + 1 < pb.njobs && (int)blockIdx.x >= pb.tile_end[j]) ++j;
+    const AlmOptPackJob& q = pb.job[j];
+    const int local = blockIdx.x - (j ? pb.tile_end[j - 1] : 0);
+    const int tcols = (q.cols_pad + 127) / 128;
+    const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float* const P = reinterpret_cast<float*>(q.p);
+    const float* const G = reinterpret_cast<const float*>(q.g);
+    float* const Mo = reinterpret_cast<float*>(q.m);
+    float* const V = reinterpret_cast<float*>(q.v);
+    bf16_t* const dst = reinterpret_cast<bf16_t*>(q.dst);
+    bf16_t* const dstT = reinterpret_cast<bf16_t*>(q.dstT);
+    float clip = 1.f;
+    if (a.sumsq) clip = fminf(1.f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));
+    if (q.step > 0) {
+        const double bc1 = 1.0 - exp((double)q.step * log((double)a.beta1)), bc2 = 1.0 - exp((double)q.step * log((double)a.beta2));
+        a.step_size = (float)((double)a.lr / bc1);
+        a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
+    const int c = c0 + 2 * tx;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i;
+        float2 pv = make_float2(0.f, 0.f);
+        if (r < q.rows) {
+            const long long o = (long long)r * q.ld + c;
+            if (c + 1 < q.cols) {
+                pv = *reinterpret_cast<const float2*>(P + o);
+                const float2 gv = *reinterpret_cast<const float2*>(G + o);
+                float2 mv = *reinterpret_cast<const float2*>(Mo + o), vv = *reinterpret_cast<const float2*>(V + o);
+                adam_one(pv.x, gv.x, mv.x, vv.x, q.wd, clip, a);
+                adam_one(pv.y, gv.y, mv.y, vv.y, q.wd, clip, a);
+                *reinterpret_cast<float2*>(P + o) = pv;
+                *reinterpret_cast<float2*>(Mo + o) = mv;
+                *reinterpret_cast<float2*>(V + o) = vv;
+            } else if (c < q.cols) {
+                float mv = Mo[o], vv = V[o];
+                pv.x = P[o];
+                adam_one(pv.x, G[o], mv, vv, q.wd, clip, a);
+                P[o] = pv.x; Mo[o] = mv; V[o] = vv;
+            }
+        }
+        const uint32_t pk = pack_bf2(pv.x, pv.y);
+        tile[i][tx] = pk;
+        if (dst && r < q.rows_pad && c < q.cols_pad) *reinterpret_cast<uint32_t*>(dst + (long long)r * q.ld_dst + c) = pk;
+    }
+    if (!dstT) return;
+    __syncthreads();
+    const int rp = tx & 31, hw = tx >> 5;
+    for (int it = ty; it < 64; it += 4) {
+        const int cc = it * 2 + hw;                                     // source column within the tile
+        const int oc = c0 + cc, orow = r0 + 2 * rp;
+        const uint32_t x = tile[2 * rp][cc >> 1], y = tile[2 * rp + 1][cc >> 1];
+        const uint32_t pk = (cc & 1) ? ((x >> 16) | (y & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
+        if (oc < q.cols_pad && orow < q.rows_pad) *reinterpret_cast<uint32_t*>(dstT + (long long)oc * q.ld_dstT + orow) = pk;
+    }
+}
+
 }  // namespace
 
 extern "C" int alm_opt_chunk_elems(void) { return CHUNK; }
@@ -158,6 +229,39 @@ extern "C" int alm_opt_adam_step(const AlmOptTensor* tensors, int ntensors, cons
         hipLaunchKernelGGL(adam_kernel, dim3(nc), dim3(256), 0, (hipStream_t)stream, tb, reinterpret_cast<const int2*>(chunks) + c0, a);
     });
     if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// jobs: HOST array (device pointers inside), any count (PACK_BATCH per launch).  Each job: one fp32 weight matrix view [rows][cols] (row stride ld) of
+// parameter / gradient / both moments + the destinations of alm_pack_weights_multi.  Requirements (ALM_ERR_BAD_ARG otherwise: the caller then takes
+// alm_opt_adam_step + a separate pack): even ld / ld_dst / ld_dstT / rows_pad / cols_pad, 8-byte aligned fp32 bases, 4-byte aligned bf16 bases.
+extern "C" int alm_opt_adam_pack_step(const AlmOptPackJob* jobs, int njobs, float lr, float beta1, float beta2, float eps, int step, int decoupled_weight_decay,
+                                      const float* sumsq, float max_norm, void* stream) {
+    if (njobs <= 0) return 0;
+    if (!jobs || step < 1) return ALM_ERR_BAD_ARG;
+    for (int j = 0; j < njobs; ++j) {
+        const AlmOptPackJob& q = jobs[j];
+        if (!q.p || !q.g || !q.m || !q.v || q.rows <= 0 || q.cols <= 0 || q.ld < q.cols || q.rows_pad < q.rows || q.cols_pad < q.cols) return ALM_ERR_BAD_ARG;
+        if ((q.dst && q.ld_dst < q.cols_pad) || (q.dstT && q.ld_dstT < q.rows_pad)) return ALM_ERR_BAD_ARG;
+        if (((q.ld | q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 1) || (((uintptr_t)q.p | (uintptr_t)q.g | (uintptr_t)q.m | (uintptr_t)q.v) & 7) ||
+            (((uintptr_t)q.dst | (uintptr_t)q.dstT) & 3))
+            return ALM_ERR_BAD_ARG;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a{lr, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), max_norm, decoupled_weight_decay, sumsq};
+    for (int j0 = 0; j0 < njobs; j0 += PACK_BATCH) {
+        OptPackBatch pb{};
+        const int nj = njobs - j0 < PACK_BATCH ? njobs - j0 : PACK_BATCH;
+        int total = 0;
+        for (int j = 0; j < nj; ++j) {
+            pb.job[j] = jobs[j0 + j];
+            total += ((pb.job[j].cols_pad + 127) / 128) * ((pb.job[j].rows_pad + 63) / 64);
+            pb.tile_end[j] = total;
+        }
+        pb.njobs = nj;
+        hipLaunchKernelGGL(adam_pack_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pb, a);
+    }
     ALM_LAUNCH_CHECK();
     return 0;
 }

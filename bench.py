@@ -290,8 +290,9 @@ def main():
     engine = parallel.DataParallelEngine(model, dist, bucket_dtype=bucket_dtype) if world > 1 else None
     cache = model.transformer._cache
 
-    def eager_step(opt=None):
-        cache.store.clear()                                     # weights "changed": re-pack bf16 copies like after an optimiser step
+    def eager_step(opt=None, repack=True):
+        if repack:
+            cache.store.clear()                                 # weights "changed": re-pack bf16 copies like after an optimiser step
         for p in model.parameters():
             p.grad = None
         with amp():
@@ -338,13 +339,13 @@ def main():
     elif want not in ('eager', 'eager2'):
         note = f'{want} is a single-GPU schedule (the gradient all-reduce is issued from backward callbacks); ran eager'
 
-    def step(opt=None):
+    def step(opt=None, repack=True):
         if gstep is not None:
             loss = gstep(**inputs)
             if opt is not None:
                 opt.step()
             return loss
-        return eager_step(opt)
+        return eager_step(opt, repack)
 
     def timed(nsteps, fn):
         barrier()
@@ -580,7 +581,10 @@ def main():
         opt_events = []
 
         def opt_step(opt, clip):
-            step()
+            # no forced re-pack here: a real optimiser step follows, the packed bf16 weight images go stale through the parameters' version counters
+            # exactly as in training -- torch.optim.Adam: every dense weight is re-packed by the next forward; FusedAdam (round 4) writes the images
+            # itself (alm_opt_adam_pack_step) and the forward finds them current
+            step(repack=False)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             clip(opt)
@@ -631,7 +635,7 @@ def main():
         del stock
         model.load_state_dict(state0)
         opt_leg = dict(ms_per_step=round(dto / nst * 1e3, 3), value=round(world * W['B'] * N / (dto / nst), 1),
-                       optimizer='FusedAdam (alm_opt_grad_sumsq + alm_opt_adam_step): clip_grad_norm_(0.5) + Adam',
+                       optimizer='FusedAdam (alm_opt_grad_sumsq + alm_opt_adam_step + alm_opt_adam_pack_step: the dense weights\' bf16 images written by the update' + ('' if core.FUSED_ADAM_PACK else ' -- OFF') + '): clip_grad_norm_(0.5) + Adam',
                        torch_adam_ms_per_step=round(dts / nst * 1e3, 3), diagnostics=dict(fused=diag_f, torch_adam=diag_s, steps=nst))
 
     if rank == 0:

@@ -302,6 +302,20 @@ int alm_opt_grad_sumsq(const AlmOptTensor* tensors, int ntensors, const int* chu
 int alm_opt_adam_step(const AlmOptTensor* tensors, int ntensors, const int* chunks, int nchunks, float lr, float beta1, float beta2, float eps, int step,
                       int decoupled_weight_decay, const float* sumsq, float max_norm, void* stream);
 
+/* The same update for the dense GEMM weights, fused with their bf16 re-pack (round 4): walks each weight matrix in alm_pack_weights_multi's tiles and
+ * writes the new fp32 parameter, both moments and both packed images (dst / dstT as in AlmPackJob) -- the forward after an optimiser step then finds its
+ * packed copies current (core.layer_weights) instead of re-reading every master weight.  `jobs`: HOST array.  Bit-identical to alm_opt_adam_step
+ * followed by alm_pack_weights_multi.  Needs even leading dimensions / paddings and 8-byte (fp32) / 4-byte (bf16) aligned bases: ALM_ERR_BAD_ARG otherwise. */
+typedef struct AlmOptPackJob {
+    void* p; const void* g; void* m; void* v;   /* fp32 [rows][cols] views, row stride ld: parameter, gradient, exp_avg, exp_avg_sq */
+    int rows, cols; long long ld;
+    void* dst; long long ld_dst; int rows_pad, cols_pad;
+    void* dstT; long long ld_dstT;
+    float wd; int step;                         /* as AlmOptTensor */
+} AlmOptPackJob;
+int alm_opt_adam_pack_step(const AlmOptPackJob* jobs, int njobs, float lr, float beta1, float beta2, float eps, int step, int decoupled_weight_decay,
+                           const float* sumsq, float max_norm, void* stream);
+
 /* ---- SoundStream tokenize path (encode only): soundstream.py:332-345, 362-380, 519-531 (causal conv encoder), :592-607 / :840 ----
  * (eval-mode GroupedResidualVQ of vector-quantize-pytorch, restated in oracle/rvq_restated.py).  All fp32: the code indices are an
  * argmin over float distances, so both kernels run on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), never bf16.

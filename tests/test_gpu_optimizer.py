@@ -79,3 +79,96 @@ def test_fused_adam_keeps_a_step_count_per_parameter():
             err = float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp(min=1e-30))
             assert err <= 2e-6, (step, tuple(p.shape), err)
     assert [float(o.state[p]['step']) for p in ours] == [float(r.state[q]['step']) for q in ref] == [3.0, 2.0, 3.0]
+
+
+def _train_model(seed=0):
+    import audiolm_pytorch_amd as A
+    torch.manual_seed(seed)
+    model = A.CoarseTransformer(dim=256, depth=2, num_semantic_tokens=100, codebook_size=64, num_coarse_quantizers=3, flash_attn=True).cuda()
+
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.)
+    w.train()
+    g = torch.Generator().manual_seed(7)
+    data = dict(semantic_token_ids=torch.randint(0, 100, (2, 40), generator=g).cuda(), coarse_token_ids=torch.randint(0, 64, (2, 30, 3), generator=g).cuda())
+    return model, w, data
+
+
+@pytest.mark.parametrize('wd', [0., 1e-2])
+def test_fused_adam_writes_the_packed_weight_images(monkeypatch, wd):
+    """Round 4 (alm_opt_adam_pack_step): the optimiser step of a dense GEMM weight also writes its packed bf16 images, so the forward after a step
+    does not re-pack.  Model A trains (forward, backward, fused step); model B -- same initial weights, never run forward, hence no packed images and
+    the plain alm_opt_adam_step for every tensor -- receives A's gradients and takes the same steps: parameters bit-identical after every step (the two
+    kernels share the arithmetic).  A packs its stack weights in the first forward only; the images the optimiser left in A's cache are bit-identical to
+    a fresh pack of the updated masters; with ALM_FUSED_ADAM_PACK off every forward re-packs.  (Losses of two separate training runs are NOT compared:
+    the embedding-gradient atomics make gradients differ in the last bit between runs, and Adam's first steps turn that into sign flips.)"""
+    import audiolm_pytorch_amd as A
+    from audiolm_pytorch_amd import core, ops
+    real = ops.pack_weights_multi
+
+    def counting(packs):
+        # the stack's weights only (jobs with a row-major destination; the logit heads pack transposed images of their own and are not fused)
+        return lambda jobs: (packs.append(sum(1 for j in jobs if j[1] is not None)), real(jobs))[1]
+
+    monkeypatch.setattr(core, 'FUSED_ADAM_PACK', True)
+    model_a, w_a, data = _train_model()
+    model_b, _, _ = _train_model()
+    for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+        assert torch.equal(pa, pb)
+    opt_a = A.get_optimizer(model_a.parameters(), lr=1e-3, wd=wd)
+    opt_b = A.get_optimizer(model_b.parameters(), lr=1e-3, wd=wd)
+    packs, per_step = [], []
+    monkeypatch.setattr(ops, 'pack_weights_multi', counting(packs))
+    for step in range(3):
+        n0 = sum(packs)
+        loss = w_a(**data, return_loss=True)
+        per_step.append(sum(packs) - n0)
+        loss.backward()
+        for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+            pb.grad = None if pa.grad is None else pa.grad.detach().clone()
+        na = opt_a.clip_grad_norm_(0.5)
+        nb = opt_b.clip_grad_norm_(0.5)
+        assert float(na) == float(nb)
+        opt_a.step()
+        opt_b.step()
+        for (k, pa), pb in zip(model_a.named_parameters(), model_b.parameters()):
+            assert torch.equal(pa, pb), (step, k)
+        opt_a.zero_grad(set_to_none=True)
+    assert per_step[0] > 0 and per_step[1:] == [0, 0], per_step            # packed once, kept current by the optimiser
+    # the images the fused step left in the cache == a fresh pack of the final masters
+    monkeypatch.setattr(ops, 'pack_weights_multi', real)
+    checked = 0
+    for key, (stamp, (W, WT)) in model_a.transformer._cache.store.items():
+        if not (isinstance(key, tuple) and len(key) == 3 and key[2] in ('wq', 'wkv', 'wo', 'w1', 'w2')):
+            continue
+        master = next(p for p in model_a.parameters() if p.data_ptr() == stamp[0])
+        assert stamp == (master.data_ptr(), master._version, tuple(master.shape)), key
+        if key[2] == 'w1':
+            ref_W, ref_WT = core._pack_w1(master.detach(), *_inner(model_a))
+        elif key[2] == 'w2':
+            ref_W, ref_WT = core._pack_w2(master.detach(), *_inner(model_a))
+        else:
+            ref_W, ref_WT = core._pack_plain(master.detach())
+        assert torch.equal(W, ref_W) and torch.equal(WT, ref_WT), key
+        checked += 1
+    assert checked >= 10, checked
+    # the switch: off -> every forward after a step re-packs
+    monkeypatch.setattr(core, 'FUSED_ADAM_PACK', False)
+    model_c, w_c, _ = _train_model()
+    opt_c = A.get_optimizer(model_c.parameters(), lr=1e-3, wd=wd)
+    packs_c, per_step_c = [], []
+    monkeypatch.setattr(ops, 'pack_weights_multi', counting(packs_c))
+    for step in range(2):
+        n0 = sum(packs_c)
+        w_c(**data, return_loss=True).backward()
+        per_step_c.append(sum(packs_c) - n0)
+        opt_c.step()
+        opt_c.zero_grad(set_to_none=True)
+    assert all(n > 0 for n in per_step_c), per_step_c
+
+
+def _inner(model):
+    cfg = model.transformer.cfg
+    return cfg.inner, cfg.inner_pad
