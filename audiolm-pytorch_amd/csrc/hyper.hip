@@ -576,8 +576,12 @@ __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
 // ALM_HC_PROBE (measurement builds only, never the shipped library: scripts/build_variant.sh): where does hc_bwd's time go?
 //   1 = memory pattern only (same loads, same stores, trivial arithmetic, no reductions / barriers)     2 = full arithmetic, stores to L2-resident rows
 //   3 = full arithmetic, loads from L2-resident rows                                                    4 = both (no HBM traffic: arithmetic + latency chains alone)
+//   5 = production arithmetic and traffic, the SECOND block barrier of a token (depth connection's reduction) left out: what one barrier per token would buy
 #ifndef ALM_HC_PROBE
 #define ALM_HC_PROBE 0
+#endif
+#ifndef ALM_HC_GLREC
+#define ALM_HC_GLREC 0                   // 1: the LDS-DMA variant takes the LDS scalar-record element loop (see hcrec) at two workgroups per CU
 #endif
 #ifndef ALM_HC_BWD_OCC
 #define ALM_HC_BWD_OCC 2                  // workgroups per CU the register allocation is bounded for (3 was tried: see DESIGN.md section 8.9)
@@ -593,8 +597,9 @@ __device__ __forceinline__ HcBwdKArgs hc_bwd_kargs() {
 // 52 KB of LDS each) with the prefetch intact -- the probes of DESIGN.md section 8.9 (b) say that is what the kernel is short of.
 constexpr int GL_WAVE = 11 * 512 + 3 * 256, GL_BUF = 4 * GL_WAVE;        // per wave: 2 S + 3 row segments of 512 B, three 256-byte scalar records (S == 4)
 template <typename RT, int S, int WPT, bool WIDTH, bool DEPTH, bool LNF, bool PF, int BC = 0, bool GL = false>
-__global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a) {
+__global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) void hc_bwd_kernel(HcBwdArgs a) {
     static_assert(!GL || (PF && BC == 0 && WIDTH && DEPTH && LNF && WPT == 4 && sizeof(RT) == 2 && !HC_LDSREC), "GL: the production variant of the inner branches only");
+    constexpr bool REC = HC_LDSREC || (GL && ALM_HC_GLREC != 0);        // the element loop reads the token's per-stream scalars from a per-wave LDS record
     using C = Coef<S>;
     const RT* const dRn = reinterpret_cast<const RT*>(a.dRn);
     const RT* const Rsv = reinterpret_cast<const RT*>(a.R);
@@ -607,7 +612,9 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
     __shared__ float red_[GL ? 1 : 2][GL ? 1 : TPB * WPT * NV];  // parity-double-buffered: possibly the only barrier of an iteration
     __shared__ float redd_[GL ? 1 : 2][GL ? 1 : TPB * WPT * 4];
     constexpr int RED_F = TPB * WPT * NV, REDD_F = TPB * WPT * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char glsm[GL ? 2 * GL_BUF + (2 * RED_F + 2 * REDD_F) * 4 : 16];     // GL: the kernel's ONLY LDS object
+    constexpr int GL_REC_OFF = 2 * GL_BUF + (2 * RED_F + 2 * REDD_F) * 4;
+    constexpr int GL_REC_BYTES = (GL && REC) ? 4 * ((S * (4 * (S + 2) + ((2 * (S + 1) + 3) / 4) * 4) + 4 + 3) / 4 * 4) * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char glsm[GL ? GL_REC_OFF + GL_REC_BYTES : 16];     // GL: the kernel's ONLY LDS object
     float* const red_base = GL ? reinterpret_cast<float*>(glsm + 2 * GL_BUF) : &red_[0][0];
     float* const redd_base = GL ? reinterpret_cast<float*>(glsm + 2 * GL_BUF) + 2 * RED_F : &redd_[0][0];
     // Per-WAVE record of the token's per-stream scalars (round 4).  The element loop needs 12 token-wide scalars per stream (the five dap, dbp, the
@@ -618,7 +625,8 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
     // Layout per stream (floats): S + 2 slots of [dR, dR, q, q] (dR = dpre / |R_s| for the S + 1 alpha slots and the beta slot, q = dR pre / |R_s|),
     // then the S + 1 alpha pairs, padded to 16 bytes; 4 dump floats at the end take the writes of the lanes that own nothing.
     constexpr int AF = ((2 * (S + 1) + 3) / 4) * 4, RS = 4 * (S + 2) + AF, RECW = S * RS + 4;
-    __shared__ __attribute__((aligned(16))) float hcrec[4][RECW];
+    constexpr int RECW4 = (RECW + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float hcrec_[(GL || !REC) ? 1 : 4][(GL || !REC) ? 4 : RECW4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = wave / WPT, wv = wave % WPT;
@@ -678,13 +686,13 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
     const int cl = lane < C::W ? lane : 0;                                   // this lane's entry of a coefficient record
     const int pre_idx = is_a ? C::AP + slot : C::BP + sl;
     // record addresses of this lane (see hcrec): its slot [dR, dR, q, q], its alpha pair; lanes that own neither write to the dump floats
-    float* const recw = hcrec[wave];
+    float* const recw = (GL && REC) ? reinterpret_cast<float*>(glsm + GL_REC_OFF) + wave * RECW4 : &hcrec_[(GL || !REC) ? 0 : wave][0];
     float* const rec_slot = recw + ((is_a || is_b) ? sl * RS + 4 * (is_a ? slot % (S + 1) : S + 1) : S * RS);
     float* const rec_alpha = recw + (lane < NB ? (lane / (S + 1)) * RS + 4 * (S + 2) + 2 * (lane % (S + 1)) : S * RS);
     auto issue_scalars = [&](auto& w, unsigned m_, const auto& a) {
         w.cf = w.cfp = w.pre = w.upb = w.ms = w.rnl = 0.f;
         if (WIDTH) {
-            if constexpr (HC_LDSREC) w.rnl = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)(C::RN + sl)) * 4u);         // 1 / |R_s| of this lane's stream
+            if constexpr (REC) w.rnl = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)(C::RN + sl)) * 4u);         // 1 / |R_s| of this lane's stream
             w.cf = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)cl) * 4u);       // 32-bit byte offsets (the launcher checks the sizes): SGPR base + VGPR offset
             w.pre = *at_bytes(a.coef, (m_ * (unsigned)C::W + (unsigned)pre_idx) * 4u);
             w.upb = *at_bytes(a.dbeta, (m_ * (unsigned)S + (unsigned)sl) * 4u);
@@ -780,8 +788,12 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
     // GL: DMA of one token's inputs into this wave's slice of an LDS buffer (`dstw`: wave-uniform).  Segment order: dRn_0..3 | R_0..3 | dxn | extra | y | (y)
     auto issue_gl = [&](unsigned char* dstw, const Tok& t) {
         const auto& a = *hc_bwd_kargs();
+#if ALM_HC_PROBE == 3 || ALM_HC_PROBE == 4
+        const unsigned m_ = blockIdx.x, b_ = 0u, n_ = blockIdx.x;
+#else
         const unsigned m_ = t.valid ? (unsigned)t.m : 0u;
         const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u;
+#endif
         const unsigned half = (unsigned)lane >> 5, l32 = (unsigned)lane & 31u;
         const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
         const unsigned el = (unsigned)(wv * 256) + l32 * 8u;                                        // 8 bf16 = 16 bytes per lane
@@ -839,7 +851,7 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
         w.cfp = sc[64 + cl];
         w.upb = sc[128 + sl];
         w.ms = sc[128 + S + (lane & 1)];
-        w.rnl = 0.f;
+        w.rnl = REC ? sc[C::RN + sl] : 0.f;
         w.gb = w.rb = w.dx = z4;
         w.lds = curw;
     };
@@ -1016,7 +1028,7 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
                     else g[t2] = unraw(w.g[t2]);
                 }
             }
-            if constexpr (HC_LDSREC) {
+            if constexpr (REC) {
             // ---- the token's per-stream scalars -> this wave's LDS record (see hcrec), read back as broadcast splat pairs
             {
                 const float dR = dpre * w.rnl;                             // dap[s][t] / |R_s|  (a slots) | dbp[s] / |R_s|  (b slots); 0 in lanes that own no slot
@@ -1044,9 +1056,11 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
                 // dR_s = alpha[s][0] dx + (1 / |R_s|) (gs - <gs, R_s> R_s / |R_s|^2) + sum_t alpha[s][t+1] dRn_t   with gs = (sum_t dap W_t + dbp wb) (gamma + 1) sqrt(D):
                 // the factors (gamma + 1) sqrt(D) sit in wa / wbv, 1 / |R_s| in dRp, <gs, R_s> / |R_s|^2 = qs (n_s . W = apre |R_s| ... see the forward)
                 float4 out_s;
+                float4 r_s = r[s];
+                if constexpr (GL) r_s = unraw(*reinterpret_cast<const uint2*>(w.lds + (S + s) * 512 + lane * 8));
 #pragma unroll
                 for (int cp = 0; cp < 2; ++cp) {
-                    const hc_f2 rv = cp ? hc_f2{r[s].z, r[s].w} : hc_f2{r[s].x, r[s].y};
+                    const hc_f2 rv = cp ? hc_f2{r_s.z, r_s.w} : hc_f2{r_s.x, r_s.y};
                     hc_f2 o = al[0] * dxv2[cp];
                     o = f2fma(dRp[S + 1], hc_f2{wbv[2 * cp], wbv[2 * cp + 1]}, o);
 #pragma unroll
@@ -1129,8 +1143,10 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
             if (WPT > 1) {                                                  // parity-double-buffered: this may be the only barrier of the iteration
                 float* rd = redd_base + par * REDD_F;
                 if ((lane & 15) == 0) rd[(tok * WPT + wv) * 4 + bfly4_slot(lane)] = db;
+#if ALM_HC_PROBE != 5                                                    // (probe 5: the depth connection's barrier left out -- timing only, dbeta wrong)
                 if constexpr (GL) lds_barrier_raw();
                 else __syncthreads();
+#endif
                 db = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < WPT; ++w2) db += rd[(tok * WPT + w2) * 4 + (lane & 3)];
@@ -1203,7 +1219,7 @@ __global__ __launch_bounds__(256, GL ? 3 : ALM_HC_BWD_OCC) void hc_bwd_kernel(Hc
     // per-(block, token slot) partial rows; the token's WPT waves own disjoint element ranges
     const int P = a.D * (S + 3) + NB + S + 2;
     float* prow = a.partial + ((long long)blockIdx.x * TPB + tok) * P;
-    const float rsc = HC_LDSREC ? cD : 1.f;                          // LDSREC accumulates R dap / |R| and applies the sqrt(D) of nhat here
+    const float rsc = REC ? cD : 1.f;                          // LDSREC accumulates R dap / |R| and applies the sqrt(D) of nhat here
     if (eok) {
 #pragma unroll
         for (int t = 0; t < S + 1; ++t) *reinterpret_cast<float4*>(prow + (long long)t * a.D + e0) = make_float4(rawa[t][0] * rsc, rawa[t][1] * rsc, rawa[t][2] * rsc, rawa[t][3] * rsc);
@@ -1514,7 +1530,10 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
         // the prefetching kernels with stream-tensor R store dR unconditionally and never the stream sum (see STRAIGHT): any other request -> plain kernel
         if (WIDTH && (bc == 0 || bc == 1) && (!a.dR || a.dsum)) bc = -1;
         if constexpr (WIDTH && DEPTH && LNF && WPT == 4 && S == 4) {
-            if (bc == 0 && hc_gl_enabled()) bc = 3;
+            // the LDS-DMA variant moves 16-byte pieces: every row it reads must start on a 16-byte boundary (bases and row strides)
+            const bool al16 = ((((uintptr_t)a.dRn | (uintptr_t)a.R | (uintptr_t)a.dxn | (uintptr_t)a.extra | (uintptr_t)a.y) & 15) == 0) &&
+                              (((a.lddxn | a.ldex | a.ldy) & 7) == 0) && a.coef_prev && a.dbeta;
+            if (bc == 0 && al16 && hc_gl_enabled()) bc = 3;
         }
     }
     int grid = bwd_grid_p<RT, S, WPT, WIDTH, DEPTH, LNF, false>(M, a.D);
