@@ -24,4 +24,7 @@ d = json.loads(open('gpurun_out/${tag}_bench_with_traffic.log').read())
 r = d['roofline']
 print('ms/step', d['ms_per_step'], 'traffic', r.get('traffic'), r.get('traffic_source'))
 PY
+# the documented fallbacks still pass: register-prefetch hc_bwd (ALM_HC_GL=0)
+ALM_HC_GL=0 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_opwise.py -m gpu -q --tb=short -p no:cacheprovider -k "hyper_connections or coarse-4-bf16-None" > gpurun_out/${tag}_gl0_tests.log 2>&1
+echo "ALM_HC_GL=0 tests rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_gl0_tests.log | cut -c1-200
 echo "total t=$((SECONDS-t0))"
