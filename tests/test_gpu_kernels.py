@@ -525,6 +525,19 @@ def test_hyper_connections_bf16_streams(ops, S, D, N):
         assert relmax(rb['dbeta'], rf['dbeta']) <= 1e-5 and relmax(rb['dy'], rf['dy']) <= 8e-3
         for k in rf['grads']:
             assert relmax(rb['grads'][k], rf['grads'][k]) <= 1e-4, k
+        # the same call with dxn / extra / y as views that start 8 bytes into a wider buffer: rows no longer begin on 16-byte boundaries, so the LDS-DMA
+        # variant of hc_bwd (round 4; 16-byte pieces) must hand over to the register-prefetch kernel -- same results
+        def off8(t):
+            wide = torch.zeros((t.shape[0], t.shape[1] + 8), dtype=t.dtype, device=t.device)
+            wide[:, 4:4 + t.shape[1]] = t
+            v = wide[:, 4:4 + t.shape[1]]
+            assert v.data_ptr() % 16 == 8
+            return v
+        rv = ops.hc_bwd(Gb, B, S, N, D, dxn=off8(dxn), extra=None if extra is None else off8(extra), mean=mean2, rstd=rstd2, ln_gamma=g2, R=R1b, coef=coef2,
+                        dbeta=dbeta2, hc=hc2, y_prev=off8(y), coef_prev=coef1, r_dtype=BF16)
+        assert relmax(rv['dR'].float(), rb['dR'].float()) <= 4e-3 and relmax(rv['dy'].float(), rb['dy'].float()) <= 8e-3 and relmax(rv['dbeta'], rb['dbeta']) <= 1e-5
+        for k in rb['grads']:
+            assert relmax(rv['grads'][k], rb['grads'][k]) <= 1e-5, k
     # width-only backward (mode 2), depth-only backward (mode 1)
     dx2 = rnd(M, D, seed=90)
     rf = ops.hc_bwd(Gb.float(), B, S, N, D, dx=dx2, R=R1b.float(), coef=coef2, dbeta=dbeta2, hc=hc2)
