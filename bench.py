@@ -94,6 +94,7 @@ def build(config, dev, rank, residual_dtype):
         else:
             n_sem, n_fr = (509, 512) if config == 'coarse2048' else (253, 256)
             N = 1 + (n_sem + 1) + 1 + n_fr * 3
+            sample_kw = dict(n_sem=n_sem, n_fr=n_fr)              # the parity / cpu_baseline sample at this configuration's own N
             inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, n_sem), generator=g).to(dev),
                           coarse_token_ids=torch.randint(0, 1024, (B, n_fr, 3), generator=g).to(dev))
             metric = METRIC if config == 'coarse2048' else 'audio-tokens/sec fwd+bwd, CoarseTransformer d=1024 seq=1024 (BASELINE configs[1])'
