@@ -125,6 +125,11 @@ def test_fused_adam_writes_the_packed_weight_images(monkeypatch, wd):
         loss = w_a(**data, return_loss=True)
         per_step.append(sum(packs) - n0)
         loss.backward()
+        if step == 0:
+            # one dense weight sits the first update out (a late-unfrozen layer): its step count then differs from its group's, the group's table entries
+            # carry per-tensor counts -- the per-tensor bias-correction branch of alm_opt_adam_pack_step
+            late = next(p for k, p in model_a.named_parameters() if 'to_q' in k and p.dim() == 2)
+            late.grad = None
         for pa, pb in zip(model_a.parameters(), model_b.parameters()):
             pb.grad = None if pa.grad is None else pa.grad.detach().clone()
         na = opt_a.clip_grad_norm_(0.5)
@@ -136,6 +141,8 @@ def test_fused_adam_writes_the_packed_weight_images(monkeypatch, wd):
             assert torch.equal(pa, pb), (step, k)
         opt_a.zero_grad(set_to_none=True)
     assert per_step[0] > 0 and per_step[1:] == [0, 0], per_step            # packed once, kept current by the optimiser
+    steps = {float(opt_a.state[p]['step']) for p in model_a.parameters() if p in opt_a.state}
+    assert steps == {2.0, 3.0}, steps                                      # (the late weight: two updates)
     # the images the fused step left in the cache == a fresh pack of the final masters
     monkeypatch.setattr(ops, 'pack_weights_multi', real)
     checked = 0
