@@ -82,6 +82,8 @@ SIGNATURES = {
     'alm_add_f32': [_P, _P, _P, _L, _F, _P],
     'alm_embed_assemble': [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P],
     'alm_embed_scatter_add': [_P, _P, _I, _P, _P, _P, _F, _L, _I, _P],
+    'alm_embed_scatter_ws_floats': [_P, _I, _L, _I],
+    'alm_embed_scatter_owned': [_P, _P, _I, _P, _P, _P, _F, _L, _I, _P, _P],
     'alm_gather_split_bf16': [_P, _L, _L, _P, _P, _P, _L, _L, _I, _P],
     'alm_gather_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],
     'alm_scatter_rows_bf16': [_P, _L, _P, _P, _L, _L, _I, _P],

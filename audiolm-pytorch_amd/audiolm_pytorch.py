@@ -728,6 +728,9 @@ class Transformer(nn.Module):
 
 # ---------------------------------------------------------------------------------------------- embedding assembly
 
+_EMBED_SCATTER_OWNED = os.environ.get('ALM_EMBED_SCATTER', 'owned') != 'atomic'
+
+
 class EmbedAssembleFn(torch.autograd.Function):
     """tokens[r] = table_a[row_a] (+ table_b[row_b]); src codes are (table_id << 24 | row), -1 = zero vector."""
 
@@ -741,13 +744,17 @@ class EmbedAssembleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous().to(torch.float32)
-        sizes = [t.numel() for t in ctx.tables]                                                   # one zero fill for all tables (the scatter adds atomically)
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dout.device)
+        sizes = [(t.numel() + 3) // 4 * 4 for t in ctx.tables]                                    # every table's slice starts on a 16-byte boundary
+        # destination-owned scatter (default): one owner per table row, fixed summation order -> bitwise run-to-run deterministic embedding gradients, and it
+        # writes every row itself (no zero fill).  ALM_EMBED_SCATTER=atomic: the round-2 kernel (fp32 L2 atomics, arrival order) for A/B runs.
+        owned = _EMBED_SCATTER_OWNED and ctx.dim % 4 == 0
+        flat = (torch.empty if owned else torch.zeros)(sum(sizes), dtype=torch.float32, device=dout.device)
         grads, o = [], 0
         for t, n in zip(ctx.tables, sizes):
-            grads.append(flat[o:o + n].view(t.shape))
+            grads.append(flat[o:o + t.numel()].view(t.shape))
             o += n
-        ops.embed_scatter_add([g.view(-1, ctx.dim) for g in grads], ctx.src[0], ctx.src[1], dout.view(-1, ctx.dim), 1.0, ctx.rows, ctx.dim)
+        fn = ops.embed_scatter_owned if owned else ops.embed_scatter_add
+        fn([g.view(-1, ctx.dim) for g in grads], ctx.src[0], ctx.src[1], dout.view(-1, ctx.dim), 1.0, ctx.rows, ctx.dim)
         return (None, None, None, None, *grads)
 
 

@@ -966,7 +966,10 @@ class TransformerStackFn(torch.autograd.Function):
         if float(opts.get('attn_dropout', 0.)) > 0. and xin.is_cuda and torch.cuda.is_current_stream_capturing():
             seed_state = graph_seed_state(xin.device)
             seed_state.add_(2 * cfg.depth)                            # part of the capture: every replay moves on to unused mask streams
-            dseed = (0, seed_state)                                   # (second half-batch: offset cfg.depth)
+            # THIS call's snapshot (the copy is captured and re-run on every replay): a second stack forward inside the same capture -- two transformers
+            # in one module, one transformer called twice, in-capture gradient accumulation -- advances the shared counter again before this call's
+            # backward runs, and the backward must see the value its own forward used (dQ / dK / dV with other keep masks otherwise)
+            dseed = (0, seed_state.clone())                           # (second half-batch: offset cfg.depth)
         if micro == 1:
             hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
                                       ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)),

@@ -100,6 +100,135 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(ScatterTabs tabs, co
     }
 }
 
+// ---- the same scatter WITHOUT atomics: every destination row has ONE owner, sums are formed in a fixed order -> bitwise run-to-run deterministic
+// gradients (the atomic form above adds in arrival order).  Two launches:
+//   (1) embed_scatter_small_kernel: the few-row tables as before (per 128-token chunk, summed in LDS in token order), but each chunk WRITES its
+//       sums to ws[chunk][small row][D] instead of adding them to the table;
+//   (2) embed_scatter_owned_kernel: workgroup g < ngroups OWNS OWN_G consecutive rows of one large table.  Each of its 4 waves owns a 256-column
+//       slice, scans the code arrays (src_a then src_b: 4 B per token and array, L2-resident, read by every workgroup) in token order, collects the
+//       tokens whose code falls in the group (ballot + prefix count: in-order compaction into a small per-wave pending list), and adds their dout
+//       slices to register accumulators in that order, 8 row loads in flight.  Workgroups g >= ngroups own one small-table row each and sum the
+//       chunk partials of (1) in chunk order.  Every row of every table is WRITTEN (zero when nothing maps to it): the caller need not clear them.
+// A code array is read once per owning workgroup (~450 x 128 KB from the L2 at the headline shape) -- cheaper than serialising 16 k fp32 atomics per
+// hot cache line, and there is no data-dependent sort on the host side.
+constexpr int OWN_G = 8;                 // destination rows per workgroup
+constexpr int OWN_PEND = 128;            // pending-list entries per wave (flushed at >= 64: a scan step adds at most 64)
+struct OwnTabs { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int small_base[MAX_TABLES]; int grp_base[MAX_TABLES + 1]; int n; int nsmall; int nchunks; };
+
+__global__ __launch_bounds__(256) void embed_scatter_small_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
+                                                                  const float* __restrict__ dout, float alpha, long long rows, int D, float* __restrict__ ws) {
+    __shared__ float acc[SMALL_ROWS][256];
+    const int t = threadIdx.x;
+    const int c = blockIdx.y * 256 + t;
+    const long long r0 = (long long)blockIdx.x * 128;
+    const int nr = (int)min(128LL, rows - r0);
+    for (int g = 0; g < tabs.nsmall; ++g) acc[g][t] = 0.f;
+    const bool cok = c < D;
+    for (int i0 = 0; i0 < nr; i0 += 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gv[u] = (cok && i0 + u < nr) ? dout[(r0 + i0 + u) * D + c] * alpha : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= nr) break;
+            const long long r = r0 + i0 + u;
+            const int codes[2] = {src_a[r], src_b[r]};                   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int code = codes[k];
+                if (code < 0 || !code_ok(tabs, code)) continue;
+                const int sb = tabs.small_base[code >> 24];
+                if (sb >= 0) acc[sb + (code & 0xffffff)][t] += gv[u];   // a column belongs to one thread: plain read-modify-write, token order
+            }
+        }
+    }
+    if (!cok) return;
+    for (int g = 0; g < tabs.nsmall; ++g) ws[((long long)blockIdx.x * tabs.nsmall + g) * D + c] = acc[g][t];
+}
+
+__global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
+                                                                  const float* __restrict__ dout, float alpha, long long rows, int D,
+                                                                  const float* __restrict__ ws, int ngroups) {
+    __shared__ int pend[4][OWN_PEND];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = (blockIdx.y * 4 + wave) * 256 + lane * 4;
+    const bool cok = col < D;                                              // D % 4 == 0: a lane's 4 columns are in or out together
+    const int g = blockIdx.x;
+    if (g >= ngroups) {
+        // ---- one small-table row: chunk partials summed in chunk order
+        const int s = g - ngroups;
+        int tb = 0;
+        while (tb + 1 < tabs.n && !(tabs.small_base[tb] >= 0 && s >= tabs.small_base[tb] && s < tabs.small_base[tb] + tabs.rows[tb])) ++tb;
+        if (!cok) return;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wp = ws + (long long)s * D + col;
+        const long long cs = (long long)tabs.nsmall * D;
+        int ch = 0;
+        for (; ch + 8 <= tabs.nchunks; ch += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(wp + (ch + u) * cs);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; ch < tabs.nchunks; ++ch) {
+            const float4 v = *reinterpret_cast<const float4*>(wp + ch * cs);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(s - tabs.small_base[tb]) * D + col) = a;
+        return;
+    }
+    // ---- OWN_G rows of a large table
+    int tb = 0;
+    while (tb + 1 < tabs.n && g >= tabs.grp_base[tb + 1]) ++tb;
+    const int row0 = (g - tabs.grp_base[tb]) * OWN_G;
+    const int nrow = min(OWN_G, tabs.rows[tb] - row0);
+    const int code_lo = (tb << 24) | row0;
+    float4 acc[OWN_G];
+#pragma unroll
+    for (int k = 0; k < OWN_G; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int* pl = pend[wave];
+    int np = 0;                                                            // wave-uniform
+    auto flush = [&]() {
+        for (int i0 = 0; i0 < np; i0 += 8) {
+            float4 v[8];
+            int d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = i0 + u < np ? pl[i0 + u] : -1;               // broadcast LDS read: (local row << 28) | token row
+                d[u] = e < 0 ? -1 : (e >> 28) & 7;
+                const long long r = e & 0x0fffffff;
+                v[u] = (e >= 0 && cok) ? *reinterpret_cast<const float4*>(dout + r * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < OWN_G; ++k)
+                    if (d[u] == k) { acc[k].x += v[u].x * alpha; acc[k].y += v[u].y * alpha; acc[k].z += v[u].z * alpha; acc[k].w += v[u].w * alpha; }
+        }
+        np = 0;
+    };
+    const long long total = 2 * rows;
+    for (long long base = 0; base < total; base += 64) {
+        const long long i = base + lane;
+        int code = -1;
+        if (i < total) code = i < rows ? src_a[i] : src_b[i - rows];
+        const unsigned off = (unsigned)(code - code_lo);
+        const bool hit = code >= 0 && off < (unsigned)nrow;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int pos = np + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (hit) pl[pos] = (int)((off << 28) | (unsigned)(i < rows ? i : i - rows));
+            np += __popcll(m);
+            if (np >= OWN_PEND - 64) flush();
+        }
+    }
+    flush();
+    if (!cok) return;
+    for (int k = 0; k < nrow; ++k) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = acc[k];
+}
+
 // out[r] = in[idx[r]] (idx < 0 -> zero row)           bf16 rows, D % 8 == 0
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ in, long long ld_in, const int* __restrict__ idx,
                                                           bf16_t* __restrict__ out, long long ld_out, long long rows, int D) {
@@ -445,6 +574,54 @@ extern "C" int alm_embed_scatter_add(float* const* grad_tables, const int* table
     if (rows <= 0 || D <= 0) return 0;
     hipLaunchKernelGGL(embed_scatter_kernel, dim3((unsigned)((rows + 127) / 128), (unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b, dout,
                        alpha, rows, D);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Deterministic form of the scatter (no atomics; every row of every table is written).  ws: alm_embed_scatter_ws_floats(...) fp32 floats.
+// Limits: rows < 2^28 (the pending entries pack a 3-bit local row + a 28-bit token row), D % 4 == 0, 16-byte aligned rows.
+static int own_tabs(OwnTabs& t, float* const* grad_tables, const int* table_rows, int ntables, long long rows) {
+    if (ntables > MAX_TABLES || !table_rows) return ALM_ERR_BAD_ARG;
+    t = OwnTabs{};
+    t.n = ntables;
+    int ng = 0;
+    for (int i = 0; i < ntables; ++i) {
+        t.p[i] = grad_tables ? grad_tables[i] : nullptr;
+        t.rows[i] = table_rows[i];
+        t.small_base[i] = -1;
+        t.grp_base[i] = ng;
+        if (table_rows[i] > 0 && t.nsmall + table_rows[i] <= SMALL_ROWS) { t.small_base[i] = t.nsmall; t.nsmall += table_rows[i]; }
+        else if (table_rows[i] > 0) ng += (table_rows[i] + OWN_G - 1) / OWN_G;
+    }
+    t.grp_base[ntables] = ng;
+    t.nchunks = (int)((rows + 127) / 128);
+    return 0;
+}
+
+extern "C" int alm_embed_scatter_ws_floats(const int* table_rows, int ntables, long long rows, int D) {
+    OwnTabs t;
+    if (rows < 0 || rows >= (1LL << 28) || own_tabs(t, nullptr, table_rows, ntables, rows)) return -1;
+    const long long fl = (long long)t.nchunks * t.nsmall * D;
+    return fl > 0x7fffffffLL ? -1 : (int)fl;
+}
+
+extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
+                                       float alpha, long long rows, int D, float* ws, void* stream) {
+    OwnTabs t;
+    int rc = own_tabs(t, grad_tables, table_rows, ntables, rows);
+    if (rc) return rc;
+    if (D <= 0 || (D & 3) || rows < 0 || rows >= (1LL << 28) || ((uintptr_t)dout & 15)) return ALM_ERR_BAD_ARG;
+    for (int i = 0; i < ntables; ++i)
+        if ((uintptr_t)t.p[i] & 15) return ALM_ERR_BAD_ARG;
+    const int ngroups = t.grp_base[ntables];
+    if (t.nsmall > 0 && t.nchunks > 0) {
+        if (!ws) return ALM_ERR_BAD_ARG;
+        hipLaunchKernelGGL(embed_scatter_small_kernel, dim3((unsigned)t.nchunks, (unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b,
+                           dout, alpha, rows, D, ws);
+    }
+    if (ngroups + t.nsmall > 0)
+        hipLaunchKernelGGL(embed_scatter_owned_kernel, dim3((unsigned)(ngroups + t.nsmall), (unsigned)((D + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, t,
+                           src_a, src_b, dout, alpha, rows, D, (const float*)ws, ngroups);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -762,6 +762,18 @@ def embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D):
               src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, _st())
 
 
+def embed_scatter_owned(grad_tables, src_a, src_b, dout, alpha, rows, D):
+    """deterministic form of embed_scatter_add (one owner per destination row, fixed summation order, no atomics): WRITES every row of every table --
+    `grad_tables` may be uninitialised memory (alm_embed_scatter_owned)"""
+    arr, tr = _ptr_array(grad_tables), _table_rows(grad_tables)
+    nws = _lib.query('alm_embed_scatter_ws_floats', ctypes.cast(tr, ctypes.c_void_p), len(grad_tables), rows, D)
+    if nws < 0:
+        raise _lib.AlmError('alm_embed_scatter_ws_floats: unsupported size')
+    ws = torch.empty(max(nws, 1), dtype=F32, device=dout.device)
+    _lib.call('alm_embed_scatter_owned', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(tr, ctypes.c_void_p), len(grad_tables),
+              src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, ws.data_ptr(), _st())
+
+
 def gather_split(inp, idx=None, rows_out=None):
     """fp32 inp [rows_in, D] (row stride arbitrary) -> (hi, lo) bf16 [rows_out, D] with hi + lo ~= inp[idx] to ~16 mantissa bits: the split-bf16
     operands of the logit heads.  idx int32 [rows_out] (-1 = zero row) or None (identity; rows past rows_in are zero = row padding)."""

@@ -258,6 +258,22 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('ALM_BENCH_LAUNCH_CHECK') == '1':
+        # launcher self-test (tests/test_bench_launch.py, runs without a GPU): every rank joins a gloo group, one all-reduce proves the rendezvous the
+        # self-launch set up works, rank 0 prints ONE JSON line.  Nothing is measured.
+        import datetime
+        import torch.distributed as dist
+        assert world == args.gpus, (world, args.gpus)
+        if world > 1:
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=120))
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t) == world
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup}), flush=True)
+        return
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     # test hook (scripts/gpu_check.sh dp2): ALM_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, to exercise the multi-rank control flow
     # (callbacks, bucket order, barriers) on a 1-GPU box; its numbers mean nothing
@@ -275,7 +291,7 @@ def main():
             dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))      # backend "nccl" IS RCCL on ROCm
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started {world} ranks (python bench.py --gpus N starts its own N ranks when no launcher did)'
 
     from audiolm_pytorch_amd import core, graphed, ops, parallel
     import audiolm_pytorch_amd as A
@@ -711,12 +727,45 @@ def _supervised(cmd, env=None, retries=1):
     return rc
 
 
+def _requested_gpus(argv):
+    """--gpus N / --gpus=N from the raw command line (1 when absent): read before argparse so that the launcher decision costs no torch import"""
+    for i, a in enumerate(argv):
+        if a == '--gpus' and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith('--gpus='):
+            return int(a.split('=', 1)[1])
+    return 1
+
+
+def _self_launch(ngpus):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (reference: `accelerate launch train.py`, README.md:344-358 -- the user
+    never types the per-rank command): start the N ranks ourselves, exactly as the driver's own command line does -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` -- one rank per GPU over RCCL; rank 0
+    prints the ONE JSON line on the stdout this process passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                                  # a port that is free NOW (the rendezvous store binds it a moment later)
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))   # dmabuf IPC: RCCL needs it on these hosts
+    env.pop('ALM_BENCH_CHILD', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ngpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    print(f'[bench.py] --gpus {ngpus} without WORLD_SIZE: launching {ngpus} ranks myself: {" ".join(cmd[1:8])} bench.py ...', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 if __name__ == '__main__':
     import faulthandler
     faulthandler.enable()                 # a SIGSEGV / SIGABRT inside a native call prints the Python stack of every thread: WHICH launch died
     # single-process runs are measured in a child process that is re-launched once if it is killed by a signal; under torch.distributed.run
-    # (one rank per GPU, rendezvous owned by the launcher) every rank measures in place
-    if os.environ.get('ALM_BENCH_CHILD') == '1' or int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('ALM_BENCH_SUPERVISE', '1') == '0':
+    # (one rank per GPU, rendezvous owned by the launcher) every rank measures in place; `--gpus N` typed without a launcher starts one itself
+    _world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    _want = _requested_gpus(sys.argv[1:])
+    if _want > 1 and _world_env == 1 and 'RANK' not in os.environ:
+        rc = _self_launch(_want)
+        sys.exit(rc if rc >= 0 else 128 - rc)
+    if os.environ.get('ALM_BENCH_CHILD') == '1' or _world_env > 1 or os.environ.get('ALM_BENCH_SUPERVISE', '1') == '0':
         main()
     else:
         rc = _supervised([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(os.environ, ALM_BENCH_CHILD='1'))

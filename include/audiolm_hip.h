@@ -262,6 +262,13 @@ int alm_embed_assemble(const float* const* tables, const int* table_rows, int nt
                        long long rows, int D, int* err_flag, void* stream);
 int alm_embed_scatter_add(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
                           float alpha, long long rows, int D, void* stream);
+/* the same scatter with ONE OWNER per destination row and fixed summation order: no atomics, bitwise run-to-run deterministic gradients (the
+ * reference's embedding backward, aten::embedding_dense_backward under audiolm_pytorch.py:709 / :901-918, is not; SURVEY section 5 asks for
+ * reproducible runs).  Every row of every table is WRITTEN (zero where no token maps to it): the gradient buffers need no clearing.
+ * ws: alm_embed_scatter_ws_floats(...) floats (chunk partials of the few-row tables).  rows < 2^28, D % 4 == 0. */
+int alm_embed_scatter_ws_floats(const int* table_rows, int ntables, long long rows, int D);
+int alm_embed_scatter_owned(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
+                            float alpha, long long rows, int D, float* ws, void* stream);
 int alm_gather_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
 int alm_scatter_rows_bf16(const void* in, long long ld_in, const int* idx, void* out, long long ld_out, long long rows, int D, void* stream);
 /* split-bf16 operands of the logit-head contraction (the heads read the fp32 final hidden states / fp32 master weights at ~16 mantissa bits:

@@ -141,6 +141,49 @@ def test_graph_replays_redraw_the_attention_dropout_masks(monkeypatch):
         assert float(w(**inputs, return_loss=True)) == float(w(**inputs, return_loss=True))
 
 
+def test_two_stack_forwards_in_one_capture_keep_their_own_dropout_masks(monkeypatch):
+    """ADVICE (round 4, medium): the mask-stream counter is ONE device int64 that every stack forward advances in place; the backward of the first of two
+    forwards inside one captured step (the same transformer called twice: in-capture gradient accumulation) therefore read the counter AFTER the second
+    forward had advanced it -- dQ / dK / dV with other keep masks than the forward.  Each call now carries its own snapshot of the counter.  Check: the
+    replay's loss and gradients equal an eager step whose two forwards are given, as host seeds, the two counter values the replay's forwards used."""
+    from audiolm_pytorch_amd import core
+    from audiolm_pytorch_amd.graphed import GraphedTrainStep
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = A.CoarseTransformer(dim=256, depth=3, num_semantic_tokens=100, codebook_size=64, num_coarse_quantizers=3, flash_attn=True, attn_dropout=0.25,
+                                residual_dtype=torch.bfloat16).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.)
+    w.train()
+
+    class Twice(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = w
+
+        def forward(self, **kw):
+            return self.w(**kw) + self.w(**kw)
+
+    twice = Twice()
+    g = torch.Generator().manual_seed(3)
+    inputs = dict(semantic_token_ids=torch.randint(0, 100, (4, 50), generator=g).to(dev), coarse_token_ids=torch.randint(0, 64, (4, 40, 3), generator=g).to(dev))
+    monkeypatch.setattr(core, '_dropout_keep', lambda shape, p, device: torch.ones(shape, dtype=torch.bfloat16, device=device))
+    step = GraphedTrainStep(twice, inputs, micro_batches=1)
+    counter = core.graph_seed_state(dev)
+    c0 = int(counter.item())
+    la = float(step(**inputs))
+    torch.cuda.synchronize()
+    depth = model.transformer.cfg.depth
+    assert int(counter.item()) - c0 == 4 * depth                    # two forwards per replay
+    ga = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    seeds = iter([c0 + 2 * depth, c0 + 4 * depth])                  # what the first / second forward of that replay read
+    monkeypatch.setattr(core, '_attn_seed', lambda: next(seeds))
+    le, ge = _eager(model, twice, inputs)
+    assert abs(le - la) <= 1e-6 * abs(la), (le, la)
+    bad = [(k, _frob(ga[k], ge[k])) for k in ge if _frob(ga[k], ge[k]) > 2e-3]
+    assert not bad, bad[:6]
+
+
 @pytest.mark.parametrize('groups', [2, 3])
 def test_eager_deferred_weight_gradient_groups_match_one_group_and_the_per_layer_path(monkeypatch, groups):
     """ADVICE (round 3): the eager ALM_DEFER_GROUPS > 1 path (the upper layer groups' batched weight-gradient launches forked to the side stream in the

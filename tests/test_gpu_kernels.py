@@ -734,6 +734,63 @@ def test_embed_scatter_large_and_small_tables(ops):
         assert torch.allclose(a.double(), b, atol=1e-4)
 
 
+def _scatter_ref(tables, src_a, src_b, dout, alpha):
+    refg = [torch.zeros_like(t, dtype=torch.float64) for t in tables]
+    for r in range(dout.shape[0]):
+        for c in (int(src_a[r]), int(src_b[r])):
+            if c >= 0 and (c >> 24) < len(refg) and (c & 0xffffff) < refg[c >> 24].shape[0]:
+                refg[c >> 24][c & 0xffffff] += alpha * dout[r].double()
+    return refg
+
+
+@pytest.mark.parametrize('D,rows,nbig', [(320, 300, 100), (1024, 1500, 301), (64, 5, 40), (2048, 700, 77)])
+def test_embed_scatter_owned_is_exact_deterministic_and_needs_no_zero_fill(ops, D, rows, nbig):
+    """alm_embed_scatter_owned (destination-owned, no atomics): equals the fp64 scatter, writes EVERY row (the buffers start as NaN garbage), two runs are
+    bit-identical.  Ragged chunks / column blocks / last row group (nbig % 8 != 0), out-of-range codes, a one-row table, D > 1024 (two column blocks)."""
+    big, small, one, big2 = rnd(nbig, D, seed=60), rnd(3, D, seed=61), rnd(1, D, seed=62), rnd(45, D, seed=65)
+    g = torch.Generator().manual_seed(63)
+    ia = torch.randint(-1, nbig, (rows,), generator=g)
+    ib = torch.randint(-1, 3, (rows,), generator=g)
+    src_a = torch.where(ia >= 0, ia, torch.full_like(ia, -1)).to(torch.int32)
+    src_b = torch.where(ib >= 0, ib + (1 << 24), torch.full_like(ib, -1)).to(torch.int32)
+    if rows > 8:
+        src_a[5] = 2 << 24                       # the one-row table
+        src_a[6] = nbig                          # out of range in the big table: skipped
+        src_b[7] = (1 << 24) | 3                 # out of range in the small table: skipped
+        src_b[8] = (3 << 24) | 44                # a second large table (45 rows), last row
+        src_a[3] = (3 << 24) | 44
+    src_a, src_b = src_a.to(dev()), src_b.to(dev())
+    dout = rnd(rows, D, seed=64)
+    tables = (big, small, one, big2)
+    outs = []
+    for _ in range(2):
+        grads = [torch.full_like(t, float('nan')) for t in tables]
+        ops.embed_scatter_owned(grads, src_a, src_b, dout, 0.5, rows, D)
+        outs.append(grads)
+    for a, b in zip(outs[0], _scatter_ref(tables, src_a.cpu(), src_b.cpu(), dout.cpu(), 0.5)):
+        assert bool(torch.isfinite(a).all())
+        assert torch.allclose(a.double().cpu(), b, atol=1e-4)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # and against the atomic form (same sums in another order)
+    grads = [torch.zeros_like(t) for t in tables]
+    ops.embed_scatter_add(grads, src_a, src_b, dout, 0.5, rows, D)
+    assert all(torch.allclose(a, b, atol=1e-4) for a, b in zip(outs[0], grads))
+
+
+def test_embed_scatter_owned_skewed_ids(ops):
+    """every token on ONE destination row (the pending list of the owning wave is flushed many times) and a table with more rows than tokens"""
+    D, rows = 256, 3000
+    big, small = rnd(5000, D, seed=70), rnd(2, D, seed=71)
+    src_a = torch.full((rows,), 4321, dtype=torch.int32, device=dev())
+    src_b = torch.full((rows,), (1 << 24) | 1, dtype=torch.int32, device=dev())
+    dout = rnd(rows, D, seed=72)
+    grads = [torch.full_like(big, float('nan')), torch.full_like(small, float('nan'))]
+    ops.embed_scatter_owned(grads, src_a, src_b, dout, 1.0, rows, D)
+    ref = dout.double().sum(0)
+    assert torch.allclose(grads[0][4321].double(), ref, atol=1e-3) and torch.allclose(grads[1][1].double(), ref, atol=1e-3)
+    assert float(grads[0].abs().sum() - grads[0][4321].abs().sum()) == 0 and float(grads[1][0].abs().max()) == 0
+
+
 def test_gather_scatter_rows(ops):
     x = rnd(50, 64, seed=55, dtype=BF16)
     idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32, device=dev())

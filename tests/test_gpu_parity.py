@@ -406,10 +406,39 @@ def test_default_ctor_full_size_properties(kind):
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
     assert all(float(g1[k].abs().max()) > 0 for k in bias_keys)
     assert l1 == l2
-    # embedding-table gradients are scatter-adds with fp32 atomics (like torch's embedding backward): reproducible to rounding only
-    exact = [k for k in g1 if 'embedding' not in k]
-    assert all(torch.equal(g1[k], g2[k]) for k in exact), [k for k in exact if not torch.equal(g1[k], g2[k])][:5]
-    assert all(_frob(g1[k], g2[k]) <= 1e-5 for k in g1 if 'embedding' in k)
+    # EVERY gradient is bit-reproducible since round 5: the embedding scatter is destination-owned (alm_embed_scatter_owned), no fp32 atomics are left
+    assert all(torch.equal(g1[k], g2[k]) for k in g1), [k for k in g1 if not torch.equal(g1[k], g2[k])][:5]
+
+
+def test_headline_step_is_bitwise_deterministic_forward_and_backward():
+    """SURVEY section 5 / VERDICT r4 (missing 6): two runs of the BENCHMARKED step (CoarseTransformer d=1024 depth=6, B=8 x N=2048, mask_prob=0.15, bf16
+    streams under autocast, deferred layer-batched weight gradients on the big tiles) give the same loss and `torch.equal` gradients for every
+    parameter -- split-K reductions, hyper-connection partials, attention dK/dV partials and the embedding scatter all sum in a fixed order."""
+    import audiolm_pytorch_amd as A
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = A.CoarseTransformer(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=False, mask_prob=0.15)
+    w.train()
+    g = torch.Generator().manual_seed(5)
+    kw = dict(semantic_token_ids=torch.randint(0, 500, (8, 509), generator=g).to(dev), coarse_token_ids=torch.randint(0, 1024, (8, 512, 3), generator=g).to(dev))
+
+    def run():
+        torch.manual_seed(1)                                   # same forgetful mask both times
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss = w(**kw, return_loss=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    l1, g1 = run()
+    l2, g2 = run()
+    l3, g3 = run()
+    assert l1 == l2 == l3
+    assert len(g1) > 100 and g1.keys() == g2.keys() == g3.keys()
+    bad = [k for k in g1 if not (torch.equal(g1[k], g2[k]) and torch.equal(g1[k], g3[k]))]
+    assert not bad, bad[:8]
 
 
 def test_fine_full_size_properties():
