@@ -102,81 +102,114 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(ScatterTabs tabs, co
 
 // ---- the same scatter WITHOUT atomics: every destination row has ONE owner, sums are formed in a fixed order -> bitwise run-to-run deterministic
 // gradients (the atomic form above adds in arrival order).  Two launches:
-//   (1) embed_scatter_small_kernel: the few-row tables as before (per 128-token chunk, summed in LDS in token order), but each chunk WRITES its
-//       sums to ws[chunk][small row][D] instead of adding them to the table;
+//   (1) embed_scatter_small_kernel: the few-row tables, per OWN_CH-token chunk, summed in LDS in token order; each chunk WRITES its sums to
+//       ws[chunk][small row][D];
 //   (2) embed_scatter_owned_kernel: workgroup g < ngroups OWNS OWN_G consecutive rows of one large table.  Each of its 4 waves owns a 256-column
 //       slice, scans the code arrays (src_a then src_b: 4 B per token and array, L2-resident, read by every workgroup) in token order, collects the
 //       tokens whose code falls in the group (ballot + prefix count: in-order compaction into a small per-wave pending list), and adds their dout
-//       slices to register accumulators in that order, 8 row loads in flight.  Workgroups g >= ngroups own one small-table row each and sum the
-//       chunk partials of (1) in chunk order.  Every row of every table is WRITTEN (zero when nothing maps to it): the caller need not clear them.
+//       slices to its accumulators in that order, 8 row loads in flight.  Workgroups g >= ngroups own one (small-table row, 256-column slice) each
+//       and sum the chunk partials of (1) in a fixed order.  Every row of every table is WRITTEN (zero when nothing maps to it): the caller need not clear them.
 // A code array is read once per owning workgroup (~450 x 128 KB from the L2 at the headline shape) -- cheaper than serialising 16 k fp32 atomics per
 // hot cache line, and there is no data-dependent sort on the host side.
 constexpr int OWN_G = 8;                 // destination rows per workgroup
-constexpr int OWN_PEND = 128;            // pending-list entries per wave (flushed at >= 64: a scan step adds at most 64)
+constexpr int OWN_PEND = 1024;           // pending-list entries per wave (flushed when fewer than one scan step's 512 slots are left)
 struct OwnTabs { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int small_base[MAX_TABLES]; int grp_base[MAX_TABLES + 1]; int n; int nsmall; int nchunks; };
 
+// chunk = OWN_CH token rows x 1024 columns per workgroup (thread = 4 columns).  The chunk's codes are fetched once into LDS (the first version read them
+// with two dependent scalar loads per token: a latency chain of 2 x 128 L2 round trips per workgroup, 91 us for 67 MB); the dout rows stream with 8
+// float4 loads per thread in flight; accumulators: one float4 per (small row, thread) in LDS, touched by their own thread only.
+constexpr int OWN_CH = 32;
 __global__ __launch_bounds__(256) void embed_scatter_small_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
                                                                   const float* __restrict__ dout, float alpha, long long rows, int D, float* __restrict__ ws) {
-    __shared__ float acc[SMALL_ROWS][256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char own_smem[];
+    int* codes = reinterpret_cast<int*>(own_smem);                          // [2][OWN_CH]: slot of the small row (>= 0) or -1
+    float4* acc = reinterpret_cast<float4*>(own_smem + 2 * OWN_CH * sizeof(int));   // [nsmall][256]
     const int t = threadIdx.x;
-    const int c = blockIdx.y * 256 + t;
-    const long long r0 = (long long)blockIdx.x * 128;
-    const int nr = (int)min(128LL, rows - r0);
-    for (int g = 0; g < tabs.nsmall; ++g) acc[g][t] = 0.f;
-    const bool cok = c < D;
+    const int col = blockIdx.y * 1024 + t * 4;
+    const bool cok = col < D;
+    const int colc = cok ? col : 0;
+    const long long r0 = (long long)blockIdx.x * OWN_CH;
+    const int nr = (int)min((long long)OWN_CH, rows - r0);
+    if (t < 2 * OWN_CH) {
+        const int k = t / OWN_CH, i = t % OWN_CH;
+        int slot = -1;
+        if (i < nr) {
+            const int code = (k == 0 ? src_a : src_b)[r0 + i];
+            if (code >= 0 && code_ok(tabs, code)) {
+                const int sb = tabs.small_base[code >> 24];
+                if (sb >= 0) slot = sb + (code & 0xffffff);
+            }
+        }
+        codes[t] = slot;
+    }
+    for (int g = 0; g < tabs.nsmall; ++g) acc[g * 256 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const float* dp = dout + r0 * D + colc;
+#pragma unroll 1
     for (int i0 = 0; i0 < nr; i0 += 8) {
-        float gv[8];
+        float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gv[u] = (cok && i0 + u < nr) ? dout[(r0 + i0 + u) * D + c] * alpha : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dp + (long long)min(i0 + u, nr - 1) * D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));      // all 8 in flight (see the owned kernel)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (i0 + u >= nr) break;
-            const long long r = r0 + i0 + u;
-            const int codes[2] = {src_a[r], src_b[r]};                   // wave-uniform
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int code = codes[k];
-                if (code < 0 || !code_ok(tabs, code)) continue;
-                const int sb = tabs.small_base[code >> 24];
-                if (sb >= 0) acc[sb + (code & 0xffffff)][t] += gv[u];   // a column belongs to one thread: plain read-modify-write, token order
+                const int slot = codes[k * OWN_CH + i0 + u];               // broadcast read, workgroup-uniform
+                if (slot < 0) continue;
+                float4 a = acc[slot * 256 + t];
+                a.x += v[u].x * alpha; a.y += v[u].y * alpha; a.z += v[u].z * alpha; a.w += v[u].w * alpha;
+                acc[slot * 256 + t] = a;
             }
         }
     }
     if (!cok) return;
-    for (int g = 0; g < tabs.nsmall; ++g) ws[((long long)blockIdx.x * tabs.nsmall + g) * D + c] = acc[g][t];
+    for (int g = 0; g < tabs.nsmall; ++g) *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * tabs.nsmall + g) * D + col) = acc[g * 256 + t];
 }
 
 __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
                                                                   const float* __restrict__ dout, float alpha, long long rows, int D,
                                                                   const float* __restrict__ ws, int ngroups) {
     __shared__ int pend[4][OWN_PEND];
+    __shared__ float4 accs[4][OWN_G][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = (blockIdx.y * 4 + wave) * 256 + lane * 4;
     const bool cok = col < D;                                              // D % 4 == 0: a lane's 4 columns are in or out together
+    const int colc = cok ? col : 0;
     const int g = blockIdx.x;
     if (g >= ngroups) {
-        // ---- one small-table row: chunk partials summed in chunk order
-        const int s = g - ngroups;
+        // ---- one small-table row x one 256-column slice: the 4 waves take every 4th chunk partial each (16 loads in flight), then their sums are
+        // combined in wave order -- a fixed association, like everything else here
+        const int s = (g - ngroups) >> 2, slice = (g - ngroups) & 3;
         int tb = 0;
         while (tb + 1 < tabs.n && !(tabs.small_base[tb] >= 0 && s >= tabs.small_base[tb] && s < tabs.small_base[tb] + tabs.rows[tb])) ++tb;
-        if (!cok) return;
+        const int scol = (blockIdx.y * 4 + slice) * 256 + lane * 4;
+        const bool sok = scol < D;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* wp = ws + (long long)s * D + col;
+        const float* wp = ws + (long long)s * D + (sok ? scol : 0);
         const long long cs = (long long)tabs.nsmall * D;
-        int ch = 0;
-        for (; ch + 8 <= tabs.nchunks; ch += 8) {
-            float4 v[8];
+        const int nch = tabs.nchunks;
+#pragma unroll 1
+        for (int ch = wave; ch < nch; ch += 64) {
+            float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(wp + (ch + u) * cs);
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(wp + (long long)min(ch + 4 * u, nch - 1) * cs);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+            for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (ch + 4 * u < nch) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        for (; ch < tabs.nchunks; ++ch) {
-            const float4 v = *reinterpret_cast<const float4*>(wp + ch * cs);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        accs[wave][0][lane] = a;
+        __syncthreads();
+        if (wave == 0 && sok) {
+            const float4 b1 = accs[1][0][lane], b2 = accs[2][0][lane], b3 = accs[3][0][lane];
+            a.x = ((a.x + b1.x) + b2.x) + b3.x; a.y = ((a.y + b1.y) + b2.y) + b3.y; a.z = ((a.z + b1.z) + b2.z) + b3.z; a.w = ((a.w + b1.w) + b2.w) + b3.w;
+            *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(s - tabs.small_base[tb]) * D + scol) = a;
         }
-        *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(s - tabs.small_base[tb]) * D + col) = a;
         return;
     }
     // ---- OWN_G rows of a large table
@@ -185,48 +218,79 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
     const int row0 = (g - tabs.grp_base[tb]) * OWN_G;
     const int nrow = min(OWN_G, tabs.rows[tb] - row0);
     const int code_lo = (tb << 24) | row0;
-    float4 acc[OWN_G];
+    // accumulators: one float4 per (destination row, lane) in LDS, a lane only ever touches its own slots (no conflicts, no barrier); register
+    // accumulators would need a select chain per (entry, row) -- 17 k lines of ISA in the first version, which ran out of the instruction cache
+    float4* myacc = &accs[wave][0][lane];
 #pragma unroll
-    for (int k = 0; k < OWN_G; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < OWN_G; ++k) myacc[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
     int* pl = pend[wave];
     int np = 0;                                                            // wave-uniform
     auto flush = [&]() {
+#pragma unroll 1
         for (int i0 = 0; i0 < np; i0 += 8) {
             float4 v[8];
             int d[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = i0 + u < np ? pl[i0 + u] : -1;               // broadcast LDS read: (local row << 28) | token row
-                d[u] = e < 0 ? -1 : (e >> 28) & 7;
+                const int e = pl[min(i0 + u, np - 1)];                     // broadcast LDS read: (local row << 28) | token row
+                d[u] = i0 + u < np ? (e >> 28) & 7 : -1;
                 const long long r = e & 0x0fffffff;
-                v[u] = (e >= 0 && cok) ? *reinterpret_cast<const float4*>(dout + r * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = *reinterpret_cast<const float4*>(dout + r * D + colc);   // unconditional: 8 row loads in flight (colc: clamped column)
             }
+            // pin the 8 loaded vectors here: without a use at this point the compiler sinks each load into "its" iteration of the loop below
+            // (load, s_waitcnt vmcnt(0), add -- one HBM round trip per entry)
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
-                for (int k = 0; k < OWN_G; ++k)
-                    if (d[u] == k) { acc[k].x += v[u].x * alpha; acc[k].y += v[u].y * alpha; acc[k].z += v[u].z * alpha; acc[k].w += v[u].w * alpha; }
+            for (int u = 0; u < 8; ++u) {
+                if (d[u] < 0) break;                                       // wave-uniform
+                float4 a = myacc[d[u] * 64];
+                a.x += v[u].x * alpha; a.y += v[u].y * alpha; a.z += v[u].z * alpha; a.w += v[u].w * alpha;
+                myacc[d[u] * 64] = a;
+            }
         }
         np = 0;
     };
-    const long long total = 2 * rows;
-    for (long long base = 0; base < total; base += 64) {
-        const long long i = base + lane;
-        int code = -1;
-        if (i < total) code = i < rows ? src_a[i] : src_b[i - rows];
-        const unsigned off = (unsigned)(code - code_lo);
-        const bool hit = code >= 0 && off < (unsigned)nrow;
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            const int pos = np + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (hit) pl[pos] = (int)((off << 28) | (unsigned)(i < rows ? i : i - rows));
-            np += __popcll(m);
-            if (np >= OWN_PEND - 64) flush();
+    // the scan: 8 coalesced dword loads per lane in flight (512 codes per step), the next step's loads issued before this step is processed.  The loads
+    // are UNCONDITIONAL (index clamped to the last row, validity applied to the value afterwards): a per-lane `i < rows ? load : -1` compiles to an
+    // exec-masked branch per load with a full s_waitcnt behind each (one L2 round trip per 64 codes: ~200 us for 32 k codes)
+    constexpr int SU = 8;
+    const int last = (int)rows - 1;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int* __restrict__ arr = pass == 0 ? src_a : src_b;
+        auto fetch = [&](int base, int (&c)[SU]) {
+#pragma unroll
+            for (int u = 0; u < SU; ++u) c[u] = arr[min(base + u * 64 + lane, last)];
+        };
+        int cur[SU], nxt[SU];
+        fetch(0, cur);
+#pragma unroll 1
+        for (int base = 0; base < (int)rows; base += SU * 64) {
+            fetch(base + SU * 64, nxt);                                    // past the end: the clamped last code, discarded below
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) any |= (unsigned)(cur[u] - code_lo) < (unsigned)nrow;    // (a negative code gives a huge unsigned offset)
+            if (__ballot(any)) {                                           // most steps hold no token of this group: one ballot instead of eight
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const unsigned off = (unsigned)(cur[u] - code_lo);
+                    const bool hit = i <= last && cur[u] >= 0 && off < (unsigned)nrow;
+                    const unsigned long long m = __ballot(hit);
+                    const int pos = np + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if (hit) pl[pos] = (int)((off << 28) | (unsigned)i);
+                    np += __popcll(m);
+                }
+            }
+            if (np >= OWN_PEND - SU * 64) flush();                         // a step adds at most SU * 64 entries
+#pragma unroll
+            for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
         }
     }
-    flush();
+    if (np > 0) flush();
     if (!cok) return;
-    for (int k = 0; k < nrow; ++k) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = acc[k];
+    for (int k = 0; k < nrow; ++k) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = myacc[k * 64];
 }
 
 // out[r] = in[idx[r]] (idx < 0 -> zero row)           bf16 rows, D % 8 == 0
@@ -594,7 +658,7 @@ static int own_tabs(OwnTabs& t, float* const* grad_tables, const int* table_rows
         else if (table_rows[i] > 0) ng += (table_rows[i] + OWN_G - 1) / OWN_G;
     }
     t.grp_base[ntables] = ng;
-    t.nchunks = (int)((rows + 127) / 128);
+    t.nchunks = (int)((rows + OWN_CH - 1) / OWN_CH);
     return 0;
 }
 
@@ -616,11 +680,19 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
     const int ngroups = t.grp_base[ntables];
     if (t.nsmall > 0 && t.nchunks > 0) {
         if (!ws) return ALM_ERR_BAD_ARG;
-        hipLaunchKernelGGL(embed_scatter_small_kernel, dim3((unsigned)t.nchunks, (unsigned)((D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, src_a, src_b,
-                           dout, alpha, rows, D, ws);
+        const size_t smem = 2 * OWN_CH * sizeof(int) + (size_t)t.nsmall * 256 * sizeof(float4);       // <= 256 B + 32 x 4 KB
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_scatter_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(2 * OWN_CH * sizeof(int) + SMALL_ROWS * 256 * sizeof(float4)));
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(embed_scatter_small_kernel, dim3((unsigned)t.nchunks, (unsigned)((D + 1023) / 1024)), dim3(256), smem, (hipStream_t)stream, t, src_a,
+                           src_b, dout, alpha, rows, D, ws);
     }
     if (ngroups + t.nsmall > 0)
-        hipLaunchKernelGGL(embed_scatter_owned_kernel, dim3((unsigned)(ngroups + t.nsmall), (unsigned)((D + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, t,
+        hipLaunchKernelGGL(embed_scatter_owned_kernel, dim3((unsigned)(ngroups + 4 * t.nsmall), (unsigned)((D + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, t,
                            src_a, src_b, dout, alpha, rows, D, (const float*)ws, ngroups);
     ALM_LAUNCH_CHECK();
     return 0;

@@ -35,7 +35,6 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int GROUP_M = 8;
 constexpr unsigned OOB = 0x80000000u;         // buffer offset beyond every num_records: the DMA returns zeros
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -60,7 +59,25 @@ struct GemmParams {
     int nsl;           // number of K slices (raster 1)
     int nbt = 0;       // total number of batched problems nb1 * nb2 (0: nb2 -- the one-level callers); raster 1 enumerates panels over all of them
     int plimit = 0;    // raster 1: > 0 = launch only the first `plimit` panels (alm_gemm_bf16_tn_batched: whole waves at full K, the tail separately)
+    int group_m = 8;   // raster 0: the logical grid is walked in groups of `group_m` tile rows (all tile columns of a group before the next group); an XCD
+                       // runs a contiguous chunk of that order, ~32 tiles at a time = group_m x (32 / group_m) tiles sharing A / B panels in its L2.
+                       // < 0: groups of |group_m| tile COLUMNS instead (the B panel is the resident one).  Chosen per launch by pick_group()
+    int nt_store = 0;  // 1: the C tile is written with non-temporal stores (does not displace the operand panels in the L2)
 };
+
+// logical block id -> (tile row, tile column): groups of g tile rows (g > 0) or of |g| tile columns (g < 0), the other dimension running fastest
+// within a group (see GemmParams::group_m)
+__device__ __forceinline__ int grouped_tile(int bid, int tiles_m, int tiles_n, int g) {     // -> tm | tn << 16
+    const bool rows = g > 0;
+    const int ga = rows ? g : -g;
+    const int t_in = rows ? tiles_n : tiles_m, t_gr = rows ? tiles_m : tiles_n;        // tiles along the fast / the grouped dimension
+    const int per_group = ga * t_in;
+    const int group = bid / per_group, rem = bid % per_group;
+    const int first = group * ga;
+    const int gsz = min(t_gr - first, ga);
+    const int a = first + rem % gsz, b = rem / gsz;                                       // a: grouped dimension, b: the other one
+    return rows ? (a | (b << 16)) : (b | (a << 16));
+}
 
 // ---- epilogue (shared by every GEMM kernel) --------------------------------------------------------------------------------------------
 // lane owns row gm of each 32-row block; register quad g holds columns n = 8*g + 4*lh + {0..3} of each 32-wide block.
@@ -114,7 +131,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #if defined(ALM_GEMM_WHATIF_NOSTORE)                                   // diagnostic build (scripts/gemm_probe.py nostore): WRONG results, timing only
                     if (gm < p.M && gn < p.N && val.x == 0x7fc12345u) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
 #else
-                    if (gm < p.M && gn < p.N) *reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES) = val;
+                    if (gm < p.M && gn < p.N) {
+                        uint4* dst = reinterpret_cast<uint4*>(Cb + ((long long)gm * p.ldc + gn) * ES);
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        if (p.nt_store) __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dst)); else *dst = val;
+                    }
 #endif
                 }
             }
@@ -208,12 +229,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     } else {
         const int nwg = tiles_m * tiles_n;
         const int bid = xcd_remap(blockIdx.x, nwg);
-        const int per_group = GROUP_M * tiles_n;
-        const int group = bid / per_group;
-        const int first_m = group * GROUP_M;
-        const int gsz = min(tiles_m - first_m, GROUP_M);
-        tm = first_m + (bid % per_group) % gsz;
-        tn = (bid % per_group) / gsz;
+        const int tt = grouped_tile(bid, tiles_m, tiles_n, p.group_m);
+        tm = tt & 0xffff;
+        tn = tt >> 16;
         zb = blockIdx.y;
         zs = blockIdx.z;
     }
@@ -442,12 +460,9 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     } else {
         const int nwg = tiles_m * tiles_n;
         const int bid = xcd_remap(blockIdx.x, nwg);
-        const int per_group = GROUP_M * tiles_n;
-        const int group = bid / per_group;
-        const int first_m = group * GROUP_M;
-        const int gsz = min(tiles_m - first_m, GROUP_M);
-        tm = first_m + (bid % per_group) % gsz;
-        tn = (bid % per_group) / gsz;
+        const int tt = grouped_tile(bid, tiles_m, tiles_n, p.group_m);
+        tm = tt & 0xffff;
+        tn = tt >> 16;
         zb = blockIdx.y;
         zs = blockIdx.z;
     }
@@ -697,12 +712,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
     } else {
         const int nwg = tiles_m * tiles_n;
         const int bid = xcd_remap(blockIdx.x, nwg);
-        const int per_group = GROUP_M * tiles_n;
-        const int group = bid / per_group;
-        const int first_m = group * GROUP_M;
-        const int gsz = min(tiles_m - first_m, GROUP_M);
-        tm = first_m + (bid % per_group) % gsz;
-        tn = (bid % per_group) / gsz;
+        const int tt = grouped_tile(bid, tiles_m, tiles_n, p.group_m);
+        tm = tt & 0xffff;
+        tn = tt >> 16;
         zb = blockIdx.y;
         zs = blockIdx.z;
     }
@@ -1074,6 +1086,84 @@ __global__ __launch_bounds__(256) void pack_weights_multi2_kernel(PackJobs2 pj) 
     }
 }
 
+// Round 5: the same pack as a wide stream -- 64 x 128 tiles again, but a thread fetches 8 consecutive columns of 4 rows (8 unconditional 16-byte loads in
+// flight: addresses clamped into the matrix, out-of-range values zeroed afterwards) and writes 16-byte vectors BOTH ways: 8 columns of a row to dst, and --
+// through an LDS image of column pairs -- 8 rows of a column to dstT (lane = row group within a column pair: 128 contiguous bytes per half ... see below).
+// The round-2 form above moved 8 / 4 / 4 bytes per lane behind per-element branches: 2.2-2.8 TB/s, 27-35 us per layer.  Up to PACK3_JOBS weights per
+// launch (all layers of the stack: one launch instead of six).  Needs: ld_dst, ld_dstT, rows_pad, cols_pad multiples of 8, 16-byte aligned dst / dstT,
+// 4-byte aligned src (any ld_src).
+constexpr int PACK3_JOBS = 40;
+struct PackJobs3 {
+    AlmPackJob job[PACK3_JOBS];
+    int tile_end[PACK3_JOBS];
+    int njobs;
+};
+static_assert(sizeof(PackJobs3) <= 3800, "kernel-argument segment");
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte load that only assumes dword alignment (ld_src = 2730: rows start 8-byte aligned)
+
+__global__ __launch_bounds__(256) void pack_weights_multi3_kernel(PackJobs3 pj) {
+    __shared__ uint32_t tile[64][65];                                       // [row][column pair]
+    int j = 0;
+    while (j + 1 < pj.njobs && (int)blockIdx.x >= pj.tile_end[j]) ++j;
+    const AlmPackJob q = pj.job[j];
+    const int local = blockIdx.x - (j ? pj.tile_end[j - 1] : 0);
+    const int tcols = (q.cols_pad + 127) / 128;
+    const int r0 = (local / tcols) * 64, c0 = (local % tcols) * 128;
+    const int t = threadIdx.x;
+    const int cg = t & 15, ri = t >> 4;                                     // column group (8 columns), row within a 16-row slab
+    const int c = c0 + cg * 8;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(q.dst);
+    bf16_t* dstT = reinterpret_cast<bf16_t*>(q.dstT);
+    f32x4u v[4][2];
+    const int cmax = q.cols >= 4 ? q.cols - 4 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = min(r0 + ri + 16 * k, q.rows - 1);
+        const float* sp = q.src + (long long)r * q.ld_src;
+        v[k][0] = *reinterpret_cast<const f32x4u*>(sp + min(c, cmax));
+        v[k][1] = *reinterpret_cast<const f32x4u*>(sp + min(c + 4, cmax));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = ri + 16 * k, r = r0 + i;
+        float e[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cb = c + 4 * h, cl = min(cb, cmax);                   // the vector was loaded at column cl <= cb: element x of column cb + x sits at x + cb - cl
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int col = cb + x, idx = col - cl;
+                float val = 0.f;
+                if (r < q.rows && col < q.cols) val = idx == 0 ? v[k][h].x : idx == 1 ? v[k][h].y : idx == 2 ? v[k][h].z : idx == 3 ? v[k][h].w : 0.f;
+                e[4 * h + x] = val;
+            }
+        }
+        const uint4 pk = make_uint4(pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7]));
+        tile[i][cg * 4 + 0] = pk.x; tile[i][cg * 4 + 1] = pk.y; tile[i][cg * 4 + 2] = pk.z; tile[i][cg * 4 + 3] = pk.w;
+        if (dst && r < q.rows_pad && c < q.cols_pad) *reinterpret_cast<uint4*>(dst + (long long)r * q.ld_dst + c) = pk;
+    }
+    if (!dstT) return;
+    __syncthreads();
+    // transposed image: a work item = (column pair cp, group of 8 source rows rg) -> two 16-byte stores (output rows 2 cp and 2 cp + 1, columns r0 + 8 rg ..).
+    // lane = rg + 8 * (cp % 8): the 8 row groups of an output row are 128 contiguous bytes; LDS word (8 rg + jj) * 65 + cp -> bank 8 rg + cp + jj: no conflict
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int w = it * 256 + t;
+        const int rg = w & 7, cp = w >> 3;                                  // 64 column pairs x 8 row groups
+        uint32_t a[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a[jj] = tile[rg * 8 + jj][cp];
+        const uint4 lo = make_uint4((a[0] & 0xffffu) | (a[1] << 16), (a[2] & 0xffffu) | (a[3] << 16), (a[4] & 0xffffu) | (a[5] << 16), (a[6] & 0xffffu) | (a[7] << 16));
+        const uint4 hi = make_uint4((a[0] >> 16) | (a[1] & 0xffff0000u), (a[2] >> 16) | (a[3] & 0xffff0000u), (a[4] >> 16) | (a[5] & 0xffff0000u),
+                                    (a[6] >> 16) | (a[7] & 0xffff0000u));
+        const int oc = c0 + 2 * cp, orow = r0 + 8 * rg;
+        if (orow < q.rows_pad) {
+            if (oc < q.cols_pad) *reinterpret_cast<uint4*>(dstT + (long long)oc * q.ld_dstT + orow) = lo;
+            if (oc + 1 < q.cols_pad) *reinterpret_cast<uint4*>(dstT + (long long)(oc + 1) * q.ld_dstT + orow) = hi;
+        }
+    }
+}
+
 // ---- launch plumbing ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
 int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
@@ -1157,11 +1247,25 @@ int pick_tile(int M, int N, int ny, int tile, bool tn) {
     return 13;
 }
 
+// Rasterisation group of a raster-0 launch (GemmParams::group_m).  An XCD's L2 (4 MiB) serves the ~32 tiles its CUs run at a time: with groups of g
+// tile rows those are g x (32 / g) tiles, and the group's A panel (g x BM rows x K) is what successive tile columns re-read -- it should FIT the L2
+// beside the streaming B tiles.  ALM_GEMM_GROUP_M=<g> (A/B runs) overrides; negative = groups of tile columns.
+int pick_group(const GemmParams& p, int tl) {
+    static const int env_g = [] { const char* e = getenv("ALM_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
+    if (env_g != 0) return env_g;
+    (void)p; (void)tl;
+    return 8;
+}
+
 template <bool TNMODE>
-int launch_gemm(const GemmParams& p, int ny, int nz, int out_f32, int tile, hipStream_t st, bool hook = true, bool only256 = false) {
+int launch_gemm(const GemmParams& p0, int ny, int nz, int out_f32, int tile, hipStream_t st, bool hook = true, bool only256 = false) {
     static const int big_tile = [] { const char* e = getenv("ALM_GEMM_BIG_TILE"); return e ? atoi(e) : 0; }();   // A/B hook: 2 / 11 / 13 for every big launch
+    static const int nt_store = [] { const char* e = getenv("ALM_GEMM_NT_STORE"); return e ? atoi(e) : 0; }();    // A/B hook: non-temporal C stores
+    GemmParams p = p0;
     int tl = pick_tile(p.M, p.N, ny * nz, tile, TNMODE);
     if (tl < 0) return ALM_ERR_UNSUPPORTED;
+    p.group_m = pick_group(p, tl);
+    p.nt_store = (nt_store == 1 || (nt_store == 2 && !out_f32)) ? 1 : 0;
     // only256: the caller's panel arithmetic (GemmParams.plimit and the tail offset of the hybrid weight-gradient plan) is in units of 256 x 256 tiles --
     // the hook may swap the 256 x 256 kernels for one another there, never re-tile the launch (a 384 x 256 grid would cover the wrong set of C tiles)
     if (hook && tl != 1 && (big_tile == 2 || big_tile == 13 || big_tile == 14 || (big_tile == 11 && !only256))) tl = big_tile;
@@ -1458,40 +1562,66 @@ extern "C" int alm_transpose_bf16_batched(const void* src, void* dst, int rows, 
     return 0;
 }
 
+static int pack3_launch(const AlmPackJob* jobs, int njobs, hipStream_t st) {
+    PackJobs3 pj{};                                  // 3 KB, by value: inside the 4 KB kernel-argument segment; indexed with a workgroup-uniform job number
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        pj.job[j] = jobs[j];
+        total += ((jobs[j].cols_pad + 127) / 128) * ((jobs[j].rows_pad + 63) / 64);
+        pj.tile_end[j] = total;
+    }
+    pj.njobs = njobs;
+    hipLaunchKernelGGL(pack_weights_multi3_kernel, dim3(total), dim3(256), 0, st, pj);
+    return 0;
+}
+
 extern "C" int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* stream) {
     if (njobs <= 0) return 0;
-    if (njobs > 8 || !jobs) return ALM_ERR_BAD_ARG;
-    bool vec = true;
+    if (!jobs) return ALM_ERR_BAD_ARG;
+    static const int wide_on = [] { const char* e = getenv("ALM_PACK_WIDE"); return e ? atoi(e) : 1; }();     // A/B switch: 0 = the round-2 kernels
+    bool vec = true, wide = wide_on != 0;
     for (int j = 0; j < njobs; ++j) {
         const AlmPackJob& q = jobs[j];
         if (q.rows <= 0 || q.cols <= 0 || q.rows_pad < q.rows || q.cols_pad < q.cols) return ALM_ERR_BAD_ARG;
         if ((q.dst && q.ld_dst < q.cols_pad) || (q.dstT && q.ld_dstT < q.rows_pad)) return ALM_ERR_BAD_ARG;
         vec = vec && !((q.ld_src | q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 1) && !((uintptr_t)q.src & 7) && !((uintptr_t)q.dst & 3) &&
               !((uintptr_t)q.dstT & 3);
+        wide = wide && !((q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 7) && !((uintptr_t)q.src & 3) && !((uintptr_t)q.dst & 15) && !((uintptr_t)q.dstT & 15);
     }
-    if (vec) {
-        PackJobs2 pj{};
-        int total = 0;
-        for (int j = 0; j < njobs; ++j) {
-            pj.job[j] = jobs[j];
-            total += ((jobs[j].cols_pad + 127) / 128) * ((jobs[j].rows_pad + 63) / 64);
-            pj.tile_end[j] = total;
+    hipStream_t st = (hipStream_t)stream;
+    if (wide) {
+        for (int j0 = 0; j0 < njobs; j0 += PACK3_JOBS) {
+            int rc = pack3_launch(jobs + j0, std::min(PACK3_JOBS, njobs - j0), st);
+            if (rc) return rc;
         }
-        pj.njobs = njobs;
-        hipLaunchKernelGGL(pack_weights_multi2_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pj);
         ALM_LAUNCH_CHECK();
         return 0;
     }
-    PackJobs pj{};
-    int total = 0;
-    for (int j = 0; j < njobs; ++j) {
-        const AlmPackJob& q = jobs[j];
-        pj.job[j] = q;
-        total += ((q.cols_pad + 63) / 64) * ((q.rows_pad + 63) / 64);
-        pj.tile_end[j] = total;
+    for (int j0 = 0; j0 < njobs; j0 += 8) {
+        const int nj = std::min(8, njobs - j0);
+        if (vec) {
+            PackJobs2 pj{};
+            int total = 0;
+            for (int j = 0; j < nj; ++j) {
+                pj.job[j] = jobs[j0 + j];
+                total += ((jobs[j0 + j].cols_pad + 127) / 128) * ((jobs[j0 + j].rows_pad + 63) / 64);
+                pj.tile_end[j] = total;
+            }
+            pj.njobs = nj;
+            hipLaunchKernelGGL(pack_weights_multi2_kernel, dim3(total), dim3(256), 0, st, pj);
+        } else {
+            PackJobs pj{};
+            int total = 0;
+            for (int j = 0; j < nj; ++j) {
+                const AlmPackJob& q = jobs[j0 + j];
+                pj.job[j] = q;
+                total += ((q.cols_pad + 63) / 64) * ((q.rows_pad + 63) / 64);
+                pj.tile_end[j] = total;
+            }
+            pj.njobs = nj;
+            hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total), dim3(256), 0, st, pj);
+        }
     }
-    pj.njobs = njobs;
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, pj);
     ALM_LAUNCH_CHECK();
     return 0;
 }

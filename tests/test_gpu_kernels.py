@@ -767,7 +767,7 @@ def test_embed_scatter_owned_is_exact_deterministic_and_needs_no_zero_fill(ops, 
         grads = [torch.full_like(t, float('nan')) for t in tables]
         ops.embed_scatter_owned(grads, src_a, src_b, dout, 0.5, rows, D)
         outs.append(grads)
-    for a, b in zip(outs[0], _scatter_ref(tables, src_a.cpu(), src_b.cpu(), dout.cpu(), 0.5)):
+    for a, b in zip(outs[0], _scatter_ref([t.cpu() for t in tables], src_a.cpu(), src_b.cpu(), dout.cpu(), 0.5)):
         assert bool(torch.isfinite(a).all())
         assert torch.allclose(a.double().cpu(), b, atol=1e-4)
     assert all(torch.equal(a, b) for a, b in zip(*outs))
