@@ -164,9 +164,9 @@ def _pack_w2(w, I, Ip):
     return W, WT
 
 
-def layer_weights(cache: WeightCache, l, branches, I, Ip):
-    """bf16 packed (W, W^T) pairs of one layer's dense weights -> {kind: {name: (W, WT)}}; when any master changed, ALL of the layer are re-packed
-    (one launch per 8 weights).  branches: _split_layer() of the layer's detached parameters."""
+def _layer_pack_plan(cache: WeightCache, l, branches, I, Ip):
+    """-> None when every packed weight of layer `l` is current, else (ws, vers, out, jobs, targets): the fresh (uninitialised) packed buffers of ALL of
+    the layer's dense weights and the pack jobs that fill them"""
     ws = []
     for kind, d, _ in branches:
         for name in ('wq', 'wkv', 'wo', 'w1', 'w2'):
@@ -174,44 +174,80 @@ def layer_weights(cache: WeightCache, l, branches, I, Ip):
                 ws.append(((kind, name), d[name]))
     vers = {k: (w.data_ptr(), tensor_version(w), tuple(w.shape)) for k, w in ws}
     hits = {k: cache.store.get((l,) + k) for k, _ in ws}
-    if not all(h is not None and h[0] == vers[k] for k, h in hits.items()):
-        out, jobs, targets = {}, [], {}
-        with torch.no_grad():
-            for k, w in ws:
-                w = w.detach()
-                if k[1] == 'w1':
-                    D = w.shape[1]
-                    W1 = torch.empty((2 * Ip, D), dtype=BF16, device=w.device)
-                    W1T = torch.empty((D, 2 * Ip), dtype=BF16, device=w.device)
-                    jobs.append((w[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
-                    jobs.append((w[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
-                    out[k] = (W1, W1T)
-                    targets[k] = [(0, I, D, W1[:Ip], W1T[:, :Ip], Ip, D), (I, w.shape[0] - I, D, W1[Ip:], W1T[:, Ip:], Ip, D)]
-                elif k[1] == 'w2':
-                    D = w.shape[0]
-                    W2 = torch.empty((D, Ip), dtype=BF16, device=w.device)
-                    W2T = torch.empty((Ip, D), dtype=BF16, device=w.device)
-                    jobs.append((w, W2, W2T, D, Ip))
-                    out[k] = (W2, W2T)
-                    targets[k] = [(0, D, w.shape[1], W2, W2T, D, Ip)]
-                else:
-                    rows, cols = w.shape
-                    rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
-                    W = torch.empty((rp, cp), dtype=BF16, device=w.device)
-                    WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
-                    jobs.append((w, W, WT, rp, cp))
-                    out[k] = (W[:rows], WT[:cols])
-                    targets[k] = [(0, rows, cols, W, WT, rp, cp)]
-            for j in range(0, len(jobs), 8):
-                ops.pack_weights_multi(jobs[j:j + 8])
-        for k, w in ws:
-            cache.store[(l,) + k] = (vers[k], out[k])
-            if FUSED_ADAM_PACK and w.is_contiguous():
-                _register_pack(w, vers[k], cache, (l,) + k, out[k], targets[k])
-        hits = {k: cache.store[(l,) + k] for k, _ in ws}
+    if all(h is not None and h[0] == vers[k] for k, h in hits.items()):
+        return None
+    out, jobs, targets = {}, [], {}
+    for k, w in ws:
+        w = w.detach()
+        if k[1] == 'w1':
+            D = w.shape[1]
+            W1 = torch.empty((2 * Ip, D), dtype=BF16, device=w.device)
+            W1T = torch.empty((D, 2 * Ip), dtype=BF16, device=w.device)
+            jobs.append((w[:I], W1[:Ip], W1T[:, :Ip], Ip, D))
+            jobs.append((w[I:], W1[Ip:], W1T[:, Ip:], Ip, D))
+            out[k] = (W1, W1T)
+            targets[k] = [(0, I, D, W1[:Ip], W1T[:, :Ip], Ip, D), (I, w.shape[0] - I, D, W1[Ip:], W1T[:, Ip:], Ip, D)]
+        elif k[1] == 'w2':
+            D = w.shape[0]
+            W2 = torch.empty((D, Ip), dtype=BF16, device=w.device)
+            W2T = torch.empty((Ip, D), dtype=BF16, device=w.device)
+            jobs.append((w, W2, W2T, D, Ip))
+            out[k] = (W2, W2T)
+            targets[k] = [(0, D, w.shape[1], W2, W2T, D, Ip)]
+        else:
+            rows, cols = w.shape
+            rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+            W = torch.empty((rp, cp), dtype=BF16, device=w.device)
+            WT = torch.empty((cp, rp), dtype=BF16, device=w.device)
+            jobs.append((w, W, WT, rp, cp))
+            out[k] = (W[:rows], WT[:cols])
+            targets[k] = [(0, rows, cols, W, WT, rp, cp)]
+    return ws, vers, out, jobs, targets
+
+
+def _commit_pack_plan(cache, l, plan):
+    ws, vers, out, _, targets = plan
+    for k, w in ws:
+        cache.store[(l,) + k] = (vers[k], out[k])
+        if FUSED_ADAM_PACK and w.is_contiguous():
+            _register_pack(w, vers[k], cache, (l,) + k, out[k], targets[k])
+
+
+# all stale layers of the stack packed by ONE launch at the top of the forward (round 5: alm_pack_weights_multi takes 40 jobs; six launches of 27-35 us
+# before).  ALM_PACK_ALL=0: layer by layer as the forward reaches them (A/B switch)
+PACK_ALL = os.environ.get('ALM_PACK_ALL', '1') != '0'
+
+
+def pack_stack_weights(cache: WeightCache, flat, cfg):
+    """re-pack the bf16 (W, W^T) images of every layer whose masters changed since they were last packed -- one launch for the whole stack"""
+    S, ppl = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend)
+    plans, jobs = [], []
+    with torch.no_grad():
+        for l in range(cfg.depth):
+            plan = _layer_pack_plan(cache, l, _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend), cfg.inner, cfg.inner_pad)
+            if plan is not None:
+                plans.append((l, plan))
+                jobs += plan[3]
+        if jobs:
+            ops.pack_weights_multi(jobs)
+    for l, plan in plans:
+        _commit_pack_plan(cache, l, plan)
+
+
+def layer_weights(cache: WeightCache, l, branches, I, Ip):
+    """bf16 packed (W, W^T) pairs of one layer's dense weights -> {kind: {name: (W, WT)}}; when any master changed, ALL of the layer are re-packed
+    (one launch).  branches: _split_layer() of the layer's detached parameters."""
+    with torch.no_grad():
+        plan = _layer_pack_plan(cache, l, branches, I, Ip)
+        if plan is not None:
+            ops.pack_weights_multi(plan[3])
+    if plan is not None:
+        _commit_pack_plan(cache, l, plan)
     res = {}
-    for (kind, name), h in hits.items():
-        res.setdefault(kind, {})[name] = h[1]
+    for kind, d, _ in branches:
+        for name in ('wq', 'wkv', 'wo', 'w1', 'w2'):
+            if name in d:
+                res.setdefault(kind, {})[name] = cache.store[(l, kind, name)][1]
     return res
 
 
@@ -464,6 +500,8 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     else:
         drop_seed = _attn_seed() if attn_dropout > 0. else 0
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
+    if PACK_ALL:
+        pack_stack_weights(cache, flat, cfg)
     for l in range(cfg.depth):
         branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
         LW = layer_weights(cache, l, branches, I, Ip)

@@ -1235,7 +1235,7 @@ int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
 // fewer rounds of 256 resident workgroups that it wins despite its 1.5x longer tile (measured per-tile cost ratio 1.41: W1 forward
 // 16384 x 5472: 6 rounds -> 4, +6 %; with N = 1024 it is 172 tiles on 256 CUs, -15 %).
 int pick_tile(int M, int N, int ny, int tile, bool tn) {
-    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14) return tile;
+    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14 || tile == 15) return tile;
     if (tile != 0) return -1;
     if (M < 256 || N < 256) return 1;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
@@ -1282,6 +1282,13 @@ int launch_gemm(const GemmParams& p0, int ny, int nz, int out_f32, int tile, hip
     if (TNMODE && hook && w4_tn_mink > 0 && tl == 13 && (p.ksplit > 0 ? p.ksplit : p.K) >= w4_tn_mink) tl = 14;
     if (tl == 14) return out_f32 ? launch_w4<TNMODE, true>(p, ny, nz, st) : launch_w4<TNMODE, false>(p, ny, nz, st);
     if (tl == 13) return out_f32 ? launch_stag<TNMODE, true>(p, ny, nz, st) : launch_stag<TNMODE, false>(p, ny, nz, st);
+    // tile 15 (round 5 experiment): 256 x 128, 8 waves as 4 x 2 (wave tile 64 x 64), one workgroup per CU -- for the N = 512 projections (Wq forward, dAO):
+    // 64 x 4 = 256 tiles = ONE round of the chip where the 128 x 128 tile runs 512 workgroups at twice the L2 -> LDS bytes per flop.
+    // ALM_GEMM_MID_TILE=1 routes the automatic small-tile choices with N >= 512 and >= 192 such tiles to it (NT only)
+    static const int mid_tile = [] { const char* e = getenv("ALM_GEMM_MID_TILE"); return e ? atoi(e) : 0; }();
+    if (!TNMODE && hook && mid_tile && tl == 1 && tile == 0 && p.ksplit == 0 && p.M >= 256 && p.N >= 512 &&
+        (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ny >= 192) tl = 15;
+    if (tl == 15) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);
@@ -1586,7 +1593,7 @@ extern "C" int alm_pack_weights_multi(const AlmPackJob* jobs, int njobs, void* s
         if ((q.dst && q.ld_dst < q.cols_pad) || (q.dstT && q.ld_dstT < q.rows_pad)) return ALM_ERR_BAD_ARG;
         vec = vec && !((q.ld_src | q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 1) && !((uintptr_t)q.src & 7) && !((uintptr_t)q.dst & 3) &&
               !((uintptr_t)q.dstT & 3);
-        wide = wide && !((q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 7) && !((uintptr_t)q.src & 3) && !((uintptr_t)q.dst & 15) && !((uintptr_t)q.dstT & 15);
+        wide = wide && q.cols >= 4 && !((q.ld_dst | q.ld_dstT | q.rows_pad | q.cols_pad) & 7) && !((uintptr_t)q.src & 3) && !((uintptr_t)q.dst & 15) && !((uintptr_t)q.dstT & 15);
     }
     hipStream_t st = (hipStream_t)stream;
     if (wide) {

@@ -149,7 +149,7 @@ def pack_weight(w, dst=None, dstT=None, rows_pad=None, cols_pad=None):
 
 
 def pack_weights_multi(jobs):
-    """jobs: list of (w fp32 [rows, cols] view, dst | None, dstT | None, rows_pad, cols_pad): up to 8 weights in one launch."""
+    """jobs: list of (w fp32 [rows, cols] view, dst | None, dstT | None, rows_pad, cols_pad): any number of weights, 40 per launch (8 on the narrow fallback kernels)."""
     arr = (_lib.AlmPackJob * len(jobs))()
     for i, (w, dst, dstT, rp, cp) in enumerate(jobs):
         _chk(w, F32)

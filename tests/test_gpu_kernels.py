@@ -54,7 +54,7 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
-@pytest.mark.parametrize('tile', [1, 2, 11, 13, 14])
+@pytest.mark.parametrize('tile', [1, 2, 11, 13, 14, 15])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192), (1536, 5472, 128), (4096, 2736, 192)])
 def test_gemm_nt_tile_configs(ops, M, N, K, tile):
     """every block-tile configuration of the product library (1 = 128x128x64 / 4 waves, 2 = 256x256x64 / 8 waves lock-step, 13 = 256x256x64
@@ -162,6 +162,25 @@ def test_pack_weights_multi(ops):
         assert torch.equal(d1, d2) and torch.equal(t1, t2)
     assert torch.equal(WT[:, :100], big[:100].to(BF16).t()) and torch.equal(WT[:, 104:204], big[100:].to(BF16).t())
     assert float(WT[:, 100:104].float().abs().max()) == 0.0
+
+
+def test_pack_weights_multi_many_jobs_one_call(ops):
+    """round 5: all layers of a stack in one alm_pack_weights_multi call (40 jobs per launch of the wide kernel: 45 jobs = two launches); shapes of the
+    real stack (dim 1024: Wq 512 x 1024, Wkv 128 x 1024, Wo 1024 x 512, the two W1 halves 2730 x 1024 into 2736-row slots, W2 1024 x 2730 into 2736 columns)
+    plus ragged ones; every image equals the single-weight kernel's, pad rows / columns are zero"""
+    shapes = [(512, 1024), (128, 1024), (1024, 512), (2730, 1024), (2730, 1024), (1024, 2730), (70, 130), (33, 129), (9, 4)] * 5
+    jobs, refs = [], []
+    for i, (rows, cols) in enumerate(shapes):
+        w = rnd(rows, cols, seed=300 + i)
+        rp, cp = (rows + 7) // 8 * 8, (cols + 7) // 8 * 8
+        d1, t1 = torch.full((rp, cp), 7.0, dtype=BF16, device=dev()), torch.full((cp, rp), 7.0, dtype=BF16, device=dev())
+        d2, t2 = torch.zeros_like(d1), torch.zeros_like(t1)
+        jobs.append((w, d1, t1, rp, cp))
+        ops.pack_weight(w, d2, t2, rows_pad=rp, cols_pad=cp)
+        refs.append((d2, t2))
+    ops.pack_weights_multi(jobs)
+    for (w, d1, t1, rp, cp), (d2, t2) in zip(jobs, refs):
+        assert torch.equal(d1, d2) and torch.equal(t1, t2), tuple(w.shape)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm / GEGLU
