@@ -143,6 +143,17 @@ def oracle_sample(kind, ctor, sd, streams, seed=0, n_sem=509, n_fr=512):
     return fn, params, dict(coarse_token_ids=c, fine_token_ids=f), mask, 2049
 
 
+def _port_ratio():
+    """oracle tokens/s over real-reference tokens/s measured back to back in the build container (profiles/r5_cpu_reference_vs_oracle.json, 4 streams)"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r5_cpu_reference_vs_oracle.json')) as fh:
+            d = json.load(fh)
+        r = next(x for x in d['runs'] if x['streams'] == 4)
+        return dict(ratio=r['oracle_over_reference'], source='profiles/r5_cpu_reference_vs_oracle.json (scripts/cpu_reference_time.py, build container, same cores)')
+    except Exception:
+        return None
+
+
 def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
     """Times the CPU oracle (fp32) on a bounded sample of the same architecture (B = 1, N = 2048 / 2049, fwd + bwd; 4 streams and 1 stream) and
     checks the HIP path's loss on EXACTLY that sample (same weights, ids and forgetful mask) against it."""
@@ -167,7 +178,11 @@ def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
         if time.time() - t_start > max_seconds:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
+    # kind "port": /root/reference cannot travel to the GPU box.  scripts/cpu_reference_time.py (build container) times the REAL shimmed reference and this
+    # oracle back to back on the same cores: profiles/r5_cpu_reference_vs_oracle.json -- the oracle runs the 4-stream step 1.06x as fast as the reference
+    # (identical loss bits), the 1-stream step 0.76x
     out['cpu_baseline'] = dict(value=round(Ns / best, 1), unit='audio-tokens/s', cores=cores, kind='port',
+                               port_over_reference=_port_ratio(),
                                sample=f'oracle (CPU fp32 restatement of the reference, 4 residual streams) fwd+bwd, B=1 x N={Ns}, best of {max(1, len(times) - 1)} after 1 warm-up')
     del params
     # the HIP path on the same sample
@@ -180,6 +195,11 @@ def cpu_baseline_and_parity(W, dev, max_seconds=30.0):
         AP.generate_mask_with_prob = orig
     rel = abs(lh - loss4) / abs(loss4)
     out['parity'] = dict(loss_hip=round(lh, 6), loss_oracle=round(loss4, 6), rel=float(f'{rel:.3e}'), bound=1e-3, ok=bool(rel <= 1e-3), sample_N=Ns,
+                         # the bounds the test suite ENFORCES (north_star's "<= 1e-3 for bf16 tensors" holds op by op, not for end-to-end logits of a
+                         # 6-layer bf16 stack: DESIGN section 5): what is asserted where
+                         enforced_bounds=dict(loss_end_to_end=1e-3, opwise_forward=1e-3, opwise_backward_bf16_streams=4e-3,
+                                              logits_end_to_end="<= the reference's own bf16-autocast deviation on the same inputs (0.9-4.7e-2)",
+                                              token_id_bookkeeping='bit-exact', tests='tests/test_gpu_fullsize.py, test_gpu_opwise.py, test_gpu_opwise_model.py, test_host_logic.py'),
                          sample=f'same weights / ids / forgetful mask as the cpu_baseline sample (B=1, N={Ns}' +
                                 ('' if Ns == W['N'] else f'; the timed configuration runs N={W["N"]}: the flash kernels at that length are covered by '
                                                          f'tests/test_gpu_kernels.py::test_mqa_attention_long_sequences_vs_chunked_fp64') + ')')
