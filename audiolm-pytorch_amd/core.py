@@ -638,6 +638,8 @@ DP_DEFER_GROUPS = max(0, int(os.environ.get('ALM_DP_DEFER_GROUPS', '2')))
 # deferred mode: the hyper-connection parameter gradients of all branches of a layer group finished together in two launches (ops.hc_param_grads_batched)
 # instead of two small launches behind every hc_bwd (A/B switch)
 HC_BATCH_FINISH = os.environ.get('ALM_HC_BATCH_FINISH', '1') != '0'
+# with several layer groups: the small weight kinds (dWq / dWkv / dWo) of ALL layers in one batched launch each, together with the last group (see stack_backward)
+DEFER_SMALL_LATE = os.environ.get('ALM_DEFER_SMALL_LATE', '1') != '0'
 # Inside a hipGraph capture ALWAYS one group (see stack_backward): more than one corrupts the replays on ROCm 7.2, not root-caused.  The reproducer
 # (scripts/debug/graph_defer_groups.py) sets core._DEBUG_DEFER_GROUPS_CAPTURE itself; there is deliberately no environment switch for it.
 _DEBUG_DEFER_GROUPS_CAPTURE = 1
@@ -746,31 +748,67 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         ngroups = min(ngroups, L)
         gsz = (L + ngroups - 1) // ngroups
         on_group = getattr(on_layer_grads, 'on_group', None)                   # parallel.DataParallelEngine: one bucket per layer GROUP
-        wg = dict(dW1=_empty((L, 2, I, D), F32, dev), dW2=_empty((L, 1, D, I), F32, dev), dWo=_empty((L, 1, D, H * dh), F32, dev),
-                  dWq=_empty((L, 1, H * dh, D), F32, dev), dWkv=_empty((L, 1, 2 * dh, D), F32, dev))
+        group_buffer = getattr(on_layer_grads, 'group_buffer', None)           # ... whose flat bucket the weight-gradient GEMMs write straight into
+        wg = True
+        wshape = dict(dW1=(2, I, D), dW2=(1, D, I), dWo=(1, D, H * dh), dWq=(1, H * dh, D), dWkv=(1, 2 * dh, D))
+        hc_n_ = 7 if S > 1 else 0
+        wslot = dict(dWq=hc_n_ + 1, dWkv=hc_n_ + 2, dWo=hc_n_ + 3, dW1=(hc_n_ + 4) + hc_n_ + 1, dW2=(hc_n_ + 4) + hc_n_ + 3)   # index of the weight within a layer's flat parameters
+
+        # With more than one group the SMALL weight kinds (dWq, dWkv, dWo: 9 % of a layer's gradient bytes) still run once, for all layers, with the last
+        # group: cut into groups their few tiles fall back to inefficient split-K plans (measured at N = 1: 2 groups +0.45 ms/step, 3 groups +0.72, almost
+        # all of it these three kinds); only dW1 / dW2 (91 % of the bytes: what the early all-reduce is for) follow the groups.  ALM_DEFER_SMALL_LATE=0: A/B
+        big_kinds, small_kinds = ('dW1', 'dW2'), ('dWo', 'dWq', 'dWkv')
+        late = DEFER_SMALL_LATE and ngroups > 1
+        handed = set()                                                         # indices into `grads` already handed to the gradient hook
+
+        def group_outputs(l0, l1, kinds, late_kinds):
+            """fp32 outputs of the group's batched weight-gradient launches, per weight kind ([l1 - l0, ...]; `late_kinds`: [L, ...], all layers): views into
+            the data-parallel engine's persistent flat bucket of this group when it offers one (the all-reduce then runs in place: no bucket copy, no copy
+            back), else fresh"""
+            views = None
+            if group_buffer is not None:
+                views = group_buffer(l0, l1, [wslot[k] for k in kinds], [wslot[k] for k in late_kinds],
+                                     [wslot[k] for k in small_kinds] if (late and not late_kinds) else [])
+            if views is not None:
+                return {k: v.view(-1, *wshape[k]) for k, v in zip(tuple(kinds) + tuple(late_kinds), views)}
+            out = {k: _empty((l1 - l0,) + wshape[k], F32, dev) for k in kinds}
+            out.update({k: _empty((L,) + wshape[k], F32, dev) for k in late_kinds})
+            return out
 
         def launch_group(l0):
             l1 = min(L, l0 + gsz)
-            jobs = [(bst['dU'][l0:l1].view(l1 - l0, M, 2, Ip).permute(0, 2, 1, 3)[..., :I], stk['XNff'][l0:l1].unsqueeze(1), wg['dW1'][l0:l1]),   # dW1 = dU^T @ XN (x | gate)
-                    (bst['dYff'][l0:l1].unsqueeze(1), stk['HN'][l0:l1][..., :I].unsqueeze(1), wg['dW2'][l0:l1]),                                  # dW2 = dY^T @ HN
-                    (bst['dYat'][l0:l1].unsqueeze(1), stk['AO'][l0:l1].unsqueeze(1), wg['dWo'][l0:l1]),                                           # dWo = dY^T @ AO
-                    (bst['dQ'][l0:l1].unsqueeze(1), stk['XNat'][l0:l1].unsqueeze(1), wg['dWq'][l0:l1]),                                           # dWq = dQ^T @ XN
-                    (bst['dKV'][l0:l1].unsqueeze(1), stk['Xat'][l0:l1].unsqueeze(1), wg['dWkv'][l0:l1])]                                          # dWkv = dKV^T @ X
+            last = l0 == 0                                                     # the groups are launched from the top of the stack down
+            kinds = big_kinds if late else big_kinds + small_kinds
+            late_kinds = small_kinds if (late and last) else ()
+            wgg = group_outputs(l0, l1, kinds, late_kinds)
+            operands = dict(dW1=lambda a, b: (bst['dU'][a:b].view(b - a, M, 2, Ip).permute(0, 2, 1, 3)[..., :I], stk['XNff'][a:b].unsqueeze(1)),   # dW1 = dU^T @ XN (x | gate)
+                            dW2=lambda a, b: (bst['dYff'][a:b].unsqueeze(1), stk['HN'][a:b][..., :I].unsqueeze(1)),                                # dW2 = dY^T @ HN
+                            dWo=lambda a, b: (bst['dYat'][a:b].unsqueeze(1), stk['AO'][a:b].unsqueeze(1)),                                         # dWo = dY^T @ AO
+                            dWq=lambda a, b: (bst['dQ'][a:b].unsqueeze(1), stk['XNat'][a:b].unsqueeze(1)),                                         # dWq = dQ^T @ XN
+                            dWkv=lambda a, b: (bst['dKV'][a:b].unsqueeze(1), stk['Xat'][a:b].unsqueeze(1)))                                        # dWkv = dKV^T @ X
+            jobs = [operands[k](l0, l1) + (wgg[k],) for k in kinds] + [operands[k](0, L) + (wgg[k],) for k in late_kinds]
             for At, Bt, C in jobs:
                 if ngroups > 1 or on_layer_grads is not None:  # (with a gradient hook even a single group goes to the side stream: its bucket follows it there)
                     side.run(lambda At=At, Bt=Bt, C=C: ops.gemm_tn_batched(At, Bt, C), At, Bt, C)
                 else:                                          # one group at the end: nothing left to run beside it -- the main stream, no fork / join
                     ops.gemm_tn_batched(At, Bt, C)             # (interleaved A/B: 13.11 -> 12.97 ms/step)
-            hc_n = 7 if S > 1 else 0
-            for l in range(l0, l1):
-                fa, ff_ = l * ppl + hc_n, l * ppl + (hc_n + 4) + hc_n           # first non-hyper-connection parameter of the attention / feed-forward branch
-                grads[fa + 1], grads[fa + 2], grads[fa + 3] = wg['dWq'][l, 0], wg['dWkv'][l, 0], wg['dWo'][l, 0]
-                grads[ff_ + 1], grads[ff_ + 3] = wg['dW1'][l].view(2 * I, D), wg['dW2'][l, 0]
+            for k in kinds:
+                for l in range(l0, l1):
+                    g_ = wgg[k][l - l0]
+                    grads[l * ppl + wslot[k]] = g_.view(2 * I, D) if k == 'dW1' else g_[0]
+            for k in late_kinds:
+                for l in range(L):
+                    grads[l * ppl + wslot[k]] = wgg[k][l, 0]
             if on_layer_grads is not None:
                 # the gradient hand-off of the GROUP, ordered after its weight-gradient launches ON THE SIDE STREAM (the critical path never waits):
-                # one call for the whole group when the hook takes groups (one bucket, one collective), else layer by layer in backward order
-                layers = list(range(l1 - 1, l0 - 1, -1))
-                per_layer = [grads[l * ppl:(l + 1) * ppl] for l in layers]
+                # one call for the whole group when the hook takes groups (one bucket, one collective), else layer by layer in backward order.
+                # Every gradient is handed over exactly once: with the small kinds late, the last call also carries those of the earlier layers.
+                layers = list(range((L if late_kinds else l1) - 1, l0 - 1, -1))
+                per_layer = []
+                for l in layers:
+                    gl = [g if (l * ppl + j) not in handed else None for j, g in enumerate(grads[l * ppl:(l + 1) * ppl])]
+                    handed.update(l * ppl + j for j, g in enumerate(gl) if g is not None)
+                    per_layer.append(gl)
                 live = [g for gl in per_layer for g in gl if g is not None]
                 if on_group is not None:
                     side.run_after_all(lambda: on_group(layers, per_layer), *live)

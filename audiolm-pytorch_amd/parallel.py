@@ -36,16 +36,17 @@ Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the
 from __future__ import annotations
 
 import contextlib
+import os
 import time
 
 import torch
 
 
 class _Bucket:
-    __slots__ = ('params', 'grads', 'flat', 'work')
+    __slots__ = ('params', 'grads', 'flat', 'work', 'direct')
 
     def __init__(self):
-        self.params, self.grads, self.flat, self.work = [], [], None, None
+        self.params, self.grads, self.flat, self.work, self.direct = [], [], None, None, None
 
 
 class DataParallelEngine:
@@ -63,6 +64,10 @@ class DataParallelEngine:
                 for p in self.params:
                     dist.broadcast(p.data, src=0, group=process_group)
         self._flat_cache = {}
+        self._flat_groups = {}                # (l0, l1) -> (flat fp32 buffer, {id(param): (offset, numel)}): see group_buffer()
+        self.direct_buckets = os.environ.get('ALM_DP_DIRECT', '1') != '0'     # A/B switch: 0 = every bucket staged through torch.cat + copied back
+        self._ev_bw_done = self._ev_all_done = None
+        self._pending_flat = None
         self._inflight = []
         self._loose = _Bucket()               # parameters outside the fused stack (heads first, embeddings last)
         self._stack_param_ids = set()
@@ -138,6 +143,52 @@ class DataParallelEngine:
 
     __call__ = _on_layer_grads
 
+    def group_buffer(self, l0, l1, dense_slots, late_slots=(), skip_slots=()):
+        """core.stack_backward (deferred mode) asks, right before it launches the batched weight-gradient GEMMs of layers [l0, l1): where should they
+        write?  `dense_slots`: per weight kind computed for THESE layers, the index of that weight within a layer's flat parameter list; `late_slots`:
+        kinds computed with this (the last) group for ALL layers of the stack; `skip_slots`: kinds of these layers that are NOT part of this group's
+        bucket (they follow with the last group).  -> per kind (dense, then late) one fp32 view [layers, *weight.shape] into this group's PERSISTENT
+        flat bucket, or None.  With the views the GEMMs produce the bucket in place: `on_group` only adds the group's few small gradients
+        (hyper-connection parameters, norm gains) to the tail and all-reduces the flat buffer, `finish()` hands out views as `.grad` -- no torch.cat
+        staging pass and no copy back (2 x 262 MB of HBM traffic per step at dim 1024 depth 6).  Only for the overlapped fp32 path: while gradients
+        accumulate (no_sync / stale .grad) a `.grad` may alias the bucket the next backward would overwrite -> None, the staged path runs."""
+        self._begin_backward()
+        self._pending_flat = None
+        if not (self.direct_buckets and self.bucket_dtype == torch.float32 and self._overlapped() and (self.world > 1 or self.force)):
+            return None
+        L, ppl = self._stack.depth, self._ppl
+        dense = [[self._stack_flat[l * ppl + slot] for l in range(l0, l1)] for slot in dense_slots]      # (the engine's own parameter objects)
+        dense += [[self._stack_flat[l * ppl + slot] for l in range(L)] for slot in late_slots]
+        key = (l0, l1, tuple(dense_slots), tuple(late_slots), tuple(skip_slots))
+        ent = self._flat_groups.get(key)
+        dev = dense[0][0].device
+        if ent is None or ent[0].device != dev:
+            offs, o = {}, 0
+            for plist in dense:                                   # dense kinds first, each kind's layers contiguous: one stacked GEMM output per kind
+                for p in plist:
+                    offs[id(p)] = (o, p.numel())
+                    o += p.numel()
+                o = (o + 3) // 4 * 4                              # 16-byte aligned starts (the GEMM epilogues store 16-byte vectors)
+            skip = {id(self._stack_flat[layer * ppl + slot]) for layer in range(l0, l1) for slot in skip_slots}
+            for layer in range(l0, l1):                           # then every other trainable parameter of the group's layers
+                for p in self._stack_flat[layer * ppl:(layer + 1) * ppl]:
+                    if p.requires_grad and id(p) not in offs and id(p) not in skip:
+                        offs[id(p)] = (o, p.numel())
+                        o += p.numel()
+            ent = (torch.empty(o, dtype=torch.float32, device=dev), offs)
+            self._flat_groups = {k: v for k, v in self._flat_groups.items() if k[:2] != (l0, l1)}        # one layout per layer range
+            self._flat_groups[key] = ent
+        flat, offs = ent
+        views = []
+        for plist in dense:
+            o0 = offs[id(plist[0])][0]
+            n = plist[0].numel()
+            if any(offs[id(p)] != (o0 + i * n, n) or not p.requires_grad or p.shape != plist[0].shape for i, p in enumerate(plist)):
+                return None                                       # (a frozen dense weight in the group: staged path)
+            views.append(flat[o0:o0 + n * len(plist)].view(len(plist), *plist[0].shape))
+        self._pending_flat = ent                                  # the on_group() call that follows is this group's
+        return views
+
     def on_group(self, layers, grads_per_layer):
         """core.stack_backward callback of the deferred (layer-batched) weight-gradient mode: the fresh gradients of a GROUP of layers, `layers` in
         backward order -- one bucket, one collective for the whole group."""
@@ -151,7 +202,35 @@ class DataParallelEngine:
                 if g is not None and p.requires_grad:
                     params.append(p)
                     grads.append(g)
+        ent, self._pending_flat = self._pending_flat, None
+        if ent is not None and params and (self.world > 1 or self.force):
+            flat, offs = ent
+            base, esz = flat.data_ptr(), flat.element_size()
+            inplace = [id(p) in offs and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == base + offs[id(p)][0] * esz for p, g in zip(params, grads)]
+            covered = sum(offs[id(p)][1] for p in params if id(p) in offs)
+            if any(inplace) and all(id(p) in offs for p in params) and covered == sum(n for _, n in offs.values()):
+                # the dense gradients already sit in the bucket (written there by the GEMMs); the rest is a handful of small tensors: one fused copy
+                rest = [(flat[offs[id(p)][0]:offs[id(p)][0] + offs[id(p)][1]].view(g.shape), g) for p, g, here in zip(params, grads, inplace) if not here]
+                if rest:
+                    torch._foreach_copy_([d for d, _ in rest], [g for _, g in rest])
+                self._launch_flat(flat, params, [tuple(g.shape) for g in grads], direct={id(p): offs[id(p)] for p in params})
+                return
         self._launch(('group', layers[0], len(layers)), params, grads)
+
+    def _launch_flat(self, flat, params, shapes, direct):
+        op = self.dist.ReduceOp.AVG if self._avg_ok else self.dist.ReduceOp.SUM
+        work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
+        self.stats['buckets'] += 1
+        self.stats['bytes'] += flat.numel() * flat.element_size()
+        self.stats['direct_buckets'] = self.stats.get('direct_buckets', 0) + 1
+        if flat.is_cuda:
+            sid = int(torch.cuda.current_stream(flat.device).cuda_stream)
+            if sid not in self.stats['launch_streams']:
+                self.stats['launch_streams'].append(sid)
+        self._t_last_launch = time.perf_counter()
+        b = _Bucket()
+        b.params, b.flat, b.work, b.grads, b.direct = list(params), flat, work, list(shapes), direct
+        self._inflight.append((b, op))
 
     def _on_loose_grad(self, p):
         self._begin_backward(skip=p)
@@ -185,10 +264,22 @@ class DataParallelEngine:
                 ps = [p for p in params if p.requires_grad and p.grad is not None]
                 self._launch(tuple(key), ps, [p.grad for p in ps])
         self._flush_loose(('loose', 'post'))
+        cuda = bool(self._inflight) and self._inflight[0][0].flat.is_cuda
+        if cuda:
+            # exposed tail on the GPU clock: from "backward's own kernels are done" (everything queued on the current stream so far) to "every bucket is
+            # reduced and handed out"; read lazily in `last_stats` (an event query needs a sync: never inside the step)
+            self._ev_bw_done = torch.cuda.Event(enable_timing=True)
+            self._ev_all_done = torch.cuda.Event(enable_timing=True)
+            self._ev_bw_done.record()
         for b, op in self._inflight:
             b.work.wait()
             if op == self.dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
+            if b.direct is not None:                                   # in-place bucket: the reduced gradients ARE the bucket -- hand out views
+                for p, shape in zip(b.params, b.grads):
+                    o, n = b.direct[id(p)]
+                    p.grad = b.flat[o:o + n].view(shape)
+                continue
             views, o = [], 0
             for p, shape in zip(b.params, b.grads):
                 n = 1
@@ -202,11 +293,21 @@ class DataParallelEngine:
             for p, v in zip(b.params, views):
                 if p.grad is None:
                     p.grad = v.to(p.dtype, copy=True)                  # a bf16 bucket must not become the .grad of an fp32 parameter
+        if cuda:
+            self._ev_all_done.record()
         if self._inflight and self._t_last_launch is not None:
             self.last_stats = dict(self.stats, tail_ms=round((time.perf_counter() - self._t_last_launch) * 1e3, 3))
         self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[])
         self._t_last_launch = None
         self._inflight = []
+
+    def exposed_tail_ms(self):
+        """GPU time of the last synchronising step between the end of backward's own work and the last bucket being reduced and handed out -- the part
+        of the gradient exchange that did NOT hide under backward.  Synchronises on the recorded events: call outside the timed region."""
+        if self._ev_bw_done is None or self._ev_all_done is None:
+            return None
+        self._ev_all_done.synchronize()
+        return round(self._ev_bw_done.elapsed_time(self._ev_all_done), 3)
 
     def remove(self):
         for h in self._hooks:

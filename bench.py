@@ -433,8 +433,11 @@ def main():
         # one line per rank on stderr, so that a driver SCALE run is diagnosable from its tail: what went on the wire and how much of the exchange
         # did NOT hide under backward (host time from the launch of the last bucket to the return of finish())
         dp_stats = dict(engine.last_stats or {}, bucket_dtype=str(bucket_dtype).replace('torch.', ''), ms_per_step=round(ms, 3))
+        # GPU-clock time of the LAST step between "backward's own kernels done" and "every bucket reduced and handed out": the part of the gradient
+        # exchange that did not hide under backward (events recorded in finish(); read here, outside the timed region)
+        dp_stats['exposed_tail_ms'] = engine.exposed_tail_ms()
         print(f'[bench rank {rank}/{world}] dp: {dp_stats["buckets"]} buckets, {dp_stats["bytes"] / 1e6:.1f} MB/step on the wire ({dp_stats["bucket_dtype"]}), '
-              f'tail after the last bucket launch {dp_stats["tail_ms"]} ms, step {ms:.3f} ms, collectives issued from a side stream: '
+              f'{dp_stats.get("direct_buckets", 0)} of them reduced in place, exposed tail {dp_stats["exposed_tail_ms"]} ms on the GPU clock (host: {dp_stats["tail_ms"]} ms after the last bucket launch), step {ms:.3f} ms, collectives issued from a side stream: '
               f'{any(sid != int(torch.cuda.current_stream(dev).cuda_stream) for sid in dp_stats.get("launch_streams", []))}', file=sys.stderr, flush=True)
 
     # host time to ISSUE one step (no synchronisation inside): eager launches vs one graph replay

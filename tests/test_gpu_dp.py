@@ -63,6 +63,8 @@ def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     eng.finish()
     torch.cuda.synchronize()
     nbuckets = eng.last_stats['buckets']
+    ndirect = eng.last_stats.get('direct_buckets', 0)
+    aliased = sum(1 for p in model.parameters() if p.grad is not None and any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f, _ in eng._flat_groups.values()))
     g1 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     # second synchronising backward WITHOUT clearing the gradients: DDP semantics = previous (already averaged) + mean of the new shares
     loss2 = w(semantic_token_ids=sem[sl].flip(0).to(dev), coarse_token_ids=coarse[sl].flip(0).to(dev), return_loss=True)
@@ -71,7 +73,7 @@ def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     torch.cuda.synchronize()
     g2 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     if rank == 0:
-        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss), buckets=nbuckets), out)
+        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss), buckets=nbuckets, direct=ndirect, aliased=aliased), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,7 +83,7 @@ def _frob(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize('bucket_dtype,dp_groups', [('float32', 2), ('bfloat16', 2), ('float32', 1), ('float32', 0)])
+@pytest.mark.parametrize('bucket_dtype,dp_groups', [('float32', 2), ('bfloat16', 2), ('float32', 1), ('float32', 0), ('float32', 3)])
 def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype, dp_groups):
     """dp_groups: layer groups of the deferred weight gradients in the data-parallel step (2 = default: groups {2}, {0, 1} of this depth-3 model, one
     bucket each; 1 = everything at the end; 0 = the per-layer path of rounds 1-3) -- all must give the big-batch gradients"""
@@ -91,6 +93,9 @@ def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype, dp_groups):
     mp.spawn(_worker, args=(2, port, out, bucket_dtype, dp_groups), nprocs=2, join=True)
     r = torch.load(out, weights_only=False)
     assert r['buckets'] == (CTOR['depth'] if dp_groups == 0 else dp_groups) + 2, r['buckets']      # stack buckets + [heads, final norm] + [embeddings]
+    # round 5: fp32 group buckets are produced IN PLACE (the weight-gradient GEMMs write into the engine's persistent flat bucket, finish() hands out views)
+    assert r['direct'] == (dp_groups if bucket_dtype == 'float32' else 0), (r['direct'], dp_groups)
+    assert (r['aliased'] > 20) == (bucket_dtype == 'float32' and dp_groups > 0), r['aliased']
     dev = torch.device('cuda:0')
     model, w = _build(dev)
     model.load_state_dict(r['sd'])

@@ -249,3 +249,69 @@ def test_dp_engine_layer_group_buckets_match_big_batch(tmp_path):
         assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
         assert torch.allclose(r['grads2'][k], p.grad, atol=1e-6), k
     assert r['stats']['buckets'] == 1 + 2, r['stats']               # [every loose parameter: here the whole backward ran before the hand-off] + 2 layer groups
+
+
+def _worker_flat_groups(rank, world, port, out):
+    """round 5: in-place group buckets.  core.stack_backward asks `group_buffer(l0, l1, dense)` where the batched weight-gradient GEMMs should write;
+    with the views the bucket is produced in place: `on_group` only copies the group's remaining (small) gradients into the tail and all-reduces the
+    flat buffer; `finish()` hands out VIEWS of the bucket as .grad (no torch.cat staging, no copy back).  Emulated here exactly as core does it: layer
+    = (dense weight w_a, small parameter w_b); the dense gradients are written into the views, the small ones are handed over as separate tensors."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(31 + rank)
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    flat = model.transformer.flat_params()
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    res = []
+    for step in range(2):                                           # the persistent buffers are re-used by the second step
+        for p in model.parameters():
+            p.grad = None
+        _loss(model, ids_all[rank:rank + 1] if step == 0 else (ids_all[rank:rank + 1] + 3) % 10).backward()
+        fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(model.transformer.depth)]
+        for p in flat[:-1]:
+            p.grad = None                                           # as inside the fused backward: the stack's .grad does not exist yet
+        for (l0, l1) in ((2, 3), (0, 2)):                           # depth 3, two groups in backward order: {2}, then {1, 0}
+            views = eng.group_buffer(l0, l1, [0])                   # one dense kind: slot 0 = the first weight of every layer
+            assert views is not None and views[0].shape == (l1 - l0, 4, 4)
+            for l in range(l0, l1):
+                views[0][l - l0].copy_(fresh[l][0])                 # "the GEMM writes its output"
+            layers = list(range(l1 - 1, l0 - 1, -1))
+            eng.on_group(layers, [[views[0][l - l0], fresh[l][1]] for l in layers])
+        eng.finish()
+        st = eng.last_stats
+        # the handed-out gradients are views of the persistent buckets
+        aliased = all(any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f, _ in eng._flat_groups.values()) for p in flat[:-1])
+        res.append(dict(grads={k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}, stats=st, aliased=aliased))
+    # while gradients accumulate the engine must NOT hand out the persistent buffer (a .grad may alias it)
+    with eng.no_sync():
+        refused = eng.group_buffer(2, 3, [0]) is None
+    eng._bw_started = False
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().clone() for k, v in model.state_dict().items()}, res=res, ids=ids_all, refused=refused), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_in_place_group_buckets(tmp_path):
+    out = str(tmp_path / 'flat.pt')
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_worker_flat_groups, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    for step, ids in enumerate((r['ids'], (r['ids'] + 3) % 10)):
+        model.zero_grad()
+        (sum(_loss(model, ids[i:i + 1]) for i in range(2)) / 2).backward()
+        rs = r['res'][step]
+        for k, p in model.named_parameters():
+            if k == 'unused':
+                assert rs['grads'][k] is None
+                continue
+            assert torch.allclose(rs['grads'][k], p.grad, atol=1e-6), (step, k)
+        assert rs['stats']['buckets'] == 1 + 2 and rs['stats'].get('direct_buckets') == 2, rs['stats']
+        assert rs['aliased']
+    assert r['refused']
