@@ -89,12 +89,26 @@ FUSED_ADAM_PACK = os.environ.get('ALM_FUSED_ADAM_PACK', '1') != '0'
 _PACK_REGISTRY = {}      # data_ptr -> dict(stamp, cache (weakref), key, out (the cache entry's packed pair), jobs [(row0, rows, cols, dst, dstT, rows_pad, cols_pad)])
 
 
+_PACK_CACHES_SEEN = set()          # id(cache) of every WeightCache that has a finaliser installed
+
+
+def _drop_cache_entries(cid):
+    _PACK_CACHES_SEEN.discard(cid)
+    for k in [k for k, e in _PACK_REGISTRY.items() if e['cid'] == cid]:
+        del _PACK_REGISTRY[k]
+
+
 def _register_pack(w, stamp, cache, key, out, jobs):
+    """An entry holds strong references to the packed images (`out` and the dst / dstT views in `jobs`: ~4 bytes per dense parameter) -- the same tensors
+    the cache's own store holds.  They must not outlive the cache: a finaliser on the WeightCache removes its entries the moment the model that owns it is
+    collected (until round 4 they were pruned only above 4096 keys, so rebuilding a dim-1024 model in a notebook or a test session pinned
+    several GB of dead images in HBM)."""
     import weakref
-    if len(_PACK_REGISTRY) > 4096:                                   # models come and go (tests): drop entries whose cache is gone
-        for k in [k for k, e in _PACK_REGISTRY.items() if e['cache']() is None]:
-            del _PACK_REGISTRY[k]
-    _PACK_REGISTRY[w.data_ptr()] = dict(stamp=stamp, cache=weakref.ref(cache), key=key, out=out, jobs=jobs)
+    cid = id(cache)
+    if cid not in _PACK_CACHES_SEEN:
+        _PACK_CACHES_SEEN.add(cid)
+        weakref.finalize(cache, _drop_cache_entries, cid)
+    _PACK_REGISTRY[w.data_ptr()] = dict(stamp=stamp, cache=weakref.ref(cache), cid=cid, key=key, out=out, jobs=jobs)
 
 
 def pack_target(p):

@@ -191,17 +191,20 @@ class FusedAdam(torch.optim.Optimizer):
             ps = g['ps']
             if not ps:
                 continue
-            for p in ps:
-                self.state[p]['step'] += 1
-            step = int(self.state[ps[0]]['step'])                # used by the tensors whose table entry carries no step of its own
+            step = int(self.state[ps[0]]['step']) + 1            # used by the tensors whose table entry carries no step of its own
             b1, b2 = group['betas']
             hyper = (float(group['lr']), float(b1), float(b2), float(group['eps']), step, int(bool(group['decoupled_weight_decay'])),
                      clip[1].data_ptr() if clip else None, clip[0] if clip else 0.0, ops._st())
+            # the fused pack step FIRST: it is the launch whose argument validation can refuse (ALM_ERR_BAD_ARG) -- if it raises, nothing of this group
+            # has been applied yet (no step count bumped, no plain tensor updated: ADVICE r4).  The table entries carry step counts that _prepare()
+            # computed as state + 1, so the counters are advanced only after both launches were accepted.
+            if g['jobs'] is not None:
+                _lib.call('alm_opt_adam_pack_step', g['jobs'][0], g['jobs'][1], *hyper)
             if g['has_plain']:
                 chunks = g['plain_chunks']
                 _lib.call('alm_opt_adam_step', g['plain'][0], g['plain'][1], chunks.data_ptr(), chunks.shape[0], *hyper)
-            if g['jobs'] is not None:
-                _lib.call('alm_opt_adam_pack_step', g['jobs'][0], g['jobs'][1], *hyper)
+            for p in ps:
+                self.state[p]['step'] += 1
             _mark_updated(ps)
             for p, e in g['packed']:
                 core.stamp_packed(p, e)

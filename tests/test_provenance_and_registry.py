@@ -94,3 +94,25 @@ def test_pack_registry_hands_over_only_current_images():
         assert core.pack_target(w) is None
     finally:
         core.FUSED_ADAM_PACK = old
+
+
+def test_pack_registry_entries_die_with_their_cache():
+    """_PACK_REGISTRY holds strong references to the packed bf16 images; they were pruned only above 4096 keys, so every rebuilt model pinned its
+    dead images.  Now a finaliser on the WeightCache drops its entries as soon as the cache (the model) is collected; other caches' entries stay."""
+    import gc
+
+    import torch
+
+    from audiolm_pytorch_amd import core
+    before = dict(core._PACK_REGISTRY)
+    c1, c2 = core.WeightCache(), core.WeightCache()
+    w1, w2 = torch.zeros(4, 4), torch.zeros(4, 4)
+    core._register_pack(w1, (w1.data_ptr(), 0, (4, 4)), c1, (0, 'attn', 'wq'), (w1, w1), [])
+    core._register_pack(w2, (w2.data_ptr(), 0, (4, 4)), c2, (0, 'attn', 'wq'), (w2, w2), [])
+    assert w1.data_ptr() in core._PACK_REGISTRY and w2.data_ptr() in core._PACK_REGISTRY
+    del c1
+    gc.collect()
+    assert w1.data_ptr() not in core._PACK_REGISTRY and w2.data_ptr() in core._PACK_REGISTRY
+    del c2
+    gc.collect()
+    assert dict(core._PACK_REGISTRY).keys() == before.keys()
