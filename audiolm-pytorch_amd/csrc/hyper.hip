@@ -28,6 +28,15 @@
 #define ALM_HC_LDSREC 0
 #endif
 
+// Residual-stream tensor layout (internal to Transformer.forward: only the kernels of this file read or write it).  Shipped: [B][S][N][D] -- the S rows
+// of one token lie N * D elements apart.  -DALM_HC_TOKEN_MAJOR=1 (measurement build, scripts/build_variant.sh): [B][N][S][D] -- one contiguous S * D block
+// per token.  Round-5 micro-benchmark (scripts/ubench/stream_layout.hip, profiles/r5a_stream_layout.log): +5-10 % on the bare access pattern.
+#ifndef ALM_HC_TOKEN_MAJOR
+#define ALM_HC_TOKEN_MAJOR 0
+#endif
+template <typename I> __device__ __forceinline__ I hc_rbase(I b, I n, I S, I N, I D) { return ALM_HC_TOKEN_MAJOR ? (b * N + n) * S * D : (b * S * N + n) * D; }
+template <typename I> __device__ __forceinline__ I hc_sstride(I N, I D) { return ALM_HC_TOKEN_MAJOR ? D : N * D; }
+
 namespace {
 
 constexpr bool HC_LDSREC = ALM_HC_LDSREC != 0;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 
     const int niter = (int)((M + TPB - 1) / TPB);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long sND = (long long)a.N * a.D;                              // stream stride of R
+    const long long sND = hc_sstride<long long>(a.N, a.D);                   // stream stride of R
     // token coordinates (b, n) advance incrementally: no 64-bit divisions in the loop; `valid` is wave-uniform, so the loads sit in ONE
     // uniform branch instead of an exec-masked region each
     unsigned bb, nn;                                                         // coordinates of the token whose loads are issued next
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
     auto issue_pf = [&](In& in, const Tok& t) {
         const int m_ = t.valid ? t.m : 0;
         const int b_ = t.valid ? t.b : 0, n_ = t.valid ? t.n : 0;                  // PF: D == WPT * 256, every lane in range
-        const RT* Rt = Rin + ((long long)b_ * S * a.N + n_) * a.D + e0;
+        const RT* Rt = Rin + hc_rbase<long long>(b_, n_, S, a.N, a.D) + e0;
 #pragma unroll
         for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
         if (DEPTH) { in.y = *reinterpret_cast<const uint2*>(a.y + (long long)m_ * a.ldy + e0); in.cf = a.coef_prev[(long long)m_ * C::W + cl]; }
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
             if (a.rin_bcast) {
                 in.rb = ld4(reinterpret_cast<const float*>(a.R_in) + (long long)t.m * a.D + e0);
             } else {
-                const RT* Rt = Rin + ((long long)t.b * S * a.N + t.n) * a.D + e0;
+                const RT* Rt = Rin + hc_rbase<long long>(t.b, t.n, S, a.N, a.D) + e0;
 #pragma unroll
                 for (int s = 0; s < S; ++s) ldraw(in.r[s], Rt + s * sND);
             }
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256) void hc_fwd_kernel(HcFwdArgs a) {
 #pragma unroll
             for (int t = 0; t < S; ++t) {
                 r[t] = FINAL ? o[t] : as_stored<RT>(o[t]);
-                if (!FINAL && ld_ok) stR(Rout + (((long long)b * S + t) * a.N + n) * a.D + e0, o[t]);
+                if (!FINAL && ld_ok) stR(Rout + hc_rbase<long long>(b, n, S, a.N, a.D) + t * sND + e0, o[t]);
             }
         }
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) 
 
     const int niter = (int)((M + TPB - 1) / TPB);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long sND = (long long)a.N * a.D;
+    const long long sND = hc_sstride<long long>(a.N, a.D);
     unsigned bb, nn;                                                         // coordinates of the token whose loads are issued next (see hc_fwd_kernel)
     {
         const unsigned m0 = (unsigned)(blockIdx.x * TPB + tok);
@@ -725,9 +734,9 @@ __global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) 
         const unsigned m_ = t.valid ? (unsigned)t.m : 0u;
         const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u, el = (unsigned)e0;         // PF: D == WPT * 256, every lane in range
 #endif
-        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
+        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = hc_sstride<unsigned>(uN, uD);
         constexpr unsigned RB = sizeof(RT);
-        const unsigned tofs = ((b_ * (unsigned)S * uN + n_) * uD + el) * RB;       // 32-bit BYTE offsets: the launcher takes this path only when every tensor is < 4 GB
+        const unsigned tofs = (hc_rbase<unsigned>(b_, n_, (unsigned)S, uN, uD) + el) * RB;       // 32-bit BYTE offsets: the launcher takes this path only when every tensor is < 4 GB
         issue_scalars(w, m_, a);
         if constexpr (BC == 1) {
             w.gb = ld4(at_bytes(reinterpret_cast<const float*>(a.dRn), (m_ * uD + el) * 4u));
@@ -759,7 +768,7 @@ __global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) 
         w.dxn = w.ex = w.y = make_uint2(0u, 0u);
         issue_scalars(w, t.valid ? (unsigned)t.m : 0u, a);
         if (t.valid && eok) {
-            const long long tofs = ((long long)t.b * S * a.N + t.n) * a.D + e0;
+            const long long tofs = hc_rbase<long long>(t.b, t.n, S, a.N, a.D) + e0;
             if (a.bcast) {
                 w.gb = ld4(reinterpret_cast<const float*>(a.dRn) + (long long)t.m * a.D + e0);
             } else {
@@ -795,9 +804,9 @@ __global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) 
         const unsigned b_ = t.valid ? (unsigned)t.b : 0u, n_ = t.valid ? (unsigned)t.n : 0u;
 #endif
         const unsigned half = (unsigned)lane >> 5, l32 = (unsigned)lane & 31u;
-        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = uN * uD;
+        const unsigned uN = (unsigned)a.N, uD = (unsigned)a.D, sND32 = hc_sstride<unsigned>(uN, uD);
         const unsigned el = (unsigned)(wv * 256) + l32 * 8u;                                        // 8 bf16 = 16 bytes per lane
-        const unsigned tofs = ((b_ * (unsigned)S * uN + n_) * uD + el) * 2u + half * sND32 * 2u;    // lanes 32-63: the next stream's row
+        const unsigned tofs = (hc_rbase<unsigned>(b_, n_, (unsigned)S, uN, uD) + el) * 2u + half * sND32 * 2u;    // lanes 32-63: the next stream's row
         gcchar* const gd = (gcchar*)a.dRn;
         gcchar* const gr = (gcchar*)a.R;
 #pragma unroll
@@ -925,8 +934,8 @@ __global__ __launch_bounds__(256, GL ? (ALM_HC_GLREC ? 2 : 3) : ALM_HC_BWD_OCC) 
         auto emit = [&](int s_, const float4& o_) {
             if (WIDTH && ld_ok) {
                 if ((STRAIGHT && BC != 2) || a.dR) {                 // (the launcher takes the prefetching kernels with BC != 2 only when dR is given)
-                    if constexpr (PF) stR(at_bytes(dRo, ((((unsigned)b * (unsigned)S + (unsigned)s_) * (unsigned)a.N + (unsigned)n) * (unsigned)a.D + (unsigned)e0) * (unsigned)sizeof(RT)), o_);
-                    else stR(dRo + (((long long)b * S + s_) * a.N + n) * a.D + e0, o_);
+                    if constexpr (PF) stR(at_bytes(dRo, (hc_rbase<unsigned>((unsigned)b, (unsigned)n, (unsigned)S, (unsigned)a.N, (unsigned)a.D) + (unsigned)s_ * hc_sstride<unsigned>((unsigned)a.N, (unsigned)a.D) + (unsigned)e0) * (unsigned)sizeof(RT)), o_);
+                    else stR(dRo + hc_rbase<long long>(b, n, S, a.N, a.D) + s_ * sND + e0, o_);
                 }
             }
             if (WIDTH) { dsum_acc.x += o_.x; dsum_acc.y += o_.y; dsum_acc.z += o_.z; dsum_acc.w += o_.w; }

@@ -32,7 +32,7 @@ Compared END TO END: the loss, EVERY logit, and the gradient of EVERY parameter,
       forward <= 1e-3, measured <= 7e-5; backward <= 3e-3; cancelling hyper-connection scalar gradients <= 1e-2).
 Synthetic hyper-connection weights are width-scaled (tests/golden/common.py): the dynamic pre-activations keep a std of ~0.4 at dim 1024.
 test_full_size_matches_real_reference_digest compares the HIP path DIRECTLY with digests of the REAL reference at these sizes (tests/golden/full_*.pt).
-Every run appends its numbers to gpurun_out/r4_fullsize_parity.jsonl (copied to profiles/ for the record).
+Every run appends its numbers to gpurun_out/r5_fullsize_parity.jsonl (copied to profiles/ for the record).
 """
 import json
 import os
@@ -50,7 +50,7 @@ import rounding_matched as RM
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r4_fullsize_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r5_fullsize_parity.jsonl')
 
 
 def _case(kind, streams, N_kind, batch=None):
