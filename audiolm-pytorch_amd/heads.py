@@ -45,37 +45,61 @@ def _pad_index(G, C, Cp, device):
     return _PAD_IDX[key]
 
 
+# Round 5: the three accumulating GEMMs of the split-bf16 logits (hi.Whi + hi.Wlo + lo.Whi) are ONE GEMM over a K-concatenated pair of operands
+# ([hi | hi | lo] . [Whi | Wlo | Whi]^T, K = 3 D): the same products summed in one fp32 accumulator chain, one fast (non-accumulating) epilogue instead of
+# two read-modify-write passes over the fp32 logits, one launch instead of three.  ALM_HEAD_KCAT=0 restores the three launches (A/B switch).
+import os as _os
+HEAD_KCAT = _os.environ.get('ALM_HEAD_KCAT', '1') != '0'
+
+
 def _pack_head(w):
-    """fp32 [G, C, D] -> (Whi bf16 [G, C, D], Wlo bf16 [G, C, D] (w ~= Whi + Wlo), WT bf16 [G, D, Cpad] = Whi^T zero padded).  Two launches for all G
-    quantizers (round 4; it was 2 G + 2: the packs are redone after every optimiser step): one split-gather into the row-padded [G, Cpad, D] images,
-    one multi-weight transpose pack."""
+    """fp32 [G, C, D] -> (Wcat bf16 [G, C, 3 D] = [Whi | Wlo | Whi] (w ~= Whi + Wlo; rows of one quantizer Cpad apart), WT bf16 [G, D, Cpad] = Whi^T zero
+    padded).  Whi / Wlo are the column blocks [0, D) / [D, 2 D) of Wcat.  Three launches for all G quantizers: one split-gather straight into the column
+    blocks of the row-padded [G, Cpad, 3 D] image, one block copy (the second Whi), one multi-weight transpose pack."""
     G, C, D = w.shape
     Cp = (C + 7) // 8 * 8
     w = w.contiguous()
     capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
     idx = _pad_index(G, C, Cp, w.device) if not capturing else None
+    Wcat = torch.empty((G, Cp, 3 * D), dtype=BF16, device=w.device)
+    flat = Wcat.view(G * Cp, 3 * D)
     if idx is not None:
-        hi, lo = ops.gather_split(w.view(G * C, D), idx)                       # rows C .. Cp-1 of every quantizer are zero
-        hi, lo = hi.view(G, Cp, D), lo.view(G, Cp, D)
+        ops.gather_split(w.view(G * C, D), idx, out=(flat[:, :D], flat[:, D:2 * D]))      # rows C .. Cp-1 of every quantizer are zero
     else:                                                                      # (index tensors are not created inside a hipGraph capture)
-        his, los = zip(*[ops.gather_split(w[g], None, rows_out=Cp) for g in range(G)])
-        hi, lo = torch.stack(his), torch.stack(los)
+        for g in range(G):
+            ops.gather_split(w[g], None, rows_out=Cp, out=(Wcat[g, :, :D], Wcat[g, :, D:2 * D]))
+    flat[:, 2 * D:].copy_(flat[:, :D])
     WT = torch.empty((G, D, Cp), dtype=BF16, device=w.device)
     for g0 in range(0, G, 8):
         ops.pack_weights_multi([(w[g], None, WT[g], Cp, D) for g in range(g0, min(G, g0 + 8))])
-    return hi[:, :C], lo[:, :C], WT
+    return Wcat[:, :C], WT
+
+
+def _full_rows(Wcat, Cp):
+    """the [G, Cpad, 3 D] image behind the [G, C, 3 D] view _pack_head returns (rows C .. Cpad-1 are zero)"""
+    G, C, K3 = Wcat.shape
+    return Wcat.as_strided((G, Cp, K3), (Wcat.stride(0), Wcat.stride(1), 1))
 
 
 def head_logits(hn, w3, bias, idx, cache, key):
-    """hn fp32 [M, D] (bf16 accepted: then there is no low half) -> (hg bf16 [G*Rg, D] = high halves of the gathered rows,
+    """hn fp32 [M, D] (bf16 accepted: then there is no low half) -> (hg bf16 [G*Rg, D] (row stride may exceed D) = high halves of the gathered rows,
     logits fp32 [G*Rg, Cpad] (first C columns valid))."""
     G, C, D = w3.shape
     Rg = idx.shape[1]
     Cp = (C + 7) // 8 * 8
-    Whi, Wlo, _ = cache.get(key, w3, _pack_head)
+    Wcat, _ = cache.get(key, w3, _pack_head)
+    Whi, Wlo = Wcat[:, :, :D], Wcat[:, :, D:2 * D]
     logits = torch.empty((G, Rg, Cp), dtype=F32, device=hn.device)
     out = logits[:, :, :C]
-    if hn.dtype == F32:
+    if hn.dtype == F32 and HEAD_KCAT:
+        Acat = torch.empty((G * Rg, 3 * D), dtype=BF16, device=hn.device)
+        hg, _ = ops.gather_split(hn, idx.reshape(-1), out=(Acat[:, :D], Acat[:, 2 * D:]))
+        Acat[:, D:2 * D].copy_(hg)
+        if bias is None:                # all Cpad columns (the pad rows of Wcat are zero): N % 4 == 0 -> the GEMM's 16-byte row-segment epilogue
+            ops.gemm_nt(Acat.view(G, Rg, 3 * D), _full_rows(Wcat, Cp), logits)
+        else:
+            ops.gemm_nt(Acat.view(G, Rg, 3 * D), Wcat, out, bias=bias)
+    elif hn.dtype == F32:
         hg, hl = ops.gather_split(hn, idx.reshape(-1))
         ops.gemm_nt(hg.view(G, Rg, D), Whi, out, bias=bias)
         ops.gemm_nt(hg.view(G, Rg, D), Wlo, out, accumulate=True)
@@ -127,7 +151,7 @@ class HeadsLossFn(torch.autograd.Function):
                 continue
             gs = go.detach().to(F32).contiguous()
             dl = ops.cross_entropy_bwd(logits, labels, lse, gs, C, Cp)            # bf16 [G*Rg, Cp], pad columns zero
-            _, _, WT = ctx.cache.get(('head', g.name), w3, _pack_head)
+            _, WT = ctx.cache.get(('head', g.name), w3, _pack_head)
             dhg = torch.empty((G, Rg, D), dtype=ctx.hn_dtype, device=dev)
             ops.gemm_nt(dl.view(G, Rg, Cp), WT, dhg)                              # dgrad: dlogits @ W
             if f32:                                                               # row copies are type-blind: fp32 rows = bf16 rows of twice the width
@@ -135,8 +159,8 @@ class HeadsLossFn(torch.autograd.Function):
             else:
                 ops.scatter_rows(dhg.view(G * Rg, D), g.idx.reshape(-1), dhn)
             dW = torch.empty((G, C, D), dtype=F32, device=dev)
-            for q in range(G):                                                    # wgrad: dlogits_q^T @ hidden_q
-                ops.gemm_tn_splitk(dl[q * Rg:(q + 1) * Rg, :C], hg[q * Rg:(q + 1) * Rg], dW[q])
+            # wgrad: dlogits_q^T @ hidden_q for all G quantizers in ONE batched launch (round 5; one split-K launch + reduce per quantizer before)
+            ops.gemm_tn_batched(dl.view(1, G, Rg, Cp)[..., :C], hg.as_strided((1, G, Rg, D), (0, Rg * hg.stride(0), hg.stride(0), 1)), dW.view(1, G, C, D))
             grads.append(dW.reshape(ctx.params[len(grads)].shape))
             if has_bias:
                 grads.append(ops.colsum(dl[:, :C]))

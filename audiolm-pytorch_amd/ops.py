@@ -774,18 +774,23 @@ def embed_scatter_owned(grad_tables, src_a, src_b, dout, alpha, rows, D):
               src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, ws.data_ptr(), _st())
 
 
-def gather_split(inp, idx=None, rows_out=None):
+def gather_split(inp, idx=None, rows_out=None, out=None):
     """fp32 inp [rows_in, D] (row stride arbitrary) -> (hi, lo) bf16 [rows_out, D] with hi + lo ~= inp[idx] to ~16 mantissa bits: the split-bf16
-    operands of the logit heads.  idx int32 [rows_out] (-1 = zero row) or None (identity; rows past rows_in are zero = row padding)."""
+    operands of the logit heads.  idx int32 [rows_out] (-1 = zero row) or None (identity; rows past rows_in are zero = row padding).
+    out = (hi, lo): bf16 [rows_out, D] views of ONE row stride (column blocks of a wider buffer: the K-concatenated head operands)."""
     _chk(inp, F32)
     rows_in, D, ld = _rows_ld(inp)
     if idx is not None:
         rows_out = idx.numel()
     elif rows_out is None:
         rows_out = rows_in
-    hi = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
-    lo = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
-    _lib.call('alm_gather_split_bf16', inp.data_ptr(), ld, rows_in, _p(idx), hi.data_ptr(), lo.data_ptr(), D, rows_out, D, _st())
+    if out is None:
+        hi = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
+        lo = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
+    else:
+        hi, lo = out
+        assert hi.shape == lo.shape == (rows_out, D) and hi.dtype == lo.dtype == BF16 and hi.stride(1) == lo.stride(1) == 1 and hi.stride(0) == lo.stride(0)
+    _lib.call('alm_gather_split_bf16', inp.data_ptr(), ld, rows_in, _p(idx), hi.data_ptr(), lo.data_ptr(), hi.stride(0), rows_out, D, _st())
     return hi, lo
 
 

@@ -637,11 +637,14 @@ def test_layernorm_fp32_output_and_fp32_upstream_gradient(ops):
     assert relmax(dx, xr.grad) <= 1e-5 and relmax(dg, gr.grad) <= 1e-5
 
 
+@pytest.mark.parametrize('kcat', [True, False])
 @pytest.mark.parametrize('G,C,D,R', [(3, 1025, 1024, 300), (1, 501, 256, 77), (5, 64, 128, 40)])
-def test_split_bf16_logit_heads(ops, G, C, D, R):
+def test_split_bf16_logit_heads(ops, G, C, D, R, kcat, monkeypatch):
     """logit heads on split-bf16 operands (heads.head_logits): fp32 hidden states x fp32 master weights to ~16 mantissa bits, vs an fp64
-    contraction.  Plain bf16 operands give ~3e-3; the split form must be >= 100 x better."""
+    contraction.  Plain bf16 operands give ~3e-3; the split form must be >= 100 x better.  kcat: the three products as ONE GEMM over K-concatenated
+    operands (round 5, default) or as three accumulating launches."""
     from audiolm_pytorch_amd import core, heads
+    monkeypatch.setattr(heads, 'HEAD_KCAT', kcat)
     hn = rnd(R * 2, D, seed=96)
     w = rnd(G, C, D, seed=97, scale=2.0 / math.sqrt(D))
     bias = rnd(C, seed=98, scale=0.1) if G == 1 else None
@@ -655,7 +658,7 @@ def test_split_bf16_logit_heads(ops, G, C, D, R):
     got = logits.view(G, R, -1)[..., :C]
     e = relmax(got, ref)
     assert e <= 3e-5, e
-    assert torch.equal(hg.view(G, R, D), rows.to(BF16))                    # the saved high halves = bf16 image of the gathered rows
+    assert torch.equal(hg.reshape(G, R, D), rows.to(BF16))                 # the saved high halves = bf16 image of the gathered rows
     hi, lo = ops.gather_split(hn)
     assert torch.equal(hi, hn.to(BF16)) and relmax(hi.float() + lo.float(), hn) <= 2 ** -15
 
