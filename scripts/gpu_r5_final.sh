@@ -28,3 +28,12 @@ PY
 ALM_HC_GL=0 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_opwise.py -m gpu -q --tb=short -p no:cacheprovider -k "hyper_connections or coarse-4-bf16-None" > gpurun_out/${tag}_gl0_tests.log 2>&1
 echo "ALM_HC_GL=0 tests rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_gl0_tests.log | cut -c1-200
 echo "total t=$((SECONDS-t0))"
+# the other BASELINE configurations (each line carries its own roofline, cpu_baseline and oracle loss-parity check)
+if [[ -n "$CONFIGS" ]]; then
+  rm -f gpurun_out/${tag}_bench_configs.jsonl
+  for cf in $CONFIGS; do
+    timeout 900 python bench.py --config $cf --steps 5 --warmup 2 2>/dev/null | tail -n 1 >> gpurun_out/${tag}_bench_configs.jsonl
+    echo "config $cf rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_bench_configs.jsonl | cut -c1-400
+  done
+fi
+echo "total t=$((SECONDS-t0))"
