@@ -25,6 +25,7 @@ SIGNATURES = {
     'alm_gemm_bf16_nt_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_splitk': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _L, _L, _L, _F, _I, _P],
     'alm_gemm_bf16_tn_batched': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    'alm_gemm_bf16_nt_group2': [_P, _P, _P, _I, _I, _I, _L, _L, _L, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
     'alm_gemm_bf16_nt_tile': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _I, _I, _P],
     'alm_transpose_bf16': [_P, _P, _I, _I, _L, _L, _I, _P],
     'alm_transpose_bf16_batched': [_P, _P, _I, _I, _L, _L, _I, _I, _L, _L, _P],

@@ -355,8 +355,9 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
         ops.gemm_nt(XN, Wq, Q)
         fside.join()
     else:
-        ops.gemm_nt(XN, Wq, Q)
-        ops.gemm_nt(X, Wkv, KV)                          # k / v from the UN-normalised branch input (:325 vs :347)
+        # to_q || to_kv in one launch (round 5): k / v from the UN-normalised branch input (:325 vs :347); alone, the N = 128 projection is 128
+        # workgroups waiting on an HBM round trip per K-step on a quarter of the CU slots
+        ops.gemm_nt_group2(XN, Wq, Q, X, Wkv, KV)
     K, Vown = KV[:, :dh], KV[:, dh:]
     if cfg.add_value_residual and st['kv0'] is not None:
         V = ops.value_residual_mix(Vown, st['kv0'][:, dh:])  # :357-358
@@ -942,9 +943,8 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
                 ops.gemm_nt(dKVp, WkvT, dcp)                                      # the prefix enters to_kv un-normalised: d(context) directly
                 add_ctx(dcp)
             dXN = _empty((M, D), BF16, dev)
-            ops.gemm_nt(dQ, WqT, dXN)
             extra = _empty((M, D), BF16, dev)
-            ops.gemm_nt(dKV, WkvT, extra)                                         # K/V-path gradient: reaches the un-normalised branch input directly
+            ops.gemm_nt_group2(dQ, WqT, dXN, dKV, WkvT, extra)                    # (extra: the K/V-path gradient reaches the un-normalised branch input directly)
             if bst is None:
                 dWq = _empty((H * dh, D), F32, dev)
                 XNs = sv['XN']

@@ -197,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // (Deeper DMA rings, a hand software-pipelined loop, a persistent variant and B-from-registers variants were built and measured slower:
 // they live in the bench-only translation unit csrc/lab/gemm_lab.hip, results in DESIGN.md section 8.1.)
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         // (its K slices and the few tiles along the other dimension) is pinned to XCD q % 8 (workgroup L runs on XCD L % 8 -- observed
         // dispatch order; a wrong guess only costs speed), so each of its K slices is fetched from HBM once and shared through that
         // XCD's L2; only the small operand is fetched by every XCD.
-        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int L = bx, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
         const int P = p.plimit > 0 ? p.plimit : tmaj * (p.nbt > 0 ? p.nbt : p.nb2);   // plimit: only the first panels (hybrid full-K + tail launch)
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
         tn = m_major ? minor : tmajor;
     } else {
         const int nwg = tiles_m * tiles_n;
-        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int bid = xcd_remap(bx, nwg);
         const int tt = grouped_tile(bid, tiles_m, tiles_n, p.group_m);
         tm = tt & 0xffff;
         tn = tt >> 16;
-        zb = blockIdx.y;
-        zs = blockIdx.z;
+        zb = by;
+        zs = bz;
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -405,6 +405,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
 }
 
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
+    gemm_body<BM, BN, WM, WN, TNMODE, OUT_F32>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// TWO independent un-batched problems in one launch (round 5): workgroups [0, tiles0) run problem 0, the rest problem 1 -- for pairs of launches that sit
+// next to each other in the step and each leave most of the chip idle or latency-bound on their own (to_q || to_kv: the N = 128 projection is 128
+// workgroups waiting on one HBM round trip per K-step; dXN_q || dX_kv).  The parameter block is selected by a workgroup-uniform pointer select.
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_group2_kernel(GemmParams p0, GemmParams p1, int tiles0) {
+    const bool second = (int)blockIdx.x >= tiles0;
+    const GemmParams& p = second ? p1 : p0;
+    gemm_body<BM, BN, WM, WN, TNMODE, OUT_F32>(p, second ? (int)blockIdx.x - tiles0 : (int)blockIdx.x, 0, 0);
+}
+
 // Bench-only cycle probe of the staggered kernel (scripts/gemm_probe.py builds gemm.hip with -DALM_GEMM_PROBE into its own library; the product build
 // has none of this): per wave, s_memtime cycles in the four parts of a slot pair + prologue / epilogue.
 #ifdef ALM_GEMM_PROBE
@@ -432,7 +447,7 @@ __device__ unsigned long long g_gemm_probe[16384 * 8];
 // operand is shared by both rows and lives 5 slots (written in slots 2j, 2j+1, read in 2j+3, 2j+4): 3 buffers x 32 KB.  Row g loads its
 // own A half and the B pieces [16 g, 16 g + 16): 8 one-KiB DMA pieces per wave and stage, as before.
 template <bool TNMODE, bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_stag_body(const GemmParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     GPROBE_DECL
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 4, TNB = 2;
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn, zb, zs;
     if (p.raster >= 1) {                                                    // split-K weight gradients: XCD-panel rasterisation (see gemm_kernel)
-        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int L = bx, xcd = L & 7, j = L >> 3;
         const bool m_major = tiles_m >= tiles_n;
         const int tmaj = m_major ? tiles_m : tiles_n, Q = m_major ? tiles_n : tiles_m;
         const int P = p.plimit > 0 ? p.plimit : tmaj * (p.nbt > 0 ? p.nbt : p.nb2);   // plimit: only the first panels (hybrid full-K + tail launch)
@@ -459,12 +474,12 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
         tn = m_major ? minor : tmajor;
     } else {
         const int nwg = tiles_m * tiles_n;
-        const int bid = xcd_remap(blockIdx.x, nwg);
+        const int bid = xcd_remap(bx, nwg);
         const int tt = grouped_tile(bid, tiles_m, tiles_n, p.group_m);
         tm = tt & 0xffff;
         tn = tt >> 16;
-        zb = blockIdx.y;
-        zs = blockIdx.z;
+        zb = by;
+        zs = bz;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int z1 = zb / p.nb2, z2 = zb % p.nb2;
@@ -652,9 +667,21 @@ __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     GPROBE_T(5);
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
     GPROBE_T(6);
-    GPROBE_FLUSH((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave);
+    GPROBE_FLUSH((bx + gridDim.x * (by + gridDim.y * bz)) * 8 + wave);
 }
 
+
+template <bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
+    gemm_stag_body<TNMODE, OUT_F32>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+template <bool TNMODE, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_stag_group2_kernel(GemmParams p0, GemmParams p1, int tiles0) {        // see gemm_group2_kernel
+    const bool second = (int)blockIdx.x >= tiles0;
+    const GemmParams& p = second ? p1 : p0;
+    gemm_stag_body<TNMODE, OUT_F32>(p, second ? (int)blockIdx.x - tiles0 : (int)blockIdx.x, 0, 0);
+}
 
 // counted wait on the vector-memory queue: at most N operations (here: LDS-DMA pieces, which retire in order) may still be in flight
 template <int N>
@@ -1383,6 +1410,52 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     if (view_too_big(384, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
     GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0, 0, 1};
     int rc = launch_gemm<false>(p, nb1 * nb2, 1, out_f32, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Two un-batched NT problems in ONE launch (gemm_group2_kernel / gemm_stag_group2_kernel): C0 = A0 . B0^T and C1 = A1 . B1^T, bf16 outputs (or fp32:
+// out_f32), no bias, alpha 1, no accumulation.  Both problems must pick the same block tile (128 x 128 or the staggered 256 x 256) and problem 0's
+// tile count must be a multiple of 8 (problem 1's workgroups keep the XCD <-> tile-order correspondence the rasterisation assumes); otherwise -- and
+// with ALM_GEMM_GROUP2=0 -- the two problems are launched one after the other: same results either way (each tile is computed by the same code).
+extern "C" int alm_gemm_bf16_nt_group2(const void* A0, const void* B0, void* C0, int M0, int N0, int K0, long long lda0, long long ldb0, long long ldc0,
+                                       const void* A1, const void* B1, void* C1, int M1, int N1, int K1, long long lda1, long long ldb1, long long ldc1,
+                                       int out_f32, void* stream) {
+    static const int on = [] { const char* e = getenv("ALM_GEMM_GROUP2"); return e ? atoi(e) : 1; }();
+    hipStream_t st = (hipStream_t)stream;
+    auto bad = [](const void* A, const void* B, int K, long long lda, long long ldb) {
+        return K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15);
+    };
+    if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0) {
+        int rc = alm_gemm_bf16_nt(A0, B0, C0, nullptr, M0, N0, K0, lda0, ldb0, ldc0, 1, 1, 0, 0, 0, 0, 0, 0, 1.f, out_f32, 0, stream);
+        if (rc) return rc;
+        return alm_gemm_bf16_nt(A1, B1, C1, nullptr, M1, N1, K1, lda1, ldb1, ldc1, 1, 1, 0, 0, 0, 0, 0, 0, 1.f, out_f32, 0, stream);
+    }
+    if (bad(A0, B0, K0, lda0, ldb0) || bad(A1, B1, K1, lda1, ldb1)) return ALM_ERR_BAD_ARG;
+    if (view_too_big(384, lda0) || view_too_big(256, ldb0) || view_too_big(384, lda1) || view_too_big(256, ldb1)) return ALM_ERR_UNSUPPORTED;
+    const int t0 = pick_tile(M0, N0, 1, 0, false), t1 = pick_tile(M1, N1, 1, 0, false);
+    const int bm = t0 == 1 ? 128 : 256;
+    const int tiles0 = ((M0 + bm - 1) / bm) * ((N0 + bm - 1) / bm), tiles1 = ((M1 + bm - 1) / bm) * ((N1 + bm - 1) / bm);
+    if (!on || t0 != t1 || (t0 != 1 && t0 != 13) || (tiles0 & 7)) {
+        int rc = alm_gemm_bf16_nt(A0, B0, C0, nullptr, M0, N0, K0, lda0, ldb0, ldc0, 1, 1, 0, 0, 0, 0, 0, 0, 1.f, out_f32, 0, stream);
+        if (rc) return rc;
+        return alm_gemm_bf16_nt(A1, B1, C1, nullptr, M1, N1, K1, lda1, ldb1, ldc1, 1, 1, 0, 0, 0, 0, 0, 0, 1.f, out_f32, 0, stream);
+    }
+    GemmParams p0{(const bf16_t*)A0, (const bf16_t*)B0, C0, nullptr, M0, N0, K0, lda0, ldb0, ldc0, 1, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, 0, 1};
+    GemmParams p1{(const bf16_t*)A1, (const bf16_t*)B1, C1, nullptr, M1, N1, K1, lda1, ldb1, ldc1, 1, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, 0, 1};
+    p0.group_m = pick_group(p0, t0);
+    p1.group_m = pick_group(p1, t1);
+    auto launch = [&](auto kfn, int threads, int smem) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kfn, dim3(tiles0 + tiles1), dim3(threads), smem, st, p0, p1, tiles0);
+        return 0;
+    };
+    int rc;
+    if (t0 == 1) rc = out_f32 ? launch(gemm_group2_kernel<128, 128, 2, 2, false, true>, 256, 2 * (128 + 128) * BK * 2)
+                              : launch(gemm_group2_kernel<128, 128, 2, 2, false, false>, 256, 2 * (128 + 128) * BK * 2);
+    else rc = out_f32 ? launch(gemm_stag_group2_kernel<false, true>, 512, 163840) : launch(gemm_stag_group2_kernel<false, false>, 512, 163840);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;

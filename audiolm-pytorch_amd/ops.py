@@ -67,6 +67,21 @@ def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
     return C
 
 
+def gemm_nt_group2(A0, B0, C0, A1, B1, C1):
+    """C0 = A0 @ B0^T and C1 = A1 @ B1^T (2-D, last dim contiguous, both outputs of one dtype) in ONE launch when the two problems pick the same block
+    tile (alm_gemm_bf16_nt_group2; two launches otherwise -- identical results)."""
+    for t in (A0, B0, A1, B1):
+        _chk(t, BF16)
+        assert t.dim() == 2 and t.stride(1) == 1
+    _chk(C0), _chk(C1)
+    assert C0.dtype == C1.dtype and C0.stride(1) == 1 and C1.stride(1) == 1
+    (M0, K0), (M1, K1), N0, N1 = A0.shape, A1.shape, B0.shape[0], B1.shape[0]
+    assert B0.shape[1] == K0 and B1.shape[1] == K1 and tuple(C0.shape) == (M0, N0) and tuple(C1.shape) == (M1, N1)
+    _lib.call('alm_gemm_bf16_nt_group2', A0.data_ptr(), B0.data_ptr(), C0.data_ptr(), M0, N0, K0, A0.stride(0), B0.stride(0), C0.stride(0),
+              A1.data_ptr(), B1.data_ptr(), C1.data_ptr(), M1, N1, K1, A1.stride(0), B1.stride(0), C1.stride(0), int(C0.dtype == F32), _st())
+    return C0, C1
+
+
 def _splitk(name, A, B, C, M, N, K, nb, sA, sB, sC, alpha, accumulate):
     nws = _lib.query('alm_gemm_splitk_ws_floats', M, N, K, nb)
     if nws < 0:

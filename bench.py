@@ -463,7 +463,7 @@ def main():
     # collectives); only rank 0's numbers are reported.
     roof = None
     events = []                                                  # (start event, end event, algorithmic work, unit, kernel key)
-    timed_names = ('gemm_nt', 'gemm_tn_splitk', 'gemm_tn_batched', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
+    timed_names = ('gemm_nt', 'gemm_nt_group2', 'gemm_tn_splitk', 'gemm_tn_batched', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
                    'layernorm_bwd', 'conv1d_causal', 'rvq_encode')       # (the last two: the SoundStream tokenize kernels of --config e2e_config5)
     originals = {n: getattr(ops, n) for n in timed_names}
 
@@ -483,6 +483,9 @@ def main():
                 nb *= d
             Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
             return 2.0 * nb * Mm * Nn * Kk, 'flop', ('nt256' if big_tile(Mm, Nn, nb) else 'nt128')
+        if name == 'gemm_nt_group2':                                             # two un-batched problems in one launch (to_q || to_kv, their two dgrads)
+            (M0, K0), N0, (M1, K1), N1 = a[0].shape, a[1].shape[0], a[3].shape, a[4].shape[0]
+            return 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), 'flop', ('nt256' if big_tile(M0, N0, 1) else 'nt128')
         if name == 'gemm_tn_splitk':
             At, Bt = a[0], a[1]
             nb = At.shape[0] if At.dim() == 3 else 1

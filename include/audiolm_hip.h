@@ -29,6 +29,12 @@ extern "C" {
 int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                      long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
                      long long sC2, float alpha, int out_f32, int accumulate, void* stream);
+/* two independent un-batched NT problems (bf16 or fp32 outputs, no bias, alpha 1) in ONE launch: pairs of projections that sit next to each other in
+ * the step and each leave most of the chip idle on their own -- to_q || to_kv (audiolm_pytorch.py:351 / :347: x_norm . Wq^T beside x . Wkv^T) and their two
+ * dgrads.  Falls back to two launches when the problems do not pick the same tile; results are identical either way. */
+int alm_gemm_bf16_nt_group2(const void* A0, const void* B0, void* C0, int M0, int N0, int K0, long long lda0, long long ldb0, long long ldc0,
+                            const void* A1, const void* B1, void* C1, int M1, int N1, int K1, long long lda1, long long ldb1, long long ldc1,
+                            int out_f32, void* stream);
 /* tile-selectable, un-batched form of alm_gemm_bf16_nt (tests / benchmarks): tile 0 = auto, 1 = 128x128x64 (4 waves), 2 = 256x256x64
  * (8 waves, lock-step), 13 = 256x256x64 with staggered wave rows (the production big tile), 11 = 384x256x64 (8 waves); other ids ->
  * ALM_ERR_UNSUPPORTED (the variants that were measured and not adopted live in the bench-only csrc/lab/gemm_lab.hip). */

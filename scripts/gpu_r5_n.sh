@@ -1,0 +1,11 @@
+#!/bin/bash
+tag=${1:-r5n}
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+t0=$SECONDS
+timeout 900 python -X faulthandler -m pytest tests/test_gpu_kernels.py tests/test_gpu_opwise.py tests/test_gpu_parity.py -m gpu -q --tb=short --timeout 600 -p no:cacheprovider -x \
+  -k "gemm_nt or opwise or golden or deterministic or coarse" > gpurun_out/${tag}_tests.log 2>&1
+echo "tests rc=$? t=$((SECONDS-t0))"; tail -n 6 gpurun_out/${tag}_tests.log | cut -c1-300
+STEPS=30 bash scripts/ab_env2.sh 3 "ALM_GEMM_GROUP2=1" "ALM_GEMM_GROUP2=0" > gpurun_out/${tag}_ab.log 2>&1
+echo "ab t=$((SECONDS-t0))"; cat gpurun_out/${tag}_ab.log | cut -c1-200
+echo "total t=$((SECONDS-t0))"

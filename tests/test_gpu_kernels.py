@@ -71,6 +71,30 @@ def test_gemm_nt_tile_configs(ops, M, N, K, tile):
         assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'GEMM wrote outside its tile'
 
 
+@pytest.mark.parametrize('shapes', [((2048, 512, 1024), (2048, 128, 1024)),        # to_q || to_kv: both on the 128 x 128 tile, 64 + 16 tiles
+                                    ((16384, 1024, 512), (16384, 1024, 128)),      # dXN_q || dX_kv: both on the staggered 256 x 256 tile, 256 + 256 tiles
+                                    ((1000, 520, 200), (300, 96, 72)),             # ragged, K tails, tiles0 = 40 (multiple of 8)
+                                    ((1100, 520, 200), (300, 96, 72)),             # tiles0 = 45: not a multiple of 8 -> two launches
+                                    ((16384, 1024, 512), (2048, 128, 1024))])      # different tiles -> two launches
+@pytest.mark.parametrize('odt', [BF16, F32])
+def test_gemm_nt_group2_equals_two_launches(ops, shapes, odt):
+    """alm_gemm_bf16_nt_group2: two independent NT problems in one launch == the two problems launched separately, bit for bit (every tile is computed
+    by the same code), nothing written outside either output"""
+    (M0, N0, K0), (M1, N1, K1) = shapes
+    A0, B0 = rnd(M0, K0, seed=21, dtype=BF16), rnd(N0, K0, seed=22, dtype=BF16)
+    A1, B1 = rnd(M1, K1, seed=23, dtype=BF16), rnd(N1, K1, seed=24, dtype=BF16)
+    C0 = torch.full((M0 + 2, N0 + 8), float('nan'), dtype=odt, device=dev())
+    C1 = torch.full((M1 + 2, N1 + 8), float('nan'), dtype=odt, device=dev())
+    ops.gemm_nt_group2(A0, B0, C0[:M0, :N0], A1, B1, C1[:M1, :N1])
+    R0, R1 = torch.empty((M0, N0), dtype=odt, device=dev()), torch.empty((M1, N1), dtype=odt, device=dev())
+    ops.gemm_nt(A0, B0, R0)
+    ops.gemm_nt(A1, B1, R1)
+    assert torch.equal(C0[:M0, :N0], R0) and torch.equal(C1[:M1, :N1], R1)
+    assert relmax(R0, A0.double() @ B0.double().t()) <= (2e-5 if odt == F32 else 4e-3)
+    for C, M, N in ((C0, M0, N0), (C1, M1, N1)):
+        assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'wrote outside its output'
+
+
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (512, 1024, 4096), (130, 200, 100), (1025, 256, 333), (2730, 1024, 2048), (128, 1024, 16384),
                                    (1024, 2730, 777), (8, 512, 4095), (32, 32, 29)])
 def test_gemm_tn_splitk(ops, M, N, K):
