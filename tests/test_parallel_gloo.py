@@ -315,3 +315,59 @@ def test_dp_engine_in_place_group_buckets(tmp_path):
         assert rs['stats']['buckets'] == 1 + 2 and rs['stats'].get('direct_buckets') == 2, rs['stats']
         assert rs['aliased']
     assert r['refused']
+
+
+def _worker_flat_groups_late(rank, world, port, out):
+    """in-place group buckets with the SMALL weight kinds late (core.stack_backward, DEFER_SMALL_LATE): the early group's bucket holds only its layers' big
+    kind (slot 0; slot 1 is skipped), the last group's bucket holds its own big kind plus slot 1 of ALL layers; every gradient is handed over exactly once."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    torch.manual_seed(41 + rank)
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    flat = model.transformer.flat_params()
+    L = model.transformer.depth
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    _loss(model, ids_all[rank:rank + 1]).backward()
+    fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(L)]
+    for p in flat[:-1]:
+        p.grad = None
+    # early group {2}: big kind only
+    v = eng.group_buffer(2, 3, [0], [], [1])
+    assert v is not None and v[0].shape == (1, 4, 4)
+    v[0][0].copy_(fresh[2][0])
+    eng.on_group([2], [[v[0][0], None]])
+    # last group {1, 0}: its big kind + the late kind of all three layers
+    v = eng.group_buffer(0, 2, [0], [1], [])
+    assert v is not None and v[0].shape == (2, 4, 4) and v[1].shape == (3, 4, 4)
+    for l in (0, 1):
+        v[0][l].copy_(fresh[l][0])
+    for l in range(L):
+        v[1][l].copy_(fresh[l][1])
+    eng.on_group([2, 1, 0], [[None, v[1][2]], [v[0][1], v[1][1]], [v[0][0], v[1][0]]])
+    eng.finish()
+    st = eng.last_stats
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    if rank == 0:
+        torch.save(dict(sd={k: v_.detach().clone() for k, v_ in model.state_dict().items()}, grads=grads, ids=ids_all, stats=st), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_in_place_group_buckets_with_late_small_kinds(tmp_path):
+    out = str(tmp_path / 'late.pt')
+    port = 21500 + (os.getpid() % 2000)
+    mp.spawn(_worker_flat_groups_late, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    (sum(_loss(model, r['ids'][i:i + 1]) for i in range(2)) / 2).backward()
+    for k, p in model.named_parameters():
+        if k == 'unused':
+            assert r['grads'][k] is None
+            continue
+        assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
+    assert r['stats']['buckets'] == 1 + 2 and r['stats'].get('direct_buckets') == 2, r['stats']
