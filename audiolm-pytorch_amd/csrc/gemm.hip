@@ -193,10 +193,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
+// counted wait on the vector-memory queue: at most N operations (here: LDS-DMA pieces, which retire in order) may still be in flight
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 8 || N == 16, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
 // Two LDS stages, one __syncthreads per K-step: the next step's DMA is in flight during the current step's MFMAs (prefetch distance 1).
 // (Deeper DMA rings, a hand software-pipelined loop, a persistent variant and B-from-registers variants were built and measured slower:
 // they live in the bench-only translation unit csrc/lab/gemm_lab.hip, results in DESIGN.md section 8.1.)
-template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int NS = 2>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int NW = WM * WN;
@@ -353,15 +362,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, con
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (Krem + BK - 1) / BK;
-    stage(0, smem);
-    __syncthreads();
+    if constexpr (NS == 2) {
+        stage(0, smem);
+        __syncthreads();
+    }
 
     // One K-step: issue the next stage's DMA into `dst`, read this stage's fragments from `sb`.  The two are DISTINCT buffers, and they are
     // `__restrict__` parameters on purpose: inlined, that becomes alias-scope metadata, without which the compiler makes every LDS read that has
     // no type-based alias info of its own -- the `ds_read_b64_tr_b16` transpose reads of the TN mode are such -- wait (`s_waitcnt vmcnt(0)`) for
     // ALL pending LDS-DMA: the DMA just issued.  The weight-gradient loops then ran DMA and MFMAs strictly one after the other.
     auto kstep = [&](unsigned char* __restrict__ dst, const unsigned char* __restrict__ sb, int kt) {
-        if (kt + 1 < nk) stage(kt + 1, dst);
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, dst);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a[TM], b[TNB];
@@ -391,11 +402,33 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, con
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);     // C^T block: lane = row m
         }
     };
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        kstep(smem + (buf ^ 1) * STAGE, smem + buf * STAGE, kt);
-        __syncthreads();          // reads of `buf` done (lgkmcnt 0), next stage landed (vmcnt 0), all waves agree
-        buf ^= 1;
+    if constexpr (NS == 2) {
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            kstep(smem + (buf ^ 1) * STAGE, smem + buf * STAGE, kt);
+            __syncthreads();          // reads of `buf` done (lgkmcnt 0), next stage landed (vmcnt 0), all waves agree
+            buf ^= 1;
+        }
+    } else {
+        // DMA RING of NS stages (round 5, the launches that cannot fill the chip: to_kv is 128 workgroups, one per CU at best, and with prefetch distance 1
+        // every K-step waited for one HBM / Infinity-Cache round trip -- 16 of them in a row): stage kt + NS - 1 is issued at the top of step kt, the wait
+        // before the step's barrier is COUNTED -- at most NS - 2 newer stages (8 pieces each per wave) may still be in flight -- so NS - 2 round trips are
+        // always hidden behind the current step.  One raw barrier per step orders both hazards: every wave's pieces of stage kt have landed (its counted
+        // wait precedes the barrier) and every wave has finished reading stage kt - 1, whose buffer the DMA issued right after the barrier overwrites.
+        static_assert(NIA + NIB == 8 && (NS == 3 || NS == 4), "counted waits below: 8 pieces per wave and stage");
+#pragma unroll
+        for (int s_ = 0; s_ < NS - 1; ++s_)
+            if (s_ < nk) stage(s_, smem + s_ * STAGE);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const int newer = min(nk - 1 - kt, NS - 2);               // stages issued after stage kt so far
+            if (newer >= 2) wait_vmcnt<16>(); else if (newer == 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(smem + ((kt + NS - 1) % NS) * STAGE, smem + (kt % NS) * STAGE, kt);
+        }
+        __syncthreads();              // the epilogue slabs reuse the stage buffers
     }
 
     // ---- epilogue: slabs reuse the (now idle) stage buffers ------------------------------------------------------------------------
@@ -408,6 +441,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, con
 template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmParams p) {
     gemm_body<BM, BN, WM, WN, TNMODE, OUT_F32>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+template <int BM, int BN, int WM, int WN, bool TNMODE, bool OUT_F32, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_ring_kernel(GemmParams p) {
+    gemm_body<BM, BN, WM, WN, TNMODE, OUT_F32, NS>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // TWO independent un-batched problems in one launch (round 5): workgroups [0, tiles0) run problem 0, the rest problem 1 -- for pairs of launches that sit
@@ -681,15 +719,6 @@ __global__ __launch_bounds__(512) void gemm_stag_group2_kernel(GemmParams p0, Ge
     const bool second = (int)blockIdx.x >= tiles0;
     const GemmParams& p = second ? p1 : p0;
     gemm_stag_body<TNMODE, OUT_F32>(p, second ? (int)blockIdx.x - tiles0 : (int)blockIdx.x, 0, 0);
-}
-
-// counted wait on the vector-memory queue: at most N operations (here: LDS-DMA pieces, which retire in order) may still be in flight
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 8 || N == 16, "add the literal");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 // ---- 256 x 256 x 64, FOUR waves (one per SIMD), wave tile 128 x 128 (tile id 14; NT and TN) -----------------------------------------------
@@ -1213,6 +1242,20 @@ int launch_cfg(const GemmParams& p, int ny, int nz, hipStream_t st) {
     return 0;
 }
 
+template <bool OUT_F32>
+int launch_ring(const GemmParams& p, int ny, int nz, hipStream_t st) {          // tile 16: 128 x 128, 4 waves, 4-stage DMA ring (128 KB of LDS, NT, raster 0)
+    constexpr int smem = 4 * (128 + 128) * BK * 2;
+    static bool attr_done = false;
+    auto kfn = gemm_ring_kernel<128, 128, 2, 2, false, OUT_F32, 4>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(((p.M + 127) / 128) * ((p.N + 127) / 128), ny, nz), dim3(256), smem, st, p);
+    return 0;
+}
+
 template <bool TNMODE, bool OUT_F32>
 int launch_stag(const GemmParams& p, int ny, int nz, hipStream_t st) {
     constexpr int smem = 163840;
@@ -1262,7 +1305,7 @@ int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
 // fewer rounds of 256 resident workgroups that it wins despite its 1.5x longer tile (measured per-tile cost ratio 1.41: W1 forward
 // 16384 x 5472: 6 rounds -> 4, +6 %; with N = 1024 it is 172 tiles on 256 CUs, -15 %).
 int pick_tile(int M, int N, int ny, int tile, bool tn) {
-    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14 || tile == 15) return tile;
+    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14 || tile == 15 || tile == 16) return tile;
     if (tile != 0) return -1;
     if (M < 256 || N < 256) return 1;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
@@ -1315,6 +1358,12 @@ int launch_gemm(const GemmParams& p0, int ny, int nz, int out_f32, int tile, hip
     static const int mid_tile = [] { const char* e = getenv("ALM_GEMM_MID_TILE"); return e ? atoi(e) : 0; }();
     if (!TNMODE && hook && mid_tile && tl == 1 && tile == 0 && p.ksplit == 0 && p.M >= 256 && p.N >= 512 &&
         (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * ny >= 192) tl = 15;
+    // tile 16 (round 5): the 128 x 128 tile with a 4-stage DMA ring, for NT launches of so few tiles that every CU holds at most one workgroup anyway
+    // (to_kv: 128) -- there the two-stage loop waits for one memory round trip per K-step.  ALM_GEMM_RING=0: off (A/B)
+    static const int ring_on = [] { const char* e = getenv("ALM_GEMM_RING"); return e ? atoi(e) : 1; }();
+    if (!TNMODE && hook && ring_on && tl == 1 && tile == 0 && p.ksplit == 0 && p.raster == 0 && p.K >= 256 &&
+        (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * ny * nz <= 256) tl = 16;
+    if (tl == 16) { if (TNMODE || p.raster != 0) return ALM_ERR_UNSUPPORTED; return out_f32 ? launch_ring<true>(p, ny, nz, st) : launch_ring<false>(p, ny, nz, st); }
     if (tl == 15) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
@@ -1484,7 +1533,8 @@ extern "C" int alm_gemm_splitk_tile(int M, int N, int K, int nb) { return splitk
 
 // Host-side plan queries (no launch, no GPU): which kernel a given launch WILL take.  Tests assert with them that the shapes of the benchmarked step
 // (B = 8: M = 16384) run on the big tiles the roofline is quoted on, bench.py files its per-kernel timings by them.
-//   alm_gemm_nt_tile_choice: block tile of alm_gemm_bf16_nt(M, N, nb = nb1 * nb2 problems): 1 = 128 x 128, 13 = 256 x 256 staggered, 11 = 384 x 256
+//   alm_gemm_nt_tile_choice: block tile of alm_gemm_bf16_nt(M, N, nb = nb1 * nb2 problems): 1 = 128 x 128 (launched in its 4-stage DMA-ring form, tile 16,
+//   when the whole launch is <= 256 such tiles and K >= 256), 13 = 256 x 256 staggered, 11 = 384 x 256
 //   (the ALM_GEMM_BIG_TILE / ALM_GEMM_W4_MINK A/B environment hooks are NOT applied: this is the shipped choice)
 extern "C" int alm_gemm_nt_tile_choice(int M, int N, int nb) { return pick_tile(M, N, nb < 1 ? 1 : nb, 0, false); }
 
