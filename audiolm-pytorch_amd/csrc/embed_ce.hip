@@ -678,6 +678,14 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
     for (int i = 0; i < ntables; ++i)
         if ((uintptr_t)t.p[i] & 15) return ALM_ERR_BAD_ARG;
     const int ngroups = t.grp_base[ntables];
+    if (rows == 0) {                                   // nothing maps anywhere: every table's gradient is zero (the scan below assumes at least one code)
+        for (int i = 0; i < ntables; ++i)
+            if (t.rows[i] > 0) {
+                hipError_t e = hipMemsetAsync(t.p[i], 0, (size_t)t.rows[i] * D * sizeof(float), (hipStream_t)stream);
+                if (e != hipSuccess) return (int)e;
+            }
+        return 0;
+    }
     if (t.nsmall > 0 && t.nchunks > 0) {
         if (!ws) return ALM_ERR_BAD_ARG;
         const size_t smem = 2 * OWN_CH * sizeof(int) + (size_t)t.nsmall * 256 * sizeof(float4);       // <= 256 B + 32 x 4 KB

@@ -1496,8 +1496,12 @@ extern "C" int alm_gemm_bf16_nt_group2(const void* A0, const void* B0, void* C0,
     p0.group_m = pick_group(p0, t0);
     p1.group_m = pick_group(p1, t1);
     auto launch = [&](auto kfn, int threads, int smem) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
+        static bool attr_done = false;                 // (one flag per kernel instantiation: the lambda is generic)
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
         hipLaunchKernelGGL(kfn, dim3(tiles0 + tiles1), dim3(threads), smem, st, p0, p1, tiles0);
         return 0;
     };

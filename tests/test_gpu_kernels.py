@@ -824,6 +824,15 @@ def test_embed_scatter_owned_is_exact_deterministic_and_needs_no_zero_fill(ops, 
     assert all(torch.allclose(a, b, atol=1e-4) for a, b in zip(outs[0], grads))
 
 
+def test_embed_scatter_owned_no_tokens(ops):
+    """rows == 0: every table gradient is written as zeros (no scan of an empty code array)"""
+    D = 64
+    big, small = torch.full((40, D), float('nan'), device=dev()), torch.full((2, D), float('nan'), device=dev())
+    e = torch.empty(0, dtype=torch.int32, device=dev())
+    ops.embed_scatter_owned([big, small], e, e, torch.empty(0, D, device=dev()), 1.0, 0, D)
+    assert float(big.abs().sum()) == 0 and float(small.abs().sum()) == 0
+
+
 def test_embed_scatter_owned_skewed_ids(ops):
     """every token on ONE destination row (the pending list of the owning wave is flushed many times) and a table with more rows than tokens"""
     D, rows = 256, 3000
