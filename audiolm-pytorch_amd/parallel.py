@@ -175,7 +175,7 @@ class DataParallelEngine:
                     if p.requires_grad and id(p) not in offs and id(p) not in skip:
                         offs[id(p)] = (o, p.numel())
                         o += p.numel()
-            ent = (torch.empty(o, dtype=torch.float32, device=dev), offs)
+            ent = (torch.zeros(o, dtype=torch.float32, device=dev), offs)      # (zeros: the alignment gaps between kinds take part in the all-reduce)
             self._flat_groups = {k: v for k, v in self._flat_groups.items() if k[:2] != (l0, l1)}        # one layout per layer range
             self._flat_groups[key] = ent
         flat, offs = ent
