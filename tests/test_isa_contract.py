@@ -54,3 +54,50 @@ def test_hc_bwd_lds_dma_variant_keeps_the_counted_wait_contract(tmp_path):
     body2 = after[:after.index('wait0')] if 'wait0' in after else after
     assert body2.count('store') >= 6 and 'load' not in body2 and 'dma' not in body2, body2
     assert 'wait0' not in ops[first:second + 8], 'no full drain inside the token loop'
+
+
+RING = 'gemm_ring_kernelILi128ELi128ELi2ELi2ELb0ELb0ELi4EE'          # <128, 128, 2, 2, NT, bf16 out, NS = 4>
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which('hipcc')), reason='needs hipcc')
+def test_gemm_ring_kernel_keeps_its_counted_waits(tmp_path):
+    """The 4-stage DMA-ring form of the 128 x 128 NT tile (csrc/gemm.hip, tile 16) orders its LDS-DMA by hand: per K-step ONE counted wait --
+    `s_waitcnt vmcnt(16)` in steady state (two newer stages of 8 pieces per wave may stay in flight), 8 and 0 in the drain -- then `lgkmcnt(0)` and a raw
+    `s_barrier`, then the 8 DMA pieces of stage kt + 3, then the MFMAs.  If the compiler ever put a full `vmcnt(0)` between the issue and the MFMAs (it
+    does when it cannot tell the DMA destination from the buffer being read) the ring would silently degrade to prefetch distance 0; if a piece were
+    added or dropped the counts 16 / 8 would be wrong and a stage could be read before it landed.  Checked on the compiler's output."""
+    out = str(tmp_path / 'gemm.s')
+    src = os.path.join(ROOT, 'audiolm-pytorch_amd', 'csrc', 'gemm.hip')
+    subprocess.run([HIPCC if os.path.exists(HIPCC) else 'hipcc', '-S', '--cuda-device-only', '--offload-arch=gfx950', '-O3', '-std=c++17', src, '-o', out],
+                   check=True, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    m = re.search(r'^(_Z\w*' + RING + r'\w*):.*?s_endpgm', text, re.S | re.M)
+    assert m, 'the ring instantiation is in the library'
+    meta = re.search(r'\.amdhsa_kernel ' + re.escape(m.group(1)) + r'.*?\.end_amdhsa_kernel', text, re.S).group(0)
+    assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', meta).group(1)) == 0
+    ev = []
+    for ln in m.group(0).split('\n'):
+        t = ln.strip()
+        if t.startswith('buffer_load_dwordx4') and ' lds' in t:
+            ev.append('dma')
+        elif t.startswith('v_mfma'):
+            ev.append('mfma')
+        elif t.startswith('s_barrier'):
+            ev.append('bar')
+        elif t.startswith('s_waitcnt') and 'vmcnt' in t:
+            ev.append('wait' + re.search(r'vmcnt\((\d+)\)', t).group(1))
+    assert {'wait16', 'wait8', 'wait0'} <= set(ev), sorted(set(ev))
+    # program order of the (rotated) loop in the listing: prologue = NS - 1 = 3 stages x 8 pieces | the step's 16 MFMAs as ONE uninterrupted run (no
+    # vector-memory wait between them: the in-flight stages stay in flight under the whole MFMA block) | the counted wait (0 / 8 / 16 by remaining stages)
+    # | raw barrier | the 8 pieces of stage kt + 3 | back edge
+    first_mfma = ev.index('mfma')
+    assert ev[:first_mfma] == ['dma'] * 24, ev[:first_mfma]
+    run = 0
+    while ev[first_mfma + run] == 'mfma':
+        run += 1
+    assert run == 16, run
+    tail = ev[first_mfma + run:]
+    i16 = tail.index('wait16')
+    assert all(e in ('wait0', 'wait8') for e in tail[:i16]), tail[:i16]          # the drain variants of the same wait, nothing else
+    assert tail[i16 + 1] == 'bar' and tail[i16 + 2:i16 + 10] == ['dma'] * 8, tail[i16:i16 + 12]
+    assert tail[i16 + 10:i16 + 12] == ['wait0', 'bar'], tail[i16 + 10:i16 + 14]  # loop exit: everything landed before the epilogue reuses the stage buffers
