@@ -17,6 +17,10 @@ _P, _I, _L, _F, _U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 # name -> argtypes (all return int).  Kept in sync with include/audiolm_hip.h (tests/test_cabi.py checks both directions).
 SIGNATURES = {
     'alm_gemm_bf16_nt': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _P],
+    'alm_gemm_bf16_nt_ws': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _P, _L, _P],
+    'alm_gemm_bf16_nt_inl': [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _I, _I, _P, _L, _P],
+    'alm_gemm_nt_plan': [_I, _I, _I, _I, _I, _P],
+    'alm_gemm_nt_ws_bytes': [],
     'alm_gemm_splitk_slices': [_I, _I, _I, _I],
     'alm_gemm_splitk_ws_floats': [_I, _I, _I, _I],
     'alm_gemm_splitk_tile': [_I, _I, _I, _I],

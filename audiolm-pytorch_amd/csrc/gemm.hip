@@ -63,6 +63,11 @@ struct GemmParams {
                        // runs a contiguous chunk of that order, ~32 tiles at a time = group_m x (32 / group_m) tiles sharing A / B panels in its L2.
                        // < 0: groups of |group_m| tile COLUMNS instead (the B panel is the resident one).  Chosen per launch by pick_group()
     int nt_store = 0;  // 1: the C tile is written with non-temporal stores (does not displace the operand panels in the L2)
+    // in-launch split-K (round 6, gemm_stag_inl_kernel): blockIdx.z = K slice (ksplit elements each); every slice writes its fp32 accumulators to its slab of
+    // `inl_ws`, the LAST ARRIVER of a tile (ticket counter inl_cnt[tile]) sums the slabs in slice order and runs the normal epilogue
+    float* inl_ws = nullptr;
+    unsigned* inl_cnt = nullptr;
+    int inl_slices = 0;
 };
 
 // logical block id -> (tile row, tile column): groups of g tile rows (g > 0) or of |g| tile columns (g < 0), the other dimension running fastest
@@ -484,7 +489,7 @@ __device__ unsigned long long g_gemm_probe[16384 * 8];
 // LDS (160 KB): the A operand is PRIVATE to a wave row (row g only reads tile rows g*128 .. +127): 2 buffers x 16 KB per row; the B
 // operand is shared by both rows and lives 5 slots (written in slots 2j, 2j+1, read in 2j+3, 2j+4): 3 buffers x 32 KB.  Row g loads its
 // own A half and the B pieces [16 g, 16 g + 16): 8 one-KiB DMA pieces per wave and stage, as before.
-template <bool TNMODE, bool OUT_F32>
+template <bool TNMODE, bool OUT_F32, bool INL = false>
 __device__ __forceinline__ void gemm_stag_body(const GemmParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     GPROBE_DECL
@@ -701,6 +706,69 @@ __device__ __forceinline__ void gemm_stag_body(const GemmParams& p, const int bx
     if (wr == 0) __syncthreads();                                           // row 0: slots 2 nk + 2, 2 nk + 3;  row 1: slot 2 nk + 3
     __builtin_amdgcn_s_barrier();
 
+    if constexpr (INL) {
+        // ---- in-launch split-K: publish this slice's accumulators, the tile's last arriver reduces (cdna_hip_programming.md, "In-launch split-K reduction";
+        // section 6 guideline 16).  Slab layout = the accumulators' own: 16-byte chunk c = (i, j, quad) of thread t at byte (c * 512 + t) * 16 -- every wave
+        // instruction moves 1 KiB of contiguous bytes.  Stores are WRITE-THROUGH (sc1: visible in memory without an L2 write-back fence), every wave
+        // drains them, the barrier collects the waves, ONE lane takes the ticket (relaxed, agent scope).  The reducer reads the slabs with sc1 loads (served
+        // by the L2 / fabric, never by this CU's L1).  Deterministic for any arrival order: 2 slices -> own + other (IEEE addition commutes); more ->
+        // every slab, the reducer's own included, is re-read and summed in slice order 0, 1, 2, ...
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int SLAB_BYTES = BM * BN * 4, NCHUNK = TM * TNB * 4;
+        const int S = p.inl_slices;
+        const int tile_lin = zb * (tiles_m * tiles_n) + tm * tiles_n + tn;
+        unsigned char* const slab0 = reinterpret_cast<unsigned char*>(p.inl_ws) + (long long)tile_lin * S * SLAB_BYTES;
+        {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (long long)zs * SLAB_BYTES, 0, SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TNB; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x4 v = {__float_as_uint(acc[i][j][4 * g]), __float_as_uint(acc[i][j][4 * g + 1]), __float_as_uint(acc[i][j][4 * g + 2]),
+                                         __float_as_uint(acc[i][j][4 * g + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, t * 16, ((i * TNB + j) * 4 + g) * 8192, 16);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // EVERY storing wave drains its write-through stores ...
+        __syncthreads();                                                    // ... before the one ticket is taken
+        unsigned* const flag = reinterpret_cast<unsigned*>(smem + 163840 - 16);   // beyond every epilogue slab (64 KB): the one LDS array, no second object
+        if (t == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.inl_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(p.inl_cnt + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning: zero again for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;                                             // whole workgroup (uniform)
+        // reduce: 4 chunks (16 VGPRs) of loads in flight at a time -- 128 accumulator registers + the loop state are live (8 chunks spilled)
+        auto add_slab = [&](int sl, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;                 // FIRST: acc = slab (the ordered sum starts from slab 0), else acc += slab
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (long long)sl * SLAB_BYTES, 0, SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int cb = 0; cb < NCHUNK; cb += 4) {
+                u32x4 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, (cb + c) * 8192, 16);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ai = (cb + c) / (4 * TNB), aj = ((cb + c) / 4) % TNB, ar = 4 * ((cb + c) % 4) + e;
+                        acc[ai][aj][ar] = FIRST ? __uint_as_float(v[c][e]) : acc[ai][aj][ar] + __uint_as_float(v[c][e]);
+                    }
+            }
+        };
+        if (S == 2) {
+            add_slab(1 - zs, std::false_type{});
+        } else {
+            add_slab(0, std::true_type{});
+#pragma unroll 1
+            for (int sl = 1; sl < S; ++sl) add_slab(sl, std::false_type{});
+        }
+    }
+
     const long long coff0 = z1 * p.sC1 + z2 * p.sC2 + (p.ksplit > 0 ? zs * p.sCk : 0);
     GPROBE_T(5);
     gemm_epilogue<BM, BN, WM, WN, TM, TNB, OUT_F32>(p, acc, smem, coff0, m0, n0, wave, wr, wc, lane, lr, lh);
@@ -712,6 +780,12 @@ __device__ __forceinline__ void gemm_stag_body(const GemmParams& p, const int bx
 template <bool TNMODE, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_stag_kernel(GemmParams p) {
     gemm_stag_body<TNMODE, OUT_F32>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// in-launch split-K form of the staggered NT tile (round 6): grid (tiles, problems, K slices); see the INL block of gemm_stag_body
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_stag_inl_kernel(GemmParams p) {
+    gemm_stag_body<false, OUT_F32, true>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 template <bool TNMODE, bool OUT_F32>
@@ -1278,6 +1352,22 @@ int launch_stag(const GemmParams& p, int ny, int nz, hipStream_t st) {
 }
 
 
+// in-launch split-K launch of the staggered NT tile: p.inl_ws / p.inl_cnt / p.inl_slices / p.ksplit set by the caller (nt_launch_ws); raster 0
+template <bool OUT_F32>
+int launch_stag_inl(const GemmParams& p, int ny, hipStream_t st) {
+    constexpr int smem = 163840;
+    static bool attr_done = false;
+    auto kfn = gemm_stag_inl_kernel<OUT_F32>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+    hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n, ny, p.inl_slices), dim3(512), smem, st, p);
+    return 0;
+}
+
 template <bool TNMODE, bool OUT_F32>
 int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
     constexpr int smem = 131072;
@@ -1372,6 +1462,74 @@ int launch_gemm(const GemmParams& p0, int ny, int nz, int out_f32, int tile, hip
 
 bool view_too_big(long long rows, long long ld) { return rows * ld * 2 >= 0x7fffffffLL; }
 
+// ---- NT launches that cannot fill the chip with 256 x 256 tiles (round 6): in-launch split-K on the staggered tile ----------------------------------------
+// pick_tile() sends every NT launch with < 192 tiles of 256 x 256 to the 128 x 128 tile (twice the L2 -> LDS bytes per flop).  With a caller-owned workspace
+// the alternative is the staggered 256 x 256 tile with each tile's K range cut over S workgroups (gemm_stag_inl_kernel): tiles x S <= 256 workgroups = ONE
+// resident round of the chip.  MEASURED on MI355X (scripts/ab_nt_inl.py, every launch on a fresh operand set; profiles/r6a_nt_inl_cost.log, r6b_*):
+//   * a half-empty chip is NOT half as fast: one K-step of a 256 x 256 workgroup takes 1.2 us with 32 workgroups in flight, 1.6 us with 128, 2.0 us with 256
+//     (L2 / fabric contention), so cutting K in two over twice the workgroups saves ~35 %, not 50 %, of the main loop;
+//   * the publish + reduce is a BURST: every workgroup ends at the same time and writes its 256-KiB slab through to memory -- 16 us with 128 workgroups (32 MB),
+//     24 us with 256 (64 MB) -- and the 128 x 128 tile it competes with runs at 0.25-0.31 of the MFMA peak on these shapes (2 workgroups per CU, all CUs busy).
+//   Net: the split wins only on LONG contractions -- M = 8192, N = 1024, K = 5472 (dXN = dU W1): 116 -> 107 us; K = 2736: 66 vs 68 us (tie); K <= 1024: the
+//   128 x 128 tile wins by 1.5-2x (to_q at M = 16384: 24.5 vs 45.6 us).  A 256 x 128 tile (one round of 256 workgroups for N = 1024) measured 0-14 % SLOWER than
+//   the 128 x 128 tile on every shape.  The model below reproduces those decisions; its constants are the fitted ones:
+//     t(256^2, S >= 2) = ceil(ksteps / S) * (1.15 + 0.0033 W) + 7 + (8 + 0.04 W) + 2.6 * slabs read        [us; W = tiles x S workgroups]
+//     t(128^2)         = rounds of 512 resident workgroups * (ksteps * 1.31 + 4.5)   |   <= 256 tiles (4-stage ring form): ksteps * 0.72 + 4.5
+// Workspace: [1024 ticket counters, zero when handed over -- the kernel leaves them zero][tiles x S slabs of 256 KiB].
+constexpr long long INL_CNT_BYTES = 4096, INL_SLAB_BYTES = 256 * 256 * 4;
+struct NtPlan { int tile, slices; };
+
+NtPlan nt_plan(int M, int N, int K, int nb) {
+    static const int mode = [] { const char* e = getenv("ALM_GEMM_NT_INL"); return e ? atoi(e) : 1; }();     // 0: off (A/B), 1: cost model, >= 2: that many slices wherever they fit
+    const int base = pick_tile(M, N, nb, 0, false);
+    if (mode == 0 || base != 1 || M < 256 || N < 256) return NtPlan{base, 1};
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * nb;
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nb;
+    if (t256 > 128) return NtPlan{base, 1};                                     // (two slices must fit one resident round)
+    const int ksteps = (K + BK - 1) / BK;
+    double best_t = t128 <= 256 ? ksteps * 0.72 + 4.5 : (double)((t128 + 511) / 512) * (ksteps * 1.31 + 4.5);
+    NtPlan best{base, 1};
+    for (int S = 2; S <= 8; ++S) {
+        const long long W = t256 * S;
+        if (W > 256) break;
+        const int kc = (ksteps + S - 1) / S;
+        if (kc < 4) break;
+        if ((ksteps + kc - 1) / kc != S) continue;                              // (no empty slices)
+        const double t = kc * (1.15 + 0.0033 * W) + 7.0 + (8.0 + 0.04 * W) + 2.6 * (S == 2 ? 1 : S);
+        if (mode >= 2 ? (S == mode || best.slices == 1) : t < best_t) { best_t = t; best = NtPlan{13, S}; }
+    }
+    return best;
+}
+
+// launch of one (possibly batched) NT problem on the plan above; p: as for launch_gemm<false>, raster 0, no split.  ws == nullptr or too small: the
+// workspace-free choice of alm_gemm_bf16_nt
+int nt_launch_ws(const GemmParams& p0, int ny, int out_f32, int force_slices, void* ws, long long ws_bytes, hipStream_t st) {
+    NtPlan pl = nt_plan(p0.M, p0.N, p0.K, ny);
+    if (force_slices > 0) {
+        const long long t256 = (long long)((p0.M + 255) / 256) * ((p0.N + 255) / 256) * ny;
+        if (p0.M < 256 || p0.N < 256 || t256 > 1024) return ALM_ERR_UNSUPPORTED;
+        pl = NtPlan{13, force_slices};
+    }
+    if (force_slices == 0 && (pl.tile != 13 || pl.slices < 2)) return launch_gemm<false>(p0, ny, 1, out_f32, 0, st);      // the workspace-free choice
+    const long long tiles = (long long)((p0.M + 255) / 256) * ((p0.N + 255) / 256) * ny;
+    if (pl.slices == 1) return launch_gemm<false>(p0, ny, 1, out_f32, 13, st, false);      // (forced: the plain staggered tile)
+    const long long need = INL_CNT_BYTES + tiles * pl.slices * INL_SLAB_BYTES;
+    if (!ws || ws_bytes < need || ((uintptr_t)ws & 15)) {
+        if (force_slices > 0) return ALM_ERR_BAD_ARG;
+        return launch_gemm<false>(p0, ny, 1, out_f32, 0, st);
+    }
+    GemmParams p = p0;
+    const int ksteps = (p.K + BK - 1) / BK;
+    p.ksplit = (ksteps + pl.slices - 1) / pl.slices * BK;
+    p.sCk = 0;
+    p.inl_slices = (p.K + p.ksplit - 1) / p.ksplit;
+    if (p.inl_slices < 2) return launch_gemm<false>(p0, ny, 1, out_f32, 13, st, false);
+    p.inl_cnt = reinterpret_cast<unsigned*>(ws);
+    p.inl_ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + INL_CNT_BYTES);
+    p.group_m = pick_group(p, 13);
+    return out_f32 ? launch_stag_inl<true>(p, ny, st) : launch_stag_inl<false>(p, ny, st);
+}
+
 // Split-K plan for `nb` same-shape problems: choose (tile, slices) minimising a simple time model --
 //   block waves over the chip x K-steps per block x measured time per K-step  +  workspace round trip through HBM.
 // (A balanced "stream-K"-like split -- one equally long K-step range per CU -- measured SLOWER: the workgroups of an XCD then walk different
@@ -1464,6 +1622,61 @@ extern "C" int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const flo
     return 0;
 }
 
+// alm_gemm_bf16_nt with a caller-owned workspace (round 6): launches that leave most of the chip idle on 256 x 256 tiles (< 192 of them: every D- / 512-wide
+// projection at M = 8192, to_q / dAO at M = 16384) run on the staggered tile with IN-LAUNCH split-K when the measured cost model says so (nt_plan): each K
+// slice publishes its fp32 accumulators to `ws`, the tile's last arriver reduces them in fixed slice order and runs the usual epilogue -- bitwise
+// deterministic, no second launch, no atomics on data.  ws: >= alm_gemm_nt_ws_bytes() bytes, 16-byte aligned, its first 4096 bytes ZERO when first handed
+// over (ticket counters; every launch leaves them zero), used by ONE stream at a time.  ws == NULL (or too small): exactly alm_gemm_bf16_nt.
+extern "C" int alm_gemm_bf16_nt_ws(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                   int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2, float alpha,
+                                   int out_f32, int accumulate, void* ws, long long ws_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || nb1 <= 0 || nb2 <= 0) return 0;
+    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return ALM_ERR_BAD_ARG;
+    if (((sA1 | sA2 | sB1 | sB2) & 7) != 0) return ALM_ERR_BAD_ARG;
+    if (view_too_big(384, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate, 0, 0, 0, 1};
+    int rc = nt_launch_ws(p, nb1 * nb2, out_f32, 0, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same with a GIVEN number of K slices on the staggered 256 x 256 tile, un-batched (tests / the cost-model benchmark scripts/ab_nt_inl.py); slices = 1: the
+// plain staggered tile.  M, N >= 256.
+extern "C" int alm_gemm_bf16_nt_inl(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                                    float alpha, int out_f32, int accumulate, int slices, void* ws, long long ws_bytes, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || slices < 1 || slices > 16) return ALM_ERR_BAD_ARG;
+    if (view_too_big(384, lda) || view_too_big(256, ldb)) return ALM_ERR_UNSUPPORTED;
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)B, C, bias, M, N, K, lda, ldb, ldc, 1, 0, 0, 0, 0, 0, 0, alpha, accumulate, 0, 0, 0, 1};
+    int rc = nt_launch_ws(p, 1, out_f32, slices, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Host-side plan query of alm_gemm_bf16_nt_ws (no launch, no GPU): plan[0] = block tile (1 = 128 x 128, 16 = its 4-stage DMA-ring form, 13 = 256 x 256 staggered,
+// 11 = 384 x 256), plan[1] = K slices of the in-launch split-K form (1: none), plan[2] = workspace bytes that plan needs (0: none), plan[3] = workgroups
+extern "C" int alm_gemm_nt_plan(int M, int N, int K, int nb, int with_ws, int* plan) {
+    nb = nb < 1 ? 1 : nb;
+    NtPlan pl = with_ws ? nt_plan(M, N, K, nb) : NtPlan{pick_tile(M, N, nb, 0, false), 1};
+    int tile = pl.tile;
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nb;
+    static const int ring_on = [] { const char* e = getenv("ALM_GEMM_RING"); return e ? atoi(e) : 1; }();
+    if (tile == 1 && ring_on && K >= 256 && t128 <= 256) tile = 16;
+    const long long bm = tile == 11 ? 384 : (tile == 13 ? 256 : 128), bn = tile == 1 || tile == 16 ? 128 : 256;
+    const long long wgs = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nb * pl.slices;
+    if (plan) {
+        plan[0] = tile; plan[1] = pl.slices;
+        plan[2] = pl.slices > 1 ? (int)(INL_CNT_BYTES + (wgs * INL_SLAB_BYTES)) : 0;
+        plan[3] = (int)wgs;
+    }
+    return 0;
+}
+
+// workspace bytes that cover EVERY plan alm_gemm_bf16_nt_ws can choose (one resident round of 256 workgroups + the ticket counters)
+extern "C" int alm_gemm_nt_ws_bytes(void) { return (int)(INL_CNT_BYTES + 256 * INL_SLAB_BYTES); }
+
 // Two un-batched NT problems in ONE launch (gemm_group2_kernel / gemm_stag_group2_kernel): C0 = A0 . B0^T and C1 = A1 . B1^T, bf16 outputs (or fp32:
 // out_f32), no bias, alpha 1, no accumulation.  Both problems must pick the same block tile (128 x 128 or the staggered 256 x 256) and problem 0's
 // tile count must be a multiple of 8 (problem 1's workgroups keep the XCD <-> tile-order correspondence the rasterisation assumes); otherwise -- and
@@ -1483,7 +1696,15 @@ extern "C" int alm_gemm_bf16_nt_group2(const void* A0, const void* B0, void* C0,
     }
     if (bad(A0, B0, K0, lda0, ldb0) || bad(A1, B1, K1, lda1, ldb1)) return ALM_ERR_BAD_ARG;
     if (view_too_big(384, lda0) || view_too_big(256, ldb0) || view_too_big(384, lda1) || view_too_big(256, ldb1)) return ALM_ERR_UNSUPPORTED;
-    const int t0 = pick_tile(M0, N0, 1, 0, false), t1 = pick_tile(M1, N1, 1, 0, false);
+    int t0 = pick_tile(M0, N0, 1, 0, false), t1 = pick_tile(M1, N1, 1, 0, false);
+    // round 6, measured and NOT adopted (switch kept for A/B runs, default off): two problems that are each too small for the big tile (< 192 tiles of
+    // 256 x 256) but TOGETHER fill the chip in one round on the staggered tile (dXN_q || dX_kv at M = 8192: 128 + 128 tiles) -- 23.1 us against 22.3 us on
+    // the 128 x 128 tile (profiles/r6b_group2.log): K = 512 / 128 is 8 / 2 K-steps, the staggered tile's fill + drain dominates
+    static const int grp_big = [] { const char* e = getenv("ALM_GEMM_GROUP2_BIG"); return e ? atoi(e) : 0; }();
+    if (grp_big && t0 == 1 && t1 == 1 && M0 >= 256 && N0 >= 256 && M1 >= 256 && N1 >= 256) {
+        const long long a = (long long)((M0 + 255) / 256) * ((N0 + 255) / 256), b = (long long)((M1 + 255) / 256) * ((N1 + 255) / 256);
+        if (a + b >= 192 && a + b <= 256 && (a & 7) == 0) t0 = t1 = 13;
+    }
     const int bm = t0 == 1 ? 128 : 256;
     const int tiles0 = ((M0 + bm - 1) / bm) * ((N0 + bm - 1) / bm), tiles1 = ((M1 + bm - 1) / bm) * ((N1 + bm - 1) / bm);
     if (!on || t0 != t1 || (t0 != 1 && t0 != 13) || (tiles0 & 7)) {
@@ -1495,20 +1716,22 @@ extern "C" int alm_gemm_bf16_nt_group2(const void* A0, const void* B0, void* C0,
     GemmParams p1{(const bf16_t*)A1, (const bf16_t*)B1, C1, nullptr, M1, N1, K1, lda1, ldb1, ldc1, 1, 0, 0, 0, 0, 0, 0, 1.f, 0, 0, 0, 0, 1};
     p0.group_m = pick_group(p0, t0);
     p1.group_m = pick_group(p1, t1);
-    auto launch = [&](auto kfn, int threads, int smem) -> int {
-        static bool attr_done = false;                 // (one flag per kernel instantiation: the lambda is generic)
-        if (!attr_done) {
+    // ONE dynamic-LDS attribute flag PER KERNEL (`which`): the four kernels decay to one function-pointer type, so a generic lambda with a local static would
+    // share a single flag between them and only the first variant launched in a process would get its attribute (round-5 advisor finding)
+    auto launch = [&](auto kfn, int which, int threads, int smem) -> int {
+        static bool attr_done[4] = {false, false, false, false};
+        if (!attr_done[which]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr_done = true;
+            attr_done[which] = true;
         }
         hipLaunchKernelGGL(kfn, dim3(tiles0 + tiles1), dim3(threads), smem, st, p0, p1, tiles0);
         return 0;
     };
     int rc;
-    if (t0 == 1) rc = out_f32 ? launch(gemm_group2_kernel<128, 128, 2, 2, false, true>, 256, 2 * (128 + 128) * BK * 2)
-                              : launch(gemm_group2_kernel<128, 128, 2, 2, false, false>, 256, 2 * (128 + 128) * BK * 2);
-    else rc = out_f32 ? launch(gemm_stag_group2_kernel<false, true>, 512, 163840) : launch(gemm_stag_group2_kernel<false, false>, 512, 163840);
+    if (t0 == 1) rc = out_f32 ? launch(gemm_group2_kernel<128, 128, 2, 2, false, true>, 0, 256, 2 * (128 + 128) * BK * 2)
+                              : launch(gemm_group2_kernel<128, 128, 2, 2, false, false>, 1, 256, 2 * (128 + 128) * BK * 2);
+    else rc = out_f32 ? launch(gemm_stag_group2_kernel<false, true>, 2, 512, 163840) : launch(gemm_stag_group2_kernel<false, false>, 3, 512, 163840);
     if (rc) return rc;
     ALM_LAUNCH_CHECK();
     return 0;

@@ -4,6 +4,7 @@ memory and the stream; all arithmetic happens in libaudiolm_hip.so.  No CPU / ea
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -47,6 +48,20 @@ def _rows_ld(t):
 
 # ------------------------------------------------------------------------------------------------ dense contractions
 
+# Workspace of the in-launch split-K NT launches (alm_gemm_bf16_nt_ws): one persistent buffer per (device, stream) -- a launch owns its slabs and ticket
+# counters until it retires, and launches on ONE stream retire in order.  Zeroed once (the counters; every launch leaves them zero).  64 MB + 4 KB.
+_NT_WS = {}
+NT_WS = os.environ.get('ALM_GEMM_NT_WS', '1') != '0'           # A/B switch: 0 = never hand a workspace over (the round-5 launches)
+
+
+def _nt_ws(dev, stream):
+    key = (dev.index, stream)
+    ws = _NT_WS.get(key)
+    if ws is None:
+        ws = _NT_WS[key] = torch.zeros(_lib.query('alm_gemm_nt_ws_bytes'), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
     """C[..., M, N] (+)= alpha * A[..., M, K] @ B[..., N, K]^T (+ bias).  Up to two leading batch dims (broadcast via stride 0)."""
     _chk(A, BF16), _chk(B, BF16), _chk(C)
@@ -62,8 +77,26 @@ def gemm_nt(A, B, C, *, bias=None, alpha=1.0, accumulate=False):
         j = 2 - nb + i
         bs[j] = A.shape[i]
         sa[j], sb[j], sc[j] = A.stride(i), B.stride(i) if B.shape[i] != 1 else 0, C.stride(i)
-    _lib.call('alm_gemm_bf16_nt', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2),
-              bs[0], bs[1], sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), int(C.dtype == F32), int(accumulate), _st())
+    st = _st()
+    if NT_WS and M >= 256 and N >= 256:
+        ws = _nt_ws(A.device, st)
+        _lib.call('alm_gemm_bf16_nt_ws', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2),
+                  bs[0], bs[1], sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), int(C.dtype == F32), int(accumulate), ws.data_ptr(), ws.numel(), st)
+    else:
+        _lib.call('alm_gemm_bf16_nt', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2),
+                  bs[0], bs[1], sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(alpha), int(C.dtype == F32), int(accumulate), st)
+    return C
+
+
+def gemm_nt_inl(A, B, C, slices, *, bias=None, alpha=1.0, accumulate=False):
+    """un-batched gemm_nt on the staggered 256 x 256 tile with a GIVEN number of in-launch K slices (alm_gemm_bf16_nt_inl): tests / benchmarks"""
+    _chk(A, BF16), _chk(B, BF16), _chk(C)
+    M, K = A.shape
+    N = B.shape[0]
+    st = _st()
+    ws = _nt_ws(A.device, st)
+    _lib.call('alm_gemm_bf16_nt_inl', A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), M, N, K, A.stride(0), B.stride(0), C.stride(0),
+              float(alpha), int(C.dtype == F32), int(accumulate), int(slices), ws.data_ptr(), ws.numel(), st)
     return C
 
 

@@ -470,6 +470,19 @@ def main():
     def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
         return M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) * nb >= 192
 
+    import ctypes as _ct
+    from audiolm_pytorch_amd import _lib as _L
+    _plan = (_ct.c_int * 4)()
+    model_dim = int(W['ctor']['dim'])
+
+    def nt_kind(M_, N_, K_, nb):
+        """kernel key of an ops.gemm_nt launch, from the library's own plan query (alm_gemm_nt_plan): nt256 = a big tile on a launch that fills the chip (the
+        dominant kernel), nt256sk = the staggered 256 x 256 tile on an UNDER-FILLED launch (round 6: in-launch split-K, or unsplit), nt128 = the 128 x 128 tile"""
+        _L.query('alm_gemm_nt_plan', M_, N_, K_, nb, int(ops.NT_WS and M_ >= 256 and N_ >= 256), _ct.cast(_plan, _ct.c_void_p))
+        if _plan[0] in (11, 13):
+            return 'nt256' if big_tile(M_, N_, nb) else 'nt256sk'
+        return 'nt128'
+
     def esz(t):
         return 0 if t is None else t.element_size()
 
@@ -482,10 +495,14 @@ def main():
             for d in Am.shape[:-2]:
                 nb *= d
             Mm, Nn, Kk = Am.shape[-2], Bm.shape[-2], Am.shape[-1]
-            return 2.0 * nb * Mm * Nn * Kk, 'flop', ('nt256' if big_tile(Mm, Nn, nb) else 'nt128')
+            # the split-bf16 logit heads run ONE K-concatenated GEMM [hi | hi | lo] x [Whi | Wlo | Whi] (heads.py): 3 K executed, K algorithmic
+            k_alg = Kk // 3 if (a[2].dtype == torch.float32 and Kk == 3 * model_dim and Am.dim() == 3) else Kk
+            return 2.0 * nb * Mm * Nn * k_alg, 'flop', nt_kind(Mm, Nn, Kk, nb)
         if name == 'gemm_nt_group2':                                             # two un-batched problems in one launch (to_q || to_kv, their two dgrads)
             (M0, K0), N0, (M1, K1), N1 = a[0].shape, a[1].shape[0], a[3].shape, a[4].shape[0]
-            return 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), 'flop', ('nt256' if big_tile(M0, N0, 1) else 'nt128')
+            t0_, t1_ = ((M0 + 255) // 256) * ((N0 + 255) // 256), ((M1 + 255) // 256) * ((N1 + 255) // 256)
+            grp_big = os.environ.get('ALM_GEMM_GROUP2_BIG', '0') != '0' and min(M0, N0, M1, N1) >= 256 and 192 <= t0_ + t1_ <= 256 and t0_ % 8 == 0   # mirrors alm_gemm_bf16_nt_group2
+            return 2.0 * (M0 * N0 * K0 + M1 * N1 * K1), 'flop', ('nt256' if big_tile(M0, N0, 1) else 'nt256sk' if grp_big else 'nt128')
         if name == 'gemm_tn_splitk':
             At, Bt = a[0], a[1]
             nb = At.shape[0] if At.dim() == 3 else 1
@@ -577,6 +594,7 @@ def main():
     PEAK_HBM_GBS = 8000.0
     desc = {'nt256': 'gemm_stag_kernel<NT> 256x256 / gemm_kernel<384,256,NT>: forward + dgrad GEMMs on the big tiles (dominant)',
             'nt128': 'NT GEMMs on the 128x128 tile or grouped launches (attention projections, logit heads)',
+            'nt256sk': 'gemm_stag_inl_kernel / gemm_stag(_group2)_kernel<NT> on launches of < 192 tiles: in-launch split-K (last-arriver reduce) or unsplit',
             'tn256': 'gemm_stag_kernel<TN>: weight gradients on the big tile, all layers of a weight kind per launch (deferred mode) or split-K per layer', 'tn128': 'weight gradients on the 128x128 tile (split-K)',
             'mqa_fwd': 'mqa_fwd_kernel (causal flash attention forward)', 'mqa_bwd': 'attn_delta + mqa_bwd_dq + mqa_bwd_dkv (flash attention backward)',
             'hc_fwd': 'hc_fwd_kernel (depth + width connection + pre-LayerNorm, fused)', 'hc_bwd': 'hc_bwd_kernel (+ its colsum / param-grad launches)',

@@ -29,6 +29,22 @@ extern "C" {
 int alm_gemm_bf16_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb,
                      long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1,
                      long long sC2, float alpha, int out_f32, int accumulate, void* stream);
+/* alm_gemm_bf16_nt with a caller-owned workspace (round 6): NT launches that leave most of the chip idle on 256 x 256 tiles (every D- / 512-wide projection
+ * of audiolm_pytorch.py:255-259, :351, :395 at M = 8192 rows; to_q / dAO at M = 16384) run on the staggered 256 x 256 tile with IN-LAUNCH split-K when the
+ * measured cost model picks it (alm_gemm_nt_plan): each K slice publishes its fp32 accumulators to `ws`, the tile's LAST ARRIVER (per-tile ticket counter,
+ * agent scope) sums them in fixed slice order and runs the usual epilogue (alpha, bias, accumulate, bf16 / fp32) -- bitwise deterministic, one launch.
+ * ws: alm_gemm_nt_ws_bytes() bytes, 16-byte aligned, used by one stream at a time; its first 4096 bytes (the counters) must be ZERO when first handed over,
+ * every launch leaves them zero.  ws == NULL or too small: exactly alm_gemm_bf16_nt. */
+int alm_gemm_bf16_nt_ws(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                        int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2, float alpha,
+                        int out_f32, int accumulate, void* ws, long long ws_bytes, void* stream);
+/* un-batched, with a GIVEN number of K slices on the staggered 256 x 256 tile (tests / scripts/ab_nt_inl.py); slices 1 = the plain staggered tile; M, N >= 256 */
+int alm_gemm_bf16_nt_inl(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                         float alpha, int out_f32, int accumulate, int slices, void* ws, long long ws_bytes, void* stream);
+/* plan of alm_gemm_bf16_nt_ws (with_ws = 1) / alm_gemm_bf16_nt (0) for nb problems, no launch: plan[0] = block tile (1 = 128 x 128, 16 = its 4-stage DMA-ring
+ * form, 13 = 256 x 256 staggered, 11 = 384 x 256), plan[1] = K slices (1: no split), plan[2] = workspace bytes that plan uses, plan[3] = workgroups */
+int alm_gemm_nt_plan(int M, int N, int K, int nb, int with_ws, int* plan);
+int alm_gemm_nt_ws_bytes(void);
 /* two independent un-batched NT problems (bf16 or fp32 outputs, no bias, alpha 1) in ONE launch: pairs of projections that sit next to each other in
  * the step and each leave most of the chip idle on their own -- to_q || to_kv (audiolm_pytorch.py:351 / :347: x_norm . Wq^T beside x . Wkv^T) and their two
  * dgrads.  Falls back to two launches when the problems do not pick the same tile; results are identical either way. */

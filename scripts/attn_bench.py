@@ -1,4 +1,5 @@
-"""Times the flash MQA attention launches at the headline shape (B=8, N=2048, H=8, dh=64, key mask on: the CoarseTransformer training call).
+"""Times the flash MQA attention launches at the timed shapes (B=8, H=8, dh=64, key mask on: the training call): N = 2048 (headline), 1024 (configs[1]),
+2049 (configs[2]), 8253 (configs[4]), 16385 (fine_t2048_q8).   usage: python scripts/attn_bench.py [N ...]
 A/B of two builds on ONE box:  ALM_LIB_PATH=/path/to/other/libaudiolm_hip.so python scripts/attn_bench.py"""
 import os
 import sys
@@ -29,8 +30,8 @@ def timeit(fn, iters=30, warm=5):
     return best * 1e3
 
 
-def main():
-    B, N, H, d = 8, 2048, 8, 64
+def run(N):
+    B, H, d = 8, 8, 64
     q = torch.randn(B * N, H * d, device=dev).to(BF16)
     kv = torch.randn(B * N, 2 * d, device=dev).to(BF16)
     k, v = kv[:, :d], kv[:, d:]
@@ -38,11 +39,13 @@ def main():
     mask[:, 0] = 1
     do = torch.randn(B * N, H * d, device=dev).to(BF16)
     o, lse = ops.mqa_attn_fwd(q, k, v, mask, B, N, H, d)
-    tf = timeit(lambda: ops.mqa_attn_fwd(q, k, v, mask, B, N, H, d))
-    tb = timeit(lambda: ops.mqa_attn_bwd(q, k, v, mask, o, lse, do, B, N, H, d))
-    fl = 4.0 * B * H * N * N * d / 2
-    print(f'{os.environ.get("ALM_LIB_PATH", "default")}: fwd {tf:7.1f} us ({fl / tf / 1e6:5.0f} TF)   bwd (delta + dQ + dK/dV) {tb:7.1f} us ({2.5 * fl / tb / 1e6:5.0f} TF)', flush=True)
+    it = 30 if N <= 4096 else 5
+    tf = timeit(lambda: ops.mqa_attn_fwd(q, k, v, mask, B, N, H, d), iters=it, warm=2)
+    tb = timeit(lambda: ops.mqa_attn_bwd(q, k, v, mask, o, lse, do, B, N, H, d), iters=it, warm=2)
+    fl = 4.0 * B * H * N * (N + 1) * d / 2
+    print(f'{os.environ.get("ALM_LIB_PATH", "default")} B={B} N={N}: fwd {tf:7.1f} us ({fl / tf / 1e6:5.0f} TF)   bwd (delta + dQ + dK/dV) {tb:7.1f} us ({2.5 * fl / tb / 1e6:5.0f} TF)', flush=True)
 
 
 if __name__ == '__main__':
-    main()
+    for N_ in [int(a) for a in sys.argv[1:]] or [1024, 2048, 2049, 8253, 16385]:
+        run(N_)

@@ -32,7 +32,10 @@ Compared END TO END: the loss, EVERY logit, and the gradient of EVERY parameter,
       forward <= 1e-3, measured <= 7e-5; backward <= 3e-3; cancelling hyper-connection scalar gradients <= 1e-2).
 Synthetic hyper-connection weights are width-scaled (tests/golden/common.py): the dynamic pre-activations keep a std of ~0.4 at dim 1024.
 test_full_size_matches_real_reference_digest compares the HIP path DIRECTLY with digests of the REAL reference at these sizes (tests/golden/full_*.pt).
-Every run appends its numbers to gpurun_out/r5_fullsize_parity.jsonl (copied to profiles/ for the record).
+Every run appends its numbers to gpurun_out/r6_fullsize_parity.jsonl (copied to profiles/ for the record).
+Round 6: the TIMED batch shapes of the other BASELINE configurations -- configs[1] at B = 8 x N = 1024 (M = 8192: every NT output of width 1024 / 512 is
+an under-filled launch there), configs[2] at B = 8 x N = 2049 (M = 16 392: a ragged last tile row in every GEMM and hyper-connection launch), and
+configs[4]'s MODEL (codebook 4096: C = 4097-column coarse heads over 3 x 4097-row tables) at its own N = 8253, B = 1.
 """
 import json
 import os
@@ -50,17 +53,18 @@ import rounding_matched as RM
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r5_fullsize_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r6_fullsize_parity.jsonl')
 
 
 def _case(kind, streams, N_kind, batch=None):
     g = torch.Generator().manual_seed(1234)
     extra = {} if streams == 4 else dict(num_residual_streams=streams)
     if kind == 'coarse':
-        ctor = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3, flash_attn=True, **extra)
-        ns, nf = (253, 256) if N_kind == 1024 else (509, 512)
+        cb = 4096 if N_kind == 8253 else 1024                                  # N = 8253: BASELINE configs[4]'s model
+        ctor = dict(dim=1024, depth=6, num_semantic_tokens=500, codebook_size=cb, num_coarse_quantizers=3, flash_attn=True, **extra)
+        ns, nf = {1024: (253, 256), 2048: (509, 512), 8253: (1500, 2250)}[N_kind]
         B = batch or (2 if N_kind == 1024 else 1)
-        inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, ns), generator=g), coarse_token_ids=torch.randint(0, 1024, (B, nf, 3), generator=g))
+        inputs = dict(semantic_token_ids=torch.randint(0, 500, (B, ns), generator=g), coarse_token_ids=torch.randint(0, cb, (B, nf, 3), generator=g))
         N = 1 + (ns + 1) + 1 + nf * 3
         inputs['forgetful_mask'] = O.generate_mask_with_prob((B, N), 0.15, 'cpu', generator=g)
         options = dict(training=True, unique_consecutive=False, mask_prob=0.15)
@@ -81,7 +85,10 @@ def _case(kind, streams, N_kind, batch=None):
                           ('fine', 4, 2049, 'fp32', None), ('fine', 4, 2049, 'bf16', None), ('fine', 1, 2049, 'fp32', None),
                           ('coarse-default-init', 4, 2048, 'bf16', None),
                           # round 4: the BENCHMARKED shape itself -- B = 8 x N = 2048, bf16 streams, synthetic and default (= bench.py's) initialisation
-                          ('coarse', 4, 2048, 'bf16', 8), ('coarse-default-init', 4, 2048, 'bf16', 8)])
+                          ('coarse', 4, 2048, 'bf16', 8), ('coarse-default-init', 4, 2048, 'bf16', 8),
+                          # round 6: the other configurations AT THEIR TIMED SHAPES -- configs[1] B = 8 x N = 1024, configs[2] B = 8 x N = 2049 (ragged
+                          # M = 16 392), configs[4]'s codebook-4096 model at N = 8253 (reference audiolm_pytorch.py:896-906, 965-983)
+                          ('coarse', 4, 1024, 'bf16', 8), ('fine', 4, 2049, 'bf16', 8), ('coarse', 4, 8253, 'bf16', 1)])
 def test_full_size_matches_oracle(kind, streams, N_kind, residual, batch):
     """residual: HBM storage of the 4 residual streams (bf16 = the benchmark's setting = what autocast gives the reference).
     batch = 8: M = 16 384 rows, the shape bench.py times -- the big-tile NT GEMMs, the hybrid-plan batched weight gradients and the stacked buffers of the
@@ -101,8 +108,16 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual, batch):
         import ctypes
         from audiolm_pytorch_amd import _lib
         plan = (ctypes.c_int * 4)()
-        assert _lib.query('alm_gemm_nt_tile_choice', B * N, 2 * 2736, 1) == 11 and _lib.query('alm_gemm_nt_tile_choice', B * N, 1024, 1) == 13
-        assert _lib.query('alm_gemm_tn_batched_plan', 2730, 1024, B * N, 12, ctypes.cast(plan, ctypes.c_void_p)) == 2
+        if N_kind == 1024:
+            # configs[1]'s timed shape, M = 8192: the two wide FFN GEMMs are on the big tiles; every D- / 512-wide output is an under-filled launch (128 / 64
+            # tiles of 256 x 256) -- the long contraction (dXN = dU W1, K = 5472) takes the in-launch split-K form of the staggered tile (round 6: the one shape
+            # where it measured faster), W2 / to_out stay on the 128 x 128 tile, to_q / to_kv on its 4-stage DMA-ring form
+            assert _lib.query('alm_gemm_nt_tile_choice', B * N, 2 * 2736, 1) in (11, 13)
+            q = lambda n_, k_: (_lib.query('alm_gemm_nt_plan', B * N, n_, k_, 1, 1, ctypes.cast(plan, ctypes.c_void_p)), plan[0], plan[1])[1:]
+            assert q(1024, 2 * 2736) == (13, 2) and q(1024, 2736)[1] == 1 and q(1024, 512) == (1, 1) and q(512, 1024) == (16, 1) and q(128, 1024) == (16, 1)
+        else:
+            assert _lib.query('alm_gemm_nt_tile_choice', B * N, 2 * 2736, 1) == 11 and _lib.query('alm_gemm_nt_tile_choice', B * N, 1024, 1) == 13
+            assert _lib.query('alm_gemm_tn_batched_plan', 2730, 1024, B * N, 12, ctypes.cast(plan, ctypes.c_void_p)) == 2
     K = dict(coarse=A.CoarseTransformer, fine=A.FineTransformer)[kind]
     torch.manual_seed(7)
     m0 = K(**ctor)
@@ -124,7 +139,7 @@ def test_full_size_matches_oracle(kind, streams, N_kind, residual, batch):
         nloss, nlogits, ngrads = oracle_run(fx)
     t0 = time.time()
     rloss = rlogits = rgrads = None
-    if batch is None:
+    if batch is None and N_kind != 8253:                                       # (one oracle pass each for the round-6 cases)
         with RM.rounding_matched(residual_bf16=(residual == 'bf16' and streams > 1)):    # (A) the rounding-matched oracle, same storage type of the streams
             rloss, rlogits, rgrads = oracle_run(fx)
         rlogits = [t.detach() for t in rlogits if t is not None]

@@ -72,6 +72,79 @@ def test_gemm_nt_tile_configs(ops, M, N, K, tile):
         assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'GEMM wrote outside its tile'
 
 
+@pytest.mark.parametrize('M,N,K,slices', [(8192, 1024, 2736, 2), (8192, 1024, 512, 2), (8192, 512, 1024, 4), (16384, 512, 1024, 2), (8192, 1024, 5472, 2),
+                                          (1000, 520, 1000, 3), (300, 256, 4096, 8), (515, 700, 264, 2), (2049, 1024, 2736, 4), (256, 256, 128, 2),
+                                          (8192, 1024, 2736, 1)])
+def test_gemm_nt_inlaunch_splitk(ops, M, N, K, slices):
+    """in-launch split-K of the staggered 256 x 256 NT tile (round 6, alm_gemm_bf16_nt_inl): every K slice publishes its fp32 accumulators, the tile's last
+    arriver reduces them in slice order and runs the epilogue.  Checked: values vs fp64 (full, ragged M / N, K tails, slices that the K range cannot fill),
+    both output types, the bias / alpha / accumulate epilogue, nothing written outside the output, BITWISE equality of repeated launches (whichever slice
+    arrives last) and of launches issued while another stream keeps part of the chip busy (uneven arrival order), and that the ticket counters are left
+    zero (the next launch on the same workspace is correct)."""
+    A, B = rnd(M, K, seed=31, dtype=BF16), rnd(N, K, seed=32, dtype=BF16)
+    ref = A.double() @ B.double().t()
+    for dt, tol in ((F32, 2e-5), (BF16, 4e-3)):
+        C = torch.full((M + 3, N + 8), float('nan'), dtype=dt, device=dev())
+        ops.gemm_nt_inl(A, B, C[:M, :N], slices)
+        assert relmax(C[:M, :N], ref) <= tol, f'in-launch split-K {M}x{N}x{K} / {slices} {dt}'
+        assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'wrote outside its tile'
+        first = C[:M, :N].clone()
+        side = torch.cuda.Stream()
+        X = rnd(4096, 4096, seed=33)
+        for rep in range(6):
+            if rep >= 3:                                      # a second stream occupies CUs: the slices of a tile start at different times
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        X = torch.tanh(X)
+            C2 = torch.full((M, N), float('nan'), dtype=dt, device=dev())
+            ops.gemm_nt_inl(A, B, C2, slices)
+            assert torch.equal(C2, first), f'in-launch split-K is not bitwise reproducible (repeat {rep})'
+        torch.cuda.synchronize()
+    ws = ops._nt_ws(A.device, ops._st())
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, 'ticket counters not left zero'
+    bias = rnd(N, seed=34)
+    C0 = rnd(M, N, seed=35)
+    C1 = C0.clone()
+    ops.gemm_nt_inl(A, B, C1, slices, bias=bias, alpha=0.5, accumulate=True)
+    assert relmax(C1, C0.double() + 0.5 * ref + bias.double()) <= 3e-5
+
+
+@pytest.mark.parametrize('M,N,K,nb', [(8192, 1024, 2736, 1), (8192, 512, 1024, 1), (16384, 512, 1024, 1), (8192, 1024, 5472, 1), (4096, 1025, 1024, 3),
+                                      (8192, 128, 1024, 1), (16384, 1024, 2736, 1)])
+def test_gemm_nt_with_workspace_follows_its_plan(ops, M, N, K, nb):
+    """ops.gemm_nt (alm_gemm_bf16_nt_ws) on the shapes of the timed steps: the result is right whatever the plan is, equals the forced-slices launch bit for bit
+    when the plan splits (same kernel, same slices), and the batched form (per-quantizer heads: nb problems) is covered by the same ticket / slab arithmetic"""
+    import ctypes
+    from audiolm_pytorch_amd import _lib
+    plan = (ctypes.c_int * 4)()
+    _lib.query('alm_gemm_nt_plan', M, N, K, nb, 1, ctypes.cast(plan, ctypes.c_void_p))
+    A, B = rnd(nb, M, K, seed=41, dtype=BF16), rnd(nb, N, K, seed=42, dtype=BF16)
+    C = torch.full((nb, M, N), float('nan'), dtype=BF16, device=dev())
+    ops.gemm_nt(A if nb > 1 else A[0], B if nb > 1 else B[0], C if nb > 1 else C[0])
+    for z in range(nb):
+        assert relmax(C[z], A[z].double() @ B[z].double().t()) <= 4e-3, (M, N, K, nb, list(plan))
+    if plan[1] > 1 and nb == 1:
+        C2 = torch.empty((M, N), dtype=BF16, device=dev())
+        ops.gemm_nt_inl(A[0], B[0], C2, plan[1])
+        assert torch.equal(C2, C[0])
+    print(f'alm_gemm_nt_plan({M}, {N}, {K}, nb={nb}) -> tile {plan[0]}, {plan[1]} K slices, {plan[2]} workspace bytes, {plan[3]} workgroups')
+
+
+def test_gemm_nt_group2_small_tile_then_big_tile_in_one_process(ops):
+    """round-5 advisor finding: the grouped launcher kept ONE dynamic-LDS attribute flag for its four kernels, so only the first variant launched in a process
+    got hipFuncAttributeMaxDynamicSharedMemorySize.  A 128 x 128 pair (64 KB of LDS) followed by a staggered 256 x 256 pair (160 KB) in the same process, both
+    output types, must both launch and be right."""
+    for odt in (BF16, F32):
+        for (M0, N0, K0), (M1, N1, K1) in (((2048, 512, 1024), (2048, 128, 1024)), ((16384, 1024, 512), (16384, 1024, 128)), ((8192, 1024, 512), (8192, 1024, 128))):
+            A0, B0 = rnd(M0, K0, seed=51, dtype=BF16), rnd(N0, K0, seed=52, dtype=BF16)
+            A1, B1 = rnd(M1, K1, seed=53, dtype=BF16), rnd(N1, K1, seed=54, dtype=BF16)
+            C0, C1 = torch.full((M0, N0), float('nan'), dtype=odt, device=dev()), torch.full((M1, N1), float('nan'), dtype=odt, device=dev())
+            ops.gemm_nt_group2(A0, B0, C0, A1, B1, C1)
+            torch.cuda.synchronize()
+            tol = 2e-5 if odt == F32 else 4e-3
+            assert relmax(C0, A0.double() @ B0.double().t()) <= tol and relmax(C1, A1.double() @ B1.double().t()) <= tol
+
+
 @pytest.mark.parametrize('shapes', [((2048, 512, 1024), (2048, 128, 1024)),        # to_q || to_kv: both on the 128 x 128 tile, 64 + 16 tiles
                                     ((16384, 1024, 512), (16384, 1024, 128)),      # dXN_q || dX_kv: both on the staggered 256 x 256 tile, 256 + 256 tiles
                                     ((1000, 520, 200), (300, 96, 72)),             # ragged, K tails, tiles0 = 40 (multiple of 8)

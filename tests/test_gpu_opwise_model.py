@@ -8,7 +8,7 @@ HIP model's `transformer.forward` and the oracle's `O.transformer` are swapped f
 ONE AND THE SAME hidden-state tensor (the real stack's output on these inputs) -- so what is compared is exactly: embeddings in, heads + CE +
 loss combination out, and their gradients.  The oracle side runs at the HIP path's rounding points (oracle/rounding_matched.py: split-bf16 head
 operands, bf16 dlogits) and, for the loss, also in plain fp32.
-Bounds (rel-Frobenius unless stated): forward <= 1e-3 (north_star's number; measured figures are printed and land in gpurun_out/r5_opwise_parity.jsonl),
+Bounds (rel-Frobenius unless stated): forward <= 1e-3 (north_star's number; measured figures are printed and land in gpurun_out/r6_opwise_parity.jsonl),
 gradients that pass through the bf16 dlogits <= 3e-3, fp32 weight / table gradients <= 1e-3, the loss |d| <= 1e-5 relative.
 Reference lines: CoarseTransformer.forward audiolm_pytorch.py:858-990, FineTransformer.forward :1136-1368, wrappers :1742-1854 / :2041-2137.
 """
@@ -28,7 +28,7 @@ from test_gpu_parity import Codec
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r5_opwise_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r6_opwise_parity.jsonl')
 bf = RM._bf
 
 
@@ -49,14 +49,17 @@ class _Stub:
         return self.hn if kw.get('return_flat_hidden') else self.hn.view(x.shape)
 
 
-@pytest.mark.parametrize('kind,batch', [('coarse', 8), ('fine', 2)])
+@pytest.mark.parametrize('kind,batch', [('coarse', 8), ('fine', 2), ('coarse4096', 1)])
 def test_embeddings_heads_and_cross_entropy_match_the_oracle_given_the_same_hidden_states(kind, batch):
     """coarse, B = 8: the benchmarked shape (the coarse head's three 4096 x 1025 x 1024 problems run on the staggered 256 x 256 tile there, the semantic
-    head on the 128 x 128 one); fine, B = 2: the zero-padded coarse head + the grouped fine head with its ragged tail (N = 2049)."""
+    head on the 128 x 128 one); fine, B = 2: the zero-padded coarse head + the grouped fine head with its ragged tail (N = 2049); coarse4096, B = 1
+    (round 6): BASELINE configs[4]'s model at its own N = 8253 -- the C = 4097-column coarse heads (three 2250 x 4097 x 1024 problems + the ragged
+    remainder, audiolm_pytorch.py:965-983), the 3 x 4097-row embedding table with the eos / next-quantizer aliasing (:896-906) and the CE over 4097 classes."""
     import audiolm_pytorch_amd as A
     from audiolm_pytorch_amd import audiolm_pytorch as AP
     dev = torch.device('cuda:0')
-    N_kind = 2048 if kind == 'coarse' else 2049
+    N_kind = dict(coarse=2048, fine=2049, coarse4096=8253)[kind]
+    kind = 'coarse' if kind == 'coarse4096' else kind
     ctor, inputs, options, N, B = _case(kind, 4, N_kind, batch)
     K = dict(coarse=A.CoarseTransformer, fine=A.FineTransformer)[kind]
     torch.manual_seed(7)
@@ -138,7 +141,7 @@ def test_embeddings_heads_and_cross_entropy_match_the_oracle_given_the_same_hidd
     full = dict(sd)
     full.update(params)
     if kind == 'coarse':
-        cfg = O.Cfg(dim=ctor['dim'], depth=ctor['depth'], streams=4, num_semantic_tokens=500, codebook_size=1024, num_coarse_quantizers=3)
+        cfg = O.Cfg(dim=ctor['dim'], depth=ctor['depth'], streams=4, num_semantic_tokens=500, codebook_size=ctor['codebook_size'], num_coarse_quantizers=3)
     else:
         cfg = O.Cfg(dim=ctor['dim'], depth=ctor['depth'], streams=4, codebook_size=1024, num_coarse_quantizers=3, num_fine_quantizers=5)
 
