@@ -931,6 +931,25 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDl, (lds_void*)rt, 4, vo, 0, 0, 0);
     };
 
+    // the same, BRANCH-FREE (the software-pipelined step issues these pieces between its MFMAs: one basic block, explicit schedule groups): the
+    // descriptor / pitch of the wave's operand (Q for kh == 0, dO for kh == 1) are scalar selects; an inactive wave fetches head 0's tile into its own slot
+    const auto rsX = kh ? rsD : rsQ;
+    const auto rsR = kh ? rsDl : rsL;
+    const unsigned ldx_bytes = (unsigned)((kh ? p.lddo : p.ldq) * 2), colx_bytes = (unsigned)(hclamp * DH * 2);
+    auto stage_piece = [&](unsigned char* __restrict__ tiles, int qt, int buf, int piece) {        // piece 0..7: tile rows 8 piece .. + 7; piece 8: the row terms
+        unsigned char* img = tiles + hl * 16384 + kh * 8192;
+        if (piece < 8) {
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ fsw(row);
+            const unsigned vo = (unsigned)(qt * 64 + row) * ldx_bytes + colx_bytes + (unsigned)c * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(img + piece * 1024), 16, vo, 0, 0, 0);
+        } else {
+            const int qi = qt * 64 + lane;
+            const unsigned vo = qi < p.N ? (unsigned)qi * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void*)(smem + ROWT + buf * 2048 + hl * 512 + kh * 256), 4, vo, 0, 0, 0);
+        }
+    };
+
     f32x16 dkt[2], dvt[2];             // [db]: (d x 32 keys) blocks
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -961,9 +980,16 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
 
     // one query-tile step; DMA destination and the images being read are distinct __restrict__ parameters of one inlined body, so that the transposed
     // Q^T / dO^T reads do not wait for the in-flight DMA (see mqa_fwd_kernel)
-    auto step = [&](unsigned char* __restrict__ ntiles_img, const unsigned char* __restrict__ ctiles, int qt) {
+    // DIAG (compile time): the diagonal query tile (qt == kblk, the first step) is the only one where the causal rule can hide a key from a query.  Round 6:
+    // off the diagonal NO per-element mask is applied at all -- every key precedes every query there, and an invalid key (key-padding mask, or beyond N) only
+    // ever produces garbage in ITS OWN column of dK^T / dV^T (the MFMA's B operand column = the key), which the epilogue replaces by zero.  That removes an
+    // index build + compare + select per score (96 of 176 VALU instructions of the step) from a loop whose VALU, MFMA and LDS phases barely overlap.
+    auto step = [&](unsigned char* __restrict__ ntiles_img, const unsigned char* __restrict__ ctiles, int qt, auto diag_c, auto more_c) {
+        constexpr bool DIAG = decltype(diag_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;                      // compile time on the pipelined path: tile qt + 1 exists (its DMA is part of the schedule)
+        constexpr bool PIPE = !DIAG && !DROP && !BIAS;
         const int buf = (qt - kblk) & 1;
-        if (qt + 1 < nqt) stage(ntiles_img, qt + 1, buf ^ 1);
+        if (!PIPE && qt + 1 < nqt) stage(ntiles_img, qt + 1, buf ^ 1);
         DKV_PROBE_T(0);
         if (active) {
             const unsigned char* Qt = ctiles + hl * 16384;
@@ -975,6 +1001,94 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             f32x16 s[2], dp[2];
             const float* rowt = reinterpret_cast<const float*>(smem + ROWT + buf * 2048 + hl * 512);      // [64] -lse/scale, [64] -delta (staged by DMA)
+            if constexpr (PIPE) {
+                // ---- off-diagonal step, SOFTWARE-PIPELINED over the two 32-query blocks (round 6).  Measured before (scripts/attn_probe.py dkv): the step spent
+                // 1095 cycles in the exp2 / dS block during which the SIMD's matrix pipe idled -- both waves of a SIMD run the same phase at the same time
+                // (one barrier per step), so nothing else filled it.  Order now:   M1(0) | M1(1) || E(0) | M2(0) || E(1) | M2(1)
+                //   M1(qb) = S', dP' MFMAs of query block qb (8), E(qb) = exp2 + dS + bf16 packs (VALU), M2(qb) = dV, dK MFMAs (8)
+                // with the VALU of one block issued BETWEEN the MFMAs of the other (explicit schedule groups: one MFMA, its fragment reads, ~7 VALU).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                auto init_rows = [&](int qb) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ql = qb * 32 + 8 * g + 4 * lh;
+                        const float4 lraw = lds_ld_f4(rowt + ql);
+                        const float4 draw = lds_ld_f4(rowt + 64 + ql);
+                        s[qb][4 * g] = lraw.x; s[qb][4 * g + 1] = lraw.y; s[qb][4 * g + 2] = lraw.z; s[qb][4 * g + 3] = lraw.w;
+                        dp[qb][4 * g] = draw.x; dp[qb][4 * g + 1] = draw.y; dp[qb][4 * g + 2] = draw.z; dp[qb][4 * g + 3] = draw.w;
+                    }
+                };
+                auto m1 = [&](int qb) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 qa = nat_frag(Qt, qb * 32 + lr, frow, ks, lh);
+                        s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s[qb], 0, 0, 0);
+                        const bf16x8 da = nat_frag(Dt, qb * 32 + lr, frow, ks, lh);
+                        dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp[qb], 0, 0, 0);
+                    }
+                };
+                bf16x8 pf[2][2], dsf[2][2];                                             // [qb][16-query step]: P and dS as bf16 B operands
+                auto e = [&](int qb) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 sv = f32x2{s[qb][r], s[qb][r + 1]} * f32x2{c2, c2};
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])};
+                        const f32x2 dv = f32x2{dp[qb][r], dp[qb][r + 1]} * pv;
+                        s[qb][r] = pv[0]; s[qb][r + 1] = pv[1];
+                        dp[qb][r] = dv[0]; dp[qb][r + 1] = dv[1];
+                    }
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) { pf[qb][st] = pack8(s[qb], st); dsf[qb][st] = pack8(dp[qb], st); }
+                };
+                auto m2 = [&](int qb) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 dotf = tr_frag(Dt, qb * 32 + st * 16, troff, db);
+                            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf[qb][st], dvt[db], 0, 0, 0);
+                            const bf16x8 qtf = tr_frag(Qt, qb * 32 + st * 16, troff, db);
+                            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[qb][st], dkt[db], 0, 0, 0);
+                        }
+                };
+                // The 8 + 1 DMA pieces of the NEXT tile ride in the same schedule -- one piece per two MFMAs (the probe: 830 cycles of DMA issue per step at
+                // the top of the step, every wave of the workgroup at once and the matrix pipe idle; an LDS-DMA piece costs ~60 cycles beside MFMAs).
+                init_rows(0);
+                init_rows(1);
+                m1(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (MORE) {
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) stage_piece(ntiles_img, qt + 1, buf ^ 1, pc);
+                }
+                m1(1);
+                e(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                                            // M1(1) || E(0): per MFMA its fragment read + a slice of the VALU block
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (MORE && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                DKV_PROBE_T(1);
+                if (MORE) {
+#pragma unroll
+                    for (int pc = 4; pc < 9; ++pc) stage_piece(ntiles_img, qt + 1, buf ^ 1, pc);
+                }
+                m2(0);
+                e(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                                            // M2(0) || E(1)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (MORE && i < 5) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                DKV_PROBE_T(2);
+                m2(1);
+            } else {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -1017,14 +1131,27 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                     dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp[qb], 0, 0, 0);
                 }
             DKV_PROBE_T(1);
-            const int nodiag = (qt == kblk) ? 0 : 0x40000000;               // off the diagonal every key precedes every query
+            if constexpr (!DIAG && !DROP) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 c2v = {c2, c2};
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {                               // packed fp32 math (v_pk_mul_f32: two scores per instruction)
+                        const f32x2 sv = f32x2{s[qb][r], s[qb][r + 1]} * c2v;
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])};
+                        const f32x2 dv = f32x2{dp[qb][r], dp[qb][r + 1]} * pv;
+                        s[qb][r] = pv[0]; s[qb][r + 1] = pv[1];
+                        dp[qb][r] = dv[0]; dp[qb][r + 1] = dv[1];
+                    }
+            } else {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qq = q0 + qb * 32 + drow(r, lh);
                     float pv = __builtin_amdgcn_exp2f(s[qb][r] * c2);
-                    if (key_eff > qq + nodiag) pv = 0.f;                            // masked key | causal (diagonal tile only)
+                    if (DIAG ? key_eff > qq : !kvalid) pv = 0.f;                    // masked key | causal (diagonal tile only)
                     if (DROP) {
                         const bool kp = drop_keep(dsalt, qq, key, p.N, p.drop_thr);
                         const float nd = rowt[64 + qb * 32 + drow(r, lh)];           // -delta of this query row
@@ -1035,6 +1162,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                         dp[qb][r] *= pv;
                     }
                 }
+            }
             DKV_PROBE_T(2);
             // dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 64 queries of the tile: 4 steps of 16)
 #pragma unroll
@@ -1051,13 +1179,24 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
                         dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkt[db], 0, 0, 0);
                     }
                 }
+            }
             DKV_PROBE_T(3);
         }
     };
+    step(smem + 65536, smem, kblk, std::true_type{}, std::true_type{});      // the diagonal tile
+    __syncthreads();
+    DKV_PROBE_T(4);
+    constexpr bool PEEL_LAST = !DROP && !BIAS;                               // (only the pipelined step bakes "a next tile exists" into its schedule)
 #pragma unroll 1
-    for (int qt = kblk; qt < nqt; ++qt) {
+    for (int qt = kblk + 1; qt + (PEEL_LAST ? 1 : 0) < nqt; ++qt) {
         const int buf = (qt - kblk) & 1;
-        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, qt);
+        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, qt, std::false_type{}, std::true_type{});
+        __syncthreads();
+        DKV_PROBE_T(4);
+    }
+    if (PEEL_LAST && nqt - 1 > kblk) {                                       // the last query tile: nothing left to fetch
+        const int buf = (nqt - 1 - kblk) & 1;
+        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, nqt - 1, std::false_type{}, std::false_type{});
         __syncthreads();
         DKV_PROBE_T(4);
     }
@@ -1086,7 +1225,11 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             const int half = kk >> 5, kl = kk & 31;
             float sum = 0.f;
             for (int hh = 0; hh < nh; ++hh) sum += red[(hh * 2 + half) * RW + d * RS + kl];
-            if (kblk * 64 + kk < p.N) outp[((long long)b * p.N + kblk * 64 + kk) * p.lddk + d] = sum * sc;
+            if (kblk * 64 + kk < p.N) {
+                // a key the padding mask hides receives no gradient: its column may hold anything (the off-diagonal steps do not mask) -- SELECT zero
+                const bool kv_ok = !p.mask || p.mask[(long long)b * p.N + kblk * 64 + kk] != 0;
+                outp[((long long)b * p.N + kblk * 64 + kk) * p.lddk + d] = kv_ok ? sum * sc : 0.f;
+            }
         }
     }
 }
