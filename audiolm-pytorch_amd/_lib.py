@@ -103,6 +103,7 @@ SIGNATURES = {
     'alm_conv1d_packed_floats': [_I, _I, _I],
     'alm_conv1d_pack': [_P, _P, _I, _I, _I, _P],
     'alm_conv1d_causal': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'alm_resunit_causal': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'alm_phase_interleave': [_P, _P, _I, _I, _I, _I, _P],
     'alm_rvq_decode': [_P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     'alm_rvq_padded_codes': [_I],

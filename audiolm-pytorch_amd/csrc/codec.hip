@@ -18,6 +18,7 @@
 //            transposed [d][C]), keeps a running (distance, index) minimum per frame with first-index tie-breaking, the waves'
 //            candidates are merged through LDS, the winning code vector is subtracted in place and the next quantizer starts --
 //            no intermediate tensor ever reaches HBM.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -50,7 +51,7 @@ struct ConvArgs {
 
 // grid: (ceil(Tout / 256), CoutP / (32 * NA), B); 4 waves along time, 64 output steps each
 template <int NA>
-__global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv1d_causal_kernel(ConvArgs a) {      // (256, 2): without the occupancy hint the compiler parks copies in AGPRs (184 registers, NA = 2)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z;
@@ -154,7 +155,11 @@ __global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
         for (int j = 0; j < 2; ++j) {
             const int t = t0 + j * 32 + lr;
             const int vb = t < a.Tout ? ((co0 + i * 32 + 4 * lh) * a.Tout + t) * 4 : (int)0x80000000;
-            float v[16];
+            float v[16], rr[16];
+            if (a.residual) {                                      // all 16 row loads in flight before the first use (they were issued and waited for one by one)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = acc[i][j][r] + bias[r];
@@ -162,10 +167,189 @@ __global__ __launch_bounds__(256) void conv1d_causal_kernel(ConvArgs a) {
             }
             if (a.residual) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0));
+                for (int r = 0; r < 16; ++r) v[r] += rr[r];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rsO, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0);
+        }
+    }
+}
+
+// ---- fused ResidualUnit (round 6; reference soundstream.py:362-369: x + ELU(conv_k1(ELU(conv_k7,dil(x))))): ONE launch per unit instead of two, the
+// C x (time tile) intermediate never leaves the registers.  Unfused, every unit of the first two encoder stages wrote and re-read a 737 MB fp32
+// activation (8 x 30 s at 24 kHz) around an HBM-bound k = 1 conv.
+//   * a wave owns ALL C channels of 32 * NJ time steps: the k7 conv accumulators (NA = C / 32 row blocks) are the k1 conv's B operands IN PLACE.  The
+//     MFMA's B operand wants lane half lh <-> contraction index 2 kk + lh; its D layout gives lane half lh the rows {0-3, 8-11, ...} + 4 lh.  So the k7
+//     conv is computed with its OUTPUT CHANNELS PERMUTED: MFMA row 8 a + 4 h + b of block i holds channel 32 i + 2 (4 a + b) + h, i.e. accumulator
+//     register r of lane half lh holds channel 32 i + 2 r + lh -- exactly the k1 conv's step kk = 16 i + r, no data movement.  (A permutation of output
+//     rows is a permutation of the weight rows fed as the A operand: every output element is still the same fma chain in the same (tap, channel pair)
+//     order as alm_conv1d_causal computes, and the k1 contraction runs over the same channel pairs in the same order -- the fused unit is BITWISE equal to
+//     the two launches it replaces; tests/test_gpu_codec.py asserts it.)
+//   * bias + ELU of the k7 conv in registers, k1 conv straight from them (weights [ci][co] from L2, double-buffered 16 steps ahead), bias + ELU + residual
+//     x + store in the usual D-layout epilogue.
+struct ResUnitArgs {
+    const float* x; const float* w7; const float* b7; const float* w1; const float* b1; float* out;
+    int B, C, T, ks, dil;
+};
+
+template <int NA, int NJ>
+__global__ __launch_bounds__(256, 2) void resunit_kernel(ResUnitArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z;
+    const int t0 = (blockIdx.x * 4 + wave) * 32 * NJ;
+    if (t0 >= a.T) return;
+    const int C = a.C;
+    const float* xb = a.x + (long long)b * C * a.T;
+    const int pad = a.dil * (a.ks - 1);
+
+    f32x16 h[NA][NJ];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[i][j][r] = 0.f;
+
+    int tin[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tin[j] = t0 + j * 32 + lr - pad;
+
+    // ---- k7 dilated conv (the loop of conv1d_causal_kernel, all C output channels, permuted rows)
+    constexpr int U = 2;
+    const int nk = C >> 1;
+    const int nsteps = a.ks * nk, ng = (nsteps + U - 1) / U;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, C * a.T * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w7), 0, a.ks * C * C * 4, 0x00020000);
+    const int prow = 2 * (4 * (lr >> 3) + (lr & 3)) + ((lr >> 2) & 1);        // channel (within a 32-block) that MFMA row lr holds
+    const int wvo = (lh * C + prow) * 4;
+    int ltap = 0, lk = 0;
+    int xvo[NJ];
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int p = tin[j] + tap * a.dil;
+            p = p < 0 ? -p : p;                                      // reflect left pad
+            xvo[j] = (lh * a.T + p) * 4;
+        }
+    };
+    set_tap(0);
+    float av[2][U][NA], bv[2][U][NJ];
+    auto load_group = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ltap < a.ks) {
+                const int wso = ((ltap * C + 2 * lk) * C) * 4, xso = (2 * lk * a.T) * 4;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) av[BUF][u][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, wvo + i * 128, wso, 0));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[BUF][u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, xvo[j], xso, 0));
+                if (++lk == nk) {
+                    lk = 0;
+                    ++ltap;
+                    set_tap(ltap);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) av[BUF][u][i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[BUF][u][j] = 0.f;
+            }
+        }
+    };
+    auto mfma_group = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) h[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[BUF][u][i], bv[BUF][u][j], h[i][j], 0, 0, 0);
+    };
+    load_group(std::integral_constant<int, 0>{});
+    for (int g = 0; g < ng; g += 2) {
+        if (g + 1 < ng) load_group(std::integral_constant<int, 1>{});
+        mfma_group(std::integral_constant<int, 0>{});
+        if (g + 2 < ng) load_group(std::integral_constant<int, 0>{});
+        if (g + 1 < ng) mfma_group(std::integral_constant<int, 1>{});
+    }
+
+    // ---- bias + ELU of the k7 conv: register r of lane half lh = channel 32 i + 2 r + lh
+    {
+        const auto rsB7 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b7), 0, C * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB7, (32 * i + 2 * r + lh) * 4, 0, 0));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) h[i][j][r] = elu1(h[i][j][r] + bb);
+            }
+    }
+
+    // ---- k1 conv out of the registers + epilogue, one 32-channel output block at a time
+    const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1), 0, C * C * 4, 0x00020000);
+    const long long ob = (long long)b * C * a.T;
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + ob, 0, C * a.T * 4, 0x00020000);
+    const auto rsB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b1), 0, C * 4, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int w1vo = (lh * C + lr) * 4;                              // A operand: W1p[ci = 2 kk + lh][co = 32 io + lr]
+    float a1[2][16];
+    auto load_a1 = [&](auto bufc, int io, int ii) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[BUF][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW1, w1vo + io * 128, (2 * (16 * ii + r) * C) * 4, 0));
+    };
+#pragma unroll 1
+    for (int io = 0; io < NA; ++io) {
+        f32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        load_a1(std::integral_constant<int, 0>{}, io, 0);
+        // the residual x and the bias of this output block are fetched NOW, under the k1 MFMAs (fetched in the epilogue, each of the 16 row loads was
+        // followed by its own wait: 16 serial L2 round trips per 32 x 32 block -- seen in the ISA, about half of the unit's time)
+        int vb[NJ];
+        float xr[NJ][16];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int t = t0 + j * 32 + lr;
+            vb[j] = t < a.T ? ((io * 32 + 4 * lh) * a.T + t) * 4 : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, vb[j], ((r & 3) + 8 * (r >> 2)) * a.T * 4, 0));
+        }
+        float bias[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rsB1, (io * 32 + 8 * g + 4 * lh) * 4, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bias[4 * g + c] = __uint_as_float(bq[c]);
+        }
+#pragma unroll
+        for (int ii = 0; ii < NA; ++ii) {
+            if (ii & 1) {
+                if (ii + 1 < NA) load_a1(std::integral_constant<int, 0>{}, io, ii + 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][r], h[ii][j][r], acc[j], 0, 0, 0);
+            } else {
+                if (ii + 1 < NA) load_a1(std::integral_constant<int, 1>{}, io, ii + 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][r], h[ii][j][r], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = elu1(acc[j][r] + bias[r]) + xr[j][r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rsO, vb[j], ((r & 3) + 8 * (r >> 2)) * a.T * 4, 0);
         }
     }
 }
@@ -209,7 +393,7 @@ struct RvqArgs {
     int T, d, C, CP, Q;
 };
 
-__global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
+__global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
     extern __shared__ float sm[];
     const int dP = (a.d + 7) & ~7;
     const int ld = dP + 4;                    // 16-B aligned rows (ds_read_b128), consecutive rows 4 banks apart
@@ -420,6 +604,35 @@ extern "C" int alm_conv1d_causal(const float* x, const float* wp, const float* b
         hipLaunchKernelGGL(conv1d_causal_kernel<2>, dim3(gx, a.CoutP / 64, B), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(conv1d_causal_kernel<1>, dim3(gx, a.CoutP / 32, B), dim3(256), 0, (hipStream_t)stream, a);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+// One ResidualUnit (reference soundstream.py:362-369) in ONE launch: out = x + ELU(b1 + W1 . ELU(b7 + conv_k,dil(x))) with the reflect left pad of a
+// CausalConv1d (stride 1).  w7p / w1p: alm_conv1d_pack images of the two weights ([k][C][C] and [1][C][C]).  C % 32 == 0, C <= 256 (else
+// ALM_ERR_UNSUPPORTED: the caller runs the two alm_conv1d_causal launches).  Bitwise equal to those two launches.
+extern "C" int alm_resunit_causal(const float* x, const float* w7p, const float* b7, const float* w1p, const float* b1, float* out, int B, int C, int T,
+                                  int ksize, int dilation, void* stream) {
+    if (B <= 0 || C <= 0 || T <= 0 || ksize <= 0 || dilation <= 0) return ALM_ERR_BAD_ARG;
+    if ((C & 31) || C > 256) return ALM_ERR_UNSUPPORTED;
+    if (dilation * (ksize - 1) >= T) return ALM_ERR_UNSUPPORTED;
+    if ((long long)(C + 32) * T * 4 >= 0x7fffffffLL || (long long)ksize * (C + 1) * (C + 31) * 4 >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    ResUnitArgs a{x, w7p, b7, w1p, b1, out, B, C, T, ksize, dilation};
+    hipStream_t st = (hipStream_t)stream;
+    const int na = C / 32;
+    // time steps per wave: 64 for C <= 64, 32 above (the k7 accumulators are C / 32 x (steps / 32) x 16 registers: two waves per SIMD up to C = 192)
+    if (na == 8) hipLaunchKernelGGL((resunit_kernel<8, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    else if (na == 1) hipLaunchKernelGGL((resunit_kernel<1, 2>), dim3((T + 255) / 256, 1, B), dim3(256), 0, st, a);
+    else if (na == 2) {
+        static const int nj64 = [] { const char* e = getenv("ALM_RESUNIT_NJ64"); return e ? atoi(e) : 2; }();      // A/B: time blocks per wave at C = 64
+        if (nj64 == 2) hipLaunchKernelGGL((resunit_kernel<2, 2>), dim3((T + 255) / 256, 1, B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((resunit_kernel<2, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    }
+    else if (na == 3) hipLaunchKernelGGL((resunit_kernel<3, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    else if (na == 4) hipLaunchKernelGGL((resunit_kernel<4, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    else if (na == 5) hipLaunchKernelGGL((resunit_kernel<5, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    else if (na == 6) hipLaunchKernelGGL((resunit_kernel<6, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((resunit_kernel<7, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
     ALM_LAUNCH_CHECK();
     return 0;
 }

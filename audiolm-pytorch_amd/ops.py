@@ -906,6 +906,20 @@ def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, 
     return out
 
 
+def resunit_supported(C):
+    return C % 32 == 0 and C <= 256
+
+
+def resunit_causal(x, w7p, b7, w1p, b1, ksize, dilation):
+    """x fp32 [B, C, T] -> x + ELU(conv_k1(ELU(conv_k,dilation(x)))) in one launch (alm_resunit_causal; C % 32 == 0, C <= 256)"""
+    _chk(x, F32)
+    B, C, T = x.shape
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.call('alm_resunit_causal', x.data_ptr(), w7p.data_ptr(), b7.data_ptr(), w1p.data_ptr(), b1.data_ptr(), out.data_ptr(), B, C, T, ksize, dilation, _st())
+    return out
+
+
 def phase_interleave(y, Cout, s):
     """y fp32 [B, s * Cout, n] (phase-major channels) -> [B, Cout, n * s]: out[b, co, q * s + r] = y[b, r * Cout + co, q]."""
     _chk(y, F32)

@@ -22,6 +22,7 @@ The module tree keeps the reference's parameter / buffer NAMES for the parts it 
 from __future__ import annotations
 
 import functools
+import os
 from itertools import cycle
 
 import torch
@@ -30,6 +31,7 @@ from torch import nn
 from . import core, ops
 
 F32 = torch.float32
+FUSE_RESUNIT = os.environ.get('ALM_FUSE_RESUNIT', '1') != '0'      # A/B switch: 0 = the two alm_conv1d_causal launches per ResidualUnit
 
 
 class CausalConv1d(nn.Module):                                   # soundstream.py:332-345
@@ -103,8 +105,12 @@ class _ResidualFn(nn.Module):
                                 CausalConv1d(chan, chan, 1, pad_mode=pad_mode), nn.ELU())
 
     def forward(self, x):                                        # soundstream.py:362-369: ELU(conv1(ELU(conv7(x)))) + x
-        h = self.fn[0].run(x, elu=True)
-        return self.fn[2].run(h, elu=True, residual=x)
+        c7, c1 = self.fn[0], self.fn[2]
+        if FUSE_RESUNIT and ops.resunit_supported(x.shape[1]) and c7.dilation * (c7.kernel_size - 1) < x.shape[2]:
+            # one launch, the intermediate in registers (alm_resunit_causal: bitwise equal to the two launches below)
+            return ops.resunit_causal(x, c7.packed(), c7.conv.bias.detach(), c1.packed(), c1.conv.bias.detach(), c7.kernel_size, c7.dilation)
+        h = c7.run(x, elu=True)
+        return c1.run(h, elu=True, residual=x)
 
 
 def ResidualUnit(chan_in, chan_out, dilation, kernel_size=7, squeeze_excite=False, pad_mode='reflect'):

@@ -464,7 +464,7 @@ def main():
     roof = None
     events = []                                                  # (start event, end event, algorithmic work, unit, kernel key)
     timed_names = ('gemm_nt', 'gemm_nt_group2', 'gemm_tn_splitk', 'gemm_tn_batched', 'mqa_attn_fwd', 'mqa_attn_bwd', 'hc_fwd', 'hc_bwd', 'geglu_ln_fwd', 'geglu_ln_bwd', 'layernorm_fwd',
-                   'layernorm_bwd', 'conv1d_causal', 'rvq_encode')       # (the last two: the SoundStream tokenize kernels of --config e2e_config5)
+                   'layernorm_bwd', 'conv1d_causal', 'resunit_causal', 'rvq_encode')       # (the last three: the SoundStream tokenize kernels of --config e2e_config5)
     originals = {n: getattr(ops, n) for n in timed_names}
 
     def big_tile(M_, N_, nb):               # mirrors pick_tile() in csrc/gemm.hip
@@ -519,6 +519,10 @@ def main():
             Bc, Cin, T = x.shape
             st_ = kw.get('stride', 1)
             return 2.0 * Bc * a[3] * Cin * a[4] * ((T - st_) // st_ + 1), 'flop32', 'conv1d_causal'
+        if name == 'resunit_causal':                                             # fused ResidualUnit: k-tap dilated conv + k = 1 conv, both C -> C: 2 B T C C (k + 1)
+            x = a[0]
+            Bc, Cc, T = x.shape
+            return 2.0 * Bc * T * Cc * Cc * (a[5] + 1), 'flop32', 'conv1d_causal'
         if name == 'rvq_encode':                                                 # distance GEMM of every quantizer stage: 2 T C d Q
             x, E = a[0], a[1]
             return 2.0 * x.shape[0] * E.shape[1] * E.shape[2] * E.shape[0], 'flop32', 'rvq_encode'
@@ -599,7 +603,7 @@ def main():
             'mqa_fwd': 'mqa_fwd_kernel (causal flash attention forward)', 'mqa_bwd': 'attn_delta + mqa_bwd_dq + mqa_bwd_dkv (flash attention backward)',
             'hc_fwd': 'hc_fwd_kernel (depth + width connection + pre-LayerNorm, fused)', 'hc_bwd': 'hc_bwd_kernel (+ its colsum / param-grad launches)',
             'geglu_ln_fwd': 'geglu_ln_fwd_kernel', 'geglu_ln_bwd': 'geglu_ln_bwd_kernel (+ colsum)', 'layernorm_fwd': 'ln_fwd_kernel', 'layernorm_bwd': 'ln_bwd_kernel (+ colsum)',
-            'conv1d_causal': 'conv1d_causal_kernel (SoundStream encoder: causal conv as implicit GEMM on the exact-fp32 MFMA; the 32-channel k = 1 convs are HBM-bound)',
+            'conv1d_causal': 'resunit_kernel + conv1d_causal_kernel (SoundStream encoder: fused ResidualUnits (k7 dilated conv + ELU + k1 conv + ELU + residual, one launch) and the strided / in / out causal convs as implicit GEMMs on the exact-fp32 MFMA)',
             'rvq_encode': 'rvq_encode_kernel (residual VQ: fp32-MFMA distance GEMM + first-index argmin over 8 quantizers)'}
     kernels = []
     for key, (k_ms, k_w, k_n, unit) in sorted(agg.items(), key=lambda kv: -kv[1][0]):

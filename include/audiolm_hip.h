@@ -354,6 +354,11 @@ int alm_conv1d_packed_floats(int Cout, int Cin, int ksize);
 int alm_conv1d_pack(const float* w, float* wp, int Cout, int Cin, int ksize, void* stream);
 int alm_conv1d_causal(const float* x, const float* wp, const float* bias, const float* residual, float* out, int B, int Cin, int Cout, int Tin,
                       int ksize, int stride, int dilation, int elu, int zero_pad, void* stream);
+/* one ResidualUnit (soundstream.py:362-369: x + ELU(conv_k1(ELU(conv_k,dilation(x)))), CausalConv1d reflect left pad, stride 1) in ONE launch; the
+ * intermediate stays in registers.  w7p / w1p: alm_conv1d_pack images of the two conv weights; x, out fp32 [B][C][T].  C % 32 == 0 and C <= 256, else
+ * ALM_ERR_UNSUPPORTED (run the two alm_conv1d_causal launches).  Bitwise equal to those two launches (same fma chains on the exact-fp32 matrix core). */
+int alm_resunit_causal(const float* x, const float* w7p, const float* b7, const float* w1p, const float* b1, float* out, int B, int C, int T,
+                       int ksize, int dilation, void* stream);
 /* decoder side (soundstream.py:347-360, 382-395, 615-627, 691-709).  zero_pad = 1 above pads with zeros instead of reflecting: a
  * CausalConvTranspose1d(k = 2 s, stride s) is that conv with k = 2 over s * Cout phase-major output channels (weights re-indexed on the host),
  * followed by alm_phase_interleave: y [B][s * Cout][n] -> out [B][Cout][n * s].  alm_rvq_decode: codes -> summed code vectors. */

@@ -53,6 +53,25 @@ def test_causal_conv1d(ops, B, Cin, Cout, T, k, stride, dil):
         assert relmax(out2, F.elu(ref) + x) <= 2e-5
 
 
+@pytest.mark.parametrize('B,C,T,dil', [(2, 32, 1000, 1), (1, 32, 777, 9), (2, 64, 641, 3), (1, 128, 515, 9), (1, 256, 300, 3), (1, 96, 200, 1), (1, 160, 130, 1),
+                                       (1, 32, 55, 9), (3, 64, 64, 1)])
+def test_fused_residual_unit(ops, B, C, T, dil):
+    """alm_resunit_causal (round 6; reference soundstream.py:362-369): x + ELU(conv_k1(ELU(conv_k7,dil(x)))) in ONE launch, the intermediate in registers.
+    BITWISE equal to the two alm_conv1d_causal launches it replaces (same fma chains on the exact-fp32 matrix core -- the code indices downstream cannot
+    move), equal to the fp32 CPU oracle within the conv tolerance, ragged time tails and every channel-block count C / 32 = 1 .. 8."""
+    x = rnd(B, C, T, seed=11)
+    w7, b7 = rnd(C, C, 7, seed=12, scale=(7 * C) ** -0.5), rnd(C, seed=13, scale=0.1)
+    w1, b1 = rnd(C, C, 1, seed=14, scale=C ** -0.5), rnd(C, seed=15, scale=0.1)
+    ref = F.elu(O.causal_conv1d(F.elu(O.causal_conv1d(x, w7, b7, dilation=dil)), w1, b1)) + x
+    xd = x.to(dev())
+    w7p, w1p = ops.conv1d_pack(w7.to(dev())), ops.conv1d_pack(w1.to(dev()))
+    h = ops.conv1d_causal(xd, w7p, b7.to(dev()), C, 7, dilation=dil, elu=True)
+    two = ops.conv1d_causal(h, w1p, b1.to(dev()), C, 1, elu=True, residual=xd)
+    one = ops.resunit_causal(xd, w7p, b7.to(dev()), w1p, b1.to(dev()), 7, dil)
+    assert one.shape == two.shape == ref.shape
+    assert torch.equal(one, two), f'fused unit differs from the two launches: max |d| {float((one - two).abs().max()):.3e}'
+    assert relmax(one, ref) <= 2e-5
+
 def _check_indices(idx, x, cbs):
     """idx (T, Q) vs the oracle on the same fp32 inputs: equal, or a float-rounding tie (replays the oracle's residual path)."""
     ref = O.rvq_encode(x[None], cbs)[0]
