@@ -175,6 +175,112 @@ __global__ __launch_bounds__(256, 2) void conv1d_causal_kernel(ConvArgs a) {    
     }
 }
 
+// ---- strided down-sampling conv of an EncoderBlock (reference soundstream.py:379: CausalConv1d(k = 2 s, stride s), reflect left pad = s) ---------------------
+// Round 6.  In conv1d_causal_kernel a lane's activation loads for consecutive output steps are s samples apart (2-8): one dword per lane and tap, 2-8 cache
+// lines per wave load -- the four down-sampling convs ran at 0.28 of the fp32-MFMA peak, the stride-1 convs at 0.6-0.7.  Here out[t] reads the 2 s CONTIGUOUS
+// samples x[(t - 1) s .. (t + 1) s) of every input channel: a lane fetches them with 16-byte loads (all taps of a channel at once, consecutive lanes
+// contiguous), and the contraction runs channel-pair-major (taps inner) instead of tap-major -- still one exact-fp32 fma chain per output, in a fixed order.
+//   the reflect pad only concerns output step 0 (samples -s .. -1 mirror s .. 1): that one lane patches its first s values with scalar loads.
+template <int NA, int S>
+__global__ __launch_bounds__(256, 2) void conv1d_strided_kernel(ConvArgs a) {
+    constexpr int K = 2 * S, NV = (K + 3) / 4;                     // taps, 16-byte loads per channel and 32-step block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * 32 * NA;
+    const int t0 = blockIdx.x * 256 + wave * 64;
+    if (t0 >= a.Tout) return;
+    const float* xb = a.x + (long long)b * a.Cin * a.Tin;
+
+    f32x16 acc[NA][2];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.CinP >> 1;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, a.Cin * a.Tin * 4, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.ks * a.CinP * a.CoutP * 4, 0x00020000);
+    const int wvo = (lh * a.CoutP + co0 + lr) * 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    int xvo[2];
+    bool first[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int t = t0 + j * 32 + lr;
+        first[j] = t == 0;
+        xvo[j] = (lh * a.Tin + max(t - 1, 0) * S) * 4;             // (step 0 loads x[0 .. 2 s) and patches / shifts below)
+    }
+    float xv[2][2][4 * NV], av[2][K][NA];
+    auto load_pair = [&](auto bufc, int lk) {
+        constexpr int BUF = decltype(bufc)::value;
+        const int xso = (2 * lk * a.Tin) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, xvo[j] + q * 16, xso, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xv[BUF][j][4 * q + c] = __uint_as_float(v[c]);
+            }
+            if (first[j]) {                                         // output step 0: taps 0 .. s-1 are the mirrored samples s .. 1, taps s .. 2s-1 the samples 0 .. s-1
+#pragma unroll
+                for (int tap = K - 1; tap >= S; --tap) xv[BUF][j][tap] = xv[BUF][j][tap - S];
+#pragma unroll
+                for (int tap = 0; tap < S; ++tap) xv[BUF][j][tap] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, (lh * a.Tin + (S - tap)) * 4, xso, 0));
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+            const int wso = ((tap * a.CinP + 2 * lk) * a.CoutP) * 4;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) av[BUF][tap][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, wvo + i * 128, wso, 0));
+        }
+    };
+    auto mfma_pair = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[BUF][tap][i], xv[BUF][j][tap], acc[i][j], 0, 0, 0);
+    };
+    load_pair(std::integral_constant<int, 0>{}, 0);
+    for (int lk = 0; lk < nk; lk += 2) {
+        if (lk + 1 < nk) load_pair(std::integral_constant<int, 1>{}, lk + 1);
+        mfma_pair(std::integral_constant<int, 0>{});
+        if (lk + 2 < nk) load_pair(std::integral_constant<int, 0>{}, lk + 2);
+        if (lk + 1 < nk) mfma_pair(std::integral_constant<int, 1>{});
+    }
+    const long long ob = (long long)b * a.Cout * a.Tout;
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + ob, 0, a.Cout * a.Tout * 4, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.Cout * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float bias[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rsB, (co0 + i * 32 + 8 * g + 4 * lh) * 4, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bias[4 * g + c] = __uint_as_float(bq[c]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + j * 32 + lr;
+            const int vb = t < a.Tout ? ((co0 + i * 32 + 4 * lh) * a.Tout + t) * 4 : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bias[r];
+                if (a.elu) v = elu1(v);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsO, vb, ((r & 3) + 8 * (r >> 2)) * a.Tout * 4, 0);
+            }
+        }
+    }
+}
+
 // ---- fused ResidualUnit (round 6; reference soundstream.py:362-369: x + ELU(conv_k1(ELU(conv_k7,dil(x))))): ONE launch per unit instead of two, the
 // C x (time tile) intermediate never leaves the registers.  Unfused, every unit of the first two encoder stages wrote and re-read a 737 MB fp32
 // activation (8 x 30 s at 24 kHz) around an HBM-bound k = 1 conv.
@@ -600,6 +706,19 @@ extern "C" int alm_conv1d_causal(const float* x, const float* wp, const float* b
     const int Tout = (Tin - stride) / stride + 1;
     ConvArgs a{x, wp, bias, residual, out, B, Cin, (Cin + 1) & ~1, Cout, (Cout + 31) & ~31, Tin, Tout, ksize, stride, dilation, pad, elu, zero_pad};
     const int gx = (Tout + 255) / 256;
+    // the down-sampling convs of the encoder (k = 2 s, stride s, no dilation, reflect pad, no residual): 16-byte activation loads, channel-major contraction
+    static const int strided_on = [] { const char* e = getenv("ALM_CONV_STRIDED"); return e ? atoi(e) : 1; }();     // A/B switch
+    if (strided_on && stride > 1 && ksize == 2 * stride && dilation == 1 && !zero_pad && !residual && a.CoutP % 64 == 0 && Tin >= 2 * stride &&
+        (stride == 2 || stride == 4 || stride == 5 || stride == 8)) {
+        const dim3 grid(gx, a.CoutP / 64, B);
+        hipStream_t st = (hipStream_t)stream;
+        if (stride == 2) hipLaunchKernelGGL((conv1d_strided_kernel<2, 2>), grid, dim3(256), 0, st, a);
+        else if (stride == 4) hipLaunchKernelGGL((conv1d_strided_kernel<2, 4>), grid, dim3(256), 0, st, a);
+        else if (stride == 5) hipLaunchKernelGGL((conv1d_strided_kernel<2, 5>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv1d_strided_kernel<2, 8>), grid, dim3(256), 0, st, a);
+        ALM_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.CoutP % 64 == 0)
         hipLaunchKernelGGL(conv1d_causal_kernel<2>, dim3(gx, a.CoutP / 64, B), dim3(256), 0, (hipStream_t)stream, a);
     else
@@ -620,19 +739,22 @@ extern "C" int alm_resunit_causal(const float* x, const float* w7p, const float*
     ResUnitArgs a{x, w7p, b7, w1p, b1, out, B, C, T, ksize, dilation};
     hipStream_t st = (hipStream_t)stream;
     const int na = C / 32;
-    // time steps per wave: 64 for C <= 64, 32 above (the k7 accumulators are C / 32 x (steps / 32) x 16 registers: two waves per SIMD up to C = 192)
-    if (na == 8) hipLaunchKernelGGL((resunit_kernel<8, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
-    else if (na == 1) hipLaunchKernelGGL((resunit_kernel<1, 2>), dim3((T + 255) / 256, 1, B), dim3(256), 0, st, a);
-    else if (na == 2) {
-        static const int nj64 = [] { const char* e = getenv("ALM_RESUNIT_NJ64"); return e ? atoi(e) : 2; }();      // A/B: time blocks per wave at C = 64
-        if (nj64 == 2) hipLaunchKernelGGL((resunit_kernel<2, 2>), dim3((T + 255) / 256, 1, B), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((resunit_kernel<2, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+    // 32-step time blocks per wave (NJ): more blocks = more MFMAs per weight (A operand) load, fewer waves.  ALM_RESUNIT_NJ=<1|2|4>: A/B override
+    static const int nj_env = [] { const char* e = getenv("ALM_RESUNIT_NJ"); return e ? atoi(e) : 0; }();
+    int nj = na == 1 ? 2 : na == 2 ? 2 : 1;
+    if (nj_env == 1 || nj_env == 2 || (nj_env == 4 && na <= 2)) nj = nj_env;
+    if (na > 4 && nj > 1) nj = 1;
+    const dim3 grid((T + 128 * nj - 1) / (128 * nj), 1, B);
+#define ALM_RU(NA_, NJ_) hipLaunchKernelGGL((resunit_kernel<NA_, NJ_>), grid, dim3(256), 0, st, a)
+    switch (na * 8 + nj) {
+        case 1 * 8 + 1: ALM_RU(1, 1); break;  case 1 * 8 + 2: ALM_RU(1, 2); break;  case 1 * 8 + 4: ALM_RU(1, 4); break;
+        case 2 * 8 + 1: ALM_RU(2, 1); break;  case 2 * 8 + 2: ALM_RU(2, 2); break;  case 2 * 8 + 4: ALM_RU(2, 4); break;
+        case 3 * 8 + 1: ALM_RU(3, 1); break;  case 3 * 8 + 2: ALM_RU(3, 2); break;
+        case 4 * 8 + 1: ALM_RU(4, 1); break;  case 4 * 8 + 2: ALM_RU(4, 2); break;
+        case 5 * 8 + 1: ALM_RU(5, 1); break;  case 6 * 8 + 1: ALM_RU(6, 1); break;  case 7 * 8 + 1: ALM_RU(7, 1); break;  case 8 * 8 + 1: ALM_RU(8, 1); break;
+        default: return ALM_ERR_UNSUPPORTED;
     }
-    else if (na == 3) hipLaunchKernelGGL((resunit_kernel<3, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
-    else if (na == 4) hipLaunchKernelGGL((resunit_kernel<4, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
-    else if (na == 5) hipLaunchKernelGGL((resunit_kernel<5, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
-    else if (na == 6) hipLaunchKernelGGL((resunit_kernel<6, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((resunit_kernel<7, 1>), dim3((T + 127) / 128, 1, B), dim3(256), 0, st, a);
+#undef ALM_RU
     ALM_LAUNCH_CHECK();
     return 0;
 }
