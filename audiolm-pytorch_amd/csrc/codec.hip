@@ -499,38 +499,44 @@ struct RvqArgs {
     int T, d, C, CP, Q;
 };
 
-__global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
+// NW = waves per workgroup (4 or 8), each scanning 1 / NW of the codebook.  Round 6: 18 000 frames are 563 tiles of 32; with 4 waves (two workgroups per CU,
+// 512 resident) that is ONE full round plus a 10 % tail that takes a second full round -- the launch ran at 0.48 of the fp32-MFMA peak; with 8 waves a tile
+// takes half as long and three rounds of 256 cost 1.5 instead of 2 tile-times (alm_rvq_encode picks NW by that round count).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void rvq_encode_kernel(RvqArgs a) {
     extern __shared__ float sm[];
     const int dP = (a.d + 7) & ~7;
     const int ld = dP + 4;                    // 16-B aligned rows (ds_read_b128), consecutive rows 4 banks apart
     float* res = sm;                          // [32][dP + 4]
     float* x2 = res + 32 * ld;                // [32]
-    float* candd = x2 + 32;                   // [4][32]
-    int* candi = reinterpret_cast<int*>(candd + 128);   // [4][32]
-    int* win = candi + 128;                   // [32]
+    float* candd = x2 + 32;                   // [NW][32]
+    int* candi = reinterpret_cast<int*>(candd + 32 * NW);   // [NW][32]
+    int* win = candi + 32 * NW;               // [32]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int f0 = blockIdx.x * 32;
 
-    // residual tile <- x (pad columns zero) ; |x|^2 per frame (thread = (frame t / 8, column phase t % 8))
-    const int fj = t >> 3, ph = t & 7;
+    // residual tile <- x (pad columns zero) ; |x|^2 per frame (thread = (frame t / NP, column phase t % NP), NP = 2 NW)
+    constexpr int NP = 2 * NW;
+    const int fj = t / NP, ph = t % NP;
     {
         float s = 0.f;
         const bool ok = f0 + fj < a.T;
-        for (int e = ph; e < dP; e += 8) {
+        for (int e = ph; e < dP; e += NP) {
             const float v = (ok && e < a.d) ? a.x[(long long)(f0 + fj) * a.ldx + e] : 0.f;
             res[fj * ld + e] = v;
             s += v * v;
         }
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (NP == 16) s += __shfl_xor(s, 8, 64);
         if (ph == 0) x2[fj] = s;
     }
     __syncthreads();
 
     constexpr int PF = 4;                     // 8-column steps per register group; two groups in flight (software pipeline)
     const int nj = dP >> 3, ng = (nj + PF - 1) / PF;
-    const int nblk = a.CP / 32;               // 32-code blocks; wave w scans block pairs 2w, 2w + 8, ...
+    const int nblk = a.CP / 32;               // 32-code blocks; wave w scans block pairs 2w, 2w + 2 NW, ...
     const float4* bp = reinterpret_cast<const float4*>(res + lr * ld + 4 * lh);          // + 2 j  (float4 units): residual[frame][8 j + 4 lh ..]
     for (int q = 0; q < a.Q; ++q) {
         const float4* Pq = reinterpret_cast<const float4*>(a.Et + (long long)q * dP * a.CP);
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
         float best = INFINITY;
         int besti = 0x7fffffff;
         // two 32-code blocks per pass share every residual (B) operand read
-        for (int cb = wave * 2; cb < nblk; cb += 8) {
+        for (int cb = wave * 2; cb < nblk; cb += 2 * NW) {
             const bool two = cb + 1 < nblk;
             f32x16 acc0, acc1;
 #pragma unroll
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
         if (t < 32) {
             float bd = candd[t];
             int bi = candi[t];
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const float od = candd[w * 32 + t];
                 const int oi = candi[w * 32 + t];
                 if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
@@ -618,12 +624,13 @@ __global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
             const int code = win[fj];
             const float* er = a.E + ((long long)q * a.C + code) * a.d;
             float s = 0.f;
-            for (int e = ph; e < a.d; e += 8) {
+            for (int e = ph; e < a.d; e += NP) {
                 const float v = res[fj * ld + e] - er[e];
                 res[fj * ld + e] = v;
                 s += v * v;
             }
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (NP == 16) s += __shfl_xor(s, 8, 64);
             if (ph == 0) x2[fj] = s;
         }
         __syncthreads();
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void rvq_encode_kernel(RvqArgs a) {
     if (a.quant) {                            // quantized = x - final residual
         const bool ok = f0 + fj < a.T;
         if (ok)
-            for (int e = ph; e < a.d; e += 8) a.quant[(long long)(f0 + fj) * a.ldq + e] = a.x[(long long)(f0 + fj) * a.ldx + e] - res[fj * ld + e];
+            for (int e = ph; e < a.d; e += NP) a.quant[(long long)(f0 + fj) * a.ldq + e] = a.x[(long long)(f0 + fj) * a.ldx + e] - res[fj * ld + e];
     }
 }
 
@@ -780,16 +787,23 @@ extern "C" int alm_rvq_encode(const float* x, long long ldx, const float* E, con
                               float* quant, long long ldq, int T, int d, int C, int Q, void* stream) {
     if (T <= 0) return 0;
     if (d <= 0 || C <= 0 || Q <= 0) return ALM_ERR_BAD_ARG;
-    const size_t smem = (size_t)(32 * (alm_rvq_padded_dim(d) + 4) + 32 + 128) * sizeof(float) + (128 + 32) * sizeof(int);
+    // waves per workgroup: the round count of the launch decides (see rvq_encode_kernel).  ALM_RVQ_WAVES=4|8: A/B override
+    static const int nw_env = [] { const char* e = getenv("ALM_RVQ_WAVES"); return e ? atoi(e) : 0; }();
+    const long long tiles = (T + 31) / 32;
+    const double cost4 = (double)((tiles + 511) / 512) / 4.0, cost8 = (double)((tiles + 255) / 256) / 8.0;      // rounds x tile time (1 / waves)
+    const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (cost8 < cost4 ? 8 : 4);
+    const size_t smem = (size_t)(32 * (alm_rvq_padded_dim(d) + 4) + 32 + 32 * nw) * sizeof(float) + (32 * nw + 32) * sizeof(int);
     if (smem > 160 * 1024) return ALM_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_encode_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_encode_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     RvqArgs a{x, ldx, E, Et, e2, idx, ldi, quant, ldq, T, d, C, alm_rvq_padded_codes(C), Q};
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3((T + 31) / 32), dim3(256), smem, (hipStream_t)stream, a);
+    if (nw == 8) hipLaunchKernelGGL(rvq_encode_kernel<8>, dim3((unsigned)tiles), dim3(512), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(rvq_encode_kernel<4>, dim3((unsigned)tiles), dim3(256), smem, (hipStream_t)stream, a);
     ALM_LAUNCH_CHECK();
     return 0;
 }
