@@ -172,8 +172,13 @@ class AlmPackJob(ctypes.Structure):
                 ('rows_pad', c_int), ('cols_pad', c_int), ('dstT', c_void_p), ('ld_dstT', c_longlong)]
 
 
+_BOUND = {}          # name -> bound ctypes function (one dict lookup per call instead of load() + getattr on the CDLL: ~150 calls per training step)
+
+
 def call(name: str, *args):
-    fn = getattr(load(), name)
+    fn = _BOUND.get(name)
+    if fn is None:
+        fn = _BOUND[name] = getattr(load(), name)
     rc = fn(*args)
     if rc != 0:
         raise AlmError(f'{name} failed with code {rc}' + (' (ALM_ERR_BAD_ARG)' if rc == 10001 else ' (ALM_ERR_UNSUPPORTED)' if rc == 10002 else ' (hipError_t)'))
@@ -182,4 +187,7 @@ def call(name: str, *args):
 
 def query(name: str, *args) -> int:
     """For the int-returning size queries (alm_*_blocks / alm_*_width)."""
-    return getattr(load(), name)(*args)
+    fn = _BOUND.get(name)
+    if fn is None:
+        fn = _BOUND[name] = getattr(load(), name)
+    return fn(*args)

@@ -1046,7 +1046,7 @@ class TransformerStackFn(torch.autograd.Function):
                                                  or (context is not None and context.requires_grad))
         xin = x.detach().contiguous().to(F32)
         bias = bias.detached() if bias is not None else None
-        flat_d = [t.detach() for t in flat]
+        flat_d = flat                                            # (autograd is off inside Function.forward: the launches only take data pointers -- no per-parameter detach)
         B = xin.shape[0]
         cx = None
         if context is not None:
@@ -1099,7 +1099,7 @@ class TransformerStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dhn):
         cfg = ctx.cfg
-        flat = [t.detach() for t in ctx.flat]
+        flat = ctx.flat                                          # (grad mode is off in backward unless create_graph: no per-parameter detach)
         dhn = dhn.contiguous()
         if dhn.dtype not in (BF16, F32):
             dhn = dhn.to(F32)

@@ -14,13 +14,15 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+# current device as ONE C call (torch.cuda.current_device() is a Python wrapper with a lazy-init check: ~0.9 us, and _chk / _st run ~600 times per step)
+_cur_dev = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
 def _st():
     """hipStream_t of torch's CURRENT stream on the current device (every alm_* launch goes there).  The raw-handle query is one C call; the
     public torch.cuda.current_stream() builds a Stream object per call (~8 us: ~1.5 ms of host time per training step at ~180 launches)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -29,7 +31,7 @@ def _chk(t, dtype=None):
         raise _lib.AlmError('audiolm_pytorch_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback')
     if dtype is not None and t.dtype != dtype:
         raise _lib.AlmError(f'expected {dtype}, got {t.dtype}')
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _cur_dev():
         # every launch goes to the CURRENT device's stream (_st): a tensor of another device would be dereferenced there
         raise _lib.AlmError(f'tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: call '
                             'torch.cuda.set_device(...) (one process per GPU) before using audiolm_pytorch_amd')

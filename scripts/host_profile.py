@@ -37,3 +37,4 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats('tottime').print_stats(45)
+st.sort_stats('cumulative').print_stats(70)
