@@ -657,6 +657,27 @@ DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '1')))
 # all-reduce runs under the lower layers' backward and only the last group's is exposed.  Until round 3 the hook forced the per-layer split-K path
 # (30 + 30 launches, +0.8 ms/step per GPU against the single-GPU step).  0 = that per-layer path (one bucket per layer, maximal overlap, slower GEMMs).
 DP_DEFER_GROUPS = max(0, int(os.environ.get('ALM_DP_DEFER_GROUPS', '2')))
+# Round 6: UNEVEN layer groups for the data-parallel path, in backward order (top of the stack first), e.g. ALM_DP_GROUP_SIZES=4,2 at depth 6: the LAST group's
+# bucket is the one whose all-reduce nothing hides (the backward is over when it starts), so it should be the small one -- 77 instead of 115 MB on the wire
+# after the last kernel.  Empty: DP_DEFER_GROUPS equal groups.  Sizes that do not sum to the depth are rejected at the first backward.
+DP_GROUP_SIZES = tuple(int(v) for v in os.environ.get('ALM_DP_GROUP_SIZES', '').replace(' ', '').split(',') if v)
+# the same cut without a gradient hook (single GPU): what the grouping itself costs at N = 1 is measured with this (bench.py --gpus 1)
+DEFER_GROUP_SIZES = tuple(int(v) for v in os.environ.get('ALM_DEFER_GROUP_SIZES', '').replace(' ', '').split(',') if v)
+
+
+def group_starts(L, ngroups, sizes=()):
+    """first layer of every weight-gradient group of an L-layer stack, ascending.  sizes: group sizes in BACKWARD order (top group first); else `ngroups`
+    equal groups (the last one may be short)"""
+    if sizes:
+        if sum(sizes) != L or min(sizes) < 1:
+            raise ValueError(f'ALM_DP_GROUP_SIZES={sizes}: the group sizes must be positive and sum to the depth {L}')
+        starts, top = [], L
+        for n in sizes:
+            top -= n
+            starts.append(top)
+        return sorted(starts)
+    gsz = (L + ngroups - 1) // ngroups
+    return list(range(0, L, gsz))
 # deferred mode: the hyper-connection parameter gradients of all branches of a layer group finished together in two launches (ops.hc_param_grads_batched)
 # instead of two small launches behind every hc_bwd (A/B switch)
 HC_BATCH_FINISH = os.environ.get('ALM_HC_BATCH_FINISH', '1') != '0'
@@ -768,7 +789,9 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
         ngroups = _DEBUG_DEFER_GROUPS_CAPTURE if (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()) else (
             DEFER_GROUPS if on_layer_grads is None else max(1, DP_DEFER_GROUPS))
         ngroups = min(ngroups, L)
-        gsz = (L + ngroups - 1) // ngroups
+        capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        starts = group_starts(L, ngroups, () if capturing else (DP_GROUP_SIZES if on_layer_grads is not None else DEFER_GROUP_SIZES))
+        ngroups = len(starts)
         on_group = getattr(on_layer_grads, 'on_group', None)                   # parallel.DataParallelEngine: one bucket per layer GROUP
         group_buffer = getattr(on_layer_grads, 'group_buffer', None)           # ... whose flat bucket the weight-gradient GEMMs write straight into
         wg = True
@@ -798,7 +821,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             return out
 
         def launch_group(l0):
-            l1 = min(L, l0 + gsz)
+            l1 = ([s_ for s_ in starts if s_ > l0] + [L])[0]                   # the group runs up to the next group's first layer
             last = l0 == 0                                                     # the groups are launched from the top of the stack down
             kinds = big_kinds if late else big_kinds + small_kinds
             late_kinds = small_kinds if (late and last) else ()
@@ -994,7 +1017,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             dR = ops.add_f32(dR, dX, dx_scale if prev is None else 1.0)
             grads[ip] = dgl
         sv.clear()
-        if wg is not None and (prev is None or prev['layer'] != l) and l % gsz == 0:
+        if wg is not None and (prev is None or prev['layer'] != l) and l in starts:
             finish_hc()                                        # (before the group's hand-off: a gradient hook wants the whole group's gradients)
             launch_group(l)                                    # this layer closes a group: its operands (and the layers' above it) are complete
         if on_layer_grads is not None and wg is None and (prev is None or prev['layer'] != l):

@@ -31,12 +31,24 @@ backward.  It is not a general DDP replacement.
     collectives were issued from, host time from the last bucket launch to the return of `finish()`
     (what the step still waited for: the tail that did not overlap)
 
+  * round 6 -- the exposed tail: (i) uneven layer groups (ALM_DP_GROUP_SIZES=4,2, core.group_starts): the last group's bucket, which starts when the
+    backward is over, is the small one; (ii) the bucket of the gradients that exist BEFORE the stack's backward (logit heads, final norm) is handed over
+    when the first group's GEMMs are about to be launched (`group_buffer`), not behind them; (iii) `last_stats['tail_model_ms']`: bytes of the buckets
+    launched after the last layer group's GEMMs over the ring (one xGMI link, ~153 GB/s) and direct (7 links) all-reduce rates of SURVEY.md section 5,
+    for an 8-GPU node -- a MODEL (no N > 1 hardware run has been made), next to the measured single-GPU `exposed_tail_ms`
+  * THE .grad-IS-A-VIEW CONTRACT of the in-place buckets: `finish()` hands out `p.grad` tensors that are VIEWS of the engine's persistent per-group flat
+    buffers; the next synchronising backward's weight-gradient GEMMs overwrite those buffers.  `optimizer.step()` + `zero_grad()` (set_to_none or not)
+    is fine; a caller that KEEPS a gradient tensor across steps (gradient statistics, an EMA of gradients, a held reference after
+    zero_grad(set_to_none=True)) would see it silently rewritten -- so the engine RAISES at the start of the next backward when a handed-out view is
+    still referenced by anything but `p.grad` (clone what you want to keep; ALM_DP_DIRECT=0 stages every bucket instead and hands out copies)
+
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
 """
 from __future__ import annotations
 
 import contextlib
 import os
+import sys
 import time
 
 import torch
@@ -49,13 +61,23 @@ class _Bucket:
         self.params, self.grads, self.flat, self.work, self.direct = [], [], None, None, None
 
 
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7          # 7 point-to-point links of ~153 GB/s per GPU on an 8 x MI355X node
+
+
+def tail_model(nbytes, world=8):
+    """MODEL of the all-reduce time of `nbytes` that nothing hides, on one `world`-GPU xGMI node: a ring moves 2 (G - 1) / G of the bytes over ONE link per
+    GPU, a direct (one-shot reduce-scatter + all-gather) exchange spreads them over all 7 links.  SURVEY.md section 5 quotes 3.0 / 0.43 ms for 262 MB."""
+    vol = 2.0 * (world - 1) / world * nbytes
+    return dict(world=world, bytes=int(nbytes), ring=round(vol / (XGMI_LINK_GBS * 1e9) * 1e3, 3), direct=round(vol / (XGMI_LINK_GBS * XGMI_LINKS * 1e9) * 1e3, 3))
+
+
 class DataParallelEngine:
     def __init__(self, model, dist, process_group=None, broadcast_parameters=True, bucket_dtype=torch.float32, force_collectives=False):
         assert bucket_dtype in (torch.float32, torch.bfloat16), bucket_dtype
         self.model, self.dist, self.pg, self.bucket_dtype = model, dist, process_group, bucket_dtype
         self.world = dist.get_world_size(process_group)
         self.force = bool(force_collectives)
-        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[])
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[], bucket_bytes=[])
         self._t_last_launch = None
         self._avg_ok = str(dist.get_backend(process_group)).lower() == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -69,6 +91,8 @@ class DataParallelEngine:
         self._ev_bw_done = self._ev_all_done = None
         self._pending_flat = None
         self._inflight = []
+        self._handed = []                     # (param, view) pairs handed out as .grad by the last finish() (in-place buckets): see _check_handed_views
+        self._exposed_from = None             # index into stats['bucket_bytes'] of the first bucket launched after the last layer group's GEMMs
         self._loose = _Bucket()               # parameters outside the fused stack (heads first, embeddings last)
         self._stack_param_ids = set()
         tr = getattr(model, 'transformer', None)
@@ -103,6 +127,24 @@ class DataParallelEngine:
         if not self._bw_started:
             self._bw_started = True
             self._stale = any(q.grad is not None for q in self.params if q is not skip)
+            self._check_handed_views()
+
+    def _check_handed_views(self):
+        """the .grad-is-a-view contract (module docstring): the in-place bucket views handed out by the last finish() are about to be overwritten by this
+        backward's GEMMs.  A view that is still `p.grad` is handled (`_stale`: this backward takes the staged path); a view that ANYTHING ELSE still
+        references would be silently rewritten -> raise."""
+        handed, self._handed = self._handed, []
+        if not self._sync:
+            self._handed = handed                                  # (an accumulation micro-step writes no bucket: check again at the next synchronising backward)
+            return
+        for i in range(len(handed)):
+            p, v = handed[i]
+            handed[i] = None
+            extra = sys.getrefcount(v) - 2 - (1 if p.grad is v else 0)      # 2 = the local name `v` + getrefcount's own argument
+            if extra > 0:
+                raise RuntimeError('DataParallelEngine: a gradient tensor handed out as `.grad` by the previous finish() is still referenced elsewhere. '
+                                   'It is a VIEW of a persistent all-reduce bucket that this backward overwrites in place -- clone gradients you keep across '
+                                   'steps, or set ALM_DP_DIRECT=0 (staged buckets, .grad are copies).')
 
     def _overlapped(self):
         return self._sync and not self._dirty and not self._stale
@@ -121,6 +163,7 @@ class DataParallelEngine:
         work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
         self.stats['buckets'] += 1
         self.stats['bytes'] += flat.numel() * flat.element_size()
+        self.stats['bucket_bytes'].append(flat.numel() * flat.element_size())
         if flat.is_cuda:
             sid = int(torch.cuda.current_stream(flat.device).cuda_stream)
             if sid not in self.stats['launch_streams']:
@@ -154,6 +197,9 @@ class DataParallelEngine:
         accumulate (no_sync / stale .grad) a `.grad` may alias the bucket the next backward would overwrite -> None, the staged path runs."""
         self._begin_backward()
         self._pending_flat = None
+        if self._overlapped():
+            # round 6: whatever exists BEFORE the stack's backward (logit heads, final norm) goes on the wire now -- ahead of this group's GEMMs, not behind them
+            self._flush_loose(('loose', 'pre', l1))
         if not (self.direct_buckets and self.bucket_dtype == torch.float32 and self._overlapped() and (self.world > 1 or self.force)):
             return None
         L, ppl = self._stack.depth, self._ppl
@@ -196,6 +242,8 @@ class DataParallelEngine:
         if not self._overlapped():
             return
         self._flush_loose(('loose', 'pre', layers[0]))
+        if 0 in layers:                                           # the LAST group: everything launched from here on starts after the backward's last kernel
+            self._exposed_from = len(self.stats['bucket_bytes'])
         params, grads = [], []
         for layer, gl in zip(layers, grads_per_layer):
             for p, g in zip(self._stack_flat[layer * self._ppl:(layer + 1) * self._ppl], gl):
@@ -222,6 +270,7 @@ class DataParallelEngine:
         work = self.dist.all_reduce(flat, op=op, group=self.pg, async_op=True)
         self.stats['buckets'] += 1
         self.stats['bytes'] += flat.numel() * flat.element_size()
+        self.stats['bucket_bytes'].append(flat.numel() * flat.element_size())
         self.stats['direct_buckets'] = self.stats.get('direct_buckets', 0) + 1
         if flat.is_cuda:
             sid = int(torch.cuda.current_stream(flat.device).cuda_stream)
@@ -278,7 +327,10 @@ class DataParallelEngine:
             if b.direct is not None:                                   # in-place bucket: the reduced gradients ARE the bucket -- hand out views
                 for p, shape in zip(b.params, b.grads):
                     o, n = b.direct[id(p)]
-                    p.grad = b.flat[o:o + n].view(shape)
+                    v = b.flat[o:o + n].view(shape)
+                    p.grad = v
+                    self._handed.append((p, v))
+                    del v
                 continue
             views, o = [], 0
             for p, shape in zip(b.params, b.grads):
@@ -297,7 +349,12 @@ class DataParallelEngine:
             self._ev_all_done.record()
         if self._inflight and self._t_last_launch is not None:
             self.last_stats = dict(self.stats, tail_ms=round((time.perf_counter() - self._t_last_launch) * 1e3, 3))
-        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[])
+            bb = self.stats['bucket_bytes']
+            ef = self._exposed_from if self._exposed_from is not None else max(0, len(bb) - 1)
+            self.last_stats['tail_model_ms'] = tail_model(sum(bb[ef:]))
+            self.last_stats['exposed_bucket_bytes'] = bb[ef:]
+        self._exposed_from = None
+        self.stats = dict(buckets=0, bytes=0, tail_ms=0.0, launch_streams=[], bucket_bytes=[])
         self._t_last_launch = None
         self._inflight = []
 

@@ -46,12 +46,16 @@ def _build(dev, seed=0):
 
 def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ALM_DP_DEFER_GROUPS=str(dp_groups))
+    sizes = tuple(int(v) for v in dp_groups.split(',')) if isinstance(dp_groups, str) else ()
+    if sizes:                                                     # round 6: uneven layer groups in backward order (the last, exposed bucket is the small one)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ALM_DP_DEFER_GROUPS=str(len(sizes)), ALM_DP_GROUP_SIZES=dp_groups)
+    else:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ALM_DP_DEFER_GROUPS=str(dp_groups))
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from audiolm_pytorch_amd import core
     from audiolm_pytorch_amd.parallel import DataParallelEngine
-    assert core.DP_DEFER_GROUPS == dp_groups
+    assert core.DP_DEFER_GROUPS == (len(sizes) if sizes else dp_groups) and core.DP_GROUP_SIZES == sizes
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     model, w = _build(dev, seed=100 + rank)                       # different init per rank: the engine must broadcast rank 0's weights
@@ -63,6 +67,7 @@ def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     eng.finish()
     torch.cuda.synchronize()
     nbuckets = eng.last_stats['buckets']
+    bucket_bytes, exposed = eng.last_stats['bucket_bytes'], eng.last_stats['exposed_bucket_bytes']
     ndirect = eng.last_stats.get('direct_buckets', 0)
     aliased = sum(1 for p in model.parameters() if p.grad is not None and any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f, _ in eng._flat_groups.values()))
     g1 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
@@ -73,7 +78,8 @@ def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     torch.cuda.synchronize()
     g2 = {k: (p.grad.detach().float().cpu() if p.grad is not None else None) for k, p in model.named_parameters()}
     if rank == 0:
-        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss), buckets=nbuckets, direct=ndirect, aliased=aliased), out)
+        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, g1=g1, g2=g2, loss=float(loss), buckets=nbuckets, direct=ndirect, aliased=aliased,
+                        bucket_bytes=bucket_bytes, exposed=exposed), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,15 +89,23 @@ def _frob(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize('bucket_dtype,dp_groups', [('float32', 2), ('bfloat16', 2), ('float32', 1), ('float32', 0), ('float32', 3)])
+@pytest.mark.parametrize('bucket_dtype,dp_groups', [('float32', 2), ('bfloat16', 2), ('float32', 1), ('float32', 0), ('float32', 3), ('float32', '2,1')])
 def test_dp2_real_stack_matches_big_batch(tmp_path, bucket_dtype, dp_groups):
     """dp_groups: layer groups of the deferred weight gradients in the data-parallel step (2 = default: groups {2}, {0, 1} of this depth-3 model, one
     bucket each; 1 = everything at the end; 0 = the per-layer path of rounds 1-3) -- all must give the big-batch gradients"""
     import torch.multiprocessing as mp
     out = str(tmp_path / 'dp.pt')
-    port = 33500 + (os.getpid() % 2000) + (7 if bucket_dtype == 'bfloat16' else 0) + 13 * dp_groups
+    uneven = isinstance(dp_groups, str)
+    port = 33500 + (os.getpid() % 2000) + (7 if bucket_dtype == 'bfloat16' else 0) + 13 * (5 if uneven else dp_groups)
     mp.spawn(_worker, args=(2, port, out, bucket_dtype, dp_groups), nprocs=2, join=True)
     r = torch.load(out, weights_only=False)
+    if uneven:
+        # ALM_DP_GROUP_SIZES=2,1: [heads + final norm] first (handed over BEFORE the top group's GEMMs), the top two layers, the bottom layer, the embeddings;
+        # what nothing hides = the small last group's bucket + the embeddings' bucket
+        bb = r['bucket_bytes']
+        assert len(bb) == 4 and min(bb) > 0, bb                    # (at dim 256 the late small kinds of all layers make the last group's bucket the larger one)
+        assert r['exposed'] == bb[2:], (r['exposed'], bb)
+        dp_groups = len(dp_groups.split(','))
     assert r['buckets'] == (CTOR['depth'] if dp_groups == 0 else dp_groups) + 2, r['buckets']      # stack buckets + [heads, final norm] + [embeddings]
     # round 5: fp32 group buckets are produced IN PLACE (the weight-gradient GEMMs write into the engine's persistent flat bucket, finish() hands out views)
     assert r['direct'] == (dp_groups if bucket_dtype == 'float32' else 0), (r['direct'], dp_groups)

@@ -371,3 +371,110 @@ def test_dp_engine_in_place_group_buckets_with_late_small_kinds(tmp_path):
             continue
         assert torch.allclose(r['grads'][k], p.grad, atol=1e-6), k
     assert r['stats']['buckets'] == 1 + 2 and r['stats'].get('direct_buckets') == 2, r['stats']
+
+
+def _worker_uneven_groups(rank, world, port, out):
+    """round 6: UNEVEN layer groups (core.group_starts with ALM_DP_GROUP_SIZES, backward order): depth 3 cut as (2, 1) -- the top two layers form the
+    first bucket, the LAST (exposed) bucket is the single bottom layer.  Same in-place protocol as _worker_flat_groups; afterwards the .grad-is-a-view
+    contract: a gradient tensor kept across steps makes the next synchronising backward raise."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.parallel import DataParallelEngine
+    from audiolm_pytorch_amd.core import group_starts
+    torch.manual_seed(53 + rank)
+    model = Model()
+    eng = DataParallelEngine(model, dist)
+    flat = model.transformer.flat_params()
+    L = model.transformer.depth
+    starts = group_starts(L, 2, (2, 1))
+    assert starts == [0, 1], starts
+    ranges = [(s, ([t for t in starts if t > s] + [L])[0]) for s in reversed(starts)]          # backward order: (1, 3), then (0, 1)
+    assert ranges == [(1, 3), (0, 1)], ranges
+    ids_all = torch.arange(12).reshape(2, 6) % 10
+    res = []
+    for step in range(2):
+        for p in model.parameters():
+            p.grad = None
+        _loss(model, ids_all[rank:rank + 1] if step == 0 else (ids_all[rank:rank + 1] + 5) % 10).backward()
+        fresh = [[p.grad.clone() for p in flat[l * 2:(l + 1) * 2]] for l in range(L)]
+        for p in flat[:-1]:
+            p.grad = None
+        for (l0, l1) in ranges:
+            views = eng.group_buffer(l0, l1, [0])
+            assert views is not None and views[0].shape == (l1 - l0, 4, 4)
+            for l in range(l0, l1):
+                views[0][l - l0].copy_(fresh[l][0])
+            layers = list(range(l1 - 1, l0 - 1, -1))
+            eng.on_group(layers, [[views[0][l - l0], fresh[l][1]] for l in layers])
+            del views
+        eng.finish()
+        res.append(dict(grads={k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}, stats=eng.last_stats))
+    # the contract: keep one handed-out gradient across the step boundary -> the next synchronising backward refuses to overwrite it
+    kept = flat[0].grad
+    for p in model.parameters():
+        p.grad = None
+    raised = False
+    try:
+        _loss(model, ids_all[rank:rank + 1]).backward()
+    except RuntimeError as e:
+        raised = 'VIEW of a persistent all-reduce bucket' in str(e)
+    del kept
+    eng._bw_started = False
+    # ... and with nothing kept the same backward goes through
+    for p in model.parameters():
+        p.grad = None
+    _loss(model, ids_all[rank:rank + 1]).backward()
+    eng.finish()
+    if rank == 0:
+        torch.save(dict(sd={k: v.detach().clone() for k, v in model.state_dict().items()}, res=res, ids=ids_all, raised=raised), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_engine_uneven_layer_groups_and_view_contract(tmp_path):
+    out = str(tmp_path / 'uneven.pt')
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_worker_uneven_groups, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    model = Model()
+    model.load_state_dict(r['sd'])
+    for step, ids in enumerate((r['ids'], (r['ids'] + 5) % 10)):
+        model.zero_grad()
+        (sum(_loss(model, ids[i:i + 1]) for i in range(2)) / 2).backward()
+        rs = r['res'][step]
+        for k, p in model.named_parameters():
+            if k == 'unused':
+                assert rs['grads'][k] is None
+                continue
+            assert torch.allclose(rs['grads'][k], p.grad, atol=1e-6), (step, k)
+        st = rs['stats']
+        assert st['buckets'] == 1 + 2 and st.get('direct_buckets') == 2, st
+        # bucket order on the wire: [loose (handed over BEFORE the first group's GEMMs), top group of 2 layers, bottom group of 1 layer]; the exposed
+        # tail is the small last bucket alone, and the model prices exactly its bytes
+        bb = st['bucket_bytes']
+        assert len(bb) == 3 and bb[1] > bb[2], bb
+        assert st['exposed_bucket_bytes'] == [bb[2]], st
+        tm = st['tail_model_ms']
+        assert tm['bytes'] == bb[2] and tm['world'] == 8 and tm['ring'] >= tm['direct'] >= 0, tm
+    assert r['raised']
+
+
+def test_group_starts_uneven_and_equal():
+    sys.path.insert(0, ROOT)
+    import audiolm_pytorch_amd  # noqa: F401
+    from audiolm_pytorch_amd.core import group_starts
+    from audiolm_pytorch_amd.parallel import tail_model
+    assert group_starts(6, 2) == [0, 3] and group_starts(6, 1) == [0] and group_starts(6, 6) == list(range(6)) and group_starts(5, 2) == [0, 3]
+    assert group_starts(6, 2, (4, 2)) == [0, 2]                    # backward order: layers 5..2 first, the exposed last bucket = layers 1..0
+    assert group_starts(6, 2, (3, 2, 1)) == [0, 1, 3]
+    for bad in ((4, 3), (6, 0), (2, 2)):
+        try:
+            group_starts(6, 2, bad)
+        except ValueError:
+            continue
+        raise AssertionError(bad)
+    # SURVEY.md section 5's figures: 262 MB over a ring of 8 -> 3.0 ms, direct over 7 links -> 0.43 ms
+    tm = tail_model(262e6)
+    assert abs(tm['ring'] - 3.0) < 0.05 and abs(tm['direct'] - 0.43) < 0.01, tm
