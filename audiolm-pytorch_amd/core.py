@@ -658,9 +658,20 @@ DEFER_GROUPS = max(1, int(os.environ.get('ALM_DEFER_GROUPS', '1')))
 # (30 + 30 launches, +0.8 ms/step per GPU against the single-GPU step).  0 = that per-layer path (one bucket per layer, maximal overlap, slower GEMMs).
 DP_DEFER_GROUPS = max(0, int(os.environ.get('ALM_DP_DEFER_GROUPS', '2')))
 # Round 6: UNEVEN layer groups for the data-parallel path, in backward order (top of the stack first), e.g. ALM_DP_GROUP_SIZES=4,2 at depth 6: the LAST group's
-# bucket is the one whose all-reduce nothing hides (the backward is over when it starts), so it should be the small one -- 77 instead of 115 MB on the wire
-# after the last kernel.  Empty: DP_DEFER_GROUPS equal groups.  Sizes that do not sum to the depth are rejected at the first backward.
-DP_GROUP_SIZES = tuple(int(v) for v in os.environ.get('ALM_DP_GROUP_SIZES', '').replace(' ', '').split(',') if v)
+# bucket is the one whose all-reduce nothing hides (the backward is over when it starts), so it should be the small one.  Sizes that do not sum to the depth
+# are rejected at the first backward.  DEFAULT (variable unset) with 2 groups: (L - 1, 1) -- the bottom layer alone closes the backward.  Measured at N = 1
+# (profiles/r6n_groups_ab.log, depth 6, 3 interleaved rounds): one group 11.08 ms/step, (3,3) +0.33, (4,2) +0.48, (5,1) +0.22 -- the cheapest cut is also the
+# one with the smallest exposed bucket (62 MB: one layer's dW1 / dW2 + the small kinds of all layers, against 129 MB for (3,3)).  ALM_DP_GROUP_SIZES=even:
+# equal groups (rounds 4-5).
+_DPGS = os.environ.get('ALM_DP_GROUP_SIZES', '').replace(' ', '').lower()
+DP_GROUP_SIZES = None if _DPGS == '' else (() if _DPGS == 'even' else tuple(int(v) for v in _DPGS.split(',') if v))
+
+
+def dp_group_sizes(L, ngroups):
+    """group sizes (backward order) of the data-parallel step's weight-gradient cut: the explicit ALM_DP_GROUP_SIZES, else (L - 1, 1) for two groups"""
+    if DP_GROUP_SIZES is not None:
+        return DP_GROUP_SIZES
+    return (L - 1, 1) if (ngroups == 2 and L >= 3) else ()
 # the same cut without a gradient hook (single GPU): what the grouping itself costs at N = 1 is measured with this (bench.py --gpus 1)
 DEFER_GROUP_SIZES = tuple(int(v) for v in os.environ.get('ALM_DEFER_GROUP_SIZES', '').replace(' ', '').split(',') if v)
 
@@ -790,7 +801,7 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
             DEFER_GROUPS if on_layer_grads is None else max(1, DP_DEFER_GROUPS))
         ngroups = min(ngroups, L)
         capturing = dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-        starts = group_starts(L, ngroups, () if capturing else (DP_GROUP_SIZES if on_layer_grads is not None else DEFER_GROUP_SIZES))
+        starts = group_starts(L, ngroups, () if capturing else (dp_group_sizes(L, ngroups) if on_layer_grads is not None else DEFER_GROUP_SIZES))
         ngroups = len(starts)
         on_group = getattr(on_layer_grads, 'on_group', None)                   # parallel.DataParallelEngine: one bucket per layer GROUP
         group_buffer = getattr(on_layer_grads, 'group_buffer', None)           # ... whose flat bucket the weight-gradient GEMMs write straight into

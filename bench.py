@@ -729,7 +729,7 @@ def main():
                        # are the deferred, layer-batched path (N > 1: cut into layer groups, one gradient bucket per group)
                        'wgrad_path': ('per-layer' if (not core.DEFER_WGRAD or (world > 1 and core.DP_DEFER_GROUPS == 0)) else
                                       f'deferred-g{core.DEFER_GROUPS if world == 1 else core.DP_DEFER_GROUPS}' +
-                                      (lambda gs: ('[' + ','.join(map(str, gs)) + ']') if gs else '')(core.DEFER_GROUP_SIZES if world == 1 else core.DP_GROUP_SIZES))},
+                                      (lambda gs: ('[' + ','.join(map(str, gs)) + ']') if gs else '')(core.DEFER_GROUP_SIZES if world == 1 else core.dp_group_sizes(model.transformer.depth, core.DP_DEFER_GROUPS)))},
             'loss': round(float(loss), 4),
             'host': host,
         }

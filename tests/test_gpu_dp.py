@@ -55,7 +55,7 @@ def _worker(rank, world, port, out, bucket_dtype, dp_groups):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from audiolm_pytorch_amd import core
     from audiolm_pytorch_amd.parallel import DataParallelEngine
-    assert core.DP_DEFER_GROUPS == (len(sizes) if sizes else dp_groups) and core.DP_GROUP_SIZES == sizes
+    assert core.DP_DEFER_GROUPS == (len(sizes) if sizes else dp_groups) and (core.DP_GROUP_SIZES or ()) == sizes
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     model, w = _build(dev, seed=100 + rank)                       # different init per rank: the engine must broadcast rank 0's weights
