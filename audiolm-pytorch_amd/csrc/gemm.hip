@@ -32,6 +32,15 @@
 #include "common.hpp"
 #include "../../include/audiolm_hip.h"
 
+// Cache policy of the operand DMA (`buffer_load ... lds` aux immediate: 1 = sc0, 2 = nt, 16 = sc1).  0 in the product build; scripts/build_variant.sh
+// builds measurement libraries with -DALM_GEMM_AUX_A=2 / -DALM_GEMM_AUX_B=2 (one operand streamed non-temporally past the L2: round 6, DESIGN labbook)
+#ifndef ALM_GEMM_AUX_A
+#define ALM_GEMM_AUX_A 0
+#endif
+#ifndef ALM_GEMM_AUX_B
+#define ALM_GEMM_AUX_B 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -327,12 +336,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, con
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, ALM_GEMM_AUX_A);
         }
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, ALM_GEMM_AUX_B);
         }
     };
 
@@ -592,12 +601,12 @@ __device__ __forceinline__ void gemm_stag_body(const GemmParams& p, const int bx
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned vo = (kcA[i] < kleft) ? offA[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(ad + dstA[i]), 16, vo, j * kstepA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(ad + dstA[i]), 16, vo, j * kstepA, 0, ALM_GEMM_AUX_A);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned vo = (kcB[i] < kleft) ? offB[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(bd + dstB[i]), 16, vo, j * kstepB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(bd + dstB[i]), 16, vo, j * kstepB, 0, ALM_GEMM_AUX_B);
         }
     };
 
@@ -924,7 +933,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NIA; ++j) {
             const unsigned vo = (kcA[j] < kleft) ? offA[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + (j * NW + wave) * 1024), 16, vo, kt * kstepA, 0, ALM_GEMM_AUX_A);
         }
     };
     auto stage_b = [&](int kt, unsigned char* base) {
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NIB; ++j) {
             const unsigned vo = (kcB[j] < kleft) ? offB[j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + A_BYTES + (j * NW + wave) * 1024), 16, vo, kt * kstepB, 0, ALM_GEMM_AUX_B);
         }
     };
     auto stage = [&](int kt, unsigned char* base) { stage_a(kt, base); stage_b(kt, base); };
