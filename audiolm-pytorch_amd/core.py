@@ -90,12 +90,14 @@ _PACK_REGISTRY = {}      # data_ptr -> dict(stamp, cache (weakref), key, out (th
 
 
 _PACK_CACHES_SEEN = set()          # id(cache) of every WeightCache that has a finaliser installed
+_PACK_GEN = [0]                    # bumped whenever an entry is (re)registered or dropped: optimizer.FusedAdam keys its prepared tables on it
 
 
 def _drop_cache_entries(cid):
     _PACK_CACHES_SEEN.discard(cid)
     for k in [k for k, e in _PACK_REGISTRY.items() if e['cid'] == cid]:
         del _PACK_REGISTRY[k]
+    _PACK_GEN[0] += 1
 
 
 def _register_pack(w, stamp, cache, key, out, jobs):
@@ -109,6 +111,7 @@ def _register_pack(w, stamp, cache, key, out, jobs):
         _PACK_CACHES_SEEN.add(cid)
         weakref.finalize(cache, _drop_cache_entries, cid)
     _PACK_REGISTRY[w.data_ptr()] = dict(stamp=stamp, cache=weakref.ref(cache), cid=cid, key=key, out=out, jobs=jobs)
+    _PACK_GEN[0] += 1
 
 
 def pack_target(p):
@@ -235,10 +238,11 @@ PACK_ALL = os.environ.get('ALM_PACK_ALL', '1') != '0'
 def pack_stack_weights(cache: WeightCache, flat, cfg):
     """re-pack the bf16 (W, W^T) images of every layer whose masters changed since they were last packed -- one launch for the whole stack"""
     S, ppl = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend)
-    plans, jobs = [], []
+    plans, jobs, split = [], [], []
     with torch.no_grad():
         for l in range(cfg.depth):
-            plan = _layer_pack_plan(cache, l, _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend), cfg.inner, cfg.inner_pad)
+            split.append(_split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend))
+            plan = _layer_pack_plan(cache, l, split[-1], cfg.inner, cfg.inner_pad)
             if plan is not None:
                 plans.append((l, plan))
                 jobs += plan[3]
@@ -246,17 +250,20 @@ def pack_stack_weights(cache: WeightCache, flat, cfg):
             ops.pack_weights_multi(jobs)
     for l, plan in plans:
         _commit_pack_plan(cache, l, plan)
+    return split                       # per layer: its branches -- every layer's images are current now (layer_weights(..., current=True) skips its own scan)
 
 
-def layer_weights(cache: WeightCache, l, branches, I, Ip):
+def layer_weights(cache: WeightCache, l, branches, I, Ip, current=False):
     """bf16 packed (W, W^T) pairs of one layer's dense weights -> {kind: {name: (W, WT)}}; when any master changed, ALL of the layer are re-packed
-    (one launch).  branches: _split_layer() of the layer's detached parameters."""
-    with torch.no_grad():
-        plan = _layer_pack_plan(cache, l, branches, I, Ip)
+    (one launch).  branches: _split_layer() of the layer's detached parameters.  current: pack_stack_weights() has just confirmed (or refreshed) this
+    layer's images in this call -- no second version scan (it doubled the per-token cache-check cost of a decode step)."""
+    if not current:
+        with torch.no_grad():
+            plan = _layer_pack_plan(cache, l, branches, I, Ip)
+            if plan is not None:
+                ops.pack_weights_multi(plan[3])
         if plan is not None:
-            ops.pack_weights_multi(plan[3])
-    if plan is not None:
-        _commit_pack_plan(cache, l, plan)
+            _commit_pack_plan(cache, l, plan)
     res = {}
     for kind, d, _ in branches:
         for name in ('wq', 'wkv', 'wo', 'w1', 'w2'):
@@ -519,11 +526,10 @@ def stack_forward(x, mask_u8, flat, cfg: StackCfg, cache: WeightCache, need_grad
     else:
         drop_seed = _attn_seed() if attn_dropout > 0. else 0
     pend_y = pend_coef = None            # S > 1: branch output + coefficient record whose depth connection is still to be applied
-    if PACK_ALL:
-        pack_stack_weights(cache, flat, cfg)
+    split = pack_stack_weights(cache, flat, cfg) if PACK_ALL else None
     for l in range(cfg.depth):
-        branches = _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
-        LW = layer_weights(cache, l, branches, I, Ip)
+        branches = split[l] if split is not None else _split_layer(flat[l * ppl:(l + 1) * ppl], S, cfg.cross_attend)
+        LW = layer_weights(cache, l, branches, I, Ip, current=split is not None)
         for kind, prm, first in branches:
             want_x = kind == 'attn'                  # only to_kv reads the un-normalised branch input
             xo = xno = None

@@ -1308,6 +1308,14 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     p.tbl = ba.tbl; p.LT = ba.LT; p.qkey4 = ba.qkey4; p.kkey4 = ba.kkey4; p.qattr = ba.qattr; p.kattr = ba.kattr;
     const int npair = ((N + 31) / 32 + 1) / 2;                           // 32-query blocks, taken two (idx, last - idx) per workgroup
     const bool drop = set_dropout(p, dropout_p, seed, seed_dev);
+    // QB = 2 (one 64-query block per workgroup and wave: half the K / V fragment reads per MFMA, heavy / light blocks paired on a CU) is what the kernel
+    // did before the equal-length pairing of QB = 1 fixed the long pole at N = 2048.  ALM_ATTN_FWD_QB2_MINN=<N>: sequences of at least N keys take it (A/B).
+    static const int qb2_minn = [] { const char* e = getenv("ALM_ATTN_FWD_QB2_MINN"); return e ? atoi(e) : 0; }();
+    if (qb2_minn > 0 && N >= qb2_minn && !drop && !p.tbl) {
+        hipLaunchKernelGGL((mqa_fwd_kernel<false, 2>), dim3(((N + 63) / 64) * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);
+        ALM_LAUNCH_CHECK();
+        return 0;
+    }
     if (drop) {
         if (p.tbl) hipLaunchKernelGGL((mqa_fwd_kernel<true, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<true>, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((mqa_fwd_kernel<false, 1, true>), dim3(npair * p.HG * B), dim3(256), FWD_LDS<false>, (hipStream_t)stream, p);

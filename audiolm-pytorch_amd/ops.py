@@ -812,16 +812,26 @@ def embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D):
               src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, _st())
 
 
+# fp32 elements of chunk partials the owned scatter may allocate per backward (default 2^28 = 1 GiB); above it the atomic kernel runs (ALM_EMBED_SCATTER_WS_CAP)
+EMBED_SCATTER_WS_CAP = int(os.environ.get('ALM_EMBED_SCATTER_WS_CAP', str(1 << 28)))
+
+
 def embed_scatter_owned(grad_tables, src_a, src_b, dout, alpha, rows, D):
     """deterministic form of embed_scatter_add (one owner per destination row, fixed summation order, no atomics): WRITES every row of every table --
-    `grad_tables` may be uninitialised memory (alm_embed_scatter_owned)"""
+    `grad_tables` may be uninitialised memory (alm_embed_scatter_owned).  -> True; False when the size is outside its range and the atomic kernel ran instead"""
     arr, tr = _ptr_array(grad_tables), _table_rows(grad_tables)
     nws = _lib.query('alm_embed_scatter_ws_floats', ctypes.cast(tr, ctypes.c_void_p), len(grad_tables), rows, D)
-    if nws < 0:
-        raise _lib.AlmError('alm_embed_scatter_ws_floats: unsupported size')
+    if nws < 0 or nws > EMBED_SCATTER_WS_CAP:
+        # outside the owned kernel's range (rows >= 2^28, or a chunk-partial workspace that grows with B * N beyond the cap: ~0.5 GB at 128 k tokens):
+        # the atomic kernel takes over on zeroed tables -- same sums, arrival-order rounding (the caller is told through the return value)
+        for g in grad_tables:
+            g.zero_()
+        embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D)
+        return False
     ws = torch.empty(max(nws, 1), dtype=F32, device=dout.device)
     _lib.call('alm_embed_scatter_owned', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(tr, ctypes.c_void_p), len(grad_tables),
               src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, ws.data_ptr(), _st())
+    return True
 
 
 def gather_split(inp, idx=None, rows_out=None, out=None):

@@ -111,10 +111,15 @@ class FusedAdam(torch.optim.Optimizer):
         flat = [p for ps in groups for p in ps]
         if not flat:
             return None
-        gkey = tuple(p.grad.data_ptr() for p in flat)
+        from . import core
+        # the tables are shared by clip_grad_norm_() and step() of ONE iteration.  With the in-place data-parallel buckets the gradient pointers are the
+        # same every step, so they alone do not identify the iteration (a clip_grad_norm_() without a following step() left tables with stale
+        # step counts / pack targets for the next one): the key also carries every parameter's version counter (advanced by each update), the step counts
+        # and the generation of the packed-weight registry.
+        gkey = (tuple(p.grad.data_ptr() for p in flat), tuple(core.tensor_version(p) for p in flat),
+                tuple(int(self.state[ps[0]]['step']) if ps else -1 for ps in groups), core._PACK_GEN[0])
         if self._prepared is not None and self._prepared[0] == gkey:
             return self._prepared[1]
-        from . import core
         dev = flat[0].device
         mixed = [len({int(self.state[p]['step']) for p in ps}) > 1 for ps in groups]
         targets = [[core.pack_target(p) for p in ps] for ps in groups]

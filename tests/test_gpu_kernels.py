@@ -72,6 +72,34 @@ def test_gemm_nt_tile_configs(ops, M, N, K, tile):
         assert bool(torch.isnan(C[M:]).all()) and bool(torch.isnan(C[:, N:]).all()), 'GEMM wrote outside its tile'
 
 
+@pytest.mark.parametrize('nb,M,N,K', [(1, 2048, 128, 1024), (1, 100, 512, 520), (3, 300, 384, 264), (2, 1024, 1024, 456), (6, 64, 520, 1000)])
+def test_gemm_nt_ring_tile_automatic_route_every_epilogue(ops, nb, M, N, K):
+    """the 4-stage DMA-ring form of the 128 x 128 tile (tile 16) is taken AUTOMATICALLY by every NT launch of <= 256 such tiles with K >= 256 --
+    batched launches, bias / alpha / accumulate epilogues, fp32 and bf16 output, M < 128 and K % 64 != 0 included, not only the un-batched `to_kv` it was
+    measured on.  Each of those through the automatic entry point against fp64, with the plan query confirming that the ring kernel is what ran."""
+    import ctypes
+    from audiolm_pytorch_amd import _lib
+    plan = (ctypes.c_int * 4)()
+    _lib.query('alm_gemm_nt_plan', M, N, K, nb, 0, ctypes.cast(plan, ctypes.c_void_p))
+    assert plan[0] == 16, list(plan)
+    A = rnd(nb, M, K, seed=21, dtype=BF16) if nb > 1 else rnd(M, K, seed=21, dtype=BF16)
+    B = rnd(nb, N, K, seed=22, dtype=BF16) if nb > 1 else rnd(N, K, seed=22, dtype=BF16)
+    bias = rnd(N, seed=23)
+    ref0 = A.double() @ B.double().transpose(-1, -2)
+    for dt, tol in ((F32, 3e-5), (BF16, 6e-3)):
+        shape = (nb, M + 3, N + 8) if nb > 1 else (M + 3, N + 8)
+        for kw, ref in ((dict(), ref0), (dict(bias=bias), ref0 + bias.double()), (dict(alpha=0.37), 0.37 * ref0)):
+            C = torch.full(shape, float('nan'), dtype=dt, device=dev())
+            ops.gemm_nt(A, B, C[..., :M, :N], **kw)
+            assert relmax(C[..., :M, :N], ref) <= tol, (dt, kw.keys())
+            assert bool(torch.isnan(C[..., M:, :]).all()) and bool(torch.isnan(C[..., :, N:]).all()), 'GEMM wrote outside its tile'
+        C0 = rnd(*shape, seed=24).to(dt)
+        C = C0.clone()
+        ops.gemm_nt(A, B, C[..., :M, :N], alpha=0.5, accumulate=True)
+        assert relmax(C[..., :M, :N], C0[..., :M, :N].double() + 0.5 * ref0) <= tol
+        assert torch.equal(C[..., M:, :], C0[..., M:, :]) and torch.equal(C[..., :, N:], C0[..., :, N:])
+
+
 @pytest.mark.parametrize('M,N,K,slices', [(8192, 1024, 2736, 2), (8192, 1024, 512, 2), (8192, 512, 1024, 4), (16384, 512, 1024, 2), (8192, 1024, 5472, 2),
                                           (1000, 520, 1000, 3), (300, 256, 4096, 8), (515, 700, 264, 2), (2049, 1024, 2736, 4), (256, 256, 128, 2),
                                           (8192, 1024, 2736, 1)])
@@ -895,6 +923,24 @@ def test_embed_scatter_owned_is_exact_deterministic_and_needs_no_zero_fill(ops, 
     grads = [torch.zeros_like(t) for t in tables]
     ops.embed_scatter_add(grads, src_a, src_b, dout, 0.5, rows, D)
     assert all(torch.allclose(a, b, atol=1e-4) for a, b in zip(outs[0], grads))
+
+
+def test_embed_scatter_owned_falls_back_to_the_atomic_kernel_above_the_workspace_cap(ops, monkeypatch):
+    """outside the owned kernel's range (rows >= 2^28 / a chunk-partial workspace above ops.EMBED_SCATTER_WS_CAP) the call must not raise
+    mid-backward: the atomic kernel runs on zeroed tables (return value False) and gives the same sums"""
+    D, rows, nbig = 320, 300, 100
+    big, small = rnd(nbig, D, seed=60), rnd(3, D, seed=61)
+    g = torch.Generator().manual_seed(63)
+    src_a = torch.randint(-1, nbig, (rows,), generator=g).to(torch.int32).to(dev())
+    ib = torch.randint(-1, 3, (rows,), generator=g)
+    src_b = torch.where(ib >= 0, ib + (1 << 24), torch.full_like(ib, -1)).to(torch.int32).to(dev())
+    dout = rnd(rows, D, seed=64)
+    ref = [torch.full_like(t, float('nan')) for t in (big, small)]
+    assert ops.embed_scatter_owned(ref, src_a, src_b, dout, 0.5, rows, D) is True
+    monkeypatch.setattr(ops, 'EMBED_SCATTER_WS_CAP', 0)
+    got = [torch.full_like(t, float('nan')) for t in (big, small)]
+    assert ops.embed_scatter_owned(got, src_a, src_b, dout, 0.5, rows, D) is False
+    assert all(bool(torch.isfinite(a).all()) and torch.allclose(a, b, atol=1e-4) for a, b in zip(got, ref))
 
 
 def test_embed_scatter_owned_no_tokens(ops):
