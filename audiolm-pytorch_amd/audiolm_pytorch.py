@@ -729,6 +729,7 @@ class Transformer(nn.Module):
 # ---------------------------------------------------------------------------------------------- embedding assembly
 
 _EMBED_SCATTER_OWNED = os.environ.get('ALM_EMBED_SCATTER', 'owned') != 'atomic'
+_SEMANTIC_PREPARE = os.environ.get('ALM_SEMANTIC_PREPARE', '1') != '0'        # A/B + test switch: 0 = the ATen id bookkeeping in SemanticTransformerWrapper.forward
 
 
 class EmbedAssembleFn(torch.autograd.Function):
@@ -1025,11 +1026,12 @@ class SemanticTransformer(_TransformerBase):
         self.to_logits = nn.Linear(dim, num_semantic_tokens + 1)
         self.dim = dim
 
-    def _tokens(self, ids, self_attn_mask):
+    def _tokens(self, ids, self_attn_mask, src_a=None):
         b, n = ids.shape
         dev = ids.device
-        sem = ids.to(torch.int32)                                                              # table 0; pad (-1) -> zero vector (:176-181)
-        src_a = torch.cat((_const_code(1, b, dev), sem), dim=1).contiguous()
+        if src_a is None:                                                                      # (else: from ops.semantic_prepare -- the same codes, one kernel)
+            sem = ids.to(torch.int32)                                                          # table 0; pad (-1) -> zero vector (:176-181)
+            src_a = torch.cat((_const_code(1, b, dev), sem), dim=1).contiguous()
         src_b = _neg(b, n + 1, dev)
         tokens = EmbedAssembleFn.apply(src_a.reshape(-1), src_b.reshape(-1), b * (n + 1), self.dim,
                                        self.semantic_embedding.weight, self.start_token).view(b, n + 1, self.dim)
@@ -1037,8 +1039,8 @@ class SemanticTransformer(_TransformerBase):
             self_attn_mask = F.pad(self_attn_mask, (1, 0), value=True)                       # :716
         return tokens, self_attn_mask
 
-    def _hidden(self, ids, self_attn_mask, context=None, context_mask=None):
-        tokens, self_attn_mask = self._tokens(ids, self_attn_mask)
+    def _hidden(self, ids, self_attn_mask, context=None, context_mask=None, src_a=None):
+        tokens, self_attn_mask = self._tokens(ids, self_attn_mask, src_a)
         b, n1 = tokens.shape[:2]
         return self.transformer(tokens, self_attn_mask=self_attn_mask, context=context, context_mask=context_mask, return_flat_hidden=True), b, n1
 
@@ -1066,7 +1068,7 @@ class SemanticTransformer(_TransformerBase):
         return self._last_logits(h, self.to_logits.weight.unsqueeze(0), self.to_logits.bias, 'semantic', 0), state
 
     def forward(self, *, ids=None, return_loss=False, text=None, text_embeds=None, self_attn_mask=None, cond_drop_prob=None,
-                unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None):
+                unique_consecutive=None, kv_cache=None, return_kv_cache=False, labels=None, _src_a=None):
         context, context_mask = self._condition(ids.shape[0], ids.device, text, text_embeds, cond_drop_prob, mask_from_embeds=False)
         if return_loss:
             ids = ids[:, :-1]                                                                # :706-707 (the reference drops the labels)
@@ -1078,7 +1080,7 @@ class SemanticTransformer(_TransformerBase):
             b, N = h.shape[:2]                                                               # only the positions the cache did not cover
             hn = h.reshape(b * N, self.dim).contiguous()
         else:
-            hn, b, N = self._hidden(ids, self_attn_mask, context, context_mask)
+            hn, b, N = self._hidden(ids, self_attn_mask, context, context_mask, src_a=None if return_loss else _src_a)
         idx, i_grid, valid = _group_index(b, N, 0, N, 1, ids.device)
         if exists(labels):                                                                   # fused loss path (wrapper)
             grp = heads.HeadGroup('semantic', self.to_logits.weight, self.to_logits.bias, idx, _group_labels(labels, i_grid, valid, N))
@@ -1469,6 +1471,14 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
             assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
             semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
         semantic_token_ids = _flatten_ids(semantic_token_ids)
+        if (self.training and return_loss and not self.unique_consecutive and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64
+                and not kwargs and _SEMANTIC_PREPARE):
+            # the training step's id bookkeeping as ONE kernel (ops.semantic_prepare: eos appended = the labels, [start | ids] embedding codes), as the
+            # Coarse / Fine wrappers have it; every other call pattern takes the ATen formulation below (equality-tested against it)
+            sem = semantic_token_ids if semantic_token_ids.stride(1) == 1 else semantic_token_ids.contiguous()
+            labels, src_a = ops.semantic_prepare(sem, self.transformer.eos_id, self.transformer.semantic_embedding.weight.shape[0])
+            self_attn_mask = generate_mask_with_prob(sem.shape, self.mask_prob, sem.device) if self.mask_prob > 0. else None
+            return self.transformer(ids=sem, text=text, text_embeds=text_embeds, self_attn_mask=self_attn_mask, labels=labels, _src_a=src_a)
         if self.training:
             semantic_token_ids = append_eos_id(semantic_token_ids, self.transformer.eos_id)        # :1536-1537
         if self.unique_consecutive:

@@ -581,6 +581,24 @@ __global__ __launch_bounds__(256) void coarse_prepare_kernel(const long long* __
     }
 }
 
+// SemanticTransformerWrapper.forward's id bookkeeping of a training step (audiolm_pytorch.py:1536-1548: eos appended, the input ids = the labels without their
+// last position) + the embedding source codes of SemanticTransformer.forward (:709-714: [start token | ids], a negative id = the zero vector, :176-181) in ONE
+// launch -- the cat / ones / cast / cat chain of ~6 ATen launches otherwise.  labels int64 [B][n0 + 1], src_a int32 [B][n0 + 1].
+__global__ __launch_bounds__(256) void semantic_prepare_kernel(const long long* __restrict__ sem, long long ld_sem, int B, int n0, long long eos_id,
+                                                               long long* __restrict__ labels, int* __restrict__ src_a) {
+    const int W = n0 + 1;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)B * W; t += (long long)gridDim.x * 256) {
+        const int b = (int)(t / W), i = (int)(t % W);
+        labels[t] = i < n0 ? sem[(long long)b * ld_sem + i] : eos_id;
+        int code = 1 << 24;                                                    // start_token (table 1)
+        if (i > 0) {
+            const long long v = sem[(long long)b * ld_sem + i - 1];            // input position i = id i - 1 (the appended eos is a label only)
+            code = v < 0 ? -1 : (int)v;                                        // table 0
+        }
+        src_a[t] = code;
+    }
+}
+
 // FineTransformer.forward's id bookkeeping (audiolm_pytorch.py:1171-1223) in ONE launch: key mask of the coarse ids (pad / eos keys are masked and their ids
 // zeroed, :1175-1177), the mask padded over [coarse start | coarse | fine start | fine] (:1179) and the embedding source codes (start tokens, per-quantizer
 // offset rows id + (i mod Q) * codebook_size of the two tables, :1186-1223) -- ~12 ATen launches otherwise.  N = 1 + n + 1 + nf.
@@ -817,6 +835,16 @@ extern "C" int alm_coarse_prepare(const long long* sem, long long ld_sem, const 
     if ((long long)(Q - 1) * C + C + 1 >= (1 << 24) || B * W >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(coarse_prepare_kernel, dim3(grid_for(B * W)), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, coarse, ld_coarse, B, ns0, nc0, pad_id,
                        sem_eos, coarse_eos, Q, C, sem_labels, coarse_labels, src_a, (unsigned char*)keep);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+/* see semantic_prepare_kernel.  sem int64 [B][n0] (row stride ld_sem) */
+extern "C" int alm_semantic_prepare(const long long* sem, long long ld_sem, int B, int n0, long long eos_id, long long num_rows, long long* labels, int* src_a,
+                                    void* stream) {
+    if (B <= 0 || n0 < 0 || !labels || !src_a || (n0 > 0 && !sem)) return ALM_ERR_BAD_ARG;
+    if (num_rows >= (1 << 24) || (long long)B * (n0 + 1) >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;      // (the table id lives in bits 24+ of a source code)
+    hipLaunchKernelGGL(semantic_prepare_kernel, dim3(grid_for((long long)B * (n0 + 1))), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, B, n0, eos_id, labels, src_a);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -429,6 +429,18 @@ def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C):
     return sl, cl, src_a, keep
 
 
+def semantic_prepare(sem, eos_id, num_rows):
+    """sem int64 [B, n0] -> (labels int64 [B, n0 + 1] = [ids | eos], src_a int32 [B, n0 + 1] = [start token | ids]): SemanticTransformerWrapper's training-step
+    id bookkeeping + SemanticTransformer's embedding source codes (C ABI: alm_semantic_prepare)."""
+    _chk(sem, torch.int64)
+    assert sem.dim() == 2 and (sem.shape[1] == 0 or sem.stride(1) == 1)
+    B, n0 = sem.shape
+    labels = torch.empty((B, n0 + 1), dtype=torch.int64, device=sem.device)
+    src_a = torch.empty((B, n0 + 1), dtype=torch.int32, device=sem.device)
+    _lib.call('alm_semantic_prepare', sem.data_ptr(), sem.stride(0), B, n0, int(eos_id), int(num_rows), labels.data_ptr(), src_a.data_ptr(), _st())
+    return labels, src_a
+
+
 def fine_prepare(coarse, fine, nf, pad_id, eos_id, Qc, Qf, C):
     """coarse int64 [B, n], fine int64 [B, >= nf] (flattened (n q)) -> (src_a int32 [B, N], keep bool [B, N]), N = n + nf + 2: FineTransformer.forward's
     id bookkeeping (C ABI: alm_fine_prepare)."""

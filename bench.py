@@ -326,11 +326,12 @@ def main():
     bucket_dtype = torch.bfloat16 if args.bucket_dtype == 'bf16' else torch.float32
     engine = parallel.DataParallelEngine(model, dist, bucket_dtype=bucket_dtype) if world > 1 else None
     cache = model.transformer._cache
+    params = list(model.parameters())                           # (as optimizer.zero_grad(set_to_none=True) holds them: no module-tree walk per step)
 
     def eager_step(opt=None, repack=True):
         if repack:
             cache.store.clear()                                 # weights "changed": re-pack bf16 copies like after an optimiser step
-        for p in model.parameters():
+        for p in params:
             p.grad = None
         with amp():
             loss = wrapper(**inputs, return_loss=True)

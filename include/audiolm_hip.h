@@ -218,6 +218,11 @@ int alm_loss_combine(const float* s0, const float* s1, const float* s2, const fl
 int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0, long long pad_id,
                        long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels, long long* coarse_labels, int* src_a, void* keep,
                        void* stream);
+/* SemanticTransformerWrapper.forward's id bookkeeping of a training step, audiolm_pytorch.py:1536-1548 (`append_eos_id`, input ids = ids[:, :-1]) + the
+ * embedding source codes of SemanticTransformer.forward :709-714 ([start token | ids]; a negative id is the zero vector, :176-181) in one launch.
+ * sem int64 [B][n0]; labels int64 [B][n0 + 1] = [ids | eos]; src_a int32 [B][n0 + 1] = [start | ids]; num_rows = rows of the embedding table (< 2^24). */
+int alm_semantic_prepare(const long long* sem, long long ld_sem, int B, int n0, long long eos_id, long long num_rows, long long* labels, int* src_a,
+                         void* stream);
 /* FineTransformer.forward's id bookkeeping, audiolm_pytorch.py:1171-1223 (key mask of pad / eos coarse keys, their ids zeroed, mask padded over
  * [coarse start | coarse | fine start | fine], embedding source codes id + (i mod Q) * codebook_size per table) in one launch.  fine: the first nf ids of
  * each row (the training wrapper drops the last one, :2086).  src_a int32 [B][n + nf + 2], keep bool [B][n + nf + 2]. */

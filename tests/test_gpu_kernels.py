@@ -1146,3 +1146,46 @@ def test_coarse_prepare_kernel_matches_the_wrapper_bookkeeping(ops, B, ns0, nf, 
     rows = coarse.to(torch.int32) + AP._quantizer_row_offsets(nc, Q, C, coarse.device)
     ref = torch.cat((AP._const_code(3, B, coarse.device), sem_clean.to(torch.int32).clamp(min=-1), AP._const_code(4, B, coarse.device), AP._code(1, rows)), dim=1)
     assert torch.equal(src_a, ref)
+
+
+@pytest.mark.parametrize('B,n0', [(3, 17), (1, 0), (4, 100), (2, 1021)])
+def test_semantic_prepare_kernel_matches_the_wrapper_bookkeeping(ops, B, n0):
+    """alm_semantic_prepare (round 6) vs the ATen formulation it replaces (SemanticTransformerWrapper.forward :1536-1548 + SemanticTransformer._tokens): labels
+    with the eos appended, [start | ids] source codes, pad ids (-1) as the zero vector; a strided (sliced) id tensor"""
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    g = torch.Generator().manual_seed(17 * B + n0)
+    n_sem, pad = 50, -1
+    wide = torch.randint(0, n_sem, (B, n0 + 3), generator=g)
+    wide[torch.rand(B, n0 + 3, generator=g) < 0.15] = pad
+    sem = wide.to(dev())[:, :n0]                                     # row stride n0 + 3
+    labels, src_a = ops.semantic_prepare(sem, n_sem, n_sem + 1)
+    ref_labels = AP.append_eos_id(sem, n_sem)
+    assert torch.equal(labels, ref_labels)
+    ref_src = torch.cat((AP._const_code(1, B, sem.device), ref_labels[:, :-1].to(torch.int32)), dim=1)
+    assert torch.equal(src_a, ref_src)
+
+
+def test_semantic_wrapper_training_step_same_loss_and_gradients_with_and_without_the_prepare_kernel(monkeypatch):
+    """the fused bookkeeping path of SemanticTransformerWrapper.forward (ops.semantic_prepare) == the ATen path: loss and every gradient bit for bit
+    (same kernels downstream, same forgetful-mask draw under the same seed)"""
+    import audiolm_pytorch_amd as A
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    torch.manual_seed(0)
+    model = A.SemanticTransformer(num_semantic_tokens=50, dim=128, depth=2, flash_attn=True).to(dev())
+    w = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=False, mask_prob=0.15)
+    w.train()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 50, (3, 40), generator=g)
+    ids[0, 30:] = -1
+    ids = ids.to(dev())
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(AP, '_SEMANTIC_PREPARE', on)
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(123)
+        loss = w(semantic_token_ids=ids, return_loss=True)
+        loss.backward()
+        res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
+    assert res[0][1].keys() == res[1][1].keys() and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
