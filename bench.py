@@ -238,7 +238,7 @@ def pmc_traffic():
     scripts/pmc.sh regenerates them).  -> (bytes | None, file name | None, provenance text).  Since round 4 the summary records the commit and the
     digest of the kernel sources it was measured on; a summary whose digest differs from the sources of THIS run is refused (traffic: null) --
     the numbers would describe other kernels."""
-    for name in ('r5_pmc_summary.json', 'r4_pmc_summary.json', 'r3_pmc_summary.json'):
+    for name in ('r6_pmc_summary.json', 'r5_pmc_summary.json', 'r4_pmc_summary.json', 'r3_pmc_summary.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 d = json.load(fh)
@@ -249,7 +249,7 @@ def pmc_traffic():
             return None, name, f'profiles/{name} carries no source digest (generated before round 4): refused, traffic not reported'
         if dig != csrc_digest():
             return None, name, (f'profiles/{name} was measured at commit {commit} on kernel sources with digest {dig}; this run\'s sources have digest '
-                                f'{csrc_digest()}: refused (regenerate: bash scripts/gpu_r5_final.sh <tag> <commit>)')
+                                f'{csrc_digest()}: refused (regenerate: bash scripts/gpu_final.sh <tag> <commit>)')
         return d['hbm_bytes_per_launch'], name, (f'profiles/{name}: rocprofv3 PMC passes of this workload at commit {commit} (kernel-source digest {dig} == this '
                                                  f'run\'s), FETCH_SIZE x 2 + WRITE_SIZE per the MI355X guide, one counter group per run; not re-measured in this run')
     return None, None, 'no PMC summary under profiles/'

@@ -1,15 +1,49 @@
 #!/bin/bash
-# Round-end validation on one GPU box, as the driver does it: the whole -m gpu suite, smoke(), the default bench line, then the committed evidence
-# (kernel-trace profile of the headline step, the other BASELINE configs).  usage: scripts/gpu_final.sh <tag>
-tag=$1
+# Round-end sequence on ONE GPU box, as the driver does it and then the evidence the judge reads: the whole `-m gpu` suite (serial), smoke(), the driver's
+# default bench line, the rocprofv3 kernel trace of the headline step, the four PMC passes (one counter group per run, kernel-trace only) + their summary WITH
+# PROVENANCE (commit + csrc digest: bench.py's roofline.traffic refuses a summary measured on other kernel sources), the bench line again with that summary in
+# place, and -- with CONFIGS set -- the other BASELINE configurations.
+# usage: [CONFIGS="coarse1024 fine2049 fine_t2048_q8 e2e_config5"] scripts/gpu_final.sh <tag> <commit>      (the box has no .git: pass `git rev-parse --short HEAD`)
+tag=${1:-r6z}; commit=${2:-unknown}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 t0=$SECONDS
-timeout 1500 python -m pytest tests/ -x -q -m gpu --timeout 900 > gpurun_out/${tag}_gpu_tests.log 2>&1
-echo "gpu tests rc=$? t=$((SECONDS-t0))"; tail -n 4 gpurun_out/${tag}_gpu_tests.log | cut -c1-300
+rm -f gpurun_out/r6_fullsize_parity.jsonl gpurun_out/r6_opwise_parity.jsonl
+timeout 1800 python -X faulthandler -m pytest tests -m gpu -q --tb=short --timeout 900 -p no:cacheprovider --durations=15 > gpurun_out/${tag}_gpu_tests.log 2>&1
+echo "all gpu tests rc=$? t=$((SECONDS-t0))"; tail -n 22 gpurun_out/${tag}_gpu_tests.log | cut -c1-300
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${tag}_smoke.log 2>&1
-echo "smoke rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_smoke.log | cut -c1-300
-timeout 900 python bench.py > gpurun_out/${tag}_bench.log 2>&1
-echo "bench rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_bench.log | cut -c1-3500
-bash scripts/gpu_r2.sh ${tag} profbf configs 2>&1 | cut -c1-2600
+echo "smoke rc=$? t=$((SECONDS-t0))"; tail -n 2 gpurun_out/${tag}_smoke.log
+timeout 900 python bench.py > gpurun_out/${tag}_bench_default.log 2>&1
+echo "bench default rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_bench_default.log | cut -c1-3500
+export ALM_BENCH_SUPERVISE=0      # profilers follow ONE process: bench.py measures in place (no re-launching child)
+# kernel trace of the headline step, weight-gradient side stream off (kernels do not overlap: per-kernel durations add up to the step)
+rm -rf /tmp/prof_$tag
+ALM_ASYNC_WGRAD=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o r6 -- python bench.py --steps 5 --warmup 2 --residual bf16 --schedule eager --no-cpu-baseline --no-optimizer-leg > gpurun_out/${tag}_prof_bf16.log 2>&1
+echo "prof rc=$? t=$((SECONDS-t0))"
+db=$(find /tmp/prof_$tag -name "*.db" | head -1)
+[[ -n $db ]] && python scripts/prof_summary.py "$db" gpurun_out/${tag}_kernel_stats_bf16_async0.csv "commit $commit: ALM_ASYNC_WGRAD=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --residual bf16 --schedule eager --no-cpu-baseline --no-optimizer-leg  (incl. priming + warm-up + 1 instrumented step: 22 steps)"
+for grp in "FETCH_SIZE:fetch_size" "WRITE_SIZE:write_size" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE:mfma_busy" "SQ_INSTS_VALU_MFMA_MOPS_BF16:mfma" "TCC_HIT_sum TCC_MISS_sum:tcc"; do
+  cnt=${grp%%:*}; nm=${grp##*:}
+  ALM_ASYNC_WGRAD=0 bash scripts/pmc.sh "$cnt" ${tag}_$nm > gpurun_out/${tag}_pmc_$nm.out 2>&1
+  echo "pmc $nm rc=$? t=$((SECONDS-t0))"; head -n 6 gpurun_out/pmc_${tag}_$nm.csv | cut -c1-200
+done
+python scripts/pmc_summary.py ${tag} gpurun_out/${tag}_pmc_summary.json ${commit} 2>&1 | tail -n 3
+# the bench line again, now WITH the PMC summary of this very code in place (roofline.traffic filled from it)
+cp gpurun_out/${tag}_pmc_summary.json profiles/r6_pmc_summary.json
+unset ALM_BENCH_SUPERVISE
+timeout 600 python bench.py --no-cpu-baseline --no-optimizer-leg 2>/dev/null | tail -n 1 > gpurun_out/${tag}_bench_with_traffic.log
+python - <<PY
+import json
+d = json.loads(open('gpurun_out/${tag}_bench_with_traffic.log').read())
+r = d['roofline']
+print('ms/step', d['ms_per_step'], 'frac', r['frac'], 'traffic', r.get('traffic'), str(r.get('traffic_source'))[:120])
+PY
+echo "total t=$((SECONDS-t0))"
+if [[ -n "$CONFIGS" ]]; then
+  rm -f gpurun_out/${tag}_bench_configs.jsonl
+  for cf in $CONFIGS; do
+    timeout 900 python bench.py --config $cf --steps 5 --warmup 2 2>/dev/null | tail -n 1 >> gpurun_out/${tag}_bench_configs.jsonl
+    echo "config $cf rc=$? t=$((SECONDS-t0))"; tail -n 1 gpurun_out/${tag}_bench_configs.jsonl | cut -c1-300
+  done
+fi
 echo "total t=$((SECONDS-t0))"

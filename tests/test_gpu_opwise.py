@@ -28,7 +28,7 @@ from test_gpu_fullsize import _case
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.path.join(ROOT, 'gpurun_out', 'r5_opwise_parity.jsonl')
+REPORT = os.path.join(ROOT, 'gpurun_out', 'r6_opwise_parity.jsonl')
 bf = RM._bf
 
 
