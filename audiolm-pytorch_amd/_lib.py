@@ -73,6 +73,7 @@ SIGNATURES = {
     'alm_fine_prepare': [_P, _L, _P, _L, _I, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P],
     'alm_loss_combine': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _F, _F, _F, _F, _I, _L, _P, _P, _P],
     'alm_mqa_head_groups': [_I],
+    'alm_mqa_bwd_parts': [_I, _I, _I],
     'alm_hc_coef_width': [_I],
     'alm_hc_partial_width': [_I, _I],
     'alm_hc_grads_width': [_I, _I],

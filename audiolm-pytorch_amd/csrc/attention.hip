@@ -872,9 +872,13 @@ __global__ __launch_bounds__(256, 2) void mqa_bwd_dq_kernel(AttnParams p) {
 //   dV^T (d x keys) += dO^T P ;  dK^T (d x keys) += Q^T dS  (x scale at the end); then summed over the heads through LDS.
 // LDS stage: per head Q tile [64 q][64 d] + dO tile (16 KB) -> 64 KB / stage, 2 stages.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool BIAS, bool DROP = false>
-__global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x 64 KiB of Q / dO tiles + 4 KiB of row terms
+// NH (round 6): heads per workgroup.  4 = one 512-thread workgroup per CU (132 KiB of LDS).  2 = 256 threads and 66 KiB: TWO workgroups per CU with independent
+// barriers -- one's barrier / DMA wait runs under the other's MFMAs -- and twice as many workgroups for short sequences (B = 8 x N = 1024: 512 instead of 256 for
+// 256 CUs); dK / dV partials per head group: H / NH of them (alm_mqa_bwd_parts tells the caller how many to allocate).
+template <bool BIAS, bool DROP = false, int NH = HPB>
+__global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
+    constexpr int NT = 128 * NH, STG = NH * 16384, RTB = NH * 512;             // threads, bytes of one stage of Q / dO tiles, bytes of one buffer of row terms
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 x NH x 16 KiB of Q / dO tiles + 2 x NH x 512 B of row terms
     __shared__ int qor_s[BIAS ? 256 : 1];                                      // BIAS: OR of the query attributes of every 64-query tile
 
     const int nkb = (p.N + 63) / 64;
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hl = wave >> 1, kh = wave & 1;                                   // head within the group, key half
-    const int head = id.hg * HPB + hl;
+    const int head = id.hg * NH + hl;
     const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
     const float c2 = p.scale * LOG2E;
@@ -914,8 +918,8 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
     const int hclamp = active ? head : 0;
     const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nlse + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
     const auto rsDl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ndelta + ((long long)b * p.H + hclamp) * p.N), 0, p.N * 4, 0x00020000);
-    constexpr int ROWT = 2 * 65536;                                            // row terms [2 buffers][4 heads][-lse/scale | -delta][64 queries] fp32
-    auto stage = [&](unsigned char* __restrict__ tiles, int qt, int buf) {                      // tiles = smem + buf * 65536
+    constexpr int ROWT = 2 * STG;                                            // row terms [2 buffers][4 heads][-lse/scale | -delta][64 queries] fp32
+    auto stage = [&](unsigned char* __restrict__ tiles, int qt, int buf) {                      // tiles = smem + buf * STG
         // wave (hl, kh) fetches head hl's Q tile (kh == 0) or dO tile (kh == 1): 8 pieces each -- and, through the SAME DMA queue, the tile's 64
         // row terms (-lse / scale for kh == 0, -delta for kh == 1: the accumulators' initial values).  They used to be 16 register loads per
         // wave at the top of every step, issued right after the next tile's DMA: vector-memory results retire in order, so waiting for them
@@ -926,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         else dma_tile<8>(rsD, img, 0, 1, lane, qt * 64, (unsigned)(p.lddo * 2), (unsigned)(head * DH * 2));
         const int qi = qt * 64 + lane;
         const unsigned vo = qi < p.N ? (unsigned)qi * 4u : OOB;               // rows >= N read 0 (harmless: their Q / dO rows are zero)
-        unsigned char* rt = smem + ROWT + buf * 2048 + hl * 512 + kh * 256;
+        unsigned char* rt = smem + ROWT + buf * RTB + hl * 512 + kh * 256;
         if (kh == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void*)rt, 4, vo, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDl, (lds_void*)rt, 4, vo, 0, 0, 0);
     };
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         } else {
             const int qi = qt * 64 + lane;
             const unsigned vo = qi < p.N ? (unsigned)qi * 4u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void*)(smem + ROWT + buf * 2048 + hl * 512 + kh * 256), 4, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_void*)(smem + ROWT + buf * RTB + hl * 512 + kh * 256), 4, vo, 0, 0, 0);
         }
     };
 
@@ -968,9 +972,9 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         rsAQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(p.qattr), 0, p.N * 4, 0x00020000);
         kk4l = p.kkey4[min(key, p.N - 1)];
         kal = p.kattr[min(key, p.N - 1)];
-        for (int i = t; i < 256; i += 512) qor_s[i] = 0;
+        for (int i = t; i < 256; i += NT) qor_s[i] = 0;
         __syncthreads();
-        for (int i = t; i < p.N; i += 512) atomicOr(&qor_s[min(i >> 6, 255)], p.qattr[i]);
+        for (int i = t; i < p.N; i += NT) atomicOr(&qor_s[min(i >> 6, 255)], p.qattr[i]);
     }
     const int kal_or = BIAS ? wave_or(kal) : 0;
 
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             // Q / dO rows are zero so P only ever meets zeros).
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             f32x16 s[2], dp[2];
-            const float* rowt = reinterpret_cast<const float*>(smem + ROWT + buf * 2048 + hl * 512);      // [64] -lse/scale, [64] -delta (staged by DMA)
+            const float* rowt = reinterpret_cast<const float*>(smem + ROWT + buf * RTB + hl * 512);      // [64] -lse/scale, [64] -delta (staged by DMA)
             if constexpr (PIPE) {
                 // ---- off-diagonal step, SOFTWARE-PIPELINED over the two 32-query blocks (round 6).  Measured before (scripts/attn_probe.py dkv): the step spent
                 // 1095 cycles in the exp2 / dS block during which the SIMD's matrix pipe idled -- both waves of a SIMD run the same phase at the same time
@@ -1183,20 +1187,20 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
             DKV_PROBE_T(3);
         }
     };
-    step(smem + 65536, smem, kblk, std::true_type{}, std::true_type{});      // the diagonal tile
+    step(smem + STG, smem, kblk, std::true_type{}, std::true_type{});      // the diagonal tile
     __syncthreads();
     DKV_PROBE_T(4);
     constexpr bool PEEL_LAST = !DROP && !BIAS;                               // (only the pipelined step bakes "a next tile exists" into its schedule)
 #pragma unroll 1
     for (int qt = kblk + 1; qt + (PEEL_LAST ? 1 : 0) < nqt; ++qt) {
         const int buf = (qt - kblk) & 1;
-        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, qt, std::false_type{}, std::true_type{});
+        step(smem + (buf ^ 1) * STG, smem + buf * STG, qt, std::false_type{}, std::true_type{});
         __syncthreads();
         DKV_PROBE_T(4);
     }
     if (PEEL_LAST && nqt - 1 > kblk) {                                       // the last query tile: nothing left to fetch
         const int buf = (nqt - 1 - kblk) & 1;
-        step(smem + (buf ^ 1) * 65536, smem + buf * 65536, nqt - 1, std::false_type{}, std::false_type{});
+        step(smem + (buf ^ 1) * STG, smem + buf * STG, nqt - 1, std::false_type{}, std::false_type{});
         __syncthreads();
         DKV_PROBE_T(4);
     }
@@ -1219,8 +1223,8 @@ __global__ __launch_bounds__(512, 2) void mqa_bwd_dkv_kernel(AttnParams p) {
         __syncthreads();
         float* outp = (pass == 0 ? p.dk : p.dv) + (long long)id.hg * p.part_stride;
         const float sc = pass == 0 ? p.scale : (DROP ? p.drop_scale : 1.f);
-        const int nh = min(HPB, p.H - id.hg * HPB);
-        for (int e = t; e < 64 * 64; e += 512) {
+        const int nh = min(NH, p.H - id.hg * NH);
+        for (int e = t; e < 64 * 64; e += NT) {
             const int kk = e >> 6, d = e & 63;          // output element (key kk of the block, dim d): coalesced along d
             const int half = kk >> 5, kl = kk & 31;
             float sum = 0.f;
@@ -1267,6 +1271,21 @@ static int check_attn(int B, int N, int H, long long ldq, long long ldk, long lo
 }
 
 extern "C" int alm_mqa_head_groups(int H) { return (H + HPB - 1) / HPB; }
+
+// heads per workgroup of the dK / dV kernel for a shape (see mqa_bwd_dkv_kernel's NH).  ALM_ATTN_DKV_NH = 4 | 2 forces one (A/B runs).
+static int dkv_heads_per_block(int B, int N, int H) {
+    static const int env_nh = [] { const char* e = getenv("ALM_ATTN_DKV_NH"); return e ? atoi(e) : 0; }();
+    if (env_nh == 2 || env_nh == 4) return env_nh;
+    (void)B; (void)H;
+    // measured (profiles/r6t_dkv_nh_ab.log, B = 8, H = 8, one box, two interleaved rounds): 2 heads per workgroup is +9 % / +8 % SLOWER at N = 1024 / 2048 (twice
+    // the workgroups, each with its own K / V load, diagonal step and head-reduce epilogue), -0.6 % at N = 8 253 and -1.3 % at N = 16 385 (the second workgroup
+    // of a CU runs under the first one's barrier / DMA waits; the per-workgroup overhead is amortised over >= 65 query-tile steps)
+    return N >= 8192 ? 2 : HPB;
+}
+extern "C" int alm_mqa_bwd_parts(int B, int N, int H) {
+    const int nh = dkv_heads_per_block(B, N, H);
+    return (H + nh - 1) / nh;
+}
 
 struct BiasArgs { const float* tbl; int LT; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part; };
 
@@ -1325,7 +1344,7 @@ static int attn_fwd_impl(const void* q, long long ldq, const void* k, long long 
     return 0;
 }
 
-// dk / dv: fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 valid columns each; partial g at + g * part_stride floats);
+// dk / dv: fp32 partials [alm_mqa_bwd_parts(B, N, H)][B*N][lddk] (64 valid columns each; partial g at + g * part_stride floats);
 // the caller (alm_kv_grad_pack) adds the partials.  delta: fp32 workspace [2][B][H][N].
 static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* mask, const void* o, long long ldo, const float* lse, const void* dout, long long lddo,
@@ -1358,20 +1377,36 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
         else hipLaunchKernelGGL((mqa_bwd_dq_kernel<false, true>), dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
     } else if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dq_kernel<true>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<true>, st, p);
     else hipLaunchKernelGGL(mqa_bwd_dq_kernel<false>, dim3(nqb * p.HG * B), dim3(256), DQ_LDS<false>, st, p);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mqa_bwd_dkv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 4096);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    // dK / dV: 4 heads per workgroup (one 512-thread workgroup per CU) or 2 (two 256-thread workgroups per CU): dkv_heads_per_block; the caller sized the
+    // partial buffers with alm_mqa_bwd_parts
+    const int nh = dkv_heads_per_block(B, N, H);
+    p.HG = (H + nh - 1) / nh;
+    auto launch_dkv = [&](auto kern, int threads, int lds) -> hipError_t {
+        // the LDS attribute is set once per KERNEL: the eight instantiations below are eight function-pointer VALUES of one type (one operator() of this
+        // lambda, one static): keyed on the value (ADVICE r5 found a per-type flag shared by four kernels in the grouped GEMM launcher)
+        static const void* done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const void* fn = reinterpret_cast<const void*>(kern);
+        bool seen = false;
+        for (int i = 0; i < 8; ++i) seen = seen || done[i] == fn;
+        if (!seen) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            for (int i = 0; i < 8; ++i) if (done[i] == nullptr) { done[i] = fn; break; }
+        }
+        hipLaunchKernelGGL(kern, dim3(nqb * p.HG * B), dim3(threads), lds, st, p);
+        return hipSuccess;
+    };
+    hipError_t le;
+    if (nh == 2) {
+        constexpr int LDS2 = 2 * 2 * 16384 + 2 * 2 * 512;
+        if (drop) le = p.tbl ? launch_dkv(mqa_bwd_dkv_kernel<true, true, 2>, 256, LDS2) : launch_dkv(mqa_bwd_dkv_kernel<false, true, 2>, 256, LDS2);
+        else le = p.tbl ? launch_dkv(mqa_bwd_dkv_kernel<true, false, 2>, 256, LDS2) : launch_dkv(mqa_bwd_dkv_kernel<false, false, 2>, 256, LDS2);
+    } else {
+        constexpr int LDS4 = 131072 + 4096;
+        if (drop) le = p.tbl ? launch_dkv(mqa_bwd_dkv_kernel<true, true, 4>, 512, LDS4) : launch_dkv(mqa_bwd_dkv_kernel<false, true, 4>, 512, LDS4);
+        else le = p.tbl ? launch_dkv(mqa_bwd_dkv_kernel<true, false, 4>, 512, LDS4) : launch_dkv(mqa_bwd_dkv_kernel<false, false, 4>, 512, LDS4);
     }
-    if (drop) {
-        if (p.tbl) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<true, true>), dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
-        else hipLaunchKernelGGL((mqa_bwd_dkv_kernel<false, true>), dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
-    } else if (p.tbl) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<true>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
-    else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<false>, dim3(nqb * p.HG * B), dim3(512), 131072 + 4096, st, p);
+    if (le != hipSuccess) return (int)le;
     ALM_LAUNCH_CHECK();
     return 0;
 }

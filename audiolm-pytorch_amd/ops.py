@@ -345,7 +345,7 @@ def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, d
     _chk(dout, BF16)
     dq = torch.empty_like(q) if dq_out is None else dq_out
     assert dq.shape == q.shape and dq.dtype == BF16 and dq.stride(1) == 1
-    hg = _lib.query('alm_mqa_head_groups', H)
+    hg = _lib.query('alm_mqa_bwd_parts', B, N, H)                  # dk / dv partial sets the dK/dV kernel writes for this shape (4 or 2 heads per workgroup)
     dkv = torch.empty((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
     delta = torch.empty((2, B, H, N), dtype=F32, device=q.device)
     if bias is not None:

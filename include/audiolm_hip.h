@@ -129,7 +129,7 @@ int alm_geglu_ln_bwd(const void* dhn_bf16, long long lddh, const void* u_bf16, l
 
 /* ---- causal multi-query flash attention: attend.py:69-146 as called from audiolm_pytorch.py:381-394 ------------------------
  * q (B,N,H*64) bf16, k/v (B,N,64) bf16 single shared head, mask (B,N) uint8 (1 = attend) or NULL, scale = 64^-0.5.
- * lse fp32 [B][H][N].  Backward: dq bf16; dk/dv fp32 partials [alm_mqa_head_groups(H)][B*N][lddk] (64 columns each, `part_stride`
+ * lse fp32 [B][H][N].  Backward: dq bf16; dk/dv fp32 partials [alm_mqa_bwd_parts(B,N,H)][B*N][lddk] (64 columns each, `part_stride`
  * floats between partials; summed by alm_kv_grad_pack: deterministic, no atomics); delta = fp32 workspace [2][B][H][N].
  * dropout_p in [0, 1) / seed: training-mode attention dropout (attend.py:92 `dropout_p`, :140 `attn_dropout(attn)`): the softmax OUTPUT of pair
  * (b, h, i, j) is kept iff hash(seed, b, h, i * N + j) >= dropout_p * 2^32 (a stateless 32-bit finaliser, the same in forward, dQ and dK/dV) and
@@ -143,8 +143,11 @@ int alm_mqa_attn_bwd(const void* q, long long ldq, const void* k, long long ldk,
                      const void* o, long long ldo, const float* lse, const void* dout, long long lddo, void* dq, long long lddq, float* dk,
                      float* dv, long long lddk, long long part_stride, float* delta, int B, int N, int H, int dim_head, float scale,
                      float dropout_p, unsigned long long seed, const void* seed_dev, void* stream);
-/* number of head groups (4 heads each) = number of dk / dv partials the backward writes */
+/* number of head groups (4 heads each) of the forward / dQ kernels (the table-gradient partial rows of the bias variants count in these) */
 int alm_mqa_head_groups(int H);
+/* number of dk / dv partial sets alm_mqa_attn_bwd / alm_mqa_attn_bias_bwd WRITE for this shape (the dK/dV kernel runs 4 or 2 heads per workgroup: H / 4 or
+ * H / 2 partials, part_stride floats apart): the caller allocates this many and hands them all to alm_kv_grad_pack(nparts) */
+int alm_mqa_bwd_parts(int B, int N, int H);
 /* The same attention with the STRUCTURED SCORE BIAS of the `flash_attn=False` models -- Attend.forward's `sim + attn_bias` (attend.py:118-
  * 121) with the bias tensors of RelativePositionBias (audiolm_pytorch.py:202-242), the Coarse cross-attention override (:924-936) and the
  * Fine (frame, quantizer) table (:1227-1298) -- without ever materialising the (h, n, n) tensor:

@@ -5,6 +5,8 @@ PyTorch restatement of the same op / the oracle function, on a real MI355X.  Tol
   * integer / index work: bit exact
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -1189,3 +1191,16 @@ def test_semantic_wrapper_training_step_same_loss_and_gradients_with_and_without
         res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
     assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
     assert res[0][1].keys() == res[1][1].keys() and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+
+
+@pytest.mark.parametrize('nh', [2, 4])
+def test_mqa_attention_backward_with_either_dkv_workgroup_shape(nh):
+    """round 6: the dK/dV kernel runs 4 heads per workgroup (N < 8192) or 2 (two workgroups per CU, H / 2 partial sets: alm_mqa_bwd_parts); the choice is a
+    process-wide policy read once, so each forced value (ALM_ATTN_DKV_NH) runs the attention / bias / dropout kernel tests in its own interpreter"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALM_ATTN_DKV_NH=str(nh))
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_kernels.py', 'tests/test_gpu_bias.py', '-m', 'gpu', '-q', '-x', '-p', 'no:cacheprovider',
+                        '-k', '(mqa_attention_fwd_bwd or biased_attention_fwd_bwd or structured_bias) and not either_dkv'], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout
