@@ -364,7 +364,7 @@ def _run_attn(cfg, W, prm, X, XN, mask_u8, B, N, st, bias, kv_out, decode, l, ct
     else:
         # to_q || to_kv in one launch (round 5): k / v from the UN-normalised branch input (:325 vs :347); alone, the N = 128 projection is 128
         # workgroups waiting on an HBM round trip per K-step on a quarter of the CU slots
-        if QKV_GROUP:
+        if QKV_GROUP == 1 or (QKV_GROUP < 0 and XN.shape[0] <= QKV_GROUP_MAX_M):
             ops.gemm_nt_group2(XN, Wq, Q, X, Wkv, KV)
         else:
             ops.gemm_nt(XN, Wq, Q)
@@ -634,7 +634,10 @@ class _SideStream:
 ASYNC_WGRAD = os.environ.get('ALM_ASYNC_WGRAD', '1') != '0'          # switch (ALM_ASYNC_WGRAD=0 turns the side stream off: A/B runs)
 # forward to_q / to_kv: two launches, to_kv (128 tiles) on the 4-stage DMA-ring form of the 128 x 128 tile (default; measured -0.03 ms/step against the
 # grouped launch, profiles/r5t_ab_qkv_ring.log); 1: to_q || to_kv as ONE grouped launch (alm_gemm_bf16_nt_group2)
-QKV_GROUP = os.environ.get('ALM_QKV_GROUP', '0') != '0'
+# Round 6: per shape class -- `auto` (default) groups them when the batch has at most QKV_GROUP_MAX_M token rows: at M = 8 192 (configs[1]) the grouped launch
+# is the faster one (-0.03 ... -0.05 ms/step, profiles/r5v_coarse1024_switches.log, r6u_qkv_group_ab.log), at M = 16 384 the ring tile is.
+QKV_GROUP = {'0': 0, '1': 1}.get(os.environ.get('ALM_QKV_GROUP', 'auto'), -1)
+QKV_GROUP_MAX_M = 8192
 ASYNC_KV = os.environ.get('ALM_ASYNC_KV', '0') != '0'                # forward: to_kv on a side stream under to_q (A/B switch; measured +-0: off)
 # Deferred weight gradients (round 3): instead of one split-K GEMM + reduce per weight and layer as the backward walks down, the activations the
 # weight gradients need (dU, dY, dQ, dKV; XN, X, AO, HN from the forward) are written into buffers STACKED over the layers, and each weight kind is
