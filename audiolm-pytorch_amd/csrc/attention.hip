@@ -181,34 +181,43 @@ struct BlockId { int blk, hg, b; };
 __device__ __forceinline__ BlockId decode_block(int L, int nblk, int HG, int B, bool heavy_is_high, bool pair_on_cu) {
     BlockId r;
     const int combos = HG * B;
+    if (pair_on_cu) {
+        // Kernels with TWO co-resident workgroups per CU (dQ).  Round 6: one ordering for every block count.  The list of an XCD (all blocks of the
+        // combos / 8 (batch element, head group) pairs pinned to it: their K / V tiles are fetched from HBM once and then hit in that XCD's L2; workgroup L runs on
+        // XCD L % 8 -- observed dispatch order, a wrong guess only costs speed) is walked in GLOBAL weight order g = 0, 1, ... (heaviest first: longest-
+        // processing-time-first list scheduling for everything dispatched after the first wave of residents), except that the first 2 x 32 positions -- the
+        // workgroups resident together at the start, position p and p + 32 sharing a CU -- are arranged as complementary (heavy, light) pairs.
+        // Until round 6 the list was [combo 0 heavy -> light][combo 1 light -> heavy]: exact for N = 2048 (64 workgroups = 64 slots, every pair sums to 33 key
+        // tiles) but with more workgroups than slots the HEAVIEST blocks of every odd combo were dispatched LAST and ran alone -- N = 2049 (33 blocks): dQ + dK/dV
+        // 201 -> 172 us with the list fixed (profiles/r6v_odd_blocks_ab.log); at N = 8 253 / 16 385 the tail was 129 / 257 key tiles long.
+        int p, ncl, half, xcd;
+        if ((combos & 7) == 0) { xcd = L & 7; p = L >> 3; ncl = combos >> 3; half = 32; }
+        else { xcd = -1; p = L; ncl = combos; half = 256; }       // (no XCD pinning: positions p and p + 256 share a CU)
+        const int W = ncl * nblk, M2 = min(W, 2 * half);
+        const int g = (p < half || p >= M2) ? p : M2 - 1 - (p - half);
+        const int rank = g / ncl, cl = g - rank * ncl;             // rank 0 = heaviest block of its combo
+        const int combo = xcd >= 0 ? cl * 8 + xcd : cl;
+        r.hg = combo % HG;
+        r.b = combo / HG;
+        r.blk = heavy_is_high ? nblk - 1 - rank : rank;
+        return r;
+    }
     int idx, combo;
-    bool flip;
     if ((combos & 7) == 0) {
-        // XCD-aware: workgroup L runs on XCD L % 8 (observed dispatch order; a wrong guess only costs speed).  All key / query blocks of
-        // one (batch element, head group) go to ONE XCD so that the Q / dO (K / V) tiles they all stream are fetched from HBM once and
-        // then hit in that XCD's L2.  Each XCD serves combos / 8 groups one after the other.
+        // XCD-aware: all key / query blocks of one (batch element, head group) go to ONE XCD (see above); each XCD serves combos / 8 groups one after the
+        // other, heaviest block first
         const int xcd = L & 7, j = L >> 3;
         const int cl = j / nblk;
         idx = j % nblk;
         combo = cl * 8 + xcd;
-        flip = pair_on_cu && (cl & 1);                // co-resident pairs on a CU (j, j + 32): complementary weights
     } else {
         idx = L % nblk;
         combo = L / nblk;
-        // the flip must be constant WITHIN a combo, or idx -> blk stops being a bijection.  Until round 4 this read `(L >> 8) & 1` ("the second
-        // co-resident round"): in a launch of more than 256 workgroups whose combo count is not a multiple of 8 (B = 1, N > 8192; B = 3, N > 2730) the
-        // combo straddling workgroup 256 mapped two idx values onto blocks it had already produced and never computed two others -- dQ rows left
-        // uninitialised.  Found by tests/test_gpu_kernels.py::test_mqa_attention_long_sequences_vs_chunked_fp64; the benchmark shapes (combos % 8 == 0)
-        // always took the branch above.
-        flip = pair_on_cu && (combo & 1);
     }
     r.hg = combo % HG;
     r.b = combo / HG;
-    // pair_on_cu: two co-resident workgroups per CU, the second gets the complementary weight; otherwise (one workgroup per CU,
-    // round-based execution) plain heaviest-first order (longest-processing-time-first list scheduling)
-    const int heavy_first = heavy_is_high ? nblk - 1 - idx : idx;
-    const int light_first = heavy_is_high ? idx : nblk - 1 - idx;
-    r.blk = flip ? light_first : heavy_first;
+    // one workgroup per CU, round-based execution: plain heaviest-first order within a combo (longest-processing-time-first list scheduling)
+    r.blk = heavy_is_high ? nblk - 1 - idx : idx;
     return r;
 }
 

@@ -386,6 +386,7 @@ def _attn_ref(q2, k2, v2, mask, B, N, H, d):
 
 
 @pytest.mark.parametrize('B,N,H', [(2, 37, 8), (1, 64, 8), (2, 200, 8), (1, 512, 8), (2, 96, 4), (1, 33, 2), (3, 130, 6), (1, 1024, 8),
+                                   (4, 300, 8), (8, 641, 8),      # (batch x head group) % 8 == 0 with an ODD block count (5, 11): the XCD block map's odd-count branch (round 6)
                                    (3, 2900, 8)])      # 6 (batch, head group) combos x 46 query blocks = 276 workgroups: the non-XCD block map past workgroup 256
 @pytest.mark.parametrize('use_mask', [False, True])
 def test_mqa_attention_fwd_bwd(ops, B, N, H, use_mask):
