@@ -123,6 +123,7 @@ struct AttnParams {
     bf16_t* dq; float* dk; float* dv;
     long long ldq, ldk, ldv, ldo, lddo, lddq, lddk, part_stride;
     int B, N, H, HG;
+    int dkv_split;                          // dK/dV kernel: 1, or 2 = SPLIT-Q (see mqa_bwd_dkv_kernel)
     float scale;
     // structured bias (null tbl = none)
     const float* tbl; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part;
@@ -891,13 +892,18 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
     __shared__ int qor_s[BIAS ? 256 : 1];                                      // BIAS: OR of the query attributes of every 64-query tile
 
     const int nkb = (p.N + 63) / 64;
-    const BlockId id = decode_block(blockIdx.x, nkb, p.HG, p.B, false, false);      // low key blocks are the heavy ones
+    // SPLIT-Q (round 6, p.dkv_split = 2; short sequences: fewer key blocks than CUs): the query-tile loop [kblk, nqt) of a key block is cut in two halves run by
+    // two workgroups, each writing its own dK / dV partial set (alm_kv_grad_pack sums them in index order: deterministic).  Taken while the doubled launch is
+    // still one round of the chip (dkv_split(): B = 8 x N = 512, -10 %); at N = 1024 (256 key-block workgroups of 16 ... 1 steps for 256 CUs) it measured +11 %
+    const int SP = p.dkv_split;
+    const BlockId id = decode_block(blockIdx.x, nkb, p.HG * SP, p.B, false, false);      // low key blocks are the heavy ones
     const int kblk = id.blk, b = id.b;
+    const int hgq = id.hg / SP, part = id.hg - hgq * SP;                       // head group, half of the query range; id.hg = index of the partial set
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hl = wave >> 1, kh = wave & 1;                                   // head within the group, key half
-    const int head = id.hg * NH + hl;
+    const int head = hgq * NH + hl;
     const bool active = head < p.H;
     const int lr = lane & 31, lh = lane >> 5;
     const float c2 = p.scale * LOG2E;
@@ -972,6 +978,8 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
     const int frow = fsw(lr);
     const TrOff troff = make_troff(lane);
     const int nqt = (p.N + 63) / 64;
+    const int qhalf = (nqt - kblk + 1) / 2;                              // SPLIT-Q: part 0 = the diagonal tile and the first half, part 1 = the rest (may be empty)
+    const int q_lo = part ? kblk + qhalf : kblk, q_hi = (SP > 1 && !part) ? kblk + qhalf : nqt;
     const int key_eff = kvalid ? key : 0x7fffffff;                       // a masked / out-of-range key "follows" every query
     int kk4l = 0, kal = 0;
     __amdgpu_buffer_rsrc_t rsT = rsL, rsKQ = rsL, rsAQ = rsL;
@@ -987,7 +995,7 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
     }
     const int kal_or = BIAS ? wave_or(kal) : 0;
 
-    stage(smem, kblk, 0);
+    if (q_lo < q_hi) stage(smem, q_lo, 0);                               // (workgroup-uniform)
     __syncthreads();
     DKV_PROBE_DECL
 
@@ -1001,8 +1009,8 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
         constexpr bool DIAG = decltype(diag_c)::value;
         constexpr bool MORE = decltype(more_c)::value;                      // compile time on the pipelined path: tile qt + 1 exists (its DMA is part of the schedule)
         constexpr bool PIPE = !DIAG && !DROP && !BIAS;
-        const int buf = (qt - kblk) & 1;
-        if (!PIPE && qt + 1 < nqt) stage(ntiles_img, qt + 1, buf ^ 1);
+        const int buf = (qt - q_lo) & 1;
+        if (!PIPE && qt + 1 < q_hi) stage(ntiles_img, qt + 1, buf ^ 1);
         DKV_PROBE_T(0);
         if (active) {
             const unsigned char* Qt = ctiles + hl * 16384;
@@ -1196,24 +1204,28 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
             DKV_PROBE_T(3);
         }
     };
-    step(smem + STG, smem, kblk, std::true_type{}, std::true_type{});      // the diagonal tile
-    __syncthreads();
+    int qfirst = q_lo;                                                       // first off-diagonal tile of this workgroup
+    if (part == 0) {
+        step(smem + STG, smem, kblk, std::true_type{}, std::true_type{});    // the diagonal tile
+        __syncthreads();
+        qfirst = kblk + 1;
+    }
     DKV_PROBE_T(4);
     constexpr bool PEEL_LAST = !DROP && !BIAS;                               // (only the pipelined step bakes "a next tile exists" into its schedule)
 #pragma unroll 1
-    for (int qt = kblk + 1; qt + (PEEL_LAST ? 1 : 0) < nqt; ++qt) {
-        const int buf = (qt - kblk) & 1;
+    for (int qt = qfirst; qt + (PEEL_LAST ? 1 : 0) < q_hi; ++qt) {
+        const int buf = (qt - q_lo) & 1;
         step(smem + (buf ^ 1) * STG, smem + buf * STG, qt, std::false_type{}, std::true_type{});
         __syncthreads();
         DKV_PROBE_T(4);
     }
-    if (PEEL_LAST && nqt - 1 > kblk) {                                       // the last query tile: nothing left to fetch
-        const int buf = (nqt - 1 - kblk) & 1;
-        step(smem + (buf ^ 1) * STG, smem + buf * STG, nqt - 1, std::false_type{}, std::false_type{});
+    if (PEEL_LAST && q_hi - 1 >= qfirst) {                                   // the last query tile: nothing left to fetch
+        const int buf = (q_hi - 1 - q_lo) & 1;
+        step(smem + (buf ^ 1) * STG, smem + buf * STG, q_hi - 1, std::false_type{}, std::false_type{});
         __syncthreads();
         DKV_PROBE_T(4);
     }
-    DKV_PROBE_FLUSH(blockIdx.x * 8 + wave, nqt - kblk);
+    DKV_PROBE_FLUSH(blockIdx.x * 8 + wave, q_hi - q_lo);
 
     // reduce over the 4 heads through LDS: red[wave][d][32 keys (+1 pad)] fp32.  The pad matters: the accumulators are written key-major (lane = key)
     // and read dim-major (lane = d, for coalesced global stores) -- with a 32-float row every lane of the read hit ONE bank (32-way conflict,
@@ -1232,7 +1244,7 @@ __global__ __launch_bounds__(128 * NH, 2) void mqa_bwd_dkv_kernel(AttnParams p) 
         __syncthreads();
         float* outp = (pass == 0 ? p.dk : p.dv) + (long long)id.hg * p.part_stride;
         const float sc = pass == 0 ? p.scale : (DROP ? p.drop_scale : 1.f);
-        const int nh = min(NH, p.H - id.hg * NH);
+        const int nh = min(NH, p.H - hgq * NH);
         for (int e = t; e < 64 * 64; e += NT) {
             const int kk = e >> 6, d = e & 63;          // output element (key kk of the block, dim d): coalesced along d
             const int half = kk >> 5, kl = kk & 31;
@@ -1291,9 +1303,19 @@ static int dkv_heads_per_block(int B, int N, int H) {
     // of a CU runs under the first one's barrier / DMA waits; the per-workgroup overhead is amortised over >= 65 query-tile steps)
     return N >= 8192 ? 2 : HPB;
 }
+// SPLIT-Q of the dK / dV kernel (see mqa_bwd_dkv_kernel): 2 when the launch would otherwise fill at most HALF the CUs.  ALM_ATTN_DKV_SPLIT = 1 | 2 forces.
+static int dkv_split(int B, int N, int H, int nh) {
+    static const int env_sp = [] { const char* e = getenv("ALM_ATTN_DKV_SPLIT"); return e ? atoi(e) : 0; }();
+    if (env_sp == 1 || env_sp == 2) return env_sp;
+    // measured (profiles/r6z_dkv_split_ab.log, B = 8, H = 8): -10 % at N = 512 (128 -> 256 workgroups: still ONE round of the 256 CUs, the heaviest block halves),
+    // but +11 % at N = 1024 and +14 % at N = 1536 -- the kernel holds 132 KiB of LDS, one workgroup per CU: 512 workgroups are two rounds (8 + 4 steps instead of
+    // 16) and every workgroup pays its own K / V load, head-reduce epilogue and partial set.  So: only while the doubled launch still fits one round.
+    const long long wgs = (long long)((N + 63) / 64) * ((H + nh - 1) / nh) * B;
+    return (N > 64 && 2 * wgs <= 256) ? 2 : 1;
+}
 extern "C" int alm_mqa_bwd_parts(int B, int N, int H) {
     const int nh = dkv_heads_per_block(B, N, H);
-    return (H + nh - 1) / nh;
+    return ((H + nh - 1) / nh) * dkv_split(B, N, H, nh);
 }
 
 struct BiasArgs { const float* tbl; int LT; const int* qkey4; const int* kkey4; const int* qattr; const int* kattr; float* dtbl_part; };
@@ -1390,6 +1412,7 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
     // partial buffers with alm_mqa_bwd_parts
     const int nh = dkv_heads_per_block(B, N, H);
     p.HG = (H + nh - 1) / nh;
+    p.dkv_split = dkv_split(B, N, H, nh);
     auto launch_dkv = [&](auto kern, int threads, int lds) -> hipError_t {
         // the LDS attribute is set once per KERNEL: the eight instantiations below are eight function-pointer VALUES of one type (one operator() of this
         // lambda, one static): keyed on the value (ADVICE r5 found a per-type flag shared by four kernels in the grouped GEMM launcher)
@@ -1402,7 +1425,7 @@ static int attn_bwd_impl(const void* q, long long ldq, const void* k, long long 
             if (e != hipSuccess) return e;
             for (int i = 0; i < 8; ++i) if (done[i] == nullptr) { done[i] = fn; break; }
         }
-        hipLaunchKernelGGL(kern, dim3(nqb * p.HG * B), dim3(threads), lds, st, p);
+        hipLaunchKernelGGL(kern, dim3(nqb * p.HG * p.dkv_split * B), dim3(threads), lds, st, p);
         return hipSuccess;
     };
     hipError_t le;
