@@ -1399,19 +1399,28 @@ int launch_w4(const GemmParams& p, int ny, int nz, hipStream_t st) {
 }
 
 // Tile ids (alm_gemm_bf16_nt_tile): 1 = 128 x 128 (4 waves, two workgroups per CU), 2 = 256 x 256 lock-step (8 waves), 13 = 256 x 256 with
-// staggered wave rows (the production big tile), 11 = 384 x 256 (8 waves, wave tile 192 x 64: 17 % fewer L2 -> LDS bytes per flop).
+// staggered wave rows (the production big tile), 11 = 384 x 256 (8 waves, wave tile 192 x 64: 17 % fewer L2 -> LDS bytes per flop), 17 = 320 x 256 (round 6).
 // Automatic choice (tile 0): small problems -> 1; otherwise 13, except that an NT problem takes 11 when the coarser tiling needs so many
 // fewer rounds of 256 resident workgroups that it wins despite its 1.5x longer tile (measured per-tile cost ratio 1.41: W1 forward
 // 16384 x 5472: 6 rounds -> 4, +6 %; with N = 1024 it is 172 tiles on 256 CUs, -15 %).
 int pick_tile(int M, int N, int ny, int tile, bool tn) {
-    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14 || tile == 15 || tile == 16) return tile;
+    if (tile == 1 || tile == 2 || tile == 11 || tile == 13 || tile == 14 || tile == 15 || tile == 16 || tile == 17) return tile;
     if (tile != 0) return -1;
     if (M < 256 || N < 256) return 1;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * ny;
     if (t256 < 192) return 1;               // not enough 256^2 tiles to occupy most of the 256 CUs
     if (!tn) {
+        // round model over the three big tiles: rounds of 256 resident workgroups x measured cost of one tile relative to 256 x 256 (384 x 256: 1.41).  Round 6:
+        // 320 x 256 (tile 17, the generic 8-wave kernel with a 160 x 64 wave tile) for RAGGED token counts -- FineTransformer N = 2049, B = 8: M = 16 392 is 65 tile
+        // rows of 256, so an N = 1024 output is 260 tiles = TWO rounds; 384 x 256 makes it 172 tiles (one round at 67 % of the CUs), 320 x 256 makes it 208
+        // (one round at 81 %, shorter tiles).  ALM_GEMM_T320_COST (x 100, default 122; 0 = never) is its relative cost in the model.
+        static const double c320 = [] { const char* e = getenv("ALM_GEMM_T320_COST"); return e ? atoi(e) / 100.0 : 1.22; }();
         const long long t384 = (long long)((M + 383) / 384) * ((N + 255) / 256) * ny;
-        if ((double)((t384 + 255) / 256) * 1.41 < (double)((t256 + 255) / 256)) return 11;
+        const long long t320 = (long long)((M + 319) / 320) * ((N + 255) / 256) * ny;
+        const double c13 = (double)((t256 + 255) / 256), c11 = (double)((t384 + 255) / 256) * 1.41;
+        const double c17 = c320 > 0. ? (double)((t320 + 255) / 256) * c320 : 1e30;
+        if (c17 < c13 && c17 < c11) return 17;
+        if (c11 < c13) return 11;
     }
     return 13;
 }
@@ -1465,6 +1474,7 @@ int launch_gemm(const GemmParams& p0, int ny, int nz, int out_f32, int tile, hip
     if (tl == 16) { if (TNMODE || p.raster != 0) return ALM_ERR_UNSUPPORTED; return out_f32 ? launch_ring<true>(p, ny, nz, st) : launch_ring<false>(p, ny, nz, st); }
     if (tl == 15) return out_f32 ? launch_cfg<256, 128, 4, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 128, 4, 2, TNMODE, false>(p, ny, nz, st);
     if (tl == 11) return out_f32 ? launch_cfg<384, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<384, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
+    if (tl == 17) { if (TNMODE) return ALM_ERR_UNSUPPORTED; return out_f32 ? launch_cfg<320, 256, 2, 4, false, true>(p, ny, nz, st) : launch_cfg<320, 256, 2, 4, false, false>(p, ny, nz, st); }
     if (tl == 2) return out_f32 ? launch_cfg<256, 256, 2, 4, TNMODE, true>(p, ny, nz, st) : launch_cfg<256, 256, 2, 4, TNMODE, false>(p, ny, nz, st);
     return out_f32 ? launch_cfg<128, 128, 2, 2, TNMODE, true>(p, ny, nz, st) : launch_cfg<128, 128, 2, 2, TNMODE, false>(p, ny, nz, st);
 }
@@ -1673,7 +1683,7 @@ extern "C" int alm_gemm_nt_plan(int M, int N, int K, int nb, int with_ws, int* p
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nb;
     static const int ring_on = [] { const char* e = getenv("ALM_GEMM_RING"); return e ? atoi(e) : 1; }();
     if (tile == 1 && ring_on && K >= 256 && t128 <= 256) tile = 16;
-    const long long bm = tile == 11 ? 384 : (tile == 13 ? 256 : 128), bn = tile == 1 || tile == 16 ? 128 : 256;
+    const long long bm = tile == 11 ? 384 : (tile == 17 ? 320 : (tile == 13 ? 256 : 128)), bn = tile == 1 || tile == 16 ? 128 : 256;
     const long long wgs = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * nb * pl.slices;
     if (plan) {
         plan[0] = tile; plan[1] = pl.slices;

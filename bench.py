@@ -480,7 +480,7 @@ def main():
         """kernel key of an ops.gemm_nt launch, from the library's own plan query (alm_gemm_nt_plan): nt256 = a big tile on a launch that fills the chip (the
         dominant kernel), nt256sk = the staggered 256 x 256 tile on an UNDER-FILLED launch (round 6: in-launch split-K, or unsplit), nt128 = the 128 x 128 tile"""
         _L.query('alm_gemm_nt_plan', M_, N_, K_, nb, int(ops.NT_WS and M_ >= 256 and N_ >= 256), _ct.cast(_plan, _ct.c_void_p))
-        if _plan[0] in (11, 13):
+        if _plan[0] in (11, 13, 17):                     # 17 = 320 x 256 (round 6: ragged token counts)
             return 'nt256' if big_tile(M_, N_, nb) else 'nt256sk'
         return 'nt128'
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# round 6, visit k: strided down-sampling conv kernel -- codec tests + tokenize A/B
-tag=${1:-r6k}
-mkdir -p gpurun_out
+# round 6: kernel traces of the OTHER configurations (looking for shape anomalies: ragged M = 16392, N = 8253 ...), side stream off
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp ALM_BENCH_SUPERVISE=0
-timeout 900 python -m pytest tests/test_gpu_codec.py -m gpu -q --tb=short > gpurun_out/${tag}_tests.log 2>&1
-echo "tests rc=$?"; tail -n 12 gpurun_out/${tag}_tests.log
-for e in "ALM_CONV_STRIDED=1" "ALM_CONV_STRIDED=0" "ALM_CONV_STRIDED=1" "ALM_CONV_STRIDED=0 ALM_FUSE_RESUNIT=0"; do echo "== $e"; env $e timeout 600 python scripts/conv_bench.py 2>&1 | tail -n 1; done > gpurun_out/${tag}_tokenize_ab.log 2>&1
-cat gpurun_out/${tag}_tokenize_ab.log
+mkdir -p gpurun_out
+for cf in fine2049 coarse1024 e2e_config5; do
+  rm -rf /tmp/prof_$cf
+  ALM_ASYNC_WGRAD=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$cf -o k -- python bench.py --config $cf --steps 3 --warmup 1 --schedule eager --no-cpu-baseline --no-optimizer-leg > gpurun_out/r6k_prof_$cf.log 2>&1
+  db=$(find /tmp/prof_$cf -name "*.db" | head -1)
+  [[ -n $db ]] && python scripts/prof_summary.py "$db" gpurun_out/r6k_kernel_stats_$cf.csv "ALM_ASYNC_WGRAD=0 rocprofv3 --kernel-trace -- python bench.py --config $cf --steps 3 --warmup 1 --schedule eager"
+done

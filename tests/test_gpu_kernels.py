@@ -56,7 +56,7 @@ def test_gemm_nt(ops, M, N, K, out_f32):
     assert err <= (2e-5 if out_f32 else 4e-3), f'gemm {M}x{N}x{K} out_f32={out_f32}: rel-max err {err}'
 
 
-@pytest.mark.parametrize('tile', [1, 2, 11, 13, 14, 15, 16])
+@pytest.mark.parametrize('tile', [1, 2, 11, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 1024), (300, 520, 200), (1000, 2736, 1024), (257, 300, 2736), (512, 256, 128), (640, 384, 192), (1536, 5472, 128), (4096, 2736, 192)])
 def test_gemm_nt_tile_configs(ops, M, N, K, tile):
     """every block-tile configuration of the product library (1 = 128x128x64 / 4 waves, 16 = the same tile with a 4-stage DMA ring and counted waits --
