@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
                                                                   const float* __restrict__ dout, float alpha, long long rows, int D,
                                                                   const float* __restrict__ ws, int ngroups) {
     __shared__ int pend[4][OWN_PEND];
+    __shared__ int pcnt[4];
     __shared__ float4 accs[4][OWN_G][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,38 +224,46 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
     float4* myacc = &accs[wave][0][lane];
 #pragma unroll
     for (int k = 0; k < OWN_G; ++k) myacc[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int* pl = pend[wave];
-    int np = 0;                                                            // wave-uniform
-    auto flush = [&]() {
+    // Round 6: the SCAN is shared by the workgroup.  Until then every one of the 4 waves (one per 256-column slice) scanned both code arrays itself: 4 x the
+    // scan work, and the scan is what the kernel costs on a large table -- codebook 4096 (12 291 rows = 1 537 workgroups) x 66 k tokens: 3.0 ms per step of
+    // `e2e_config5`, against 44 us at the headline shape.  Now wave w scans every 4th 512-code block, collects ITS hits (ballot + prefix count: in-order
+    // compaction) in its own list pend[w]; after each round of 4 blocks a barrier, and when some list could overflow in the next round (or at the end) ALL waves
+    // add the entries of list 0, 1, 2, 3 -- in that fixed order -- to their own column slice, 8 row loads in flight.  The order of the additions is a fixed
+    // function of the code arrays (not token order any more, but the same in every run): bitwise deterministic as before.
+    // AU row loads in flight per lane (16: a hot destination row -- skewed token ids, e.g. the codes of silence -- makes ONE workgroup add thousands of 4 KB
+    // rows one after the other; the memory-level parallelism of that chain is AU x 16 B per lane)
+    constexpr int AU = 16;
+    auto add_list = [&](const int* __restrict__ pl, int np) {
 #pragma unroll 1
-        for (int i0 = 0; i0 < np; i0 += 8) {
-            float4 v[8];
-            int d[8];
+        for (int i0 = 0; i0 < np; i0 += AU) {
+            float4 v[AU];
+            int d[AU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < AU; ++u) {
                 const int e = pl[min(i0 + u, np - 1)];                     // broadcast LDS read: (local row << 28) | token row
                 d[u] = i0 + u < np ? (e >> 28) & 7 : -1;
                 const long long r = e & 0x0fffffff;
-                v[u] = *reinterpret_cast<const float4*>(dout + r * D + colc);   // unconditional: 8 row loads in flight (colc: clamped column)
+                v[u] = *reinterpret_cast<const float4*>(dout + r * D + colc);   // unconditional: AU row loads in flight (colc: clamped column)
             }
-            // pin the 8 loaded vectors here: without a use at this point the compiler sinks each load into "its" iteration of the loop below
+            // pin the loaded vectors here: without a use at this point the compiler sinks each load into "its" iteration of the loop below
             // (load, s_waitcnt vmcnt(0), add -- one HBM round trip per entry)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+            for (int u = 0; u < AU; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < AU; ++u) {
                 if (d[u] < 0) break;                                       // wave-uniform
                 float4 a = myacc[d[u] * 64];
                 a.x += v[u].x * alpha; a.y += v[u].y * alpha; a.z += v[u].z * alpha; a.w += v[u].w * alpha;
                 myacc[d[u] * 64] = a;
             }
         }
-        np = 0;
     };
-    // the scan: 8 coalesced dword loads per lane in flight (512 codes per step), the next step's loads issued before this step is processed.  The loads
+    int* pl = pend[wave];
+    int np = 0;                                                            // wave-uniform: entries in this wave's list
+    // the scan: 8 coalesced dword loads per lane in flight (512 codes per block), the next block's loads issued before this one is processed.  The loads
     // are UNCONDITIONAL (index clamped to the last row, validity applied to the value afterwards): a per-lane `i < rows ? load : -1` compiles to an
     // exec-masked branch per load with a full s_waitcnt behind each (one L2 round trip per 64 codes: ~200 us for 32 k codes)
-    constexpr int SU = 8;
+    constexpr int SU = 8, BLK = SU * 64;
     const int last = (int)rows - 1;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -264,14 +273,15 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
             for (int u = 0; u < SU; ++u) c[u] = arr[min(base + u * 64 + lane, last)];
         };
         int cur[SU], nxt[SU];
-        fetch(0, cur);
+        fetch(wave * BLK, cur);
 #pragma unroll 1
-        for (int base = 0; base < (int)rows; base += SU * 64) {
-            fetch(base + SU * 64, nxt);                                    // past the end: the clamped last code, discarded below
+        for (int base0 = 0; base0 < (int)rows; base0 += 4 * BLK) {          // one round: blocks base0 + {0, 1, 2, 3} * BLK, one per wave
+            const int base = base0 + wave * BLK;
+            fetch(base + 4 * BLK, nxt);                                     // past the end: the clamped last code, discarded below
             bool any = false;
 #pragma unroll
             for (int u = 0; u < SU; ++u) any |= (unsigned)(cur[u] - code_lo) < (unsigned)nrow;    // (a negative code gives a huge unsigned offset)
-            if (__ballot(any)) {                                           // most steps hold no token of this group: one ballot instead of eight
+            if (__ballot(any)) {                                            // most blocks hold no token of this group: one ballot instead of eight
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const int i = base + u * 64 + lane;
@@ -283,12 +293,20 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
                     np += __popcll(m);
                 }
             }
-            if (np >= OWN_PEND - SU * 64) flush();                         // a step adds at most SU * 64 entries
+            const bool final_round = pass == 1 && base0 + 4 * BLK >= (int)rows;
+            if (lane == 0) pcnt[wave] = np;
+            __syncthreads();                                                // the four lists and their lengths are visible
+            const int n0 = pcnt[0], n1 = pcnt[1], n2 = pcnt[2], n3 = pcnt[3];
+            const bool flush = final_round || max(max(n0, n1), max(n2, n3)) > OWN_PEND - BLK;       // (a round adds at most BLK entries per list); uniform
+            if (flush) {
+                add_list(pend[0], n0); add_list(pend[1], n1); add_list(pend[2], n2); add_list(pend[3], n3);
+                np = 0;
+            }
+            __syncthreads();                                                // nobody overwrites a list (or a count) that is still being read
 #pragma unroll
             for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
         }
     }
-    if (np > 0) flush();
     if (!cok) return;
     for (int k = 0; k < nrow; ++k) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = myacc[k * 64];
 }
