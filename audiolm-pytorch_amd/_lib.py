@@ -116,6 +116,10 @@ SIGNATURES = {
     'alm_layernorm_bct': [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     'alm_geglu_bct': [_P, _P, _I, _I, _I, _P],
     'alm_local_attn': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    'alm_memset_zero': [_P, _L, _P],
+    'alm_list_op_id': [ctypes.c_char_p],
+    'alm_list_op_nargs': [_I],
+    'alm_list_run': [_P, _I, _P, _P, _I, _P, _I, _P, _P],
 }
 
 _lib = None
@@ -168,6 +172,11 @@ class AlmOptPackJob(ctypes.Structure):
                 ('wd', c_float), ('step', c_int)]
 
 
+class AlmListEntry(ctypes.Structure):
+    """mirror of AlmListEntry in include/audiolm_hip.h"""
+    _fields_ = [('op', c_int), ('nargs', c_int), ('first', c_int), ('reserved', c_int)]
+
+
 class AlmPackJob(ctypes.Structure):
     """mirror of AlmPackJob in include/audiolm_hip.h"""
     _fields_ = [('src', c_void_p), ('rows', c_int), ('cols', c_int), ('ld_src', c_longlong), ('dst', c_void_p), ('ld_dst', c_longlong),
@@ -175,12 +184,15 @@ class AlmPackJob(ctypes.Structure):
 
 
 _BOUND = {}          # name -> bound ctypes function (one dict lookup per call instead of load() + getattr on the CDLL: ~150 calls per training step)
+RECORDER = None      # launchlist.Recorder while a stack pass is being recorded (the launches still run: recording is an ordinary step that is also written down)
 
 
 def call(name: str, *args):
     fn = _BOUND.get(name)
     if fn is None:
         fn = _BOUND[name] = getattr(load(), name)
+    if RECORDER is not None:
+        RECORDER.note(name, args)
     rc = fn(*args)
     if rc != 0:
         raise AlmError(f'{name} failed with code {rc}' + (' (ALM_ERR_BAD_ARG)' if rc == 10001 else ' (ALM_ERR_UNSUPPORTED)' if rc == 10002 else ' (hipError_t)'))

@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, 'build')                       # git-ignored (objects +
 LIB = os.path.join(HERE, 'libaudiolm_hip.so')
 STAMP = os.path.join(HERE, '.libaudiolm_hip.stamp')
 SOURCES = ['gemm.hip', 'norm_act.hip', 'attention.hip', 'hyper.hip', 'embed_ce.hip', 'codec.hip', 'relpos.hip', 'optim.hip', 'decode.hip',
-           'xattn.hip', 'local_attn.hip']
+           'xattn.hip', 'local_attn.hip', 'launchlist.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value']
 
 

@@ -15,11 +15,12 @@ Data layout in HBM (B sequences, N tokens, M = B*N rows, D model width, S residu
 from __future__ import annotations
 
 import os
+import sys
 from dataclasses import dataclass
 
 import torch
 
-from . import ops, relpos, xattn
+from . import launchlist, ops, relpos, xattn
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -294,7 +295,7 @@ def autocast_bf16():
 
 
 def _empty(shape, dtype, dev):
-    return torch.empty(shape, dtype=dtype, device=dev)
+    return ops._new(shape, dtype, dev)                   # (torch.empty, or the arena of a stack pass that launchlist.py is sizing / recording)
 
 
 class DecodeCache:
@@ -769,9 +770,9 @@ def stack_backward(dhn, mask_u8, flat, cfg: StackCfg, cache: WeightCache, saved,
     dxs, dgam = ops.layernorm_bwd(dhn, saved['xs'], saved['fmean'], saved['frstd'], flat[-1])
     grads[-1] = dgam
     multi = cfg.add_value_residual and cfg.depth > 1
-    acc_v0 = torch.zeros((M, dh), dtype=F32, device=dev) if multi else None
-    acc_vp0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.prefix) else None
-    acc_vc0 = torch.zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.cross_attend) else None
+    acc_v0 = ops._new_zeros((M, dh), dtype=F32, device=dev) if multi else None
+    acc_vp0 = ops._new_zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.prefix) else None
+    acc_vc0 = ops._new_zeros((B * ctx.m, dh), dtype=F32, device=dev) if (multi and cfg.cross_attend) else None
     dctx = None                                                                # fp32 [B*m, Dc], summed over layers
     dense = isinstance(bias, relpos.DenseBias)
     dtbl_part = ops.attn_bias_part(B, N, H, bias.tbl.shape[1], dev) if (bias is not None and not dense) else None
@@ -1111,9 +1112,20 @@ class TransformerStackFn(torch.autograd.Function):
             # backward runs, and the backward must see the value its own forward used (dQ / dK / dV with other keep masks otherwise)
             dseed = (0, seed_state.clone())                           # (second half-batch: offset cfg.depth)
         if micro == 1:
-            hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
-                                      ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)),
-                                      defer_wgrad=DEFER_WGRAD and (hooks is None or DP_DEFER_GROUPS > 0), drop_seed=dseed)
+            defer = DEFER_WGRAD and (hooks is None or DP_DEFER_GROUPS > 0)
+            plan = None
+            if (launchlist.ENABLED and hooks is None and cx is None and opts.get('kv_out') is None and opts.get('decode') is None and TRACE is None
+                    and float(opts.get('ff_dropout', 0.)) == 0. and float(opts.get('attn_dropout', 0.)) == 0. and not isinstance(bias, relpos.DenseBias)
+                    and xin.is_cuda and not torch.cuda.is_current_stream_capturing()):
+                # plain training / evaluation call: the launch sequence is a function of (configuration, shape) alone -- sized, recorded, then re-issued
+                # from one C call per pass (launchlist.py)
+                plan = launchlist.plan_for(sys.modules[__name__], xin, mask_u8, cfg, need, bias, len(flat_d), defer, cfg.grad_shrink_alpha)
+            if plan is not None:
+                hn, saved = launchlist.forward(sys.modules[__name__], plan, xin, mask_u8, flat_d, cfg, cache, need, bias, defer)
+            else:
+                hn, saved = stack_forward(xin, mask_u8, flat_d, cfg, cache, need, bias, kv_out=opts.get('kv_out'), decode=opts.get('decode'), ctx=cx,
+                                          ff_dropout=float(opts.get('ff_dropout', 0.)), attn_dropout=float(opts.get('attn_dropout', 0.)),
+                                          defer_wgrad=defer, drop_seed=dseed)
         else:
             S, ppl, h = cfg.streams, params_per_layer(cfg.streams, cfg.cross_attend), B // 2
             for l in range(cfg.depth):                                   # pack the bf16 weight copies once, ahead of the fork
@@ -1146,7 +1158,9 @@ class TransformerStackFn(torch.autograd.Function):
         dhn = dhn.contiguous()
         if dhn.dtype not in (BF16, F32):
             dhn = dhn.to(F32)
-        if ctx.micro == 1:
+        if ctx.micro == 1 and (isinstance(ctx.saved, launchlist.Replay) or '_ll' in ctx.saved):
+            dx, grads, dtbl, dctx = launchlist.backward(sys.modules[__name__], dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.bias, cfg.grad_shrink_alpha)
+        elif ctx.micro == 1:
             dx, grads, dtbl, dctx = stack_backward(dhn, ctx.mask, flat, cfg, ctx.cache, ctx.saved, ctx.hooks, ctx.bias, dx_scale=cfg.grad_shrink_alpha)
         else:
             sva, svb = ctx.saved

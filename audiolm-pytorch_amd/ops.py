@@ -42,6 +42,42 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# Every device buffer an op wrapper creates goes through _new / _new_zeros / _new_like.  ALLOC is None in ordinary use (torch's caching allocator); while
+# launchlist.py sizes or records a stack pass it is an allocator object (a byte tally / a bump allocator over the pass's arena), so that every temporary of
+# the pass sits at a fixed offset of ONE buffer and the recorded launch list can be re-issued against a fresh arena.
+ALLOC = None
+
+
+def _new(shape, dtype=None, device=None):
+    if ALLOC is not None:
+        return ALLOC.empty(shape, dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _new_zeros(shape, dtype=None, device=None):
+    if ALLOC is not None:
+        return ALLOC.zeros(shape, dtype, device)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def _new_like(t):
+    if ALLOC is not None and t.is_contiguous():
+        return ALLOC.empty(t.shape, t.dtype, t.device)
+    return torch.empty_like(t)
+
+
+def memset_zero(t):
+    """hipMemsetAsync(0) over a contiguous tensor on the current stream (C ABI: alm_memset_zero)"""
+    assert t.is_contiguous()
+    _lib.call('alm_memset_zero', t.data_ptr(), t.numel() * t.element_size(), _st())
+    return t
+
+
+def persistent_buffers():
+    """device buffers that live at a fixed address for the life of the process (a recorded launch list may carry their addresses as literals)"""
+    return list(_NT_WS.values())
+
+
 def _rows_ld(t):
     """2-D row-major view -> (rows, cols, ld)."""
     assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
@@ -121,7 +157,7 @@ def _splitk(name, A, B, C, M, N, K, nb, sA, sB, sC, alpha, accumulate):
     nws = _lib.query('alm_gemm_splitk_ws_floats', M, N, K, nb)
     if nws < 0:
         raise _lib.AlmError('split-K workspace exceeds 2^31 floats')
-    ws = torch.empty(nws, dtype=F32, device=A.device) if nws > 0 else None
+    ws = _new(nws, dtype=F32, device=A.device) if nws > 0 else None
     _lib.call(name, A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(ws), M, N, K, A.stride(-2), B.stride(-2), C.stride(-2), nb, sA, sB, sC,
               float(alpha), int(accumulate), _st())
     return C
@@ -163,7 +199,7 @@ def gemm_tn_batched(At, Bt, C, *, alpha=1.0, accumulate=False):
     nws = _lib.query('alm_gemm_splitk_ws_floats', M, N, K, n1 * n2)
     if nws < 0:
         raise _lib.AlmError('split-K workspace exceeds 2^31 floats')
-    ws = torch.empty(nws, dtype=F32, device=At.device) if nws > 0 else None
+    ws = _new(nws, dtype=F32, device=At.device) if nws > 0 else None
     _lib.call('alm_gemm_bf16_tn_batched', At.data_ptr(), Bt.data_ptr(), C.data_ptr(), _p(ws), M, N, K, At.stride(-2), Bt.stride(-2), C.stride(-2), n1, n2,
               At.stride(0), At.stride(1), sb[0], sb[1], C.stride(0), C.stride(1), float(alpha), int(accumulate), _st())
     return C
@@ -184,7 +220,7 @@ def transpose(src, rows_pad=None):
     _chk(src, BF16)
     rows, cols, ld = _rows_ld(src)
     rp = rows_pad or ((rows + 7) // 8 * 8)
-    dst = torch.empty((cols, rp), dtype=BF16, device=src.device)
+    dst = _new((cols, rp), dtype=BF16, device=src.device)
     _lib.call('alm_transpose_bf16', src.data_ptr(), dst.data_ptr(), rows, cols, ld, rp, rp, _st())
     return dst
 
@@ -215,11 +251,11 @@ def layernorm_fwd(x, gamma, *, want_copy=False, out_f32=False, y_out=None, xc_ou
     """x [rows, D] fp32|bf16 -> (y bf16 (fp32 with out_f32: the final LayerNorm feeding the logit heads), xcopy bf16|None, mean, rstd)."""
     _chk(x)
     rows, D, ld = _rows_ld(x)
-    y = torch.empty((rows, D), dtype=F32 if out_f32 else BF16, device=x.device) if y_out is None else y_out
-    xc = (torch.empty((rows, D), dtype=BF16, device=x.device) if xc_out is None else xc_out) if want_copy else None
+    y = _new((rows, D), dtype=F32 if out_f32 else BF16, device=x.device) if y_out is None else y_out
+    xc = (_new((rows, D), dtype=BF16, device=x.device) if xc_out is None else xc_out) if want_copy else None
     assert y.shape == (rows, D) and y.is_contiguous() and (xc is None or (xc.shape == (rows, D) and xc.is_contiguous()))
-    mean = torch.empty(rows, dtype=F32, device=x.device)
-    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    mean = _new(rows, dtype=F32, device=x.device)
+    rstd = _new(rows, dtype=F32, device=x.device)
     _lib.call('alm_layernorm_fwd', x.data_ptr(), int(x.dtype == BF16), ld, gamma.data_ptr(), y.data_ptr(), int(out_f32), D, _p(xc), D, mean.data_ptr(),
               rstd.data_ptr(), rows, D, _st())
     return y, xc, mean, rstd
@@ -229,9 +265,9 @@ def colsum(inp, out=None, scale=1.0, accumulate=False):
     _chk(inp)
     rows, cols, ld = _rows_ld(inp)
     if out is None:
-        out = torch.empty(cols, dtype=F32, device=inp.device)
+        out = _new(cols, dtype=F32, device=inp.device)
     chunks = _lib.query('alm_colsum_chunks', rows)
-    ws = torch.empty((chunks, cols), dtype=F32, device=inp.device) if chunks > 1 else None
+    ws = _new((chunks, cols), dtype=F32, device=inp.device) if chunks > 1 else None
     _lib.call('alm_colsum', inp.data_ptr(), int(inp.dtype == BF16), ld, rows, cols, out.data_ptr(), float(scale), int(accumulate), _p(ws), _st())
     return out
 
@@ -241,11 +277,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, extra=None, dx_dtype=F32, want_dg
     _chk(dy), _chk(x)
     assert dy.dtype in (BF16, F32)
     rows, D, lddy = _rows_ld(dy)
-    dx = torch.empty((rows, D), dtype=dx_dtype, device=dy.device)
+    dx = _new((rows, D), dtype=dx_dtype, device=dy.device)
     part = None
     if want_dgamma:
         nblk = _lib.query('alm_ln_partial_blocks', rows)
-        part = torch.empty((nblk, D), dtype=F32, device=dy.device)
+        part = _new((nblk, D), dtype=F32, device=dy.device)
     _lib.call('alm_layernorm_bwd', dy.data_ptr(), int(dy.dtype == F32), lddy, x.data_ptr(), int(x.dtype == BF16), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
               gamma.data_ptr(), _p(extra), extra.stride(0) if extra is not None else 0, dx.data_ptr(), int(dx_dtype == BF16), D, _p(part),
               rows, D, _st())
@@ -257,7 +293,7 @@ def geglu_fwd(x):
     _chk(x, F32)
     rows, two_i, ld = _rows_ld(x)
     assert ld == two_i and two_i % 2 == 0
-    y = torch.empty((rows, two_i // 2), dtype=F32, device=x.device)
+    y = _new((rows, two_i // 2), dtype=F32, device=x.device)
     _lib.call('alm_geglu_fwd', x.data_ptr(), y.data_ptr(), rows, two_i // 2, _st())
     return y
 
@@ -266,7 +302,7 @@ def geglu_bwd(dy, x):
     _chk(dy, F32), _chk(x, F32)
     rows, two_i, ld = _rows_ld(x)
     assert ld == two_i and dy.shape == (rows, two_i // 2) and dy.is_contiguous()
-    dx = torch.empty_like(x)
+    dx = _new_like(x)
     _lib.call('alm_geglu_bwd', dy.data_ptr(), x.data_ptr(), dx.data_ptr(), rows, two_i // 2, _st())
     return dx
 
@@ -276,10 +312,10 @@ def geglu_ln_fwd(u, gamma, inner, inner_pad, out=None):
     _chk(u, BF16)
     rows, _, ldu = _rows_ld(u)
     if out is None:
-        out = torch.empty((rows, inner_pad), dtype=BF16, device=u.device)
+        out = _new((rows, inner_pad), dtype=BF16, device=u.device)
     assert out.shape == (rows, inner_pad) and out.dtype == BF16 and out.stride(1) == 1 and out.stride(0) == inner_pad
-    mean = torch.empty(rows, dtype=F32, device=u.device)
-    rstd = torch.empty(rows, dtype=F32, device=u.device)
+    mean = _new(rows, dtype=F32, device=u.device)
+    rstd = _new(rows, dtype=F32, device=u.device)
     _lib.call('alm_geglu_ln_fwd', u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), out.data_ptr(), inner_pad, mean.data_ptr(), rstd.data_ptr(),
               rows, inner, inner_pad, _st())
     return out, mean, rstd
@@ -288,10 +324,10 @@ def geglu_ln_fwd(u, gamma, inner, inner_pad, out=None):
 def geglu_ln_bwd(dhn, u, gamma, mean, rstd, inner, inner_pad, du_out=None):
     """-> (du bf16 [rows, 2 * inner_pad] (written into `du_out` when given: same shape and row stride as u), dgamma [inner])."""
     rows, _, ldu = _rows_ld(u)
-    du = torch.empty_like(u) if du_out is None else du_out
+    du = _new_like(u) if du_out is None else du_out
     assert du.shape == u.shape and du.stride(0) == ldu and du.stride(1) == 1 and du.dtype == BF16
     nblk = _lib.query('alm_geglu_partial_blocks', rows)
-    part = torch.empty((nblk, inner), dtype=F32, device=u.device)
+    part = _new((nblk, inner), dtype=F32, device=u.device)
     _lib.call('alm_geglu_ln_bwd', dhn.data_ptr(), dhn.stride(0), u.data_ptr(), ldu, inner_pad, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
               du.data_ptr(), part.data_ptr(), rows, inner, inner_pad, _st())
     return du, colsum(part)
@@ -311,12 +347,12 @@ def _bias_args(bias, N, H):
 
 def attn_bias_part(B, N, H, LT, device):
     """zeroed per-workgroup partial tables the biased attention backward accumulates the table gradient into"""
-    return torch.zeros((_lib.query('alm_attn_bias_part_rows', B, N, H), LT), dtype=F32, device=device)
+    return _new_zeros((_lib.query('alm_attn_bias_part_rows', B, N, H), LT), dtype=F32, device=device)
 
 
 def attn_bias_grad_reduce(part, B, N, H, dim_head=64):
     LT = part.shape[1]
-    dtbl = torch.empty((H, LT), dtype=F32, device=part.device)
+    dtbl = _new((H, LT), dtype=F32, device=part.device)
     _lib.call('alm_attn_bias_grad_reduce', part.data_ptr(), dtbl.data_ptr(), B, N, H, LT, float(dim_head) ** -0.5, _st())
     return dtbl
 
@@ -327,9 +363,9 @@ def mqa_attn_fwd(q, k, v, mask, B, N, H, dim_head=64, bias=None, dropout_p=0., s
     backward must get the same pair); seed_dev (int64 [1] device tensor | None): the stream is seed + seed_dev[0], read when the kernel runs."""
     _chk(q, BF16), _chk(k, BF16), _chk(v, BF16)
     if o is None:
-        o = torch.empty((B * N, H * dim_head), dtype=BF16, device=q.device)
+        o = _new((B * N, H * dim_head), dtype=BF16, device=q.device)
     assert o.shape == (B * N, H * dim_head) and o.dtype == BF16 and o.stride(1) == 1
-    lse = torch.empty((B, H, N), dtype=F32, device=q.device)
+    lse = _new((B, H, N), dtype=F32, device=q.device)
     if bias is not None:
         _lib.call('alm_mqa_attn_bias_fwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask), o.data_ptr(),
                   o.stride(0), lse.data_ptr(), B, N, H, dim_head, float(dim_head) ** -0.5, *_bias_args(bias, N, H), float(dropout_p), int(seed), _p(seed_dev), _st())
@@ -343,11 +379,11 @@ def mqa_attn_bwd(q, k, v, mask, o, lse, dout, B, N, H, dim_head=64, bias=None, d
     """-> (dq bf16 [B*N, H*dh], dkv fp32 [HG, B*N, 2*dh] = per-head-group partials of (dk | dv); kv_grad_pack sums them).
     With `bias`, the table gradient is accumulated into dtbl_part (attn_bias_part)."""
     _chk(dout, BF16)
-    dq = torch.empty_like(q) if dq_out is None else dq_out
+    dq = _new_like(q) if dq_out is None else dq_out
     assert dq.shape == q.shape and dq.dtype == BF16 and dq.stride(1) == 1
     hg = _lib.query('alm_mqa_bwd_parts', B, N, H)                  # dk / dv partial sets the dK/dV kernel writes for this shape (4 or 2 heads per workgroup)
-    dkv = torch.empty((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
-    delta = torch.empty((2, B, H, N), dtype=F32, device=q.device)
+    dkv = _new((hg, B * N, 2 * dim_head), dtype=F32, device=q.device)
+    delta = _new((2, B, H, N), dtype=F32, device=q.device)
     if bias is not None:
         assert dtbl_part is not None and dtbl_part.shape[1] == bias.tbl.shape[1] and dtbl_part.is_contiguous()
         _lib.call('alm_mqa_attn_bias_bwd', q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), _p(mask),
@@ -369,7 +405,7 @@ def mqa_decode_attn(q, cache, kv_new, pos, mask, H, dim_head=64, bias=None, pos_
     _chk(q, BF16), _chk(cache, BF16), _chk(kv_new, BF16)
     B, Nmax = cache.shape[0], cache.shape[1]
     assert cache.is_contiguous() and cache.shape[2] == 2 * dim_head and kv_new.shape == (B, 2 * dim_head) and kv_new.stride(1) == 1
-    out = torch.empty((B, H * dim_head), dtype=BF16, device=q.device)
+    out = _new((B, H * dim_head), dtype=BF16, device=q.device)
     qk = qa = 0
     tb = (None, 0)
     vecs = (None, None, None, None)
@@ -389,7 +425,7 @@ def mqa_decode_attn(q, cache, kv_new, pos, mask, H, dim_head=64, bias=None, pos_
 
 def value_residual_mix(v, v0):
     rows, dh, _ = _rows_ld(v)
-    out = torch.empty((rows, dh), dtype=BF16, device=v.device)
+    out = _new((rows, dh), dtype=BF16, device=v.device)
     _lib.call('alm_value_residual_mix', v.data_ptr(), v.stride(0), v0.data_ptr(), v0.stride(0), out.data_ptr(), dh, rows, dh, _st())
     return out
 
@@ -404,8 +440,8 @@ def loss_combine(sums, labels, weights, ignore_index=-1):
     for t, l in zip(sums, labels):
         _chk(t, F32)
         _chk(l, torch.int64)
-    loss = torch.empty(1, dtype=F32, device=dev)
-    scales = torch.empty(G, dtype=F32, device=dev)
+    loss = _new(1, dtype=F32, device=dev)
+    scales = _new(G, dtype=F32, device=dev)
     pad = [None] * (4 - G)
     _lib.call('alm_loss_combine', *[t.data_ptr() for t in sums], *pad, *[l.data_ptr() for l in labels], *pad, *[l.numel() for l in labels], *([0] * (4 - G)),
               *[float(w) for w in weights], *([0.0] * (4 - G)), G, int(ignore_index), loss.data_ptr(), scales.data_ptr(), _st())
@@ -420,10 +456,10 @@ def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C):
     B, ns0 = sem.shape
     nc0 = coarse.shape[1]
     N, dev = ns0 + nc0 + 3, sem.device
-    sl = torch.empty((B, ns0 + 1), dtype=torch.int64, device=dev)
-    cl = torch.empty((B, nc0 + 1), dtype=torch.int64, device=dev)
-    src_a = torch.empty((B, N), dtype=torch.int32, device=dev)
-    keep = torch.empty((B, N), dtype=torch.bool, device=dev)
+    sl = _new((B, ns0 + 1), dtype=torch.int64, device=dev)
+    cl = _new((B, nc0 + 1), dtype=torch.int64, device=dev)
+    src_a = _new((B, N), dtype=torch.int32, device=dev)
+    keep = _new((B, N), dtype=torch.bool, device=dev)
     _lib.call('alm_coarse_prepare', sem.data_ptr(), sem.stride(0), coarse.data_ptr(), coarse.stride(0), B, ns0, nc0, int(pad_id), int(sem_eos), int(coarse_eos),
               int(Q), int(C), sl.data_ptr(), cl.data_ptr(), src_a.data_ptr(), keep.data_ptr(), _st())
     return sl, cl, src_a, keep
@@ -435,8 +471,8 @@ def semantic_prepare(sem, eos_id, num_rows):
     _chk(sem, torch.int64)
     assert sem.dim() == 2 and (sem.shape[1] == 0 or sem.stride(1) == 1)
     B, n0 = sem.shape
-    labels = torch.empty((B, n0 + 1), dtype=torch.int64, device=sem.device)
-    src_a = torch.empty((B, n0 + 1), dtype=torch.int32, device=sem.device)
+    labels = _new((B, n0 + 1), dtype=torch.int64, device=sem.device)
+    src_a = _new((B, n0 + 1), dtype=torch.int32, device=sem.device)
     _lib.call('alm_semantic_prepare', sem.data_ptr(), sem.stride(0), B, n0, int(eos_id), int(num_rows), labels.data_ptr(), src_a.data_ptr(), _st())
     return labels, src_a
 
@@ -448,8 +484,8 @@ def fine_prepare(coarse, fine, nf, pad_id, eos_id, Qc, Qf, C):
     assert coarse.dim() == 2 and fine.dim() == 2 and coarse.stride(1) == 1 and fine.stride(1) == 1 and coarse.shape[0] == fine.shape[0] and fine.shape[1] >= nf
     B, n = coarse.shape
     N, dev = n + nf + 2, coarse.device
-    src_a = torch.empty((B, N), dtype=torch.int32, device=dev)
-    keep = torch.empty((B, N), dtype=torch.bool, device=dev)
+    src_a = _new((B, N), dtype=torch.int32, device=dev)
+    keep = _new((B, N), dtype=torch.bool, device=dev)
     _lib.call('alm_fine_prepare', coarse.data_ptr(), coarse.stride(0), fine.data_ptr(), fine.stride(0), B, n, nf, int(pad_id), int(eos_id), int(Qc), int(Qf),
               int(C), src_a.data_ptr(), keep.data_ptr(), _st())
     return src_a, keep
@@ -473,7 +509,7 @@ def kv_grad_pack(dkv_f32, acc_v0, mode, dim_head=64, out=None):
         dkv_f32 = dkv_f32.unsqueeze(0)
     nparts, rows = dkv_f32.shape[0], dkv_f32.shape[1]
     if out is None:
-        out = torch.empty((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
+        out = _new((rows, 2 * dim_head), dtype=BF16, device=dkv_f32.device)
     assert out.shape == (rows, 2 * dim_head) and out.dtype == BF16 and out.stride(1) == 1
     _lib.call('alm_kv_grad_pack', dkv_f32.data_ptr(), dkv_f32.data_ptr() + 4 * dim_head, dkv_f32.stride(1), nparts, dkv_f32.stride(0),
               _p(acc_v0), out.data_ptr(), out.stride(0), rows, dim_head, mode, _st())
@@ -488,8 +524,8 @@ def posmlp_in_fwd(x, W, b):
     L, ind = x.shape
     C = W.shape[0]
     assert W.shape == (C, ind) and x.is_contiguous() and W.is_contiguous()
-    pre = torch.empty((L, C), dtype=F32, device=x.device)
-    act = torch.empty((L, C), dtype=BF16, device=x.device)
+    pre = _new((L, C), dtype=F32, device=x.device)
+    act = _new((L, C), dtype=BF16, device=x.device)
     _lib.call('alm_posmlp_in_fwd', x.data_ptr(), W.data_ptr(), b.data_ptr(), pre.data_ptr(), act.data_ptr(), L, ind, C, _st())
     return pre, act
 
@@ -500,7 +536,7 @@ def posmlp_in_bwd(dpre, x):
     L, C = dpre.shape
     ind = x.shape[1]
     chunks = _lib.query('alm_posmlp_in_bwd_chunks', L)
-    part = torch.empty((chunks, (1 + ind) * C), dtype=F32, device=x.device)
+    part = _new((chunks, (1 + ind) * C), dtype=F32, device=x.device)
     _lib.call('alm_posmlp_in_bwd', dpre.data_ptr(), x.data_ptr(), part.data_ptr(), L, ind, C, _st())
     s = colsum(part)
     return s[C:].view(ind, C).t().contiguous(), s[:C]
@@ -508,14 +544,14 @@ def posmlp_in_bwd(dpre, x):
 
 def silu_fwd(pre):
     _chk(pre, F32)
-    act = torch.empty(pre.shape, dtype=BF16, device=pre.device)
+    act = _new(pre.shape, dtype=BF16, device=pre.device)
     _lib.call('alm_silu_fwd', pre.data_ptr(), act.data_ptr(), pre.numel(), _st())
     return act
 
 
 def silu_bwd(dact, pre):
     _chk(dact, F32), _chk(pre, F32)
-    dpre = torch.empty(pre.shape, dtype=BF16, device=pre.device)
+    dpre = _new(pre.shape, dtype=BF16, device=pre.device)
     _lib.call('alm_silu_bwd', dact.data_ptr(), pre.data_ptr(), dpre.data_ptr(), pre.numel(), _st())
     return dpre
 
@@ -525,7 +561,7 @@ def posmlp_out_fwd(act, W, b, special, inv_scale):
     _chk(act, BF16), _chk(W, F32), _chk(b, F32)
     L, C = act.shape
     H = W.shape[0]
-    tbl = torch.empty((H, L + 1), dtype=F32, device=act.device)
+    tbl = _new((H, L + 1), dtype=F32, device=act.device)
     _lib.call('alm_posmlp_out_fwd', act.data_ptr(), W.data_ptr(), b.data_ptr(), _p(special), tbl.data_ptr(), L, C, H, float(inv_scale), _st())
     return tbl
 
@@ -537,9 +573,9 @@ def posmlp_out_bwd(dtbl, W, pre, inv_scale):
     L, C = pre.shape
     assert LT == L + 1 and dtbl.is_contiguous()
     Hp = (H + 7) // 8 * 8
-    g = torch.empty((L, Hp), dtype=BF16, device=pre.device)
-    dpre = torch.empty((L, C), dtype=BF16, device=pre.device)
-    dsp = torch.empty(H, dtype=F32, device=pre.device)
+    g = _new((L, Hp), dtype=BF16, device=pre.device)
+    dpre = _new((L, C), dtype=BF16, device=pre.device)
+    dsp = _new(H, dtype=F32, device=pre.device)
     _lib.call('alm_posmlp_out_bwd', dtbl.data_ptr(), W.data_ptr(), pre.data_ptr(), g.data_ptr(), dpre.data_ptr(), dsp.data_ptr(), L, C, H, Hp,
               float(inv_scale), _st())
     return g, dpre, dsp
@@ -564,22 +600,22 @@ def hc_fwd(R_in, B, S, N, D, *, y_prev=None, coef_prev=None, hc=None, ln_gamma=N
     depth, width = y_prev is not None, hc is not None
     mode = (1 if depth else 0) | (2 if width else 0) | (4 if final else 0)
     out = {}
-    R_out = torch.empty((B, S, N, D), dtype=r_dtype, device=dev) if (depth and not final) else None
+    R_out = _new((B, S, N, D), dtype=r_dtype, device=dev) if (depth and not final) else None
     x = xn = xn32 = mean = rstd = coef = xs = None
     if width or final:
         if final and final_f32:
-            xn32 = torch.empty((M, D), dtype=F32, device=dev)
+            xn32 = _new((M, D), dtype=F32, device=dev)
         else:
-            xn = torch.empty((M, D), dtype=BF16, device=dev) if xn_out is None else xn_out
+            xn = _new((M, D), dtype=BF16, device=dev) if xn_out is None else xn_out
             assert xn.shape == (M, D) and xn.dtype == BF16 and xn.is_contiguous()
-        mean = torch.empty(M, dtype=F32, device=dev)
-        rstd = torch.empty(M, dtype=F32, device=dev)
+        mean = _new(M, dtype=F32, device=dev)
+        rstd = _new(M, dtype=F32, device=dev)
     if width:
-        x = (torch.empty((M, D), dtype=BF16, device=dev) if x_out is None else x_out) if want_x else None
+        x = (_new((M, D), dtype=BF16, device=dev) if x_out is None else x_out) if want_x else None
         assert x is None or (x.shape == (M, D) and x.dtype == BF16 and x.is_contiguous())
-        coef = torch.empty((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
+        coef = _new((M, _lib.query('alm_hc_coef_width', S)), dtype=F32, device=dev)
     if final:
-        xs = torch.empty((M, D), dtype=F32, device=dev)
+        xs = _new((M, D), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in _HC_KEYS7] if width else [None] * 7
     _lib.call('alm_hc_fwd', R_in.data_ptr(), int(rin_bcast), int(r_dtype == BF16), _p(y_prev), y_prev.stride(0) if depth else 0, _p(coef_prev), _p(R_out),
               *hp, _p(ln_gamma), _p(x), D, _p(xn), D, _p(xn32), _p(mean), _p(rstd), _p(coef), _p(xs), mode, B, S, N, D, _st())
@@ -610,16 +646,16 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
     if width:
         assert (dx is None) != (dxn is None)
         if sum_only:
-            dsum = torch.empty((M, D), dtype=F32, device=dev)
+            dsum = _new((M, D), dtype=F32, device=dev)
         else:
-            dR = torch.empty((B, S, N, D), dtype=r_dtype, device=dev)
+            dR = _new((B, S, N, D), dtype=r_dtype, device=dev)
         rows = _lib.query('alm_hc_partial_rows', mode, int(dxn is not None), rbf, S, M, D)
         P = _lib.query('alm_hc_partial_width', S, D)
-        part = torch.empty((rows, P), dtype=F32, device=dev)
+        part = _new((rows, P), dtype=F32, device=dev)
     if depth:
-        dy = torch.empty((M, D), dtype=BF16, device=dev) if dy_out is None else dy_out
+        dy = _new((M, D), dtype=BF16, device=dev) if dy_out is None else dy_out
         assert dy.shape == (M, D) and dy.dtype == BF16 and dy.is_contiguous()
-        dbo = torch.empty((M, S), dtype=F32, device=dev)
+        dbo = _new((M, S), dtype=F32, device=dev)
     hp = [hc[k].data_ptr() for k in ('gamma', 'Wa', 'sa', 'wb', 'sb')] if width else [None] * 5
     _lib.call('alm_hc_bwd', dRn.data_ptr(), int(bcast), rbf, _p(dx), dx.stride(0) if dx is not None else 0, _p(dxn),
               dxn.stride(0) if dxn is not None else 0, _p(extra), extra.stride(0) if extra is not None else 0, _p(mean), _p(rstd), _p(ln_gamma),
@@ -631,11 +667,11 @@ def hc_bwd(dRn, B, S, N, D, *, bcast=False, dx=None, dxn=None, extra=None, mean=
     if width:
         chunks = _lib.query('alm_colsum_chunks', rows)
         if chunks > 1:                                       # stage 1 of the column sums; the chunk rows are summed inside alm_hc_param_grads
-            ws = torch.empty((chunks, P), dtype=F32, device=dev)
+            ws = _new((chunks, P), dtype=F32, device=dev)
             _lib.call('alm_colsum_partial', part.data_ptr(), P, rows, P, ws.data_ptr(), _st())
         else:
             ws = colsum(part)
-        g = torch.empty(_lib.query('alm_hc_grads_width', S, D), dtype=F32, device=dev)
+        g = _new(_lib.query('alm_hc_grads_width', S, D), dtype=F32, device=dev)
         _lib.call('alm_hc_param_grads', ws.data_ptr(), chunks, hc['gamma'].data_ptr(), hc['Wa'].data_ptr(), hc['wb'].data_ptr(), g.data_ptr(), S, D, _st())
         o = 0
         grads = {}
@@ -667,8 +703,8 @@ def hc_param_grads_batched(parts, S, D):
         grp = parts[i0:i0 + 16]
         nb, dev = len(grp), grp[0][0].device
         P, GW = _lib.query('alm_hc_partial_width', S, D), _lib.query('alm_hc_grads_width', S, D)
-        g = torch.empty((nb, GW), dtype=F32, device=dev)
-        ws = torch.empty((nb, 16, P), dtype=F32, device=dev)
+        g = _new((nb, GW), dtype=F32, device=dev)
+        ws = _new((nb, 16, P), dtype=F32, device=dev)
         arr_p = (ctypes.c_void_p * nb)(*[t[0].data_ptr() for t in grp])
         arr_r = (ctypes.c_int * nb)(*[int(t[1]) for t in grp])
         arr_g = (ctypes.c_void_p * nb)(*[t[2]['gamma'].data_ptr() for t in grp])
@@ -703,14 +739,14 @@ def hc_width_bwd(dRn, dx, R, coef, dbeta, hc, B, S, N, D):
 def streams_expand(x, B, S):
     _chk(x, F32)
     nd = x.numel() // B
-    R = torch.empty((B, S) + tuple(x.shape[1:]), dtype=F32, device=x.device)
+    R = _new((B, S) + tuple(x.shape[1:]), dtype=F32, device=x.device)
     _lib.call('alm_streams_expand', x.data_ptr(), R.data_ptr(), B, S, nd, _st())
     return R
 
 
 def streams_reduce(R, B, S):
     nd = R.numel() // (B * S)
-    x = torch.empty((B,) + tuple(R.shape[2:]), dtype=F32, device=R.device)
+    x = _new((B,) + tuple(R.shape[2:]), dtype=F32, device=R.device)
     _lib.call('alm_streams_reduce', R.data_ptr(), x.data_ptr(), B, S, nd, _st())
     return x
 
@@ -718,7 +754,7 @@ def streams_reduce(R, B, S):
 def residual_add(x, y):
     """fp32 x [rows, D] + bf16 y [rows, D] -> new fp32."""
     rows, D = y.shape
-    out = torch.empty((rows, D), dtype=F32, device=y.device)
+    out = _new((rows, D), dtype=F32, device=y.device)
     _lib.call('alm_residual_add', x.data_ptr(), y.data_ptr(), y.stride(0), out.data_ptr(), rows, D, _st())
     return out
 
@@ -726,7 +762,7 @@ def residual_add(x, y):
 def f32_to_bf16(a, b=None, out=None):
     rows, D = a.shape
     if out is None:
-        out = torch.empty((rows, D), dtype=BF16, device=a.device)
+        out = _new((rows, D), dtype=BF16, device=a.device)
     assert out.shape == (rows, D) and out.dtype == BF16 and out.is_contiguous()
     _lib.call('alm_f32_to_bf16', a.data_ptr(), _p(b), out.data_ptr(), D, rows, D, _st())
     return out
@@ -734,7 +770,7 @@ def f32_to_bf16(a, b=None, out=None):
 
 def add_f32(a, b, scale=1.0):
     """(a + b) * scale, fp32"""
-    out = torch.empty_like(a)
+    out = _new_like(a)
     _lib.call('alm_add_f32', a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), float(scale), _st())
     return out
 
@@ -810,7 +846,7 @@ def _table_rows(tables):
 
 def embed_assemble(tables, src_a, src_b, rows, D):
     """tables: fp32 [rows_t, D] each.  Ids outside a table never touch memory: zero vector + device error flag (see device_error_flag)."""
-    out = torch.empty((rows, D), dtype=F32, device=src_a.device)
+    out = _new((rows, D), dtype=F32, device=src_a.device)
     arr = _ptr_array(tables)
     poll_device_errors(src_a.device)
     _lib.call('alm_embed_assemble', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(_table_rows(tables), ctypes.c_void_p), len(tables), src_a.data_ptr(),
@@ -840,7 +876,7 @@ def embed_scatter_owned(grad_tables, src_a, src_b, dout, alpha, rows, D):
             g.zero_()
         embed_scatter_add(grad_tables, src_a, src_b, dout, alpha, rows, D)
         return False
-    ws = torch.empty(max(nws, 1), dtype=F32, device=dout.device)
+    ws = _new(max(nws, 1), dtype=F32, device=dout.device)
     _lib.call('alm_embed_scatter_owned', ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(tr, ctypes.c_void_p), len(grad_tables),
               src_a.data_ptr(), src_b.data_ptr(), dout.data_ptr(), float(alpha), rows, D, ws.data_ptr(), _st())
     return True
@@ -857,8 +893,8 @@ def gather_split(inp, idx=None, rows_out=None, out=None):
     elif rows_out is None:
         rows_out = rows_in
     if out is None:
-        hi = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
-        lo = torch.empty((rows_out, D), dtype=BF16, device=inp.device)
+        hi = _new((rows_out, D), dtype=BF16, device=inp.device)
+        lo = _new((rows_out, D), dtype=BF16, device=inp.device)
     else:
         hi, lo = out
         assert hi.shape == lo.shape == (rows_out, D) and hi.dtype == lo.dtype == BF16 and hi.stride(1) == lo.stride(1) == 1 and hi.stride(0) == lo.stride(0)
@@ -870,7 +906,7 @@ def gather_rows(inp, idx, out=None):
     rows = idx.numel()
     D = inp.shape[1]
     if out is None:
-        out = torch.empty((rows, D), dtype=BF16, device=inp.device)
+        out = _new((rows, D), dtype=BF16, device=inp.device)
     _lib.call('alm_gather_rows_bf16', inp.data_ptr(), inp.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), rows, D, _st())
     return out
 
@@ -885,22 +921,22 @@ def cross_entropy_fwd(logits, labels, C, ignore_index=-1):
     """logits fp32 [rows, >= C]; labels int64 [rows] -> (loss_rows fp32, lse fp32)."""
     _chk(logits, F32), _chk(labels, torch.int64)
     rows = labels.numel()
-    loss = torch.empty(rows, dtype=F32, device=logits.device)
-    lse = torch.empty(rows, dtype=F32, device=logits.device)
+    loss = _new(rows, dtype=F32, device=logits.device)
+    lse = _new(rows, dtype=F32, device=logits.device)
     _lib.call('alm_cross_entropy_fwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), loss.data_ptr(), lse.data_ptr(), rows, C, ignore_index, _st())
     return loss, lse
 
 
 def cross_entropy_bwd(logits, labels, lse, gscale, C, Cpad, ignore_index=-1):
     rows = labels.numel()
-    d = torch.empty((rows, Cpad), dtype=BF16, device=logits.device)
+    d = _new((rows, Cpad), dtype=BF16, device=logits.device)
     _lib.call('alm_cross_entropy_bwd', logits.data_ptr(), logits.stride(0), labels.data_ptr(), lse.data_ptr(), gscale.data_ptr(), d.data_ptr(), Cpad,
               rows, C, Cpad, ignore_index, _st())
     return d
 
 
 def reduce_sum(x, scale=1.0):
-    out = torch.empty((), dtype=F32, device=x.device)
+    out = _new((), dtype=F32, device=x.device)
     _lib.call('alm_reduce_sum', x.data_ptr(), x.numel(), out.data_ptr(), float(scale), _st())
     return out
 
@@ -911,7 +947,7 @@ def conv1d_pack(w):
     """nn.Conv1d weight fp32 [Cout, Cin, k] -> packed [k][Cin_pad][Cout_pad] fp32 (once per weight update)."""
     _chk(w, F32)
     Cout, Cin, ks = w.shape
-    wp = torch.empty(_lib.query('alm_conv1d_packed_floats', Cout, Cin, ks), dtype=F32, device=w.device)
+    wp = _new(_lib.query('alm_conv1d_packed_floats', Cout, Cin, ks), dtype=F32, device=w.device)
     _lib.call('alm_conv1d_pack', w.contiguous().data_ptr(), wp.data_ptr(), Cout, Cin, ks, _st())
     return wp
 
@@ -922,7 +958,7 @@ def conv1d_causal(x, wp, bias, Cout, ksize, *, stride=1, dilation=1, elu=False, 
     B, Cin, T = x.shape
     assert x.is_contiguous()
     Tout = (T - stride) // stride + 1
-    out = torch.empty((B, Cout, Tout), dtype=F32, device=x.device)
+    out = _new((B, Cout, Tout), dtype=F32, device=x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     _lib.call('alm_conv1d_causal', x.data_ptr(), wp.data_ptr(), bias.data_ptr(), _p(residual), out.data_ptr(), B, Cin, Cout, T, ksize, stride,
@@ -939,7 +975,7 @@ def resunit_causal(x, w7p, b7, w1p, b1, ksize, dilation):
     _chk(x, F32)
     B, C, T = x.shape
     assert x.is_contiguous()
-    out = torch.empty_like(x)
+    out = _new_like(x)
     _lib.call('alm_resunit_causal', x.data_ptr(), w7p.data_ptr(), b7.data_ptr(), w1p.data_ptr(), b1.data_ptr(), out.data_ptr(), B, C, T, ksize, dilation, _st())
     return out
 
@@ -949,7 +985,7 @@ def phase_interleave(y, Cout, s):
     _chk(y, F32)
     B, SC, n = y.shape
     assert SC == s * Cout and y.is_contiguous()
-    out = torch.empty((B, Cout, n * s), dtype=F32, device=y.device)
+    out = _new((B, Cout, n * s), dtype=F32, device=y.device)
     _lib.call('alm_phase_interleave', y.data_ptr(), out.data_ptr(), B, Cout, s, n, _st())
     return out
 
@@ -968,8 +1004,8 @@ def rvq_pack(E):
     _chk(E, F32)
     Q, C, d = E.shape
     CP = _lib.query('alm_rvq_padded_codes', C)
-    Et = torch.empty((Q, _lib.query('alm_rvq_padded_dim', d), CP), dtype=F32, device=E.device)
-    e2 = torch.empty((Q, CP), dtype=F32, device=E.device)
+    Et = _new((Q, _lib.query('alm_rvq_padded_dim', d), CP), dtype=F32, device=E.device)
+    e2 = _new((Q, CP), dtype=F32, device=E.device)
     _lib.call('alm_rvq_pack', E.contiguous().data_ptr(), Et.data_ptr(), e2.data_ptr(), Q, C, d, _st())
     return Et, e2
 
@@ -981,7 +1017,7 @@ def rvq_encode(x, E, Et, e2, idx_out=None, quant_out=None):
     Q, C, _ = E.shape
     assert x.stride(1) == 1
     if idx_out is None:
-        idx_out = torch.empty((T, Q), dtype=torch.int64, device=x.device)
+        idx_out = _new((T, Q), dtype=torch.int64, device=x.device)
     assert idx_out.shape == (T, Q) and idx_out.stride(1) == 1
     _lib.call('alm_rvq_encode', x.data_ptr(), x.stride(0), E.data_ptr(), Et.data_ptr(), e2.data_ptr(), idx_out.data_ptr(), idx_out.stride(0),
               _p(quant_out), quant_out.stride(0) if quant_out is not None else 0, T, d, C, Q, _st())
@@ -990,7 +1026,7 @@ def rvq_encode(x, E, Et, e2, idx_out=None, quant_out=None):
 
 def bct_to_btc(x):
     B, C, T = x.shape
-    out = torch.empty((B, T, C), dtype=F32, device=x.device)
+    out = _new((B, T, C), dtype=F32, device=x.device)
     _lib.call('alm_bct_to_btc', x.data_ptr(), out.data_ptr(), B, C, T, _st())
     return out
 
@@ -1001,7 +1037,7 @@ def layernorm_bct(x, gamma, beta, eps=1e-5):
     _chk(x, F32)
     B, C, T = x.shape
     assert x.is_contiguous()
-    out = torch.empty_like(x)
+    out = _new_like(x)
     _lib.call('alm_layernorm_bct', x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), B, C, T, float(eps), _st())
     return out
 
@@ -1011,7 +1047,7 @@ def geglu_bct(x):
     _chk(x, F32)
     B, C2, T = x.shape
     assert x.is_contiguous() and C2 % 2 == 0
-    out = torch.empty((B, C2 // 2, T), dtype=F32, device=x.device)
+    out = _new((B, C2 // 2, T), dtype=F32, device=x.device)
     _lib.call('alm_geglu_bct', x.data_ptr(), out.data_ptr(), B, C2 // 2, T, _st())
     return out
 
@@ -1023,7 +1059,7 @@ def local_attn(qkv, q_scale, k_scale, cos_t, sin_t, xpos_t, gates, heads, dim_he
     assert qkv.is_contiguous() and C3 == 3 * heads * dim_head
     for t in (cos_t, sin_t, xpos_t):
         assert t.dtype == F32 and t.is_contiguous() and tuple(t.shape) == (2 * window, dim_head) and t.device == qkv.device
-    out = torch.empty((B, heads * dim_head, T), dtype=F32, device=qkv.device)
+    out = _new((B, heads * dim_head, T), dtype=F32, device=qkv.device)
     _lib.call('alm_local_attn', qkv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), xpos_t.data_ptr(), _p(gates),
               out.data_ptr(), B, heads, dim_head, T, window, float(scale), _st())
     return out

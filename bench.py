@@ -313,7 +313,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))      # backend "nccl" IS RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started {world} ranks (python bench.py --gpus N starts its own N ranks when no launcher did)'
 
-    from audiolm_pytorch_amd import core, graphed, ops, parallel
+    from audiolm_pytorch_amd import core, graphed, launchlist, ops, parallel
     import audiolm_pytorch_amd as A
 
     W = build(args.config, dev, rank, {'bf16': torch.bfloat16, 'fp32': torch.float32, 'auto': None}[args.residual])
@@ -443,10 +443,15 @@ def main():
 
     # host time to ISSUE one step (no synchronisation inside): eager launches vs one graph replay
     host = {}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eager_step()
-    host['eager_issue_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+    issue = []
+    for _ in range(5):                                          # median of 5 single steps (one sample swings by +-1.5 ms with the host's other work)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eager_step()
+        issue.append((time.perf_counter() - t0) * 1e3)
+    host['eager_issue_ms'] = round(sorted(issue)[2], 3)
+    host['eager_issue_ms_samples'] = [round(v, 3) for v in issue]
+    host['launch_list'] = dict(launchlist.STATS, enabled=launchlist.ENABLED)       # stack passes sized / recorded / replayed so far (replayed > 0: the timed steps ran from the lists)
     torch.cuda.synchronize()
     if gstep is not None:
         t0 = time.perf_counter()
@@ -578,6 +583,7 @@ def main():
     for n in timed_names:
         setattr(ops, n, make_timed(n))
     was_async, core.ASYNC_WGRAD = core.ASYNC_WGRAD, False      # per-kernel durations: no concurrent side-stream GEMMs in this step
+    was_ll, launchlist.ENABLED = launchlist.ENABLED, False     # ... and every launch issued from Python through the wrappers above (a replayed launch list by-passes them)
     try:
         eager_step()
         torch.cuda.synchronize()
@@ -585,6 +591,7 @@ def main():
         for n in timed_names:
             setattr(ops, n, originals[n])
         core.ASYNC_WGRAD = was_async
+        launchlist.ENABLED = was_ll
     agg = {}
     for e0, e1, wk, unit, key in events:
         a = agg.setdefault(key, [0.0, 0.0, 0, unit])
@@ -719,7 +726,10 @@ def main():
             'dtype': 'bf16',
             'data': 'synthetic (uniform random semantic / acoustic RVQ token ids, random-init weights)',
             'config': {'workload': W['workload'], 'global_batch': world * W['B'], 'seq_len': N, 'parallelism': f'dp{world}',
-                       'schedule': {'eager': 'eager (every kernel launched from Python each step)',
+                       'schedule': {'eager': ('eager: every kernel launched each step, no hipGraph -- the transformer stack\'s forward / backward launch sequences recorded once per '
+                                              'shape and re-issued from one C call each (alm_list_run: same entry points, same order, live addresses; bit-identical to the '
+                                              'Python-issued step), everything around the stack launched from Python') if (launchlist.ENABLED and launchlist.STATS['replayed']) else
+                                             'eager (every kernel launched from Python each step)',
                                     'eager2': 'eager, two half-batches on two HIP streams inside the stack (diagnostic: host-bound)',
                                     'graph': 'one hipGraph replay per step (captured fwd + bwd)',
                                     'graph2': 'one hipGraph replay per step: two half-batches of 4 sequences on two HIP streams (row kernels of one half under the GEMMs '

@@ -394,6 +394,29 @@ int alm_geglu_bct(const float* x, float* out, int B, int I, int T, void* stream)
 int alm_local_attn(const float* qkv, const float* q_scale, const float* k_scale, const float* cos_t, const float* sin_t, const float* xpos_t,
                    const float* gates, float* out, int B, int H, int dim_head, int T, int window, float scale, void* stream);
 
+/* ---- launch lists (round 6): a recorded sequence of the launches above re-issued by ONE host call ---------------------------------------------
+ * The depth loop of audiolm_pytorch.py:528-547 (Transformer.forward) and its backward are ~190 launches per training step whose ORDER and scalar arguments
+ * depend only on the model configuration and the batch shape; only buffer addresses change between steps.  The host records the sequence once per shape
+ * (audiolm-pytorch_amd/launchlist.py: every pointer argument classified as base + byte offset against a table of bases -- the step's activation arena, the
+ * inputs, every parameter, every packed weight image) and alm_list_run re-issues it: the same entry points, in the same order, on `stream` -- the results are
+ * bit-identical to issuing them one by one.  Nothing is baked (unlike a hipGraph replay): addresses, the stream and the weight images are live.
+ *   entries[e] = {op (alm_list_op_id of the entry point), nargs (must equal alm_list_op_nargs), first (index of its first slot)}
+ *   slots[i]   = one 64-bit value per C argument (int / long long sign-extended, float = its bit pattern in the low word, pointer = byte offset)
+ *   reloc[i]   = ALM_LIST_LITERAL: slots[i] as is;  1 .. nbases: bases[reloc - 1] + slots[i];  ALM_LIST_STREAM: the `stream` argument;
+ *                ALM_LIST_HOST_PTRS: a HOST array of pointers = the resolved slots starting at index slots[i];  ALM_LIST_HOST_INTS: a HOST array of ints
+ *                packed into the slots starting at index slots[i] (alm_hc_param_grads_batched takes both)
+ * Returns 0, or the first failing launch's code with its index in *failed_at (launches before it were issued).  alm_memset_zero = hipMemsetAsync(ptr, 0). */
+typedef struct { int op; int nargs; int first; int reserved; } AlmListEntry;
+#define ALM_LIST_LITERAL 0
+#define ALM_LIST_STREAM 0xFFFF
+#define ALM_LIST_HOST_PTRS 0xFFFE
+#define ALM_LIST_HOST_INTS 0xFFFD
+int alm_memset_zero(void* ptr, long long bytes, void* stream);
+int alm_list_op_id(const char* name);
+int alm_list_op_nargs(int op);
+int alm_list_run(const AlmListEntry* entries, int n, const unsigned long long* slots, const unsigned short* reloc, int nslots,
+                 const unsigned long long* bases, int nbases, void* stream, int* failed_at);
+
 #ifdef __cplusplus
 }
 #endif

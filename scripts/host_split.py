@@ -37,6 +37,22 @@ def sb(*a, **k):
 
 
 core.stack_forward, core.stack_backward = sf, sb
+from audiolm_pytorch_amd import launchlist  # noqa: E402
+if launchlist.ENABLED:                       # replayed launch lists by-pass core.stack_*: time the list calls instead (the sized / recorded passes fall in the warm-up)
+    olf, olb = launchlist.forward, launchlist.backward
+
+    def lf(*a, **k):
+        t0 = time.perf_counter()
+        r = olf(*a, **k)
+        acc['sf'] = acc['sf'] + time.perf_counter() - t0 if launchlist.STATS['replayed'] else acc['sf']
+        return r
+
+    def lb(*a, **k):
+        t0 = time.perf_counter()
+        r = olb(*a, **k)
+        acc['sb'] = acc['sb'] + time.perf_counter() - t0 if launchlist.STATS['replayed'] else acc['sb']
+        return r
+    launchlist.forward, launchlist.backward = lf, lb
 
 
 def step():
@@ -63,4 +79,5 @@ for _ in range(n):
     tot += t2 - t0
     fwd += t1 - t0
 torch.cuda.synchronize()
+print(f'launch lists: {dict(launchlist.STATS, enabled=launchlist.ENABLED)}')
 print(f'{cfg}: issue {tot / n * 1e3:.2f} ms/step = forward {fwd / n * 1e3:.2f} (stack {acc["sf"] / n * 1e3:.2f}) + backward {(tot - fwd) / n * 1e3:.2f} (stack {acc["sb"] / n * 1e3:.2f})')
