@@ -1191,7 +1191,7 @@ class TransformerStackFn(torch.autograd.Function):
         ctx.saved = None                                                      # (grad_shrink, audiolm_pytorch.py:93-94, :478: applied inside stack_backward)
         out = []
         for p, g in zip(ctx.flat, grads):
-            out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
+            out.append((g if g.shape == p.shape else g.reshape(p.shape)) if (g is not None and p.requires_grad) else None)
         dcontext = None
         if dctx is not None and ctx.ctx_meta is not None:
             dcontext = dctx.reshape(ctx.ctx_meta[0]).to(ctx.ctx_meta[1])

@@ -259,6 +259,8 @@ class Plan:
         self.fwd_bytes = self.bwd_bytes = None
         self.fwd = self.bwd = None
         self.why = None
+        self.dhn_dtype = None               # dtype of the gradient the backward list was recorded with (a scalar argument of its first launch depends on it)
+        self.orphans = 0                    # forwards recorded since the last recorded backward (a caller that never runs backward must not keep recording)
 
 
 class Replay:
@@ -348,6 +350,10 @@ def forward(core, plan, xin, mask_u8, flat, cfg, cache, need, bias, defer):
             saved['_ll'] = (plan, 'size', None, xin)
         return hn, saved
     # record (also: a forward that arrives while the backward list does not exist yet)
+    plan.orphans += 1
+    if plan.orphans > 8:
+        _turn_off(plan, 'forwards with gradients enabled whose backward never ran')
+        return core.stack_forward(xin, mask_u8, flat, cfg, cache, need, bias, **kw)
     bases = [None, xin, mask_u8] + _bias_tensors(bias) + list(flat) + _weight_images(core, cache, cfg)
     arena = _Arena(plan.fwd_bytes, xin.device)
     bases[0] = (arena.base, arena.cap)
@@ -376,6 +382,11 @@ def backward(core, dhn, mask_u8, flat, cfg, cache, saved, bias, dx_scale):
     """stack_backward under the plan's current state -> (dx, grads, dtbl, dctx)"""
     if isinstance(saved, Replay):
         plan, rec, farena = saved.plan, saved.plan.bwd, saved.arena
+        if dhn.dtype != plan.dhn_dtype:
+            if plan.dhn_dtype != torch.float32:
+                raise _lib.AlmError(f'the backward launch list of this stack was recorded with a {plan.dhn_dtype} output gradient and now receives {dhn.dtype} '
+                                    '(ALM_LAUNCH_LIST=0 keeps the launch-by-launch path)')
+            dhn = dhn.to(torch.float32)                   # (exact: the kernel widens bf16 gradients to fp32 itself)
         core.pack_stack_weights(cache, flat, cfg)
         arena = torch.empty(rec.arena_bytes, dtype=torch.uint8, device=dhn.device)
         rec.bases[0], rec.bases[1] = arena.data_ptr(), farena.data_ptr()
@@ -418,7 +429,7 @@ def backward(core, dhn, mask_u8, flat, cfg, cache, saved, bias, dx_scale):
         if plan.state != 'off':
             _turn_off(plan, 'backward: ' + rec.failed)
     elif plan.state != 'off' and plan.fwd is not None:
-        plan.bwd = out
+        plan.bwd, plan.dhn_dtype, plan.orphans = out, dhn.dtype, 0
         plan.state = 'ready'
         STATS['recorded'] += 1
     return dx, grads, dtbl, dctx
