@@ -113,23 +113,45 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(ScatterTabs tabs, co
 // hot cache line, and there is no data-dependent sort on the host side.
 constexpr int OWN_G = 8;                 // destination rows per workgroup
 constexpr int OWN_PEND = 1024;           // pending-list entries per wave (flushed when fewer than one scan step's 512 slots are left)
-struct OwnTabs { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int small_base[MAX_TABLES]; int grp_base[MAX_TABLES + 1]; int n; int nsmall; int nchunks; };
+// HOT ROWS (round 6): a destination row that very many tokens map to (skewed ids: the codes of silence, a collapsed codebook, a dominant semantic unit) made
+// its ONE owner add thousands of 4 KB rows one after the other while the rest of the chip idled (half the tokens on 4 rows: 1.65 ms at 66 k tokens against
+// 0.2 ms with uniform ids).  Now the first launch also HISTOGRAMS the codes of the large tables (integer atomics: the counts are exact, hence deterministic),
+// its last-arriving workgroup lists the rows with more than HOT_T tokens in row order and gives each `parts` = ceil(count / HOT_PT) (2 ... HOT_PMAX) equal
+// TOKEN RANGES; the second launch's first HOT_NSPLIT workgroups take (hot row, part) items: scan only their token range, sum the matching dout rows as an
+// owner would, publish the partial with write-through stores, and the row's last arriver (ticket) adds the partials in part order 0, 1, 2, ... and writes the
+// row.  Owners skip the rows that were listed.  Every sum is still a fixed function of the code arrays: bitwise run-to-run deterministic, no float atomics.
+constexpr int HOT_T = 128;               // a row is hot above this many tokens
+constexpr int HOT_PT = 256;              // target tokens per part
+constexpr int HOT_PMAX = 64;             // parts per hot row at most
+constexpr int HOT_MAX = 256;             // listed hot rows at most (further ones stay with their owners)
+constexpr int HOT_NSPLIT = 256;          // workgroups of the second launch that take (hot row, part) items
+constexpr int HOT_NY = 8;                // column blocks (of 1024) the ticket table covers: D <= 8192, wider rows keep the plain owner path
+// int workspace (zeroed by the caller's memset): [0] arrival ticket of the histogram, [1] nhot, [2] total parts, [4, 4 + HOT_MAX) hot codes,
+// [.., + HOT_MAX + 1) part offsets, [.., + HOT_MAX * HOT_NY) row tickets, then one count per large-table row (after listing: -(hot index + 1) for listed rows)
+constexpr int IW_HOT = 4, IW_POFF = IW_HOT + HOT_MAX, IW_TICK = IW_POFF + HOT_MAX + 1, IW_CNT = (IW_TICK + HOT_MAX * HOT_NY + 3) & ~3;     // (counts: 16-byte aligned)
+struct OwnTabs { float* p[MAX_TABLES]; int rows[MAX_TABLES]; int small_base[MAX_TABLES]; int grp_base[MAX_TABLES + 1]; int lrow_base[MAX_TABLES]; int n; int nsmall;
+                 int nchunks; int ltot; };
+__device__ __forceinline__ int hot_parts(int c) { return min(HOT_PMAX, max(2, (c + HOT_PT - 1) / HOT_PT)); }
 
 // chunk = OWN_CH token rows x 1024 columns per workgroup (thread = 4 columns).  The chunk's codes are fetched once into LDS (the first version read them
 // with two dependent scalar loads per token: a latency chain of 2 x 128 L2 round trips per workgroup, 91 us for 67 MB); the dout rows stream with 8
 // float4 loads per thread in flight; accumulators: one float4 per (small row, thread) in LDS, touched by their own thread only.
+// iw != NULL: the workgroups of column block 0 also count the codes of the large tables, and the last of them to arrive lists the hot rows (see above).
 constexpr int OWN_CH = 32;
 __global__ __launch_bounds__(256) void embed_scatter_small_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
-                                                                  const float* __restrict__ dout, float alpha, long long rows, int D, float* __restrict__ ws) {
+                                                                  const float* __restrict__ dout, float alpha, long long rows, int D, float* __restrict__ ws,
+                                                                  int* __restrict__ iw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char own_smem[];
     int* codes = reinterpret_cast<int*>(own_smem);                          // [2][OWN_CH]: slot of the small row (>= 0) or -1
     float4* acc = reinterpret_cast<float4*>(own_smem + 2 * OWN_CH * sizeof(int));   // [nsmall][256]
+    __shared__ int hs_hot[256], hs_parts[256], hs_flag;
     const int t = threadIdx.x;
     const int col = blockIdx.y * 1024 + t * 4;
     const bool cok = col < D;
     const int colc = cok ? col : 0;
     const long long r0 = (long long)blockIdx.x * OWN_CH;
     const int nr = (int)min((long long)OWN_CH, rows - r0);
+    const bool hist = iw != nullptr && blockIdx.y == 0;
     if (t < 2 * OWN_CH) {
         const int k = t / OWN_CH, i = t % OWN_CH;
         int slot = -1;
@@ -138,49 +160,130 @@ __global__ __launch_bounds__(256) void embed_scatter_small_kernel(OwnTabs tabs, 
             if (code >= 0 && code_ok(tabs, code)) {
                 const int sb = tabs.small_base[code >> 24];
                 if (sb >= 0) slot = sb + (code & 0xffffff);
+                else if (hist) __hip_atomic_fetch_add(iw + IW_CNT + tabs.lrow_base[code >> 24] + (code & 0xffffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         codes[t] = slot;
     }
     for (int g = 0; g < tabs.nsmall; ++g) acc[g * 256 + t] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    const float* dp = dout + r0 * D + colc;
+    if (tabs.nsmall > 0) {
+        const float* dp = dout + r0 * D + colc;
 #pragma unroll 1
-    for (int i0 = 0; i0 < nr; i0 += 8) {
-        float4 v[8];
+        for (int i0 = 0; i0 < nr; i0 += 8) {
+            float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dp + (long long)min(i0 + u, nr - 1) * D);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dp + (long long)min(i0 + u, nr - 1) * D);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));      // all 8 in flight (see the owned kernel)
+            for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));      // all 8 in flight (see the owned kernel)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (i0 + u >= nr) break;
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= nr) break;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int slot = codes[k * OWN_CH + i0 + u];               // broadcast read, workgroup-uniform
-                if (slot < 0) continue;
-                float4 a = acc[slot * 256 + t];
-                a.x += v[u].x * alpha; a.y += v[u].y * alpha; a.z += v[u].z * alpha; a.w += v[u].w * alpha;
-                acc[slot * 256 + t] = a;
+                for (int k = 0; k < 2; ++k) {
+                    const int slot = codes[k * OWN_CH + i0 + u];               // broadcast read, workgroup-uniform
+                    if (slot < 0) continue;
+                    float4 a = acc[slot * 256 + t];
+                    a.x += v[u].x * alpha; a.y += v[u].y * alpha; a.z += v[u].z * alpha; a.w += v[u].w * alpha;
+                    acc[slot * 256 + t] = a;
+                }
             }
         }
+        if (cok)
+            for (int g = 0; g < tabs.nsmall; ++g) *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * tabs.nsmall + g) * D + col) = acc[g * 256 + t];
     }
-    if (!cok) return;
-    for (int g = 0; g < tabs.nsmall; ++g) *reinterpret_cast<float4*>(ws + ((long long)blockIdx.x * tabs.nsmall + g) * D + col) = acc[g * 256 + t];
+    if (!hist) return;                                                      // (workgroup-uniform)
+    // ---- the histogram's last arriver lists the hot rows.  The counting atomics above are agent-scope read-modify-writes; every wave drains its own, the
+    // barrier collects the waves, one lane takes the ticket (the in-launch split-K idiom of gemm.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) hs_flag = __hip_atomic_fetch_add(iw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!hs_flag) return;
+    // counts: KC coalesced 16-byte loads per thread in flight (sc1: served by the fabric, never by a stale L2 line), thread t holds rows kb * 1024 * KC +
+    // u * 1024 + 4 t + {0..3}.  List order = (thread, batch, load, element): a fixed function of the counts, which is all determinism needs.  (The first
+    // version walked 48 consecutive rows per thread with dependent atomic loads: +36 us on the 12 291-row table.)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int KC = 8;
+    int* const cnt = iw + IW_CNT;
+    const int lpad = (tabs.ltot + 3) & ~3;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(cnt, 0, lpad * 4, 0x00020000);        // (past the end: zeros = not hot)
+    const int nb = (lpad + 1024 * KC - 1) / (1024 * KC);
+    int nh = 0, npt = 0;
+#pragma unroll 1
+    for (int kb = 0; kb < nb; ++kb) {
+        u32x4 v[KC];
+#pragma unroll
+        for (int u = 0; u < KC; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((kb * KC + u) * 1024 + t * 4) * 4, 0, 16);
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (int)v[u][e];
+                if (c > HOT_T) { ++nh; npt += hot_parts(c); }
+            }
+    }
+    hs_hot[t] = nh; hs_parts[t] = npt;
+    __syncthreads();
+    if (t < 64) {                                                           // exclusive prefix over the 256 threads' (rows, parts): wave 0, 4 entries per lane
+        int x[4], y[4], sx = 0, sy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = hs_hot[4 * t + k]; y[k] = hs_parts[4 * t + k]; sx += x[k]; sy += y[k]; }
+        int ix = sx, iy = sy;                                               // inclusive scan of the lane sums
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ux = __shfl_up(ix, d), uy = __shfl_up(iy, d);
+            if (t >= d) { ix += ux; iy += uy; }
+        }
+        int a = ix - sx, b = iy - sy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hs_hot[4 * t + k] = a; hs_parts[4 * t + k] = b; a += x[k]; b += y[k]; }
+        if (t == 63) {                                                      // (a, b) = the totals
+            const int listed = min(a, HOT_MAX);
+            iw[1] = listed;
+            if (a <= HOT_MAX) { iw[2] = b; iw[IW_POFF + listed] = b; }       // (a > HOT_MAX: the thread that lists entry HOT_MAX - 1 writes the totals)
+        }
+    }
+    __syncthreads();
+    int h = hs_hot[t], po = hs_parts[t];
+    if (nh == 0 || h >= HOT_MAX) return;                                    // (no barrier below)
+#pragma unroll 1
+    for (int kb = 0; kb < nb; ++kb) {
+        u32x4 v[KC];
+#pragma unroll
+        for (int u = 0; u < KC; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((kb * KC + u) * 1024 + t * 4) * 4, 0, 16);
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                                   // (unrolled: v[] stays in registers; the body runs for hot rows only)
+                const int c = (int)v[u][e];
+                if (c <= HOT_T || h >= HOT_MAX) continue;
+                const int i = (kb * KC + u) * 1024 + t * 4 + e;
+                int tb = 0;
+                while (tb + 1 < tabs.n && !(tabs.lrow_base[tb] >= 0 && i >= tabs.lrow_base[tb] && i < tabs.lrow_base[tb] + tabs.rows[tb])) ++tb;
+                iw[IW_HOT + h] = (tb << 24) | (i - tabs.lrow_base[tb]);
+                iw[IW_POFF + h] = po;
+                cnt[i] = -(h + 1);                                          // listed: its owner skips it (read by the NEXT launch)
+                po += hot_parts(c);
+                if (++h == HOT_MAX) { iw[2] = po; iw[IW_POFF + HOT_MAX] = po; }
+            }
+    }
 }
 
 __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, const int* __restrict__ src_a, const int* __restrict__ src_b,
                                                                   const float* __restrict__ dout, float alpha, long long rows, int D,
-                                                                  const float* __restrict__ ws, int ngroups) {
+                                                                  const float* __restrict__ ws, int ngroups, int nsplit, int* __restrict__ iw,
+                                                                  float* __restrict__ hp) {
     __shared__ int pend[4][OWN_PEND];
     __shared__ int pcnt[4];
+    __shared__ int hflag;
     __shared__ float4 accs[4][OWN_G][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = (blockIdx.y * 4 + wave) * 256 + lane * 4;
     const bool cok = col < D;                                              // D % 4 == 0: a lane's 4 columns are in or out together
     const int colc = cok ? col : 0;
-    const int g = blockIdx.x;
+    const int g = (int)blockIdx.x - nsplit;                                 // < 0: a (hot row, part) worker; < ngroups: an owner; else a small-row reducer
     if (g >= ngroups) {
         // ---- one small-table row x one 256-column slice: the 4 waves take every 4th chunk partial each (16 loads in flight), then their sums are
         // combined in wave order -- a fixed association, like everything else here
@@ -213,17 +316,9 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
         }
         return;
     }
-    // ---- OWN_G rows of a large table
-    int tb = 0;
-    while (tb + 1 < tabs.n && g >= tabs.grp_base[tb + 1]) ++tb;
-    const int row0 = (g - tabs.grp_base[tb]) * OWN_G;
-    const int nrow = min(OWN_G, tabs.rows[tb] - row0);
-    const int code_lo = (tb << 24) | row0;
     // accumulators: one float4 per (destination row, lane) in LDS, a lane only ever touches its own slots (no conflicts, no barrier); register
     // accumulators would need a select chain per (entry, row) -- 17 k lines of ISA in the first version, which ran out of the instruction cache
     float4* myacc = &accs[wave][0][lane];
-#pragma unroll
-    for (int k = 0; k < OWN_G; ++k) myacc[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
     // Round 6: the SCAN is shared by the workgroup.  Until then every one of the 4 waves (one per 256-column slice) scanned both code arrays itself: 4 x the
     // scan work, and the scan is what the kernel costs on a large table -- codebook 4096 (12 291 rows = 1 537 workgroups) x 66 k tokens: 3.0 ms per step of
     // `e2e_config5`, against 44 us at the headline shape.  Now wave w scans every 4th 512-code block, collects ITS hits (ballot + prefix count: in-order
@@ -258,57 +353,116 @@ __global__ __launch_bounds__(256) void embed_scatter_owned_kernel(OwnTabs tabs, 
             }
         }
     };
-    int* pl = pend[wave];
-    int np = 0;                                                            // wave-uniform: entries in this wave's list
-    // the scan: 8 coalesced dword loads per lane in flight (512 codes per block), the next block's loads issued before this one is processed.  The loads
-    // are UNCONDITIONAL (index clamped to the last row, validity applied to the value afterwards): a per-lane `i < rows ? load : -1` compiles to an
-    // exec-masked branch per load with a full s_waitcnt behind each (one L2 round trip per 64 codes: ~200 us for 32 k codes)
+    // the scan of token rows [t0, t1) for codes code_lo + [0, nrow) whose bit in `skip` is clear: 8 coalesced dword loads per lane in flight (512 codes per
+    // block), the next block's loads issued before this one is processed.  The loads are UNCONDITIONAL (index clamped to the last row, validity applied to the
+    // value afterwards): a per-lane `i < rows ? load : -1` compiles to an exec-masked branch per load with a full s_waitcnt behind each (one L2 round trip per
+    // 64 codes: ~200 us for 32 k codes)
     constexpr int SU = 8, BLK = SU * 64;
     const int last = (int)rows - 1;
+    auto scan_add = [&](const int code_lo, const int nrow, const unsigned skip, const int t0, const int t1) {
+        int* pl = pend[wave];
+        int np = 0;                                                        // wave-uniform: entries in this wave's list
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        const int* __restrict__ arr = pass == 0 ? src_a : src_b;
-        auto fetch = [&](int base, int (&c)[SU]) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int* __restrict__ arr = pass == 0 ? src_a : src_b;
+            auto fetch = [&](int base, int (&c)[SU]) {
 #pragma unroll
-            for (int u = 0; u < SU; ++u) c[u] = arr[min(base + u * 64 + lane, last)];
-        };
-        int cur[SU], nxt[SU];
-        fetch(wave * BLK, cur);
+                for (int u = 0; u < SU; ++u) c[u] = arr[min(base + u * 64 + lane, last)];
+            };
+            int cur[SU], nxt[SU];
+            fetch(t0 + wave * BLK, cur);
 #pragma unroll 1
-        for (int base0 = 0; base0 < (int)rows; base0 += 4 * BLK) {          // one round: blocks base0 + {0, 1, 2, 3} * BLK, one per wave
-            const int base = base0 + wave * BLK;
-            fetch(base + 4 * BLK, nxt);                                     // past the end: the clamped last code, discarded below
-            bool any = false;
+            for (int base0 = t0; base0 < t1; base0 += 4 * BLK) {            // one round: blocks base0 + {0, 1, 2, 3} * BLK, one per wave
+                const int base = base0 + wave * BLK;
+                fetch(base + 4 * BLK, nxt);                                 // past the end: the clamped last code, discarded below
+                bool any = false;
 #pragma unroll
-            for (int u = 0; u < SU; ++u) any |= (unsigned)(cur[u] - code_lo) < (unsigned)nrow;    // (a negative code gives a huge unsigned offset)
-            if (__ballot(any)) {                                            // most blocks hold no token of this group: one ballot instead of eight
+                for (int u = 0; u < SU; ++u) any |= (unsigned)(cur[u] - code_lo) < (unsigned)nrow;    // (a negative code gives a huge unsigned offset)
+                if (__ballot(any)) {                                        // most blocks hold no token of this group: one ballot instead of eight
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int i = base + u * 64 + lane;
-                    const unsigned off = (unsigned)(cur[u] - code_lo);
-                    const bool hit = i <= last && cur[u] >= 0 && off < (unsigned)nrow;
-                    const unsigned long long m = __ballot(hit);
-                    const int pos = np + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    if (hit) pl[pos] = (int)((off << 28) | (unsigned)i);
-                    np += __popcll(m);
+                    for (int u = 0; u < SU; ++u) {
+                        const int i = base + u * 64 + lane;
+                        const unsigned off = (unsigned)(cur[u] - code_lo);
+                        const bool hit = i < t1 && cur[u] >= 0 && off < (unsigned)nrow && !((skip >> (off & 7)) & 1u);
+                        const unsigned long long m = __ballot(hit);
+                        const int pos = np + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        if (hit) pl[pos] = (int)((off << 28) | (unsigned)i);
+                        np += __popcll(m);
+                    }
                 }
-            }
-            const bool final_round = pass == 1 && base0 + 4 * BLK >= (int)rows;
-            if (lane == 0) pcnt[wave] = np;
-            __syncthreads();                                                // the four lists and their lengths are visible
-            const int n0 = pcnt[0], n1 = pcnt[1], n2 = pcnt[2], n3 = pcnt[3];
-            const bool flush = final_round || max(max(n0, n1), max(n2, n3)) > OWN_PEND - BLK;       // (a round adds at most BLK entries per list); uniform
-            if (flush) {
-                add_list(pend[0], n0); add_list(pend[1], n1); add_list(pend[2], n2); add_list(pend[3], n3);
-                np = 0;
-            }
-            __syncthreads();                                                // nobody overwrites a list (or a count) that is still being read
+                const bool final_round = pass == 1 && base0 + 4 * BLK >= t1;
+                if (lane == 0) pcnt[wave] = np;
+                __syncthreads();                                            // the four lists and their lengths are visible
+                const int n0 = pcnt[0], n1 = pcnt[1], n2 = pcnt[2], n3 = pcnt[3];
+                const bool flush = final_round || max(max(n0, n1), max(n2, n3)) > OWN_PEND - BLK;       // (a round adds at most BLK entries per list); uniform
+                if (flush) {
+                    add_list(pend[0], n0); add_list(pend[1], n1); add_list(pend[2], n2); add_list(pend[3], n3);
+                    np = 0;
+                }
+                __syncthreads();                                            // nobody overwrites a list (or a count) that is still being read
 #pragma unroll
-            for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
+                for (int u = 0; u < SU; ++u) cur[u] = nxt[u];
+            }
         }
+    };
+    if (g < 0) {
+        // ---- (hot row, part) items: item = poff[h] + part.  The partial goes out with write-through stores (sc1), every wave drains them, one lane takes the
+        // row's ticket; the last arriver re-reads ALL partials of the row with sc1 loads and adds them in part order
+        const int nparts = iw[2], nhot = iw[1];
+#pragma unroll 1
+        for (int item = (int)blockIdx.x; item < nparts; item += nsplit) {
+            int lo = 0, hi = nhot - 1;                                      // largest h with poff[h] <= item
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (iw[IW_POFF + mid] <= item) lo = mid; else hi = mid - 1; }
+            const int h = lo, p0 = iw[IW_POFF + h], P = iw[IW_POFF + h + 1] - p0, part = item - p0;
+            const int code = iw[IW_HOT + h];
+            const int t0 = (int)((long long)rows * part / P), t1 = (int)((long long)rows * (part + 1) / P);
+            myacc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            scan_add(code, 1, 0u, t0, t1);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(hp + (long long)p0 * D, 0, (int)((long long)P * D * 4), 0x00020000);
+            if (cok) {
+                const float4 a = myacc[0];
+                const u32x4 v = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (part * D + col) * 4, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                hflag = __hip_atomic_fetch_add(iw + IW_TICK + h * HOT_NY + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P - 1;
+            __syncthreads();
+            if (hflag && cok) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+                for (int q0 = 0; q0 < P; q0 += 16) {
+                    u32x4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (min(q0 + u, P - 1) * D + col) * 4, 0, 16);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (q0 + u < P) { a.x += __uint_as_float(v[u].x); a.y += __uint_as_float(v[u].y); a.z += __uint_as_float(v[u].z); a.w += __uint_as_float(v[u].w); }
+                }
+                *reinterpret_cast<float4*>(tabs.p[code >> 24] + (long long)(code & 0xffffff) * D + col) = a;
+            }
+            __syncthreads();                                                // hflag is rewritten by the next item
+        }
+        return;
     }
+    // ---- OWN_G rows of a large table
+    int tb = 0;
+    while (tb + 1 < tabs.n && g >= tabs.grp_base[tb + 1]) ++tb;
+    const int row0 = (g - tabs.grp_base[tb]) * OWN_G;
+    const int nrow = min(OWN_G, tabs.rows[tb] - row0);
+    const int code_lo = (tb << 24) | row0;
+    unsigned skip = 0;                                                     // rows of this group that (hot row, part) workers take
+    if (iw != nullptr)
+        for (int k = 0; k < nrow; ++k) skip |= (iw[IW_CNT + tabs.lrow_base[tb] + row0 + k] < 0 ? 1u : 0u) << k;
+    if (skip == (1u << nrow) - 1u) return;                                  // (uniform) nothing left to own
+#pragma unroll
+    for (int k = 0; k < OWN_G; ++k) myacc[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+    scan_add(code_lo, nrow, skip, 0, (int)rows);
     if (!cok) return;
-    for (int k = 0; k < nrow; ++k) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = myacc[k * 64];
+    for (int k = 0; k < nrow; ++k)
+        if (!((skip >> k) & 1u)) *reinterpret_cast<float4*>(tabs.p[tb] + (long long)(row0 + k) * D + col) = myacc[k * 64];
 }
 
 // out[r] = in[idx[r]] (idx < 0 -> zero row)           bf16 rows, D % 8 == 0
@@ -678,9 +832,11 @@ extern "C" int alm_embed_scatter_add(float* const* grad_tables, const int* table
     return 0;
 }
 
-// Deterministic form of the scatter (no atomics; every row of every table is written).  ws: alm_embed_scatter_ws_floats(...) fp32 floats.
+// Deterministic form of the scatter (no float atomics; every row of every table is written).  ws: alm_embed_scatter_ws_floats(...) fp32 floats:
+// [chunk partials of the few-row tables][partials of the (hot row, part) items][the int workspace of the hot-row listing].
 // Limits: rows < 2^28 (the pending entries pack a 3-bit local row + a 28-bit token row), D % 4 == 0, 16-byte aligned rows.
-static int own_tabs(OwnTabs& t, float* const* grad_tables, const int* table_rows, int ntables, long long rows) {
+struct OwnPlan { long long small_fl, hot_fl, int_fl; bool hot; };
+static int own_tabs(OwnTabs& t, OwnPlan& pl, float* const* grad_tables, const int* table_rows, int ntables, long long rows, int D) {
     if (ntables > MAX_TABLES || !table_rows) return ALM_ERR_BAD_ARG;
     t = OwnTabs{};
     t.n = ntables;
@@ -689,28 +845,36 @@ static int own_tabs(OwnTabs& t, float* const* grad_tables, const int* table_rows
         t.p[i] = grad_tables ? grad_tables[i] : nullptr;
         t.rows[i] = table_rows[i];
         t.small_base[i] = -1;
+        t.lrow_base[i] = -1;
         t.grp_base[i] = ng;
         if (table_rows[i] > 0 && t.nsmall + table_rows[i] <= SMALL_ROWS) { t.small_base[i] = t.nsmall; t.nsmall += table_rows[i]; }
-        else if (table_rows[i] > 0) ng += (table_rows[i] + OWN_G - 1) / OWN_G;
+        else if (table_rows[i] > 0) { ng += (table_rows[i] + OWN_G - 1) / OWN_G; t.lrow_base[i] = t.ltot; t.ltot += table_rows[i]; }
     }
     t.grp_base[ntables] = ng;
     t.nchunks = (int)((rows + OWN_CH - 1) / OWN_CH);
+    static const int hot_env = [] { const char* e = getenv("ALM_EMBED_SCATTER_HOT"); return e ? atoi(e) : 1; }();     // 0: the plain owner path (A/B)
+    pl.small_fl = (long long)t.nchunks * t.nsmall * D;
+    pl.hot = hot_env != 0 && ng > 0 && D > 0 && (D + 1023) / 1024 <= HOT_NY && 2 * rows > HOT_T;
+    pl.hot_fl = pl.hot ? (2 * rows / HOT_PT + 2 * HOT_MAX + 1) * (long long)D : 0;
+    pl.int_fl = pl.hot ? (long long)IW_CNT + ((t.ltot + 3) & ~3) : 0;
     return 0;
 }
 
 extern "C" int alm_embed_scatter_ws_floats(const int* table_rows, int ntables, long long rows, int D) {
     OwnTabs t;
-    if (rows < 0 || rows >= (1LL << 28) || own_tabs(t, nullptr, table_rows, ntables, rows)) return -1;
-    const long long fl = (long long)t.nchunks * t.nsmall * D;
+    OwnPlan pl;
+    if (rows < 0 || rows >= (1LL << 28) || own_tabs(t, pl, nullptr, table_rows, ntables, rows, D)) return -1;
+    const long long fl = pl.small_fl + pl.hot_fl + pl.int_fl;
     return fl > 0x7fffffffLL ? -1 : (int)fl;
 }
 
 extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
                                        float alpha, long long rows, int D, float* ws, void* stream) {
     OwnTabs t;
-    int rc = own_tabs(t, grad_tables, table_rows, ntables, rows);
+    OwnPlan pl;
+    int rc = own_tabs(t, pl, grad_tables, table_rows, ntables, rows, D);
     if (rc) return rc;
-    if (D <= 0 || (D & 3) || rows < 0 || rows >= (1LL << 28) || ((uintptr_t)dout & 15)) return ALM_ERR_BAD_ARG;
+    if (D <= 0 || (D & 3) || rows < 0 || rows >= (1LL << 28) || ((uintptr_t)dout & 15) || ((uintptr_t)ws & 15)) return ALM_ERR_BAD_ARG;
     for (int i = 0; i < ntables; ++i)
         if ((uintptr_t)t.p[i] & 15) return ALM_ERR_BAD_ARG;
     const int ngroups = t.grp_base[ntables];
@@ -722,8 +886,14 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
             }
         return 0;
     }
-    if (t.nsmall > 0 && t.nchunks > 0) {
-        if (!ws) return ALM_ERR_BAD_ARG;
+    if ((pl.small_fl > 0 || pl.hot) && !ws) return ALM_ERR_BAD_ARG;
+    float* const hp = pl.hot ? ws + pl.small_fl : nullptr;
+    int* const iw = pl.hot ? reinterpret_cast<int*>(ws + pl.small_fl + pl.hot_fl) : nullptr;
+    if (pl.hot) {                                      // tickets, counts: zero (the kernels do not clean up after themselves: a fresh workspace per call)
+        hipError_t e = hipMemsetAsync(iw, 0, (size_t)pl.int_fl * sizeof(int), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    if ((t.nsmall > 0 || pl.hot) && t.nchunks > 0) {
         const size_t smem = 2 * OWN_CH * sizeof(int) + (size_t)t.nsmall * 256 * sizeof(float4);       // <= 256 B + 32 x 4 KB
         static bool attr_done = false;
         if (!attr_done) {
@@ -733,11 +903,12 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
             attr_done = true;
         }
         hipLaunchKernelGGL(embed_scatter_small_kernel, dim3((unsigned)t.nchunks, (unsigned)((D + 1023) / 1024)), dim3(256), smem, (hipStream_t)stream, t, src_a,
-                           src_b, dout, alpha, rows, D, ws);
+                           src_b, dout, alpha, rows, D, ws, iw);
     }
+    const int nsplit = pl.hot ? HOT_NSPLIT : 0;
     if (ngroups + t.nsmall > 0)
-        hipLaunchKernelGGL(embed_scatter_owned_kernel, dim3((unsigned)(ngroups + 4 * t.nsmall), (unsigned)((D + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, t,
-                           src_a, src_b, dout, alpha, rows, D, (const float*)ws, ngroups);
+        hipLaunchKernelGGL(embed_scatter_owned_kernel, dim3((unsigned)(nsplit + ngroups + 4 * t.nsmall), (unsigned)((D + 1023) / 1024)), dim3(256), 0,
+                           (hipStream_t)stream, t, src_a, src_b, dout, alpha, rows, D, (const float*)ws, ngroups, nsplit, iw, hp);
     ALM_LAUNCH_CHECK();
     return 0;
 }

@@ -295,7 +295,10 @@ int alm_embed_scatter_add(float* const* grad_tables, const int* table_rows, int 
 /* the same scatter with ONE OWNER per destination row and fixed summation order: no atomics, bitwise run-to-run deterministic gradients (the
  * reference's embedding backward, aten::embedding_dense_backward under audiolm_pytorch.py:709 / :901-918, is not; SURVEY section 5 asks for
  * reproducible runs).  Every row of every table is WRITTEN (zero where no token maps to it): the gradient buffers need no clearing.
- * ws: alm_embed_scatter_ws_floats(...) floats (chunk partials of the few-row tables).  rows < 2^28, D % 4 == 0. */
+ * Skewed ids: destination rows with more than 128 tokens are listed by a histogram (integer atomics: exact) and summed by (row, token-range) workers whose
+ * partials the row's last arriver adds in range order -- the sums stay a fixed function of the code arrays.  ALM_EMBED_SCATTER_HOT=0: owners only (A/B).
+ * ws: alm_embed_scatter_ws_floats(...) floats (chunk partials of the few-row tables + hot-row partials + the listing's int workspace; the call zeroes what
+ * it needs).  rows < 2^28, D % 4 == 0, ws 16-byte aligned. */
 int alm_embed_scatter_ws_floats(const int* table_rows, int ntables, long long rows, int D);
 int alm_embed_scatter_owned(float* const* grad_tables, const int* table_rows, int ntables, const int* src_a, const int* src_b, const float* dout,
                             float alpha, long long rows, int D, float* ws, void* stream);

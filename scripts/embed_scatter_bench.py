@@ -38,9 +38,14 @@ def run(tokens, nsem, ncoarse, D=1024, hot=0.0):
     print(f'{os.path.basename(os.environ.get("ALM_LIB_PATH", "default"))}: tokens {tokens} rows {nsem}+{ncoarse} hot {hot}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us (small + owned launches)', flush=True)
 
 
+if os.environ.get('SCATTER_CASES') == 'headline':
+    run(16384, 501, 3075)
+    sys.exit(0)
 run(16384, 501, 3075)
 run(66024, 501, 12291)
 run(66024, 501, 3075)
 run(16384, 501, 12291)
 run(66024, 501, 12291, hot=0.5)
 run(16384, 501, 3075, hot=0.5)
+run(16384, 501, 3075, hot=0.1)
+run(66024, 501, 12291, hot=0.1)

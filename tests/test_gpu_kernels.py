@@ -969,6 +969,69 @@ def test_embed_scatter_owned_skewed_ids(ops):
     assert float(grads[0].abs().sum() - grads[0][4321].abs().sum()) == 0 and float(grads[1][0].abs().max()) == 0
 
 
+def _scatter_ref_fast(tables, src_a, src_b, dout, alpha):
+    """fp64 scatter by index_add_ (the per-token loop of _scatter_ref is too slow for tens of thousands of tokens)"""
+    refg = [torch.zeros(t.shape, dtype=torch.float64) for t in tables]
+    for src in (src_a.long(), src_b.long()):
+        tb, row = src >> 24, src & 0xffffff
+        for i, g in enumerate(refg):
+            m = (src >= 0) & (tb == i) & (row < g.shape[0])
+            g.index_add_(0, row[m], alpha * dout[m].double())
+    return refg
+
+
+@pytest.mark.parametrize('case', ['four-hot-rows', 'threshold', 'more-hot-rows-than-listed', 'two-column-blocks', 'clustered', 'no-small-table'])
+def test_embed_scatter_owned_hot_rows(ops, case):
+    """skewed ids (round 6): rows with more than 128 tokens are listed by the histogram's last arriver and summed by (row, token-range) workers + a ticketed
+    ordered reduction (csrc/embed_ce.hip, HOT_*).  Against the fp64 scatter and the atomic kernel; written everywhere (NaN garbage before); bitwise run to run."""
+    g = torch.Generator().manual_seed(80)
+    D, rows, nbig, nbig2 = 1024, 20000, 3000, 700
+    if case == 'two-column-blocks':
+        D, rows = 2048, 6000
+    if case == 'more-hot-rows-than-listed':
+        D, rows = 256, 90000
+    a = torch.randint(0, nbig, (rows,), generator=g)
+    b = torch.randint(0, 3, (rows,), generator=g) + (1 << 24)
+    if case in ('four-hot-rows', 'two-column-blocks', 'no-small-table'):
+        m = torch.rand(rows, generator=g) < 0.5
+        a[m] = torch.randint(0, 4, (int(m.sum()),), generator=g) * 7
+        m2 = torch.rand(rows, generator=g) < 0.2                             # the second code array feeds a hot row of a SECOND large table too
+        b[m2] = (2 << 24) | 699
+    elif case == 'threshold':                                                # exactly 128 tokens (not hot), 129 (hot), and one row that takes a third of the batch
+        a[:] = torch.randint(10, nbig, (rows,), generator=g)
+        perm = torch.randperm(rows, generator=g)
+        a[perm[:128]] = 3
+        a[perm[128:257]] = 4
+        a[perm[257:257 + rows // 3]] = 5
+    elif case == 'more-hot-rows-than-listed':                                # 300 rows x 200 tokens: 256 are listed, 44 stay with their owners
+        perm = torch.randperm(rows, generator=g)
+        for r in range(300):
+            a[perm[r * 200:(r + 1) * 200]] = r * 9 + 1
+    elif case == 'clustered':                                                # every hot token inside ONE token range (a long silence): one part does all the work
+        a[4000:9000] = 77
+    src_a, src_b = a.to(torch.int32).to(dev()), b.to(torch.int32).to(dev())
+    dout = rnd(rows, D, seed=81)
+    shapes = [(nbig, D), (3, D), (nbig2, D)]
+    if case == 'no-small-table':
+        shapes = [(nbig, D), (40, D), (nbig2, D)]                            # 40 rows > the 32-row small path: three large tables, no small one
+        src_b = torch.where(src_b >> 24 == 1, torch.full_like(src_b, (1 << 24) | 17), src_b).to(torch.int32)
+    outs = []
+    for _ in range(2):
+        grads = [torch.full(sh, float('nan'), device=dev()) for sh in shapes]
+        assert ops.embed_scatter_owned(grads, src_a, src_b, dout, 0.5, rows, D) is True
+        outs.append(grads)
+    ref = _scatter_ref_fast([torch.empty(sh) for sh in shapes], src_a.cpu(), src_b.cpu(), dout.cpu(), 0.5)
+    for x, r in zip(outs[0], ref):
+        assert bool(torch.isfinite(x).all())
+        scale = float(r.abs().max()) + 1e-30
+        assert float((x.double().cpu() - r).abs().max()) <= 1e-4 * scale, case        # fp32 sums of up to ~10 k terms
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+    grads = [torch.zeros(sh, device=dev()) for sh in shapes]
+    ops.embed_scatter_add(grads, src_a, src_b, dout, 0.5, rows, D)
+    for x, y in zip(outs[0], grads):
+        assert float((x - y).abs().max()) <= 1e-4 * (float(y.abs().max()) + 1e-30)
+
+
 def test_gather_scatter_rows(ops):
     x = rnd(50, 64, seed=55, dtype=BF16)
     idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32, device=dev())
