@@ -68,8 +68,9 @@ SIGNATURES = {
     'alm_value_residual_mix': [_P, _L, _P, _L, _P, _L, _L, _I, _P],
     'alm_kv_grad_pack': [_P, _P, _L, _I, _L, _P, _P, _L, _L, _I, _I, _P],
     'alm_forgetful_mask': [_P, _L, _P, _L, _I, _I, _I, _P],
-    'alm_coarse_prepare': [_P, _L, _P, _L, _I, _I, _I, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P],
-    'alm_semantic_prepare': [_P, _L, _I, _I, _L, _L, _P, _P, _P],
+    'alm_coarse_prepare': [_P, _L, _P, _L, _I, _I, _I, _L, _L, _L, _I, _I, _P, _P, _P, _P, _I, _P],
+    'alm_semantic_prepare': [_P, _L, _I, _I, _L, _L, _P, _P, _I, _P],
+    'alm_unique_consecutive_i64': [_P, _L, _I, _I, _I, _L, _L, _P, _L, _P, _P],
     'alm_fine_prepare': [_P, _L, _P, _L, _I, _I, _I, _L, _L, _I, _I, _I, _P, _P, _P],
     'alm_loss_combine': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _F, _F, _F, _F, _I, _L, _P, _P, _P],
     'alm_mqa_head_groups': [_I],

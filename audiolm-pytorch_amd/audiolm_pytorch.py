@@ -119,6 +119,10 @@ def append_eos_id(ids, eos_id):                               # semantics of aud
 def batch_unique_consecutive(t, pad_value=0.):                # semantics of audiolm_pytorch.py:162-164
     """per row: collapse runs of equal ids; rows are ragged afterwards and right-padded with pad_value to the longest one
     (data-dependent width -> a host loop over the batch, as in the reference)"""
+    if t.is_cuda and t.dtype == torch.int64 and t.dim() == 2 and t.numel() > 0:
+        # one launch + ONE host read of the row lengths (ops.unique_consecutive) instead of a synchronising torch.unique_consecutive per row
+        out, lengths = ops.unique_consecutive(t if t.stride(1) == 1 else t.contiguous(), None, int(pad_value))
+        return out[:, :int(lengths.max())].contiguous()
     rows = [torch.unique_consecutive(row) for row in t]
     out = t.new_full((len(rows), max(r.numel() for r in rows)), pad_value)
     for i, r in enumerate(rows):
@@ -1471,12 +1475,20 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
             assert exists(self.wav2vec), 'VQWav2Vec must be be provided if given raw wave for training'
             semantic_token_ids = self.wav2vec(raw_wave, flatten=False)
         semantic_token_ids = _flatten_ids(semantic_token_ids)
-        if (self.training and return_loss and not self.unique_consecutive and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64
+        if (self.training and return_loss and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64 and semantic_token_ids.numel() > 0
                 and not kwargs and _SEMANTIC_PREPARE):
             # the training step's id bookkeeping as ONE kernel (ops.semantic_prepare: eos appended = the labels, [start | ids] embedding codes), as the
             # Coarse / Fine wrappers have it; every other call pattern takes the ATen formulation below (equality-tested against it)
             sem = semantic_token_ids if semantic_token_ids.stride(1) == 1 else semantic_token_ids.contiguous()
-            labels, src_a = ops.semantic_prepare(sem, self.transformer.eos_id, self.transformer.semantic_embedding.weight.shape[0])
+            rows = self.transformer.semantic_embedding.weight.shape[0]
+            if self.unique_consecutive:
+                # :1536-1539 -- eos appended, runs collapsed, rows right-padded to the longest: one launch + one host read (the width is data-dependent)
+                full, lengths = ops.unique_consecutive(sem, self.transformer.eos_id, self.pad_id)
+                full = full[:, :int(lengths.max())]                                                   # [ids | eos | pad ...]
+                labels, src_a = ops.semantic_prepare(full, self.transformer.eos_id, rows, has_eos=True)
+                sem = full[:, :-1]                                                                     # the input ids (shape only from here on)
+            else:
+                labels, src_a = ops.semantic_prepare(sem, self.transformer.eos_id, rows)
             self_attn_mask = generate_mask_with_prob(sem.shape, self.mask_prob, sem.device) if self.mask_prob > 0. else None
             return self.transformer(ids=sem, text=text, text_embeds=text_embeds, self_attn_mask=self_attn_mask, labels=labels, _src_a=src_a)
         if self.training:
@@ -1586,7 +1598,7 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
             coarse_token_ids = coarse_token_ids.clone()
         semantic_token_ids = _flatten_ids(semantic_token_ids)
         coarse_token_ids = _flatten_ids(coarse_token_ids)
-        if (FUSED_PREPARE and self.training and return_loss and not self.unique_consecutive and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64
+        if (FUSED_PREPARE and self.training and return_loss and semantic_token_ids.is_cuda and semantic_token_ids.dtype == torch.int64
                 and coarse_token_ids.dtype == torch.int64 and 'kv_cache' not in kwargs and 'embed_cache' not in kwargs and 'return_cache' not in kwargs):
             return self._forward_train_fused(semantic_token_ids, coarse_token_ids, text, text_embeds, kwargs)
         if self.training:                                                                         # :1788-1790
@@ -1632,17 +1644,34 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
     def _forward_train_fused(self, sem, coarse, text, text_embeds, kwargs):
         """The training step of forward() (:1785-1854) with its id bookkeeping as ONE kernel (ops.coarse_prepare: eos appended, key mask, zeroed masked ids,
         padded mask, embedding source codes, labels) instead of ~18 small ATen launches; same arithmetic, same RNG consumption (one randn for the
-        forgetful mask).  Taken when the ids are given, unique_consecutive is off and the wrapper is in training mode; everything else runs forward()."""
+        forgetful mask).  Taken when the ids are given and the wrapper is in training mode; everything else runs forward().  unique_consecutive (the
+        reference's default): one more launch collapses the runs of the [ids | eos] rows and ONE host read of the row lengths fixes the data-dependent
+        width and the logit counts of the loss weights -- the reference formulation synchronises once per row."""
         tr = self.transformer
-        sem_labels, coarse_labels, src_a, keep = ops.coarse_prepare(sem if sem.stride(1) == 1 else sem.contiguous(), coarse if coarse.stride(1) == 1 else coarse.contiguous(),
-                                                                    self.pad_id, tr.semantic_eos_id, tr.coarse_eos_id, tr.num_coarse_quantizers, tr.codebook_size)
+        sem = sem if sem.stride(1) == 1 else sem.contiguous()
+        coarse = coarse if coarse.stride(1) == 1 else coarse.contiguous()
+        use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(tr.to_semantic_logits)
+        if self.unique_consecutive and sem.numel() > 0:
+            full, lengths = ops.unique_consecutive(sem, tr.semantic_eos_id, self.pad_id)                  # :1788-1795
+            lens = lengths.tolist()
+            sem = full[:, :max(lens)]                                                                     # [ids | eos | pad ...]
+            sem_labels, coarse_labels, src_a, keep = ops.coarse_prepare(sem, coarse, self.pad_id, tr.semantic_eos_id, tr.coarse_eos_id, tr.num_coarse_quantizers,
+                                                                        tr.codebook_size, sem_has_eos=True)
+            ns = sem.shape[1]
+            n_c, n_s = coarse_labels.numel(), (sum(lens) if use_sem else 0)                               # :1828-1831 (numel / the non-pad semantic labels)
+        else:
+            sem_labels, coarse_labels, src_a, keep = ops.coarse_prepare(sem, coarse, self.pad_id, tr.semantic_eos_id, tr.coarse_eos_id, tr.num_coarse_quantizers,
+                                                                        tr.codebook_size)
+            ns = sem.shape[1] + 1
+            if self.unique_consecutive:                                                                   # (an empty semantic prompt: nothing to collapse)
+                n_c, n_s = coarse_labels.numel(), (sem_labels.numel() if use_sem else 0)
+            else:
+                n_c, n_s = coarse_labels.shape[-1], (sem_labels.shape[-1] if use_sem else 0)
         if self.mask_prob > 0:                                                                    # forgetful causal mask, :1809-1810
             keep = _forgetful_and_(keep, self.mask_prob)
-        use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(tr.to_semantic_logits)
-        n_c, n_s = coarse_labels.shape[-1], (sem_labels.shape[-1] if use_sem else 0)
         w = (n_s * self.semantic_cross_entropy_loss_weight / (n_s + n_c), n_c / (n_s + n_c))    # :1826-1854 with integer logit counts
         return tr(semantic_token_ids=sem, coarse_token_ids=coarse, self_attn_mask=keep, text=text, text_embeds=text_embeds,
-                  labels=(sem_labels, coarse_labels), loss_weights=w, _prepared=(src_a, sem.shape[1] + 1, coarse.shape[1]), **kwargs)
+                  labels=(sem_labels, coarse_labels), loss_weights=w, _prepared=(src_a, ns, coarse.shape[1]), **kwargs)
 
 
 class FineTransformerWrapper(_WrapperBase):                   # audiolm_pytorch.py:1856-2137

@@ -715,6 +715,37 @@ __global__ __launch_bounds__(1024) void loss_combine_kernel(LossGroups g, float*
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// batch_unique_consecutive (reference audiolm_pytorch.py:162-164: per row torch.unique_consecutive, rows right-padded to the longest) as ONE launch and ONE
+// host read instead of a host loop over the batch with a device synchronisation per row.  Workgroup = one row: keep[i] = (i == 0 || id[i] != id[i - 1]),
+// in-order compaction (ballot + prefix count per wave, wave totals through LDS), the tail of the row filled with pad, lengths[b] = kept ids.  append_eos:
+// the row is [ids | eos_id] (append_eos_id :155-160 happens BEFORE the collapse in the wrappers, :1536-1539 / :1788-1795).  out int64 [B][n + append_eos].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unique_consecutive_kernel(const long long* __restrict__ ids, long long ld, int n, int append_eos, long long eos_id,
+                                                                 long long pad, long long* __restrict__ out, long long ld_out, int* __restrict__ lengths) {
+    __shared__ int wsum[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int W = n + (append_eos ? 1 : 0);
+    const long long* row = ids + (long long)blockIdx.x * ld;
+    long long* orow = out + (long long)blockIdx.x * ld_out;
+    auto at = [&](int i) -> long long { return i < n ? row[i] : eos_id; };
+    int base = 0, buf = 0;
+    for (int i0 = 0; i0 < W; i0 += 256, buf ^= 1) {
+        const int i = i0 + t;
+        const long long v = i < W ? at(i) : 0;
+        const bool keep = i < W && (i == 0 || v != at(i - 1));
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[buf][wave] = __popcll(m);
+        __syncthreads();                                                    // (two buffers: the next round's totals do not overwrite the ones still being read)
+        int off = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        for (int w = 0; w < wave; ++w) off += wsum[buf][w];
+        if (keep) orow[off] = v;
+        base += wsum[buf][0] + wsum[buf][1] + wsum[buf][2] + wsum[buf][3];
+    }
+    for (int i = base + t; i < W; i += 256) orow[i] = pad;
+    if (t == 0) lengths[blockIdx.x] = base;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // CoarseTransformerWrapper.forward's id bookkeeping for a training step (audiolm_pytorch.py:1785-1810 + the code arithmetic of :894-918) in ONE launch:
 // append the eos ids, key mask of the semantic ids (pad / eos keys are masked and their ids zeroed), padded mask over the whole sequence, embedding
 // source codes (start tokens, semantic ids, per-quantizer offset coarse rows) and the two label tensors -- ~18 ATen launches of <= 5 us otherwise.
@@ -724,8 +755,9 @@ __global__ __launch_bounds__(256) void coarse_prepare_kernel(const long long* __
                                                              long long ld_coarse, int B, int ns0, int nc0, long long pad_id, long long sem_eos,
                                                              long long coarse_eos, int Q, int C, long long* __restrict__ sem_labels,
                                                              long long* __restrict__ coarse_labels, int* __restrict__ src_a,
-                                                             unsigned char* __restrict__ keep) {
-    const int ns = ns0 + 1, N = ns + nc0 + 2, W = max(N, nc0 + 1);
+                                                             unsigned char* __restrict__ keep, int sem_has_eos) {
+    // sem_has_eos: the semantic rows already are [ids | eos | pad ...] (alm_unique_consecutive_i64 with the eos appended): nothing is appended here
+    const int ns = ns0 + (sem_has_eos ? 0 : 1), N = ns + nc0 + 2, W = max(N, nc0 + 1);
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)B * W; t += (long long)gridDim.x * 256) {
         const int b = (int)(t / W), i = (int)(t % W);
         if (i < N) {
@@ -757,8 +789,8 @@ __global__ __launch_bounds__(256) void coarse_prepare_kernel(const long long* __
 // last position) + the embedding source codes of SemanticTransformer.forward (:709-714: [start token | ids], a negative id = the zero vector, :176-181) in ONE
 // launch -- the cat / ones / cast / cat chain of ~6 ATen launches otherwise.  labels int64 [B][n0 + 1], src_a int32 [B][n0 + 1].
 __global__ __launch_bounds__(256) void semantic_prepare_kernel(const long long* __restrict__ sem, long long ld_sem, int B, int n0, long long eos_id,
-                                                               long long* __restrict__ labels, int* __restrict__ src_a) {
-    const int W = n0 + 1;
+                                                               long long* __restrict__ labels, int* __restrict__ src_a, int has_eos) {
+    const int W = n0 + (has_eos ? 0 : 1);                                      // has_eos: the rows already are [ids | eos | pad ...]: labels = the rows
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < (long long)B * W; t += (long long)gridDim.x * 256) {
         const int b = (int)(t / W), i = (int)(t % W);
         labels[t] = i < n0 ? sem[(long long)b * ld_sem + i] : eos_id;
@@ -1018,22 +1050,34 @@ extern "C" int alm_loss_combine(const float* s0, const float* s1, const float* s
 // (embedding source codes, table << 24 | row), keep bytes [B][N] (torch.bool storage; the forgetful mask is ANDed in afterwards), N = ns0 + nc0 + 3.
 extern "C" int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0,
                                   long long pad_id, long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels,
-                                  long long* coarse_labels, int* src_a, void* keep, void* stream) {
-    if (B <= 0 || ns0 < 0 || nc0 < 0 || Q < 1) return ALM_ERR_BAD_ARG;
-    const long long N = (long long)ns0 + nc0 + 3, W = N > nc0 + 1 ? N : nc0 + 1;
+                                  long long* coarse_labels, int* src_a, void* keep, int sem_has_eos, void* stream) {
+    if (B <= 0 || ns0 < 0 || nc0 < 0 || Q < 1 || (sem_has_eos && ns0 < 1)) return ALM_ERR_BAD_ARG;
+    const long long N = (long long)ns0 + nc0 + 3 - (sem_has_eos ? 1 : 0), W = N > nc0 + 1 ? N : nc0 + 1;
     if ((long long)(Q - 1) * C + C + 1 >= (1 << 24) || B * W >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(coarse_prepare_kernel, dim3(grid_for(B * W)), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, coarse, ld_coarse, B, ns0, nc0, pad_id,
-                       sem_eos, coarse_eos, Q, C, sem_labels, coarse_labels, src_a, (unsigned char*)keep);
+                       sem_eos, coarse_eos, Q, C, sem_labels, coarse_labels, src_a, (unsigned char*)keep, sem_has_eos);
     ALM_LAUNCH_CHECK();
     return 0;
 }
 
 /* see semantic_prepare_kernel.  sem int64 [B][n0] (row stride ld_sem) */
 extern "C" int alm_semantic_prepare(const long long* sem, long long ld_sem, int B, int n0, long long eos_id, long long num_rows, long long* labels, int* src_a,
-                                    void* stream) {
-    if (B <= 0 || n0 < 0 || !labels || !src_a || (n0 > 0 && !sem)) return ALM_ERR_BAD_ARG;
+                                    int has_eos, void* stream) {
+    if (B <= 0 || n0 < 0 || !labels || !src_a || (n0 > 0 && !sem) || (has_eos && n0 < 1)) return ALM_ERR_BAD_ARG;
     if (num_rows >= (1 << 24) || (long long)B * (n0 + 1) >= 0x7fffffffLL) return ALM_ERR_UNSUPPORTED;      // (the table id lives in bits 24+ of a source code)
-    hipLaunchKernelGGL(semantic_prepare_kernel, dim3(grid_for((long long)B * (n0 + 1))), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, B, n0, eos_id, labels, src_a);
+    hipLaunchKernelGGL(semantic_prepare_kernel, dim3(grid_for((long long)B * (n0 + 1))), dim3(256), 0, (hipStream_t)stream, sem, ld_sem, B, n0, eos_id, labels, src_a,
+                       has_eos);
+    ALM_LAUNCH_CHECK();
+    return 0;
+}
+
+/* see unique_consecutive_kernel.  ids int64 [B][n] (row stride ld), out int64 [B][n + append_eos] (row stride ld_out), lengths int32 [B] */
+extern "C" int alm_unique_consecutive_i64(const long long* ids, long long ld, int B, int n, int append_eos, long long eos_id, long long pad, long long* out,
+                                          long long ld_out, int* lengths, void* stream) {
+    if (B < 0 || n < 0 || !lengths || (n > 0 && !ids) || ld_out < n + (append_eos ? 1 : 0)) return ALM_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (n + (append_eos ? 1 : 0) > 0 && !out) return ALM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(unique_consecutive_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ids, ld, n, append_eos ? 1 : 0, eos_id, pad, out, ld_out, lengths);
     ALM_LAUNCH_CHECK();
     return 0;
 }

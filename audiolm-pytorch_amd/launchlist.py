@@ -30,6 +30,7 @@ from . import _lib, ops
 
 ENABLED = os.environ.get('ALM_LAUNCH_LIST', '1') != '0'
 MAX_ARENA_BYTES = int(float(os.environ.get('ALM_LAUNCH_LIST_MAX_GB', '24')) * (1 << 30))    # per pass; larger steps keep the eager path (frees as it goes)
+MAX_PLANS = max(1, int(os.environ.get('ALM_LAUNCH_LIST_MAX_PLANS', '64')))                   # recorded (configuration, shape) keys kept; least recently used dropped
 ALIGN = 256
 LITERAL, STREAM, HOST_PTRS, HOST_INTS = 0, 0xFFFF, 0xFFFE, 0xFFFD
 _P, _I, _L, _F, _U = _lib._P, _lib._I, _lib._L, _lib._F, _lib._U
@@ -285,9 +286,12 @@ def plan_for(core, x, mask_u8, cfg, need, bias, nflat, defer, dx_scale):
     dev = x.device
     key = (dev.index, ops._st(), tuple(x.shape), need, mask_u8 is None, None if bias is None else int(bias.tbl.shape[1]), dataclasses.astuple(cfg), nflat,
            bool(defer), float(dx_scale), _switches(core))
-    plan = PLANS.get(key)
+    plan = PLANS.pop(key, None)
     if plan is None:
-        plan = PLANS[key] = Plan(key)
+        plan = Plan(key)
+        while len(PLANS) >= MAX_PLANS:                   # least recently used first (a dict keeps insertion order; a hit is re-inserted below): data-dependent
+            PLANS.pop(next(iter(PLANS)))                 # sequence lengths (unique_consecutive, ragged batches) would otherwise grow the table without bound
+    PLANS[key] = plan
     return None if plan.state == 'off' else plan
 
 

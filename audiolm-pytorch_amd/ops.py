@@ -448,33 +448,53 @@ def loss_combine(sums, labels, weights, ignore_index=-1):
     return loss, scales
 
 
-def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C):
-    """sem int64 [B, ns0], coarse int64 [B, nc0] (flattened (n q)) -> (sem_labels [B, ns0+1], coarse_labels [B, nc0+1], src_a int32 [B, N],
-    keep bool [B, N]) with N = ns0 + nc0 + 3: CoarseTransformerWrapper's training-step id bookkeeping (C ABI: alm_coarse_prepare)."""
+def coarse_prepare(sem, coarse, pad_id, sem_eos, coarse_eos, Q, C, sem_has_eos=False):
+    """sem int64 [B, ns0], coarse int64 [B, nc0] (flattened (n q)) -> (sem_labels [B, ns], coarse_labels [B, nc0+1], src_a int32 [B, N],
+    keep bool [B, N]) with ns = ns0 + 1, N = ns + nc0 + 2: CoarseTransformerWrapper's training-step id bookkeeping (C ABI: alm_coarse_prepare).
+    sem_has_eos: the rows of `sem` already are [ids | eos | pad ...] (unique_consecutive): ns = ns0."""
     _chk(sem, torch.int64), _chk(coarse, torch.int64)
     assert sem.dim() == 2 and coarse.dim() == 2 and sem.stride(1) == 1 and coarse.stride(1) == 1 and sem.shape[0] == coarse.shape[0]
     B, ns0 = sem.shape
     nc0 = coarse.shape[1]
-    N, dev = ns0 + nc0 + 3, sem.device
-    sl = _new((B, ns0 + 1), dtype=torch.int64, device=dev)
+    ns = ns0 + (0 if sem_has_eos else 1)
+    N, dev = ns + nc0 + 2, sem.device
+    sl = _new((B, ns), dtype=torch.int64, device=dev)
     cl = _new((B, nc0 + 1), dtype=torch.int64, device=dev)
     src_a = _new((B, N), dtype=torch.int32, device=dev)
     keep = _new((B, N), dtype=torch.bool, device=dev)
     _lib.call('alm_coarse_prepare', sem.data_ptr(), sem.stride(0), coarse.data_ptr(), coarse.stride(0), B, ns0, nc0, int(pad_id), int(sem_eos), int(coarse_eos),
-              int(Q), int(C), sl.data_ptr(), cl.data_ptr(), src_a.data_ptr(), keep.data_ptr(), _st())
+              int(Q), int(C), sl.data_ptr(), cl.data_ptr(), src_a.data_ptr(), keep.data_ptr(), 1 if sem_has_eos else 0, _st())
     return sl, cl, src_a, keep
 
 
-def semantic_prepare(sem, eos_id, num_rows):
+def semantic_prepare(sem, eos_id, num_rows, has_eos=False):
     """sem int64 [B, n0] -> (labels int64 [B, n0 + 1] = [ids | eos], src_a int32 [B, n0 + 1] = [start token | ids]): SemanticTransformerWrapper's training-step
-    id bookkeeping + SemanticTransformer's embedding source codes (C ABI: alm_semantic_prepare)."""
+    id bookkeeping + SemanticTransformer's embedding source codes (C ABI: alm_semantic_prepare).  has_eos: the rows already are [ids | eos | pad ...]
+    (unique_consecutive): labels [B, n0] = the rows, src_a [B, n0] = [start token | rows without their last column]."""
     _chk(sem, torch.int64)
     assert sem.dim() == 2 and (sem.shape[1] == 0 or sem.stride(1) == 1)
     B, n0 = sem.shape
-    labels = _new((B, n0 + 1), dtype=torch.int64, device=sem.device)
-    src_a = _new((B, n0 + 1), dtype=torch.int32, device=sem.device)
-    _lib.call('alm_semantic_prepare', sem.data_ptr(), sem.stride(0), B, n0, int(eos_id), int(num_rows), labels.data_ptr(), src_a.data_ptr(), _st())
+    W = n0 + (0 if has_eos else 1)
+    labels = _new((B, W), dtype=torch.int64, device=sem.device)
+    src_a = _new((B, W), dtype=torch.int32, device=sem.device)
+    _lib.call('alm_semantic_prepare', sem.data_ptr(), sem.stride(0), B, n0, int(eos_id), int(num_rows), labels.data_ptr(), src_a.data_ptr(), 1 if has_eos else 0, _st())
     return labels, src_a
+
+
+def unique_consecutive(ids, eos_id=None, pad=-1):
+    """ids int64 [B, n] -> (out int64 [B, n + e], lengths int32 [B]): every row with its runs of equal ids collapsed, followed by `pad`; e = 1 and the rows
+    are [ids | eos_id] when eos_id is given (C ABI: alm_unique_consecutive_i64; reference batch_unique_consecutive, audiolm_pytorch.py:162-164, after
+    append_eos_id).  The caller reads `lengths` once and slices out[:, :max]."""
+    _chk(ids, torch.int64)
+    assert ids.dim() == 2 and (ids.shape[1] == 0 or ids.stride(1) == 1)
+    B, n = ids.shape
+    W = n + (0 if eos_id is None else 1)
+    out = _new((B, W), dtype=torch.int64, device=ids.device)
+    lengths = _new((B,), dtype=torch.int32, device=ids.device)
+    if B:
+        _lib.call('alm_unique_consecutive_i64', ids.data_ptr(), ids.stride(0), B, n, 0 if eos_id is None else 1, 0 if eos_id is None else int(eos_id), int(pad),
+                  out.data_ptr(), W, lengths.data_ptr(), _st())
+    return out, lengths
 
 
 def fine_prepare(coarse, fine, nf, pad_id, eos_id, Qc, Qf, C):

@@ -217,15 +217,24 @@ int alm_loss_combine(const float* s0, const float* s1, const float* s2, const fl
 
 /* CoarseTransformerWrapper.forward's id bookkeeping of a training step, audiolm_pytorch.py:1785-1810 (append eos, key mask of pad / eos semantic keys,
  * their ids zeroed, mask padded over [start | semantic | coarse start | coarse]) + the embedding source codes of :894-918 (start tokens, semantic ids,
- * coarse rows id + (i mod Q) * codebook_size) + the label tensors (ids with the eos appended), in one launch.  N = ns0 + nc0 + 3. */
+ * coarse rows id + (i mod Q) * codebook_size) + the label tensors (ids with the eos appended), in one launch.  N = ns0 + nc0 + 3.
+ * sem_has_eos != 0: the semantic rows already are [ids | eos | pad ...] (alm_unique_consecutive_i64, unique_consecutive = True, :1794-1795): nothing is
+ * appended to them, sem_labels is [B][ns0] and N = ns0 + nc0 + 2. */
 int alm_coarse_prepare(const long long* sem, long long ld_sem, const long long* coarse, long long ld_coarse, int B, int ns0, int nc0, long long pad_id,
                        long long sem_eos, long long coarse_eos, int Q, int C, long long* sem_labels, long long* coarse_labels, int* src_a, void* keep,
-                       void* stream);
+                       int sem_has_eos, void* stream);
 /* SemanticTransformerWrapper.forward's id bookkeeping of a training step, audiolm_pytorch.py:1536-1548 (`append_eos_id`, input ids = ids[:, :-1]) + the
  * embedding source codes of SemanticTransformer.forward :709-714 ([start token | ids]; a negative id is the zero vector, :176-181) in one launch.
- * sem int64 [B][n0]; labels int64 [B][n0 + 1] = [ids | eos]; src_a int32 [B][n0 + 1] = [start | ids]; num_rows = rows of the embedding table (< 2^24). */
+ * sem int64 [B][n0]; labels int64 [B][n0 + 1] = [ids | eos]; src_a int32 [B][n0 + 1] = [start | ids]; num_rows = rows of the embedding table (< 2^24).
+ * has_eos != 0: the rows already are [ids | eos | pad ...]: labels [B][n0] = the rows, src_a [B][n0] = [start | rows without their last column]. */
 int alm_semantic_prepare(const long long* sem, long long ld_sem, int B, int n0, long long eos_id, long long num_rows, long long* labels, int* src_a,
-                         void* stream);
+                         int has_eos, void* stream);
+/* batch_unique_consecutive, audiolm_pytorch.py:162-164 (per row torch.unique_consecutive, right-padded with `pad` to the longest row), as one launch:
+ * out int64 [B][n + append_eos] holds every collapsed row followed by pad, lengths int32 [B] the kept ids per row -- the caller reads the lengths ONCE and
+ * slices out[:, :max(lengths)] (the reference's host loop synchronises per row).  append_eos != 0: the rows are [ids | eos_id] (append_eos_id :155-160, which
+ * the wrappers apply before the collapse, :1536-1539 / :1788-1795). */
+int alm_unique_consecutive_i64(const long long* ids, long long ld, int B, int n, int append_eos, long long eos_id, long long pad, long long* out,
+                               long long ld_out, int* lengths, void* stream);
 /* FineTransformer.forward's id bookkeeping, audiolm_pytorch.py:1171-1223 (key mask of pad / eos coarse keys, their ids zeroed, mask padded over
  * [coarse start | coarse | fine start | fine], embedding source codes id + (i mod Q) * codebook_size per table) in one launch.  fine: the first nf ids of
  * each row (the training wrapper drops the last one, :2086).  src_a int32 [B][n + nf + 2], keep bool [B][n + nf + 2]. */

@@ -1257,6 +1257,86 @@ def test_semantic_wrapper_training_step_same_loss_and_gradients_with_and_without
     assert res[0][1].keys() == res[1][1].keys() and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
 
 
+@pytest.mark.parametrize('B,n,eos', [(1, 1, None), (3, 40, 50), (4, 255, None), (2, 256, 50), (5, 257, 50), (8, 1500, 50), (2, 3000, None), (3, 0, 50)])
+def test_unique_consecutive_kernel_matches_torch_per_row(ops, B, n, eos):
+    """alm_unique_consecutive_i64 == the reference's batch_unique_consecutive (audiolm_pytorch.py:162-164: torch.unique_consecutive per row, right-padded)
+    applied after append_eos_id: collapsed rows, pad tail, row lengths; strided input rows; runs that cross the 256-id rounds of the kernel"""
+    g = torch.Generator().manual_seed(31 * B + n)
+    wide = torch.randint(0, 50, (B, n + 2), generator=g)
+    for _ in range(3):                                                   # runs: ~40 % of the positions repeat their predecessor (up to 4 long)
+        m = torch.rand(B, n + 2, generator=g) < 0.4
+        wide[:, 1:] = torch.where(m[:, 1:], wide[:, :-1], wide[:, 1:])
+    if n > 300:
+        wide[0, 250:262] = 7                                             # one run across a round boundary
+        wide[1 % B, :n] = 3                                              # a whole row collapses to one id
+    ids = wide.to(dev())[:, :n]                                          # row stride n + 2
+    out, lengths = ops.unique_consecutive(ids, eos, -1)
+    rows = []
+    for r in ids.cpu():
+        if eos is not None:
+            r = torch.cat((r, torch.tensor([eos])))
+        rows.append(torch.unique_consecutive(r))
+    assert lengths.cpu().tolist() == [r.numel() for r in rows]
+    W = n + (eos is not None)
+    assert out.shape == (B, W)
+    for b, r in enumerate(rows):
+        assert torch.equal(out[b, :r.numel()].cpu(), r)
+        assert bool((out[b, r.numel():] == -1).all())
+
+
+def test_prepare_kernels_on_rows_that_already_hold_their_eos(ops):
+    """sem_has_eos / has_eos (unique_consecutive = True): coarse_prepare / semantic_prepare on [ids | eos | pad ...] rows == the ATen bookkeeping of the
+    wrappers on those rows (CoarseTransformerWrapper.forward :1797-1806 + _assemble; SemanticTransformerWrapper.forward :1541-1548 + _tokens)"""
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    g = torch.Generator().manual_seed(9)
+    B, L, nf, Q, C, n_sem = 3, 17, 5, 3, 64, 50
+    sem = torch.randint(0, n_sem, (B, L + 2), generator=g)
+    for b, ln in enumerate((17, 9, 1)):                                  # row b: ln - 1 ids, the eos, pads
+        sem[b, ln - 1] = n_sem
+        sem[b, ln:] = -1
+    coarse = torch.randint(0, C, (B, nf * Q), generator=g).to(dev())
+    sem = sem.to(dev())[:, :L]                                           # row stride L + 2
+    sl, cl, src_a, keep = ops.coarse_prepare(sem, coarse, -1, n_sem, C, Q, C, sem_has_eos=True)
+    assert torch.equal(sl, sem) and torch.equal(cl, AP.append_eos_id(coarse, C))
+    mask = (sem != -1) & (sem != n_sem)
+    assert torch.equal(keep, F.pad(mask, (1, coarse.shape[1] + 1), value=True))
+    rows = coarse.to(torch.int32) + AP._quantizer_row_offsets(coarse.shape[1], Q, C, sem.device)
+    ref = torch.cat((AP._const_code(3, B, sem.device), sem.masked_fill(~mask, 0).to(torch.int32), AP._const_code(4, B, sem.device), AP._code(1, rows)), dim=1)
+    assert torch.equal(src_a, ref)
+    labels, src = ops.semantic_prepare(sem, n_sem, n_sem + 1, has_eos=True)
+    assert torch.equal(labels, sem)
+    assert torch.equal(src, torch.cat((AP._const_code(1, B, sem.device), sem[:, :-1].to(torch.int32).clamp(min=-1)), dim=1))
+
+
+def test_semantic_wrapper_unique_consecutive_training_step_fused_equals_unfused(monkeypatch):
+    """unique_consecutive = True (the reference's default): the fused path (one collapse launch + one host read + ops.semantic_prepare) == the ATen path
+    (append_eos_id, batch_unique_consecutive, slicing): loss and every gradient bit for bit"""
+    import audiolm_pytorch_amd as A
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    torch.manual_seed(0)
+    model = A.SemanticTransformer(num_semantic_tokens=50, dim=128, depth=2, flash_attn=True).to(dev())
+    w = A.SemanticTransformerWrapper(transformer=model, unique_consecutive=True, mask_prob=0.15)
+    w.train()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 50, (3, 40), generator=g)
+    ids[0, 10:25] = 4                                                    # runs: the rows collapse to different lengths
+    ids[1, 1::2] = ids[1, 0::2]
+    ids = ids.to(dev())
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(AP, '_SEMANTIC_PREPARE', on)
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(123)
+        loss = w(semantic_token_ids=ids, return_loss=True)
+        loss.backward()
+        res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
+    assert res[0][1].keys() == res[1][1].keys() and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+    # and the host formulation of the collapse itself (a CPU tensor takes the per-row torch.unique_consecutive loop)
+    assert torch.equal(AP.batch_unique_consecutive(ids, pad_value=-1).cpu(), AP.batch_unique_consecutive(ids.cpu(), pad_value=-1))
+
+
 @pytest.mark.parametrize('nh', [2, 4])
 def test_mqa_attention_backward_with_either_dkv_workgroup_shape(nh):
     """round 6: the dK/dV kernel runs 4 heads per workgroup (N < 8192) or 2 (two workgroups per CU, H / 2 partial sets: alm_mqa_bwd_parts); the choice is a

@@ -525,6 +525,46 @@ def test_coarse_wrapper_fused_training_bookkeeping_equals_the_unfused_path():
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max().clamp(min=1e-30)), k      # (the embedding scatter adds atomically: order-dependent last bits)
 
 
+def test_coarse_wrapper_unique_consecutive_fused_equals_the_unfused_path():
+    """unique_consecutive = True (the reference's default, audiolm_pytorch.py:1794-1795, :1828-1831): _forward_train_fused with the collapse kernel, ONE host
+    read of the row lengths and integer logit counts == forward()'s ATen bookkeeping with its tensor-valued loss weights -- rows that collapse to
+    different lengths (pads inside the semantic segment), the forgetful mask replayed"""
+    import audiolm_pytorch_amd as A
+    import audiolm_pytorch_amd.audiolm_pytorch as AP
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+
+    class Codec:
+        rq_groups = 1
+        num_quantizers = 8
+    model = A.CoarseTransformer(dim=128, depth=2, num_semantic_tokens=50, codebook_size=64, num_coarse_quantizers=3, flash_attn=True).to(dev)
+    w = A.CoarseTransformerWrapper(transformer=model, codec=Codec(), unique_consecutive=True, mask_prob=0.15, semantic_cross_entropy_loss_weight=0.7)
+    w.train()
+    g = torch.Generator().manual_seed(4)
+    sem = torch.randint(0, 50, (3, 40), generator=g)
+    sem[0, 5:30] = 11                                                         # a long run: row 0 collapses to 16 ids
+    sem[2, 1::2] = sem[2, 0::2]                                               # pairs: row 2 collapses to ~20
+    coarse = torch.randint(0, 64, (3, 20, 3), generator=g)
+    sem, coarse = sem.to(dev), coarse.to(dev)
+    losses = []
+    for fused in (True, False):
+        AP.FUSED_PREPARE = fused
+        try:
+            torch.manual_seed(123)                                            # the same forgetful draw
+            for p in model.parameters():
+                p.grad = None
+            loss = w(semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True)
+            loss.backward()
+            losses.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            AP.FUSED_PREPARE = True
+    assert abs(losses[0][0] - losses[1][0]) <= 2e-6 * abs(losses[1][0]), (losses[0][0], losses[1][0])     # (the weighted combination: one kernel vs tensor ops)
+    assert losses[0][1].keys() == losses[1][1].keys()
+    for k in losses[0][1]:
+        a, b = losses[0][1][k], losses[1][1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max().clamp(min=1e-30)), k
+
+
 def test_fine_fused_id_bookkeeping_equals_the_unfused_path():
     """FineTransformer._assemble with ops.fine_prepare (key mask of pad / eos coarse ids, zeroed ids, padded mask, embedding source codes: one kernel,
     round 4) vs the ATen formulation: identical source codes and key mask, identical loss -- pad and eos ids inside the coarse rows, a caller-supplied

@@ -113,3 +113,32 @@ def test_arena_layout_matches_the_tally():
     spec = LL._spec(outs[0], a, LL.Recorder([], 0))
     again = LL._rebuild(spec, {torch.float32: a.buf.view(torch.float32)})
     assert again.data_ptr() == outs[0].data_ptr() and again.shape == outs[0].shape
+
+
+def test_plan_table_is_bounded_least_recently_used(monkeypatch):
+    """data-dependent sequence lengths (unique_consecutive, ragged batches) meet a new (configuration, shape) key almost every step: the table keeps the
+    MAX_PLANS most recently used plans; a plan that is still referenced by a forward in flight survives its eviction as an object"""
+    import dataclasses
+    import types
+
+    from audiolm_pytorch_amd import ops
+
+    @dataclasses.dataclass
+    class Cfg:
+        depth: int = 2
+
+    core = types.SimpleNamespace(**{k: 0 for k in ('QKV_GROUP', 'QKV_GROUP_MAX_M', 'ASYNC_KV', 'DEFER_WGRAD', 'DEFER_GROUPS', 'DEFER_GROUP_SIZES', 'DEFER_MAX_BYTES',
+                                                   'HC_BATCH_FINISH', 'PACK_ALL', 'ASYNC_WGRAD', 'SIDE_STREAMS')})
+    monkeypatch.setattr(ops, '_st', lambda: 0)
+    monkeypatch.setattr(LL, 'PLANS', {})
+    monkeypatch.setattr(LL, 'MAX_PLANS', 4)
+    monkeypatch.setattr(LL, 'ENABLED', True)
+    plans = [LL.plan_for(core, torch.empty((1, n, 8)), None, Cfg(), True, None, 10, False, 1.0) for n in range(1, 7)]
+    assert len(LL.PLANS) == 4 and all(p is not None for p in plans)
+    assert [k[2][1] for k in LL.PLANS] == [3, 4, 5, 6]                       # the two oldest shapes were dropped
+    again = LL.plan_for(core, torch.empty((1, 3, 8)), None, Cfg(), True, None, 10, False, 1.0)
+    assert again is plans[2] and [k[2][1] for k in LL.PLANS] == [4, 5, 6, 3]    # a hit becomes the most recent
+    LL.plan_for(core, torch.empty((1, 9, 8)), None, Cfg(), True, None, 10, False, 1.0)
+    assert [k[2][1] for k in LL.PLANS] == [5, 6, 3, 9]
+    fresh = LL.plan_for(core, torch.empty((1, 1, 8)), None, Cfg(), True, None, 10, False, 1.0)
+    assert fresh is not plans[0] and fresh.state == 'size'                     # an evicted key starts over
