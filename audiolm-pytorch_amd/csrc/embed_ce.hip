@@ -867,6 +867,11 @@ extern "C" int alm_embed_scatter_add(float* const* grad_tables, const int* table
 // Deterministic form of the scatter (no float atomics; every row of every table is written).  ws: alm_embed_scatter_ws_floats(...) fp32 floats:
 // [chunk partials of the few-row tables][partials of the (hot row, part) items][the int workspace of the hot-row listing].
 // Limits: rows < 2^28 (the pending entries pack a 3-bit local row + a 28-bit token row), D % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void zero_ints_kernel(int4* __restrict__ p, int n4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_int4(0, 0, 0, 0);
+}
+
 struct OwnPlan { long long small_fl, hot_fl, int_fl; bool hot; };
 static int own_tabs(OwnTabs& t, OwnPlan& pl, float* const* grad_tables, const int* table_rows, int ntables, long long rows, int D) {
     if (ntables > MAX_TABLES || !table_rows) return ALM_ERR_BAD_ARG;
@@ -921,10 +926,12 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
     if ((pl.small_fl > 0 || pl.hot) && !ws) return ALM_ERR_BAD_ARG;
     float* const hp = pl.hot ? ws + pl.small_fl : nullptr;
     int* const iw = pl.hot ? reinterpret_cast<int*>(ws + pl.small_fl + pl.hot_fl) : nullptr;
-    if (pl.hot) {                                      // tickets, counts: zero (the kernels do not clean up after themselves: a fresh workspace per call)
-        hipError_t e = hipMemsetAsync(iw, 0, (size_t)pl.int_fl * sizeof(int), (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-    }
+    // tickets, counts: zero (the kernels do not clean up after themselves: a fresh workspace per call).  A KERNEL, not hipMemsetAsync: captured into a hipGraph
+    // (graphed.GraphedTrainStep) the memset node left the workspace uncleared on replay -- the listing then read the previous replay's leftovers and the step
+    // faulted (tests/test_gpu_graphed.py found it); a kernel node replays like every other launch of the step
+    if (pl.hot)
+        hipLaunchKernelGGL(zero_ints_kernel, dim3((unsigned)((pl.int_fl / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<int4*>(iw),
+                           (int)(pl.int_fl / 4));
     if ((t.nsmall > 0 || pl.hot) && t.nchunks > 0) {
         const size_t smem = 2 * OWN_CH * sizeof(int) + (size_t)t.nsmall * 256 * sizeof(float4);       // <= 256 B + 32 x 4 KB
         static bool attr_done = false;
