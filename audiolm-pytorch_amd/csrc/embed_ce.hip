@@ -918,8 +918,8 @@ extern "C" int alm_embed_scatter_owned(float* const* grad_tables, const int* tab
     if (rows == 0) {                                   // nothing maps anywhere: every table's gradient is zero (the scan below assumes at least one code)
         for (int i = 0; i < ntables; ++i)
             if (t.rows[i] > 0) {
-                hipError_t e = hipMemsetAsync(t.p[i], 0, (size_t)t.rows[i] * D * sizeof(float), (hipStream_t)stream);
-                if (e != hipSuccess) return (int)e;
+                const int e = alm_memset_zero(t.p[i], (long long)t.rows[i] * D * (long long)sizeof(float), stream);
+                if (e != 0) return e;
             }
         return 0;
     }

@@ -1555,7 +1555,8 @@ void launch_bwd_w(const HcBwdArgs& a, hipStream_t st) {
     if (WIDTH && a.partial) {
         const int rows_used = (4 / WPT) * grid;
         const long long P = (long long)a.D * (S + 3) + S * (S + 1) + S + 2;
-        if (rows_used < rows_alloc) (void)hipMemsetAsync(a.partial + (long long)rows_used * P, 0, (size_t)(rows_alloc - rows_used) * P * sizeof(float), st);
+        // (alm_memset_zero is a kernel: a small hipMemsetAsync node of a captured hipGraph does not clear its buffer on replay, csrc/launchlist.hip)
+        if (rows_used < rows_alloc) (void)alm_memset_zero(a.partial + (long long)rows_used * P, (long long)(rows_alloc - rows_used) * P * (long long)sizeof(float), (void*)st);
     }
     if constexpr (sizeof(RT) == 2) {
         if (bc == 0) { hipLaunchKernelGGL((hc_bwd_kernel<RT, S, WPT, WIDTH, DEPTH, LNF, true, 0>), dim3(grid), dim3(256), 0, st, a); return; }

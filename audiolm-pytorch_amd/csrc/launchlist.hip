@@ -48,6 +48,20 @@ struct Op {
 #define ALM_OP(fn) {#fn, arity(fn), [](const uint64_t* a) -> int { return call_packed(fn, a); }}
 
 // every entry: all pointer arguments are DEVICE pointers (or host arrays the recorder knows how to rebuild: alm_hc_param_grads_batched), the LAST argument is the stream
+// zero [p, p + n): 16-byte stores over the aligned middle (grid-stride), single bytes at the two ragged ends
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* __restrict__ p, long long n) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const long long head = (long long)((16 - (a & 15)) & 15) < n ? (long long)((16 - (a & 15)) & 15) : n;     // bytes before the first 16-byte boundary
+    const long long nvec = (n - head) / 16;
+    uint4* v = reinterpret_cast<uint4*>(p + head);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) v[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0) {
+        if ((long long)threadIdx.x < head) p[threadIdx.x] = 0;
+        const long long tail0 = head + nvec * 16;
+        if (tail0 + threadIdx.x < n && threadIdx.x < 16) p[tail0 + threadIdx.x] = 0;
+    }
+}
+
 const Op OPS[] = {
     ALM_OP(alm_memset_zero),
     ALM_OP(alm_gemm_bf16_nt),
@@ -85,10 +99,16 @@ constexpr int NOPS = (int)(sizeof(OPS) / sizeof(OPS[0]));
 
 extern "C" {
 
+// A KERNEL, not hipMemsetAsync: captured into a hipGraph, a small memset node does not clear its buffer on the second and later replays on this ROCm (16 B and
+// 10 KB: garbage; 1 MB: fine -- scripts/debug/memset_node_probe.py, profiles/r6u_memset_node_probe.log); a kernel node replays like every other launch.
 int alm_memset_zero(void* ptr, long long bytes, void* stream) {
     if (bytes < 0 || (bytes > 0 && ptr == nullptr)) return ALM_ERR_BAD_ARG;
     if (bytes == 0) return 0;
-    return (int)hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);
+    const long long chunks = (bytes + 15) / 16 + 1;                       // (+1: an unaligned start spills into one more 16-byte chunk)
+    const long long blocks = (chunks + 255) / 256;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks < 65535 * 16 ? blocks : 65535 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned char*>(ptr), bytes);
+    return (int)hipGetLastError();
 }
 
 int alm_list_op_id(const char* name) {

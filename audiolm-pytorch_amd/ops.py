@@ -67,7 +67,7 @@ def _new_like(t):
 
 
 def memset_zero(t):
-    """hipMemsetAsync(0) over a contiguous tensor on the current stream (C ABI: alm_memset_zero)"""
+    """zero-fill of a contiguous tensor on the current stream by a kernel (C ABI: alm_memset_zero; not hipMemsetAsync: its small graph nodes replay wrongly)"""
     assert t.is_contiguous()
     _lib.call('alm_memset_zero', t.data_ptr(), t.numel() * t.element_size(), _st())
     return t

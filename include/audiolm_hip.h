@@ -417,7 +417,7 @@ int alm_local_attn(const float* qkv, const float* q_scale, const float* k_scale,
  *   reloc[i]   = ALM_LIST_LITERAL: slots[i] as is;  1 .. nbases: bases[reloc - 1] + slots[i];  ALM_LIST_STREAM: the `stream` argument;
  *                ALM_LIST_HOST_PTRS: a HOST array of pointers = the resolved slots starting at index slots[i];  ALM_LIST_HOST_INTS: a HOST array of ints
  *                packed into the slots starting at index slots[i] (alm_hc_param_grads_batched takes both)
- * Returns 0, or the first failing launch's code with its index in *failed_at (launches before it were issued).  alm_memset_zero = hipMemsetAsync(ptr, 0). */
+ * Returns 0, or the first failing launch's code with its index in *failed_at (launches before it were issued).  alm_memset_zero: zero-fill by a kernel (a small hipMemsetAsync node of a captured hipGraph is not replayed correctly on ROCm 7.0: scripts/debug/memset_node_probe.py). */
 typedef struct { int op; int nargs; int first; int reserved; } AlmListEntry;
 #define ALM_LIST_LITERAL 0
 #define ALM_LIST_STREAM 0xFFFF

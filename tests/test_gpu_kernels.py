@@ -1032,6 +1032,31 @@ def test_embed_scatter_owned_hot_rows(ops, case):
         assert float((x - y).abs().max()) <= 1e-4 * (float(y.abs().max()) + 1e-30)
 
 
+@pytest.mark.parametrize('nbytes,offset', [(1, 0), (15, 1), (16, 0), (17, 3), (4096, 0), (10260, 4), (1 << 20, 0), ((1 << 20) + 5, 7)])
+def test_memset_zero_is_a_kernel_with_ragged_ends_and_survives_graph_replay(ops, nbytes, offset):
+    """alm_memset_zero zero-fills exactly [ptr, ptr + bytes) -- unaligned start, ragged tail, neighbours untouched -- and, captured into a hipGraph, clears on
+    EVERY replay (a small hipMemsetAsync node does not on ROCm 7.0: scripts/debug/memset_node_probe.py; the owned embedding scatter and hc_bwd rely on this)"""
+    buf = torch.full((nbytes + 64,), 0x5a, dtype=torch.uint8, device=dev())
+    view = buf[offset:offset + nbytes]
+    ops.memset_zero(view)
+    assert int(view.max()) == 0 and bool((buf[:offset] == 0x5a).all()) and bool((buf[offset + nbytes:] == 0x5a).all())
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        buf.fill_(7); ops.memset_zero(view); view.add_(1)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        buf.fill_(7)
+        ops.memset_zero(view)
+        view.add_(1)
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(view.min()) == 1 and int(view.max()) == 1
+        assert bool((buf[:offset] == 7).all()) and bool((buf[offset + nbytes:] == 7).all())
+
+
 def test_gather_scatter_rows(ops):
     x = rnd(50, 64, seed=55, dtype=BF16)
     idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32, device=dev())
