@@ -574,6 +574,9 @@ class Transformer(nn.Module):
         forward that finds a master weight changed).  graphed.GraphedTrainStep calls this ahead of forking its two half-batch streams."""
         flat = [t.detach() for t in self.flat_params()]
         cfg = self.cfg
+        if core.PACK_ALL:                                          # the forward's own form: every stale layer in one launch
+            core.pack_stack_weights(self._cache, flat, cfg)
+            return
         ppl = core.params_per_layer(cfg.streams, cfg.cross_attend)
         for l in range(cfg.depth):
             core.layer_weights(self._cache, l, core._split_layer(flat[l * ppl:(l + 1) * ppl], cfg.streams, cfg.cross_attend), cfg.inner, cfg.inner_pad)
@@ -1484,6 +1487,7 @@ class SemanticTransformerWrapper(_WrapperBase):               # audiolm_pytorch.
             if self.unique_consecutive:
                 # :1536-1539 -- eos appended, runs collapsed, rows right-padded to the longest: one launch + one host read (the width is data-dependent)
                 full, lengths = ops.unique_consecutive(sem, self.transformer.eos_id, self.pad_id)
+                self.transformer.transformer.prepack_weights()                                        # (width-independent work before the host read)
                 full = full[:, :int(lengths.max())]                                                   # [ids | eos | pad ...]
                 labels, src_a = ops.semantic_prepare(full, self.transformer.eos_id, rows, has_eos=True)
                 sem = full[:, :-1]                                                                     # the input ids (shape only from here on)
@@ -1653,7 +1657,8 @@ class CoarseTransformerWrapper(_WrapperBase):                 # audiolm_pytorch.
         use_sem = self.semantic_cross_entropy_loss_weight > 0 and exists(tr.to_semantic_logits)
         if self.unique_consecutive and sem.numel() > 0:
             full, lengths = ops.unique_consecutive(sem, tr.semantic_eos_id, self.pad_id)                  # :1788-1795
-            lens = lengths.tolist()
+            tr.transformer.prepack_weights()             # width-independent work of the step goes out BEFORE the host read: the GPU idles for whatever the host
+            lens = lengths.tolist()                      # still has to do between the read and the first big launch
             sem = full[:, :max(lens)]                                                                     # [ids | eos | pad ...]
             sem_labels, coarse_labels, src_a, keep = ops.coarse_prepare(sem, coarse, self.pad_id, tr.semantic_eos_id, tr.coarse_eos_id, tr.num_coarse_quantizers,
                                                                         tr.codebook_size, sem_has_eos=True)
